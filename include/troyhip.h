@@ -1,0 +1,127 @@
+/* troyhip.h -- C ABI of libtroyhip.so, the MI355X (gfx950) evaluator that drops in under the
+ * troyn:: API of lightbulb128/troy (src/troy_cuda.cuh).
+ *
+ * The reference has no FFI seam: troyn:: is a set of aliases over CUDA classes compiled into
+ * libtroy.so (src/troy_cuda.cuh:20-43).  This header is the seam a maintainer binds instead: each
+ * entry point names the reference member function(s) it replaces.  INTEGRATION.md shows the C++ side.
+ *
+ * Conventions
+ *  - every function returns a status (0 = ok); troyhip_last_error() returns the message of the last
+ *    failure on the calling thread.  Status values mirror the reference's exception classes
+ *    (SURVEY.md 8b): 1 std::invalid_argument, 2 std::logic_error, 3 std::out_of_range,
+ *    4 std::runtime_error ("CUDA error." in the reference), 5 "KernelProvider not initialized."
+ *  - all ciphertext data are device pointers to uint64 in the reference's layout
+ *    [size][coeff_modulus_size][poly_modulus_degree] (src/ciphertext_cuda.cuh:62-67); a batch of B
+ *    independent ciphertexts of identical shape is addressed with an explicit batch stride.
+ *  - `stream` is a hipStream_t (NULL = default stream).  No call synchronises unless it says so.
+ *  - the caller owns every buffer; the library owns the context tables and one grow-only scratch
+ *    arena per context (ops on one context must be issued in stream order).
+ */
+#ifndef TROYHIP_H
+#define TROYHIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { TROYHIP_OK = 0, TROYHIP_INVALID_ARGUMENT = 1, TROYHIP_LOGIC_ERROR = 2, TROYHIP_OUT_OF_RANGE = 3,
+       TROYHIP_RUNTIME_ERROR = 4, TROYHIP_NOT_INITIALIZED = 5 };
+enum { TROYHIP_BFV = 1, TROYHIP_CKKS = 2, TROYHIP_BGV = 3 }; /* SchemeType, src/encryptionparams.h */
+
+typedef struct troyhip_context troyhip_context;
+
+/* CiphertextCuda metadata + data pointer (src/ciphertext_cuda.cuh:251-267) */
+typedef struct {
+    uint64_t *data;            /* device */
+    uint64_t batch_stride;     /* uint64 words between consecutive ciphertexts of the batch */
+    int32_t size;              /* number of polynomials */
+    int32_t limbs;             /* coeffModulusSize(): identifies the level (parms_id) */
+    int32_t is_ntt_form;
+    double scale;              /* CKKS */
+    uint64_t correction_factor;/* BGV */
+} troyhip_ct;
+
+typedef struct {
+    int32_t scheme;
+    uint64_t poly_modulus_degree;
+    int32_t key_limbs;         /* K: coeff_modulus size at the key level */
+    int32_t first_limbs;       /* limbs of a fresh ciphertext (firstParmsID) */
+    int32_t last_limbs;        /* limbs at lastParmsID */
+    uint64_t plain_modulus;
+} troyhip_context_info_t;
+
+/* ---- KernelProvider (src/kernelprovider.cuh:24-85) ---- */
+int troyhip_initialize(int device);                 /* KernelProvider::initialize (cudaSetDevice(0) there) */
+int troyhip_is_initialized(void);
+const char *troyhip_last_error(void);
+const char *troyhip_build_info(void);               /* "gfx950" for the product build */
+int troyhip_malloc(void **out, size_t bytes);       /* KernelProvider::malloc */
+int troyhip_free(void *p);                          /* KernelProvider::free */
+int troyhip_copy_h2d(void *dst, const void *src, size_t bytes, void *stream);   /* KernelProvider::copy */
+int troyhip_copy_d2h(void *dst, const void *src, size_t bytes, void *stream);   /* KernelProvider::retrieve */
+int troyhip_copy_d2d(void *dst, const void *src, size_t bytes, void *stream);   /* KernelProvider::copyOnDevice */
+int troyhip_memset_zero(void *dst, size_t bytes, void *stream);                 /* KernelProvider::memsetZero */
+int troyhip_stream_synchronize(void *stream);
+int troyhip_mem_info(size_t *free_bytes, size_t *total_bytes);
+/* HIP-event timers on the caller's stream (bench.py roofline measurement) */
+int troyhip_timer_create(void **timer);
+int troyhip_timer_destroy(void *timer);
+int troyhip_timer_start(void *timer, void *stream);
+int troyhip_timer_stop(void *timer, void *stream);
+int troyhip_timer_elapsed_ms(void *timer, float *ms); /* synchronises on the stop event */
+
+/* ---- parameters (src/modulus.h:485,528; src/modulus.cpp:80-121) ---- */
+int troyhip_coeff_modulus_create(uint64_t poly_modulus_degree, const int *bit_sizes, int count, uint64_t *out);
+int troyhip_plain_modulus_batching(uint64_t poly_modulus_degree, int bit_size, uint64_t *out);
+
+/* ---- SEALContextCuda (src/context_cuda.cuh:146-186, src/context_cuda.cu:5-62) ----
+ * Builds every table the reference computes on the CPU and uploads (NTT roots, BEHZ constants,
+ * mod-switch factors) for the whole modulus-switching chain; SecurityLevel::none semantics. */
+int troyhip_context_create(int scheme, uint64_t poly_modulus_degree, const uint64_t *coeff_modulus, int coeff_modulus_size,
+                           uint64_t plain_modulus, troyhip_context **out);
+int troyhip_context_destroy(troyhip_context *ctx);
+int troyhip_context_info(const troyhip_context *ctx, troyhip_context_info_t *out);
+/* BEHZ auxiliary base of a level (RNSToolCuda, src/utils/rns_cuda.cu:206-269): bsk_out gets |Bsk| primes (B then m_sk) */
+int troyhip_context_behz_bases(const troyhip_context *ctx, int limbs, uint64_t *bsk_out, int *bsk_size, uint64_t *gamma);
+/* host copy of the NTT tables of one prime of the context (NTTTablesCuda, src/utils/ntt_cuda.cuh:81-100); each array N entries */
+int troyhip_context_ntt_tables(const troyhip_context *ctx, uint64_t prime, uint64_t *root_operand, uint64_t *root_quotient,
+                               uint64_t *inv_root_operand, uint64_t *inv_root_quotient, uint64_t *inv_degree2, uint64_t *root);
+int troyhip_context_reserve_scratch(troyhip_context *ctx, size_t words);
+int troyhip_context_scratch_words(const troyhip_context *ctx, int op, int limbs, uint64_t batch, size_t *words); /* op: 0 multiply(2x2), 1 switch_key */
+int troyhip_galois_elt_from_step(const troyhip_context *ctx, int step, uint32_t *out);   /* GaloisToolCuda::getEltFromStep (galois_cuda.cu:44-86) */
+
+/* ---- kernel_util (src/kernelutils.cuh:562-672) ----
+ * rows limb-polynomials of N coefficients at `data`; row r is reduced modulo row_primes[(r / inner) % period].
+ * kNttNegacyclicHarvey / kInverseNttNegacyclicHarvey: outputs canonical in [0,p). */
+int troyhip_ntt(troyhip_context *ctx, uint64_t *data, uint64_t rows, const uint64_t *row_primes, int period, int inner, int inverse, void *stream);
+/* synthetic uniform residues (bench / tests): value(row, n) = splitmix64(seed ^ (row0+row)*C, n) mod p_row */
+int troyhip_fill_uniform(troyhip_context *ctx, uint64_t *data, uint64_t rows, const uint64_t *row_primes, int period, int inner,
+                         uint64_t seed, uint64_t row0, void *stream);
+
+/* ---- EvaluatorCuda (src/evaluator_cuda.cuh:23-349) ---- all ops take a batch of `batch` ciphertexts */
+int troyhip_negate(troyhip_context *ctx, troyhip_ct *a, uint64_t batch, void *stream);                       /* negateInplace */
+int troyhip_add(troyhip_context *ctx, troyhip_ct *a, const troyhip_ct *b, uint64_t batch, void *stream);     /* addInplace */
+int troyhip_sub(troyhip_context *ctx, troyhip_ct *a, const troyhip_ct *b, uint64_t batch, void *stream);     /* subInplace */
+/* multiply / multiplyInplace / square: out->data, out->batch_stride are inputs (may alias a or b), the rest of *out is set */
+int troyhip_multiply(troyhip_context *ctx, const troyhip_ct *a, const troyhip_ct *b, troyhip_ct *out, uint64_t batch, void *stream);
+/* key-switching keys: device array [K-1][2][K][N] (NTT form): KSwitchKeysCuda::data()[index] (src/kswitchkeys_cuda.cuh:43-56) */
+int troyhip_relinearize(troyhip_context *ctx, troyhip_ct *ct, const uint64_t *relin_key, uint64_t batch, void *stream);      /* relinearizeInplace */
+int troyhip_switch_key(troyhip_context *ctx, troyhip_ct *ct, const uint64_t *target, uint64_t target_batch_stride,
+                       const uint64_t *kswitch_key, uint64_t batch, void *stream);                            /* applyKeySwitchingInplace / switchKeyInplace */
+int troyhip_mod_switch_to_next(troyhip_context *ctx, const troyhip_ct *in, troyhip_ct *out, uint64_t batch, void *stream);   /* modSwitchToNext */
+int troyhip_rescale_to_next(troyhip_context *ctx, const troyhip_ct *in, troyhip_ct *out, uint64_t batch, void *stream);      /* rescaleToNext */
+int troyhip_apply_galois(troyhip_context *ctx, troyhip_ct *ct, uint32_t galois_elt, const uint64_t *galois_key, uint64_t batch, void *stream); /* applyGaloisInplace */
+/* rotateRows / rotateVector (steps != 0), rotateColumns / complexConjugate (steps == 0 and conjugate != 0).
+ * key_elts/keys: the Galois keys the caller holds; a missing key is decomposed by NAF as the reference does
+ * (evaluator_cuda.cu:2119-2176). */
+int troyhip_rotate(troyhip_context *ctx, troyhip_ct *ct, int steps, int conjugate, const uint32_t *key_elts, const uint64_t *const *keys,
+                   int n_keys, uint64_t batch, void *stream);
+int troyhip_transform_to_ntt(troyhip_context *ctx, troyhip_ct *ct, uint64_t batch, void *stream);            /* transformToNttInplace(Ciphertext) */
+int troyhip_transform_from_ntt(troyhip_context *ctx, troyhip_ct *ct, uint64_t batch, void *stream);          /* transformFromNttInplace */
+int troyhip_multiply_plain_ntt(troyhip_context *ctx, troyhip_ct *ct, const uint64_t *plain, double plain_scale, uint64_t batch, void *stream); /* multiplyPlainInplace, NTT-form operands */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

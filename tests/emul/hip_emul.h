@@ -1,0 +1,190 @@
+// hip_emul.h -- TEST-ONLY single-threaded SIMT emulator used to compile troy_amd/csrc/*.hip for the
+// host (g++ -DTROYHIP_CPU_EMUL).  Purpose: debug kernels and run sanitizers in a container without a
+// GPU ("run sanitizers on the CPU build only").  It is NOT a product path: troy_amd never loads the
+// emulated library, and GPU parity is established by the `-m gpu` tests on real hardware.
+//
+// Model: one block at a time; every HIP thread of the block is a ucontext fiber.  __syncthreads()
+// parks a fiber until all live fibers of the block are parked at a barrier; wave-level exchanges
+// (__shfl*) park until all live lanes of the 64-wide wave arrived.  Wave size is 64 as on gfx950.
+#pragma once
+#include <chrono>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <ucontext.h>
+#include <vector>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __shared__ static
+#define __launch_bounds__(...)
+#define HIP_KERNEL_NAME(...) __VA_ARGS__
+#define __HIP_DEVICE_COMPILE__ 0
+
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct alignas(16) ulonglong2 { unsigned long long x, y; };
+typedef int hipError_t;
+typedef void *hipStream_t;
+struct hipEmulEvent { std::chrono::steady_clock::time_point t; };
+typedef hipEmulEvent *hipEvent_t;
+enum { hipSuccess = 0, hipErrorInvalidValue = 1 };
+enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
+
+namespace hip_emul {
+
+struct Fiber {
+    ucontext_t ctx;
+    char *stack = nullptr;
+    int state = 0; // 0 runnable, 1 at block barrier, 2 at wave exchange, 3 done
+};
+struct State {
+    dim3 threadIdx, blockIdx, blockDim, gridDim;
+    ucontext_t sched;
+    std::vector<Fiber> fibers;
+    int cur = -1;
+    const std::function<void()> *body = nullptr;
+    uint64_t wave_buf[64 * 64]; // [wave][lane]
+};
+inline State &S() {
+    static State s;
+    return s;
+}
+static const size_t kStack = 256 * 1024;
+
+inline void fiber_entry() {
+    State &s = S();
+    (*s.body)();
+    s.fibers[s.cur].state = 3;
+    swapcontext(&s.fibers[s.cur].ctx, &s.sched);
+}
+inline void set_tid(int t) {
+    State &s = S();
+    s.threadIdx.x = t % s.blockDim.x;
+    s.threadIdx.y = (t / s.blockDim.x) % s.blockDim.y;
+    s.threadIdx.z = t / (s.blockDim.x * s.blockDim.y);
+}
+inline void park(int st) {
+    State &s = S();
+    int me = s.cur;
+    s.fibers[me].state = st;
+    swapcontext(&s.fibers[me].ctx, &s.sched);
+    set_tid(me);
+}
+inline void run_block(int nthreads) {
+    State &s = S();
+    if ((int)s.fibers.size() < nthreads) {
+        size_t old = s.fibers.size();
+        s.fibers.resize(nthreads);
+        for (size_t i = old; i < s.fibers.size(); i++) s.fibers[i].stack = (char *)malloc(kStack);
+    }
+    for (int t = 0; t < nthreads; t++) {
+        Fiber &f = s.fibers[t];
+        getcontext(&f.ctx);
+        f.ctx.uc_stack.ss_sp = f.stack;
+        f.ctx.uc_stack.ss_size = kStack;
+        f.ctx.uc_link = nullptr;
+        makecontext(&f.ctx, (void (*)())fiber_entry, 0);
+        f.state = 0;
+    }
+    int done = 0;
+    while (done < nthreads) {
+        bool progressed = false;
+        for (int t = 0; t < nthreads; t++) {
+            Fiber &f = s.fibers[t];
+            if (f.state != 0) continue;
+            s.cur = t;
+            set_tid(t);
+            swapcontext(&s.sched, &f.ctx);
+            progressed = true;
+            if (f.state == 3) done++;
+        }
+        // release block barrier when every live fiber is parked at it
+        int at_bar = 0, live = 0;
+        for (int t = 0; t < nthreads; t++) { if (s.fibers[t].state != 3) live++; if (s.fibers[t].state == 1) at_bar++; }
+        if (live && at_bar == live) { for (int t = 0; t < nthreads; t++) if (s.fibers[t].state == 1) s.fibers[t].state = 0; progressed = true; }
+        // release wave exchanges wave by wave
+        for (int w = 0; w * 64 < nthreads; w++) {
+            int wl = 0, wa = 0;
+            for (int t = w * 64; t < nthreads && t < (w + 1) * 64; t++) { if (s.fibers[t].state != 3) wl++; if (s.fibers[t].state == 2) wa++; }
+            if (wl && wa == wl) { for (int t = w * 64; t < nthreads && t < (w + 1) * 64; t++) if (s.fibers[t].state == 2) s.fibers[t].state = 0; progressed = true; }
+        }
+        if (!progressed) { fprintf(stderr, "hip_emul: deadlock (divergent barrier)\n"); abort(); }
+    }
+}
+inline void launch(dim3 grid, dim3 block, const std::function<void()> &body) {
+    State &s = S();
+    s.gridDim = grid;
+    s.blockDim = block;
+    s.body = &body;
+    int nthreads = block.x * block.y * block.z;
+    for (unsigned bz = 0; bz < grid.z; bz++)
+        for (unsigned by = 0; by < grid.y; by++)
+            for (unsigned bx = 0; bx < grid.x; bx++) {
+                s.blockIdx = dim3(bx, by, bz);
+                run_block(nthreads);
+            }
+}
+inline int lane_id() { State &s = S(); return s.cur & 63; }
+inline int wave_id() { State &s = S(); return s.cur >> 6; }
+template <class T> inline T wave_exchange(T v, int src_lane) {
+    static_assert(sizeof(T) <= 8, "wave_exchange");
+    State &s = S();
+    uint64_t bits = 0;
+    memcpy(&bits, &v, sizeof(T));
+    s.wave_buf[wave_id() * 64 + lane_id()] = bits;
+    park(2);
+    uint64_t r = s.wave_buf[wave_id() * 64 + (src_lane & 63)];
+    park(2); // everyone has read before anyone overwrites
+    T out;
+    memcpy(&out, &r, sizeof(T));
+    return out;
+}
+} // namespace hip_emul
+
+#define threadIdx (hip_emul::S().threadIdx)
+#define blockIdx (hip_emul::S().blockIdx)
+#define blockDim (hip_emul::S().blockDim)
+#define gridDim (hip_emul::S().gridDim)
+
+inline void __syncthreads() { hip_emul::park(1); }
+template <class T> inline T __shfl(T v, int src, int width = 64) { int l = hip_emul::lane_id(); return hip_emul::wave_exchange(v, (l & ~(width - 1)) | (src & (width - 1))); }
+template <class T> inline T __shfl_xor(T v, int mask, int width = 64) { int l = hip_emul::lane_id(); return hip_emul::wave_exchange(v, l ^ mask); }
+template <class T> inline T __shfl_down(T v, unsigned d, int width = 64) { int l = hip_emul::lane_id(); int s = l + d; if ((s & ~(width - 1)) != (l & ~(width - 1))) s = l; return hip_emul::wave_exchange(v, s); }
+template <class T> inline T __shfl_up(T v, unsigned d, int width = 64) { int l = hip_emul::lane_id(); int s = l - (int)d; if (s < (l & ~(width - 1))) s = l; return hip_emul::wave_exchange(v, s); }
+
+inline uint64_t __umul64hi(uint64_t a, uint64_t b) { return (uint64_t)(((unsigned __int128)a * b) >> 64); }
+inline uint32_t __umulhi(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
+inline uint32_t __brev(uint32_t x) { uint32_t r = 0; for (int i = 0; i < 32; i++) r |= ((x >> i) & 1u) << (31 - i); return r; }
+template <class T> inline T atomicAdd(T *p, T v) { T o = *p; *p += v; return o; }
+
+#define TROY_LAUNCH(kernel, grid, block, shmem, stream, ...) \
+    do { auto _k = [=]() { kernel(__VA_ARGS__); }; hip_emul::launch(dim3(grid), dim3(block), _k); } while (0)
+
+// ---- host runtime API subset ----
+inline const char *hipGetErrorString(hipError_t) { return "emulated"; }
+inline hipError_t hipGetLastError() { return hipSuccess; }
+inline hipError_t hipSetDevice(int) { return hipSuccess; }
+inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
+inline hipError_t hipMalloc(void **p, size_t n) { *p = aligned_alloc(256, (n + 255) / 256 * 256); return *p ? hipSuccess : hipErrorInvalidValue; }
+inline hipError_t hipFree(void *p) { free(p); return hipSuccess; }
+inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
+inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t) { memmove(d, s, n); return hipSuccess; }
+inline hipError_t hipMemset(void *d, int v, size_t n) { memset(d, v, n); return hipSuccess; }
+inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }
+inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+inline hipError_t hipStreamCreate(hipStream_t *s) { *s = nullptr; return hipSuccess; }
+inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+inline hipError_t hipEventCreate(hipEvent_t *e) { *e = new hipEmulEvent(); return hipSuccess; }
+inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
+inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { e->t = std::chrono::steady_clock::now(); return hipSuccess; }
+inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b) { *ms = std::chrono::duration<float, std::milli>(b->t - a->t).count(); return hipSuccess; }
+inline hipError_t hipMemGetInfo(size_t *f, size_t *t) { *f = *t = size_t(8) << 30; return hipSuccess; }

@@ -1,0 +1,7 @@
+"""troy_amd -- MI355X-native (gfx950) homomorphic-encryption evaluator behind the troyn:: API of
+lightbulb128/troy.  Product = troy_amd/libtroyhip.so (hand-written HIP kernels + host precompute, C ABI in
+include/troyhip.h); this package is the thin host-side mirror used by tests and bench.py.
+"""
+from . import capi  # noqa: F401
+from .api import (BFV, BGV, CKKS, Ciphertext, CoeffModulus, DeviceBuffer, Evaluator, GaloisKeys, KernelProvider,  # noqa: F401
+                  KSwitchKeys, PlainModulus, RelinKeys, SEALContext, synchronize)

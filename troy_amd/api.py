@@ -1,0 +1,421 @@
+"""Host-side mirror of the reference's troyn:: interface over the C ABI (include/troyhip.h).
+
+Names and argument meaning follow src/troy_cuda.cuh / src/evaluator_cuda.cuh (KernelProvider,
+SEALContext, Ciphertext, RelinKeys/GaloisKeys, Evaluator::multiply / relinearizeInplace /
+rotateRowsInplace / rescaleToNextInplace ...), with one extension: a `Ciphertext` here is a *batch* of B
+independent ciphertexts of identical shape (B = 1 is the reference's object).  The C++ form of the same
+mirror is include/troy_cuda.cuh.  Everything runs through libtroyhip.so; there is no CPU path.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import capi
+from .capi import BFV, BGV, CKKS, CtStruct  # noqa: F401
+
+
+def _u64p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class KernelProvider:
+    """src/kernelprovider.cuh:24-85"""
+    _lib = None
+
+    @classmethod
+    def initialize(cls, device=0, _lib=None):
+        cls._lib = _lib or capi.load()
+        capi.check(cls._lib, cls._lib.troyhip_initialize(int(device)))
+
+    @classmethod
+    def lib(cls):
+        if cls._lib is None:
+            cls._lib = capi.load()  # calls below then fail with "KernelProvider not initialized."
+        return cls._lib
+
+
+class DeviceBuffer:
+    """DeviceArray<uint64_t> (src/utils/devicearray.cuh): owning device allocation, deep copy on copy()."""
+
+    def __init__(self, words):
+        self.lib = KernelProvider.lib()
+        self.words = int(words)
+        p = C.c_void_p()
+        capi.check(self.lib, self.lib.troyhip_malloc(C.byref(p), C.c_size_t(self.words * 8)))
+        self.ptr = p.value
+
+    @classmethod
+    def from_numpy(cls, arr):
+        arr = np.ascontiguousarray(arr, dtype=np.uint64)
+        b = cls(arr.size)
+        capi.check(b.lib, b.lib.troyhip_copy_h2d(C.c_void_p(b.ptr), _u64p(arr), C.c_size_t(arr.size * 8), None))
+        return b
+
+    def to_numpy(self, words=None, offset=0):
+        n = self.words - offset if words is None else int(words)
+        out = np.empty(n, dtype=np.uint64)
+        capi.check(self.lib, self.lib.troyhip_copy_d2h(_u64p(out), C.c_void_p(self.ptr + 8 * offset), C.c_size_t(n * 8), None))
+        return out
+
+    def copy(self):
+        b = DeviceBuffer(self.words)
+        capi.check(self.lib, self.lib.troyhip_copy_d2d(C.c_void_p(b.ptr), C.c_void_p(self.ptr), C.c_size_t(self.words * 8), None))
+        return b
+
+    def zero(self):
+        capi.check(self.lib, self.lib.troyhip_memset_zero(C.c_void_p(self.ptr), C.c_size_t(self.words * 8), None))
+
+    def __del__(self):
+        if getattr(self, "ptr", None):
+            try:
+                self.lib.troyhip_free(C.c_void_p(self.ptr))
+            except Exception:
+                pass
+            self.ptr = None
+
+
+def synchronize(stream=None):
+    lib = KernelProvider.lib()
+    capi.check(lib, lib.troyhip_stream_synchronize(stream))
+
+
+class CoeffModulus:
+    @staticmethod
+    def Create(poly_modulus_degree, bit_sizes):  # src/modulus.h:485
+        lib = KernelProvider.lib()
+        out = np.zeros(len(bit_sizes), dtype=np.uint64)
+        bits = (C.c_int * len(bit_sizes))(*bit_sizes)
+        capi.check(lib, lib.troyhip_coeff_modulus_create(C.c_uint64(poly_modulus_degree), bits, len(bit_sizes), _u64p(out)))
+        return [int(x) for x in out]
+
+
+class PlainModulus:
+    @staticmethod
+    def Batching(poly_modulus_degree, bit_size):  # src/modulus.h:528
+        lib = KernelProvider.lib()
+        out = C.c_uint64()
+        capi.check(lib, lib.troyhip_plain_modulus_batching(C.c_uint64(poly_modulus_degree), bit_size, C.byref(out)))
+        return out.value
+
+
+class SEALContext:
+    """SEALContextCuda (src/context_cuda.cuh:146-186); SecurityLevel::none semantics."""
+
+    def __init__(self, scheme, poly_modulus_degree, coeff_modulus, plain_modulus=0):
+        self.lib = KernelProvider.lib()
+        self.scheme, self.N = scheme, int(poly_modulus_degree)
+        self.coeff_modulus = [int(p) for p in coeff_modulus]
+        self.plain_modulus = int(plain_modulus)
+        arr = np.array(self.coeff_modulus, dtype=np.uint64)
+        h = C.c_void_p()
+        capi.check(self.lib, self.lib.troyhip_context_create(scheme, C.c_uint64(self.N), _u64p(arr), len(arr), C.c_uint64(self.plain_modulus), C.byref(h)))
+        self.h = h
+        info = capi.ContextInfo()
+        capi.check(self.lib, self.lib.troyhip_context_info(self.h, C.byref(info)))
+        self.key_limbs, self.first_limbs, self.last_limbs = info.key_limbs, info.first_limbs, info.last_limbs
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            try:
+                self.lib.troyhip_context_destroy(self.h)
+            except Exception:
+                pass
+            self.h = None
+
+    def behz_bases(self, limbs):
+        out = np.zeros(limbs + 3, dtype=np.uint64)
+        n, g = C.c_int(), C.c_uint64()
+        capi.check(self.lib, self.lib.troyhip_context_behz_bases(self.h, limbs, _u64p(out), C.byref(n), C.byref(g)))
+        return [int(x) for x in out[:n.value]], g.value
+
+    def ntt_tables(self, prime):
+        N = self.N
+        rop, rquo, iop, iquo = (np.zeros(N, dtype=np.uint64) for _ in range(4))
+        invd = np.zeros(2, dtype=np.uint64)
+        root = C.c_uint64()
+        capi.check(self.lib, self.lib.troyhip_context_ntt_tables(self.h, C.c_uint64(prime), _u64p(rop), _u64p(rquo), _u64p(iop), _u64p(iquo), _u64p(invd), C.byref(root)))
+        return dict(root=root.value, root_op=rop, root_quo=rquo, inv_op=iop, inv_quo=iquo, inv_degree=invd)
+
+    def galois_elt_from_step(self, step):
+        out = C.c_uint32()
+        capi.check(self.lib, self.lib.troyhip_galois_elt_from_step(self.h, step, C.byref(out)))
+        return out.value
+
+    def reserve_scratch(self, words):
+        capi.check(self.lib, self.lib.troyhip_context_reserve_scratch(self.h, C.c_size_t(int(words))))
+
+    def scratch_words(self, op, limbs, batch):
+        out = C.c_size_t()
+        capi.check(self.lib, self.lib.troyhip_context_scratch_words(self.h, op, limbs, C.c_uint64(batch), C.byref(out)))
+        return out.value
+
+    # kernel_util level entry points
+    def ntt(self, buf, rows, row_primes, inverse=False, inner=1, offset_words=0, stream=None):
+        pr = np.array([int(p) for p in row_primes], dtype=np.uint64)
+        capi.check(self.lib, self.lib.troyhip_ntt(self.h, C.c_void_p(buf.ptr + 8 * offset_words), C.c_uint64(rows), _u64p(pr), len(pr), inner, int(inverse), stream))
+
+    def fill_uniform(self, buf, rows, row_primes, seed, row0=0, inner=1, offset_words=0, stream=None):
+        pr = np.array([int(p) for p in row_primes], dtype=np.uint64)
+        capi.check(self.lib, self.lib.troyhip_fill_uniform(self.h, C.c_void_p(buf.ptr + 8 * offset_words), C.c_uint64(rows), _u64p(pr), len(pr), inner, C.c_uint64(seed), C.c_uint64(row0), stream))
+
+
+class Ciphertext:
+    """CiphertextCuda (src/ciphertext_cuda.cuh:12-268) x batch.  Device data [batch][capacity][limbs][N]."""
+
+    def __init__(self, context, batch, size, limbs, is_ntt_form=False, scale=1.0, correction_factor=1, capacity=None, buf=None):
+        self.context, self.batch, self._size, self.limbs = context, int(batch), int(size), int(limbs)
+        self.is_ntt_form, self.scale, self.correction_factor = bool(is_ntt_form), float(scale), int(correction_factor)
+        self.capacity = int(capacity or size)
+        self.buf = buf if buf is not None else DeviceBuffer(self.batch * self.capacity * self.limbs * context.N)
+
+    @classmethod
+    def from_numpy(cls, context, data, is_ntt_form=False, scale=1.0, correction_factor=1, capacity=None):
+        """data: uint64 [batch][size][limbs][N] (or [size][limbs][N] for a single ciphertext)."""
+        data = np.asarray(data, dtype=np.uint64)
+        if data.ndim == 3:
+            data = data[None]
+        B, size, limbs, N = data.shape
+        assert N == context.N
+        cap = int(capacity or size)
+        if cap != size:
+            full = np.zeros((B, cap, limbs, N), dtype=np.uint64)
+            full[:, :size] = data
+            data = full
+        return cls(context, B, size, limbs, is_ntt_form, scale, correction_factor, cap, DeviceBuffer.from_numpy(data))
+
+    def cpu(self):  # CiphertextCuda::cpu / toHost
+        n = self.batch * self.capacity * self.limbs * self.context.N
+        a = self.buf.to_numpy(n).reshape(self.batch, self.capacity, self.limbs, self.context.N)
+        return a[:, :self._size].copy()
+
+    def size(self):
+        return self._size
+
+    def coeffModulusSize(self):
+        return self.limbs
+
+    def polyModulusDegree(self):
+        return self.context.N
+
+    def isNttForm(self):
+        return self.is_ntt_form
+
+    @property
+    def bstride(self):
+        return self.capacity * self.limbs * self.context.N
+
+    def struct(self):
+        return CtStruct(self.buf.ptr, self.bstride, self._size, self.limbs, int(self.is_ntt_form), self.scale, self.correction_factor)
+
+    def _absorb(self, st):
+        self._size, self.limbs, self.is_ntt_form = st.size, st.limbs, bool(st.is_ntt_form)
+        self.scale, self.correction_factor = st.scale, st.correction_factor
+
+    def copy(self):  # deep device copy (src/utils/devicearray.cuh:153-164)
+        return Ciphertext(self.context, self.batch, self._size, self.limbs, self.is_ntt_form, self.scale, self.correction_factor, self.capacity, self.buf.copy())
+
+
+class KSwitchKeys:
+    """KSwitchKeysCuda (src/kswitchkeys_cuda.cuh:43-56): data()[index] = one key-switching key, uploaded from
+    the host array [K-1][2][K][N] (NTT form)."""
+
+    def __init__(self, context):
+        self.context, self.keys = context, {}
+
+    def set(self, index, host_array):
+        a = np.ascontiguousarray(host_array, dtype=np.uint64)
+        K, N = self.context.key_limbs, self.context.N
+        if a.shape != (K - 1, 2, K, N):
+            raise capi.InvalidArgument(capi.INVALID_ARGUMENT, "kswitch_keys is not valid for encryption parameters")
+        self.keys[index] = DeviceBuffer.from_numpy(a)
+
+    def hasKey(self, index):
+        return index in self.keys
+
+
+class RelinKeys(KSwitchKeys):  # src/relinkeys_cuda.cuh:56-59
+    @staticmethod
+    def getIndex(key_power):
+        if key_power < 2:
+            raise capi.InvalidArgument(capi.INVALID_ARGUMENT, "key_power cannot be less than 2")
+        return key_power - 2
+
+
+class GaloisKeys(KSwitchKeys):  # src/galoiskeys_cuda.cuh:74-77
+    @staticmethod
+    def getIndex(galois_elt):  # src/utils/galois_cuda.cuh:45-48
+        if not galois_elt & 1:
+            raise capi.InvalidArgument(capi.INVALID_ARGUMENT, "galois_elt is not valid")
+        return (galois_elt - 1) >> 1
+
+    def set_elt(self, galois_elt, host_array):
+        self.set(self.getIndex(galois_elt), host_array)
+
+
+class Evaluator:
+    """EvaluatorCuda (src/evaluator_cuda.cuh:13-361) over batches."""
+
+    def __init__(self, context, stream=None):
+        self.context, self.lib, self.stream = context, context.lib, stream
+
+    def _chk(self, rc):
+        capi.check(self.lib, rc)
+
+    # -- negate / add / sub
+    def negateInplace(self, a):
+        st = a.struct()
+        self._chk(self.lib.troyhip_negate(self.context.h, C.byref(st), C.c_uint64(a.batch), self.stream))
+        a._absorb(st)
+
+    def addInplace(self, a, b):
+        if b.size() > a.capacity:
+            raise capi.InvalidArgument(capi.INVALID_ARGUMENT, "destination capacity too small")
+        sa, sb = a.struct(), b.struct()
+        self._chk(self.lib.troyhip_add(self.context.h, C.byref(sa), C.byref(sb), C.c_uint64(a.batch), self.stream))
+        a._absorb(sa)
+
+    def subInplace(self, a, b):
+        if b.size() > a.capacity:
+            raise capi.InvalidArgument(capi.INVALID_ARGUMENT, "destination capacity too small")
+        sa, sb = a.struct(), b.struct()
+        self._chk(self.lib.troyhip_sub(self.context.h, C.byref(sa), C.byref(sb), C.c_uint64(a.batch), self.stream))
+        a._absorb(sa)
+
+    def add(self, a, b):
+        r = self._grown_copy(a, max(a.size(), b.size()))
+        self.addInplace(r, b)
+        return r
+
+    def sub(self, a, b):
+        r = self._grown_copy(a, max(a.size(), b.size()))
+        self.subInplace(r, b)
+        return r
+
+    def negate(self, a):
+        r = a.copy()
+        self.negateInplace(r)
+        return r
+
+    def _grown_copy(self, a, cap):
+        if cap <= a.capacity:
+            return a.copy()
+        return Ciphertext.from_numpy(a.context, a.cpu(), a.is_ntt_form, a.scale, a.correction_factor, capacity=cap)
+
+    # -- multiply / square
+    def multiply(self, a, b, destination=None):
+        ds = a.size() + b.size() - 1
+        out = destination or Ciphertext(a.context, a.batch, ds, a.limbs, capacity=ds)
+        if out.capacity < ds:
+            raise capi.InvalidArgument(capi.INVALID_ARGUMENT, "destination capacity too small")
+        sa, sb, so = a.struct(), b.struct(), out.struct()
+        self._chk(self.lib.troyhip_multiply(self.context.h, C.byref(sa), C.byref(sb), C.byref(so), C.c_uint64(a.batch), self.stream))
+        out._absorb(so)
+        return out
+
+    def multiplyInplace(self, a, b):
+        ds = a.size() + b.size() - 1
+        if a.capacity >= ds:
+            return self.multiply(a, b, a)
+        out = self.multiply(a, b)
+        a.__dict__.update(out.__dict__)
+        return a
+
+    def square(self, a):
+        return self.multiply(a, a)
+
+    def squareInplace(self, a):
+        return self.multiplyInplace(a, a)
+
+    # -- key switching
+    def relinearizeInplace(self, a, relin_keys):
+        idx = RelinKeys.getIndex(2)
+        if a.size() > 2 and not relin_keys.hasKey(idx):
+            raise capi.InvalidArgument(capi.INVALID_ARGUMENT, "not enough relinearization keys")
+        st = a.struct()
+        key = relin_keys.keys[idx].ptr if relin_keys.hasKey(idx) else None
+        self._chk(self.lib.troyhip_relinearize(self.context.h, C.byref(st), C.c_void_p(key), C.c_uint64(a.batch), self.stream))
+        a._absorb(st)
+
+    def relinearize(self, a, relin_keys):
+        r = a.copy()
+        self.relinearizeInplace(r, relin_keys)
+        return r
+
+    def applyKeySwitchingInplace(self, a, kswitch_keys, index=0):
+        """switchKeyInplace(a, a[1], keys[index]) after zeroing nothing: the reference's applyKeySwitchingInplace
+        (evaluator_cuda.cu:1365-1378) switches poly 1 of a size-2 ciphertext to a new key."""
+        raise NotImplementedError
+
+    def applyGaloisInplace(self, a, galois_elt, galois_keys):
+        idx = GaloisKeys.getIndex(galois_elt)
+        if not galois_keys.hasKey(idx):
+            raise capi.InvalidArgument(capi.INVALID_ARGUMENT, "Galois key not present")
+        st = a.struct()
+        self._chk(self.lib.troyhip_apply_galois(self.context.h, C.byref(st), C.c_uint32(galois_elt), C.c_void_p(galois_keys.keys[idx].ptr), C.c_uint64(a.batch), self.stream))
+        a._absorb(st)
+
+    def _rotate(self, a, steps, conjugate, galois_keys):
+        elts = [2 * i + 1 for i in galois_keys.keys]
+        n = len(elts)
+        e = (C.c_uint32 * max(n, 1))(*elts)
+        k = (C.c_void_p * max(n, 1))(*[galois_keys.keys[(x - 1) >> 1].ptr for x in elts])
+        st = a.struct()
+        self._chk(self.lib.troyhip_rotate(self.context.h, C.byref(st), int(steps), int(conjugate), e, k, n, C.c_uint64(a.batch), self.stream))
+        a._absorb(st)
+
+    def rotateRowsInplace(self, a, steps, galois_keys):
+        if self.context.scheme not in (BFV, BGV):
+            raise capi.LogicError(capi.LOGIC_ERROR, "unsupported scheme")
+        self._rotate(a, steps, 0, galois_keys)
+
+    def rotateColumnsInplace(self, a, galois_keys):
+        if self.context.scheme not in (BFV, BGV):
+            raise capi.LogicError(capi.LOGIC_ERROR, "unsupported scheme")
+        self._rotate(a, 0, 1, galois_keys)
+
+    def rotateVectorInplace(self, a, steps, galois_keys):
+        if self.context.scheme != CKKS:
+            raise capi.LogicError(capi.LOGIC_ERROR, "unsupported scheme")
+        self._rotate(a, steps, 0, galois_keys)
+
+    def complexConjugateInplace(self, a, galois_keys):
+        if self.context.scheme != CKKS:
+            raise capi.LogicError(capi.LOGIC_ERROR, "unsupported scheme")
+        self._rotate(a, 0, 1, galois_keys)
+
+    # -- modulus switching
+    def _next(self, a, fn):
+        out = Ciphertext(a.context, a.batch, a.size(), max(a.limbs - 1, 1), capacity=a.size())
+        si, so = a.struct(), out.struct()
+        self._chk(fn(self.context.h, C.byref(si), C.byref(so), C.c_uint64(a.batch), self.stream))
+        out._absorb(so)
+        return out
+
+    def modSwitchToNext(self, a):
+        return self._next(a, self.lib.troyhip_mod_switch_to_next)
+
+    def modSwitchToNextInplace(self, a):
+        a.__dict__.update(self.modSwitchToNext(a).__dict__)
+
+    def rescaleToNext(self, a):
+        return self._next(a, self.lib.troyhip_rescale_to_next)
+
+    def rescaleToNextInplace(self, a):
+        a.__dict__.update(self.rescaleToNext(a).__dict__)
+
+    # -- NTT form
+    def transformToNttInplace(self, a):
+        st = a.struct()
+        self._chk(self.lib.troyhip_transform_to_ntt(self.context.h, C.byref(st), C.c_uint64(a.batch), self.stream))
+        a._absorb(st)
+
+    def transformFromNttInplace(self, a):
+        st = a.struct()
+        self._chk(self.lib.troyhip_transform_from_ntt(self.context.h, C.byref(st), C.c_uint64(a.batch), self.stream))
+        a._absorb(st)
+
+    def multiplyPlainInplace(self, a, plain_ntt, plain_scale=1.0):
+        """NTT-form operands only (multiplyPlainNtt, evaluator_cuda.cu:1824-1863); plain_ntt: DeviceBuffer [limbs][N]."""
+        st = a.struct()
+        self._chk(self.lib.troyhip_multiply_plain_ntt(self.context.h, C.byref(st), C.c_void_p(plain_ntt.ptr), C.c_double(plain_scale), C.c_uint64(a.batch), self.stream))
+        a._absorb(st)

@@ -1,0 +1,242 @@
+// capi.cpp -- extern "C" boundary of libtroyhip.so (include/troyhip.h).  No exceptions cross it.
+#include "../../include/troyhip.h"
+#include "evaluator.h"
+#include "kernels.h"
+#include <atomic>
+#include <cstring>
+#include <string>
+
+using namespace troyhip;
+
+struct troyhip_context {
+    Context ctx;
+    Evaluator ev;
+    troyhip_context(int scheme, u64 N, const std::vector<u64> &q, u64 t) : ctx(scheme, N, q, t), ev(ctx) {}
+};
+
+namespace {
+thread_local std::string g_err;
+std::atomic<bool> g_init{false};
+
+template <class F> int guard(F f, bool need_init = true) {
+    try {
+        if (need_init && !g_init.load()) throw Error(ST_NOT_INITIALIZED, "KernelProvider not initialized.");
+        f();
+        return TROYHIP_OK;
+    } catch (const Error &e) {
+        g_err = e.what();
+        return e.code;
+    } catch (const std::bad_alloc &) {
+        g_err = "out of host memory";
+        return TROYHIP_RUNTIME_ERROR;
+    } catch (const std::exception &e) {
+        g_err = e.what();
+        return TROYHIP_RUNTIME_ERROR;
+    }
+}
+CtBatch view(const troyhip_ct *c) {
+    if (!c) throw Error(ST_INVALID_ARGUMENT, "null ciphertext descriptor");
+    CtBatch b;
+    b.data = c->data; b.bstride = c->batch_stride; b.size = c->size; b.limbs = c->limbs;
+    b.ntt = c->is_ntt_form != 0; b.scale = c->scale; b.cf = c->correction_factor;
+    return b;
+}
+void store(const CtBatch &b, troyhip_ct *c) {
+    c->size = b.size; c->limbs = b.limbs; c->is_ntt_form = b.ntt ? 1 : 0; c->scale = b.scale; c->correction_factor = b.cf;
+}
+LimbMap map_from_primes(const Context &c, const u64 *row_primes, int period, int inner) {
+    if (!row_primes || period < 1 || period > 64 || inner < 1) throw Error(ST_INVALID_ARGUMENT, "invalid limb description");
+    std::vector<uint8_t> ids;
+    for (int i = 0; i < period; i++) ids.push_back((uint8_t)c.prime_id(row_primes[i]));
+    return c.ids_map(ids, (uint32_t)inner);
+}
+struct Timer { hipEvent_t a, b; };
+} // namespace
+
+extern "C" {
+
+int troyhip_initialize(int device) {
+    return guard([&] {
+        HIP_CHECK(hipSetDevice(device));
+        g_init.store(true);
+    }, false);
+}
+int troyhip_is_initialized(void) { return g_init.load() ? 1 : 0; }
+const char *troyhip_last_error(void) { return g_err.c_str(); }
+const char *troyhip_build_info(void) {
+#ifdef TROYHIP_CPU_EMUL
+    return "cpu-emulation (test only)";
+#else
+    return "gfx950";
+#endif
+}
+int troyhip_malloc(void **out, size_t bytes) { return guard([&] { if (!out) throw Error(ST_INVALID_ARGUMENT, "null"); HIP_CHECK(hipMalloc(out, bytes ? bytes : 8)); }); }
+int troyhip_free(void *p) { return guard([&] { if (p) (void)hipFree(p); }); }
+int troyhip_copy_h2d(void *dst, const void *src, size_t bytes, void *stream) {
+    return guard([&] { HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream)); HIP_CHECK(hipStreamSynchronize((hipStream_t)stream)); });
+}
+int troyhip_copy_d2h(void *dst, const void *src, size_t bytes, void *stream) {
+    return guard([&] { HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream)); HIP_CHECK(hipStreamSynchronize((hipStream_t)stream)); });
+}
+int troyhip_copy_d2d(void *dst, const void *src, size_t bytes, void *stream) {
+    return guard([&] { HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream)); });
+}
+int troyhip_memset_zero(void *dst, size_t bytes, void *stream) { return guard([&] { HIP_CHECK(hipMemsetAsync(dst, 0, bytes, (hipStream_t)stream)); }); }
+int troyhip_stream_synchronize(void *stream) { return guard([&] { HIP_CHECK(hipStreamSynchronize((hipStream_t)stream)); }); }
+int troyhip_mem_info(size_t *free_bytes, size_t *total_bytes) { return guard([&] { HIP_CHECK(hipMemGetInfo(free_bytes, total_bytes)); }); }
+
+int troyhip_timer_create(void **timer) {
+    return guard([&] {
+        Timer *t = new Timer();
+        HIP_CHECK(hipEventCreate(&t->a));
+        HIP_CHECK(hipEventCreate(&t->b));
+        *timer = t;
+    });
+}
+int troyhip_timer_destroy(void *timer) { return guard([&] { Timer *t = (Timer *)timer; if (t) { (void)hipEventDestroy(t->a); (void)hipEventDestroy(t->b); delete t; } }); }
+int troyhip_timer_start(void *timer, void *stream) { return guard([&] { HIP_CHECK(hipEventRecord(((Timer *)timer)->a, (hipStream_t)stream)); }); }
+int troyhip_timer_stop(void *timer, void *stream) { return guard([&] { HIP_CHECK(hipEventRecord(((Timer *)timer)->b, (hipStream_t)stream)); }); }
+int troyhip_timer_elapsed_ms(void *timer, float *ms) {
+    return guard([&] { Timer *t = (Timer *)timer; HIP_CHECK(hipEventSynchronize(t->b)); HIP_CHECK(hipEventElapsedTime(ms, t->a, t->b)); });
+}
+
+int troyhip_coeff_modulus_create(uint64_t N, const int *bit_sizes, int count, uint64_t *out) {
+    return guard([&] {
+        if (!bit_sizes || !out || count < 1 || count > 64) throw Error(ST_INVALID_ARGUMENT, "bit_sizes is invalid");
+        auto v = host::coeff_modulus_create(N, std::vector<int>(bit_sizes, bit_sizes + count));
+        std::copy(v.begin(), v.end(), out);
+    }, false);
+}
+int troyhip_plain_modulus_batching(uint64_t N, int bit_size, uint64_t *out) {
+    return guard([&] { *out = host::coeff_modulus_create(N, {bit_size})[0]; }, false);
+}
+
+int troyhip_context_create(int scheme, uint64_t N, const uint64_t *coeff_modulus, int K, uint64_t plain_modulus, troyhip_context **out) {
+    return guard([&] {
+        if (!coeff_modulus || !out || K < 1) throw Error(ST_INVALID_ARGUMENT, "coeff_modulus is invalid");
+        *out = new troyhip_context(scheme, N, std::vector<u64>(coeff_modulus, coeff_modulus + K), plain_modulus);
+    });
+}
+int troyhip_context_destroy(troyhip_context *ctx) { return guard([&] { delete ctx; }); }
+int troyhip_context_info(const troyhip_context *ctx, troyhip_context_info_t *out) {
+    return guard([&] {
+        if (!ctx || !out) throw Error(ST_INVALID_ARGUMENT, "null");
+        const Context &c = ctx->ctx;
+        out->scheme = c.scheme; out->poly_modulus_degree = c.N; out->key_limbs = c.K;
+        out->first_limbs = c.first_limbs; out->last_limbs = c.last_limbs; out->plain_modulus = c.t;
+    });
+}
+int troyhip_context_behz_bases(const troyhip_context *ctx, int limbs, uint64_t *bsk_out, int *bsk_size, uint64_t *gamma) {
+    return guard([&] {
+        const host::RnsLevel &r = ctx->ctx.level(limbs).rns;
+        std::copy(r.Bsk.begin(), r.Bsk.end(), bsk_out);
+        *bsk_size = (int)r.Bsk.size();
+        *gamma = r.gamma;
+    });
+}
+int troyhip_context_ntt_tables(const troyhip_context *ctx, uint64_t prime, uint64_t *rop, uint64_t *rquo, uint64_t *iop, uint64_t *iquo,
+                               uint64_t *inv_degree2, uint64_t *root) {
+    return guard([&] {
+        const Context &c = ctx->ctx;
+        const host::NttTable &t = c.tables[c.prime_id(prime)];
+        for (u64 i = 0; i < c.N; i++) { rop[i] = t.root[i].op; rquo[i] = t.root[i].quo; iop[i] = t.iroot[i].op; iquo[i] = t.iroot[i].quo; }
+        inv_degree2[0] = t.inv_n.op; inv_degree2[1] = t.inv_n.quo;
+        *root = t.psi;
+    });
+}
+int troyhip_context_reserve_scratch(troyhip_context *ctx, size_t words) { return guard([&] { ctx->ctx.arena.reset(); ctx->ctx.arena.reserve(words); }); }
+int troyhip_context_scratch_words(const troyhip_context *ctx, int op, int limbs, uint64_t batch, size_t *words) {
+    return guard([&] {
+        if (op == 0) *words = ctx->ev.scratch_multiply(2, 2, limbs, batch);
+        else *words = ctx->ev.scratch_switch_key(limbs, batch) + 2 * batch * limbs * ctx->ctx.N + 128;
+    });
+}
+int troyhip_galois_elt_from_step(const troyhip_context *ctx, int step, uint32_t *out) {
+    return guard([&] { *out = host::galois_elt_from_step(ctx->ctx.N, step); });
+}
+
+int troyhip_ntt(troyhip_context *ctx, uint64_t *data, uint64_t rows, const uint64_t *row_primes, int period, int inner, int inverse, void *stream) {
+    return guard([&] {
+        Context &c = ctx->ctx;
+        launch_ntt(data, c.d_desc, map_from_primes(c, row_primes, period, inner), rows, c.logn, inverse != 0, (hipStream_t)stream);
+    });
+}
+int troyhip_fill_uniform(troyhip_context *ctx, uint64_t *data, uint64_t rows, const uint64_t *row_primes, int period, int inner, uint64_t seed,
+                         uint64_t row0, void *stream) {
+    return guard([&] {
+        Context &c = ctx->ctx;
+        launch_fill_uniform(data, c.d_desc, map_from_primes(c, row_primes, period, inner), c.logn, seed, row0, rows, (hipStream_t)stream);
+    });
+}
+
+int troyhip_negate(troyhip_context *ctx, troyhip_ct *a, uint64_t batch, void *stream) {
+    return guard([&] { CtBatch x = view(a); ctx->ev.negate(x, batch, (hipStream_t)stream); store(x, a); });
+}
+int troyhip_add(troyhip_context *ctx, troyhip_ct *a, const troyhip_ct *b, uint64_t batch, void *stream) {
+    return guard([&] { CtBatch x = view(a); ctx->ev.add_sub(x, view(b), batch, false, (hipStream_t)stream); store(x, a); });
+}
+int troyhip_sub(troyhip_context *ctx, troyhip_ct *a, const troyhip_ct *b, uint64_t batch, void *stream) {
+    return guard([&] { CtBatch x = view(a); ctx->ev.add_sub(x, view(b), batch, true, (hipStream_t)stream); store(x, a); });
+}
+int troyhip_multiply(troyhip_context *ctx, const troyhip_ct *a, const troyhip_ct *b, troyhip_ct *out, uint64_t batch, void *stream) {
+    return guard([&] { CtBatch o = view(out); ctx->ev.multiply(view(a), view(b), o, batch, (hipStream_t)stream); store(o, out); });
+}
+int troyhip_relinearize(troyhip_context *ctx, troyhip_ct *ct, const uint64_t *relin_key, uint64_t batch, void *stream) {
+    return guard([&] {
+        if (!relin_key) throw Error(ST_INVALID_ARGUMENT, "not enough relinearization keys");
+        CtBatch x = view(ct);
+        ctx->ev.relinearize(x, KsKey{relin_key}, batch, (hipStream_t)stream);
+        store(x, ct);
+    });
+}
+int troyhip_switch_key(troyhip_context *ctx, troyhip_ct *ct, const uint64_t *target, uint64_t target_batch_stride, const uint64_t *kswitch_key,
+                       uint64_t batch, void *stream) {
+    return guard([&] { CtBatch x = view(ct); ctx->ev.switch_key(x, target, target_batch_stride, KsKey{kswitch_key}, batch, (hipStream_t)stream); store(x, ct); });
+}
+int troyhip_mod_switch_to_next(troyhip_context *ctx, const troyhip_ct *in, troyhip_ct *out, uint64_t batch, void *stream) {
+    return guard([&] { CtBatch o = view(out); ctx->ev.mod_switch_to_next(view(in), o, batch, (hipStream_t)stream); store(o, out); });
+}
+int troyhip_rescale_to_next(troyhip_context *ctx, const troyhip_ct *in, troyhip_ct *out, uint64_t batch, void *stream) {
+    return guard([&] { CtBatch o = view(out); ctx->ev.rescale_to_next(view(in), o, batch, (hipStream_t)stream); store(o, out); });
+}
+int troyhip_apply_galois(troyhip_context *ctx, troyhip_ct *ct, uint32_t galois_elt, const uint64_t *galois_key, uint64_t batch, void *stream) {
+    return guard([&] { CtBatch x = view(ct); ctx->ev.apply_galois(x, galois_elt, KsKey{galois_key}, batch, (hipStream_t)stream); store(x, ct); });
+}
+
+static void rotate_internal(troyhip_context *ctx, CtBatch &x, int steps, const uint32_t *elts, const uint64_t *const *keys, int n_keys, u64 batch, hipStream_t s) {
+    if (steps == 0) return; // evaluator_cuda.cu:2140-2143
+    const u64 N = ctx->ctx.N;
+    auto find = [&](uint32_t e) -> const uint64_t * { for (int i = 0; i < n_keys; i++) if (elts[i] == e) return keys[i]; return nullptr; };
+    uint32_t elt = host::galois_elt_from_step(N, steps);
+    if (const uint64_t *k = find(elt)) { ctx->ev.apply_galois(x, elt, KsKey{k}, batch, s); return; }
+    auto ns = host::naf(steps); // evaluator_cuda.cu:2152-2175
+    if (ns.size() == 1) throw Error(ST_INVALID_ARGUMENT, "Galois key not present");
+    for (int st : ns) if ((u64)std::abs(st) != (N >> 1)) rotate_internal(ctx, x, st, elts, keys, n_keys, batch, s);
+}
+int troyhip_rotate(troyhip_context *ctx, troyhip_ct *ct, int steps, int conjugate, const uint32_t *key_elts, const uint64_t *const *keys, int n_keys,
+                   uint64_t batch, void *stream) {
+    return guard([&] {
+        CtBatch x = view(ct);
+        if (conjugate) { // rotateColumns / complexConjugate: element 2N-1 (evaluator_cuda.cuh:399-420)
+            uint32_t elt = (uint32_t)(2 * ctx->ctx.N - 1);
+            const uint64_t *k = nullptr;
+            for (int i = 0; i < n_keys; i++) if (key_elts[i] == elt) k = keys[i];
+            if (!k) throw Error(ST_INVALID_ARGUMENT, "Galois key not present");
+            ctx->ev.apply_galois(x, elt, KsKey{k}, batch, (hipStream_t)stream);
+        } else {
+            rotate_internal(ctx, x, steps, key_elts, keys, n_keys, batch, (hipStream_t)stream);
+        }
+        store(x, ct);
+    });
+}
+int troyhip_transform_to_ntt(troyhip_context *ctx, troyhip_ct *ct, uint64_t batch, void *stream) {
+    return guard([&] { CtBatch x = view(ct); ctx->ev.transform_to_ntt(x, batch, (hipStream_t)stream); store(x, ct); });
+}
+int troyhip_transform_from_ntt(troyhip_context *ctx, troyhip_ct *ct, uint64_t batch, void *stream) {
+    return guard([&] { CtBatch x = view(ct); ctx->ev.transform_from_ntt(x, batch, (hipStream_t)stream); store(x, ct); });
+}
+int troyhip_multiply_plain_ntt(troyhip_context *ctx, troyhip_ct *ct, const uint64_t *plain, double plain_scale, uint64_t batch, void *stream) {
+    return guard([&] { CtBatch x = view(ct); ctx->ev.multiply_plain_ntt(x, plain, plain_scale, batch, (hipStream_t)stream); store(x, ct); });
+}
+
+} // extern "C"

@@ -1,0 +1,193 @@
+// context.cpp -- see context.h.
+#include "context.h"
+#include "kernels.h"
+#include <algorithm>
+#include <cstring>
+
+namespace troyhip {
+
+Arena::~Arena() {
+    if (base_) (void)hipFree(base_);
+    for (u64 *p : retired_) (void)hipFree(p);
+}
+void Arena::reserve(size_t count) {
+    if (count <= cap_) return;
+    // grow-only; the old block may still be referenced by work already queued on the stream, so it is
+    // retired (freed with the context) instead of being freed here
+    size_t want = std::max(count, cap_ * 2);
+    u64 *nb = nullptr;
+    HIP_CHECK(hipMalloc((void **)&nb, want * sizeof(u64)));
+    if (base_) retired_.push_back(base_);
+    base_ = nb;
+    cap_ = want;
+    used_ = 0;
+}
+u64 *Arena::take(size_t count) {
+    count = (count + 31) & ~size_t(31); // keep 256-byte alignment
+    if (used_ + count > cap_) {
+        if (used_ != 0) throw Error(ST_LOGIC_ERROR, "scratch arena exhausted inside an op (reserve() must be called first)");
+        reserve(count);
+    }
+    u64 *p = base_ + used_;
+    used_ += count;
+    return p;
+}
+
+template <class T> T *Context::upload(const std::vector<T> &v, std::vector<void *> &owner) {
+    if (v.empty()) return nullptr;
+    T *d = nullptr;
+    HIP_CHECK(hipMalloc((void **)&d, v.size() * sizeof(T)));
+    owner.push_back(d);
+    HIP_CHECK(hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return d;
+}
+
+int Context::register_prime(u64 p) {
+    for (size_t i = 0; i < primes.size(); i++) if (primes[i] == p) return (int)i;
+    if (primes.size() >= 255) throw Error(ST_LOGIC_ERROR, "too many primes");
+    primes.push_back(p);
+    tables.emplace_back();
+    tables.back().build(logn, p);
+    return (int)primes.size() - 1;
+}
+int Context::prime_id(u64 p) const {
+    for (size_t i = 0; i < primes.size(); i++) if (primes[i] == p) return (int)i;
+    throw Error(ST_INVALID_ARGUMENT, "prime is not part of the context");
+}
+
+Context::Context(int scheme_, u64 N_, const std::vector<u64> &key_primes, u64 t_) : scheme(scheme_), N(N_), t(scheme_ == SCHEME_CKKS ? 0 : t_) {
+    if (scheme < SCHEME_BFV || scheme > SCHEME_BGV) throw Error(ST_INVALID_ARGUMENT, "unsupported scheme");
+    if (N < 2 || N > 131072 || (N & (N - 1))) throw Error(ST_INVALID_ARGUMENT, "poly_modulus_degree is invalid");
+    logn = 63 - __builtin_clzll(N);
+    K = (int)key_primes.size();
+    if (K < 1 || K > 64) throw Error(ST_INVALID_ARGUMENT, "coeff_modulus size is invalid");
+    for (u64 p : key_primes) {
+        if ((p >> 60) || p < 2) throw Error(ST_INVALID_ARGUMENT, "coeff_modulus primes must be at most 60 bits");
+        if (std::count(key_primes.begin(), key_primes.end(), p) != 1) throw Error(ST_INVALID_ARGUMENT, "coeff_modulus primes must be distinct");
+        if (!host::is_prime(p) || (p - 1) % (2 * N)) throw Error(ST_INVALID_ARGUMENT, "coeff_modulus primes must be NTT-friendly primes");
+        register_prime(p);
+    }
+    if (scheme != SCHEME_CKKS) {
+        if (t < 2 || (t >> 60)) throw Error(ST_INVALID_ARGUMENT, "plain_modulus is invalid");
+        for (u64 p : key_primes) if (p % t == 0 || t % p == 0) throw Error(ST_INVALID_ARGUMENT, "plain_modulus must be coprime to coeff_modulus");
+    }
+    // modulus-switching chain (src/context.cpp:426-531): key level, then drop the last prime while valid
+    first_limbs = K > 1 ? K - 1 : K;
+    last_limbs = 0;
+    for (int limbs = K; limbs >= 1; limbs--) {
+        std::vector<u64> q(key_primes.begin(), key_primes.begin() + limbs);
+        if (scheme != SCHEME_CKKS && host::bit_length_of_product(q) <= 64) {
+            u128 prod = 1;
+            for (u64 p : q) prod *= p;
+            if (prod <= (u128)t) break; // plain modulus must stay below the coefficient modulus
+        }
+        build_level(limbs);
+        last_limbs = limbs;
+    }
+    if (!has_level(first_limbs)) throw Error(ST_INVALID_ARGUMENT, "encryption parameters are not valid");
+    upload_tables();
+}
+
+Context::~Context() {
+    for (void *p : dev_allocs_) (void)hipFree(p);
+    for (auto &kv : levels) for (void *p : kv.second.dev_blocks) (void)hipFree(p);
+}
+
+const Level &Context::level(int limbs) const {
+    auto it = levels.find(limbs);
+    if (it == levels.end()) throw Error(ST_INVALID_ARGUMENT, "no such level in the modulus chain");
+    return it->second;
+}
+
+LimbMap Context::ct_map(int limbs) const {
+    LimbMap m;
+    std::memset(&m, 0, sizeof(m));
+    for (int i = 0; i < limbs; i++) m.id[i] = (uint8_t)i;
+    m.period = (uint32_t)limbs;
+    m.inner = 1;
+    return m;
+}
+LimbMap Context::ids_map(const std::vector<uint8_t> &ids, uint32_t inner) const {
+    LimbMap m;
+    std::memset(&m, 0, sizeof(m));
+    if (ids.size() > 64) throw Error(ST_LOGIC_ERROR, "limb map too long");
+    for (size_t i = 0; i < ids.size(); i++) m.id[i] = ids[i];
+    m.period = (uint32_t)ids.size();
+    m.inner = inner;
+    return m;
+}
+LimbMap Context::single_map(int id) const { return ids_map({(uint8_t)id}); }
+
+void Context::build_level(int limbs) {
+    Level &lv = levels[limbs];
+    lv.limbs = limbs;
+    std::vector<u64> q(primes.begin(), primes.begin() + limbs);
+    lv.rns.build(N, q, t);
+    for (u64 p : lv.rns.Bsk) lv.bsk_ids.push_back((uint8_t)register_prime(p));
+}
+
+void Context::upload_tables() {
+    // NTT tables
+    h_desc.resize(primes.size());
+    for (size_t i = 0; i < primes.size(); i++) {
+        const host::NttTable &tb = tables[i];
+        Mod m = make_mod(tb.p);
+        PrimeDesc &d = h_desc[i];
+        d.p = m.p; d.cr0 = m.cr0; d.cr1 = m.cr1; d.two_p = 2 * m.p;
+        d.inv_n = tb.inv_n;
+        d.iroot_last_scaled = tb.iroot_last_scaled;
+        d.root = upload(tb.root, dev_allocs_);
+        d.iroot = upload(tb.iroot, dev_allocs_);
+    }
+    d_desc = upload(h_desc, dev_allocs_);
+
+    if (scheme != SCHEME_BFV) return;
+    // BEHZ constants, per data level
+    for (auto &kv : levels) {
+        Level &lv = kv.second;
+        if (!is_data_level(lv.limbs)) continue;
+        const host::RnsLevel &r = lv.rns;
+        const int L = lv.limbs, nB = (int)r.B.size(), nBsk = (int)r.Bsk.size();
+        auto c = std::make_shared<BehzDev>();
+        std::memset(c.get(), 0, sizeof(BehzDev));
+        c->L = L; c->nB = nB; c->nBsk = nBsk;
+        for (int l = 0; l < L; l++) c->q_id[l] = (uint8_t)l;
+        for (int o = 0; o < nBsk; o++) c->bsk_id[o] = lv.bsk_ids[o];
+        std::vector<Shoup> ext_pre(L), floor_pre(L), inv_mt(nBsk), t_bsk(nBsk), inv_q(nBsk), B_pre(nB);
+        std::vector<u64> q2bsk((size_t)(nBsk + 1) * L), B2q((size_t)L * nB), B2msk(nB);
+        for (int l = 0; l < L; l++) {
+            u64 ql = r.q[l], ip = r.q_to_Bsk.inv_punct[l];
+            ext_pre[l] = make_shoup(host::mul_mod(r.m_tilde % ql, ip, ql), ql);
+            floor_pre[l] = make_shoup(host::mul_mod(t % ql, ip, ql), ql);
+            for (int o = 0; o < nBsk; o++) q2bsk[(size_t)o * L + l] = r.q_to_Bsk.mat[o][l];
+            q2bsk[(size_t)nBsk * L + l] = r.q_to_mtilde.mat[0][l];
+            for (int b = 0; b < nB; b++) B2q[(size_t)l * nB + b] = r.B_to_q.mat[l][b];
+        }
+        for (int o = 0; o < nBsk; o++) {
+            u64 p = r.Bsk[o];
+            inv_mt[o] = make_shoup(r.inv_mtilde_mod_Bsk[o], p);
+            t_bsk[o] = make_shoup(t % p, p);
+            inv_q[o] = make_shoup(r.inv_prod_q_mod_Bsk[o], p);
+        }
+        for (int b = 0; b < nB; b++) {
+            B_pre[b] = make_shoup(r.B_to_q.inv_punct[b], r.B[b]);
+            B2msk[b] = r.B_to_msk.mat[0][b];
+        }
+        c->ext_pre = upload(ext_pre, lv.dev_blocks);
+        c->q2bsk = upload(q2bsk, lv.dev_blocks);
+        c->neg_inv_q_mod_mt = r.neg_inv_prod_q_mod_mtilde;
+        c->prod_q_mod_bsk = upload(r.prod_q_mod_Bsk, lv.dev_blocks);
+        c->inv_mt_mod_bsk = upload(inv_mt, lv.dev_blocks);
+        c->floor_pre = upload(floor_pre, lv.dev_blocks);
+        c->t_mod_bsk = upload(t_bsk, lv.dev_blocks);
+        c->inv_q_mod_bsk = upload(inv_q, lv.dev_blocks);
+        c->B_pre = upload(B_pre, lv.dev_blocks);
+        c->B2q = upload(B2q, lv.dev_blocks);
+        c->B2msk = upload(B2msk, lv.dev_blocks);
+        c->inv_B_mod_msk = make_shoup(r.inv_prod_B_mod_msk, r.m_sk);
+        c->prod_B_mod_q = upload(r.prod_B_mod_q, lv.dev_blocks);
+        lv.behz = c;
+    }
+}
+
+} // namespace troyhip

@@ -1,0 +1,78 @@
+// context.h -- device context of libtroyhip: the MI355X counterpart of SEALContextCuda /
+// ContextDataCuda / RNSToolCuda / NTTTablesCuda (src/context_cuda.cu:5-62, src/utils/rns_cuda.cu:206-269,
+// src/utils/ntt_cuda.cuh:24-29).  Built from the encryption parameters alone; every table lives in HBM
+// for the lifetime of the context.
+#pragma once
+#include "device_types.h"
+#include "hostmath.h"
+#include <map>
+#include <memory>
+#include <vector>
+
+namespace troyhip {
+
+struct BehzDev; // behz.hip
+
+enum Scheme { SCHEME_BFV = 1, SCHEME_CKKS = 2, SCHEME_BGV = 3 };
+
+// Grow-only device scratch (the reference's DeviceDynamicArray::ensure, src/utils/devicearray.cuh:289-297).
+// One arena per context; ops on one context are stream-ordered by the caller.
+class Arena {
+public:
+    ~Arena();
+    // carve `count` u64 from the arena for the current op; valid until reset()
+    u64 *take(size_t count);
+    void reset() { used_ = 0; }
+    void reserve(size_t count);
+    size_t capacity() const { return cap_; }
+private:
+    u64 *base_ = nullptr;
+    size_t cap_ = 0, used_ = 0;
+    std::vector<u64 *> retired_; // blocks replaced by a larger one; freed with the context
+};
+
+struct Level {
+    int limbs = 0;
+    host::RnsLevel rns;
+    std::vector<uint8_t> bsk_ids;
+    std::shared_ptr<BehzDev> behz; // BFV only
+    std::vector<void *> dev_blocks;
+};
+
+class Context {
+public:
+    Context(int scheme, u64 N, const std::vector<u64> &primes, u64 t);
+    ~Context();
+    Context(const Context &) = delete;
+    Context &operator=(const Context &) = delete;
+
+    int scheme;
+    u64 N;
+    int logn;
+    int K;          // key-level limb count
+    u64 t;
+    int first_limbs, last_limbs;
+    std::vector<u64> primes;     // registry: [0,K) key primes, then the BEHZ aux primes
+    std::vector<host::NttTable> tables;
+    std::vector<PrimeDesc> h_desc;
+    PrimeDesc *d_desc = nullptr;
+    std::map<int, Level> levels; // by limb count, K .. last_limbs
+    Arena arena;
+
+    const Level &level(int limbs) const;
+    bool has_level(int limbs) const { return levels.count(limbs) != 0; }
+    bool is_data_level(int limbs) const { return has_level(limbs) && (K == 1 || limbs < K); }
+    int prime_id(u64 p) const;
+    LimbMap ct_map(int limbs) const;            // rows cycle through key primes 0..limbs-1
+    LimbMap ids_map(const std::vector<uint8_t> &ids, uint32_t inner = 1) const;
+    LimbMap single_map(int id) const;
+
+private:
+    int register_prime(u64 p);
+    void upload_tables();
+    void build_level(int limbs);
+    std::vector<void *> dev_allocs_;
+    template <class T> T *upload(const std::vector<T> &v, std::vector<void *> &owner);
+};
+
+} // namespace troyhip

@@ -1,0 +1,411 @@
+// evaluator.cpp -- see evaluator.h.  Host-side orchestration only; all arithmetic is in the kernels.
+#include "evaluator.h"
+#include "kernels.h"
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace troyhip {
+
+static inline u64 poly_words(const Context &c, int limbs) { return (u64)limbs * c.N; }
+
+void Evaluator::check_ct(const CtBatch &a) const {
+    if (!a.data) throw Error(ST_INVALID_ARGUMENT, "encrypted is not valid for encryption parameters");
+    if (!c.is_data_level(a.limbs)) throw Error(ST_INVALID_ARGUMENT, "encrypted is not valid for encryption parameters");
+    if (a.size < 1 || a.size > 16) throw Error(ST_INVALID_ARGUMENT, "encrypted is not valid for encryption parameters");
+    if (a.bstride < (u64)a.size * poly_words(c, a.limbs)) throw Error(ST_INVALID_ARGUMENT, "batch stride is smaller than one ciphertext");
+}
+
+// evaluator_cuda.cu:32-51 isScaleWithinBounds
+bool Evaluator::scale_ok(double scale, int limbs) const {
+    std::vector<u64> q(c.primes.begin(), c.primes.begin() + limbs);
+    int bound = host::bit_length_of_product(q);
+    return !(scale <= 0 || ((int)std::log2(scale) >= bound));
+}
+
+// evaluator_cuda.cu:53-115 balanceCorrectionFactors
+void Evaluator::balance_correction(u64 f1, u64 f2, u64 &f, u64 &e1_out, u64 &e2_out) const {
+    const u64 t = c.t, half_t = t / 2;
+    auto sum_abs = [&](u64 x, u64 y) {
+        int64_t xb = (int64_t)(x > half_t ? x - t : x), yb = (int64_t)(y > half_t ? y - t : y);
+        return std::llabs(xb) + std::llabs(yb);
+    };
+    u64 ratio;
+    if (!host::inv_mod(f1, t, ratio)) throw Error(ST_LOGIC_ERROR, "invalid correction factor1");
+    ratio = host::mul_mod(ratio, f2 % t, t);
+    u64 e1 = ratio, e2 = 1;
+    int64_t sum = sum_abs(e1, e2);
+    int64_t prev_a = (int64_t)t, prev_b = 0, a = (int64_t)ratio, b = 1;
+    auto gcd = [](u64 x, u64 y) { while (y) { u64 r = x % y; x = y; y = r; } return x; };
+    while (a != 0) {
+        int64_t q = prev_a / a, tmp = prev_a % a;
+        prev_a = a; a = tmp;
+        tmp = prev_b - b * q; prev_b = b; b = tmp;
+        u64 a_mod = (u64)std::llabs(a) % t;
+        if (a < 0 && a_mod) a_mod = t - a_mod;
+        u64 b_mod = (u64)std::llabs(b) % t;
+        if (b < 0 && b_mod) b_mod = t - b_mod;
+        if (a_mod != 0 && gcd(a_mod, t) == 1) {
+            int64_t ns = sum_abs(a_mod, b_mod);
+            if (ns < sum) { sum = ns; e1 = a_mod; e2 = b_mod; }
+        }
+    }
+    f = host::mul_mod(e1, f1 % t, t);
+    e1_out = e1;
+    e2_out = e2;
+}
+
+void Evaluator::scalar_mul(CtBatch &a, u64 scalar, u64 batch, hipStream_t s) {
+    u64 sc[64];
+    for (int l = 0; l < a.limbs; l++) sc[l] = scalar % c.primes[l];
+    LimbMap map = c.ct_map(a.limbs);
+    const u64 words = (u64)a.size * poly_words(c, a.limbs);
+    if (a.bstride == words) launch_mul_scalar(a.data, c.d_desc, map, sc, c.logn, batch * a.size * a.limbs, s);
+    else for (u64 b = 0; b < batch; b++) launch_mul_scalar(a.data + b * a.bstride, c.d_desc, map, sc, c.logn, (u64)a.size * a.limbs, s);
+}
+
+// addInplace / subInplace (evaluator_cuda.cu:145-260)
+void Evaluator::add_sub(CtBatch &a, const CtBatch &b_in, u64 batch, bool sub, hipStream_t s) {
+    check_ct(a);
+    check_ct(b_in);
+    if (a.limbs != b_in.limbs) throw Error(ST_INVALID_ARGUMENT, "encrypted1 and encrypted2 parameter mismatch");
+    if (a.ntt != b_in.ntt) throw Error(ST_INVALID_ARGUMENT, "NTT form mismatch");
+    if (!(a.scale == b_in.scale || std::fabs(a.scale - b_in.scale) < std::ldexp(std::max(std::fabs(a.scale), 1.0), -40))) throw Error(ST_INVALID_ARGUMENT, "scale mismatch");
+    const u64 pw = poly_words(c, a.limbs);
+    CtBatch b = b_in;
+    c.arena.reset();
+    if (a.cf != b.cf) {
+        // BGV: balance the correction factors first (evaluator_cuda.cu:170-190)
+        u64 f, e1, e2;
+        balance_correction(a.cf, b.cf, f, e1, e2);
+        scalar_mul(a, e1, batch, s);
+        u64 *copy = c.arena.take(batch * b.size * pw);
+        launch_copy_strided(b.data, b.bstride, copy, b.size * pw, b.size * pw, batch, s);
+        b.data = copy;
+        b.bstride = b.size * pw;
+        scalar_mul(b, e2, batch, s);
+        a.cf = f;
+        b.cf = f;
+    }
+    const int mn = std::min(a.size, b.size), mx = std::max(a.size, b.size);
+    if (a.bstride < (u64)mx * pw) throw Error(ST_INVALID_ARGUMENT, "destination batch stride too small for the result size");
+    LimbMap map = c.ct_map(a.limbs);
+    if (a.size == b.size && a.bstride == a.size * pw && b.bstride == a.bstride) {
+        launch_ew(sub ? 1 : 0, a.data, b.data, a.data, c.d_desc, map, c.logn, batch * a.size * a.limbs, s);
+    } else {
+        for (u64 i = 0; i < batch; i++) {
+            u64 *x = a.data + i * a.bstride;
+            const u64 *y = b.data + i * b.bstride;
+            launch_ew(sub ? 1 : 0, x, y, x, c.d_desc, map, c.logn, (u64)mn * a.limbs, s);
+            if (a.size < b.size) { // tail polys: copy (add) or negate (sub), evaluator_cuda.cu:199-204,253-258
+                if (sub) launch_ew(2, y + mn * pw, nullptr, x + mn * pw, c.d_desc, map, c.logn, (u64)(b.size - mn) * a.limbs, s);
+                else launch_copy_strided(y + mn * pw, 0, x + mn * pw, 0, (b.size - mn) * pw, 1, s);
+            }
+        }
+    }
+    a.size = mx;
+}
+
+void Evaluator::negate(CtBatch &a, u64 batch, hipStream_t s) { // evaluator_cuda.cu:117-143
+    check_ct(a);
+    LimbMap map = c.ct_map(a.limbs);
+    const u64 words = (u64)a.size * poly_words(c, a.limbs);
+    if (a.bstride == words) launch_ew(2, a.data, nullptr, a.data, c.d_desc, map, c.logn, batch * a.size * a.limbs, s);
+    else for (u64 b = 0; b < batch; b++) launch_ew(2, a.data + b * a.bstride, nullptr, a.data + b * a.bstride, c.d_desc, map, c.logn, (u64)a.size * a.limbs, s);
+}
+
+size_t Evaluator::scratch_multiply(int sa, int sb, int limbs, u64 batch) const {
+    const u64 N = c.N;
+    const int ds = sa + sb - 1;
+    size_t pad = 64;
+    if (c.scheme == SCHEME_BFV) {
+        const int nb = (int)c.level(limbs).rns.Bsk.size();
+        return (size_t)batch * N * ((size_t)(sa + sb) * (limbs + nb) + (size_t)ds * (limbs + nb) * 2) + 8 * pad;
+    }
+    return (size_t)batch * N * limbs * (sa + sb + ds) + 4 * pad;
+}
+
+// multiplyInplace -> bfvMultiply / ckksMultiply / bgvMultiply (evaluator_cuda.cu:262-501)
+void Evaluator::multiply(const CtBatch &a, const CtBatch &b, CtBatch &out, u64 batch, hipStream_t s) {
+    check_ct(a);
+    check_ct(b);
+    if (a.limbs != b.limbs) throw Error(ST_INVALID_ARGUMENT, "encrypted1 and encrypted2 parameter mismatch");
+    const int L = a.limbs, sa = a.size, sb = b.size, ds = sa + sb - 1;
+    const u64 N = c.N, pw = poly_words(c, L);
+    if (!out.data || out.bstride < (u64)ds * pw) throw Error(ST_INVALID_ARGUMENT, "destination batch stride too small for the result size");
+    if (ds > 5 || sa > 3 || sb > 3) throw Error(ST_INVALID_ARGUMENT, "ciphertext sizes above 3 are not supported by multiply");
+    LimbMap qmap = c.ct_map(L);
+    c.arena.reset();
+    c.arena.reserve(scratch_multiply(sa, sb, L, batch));
+    double new_scale = a.scale;
+    u64 new_cf = a.cf;
+    const bool same = (a.data == b.data && a.bstride == b.bstride && sa == sb);
+    (void)same;
+
+    if (c.scheme == SCHEME_BFV) {
+        if (a.ntt || b.ntt) throw Error(ST_INVALID_ARGUMENT, "encrypted1 or encrypted2 cannot be in NTT form");
+        const Level &lv = c.level(L);
+        const int nb = (int)lv.rns.Bsk.size();
+        const u64 bw = (u64)nb * N;
+        const int sp = sa + sb;
+        u64 *xq = c.arena.take(batch * sp * pw), *xb = c.arena.take(batch * sp * bw);
+        u64 *dq = c.arena.take(batch * ds * pw), *db = c.arena.take(batch * ds * bw);
+        // BEHZ steps (1)-(3): copy, extend q -> Bsk, forward NTT in both bases
+        launch_copy_strided(a.data, a.bstride, xq, sp * pw, sa * pw, batch, s);
+        launch_copy_strided(b.data, b.bstride, xq + sa * pw, sp * pw, sb * pw, batch, s);
+        launch_behz_extend(xq, pw, xb, bw, c.d_desc, *lv.behz, N, batch * sp, s);
+        launch_ntt(xq, c.d_desc, qmap, batch * sp * L, c.logn, false, s);
+        launch_ntt(xb, c.d_desc, c.ids_map(lv.bsk_ids), batch * sp * nb, c.logn, false, s);
+        // (4) tensor in both bases
+        launch_tensor(sa, sb, xq, xq + sa * pw, dq, sp * pw, sp * pw, c.d_desc, qmap, c.logn, L, batch, s);
+        launch_tensor(sa, sb, xb, xb + sa * bw, db, sp * bw, sp * bw, c.d_desc, c.ids_map(lv.bsk_ids), c.logn, nb, batch, s);
+        // (5) inverse NTT
+        launch_ntt(dq, c.d_desc, qmap, batch * ds * L, c.logn, true, s);
+        launch_ntt(db, c.d_desc, c.ids_map(lv.bsk_ids), batch * ds * nb, c.logn, true, s);
+        // (6)-(8) multiply by t, floor, Shenoy-Kumaresan back to base q
+        if (out.bstride == (u64)ds * pw) {
+            launch_behz_floor_sk(dq, pw, db, bw, out.data, pw, c.d_desc, *lv.behz, N, batch * ds, s);
+        } else {
+            u64 *res = xq; // xq is dead by now and large enough (sp >= ds)
+            launch_behz_floor_sk(dq, pw, db, bw, res, pw, c.d_desc, *lv.behz, N, batch * ds, s);
+            launch_copy_strided(res, ds * pw, out.data, out.bstride, ds * pw, batch, s);
+        }
+    } else if (c.scheme == SCHEME_CKKS) {
+        if (!(a.ntt && b.ntt)) throw Error(ST_INVALID_ARGUMENT, "encrypted1 or encrypted2 must be in NTT form");
+        new_scale = a.scale * b.scale;
+        if (!scale_ok(new_scale, L)) throw Error(ST_INVALID_ARGUMENT, "scale out of bounds");
+        u64 *d = c.arena.take(batch * ds * pw);
+        launch_tensor(sa, sb, a.data, b.data, d, a.bstride, b.bstride, c.d_desc, qmap, c.logn, L, batch, s);
+        launch_copy_strided(d, ds * pw, out.data, out.bstride, ds * pw, batch, s);
+    } else {
+        if (a.ntt || b.ntt) throw Error(ST_INVALID_ARGUMENT, "encryped1 or encrypted2 must be not in NTT form");
+        const int sp = sa + sb;
+        u64 *x = c.arena.take(batch * sp * pw), *d = c.arena.take(batch * ds * pw);
+        launch_copy_strided(a.data, a.bstride, x, sp * pw, sa * pw, batch, s);
+        launch_copy_strided(b.data, b.bstride, x + sa * pw, sp * pw, sb * pw, batch, s);
+        launch_ntt(x, c.d_desc, qmap, batch * sp * L, c.logn, false, s);
+        launch_tensor(sa, sb, x, x + sa * pw, d, sp * pw, sp * pw, c.d_desc, qmap, c.logn, L, batch, s);
+        launch_ntt(d, c.d_desc, qmap, batch * ds * L, c.logn, true, s);
+        launch_copy_strided(d, ds * pw, out.data, out.bstride, ds * pw, batch, s);
+        new_cf = host::mul_mod(a.cf % c.t, b.cf % c.t, c.t);
+    }
+    out.size = ds;
+    out.limbs = L;
+    out.ntt = a.ntt;
+    out.scale = new_scale;
+    out.cf = new_cf;
+}
+
+size_t Evaluator::scratch_switch_key(int limbs, u64 batch) const {
+    const size_t N = c.N, dl = limbs, rl = limbs + 1;
+    return batch * N * (dl /*t_target*/ + rl * dl /*D*/ + 2 * rl /*acc*/ + 2 * dl /*corr*/ + 2 /*last*/) + 512;
+}
+
+// switchKeyInplace (evaluator_cuda.cu:1163-1362; CPU src/evaluator.cpp:2310-2653)
+void Evaluator::switch_key(CtBatch &ct, const u64 *target, u64 t_bstride, const KsKey &key, u64 batch, hipStream_t s) {
+    check_ct(ct);
+    if (!target) throw Error(ST_INVALID_ARGUMENT, "target_iter");
+    if (c.K < 2) throw Error(ST_LOGIC_ERROR, "keyswitching is not supported by the context");
+    if (!key.data) throw Error(ST_INVALID_ARGUMENT, "kswitch_keys is not valid for encryption parameters");
+    if (c.scheme == SCHEME_BFV && ct.ntt) throw Error(ST_INVALID_ARGUMENT, "BFV encrypted cannot be in NTT form");
+    if (c.scheme == SCHEME_CKKS && !ct.ntt) throw Error(ST_INVALID_ARGUMENT, "CKKS encrypted must be in NTT form");
+    if (c.scheme == SCHEME_BGV && ct.ntt) throw Error(ST_INVALID_ARGUMENT, "BGV encrypted cannot be in NTT form");
+    if (ct.size < 2) throw Error(ST_INVALID_ARGUMENT, "encrypted size must be at least 2");
+    const u64 N = c.N, dl = ct.limbs, rl = dl + 1, K = c.K;
+    const host::RnsLevel &key_rns = c.level((int)K).rns;
+    KsArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.primes = c.d_desc;
+    for (u64 i = 0; i < dl; i++) { a.key_id[i] = (uint8_t)i; a.key_limb[i] = (uint8_t)i; }
+    a.key_id[dl] = (uint8_t)(K - 1);
+    a.key_limb[dl] = (uint8_t)(K - 1);
+    const u64 qk = c.primes[K - 1];
+    for (u64 j = 0; j < dl; j++) a.inv_qk[j] = make_shoup(key_rns.inv_q_last_mod_q[j], c.primes[j]);
+    a.half = qk >> 1;
+    if (c.t) {
+        Mod tm = make_mod(c.t);
+        a.t_p = tm.p; a.t_cr0 = tm.cr0; a.t_cr1 = tm.cr1;
+        a.inv_qk_mod_t = key_rns.inv_q_last_mod_t;
+    }
+    a.logn = c.logn; a.dl = dl; a.K = K; a.batch = batch;
+
+    c.arena.reset();
+    c.arena.reserve(scratch_switch_key((int)dl, batch));
+    u64 *D = c.arena.take(batch * rl * dl * N);
+    u64 *acc = c.arena.take(batch * 2 * rl * N);
+    std::vector<uint8_t> out_ids(a.key_id, a.key_id + rl);
+
+    const u64 *coeff_target = target;
+    u64 ct_tb = t_bstride;
+    if (c.scheme == SCHEME_CKKS) { // bring the target to coefficient form (evaluator_cuda.cu:1215-1216)
+        u64 *tt = c.arena.take(batch * dl * N);
+        launch_copy_strided(target, t_bstride, tt, dl * N, dl * N, batch, s);
+        launch_ntt(tt, c.d_desc, c.ct_map((int)dl), batch * dl, c.logn, true, s);
+        coeff_target = tt;
+        ct_tb = dl * N;
+    }
+    // decompose + extend every limb to every output prime, then ONE batched NTT over all (L+1)*L rows
+    launch_ks_expand(coeff_target, ct_tb, D, a, s);
+    launch_ntt(D, c.d_desc, c.ids_map(out_ids, (uint32_t)dl), batch * rl * dl, c.logn, false, s);
+    // inner products with the key (128-bit lazy accumulation, one reduction per output)
+    launch_ks_mac(D, key.data, c.scheme == SCHEME_CKKS ? target : nullptr, t_bstride, acc, a, s);
+
+    if (c.scheme == SCHEME_CKKS) {
+        // special-prime limb -> coefficient form, correction polynomial -> NTT form, combine
+        u64 *last = c.arena.take(batch * 2 * N), *corr = c.arena.take(batch * 2 * dl * N);
+        launch_gather_limb(acc, last, c.logn, rl * N, dl, batch * 2, s);
+        launch_ntt(last, c.d_desc, c.single_map((int)K - 1), batch * 2, c.logn, true, s);
+        launch_ks_ckks_corr(last, corr, a, s);
+        launch_ntt(corr, c.d_desc, c.ct_map((int)dl), batch * 2 * dl, c.logn, false, s);
+        launch_ks_ckks_combine(acc, corr, ct.data, ct.bstride, a, s);
+    } else {
+        launch_ntt(acc, c.d_desc, c.ids_map(out_ids), batch * 2 * rl, c.logn, true, s);
+        launch_ks_moddown(c.scheme == SCHEME_BFV ? 0 : 2, acc, ct.data, ct.bstride, a, s);
+    }
+}
+
+// relinearizeInternal (evaluator_cuda.cu:703-744), destination size 2
+void Evaluator::relinearize(CtBatch &ct, const KsKey &key, u64 batch, hipStream_t s) {
+    check_ct(ct);
+    if (ct.size == 2) return;
+    if (ct.size != 3) throw Error(ST_INVALID_ARGUMENT, "only size-3 ciphertexts can be relinearized");
+    const u64 pw = poly_words(c, ct.limbs);
+    switch_key(ct, ct.data + 2 * pw, ct.bstride, key, batch, s);
+    ct.size = 2;
+}
+
+// modSwitchScaleToNext (evaluator_cuda.cu:749-824)
+void Evaluator::mod_switch_scale(const CtBatch &in, CtBatch &out, u64 batch, hipStream_t s) {
+    check_ct(in);
+    const int L = in.limbs, nl = L - 1;
+    if (L < 2 || !c.is_data_level(nl)) throw Error(ST_INVALID_ARGUMENT, "end of modulus switching chain reached");
+    if (c.scheme == SCHEME_BFV && in.ntt) throw Error(ST_INVALID_ARGUMENT, "BFV encrypted cannot be in NTT form");
+    if (c.scheme == SCHEME_CKKS && !in.ntt) throw Error(ST_INVALID_ARGUMENT, "CKKS encrypted must be in NTT form");
+    if (c.scheme == SCHEME_BGV && in.ntt) throw Error(ST_INVALID_ARGUMENT, "BGV encrypted cannot be in NTT form");
+    const u64 N = c.N, pw = poly_words(c, L), npw = poly_words(c, nl);
+    if (!out.data || out.bstride < (u64)in.size * npw) throw Error(ST_INVALID_ARGUMENT, "destination batch stride too small for the result size");
+    const host::RnsLevel &r = c.level(L).rns;
+    ModSwitchArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.primes = c.d_desc;
+    a.map = c.ct_map(L);
+    for (int l = 0; l < nl; l++) a.inv_qlast[l] = make_shoup(r.inv_q_last_mod_q[l], c.primes[l]);
+    a.half = c.primes[L - 1] >> 1;
+    if (c.t) {
+        Mod tm = make_mod(c.t);
+        a.t_p = tm.p; a.t_cr0 = tm.cr0; a.t_cr1 = tm.cr1;
+        a.inv_qlast_mod_t = r.inv_q_last_mod_t;
+    }
+    a.logn = c.logn; a.limbs = L; a.polys = batch * in.size;
+
+    c.arena.reset();
+    const bool dense_in = in.bstride == (u64)in.size * pw, dense_out = out.bstride == (u64)in.size * npw;
+    const u64 *src = in.data;
+    if (!dense_in) {
+        u64 *tmp = c.arena.take(batch * in.size * pw);
+        launch_copy_strided(in.data, in.bstride, tmp, in.size * pw, in.size * pw, batch, s);
+        src = tmp;
+    }
+    u64 *dst = dense_out ? out.data : c.arena.take(batch * in.size * npw);
+    if (dst == src) throw Error(ST_INVALID_ARGUMENT, "mod switch cannot run in place");
+    if (c.scheme == SCHEME_CKKS) {
+        u64 *last = c.arena.take(batch * in.size * N), *corr = c.arena.take(batch * in.size * npw);
+        launch_gather_limb(src, last, c.logn, pw, (u64)nl, batch * in.size, s);
+        launch_ntt(last, c.d_desc, c.single_map(L - 1), batch * in.size, c.logn, true, s);
+        launch_rescale_stepA(last, N, corr, a, s);
+        launch_ntt(corr, c.d_desc, c.ct_map(nl), batch * in.size * nl, c.logn, false, s);
+        launch_rescale_stepB(src, corr, dst, a, s);
+    } else {
+        launch_modswitch(c.scheme == SCHEME_BFV ? 0 : 2, src, dst, a, s);
+    }
+    if (!dense_out) launch_copy_strided(dst, in.size * npw, out.data, out.bstride, in.size * npw, batch, s);
+    out.size = in.size;
+    out.limbs = nl;
+    out.ntt = in.ntt;
+    out.scale = in.scale;
+    out.cf = in.cf;
+    if (c.scheme == SCHEME_CKKS) out.scale = in.scale / (double)c.primes[L - 1];
+    else if (c.scheme == SCHEME_BGV) out.cf = host::mul_mod(in.cf % c.t, r.inv_q_last_mod_t, c.t);
+}
+
+// modSwitchToNext (evaluator_cuda.cu:926-980): CKKS drops the last limb, BFV/BGV scale
+void Evaluator::mod_switch_to_next(const CtBatch &in, CtBatch &out, u64 batch, hipStream_t s) {
+    if (c.scheme != SCHEME_CKKS) { mod_switch_scale(in, out, batch, s); return; }
+    check_ct(in);
+    const int L = in.limbs, nl = L - 1;
+    if (L < 2 || !c.is_data_level(nl)) throw Error(ST_INVALID_ARGUMENT, "end of modulus switching chain reached");
+    if (!in.ntt) throw Error(ST_INVALID_ARGUMENT, "CKKS encrypted must be in NTT form");
+    if (!scale_ok(in.scale, nl)) throw Error(ST_INVALID_ARGUMENT, "scale out of bounds");
+    const u64 pw = poly_words(c, L), npw = poly_words(c, nl);
+    if (!out.data || out.bstride < (u64)in.size * npw) throw Error(ST_INVALID_ARGUMENT, "destination batch stride too small for the result size");
+    if (in.bstride == (u64)in.size * pw && out.bstride == (u64)in.size * npw) {
+        launch_drop_last(in.data, out.data, c.logn, L, batch * in.size, s);
+    } else {
+        for (u64 b = 0; b < batch; b++) launch_drop_last(in.data + b * in.bstride, out.data + b * out.bstride, c.logn, L, in.size, s);
+    }
+    out.size = in.size; out.limbs = nl; out.ntt = in.ntt; out.scale = in.scale; out.cf = in.cf;
+}
+
+void Evaluator::rescale_to_next(const CtBatch &in, CtBatch &out, u64 batch, hipStream_t s) { // evaluator_cuda.cu:1380-1404
+    if (c.scheme != SCHEME_CKKS) throw Error(ST_INVALID_ARGUMENT, "unsupported operation for scheme type");
+    mod_switch_scale(in, out, batch, s);
+}
+
+// applyGaloisInplace (evaluator_cuda.cu:2024-2117)
+void Evaluator::apply_galois(CtBatch &ct, uint32_t elt, const KsKey &key, u64 batch, hipStream_t s) {
+    check_ct(ct);
+    if (!key.data) throw Error(ST_INVALID_ARGUMENT, "Galois key not present");
+    if (!(elt & 1) || elt >= 2 * c.N) throw Error(ST_INVALID_ARGUMENT, "Galois element is not valid");
+    if (ct.size > 2) throw Error(ST_INVALID_ARGUMENT, "encrypted size must be 2");
+    const u64 pw = poly_words(c, ct.limbs);
+    const int L = ct.limbs;
+    // sigma(c0), sigma(c1) into dense temporaries; they must outlive switch_key's own scratch, so they are
+    // carved from the arena tail after reserving the key-switch working set
+    c.arena.reset();
+    const size_t ks = scratch_switch_key(L, batch);
+    c.arena.reserve(ks + 2 * batch * pw + 128);
+    (void)c.arena.take(ks);
+    u64 *t0 = c.arena.take(batch * pw), *t1 = c.arena.take(batch * pw);
+    LimbMap map = c.ct_map(L);
+    const bool ntt_form = c.scheme == SCHEME_CKKS;
+    for (u64 b = 0; b < batch; b++) {
+        launch_galois(ntt_form, ct.data + b * ct.bstride, t0 + b * pw, c.d_desc, map, c.logn, elt, L, s);
+        launch_galois(ntt_form, ct.data + b * ct.bstride + pw, t1 + b * pw, c.d_desc, map, c.logn, elt, L, s);
+    }
+    launch_copy_strided(t0, pw, ct.data, ct.bstride, pw, batch, s);
+    launch_zero_strided(ct.data + pw, ct.bstride, pw, batch, s);
+    // switch_key resets the arena but never grows it now, so t1 (beyond its working set) stays intact
+    switch_key(ct, t1, pw, key, batch, s);
+}
+
+void Evaluator::transform_to_ntt(CtBatch &ct, u64 batch, hipStream_t s) { // evaluator_cuda.cu:1950-1985
+    check_ct(ct);
+    if (ct.ntt) throw Error(ST_INVALID_ARGUMENT, "encrypted is already in NTT form");
+    const u64 words = (u64)ct.size * poly_words(c, ct.limbs);
+    if (ct.bstride == words) launch_ntt(ct.data, c.d_desc, c.ct_map(ct.limbs), batch * ct.size * ct.limbs, c.logn, false, s);
+    else for (u64 b = 0; b < batch; b++) launch_ntt(ct.data + b * ct.bstride, c.d_desc, c.ct_map(ct.limbs), (u64)ct.size * ct.limbs, c.logn, false, s);
+    ct.ntt = true;
+}
+void Evaluator::transform_from_ntt(CtBatch &ct, u64 batch, hipStream_t s) { // evaluator_cuda.cu:1987-2021
+    check_ct(ct);
+    if (!ct.ntt) throw Error(ST_INVALID_ARGUMENT, "encrypted_ntt is not in NTT form");
+    const u64 words = (u64)ct.size * poly_words(c, ct.limbs);
+    if (ct.bstride == words) launch_ntt(ct.data, c.d_desc, c.ct_map(ct.limbs), batch * ct.size * ct.limbs, c.logn, true, s);
+    else for (u64 b = 0; b < batch; b++) launch_ntt(ct.data + b * ct.bstride, c.d_desc, c.ct_map(ct.limbs), (u64)ct.size * ct.limbs, c.logn, true, s);
+    ct.ntt = false;
+}
+// multiplyPlainNtt (evaluator_cuda.cu:1824-1863): one plaintext [limbs][N] (NTT form) for the whole batch
+void Evaluator::multiply_plain_ntt(CtBatch &ct, const u64 *plain, double plain_scale, u64 batch, hipStream_t s) {
+    check_ct(ct);
+    if (!ct.ntt) throw Error(ST_INVALID_ARGUMENT, "encrypted_ntt is not in NTT form");
+    if (!plain) throw Error(ST_INVALID_ARGUMENT, "plain_ntt is not valid for encryption parameters");
+    double new_scale = ct.scale * plain_scale;
+    if (c.scheme == SCHEME_CKKS && !scale_ok(new_scale, ct.limbs)) throw Error(ST_INVALID_ARGUMENT, "scale out of bounds");
+    const u64 words = (u64)ct.size * poly_words(c, ct.limbs);
+    LimbMap map = c.ct_map(ct.limbs);
+    if (ct.bstride == words) launch_mul_plain(ct.data, plain, c.d_desc, map, c.logn, ct.limbs, batch * ct.size * ct.limbs, s);
+    else for (u64 b = 0; b < batch; b++) launch_mul_plain(ct.data + b * ct.bstride, plain, c.d_desc, map, c.logn, ct.limbs, (u64)ct.size * ct.limbs, s);
+    ct.scale = new_scale;
+}
+
+} // namespace troyhip

@@ -1,0 +1,58 @@
+// evaluator.h -- batched homomorphic operations on raw device buffers: the MI355X counterpart of
+// EvaluatorCuda (src/evaluator_cuda.cu).  Every op works on a batch of B independent ciphertexts that
+// share one shape (size, level, form); B = 1 is the reference's per-ciphertext call.  All launches go
+// to the caller's stream; nothing here synchronises.
+#pragma once
+#include "context.h"
+
+namespace troyhip {
+
+// A batch of ciphertexts: item b, polynomial i, limb l, coefficient n lives at
+//   data[b * bstride + (i * limbs + l) * N + n]        (the reference's [size][limb][N] layout,
+// src/ciphertext_cuda.cuh:62-67, with an explicit batch stride)
+struct CtBatch {
+    u64 *data = nullptr;
+    u64 bstride = 0;
+    int size = 0, limbs = 0;
+    bool ntt = false;
+    double scale = 1.0;
+    u64 cf = 1; // BGV correction factor
+};
+
+// Key-switching key in HBM: [K-1 decomposition limbs][2 components][K limbs][N], NTT form
+// (the reference keeps one allocation per decomposition limb, src/kswitchkeys_cuda.cuh:43-56)
+struct KsKey {
+    const u64 *data = nullptr;
+};
+
+class Evaluator {
+public:
+    explicit Evaluator(Context &ctx) : c(ctx) {}
+    Context &c;
+
+    void add_sub(CtBatch &a, const CtBatch &b, u64 batch, bool sub, hipStream_t s);
+    void negate(CtBatch &a, u64 batch, hipStream_t s);
+    // out may alias a or b; out.size/limbs/... are set; out.data/out.bstride are the caller's
+    void multiply(const CtBatch &a, const CtBatch &b, CtBatch &out, u64 batch, hipStream_t s);
+    void switch_key(CtBatch &ct, const u64 *target, u64 t_bstride, const KsKey &key, u64 batch, hipStream_t s);
+    void relinearize(CtBatch &ct, const KsKey &key, u64 batch, hipStream_t s);
+    void mod_switch_to_next(const CtBatch &in, CtBatch &out, u64 batch, hipStream_t s);
+    void rescale_to_next(const CtBatch &in, CtBatch &out, u64 batch, hipStream_t s);
+    void apply_galois(CtBatch &ct, uint32_t elt, const KsKey &key, u64 batch, hipStream_t s);
+    void transform_to_ntt(CtBatch &ct, u64 batch, hipStream_t s);
+    void transform_from_ntt(CtBatch &ct, u64 batch, hipStream_t s);
+    void multiply_plain_ntt(CtBatch &ct, const u64 *plain, double plain_scale, u64 batch, hipStream_t s);
+
+    // scratch words needed by the ops (so callers can pre-reserve outside timed regions)
+    size_t scratch_multiply(int sa, int sb, int limbs, u64 batch) const;
+    size_t scratch_switch_key(int limbs, u64 batch) const;
+
+private:
+    void check_ct(const CtBatch &a) const;
+    bool scale_ok(double scale, int limbs) const;
+    void mod_switch_scale(const CtBatch &in, CtBatch &out, u64 batch, hipStream_t s);
+    void balance_correction(u64 f1, u64 f2, u64 &f, u64 &e1, u64 &e2) const;
+    void scalar_mul(CtBatch &a, u64 scalar, u64 batch, hipStream_t s);
+};
+
+} // namespace troyhip

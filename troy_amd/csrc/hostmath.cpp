@@ -1,0 +1,238 @@
+// hostmath.cpp -- see hostmath.h.  Plain 128-bit integer arithmetic on the host; none of this is on
+// the hot path (it runs once per context).
+#include "hostmath.h"
+#include <algorithm>
+#include <cstdlib>
+#include <map>
+
+namespace troyhip {
+namespace host {
+
+u64 mul_mod(u64 a, u64 b, u64 p) { return (u64)(((u128)a * b) % p); }
+
+u64 pow_mod(u64 a, u64 e, u64 p) {
+    u64 r = 1 % p;
+    a %= p;
+    for (; e; e >>= 1) {
+        if (e & 1) r = mul_mod(r, a, p);
+        a = mul_mod(a, a, p);
+    }
+    return r;
+}
+
+bool inv_mod(u64 a, u64 p, u64 &out) {
+    a %= p;
+    if (!a) return false;
+    __int128 old_r = p, r = a, old_s = 0, s = 1;
+    while (r) {
+        __int128 q = old_r / r, tmp = old_r - q * r;
+        old_r = r; r = tmp;
+        tmp = old_s - q * s; old_s = s; s = tmp;
+    }
+    if (old_r != 1) return false;
+    out = (u64)(old_s < 0 ? old_s + p : old_s);
+    return true;
+}
+u64 inv_mod_checked(u64 a, u64 p) {
+    u64 r;
+    if (!inv_mod(a, p, r)) throw Error(ST_LOGIC_ERROR, "invalid rns bases");
+    return r;
+}
+
+// Deterministic Miller-Rabin for 64-bit inputs (the reference uses base 2 + random bases,
+// numth.cpp:162-247; both accept exactly the primes).
+bool is_prime(u64 v) {
+    static const u64 small[] = {2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37};
+    if (v < 2) return false;
+    for (u64 s : small) {
+        if (v == s) return true;
+        if (v % s == 0) return false;
+    }
+    u64 d = v - 1;
+    int r = 0;
+    while (!(d & 1)) { d >>= 1; r++; }
+    for (u64 a : small) {
+        u64 x = pow_mod(a, d, v);
+        if (x == 1 || x == v - 1) continue;
+        bool composite = true;
+        for (int i = 1; i < r && composite; i++) {
+            x = mul_mod(x, x, v);
+            if (x == v - 1) composite = false;
+        }
+        if (composite) return false;
+    }
+    return true;
+}
+
+std::vector<u64> get_primes(u64 factor, int bits, size_t count) { // numth.cpp:261-285
+    std::vector<u64> out;
+    u64 v = ((u64(1) << bits) - 1) / factor * factor + 1, lower = u64(1) << (bits - 1);
+    for (; count && v > lower; v -= factor)
+        if (is_prime(v)) { out.push_back(v); count--; }
+    if (count) throw Error(ST_LOGIC_ERROR, "failed to find enough qualifying primes");
+    return out;
+}
+
+std::vector<u64> coeff_modulus_create(u64 N, const std::vector<int> &bits) { // modulus.cpp:80-121
+    if (N < 2 || N > 131072 || (N & (N - 1))) throw Error(ST_INVALID_ARGUMENT, "poly_modulus_degree is invalid");
+    std::map<int, size_t> need;
+    for (int b : bits) {
+        if (b < 2 || b > 60) throw Error(ST_INVALID_ARGUMENT, "bit_sizes is invalid");
+        need[b]++;
+    }
+    std::map<int, std::vector<u64>> pool;
+    for (auto &kv : need) pool[kv.first] = get_primes(2 * N, kv.first, kv.second);
+    std::vector<u64> out;
+    for (int b : bits) { out.push_back(pool[b].back()); pool[b].pop_back(); }
+    return out;
+}
+
+// Minimum over all primitive degree-th roots of unity mod p (numth.cpp:335-363).
+bool minimal_primitive_root(u64 degree, u64 p, u64 &out) {
+    if ((p - 1) % degree) return false;
+    u64 cofactor = (p - 1) / degree, g = 0;
+    for (u64 base = 2; base < 4096 && !g; base++) {
+        u64 c = pow_mod(base, cofactor, p);
+        if (pow_mod(c, degree / 2, p) == p - 1) g = c;
+    }
+    if (!g) return false;
+    u64 g2 = mul_mod(g, g, p), cur = g, best = g;
+    for (u64 i = 0; i < degree / 2; i++) { // odd powers g, g^3, ...
+        best = std::min(best, cur);
+        cur = mul_mod(cur, g2, p);
+    }
+    out = best;
+    return true;
+}
+
+uint32_t reverse_bits(uint32_t x, int bits) {
+    uint32_t r = 0;
+    for (int i = 0; i < bits; i++) r |= ((x >> i) & 1u) << (bits - 1 - i);
+    return r;
+}
+
+int bit_length_of_product(const std::vector<u64> &v) {
+    std::vector<u64> acc{1};
+    for (u64 m : v) {
+        u64 carry = 0;
+        for (auto &w : acc) {
+            u128 t = (u128)w * m + carry;
+            w = (u64)t;
+            carry = (u64)(t >> 64);
+        }
+        if (carry) acc.push_back(carry);
+    }
+    return (int)(64 * (acc.size() - 1) + (64 - __builtin_clzll(acc.back())));
+}
+
+u64 product_mod(const std::vector<u64> &v, u64 p) {
+    u64 r = 1 % p;
+    for (u64 x : v) r = mul_mod(r, x % p, p);
+    return r;
+}
+
+uint32_t galois_elt_from_step(u64 N, int step) { // galois.cpp:44-86
+    uint32_t n = (uint32_t)N, m = 2 * n;
+    if (step == 0) return m - 1;
+    uint32_t pos = (uint32_t)std::abs(step);
+    if (pos >= (n >> 1)) throw Error(ST_INVALID_ARGUMENT, "step count too large");
+    uint32_t e = step < 0 ? (n >> 1) - pos : pos;
+    u64 g = 1;
+    while (e--) g = (g * 3) & (m - 1);
+    return (uint32_t)g;
+}
+
+std::vector<int> naf(int value) { // numth.h:16-36
+    std::vector<int> res;
+    bool neg = value < 0;
+    value = std::abs(value);
+    for (int i = 0; value; i++) {
+        int zi = (value & 1) ? 2 - (value & 3) : 0;
+        value = (value - zi) >> 1;
+        if (zi) res.push_back((neg ? -zi : zi) * (1 << i));
+    }
+    return res;
+}
+
+void NttTable::build(int logn_, u64 p_) {
+    logn = logn_;
+    p = p_;
+    size_t n = size_t(1) << logn;
+    if (!minimal_primitive_root(2 * n, p, psi)) throw Error(ST_INVALID_ARGUMENT, "invalid modulus");
+    u64 ipsi = inv_mod_checked(psi, p);
+    root.assign(n, Shoup{0, 0});
+    iroot.assign(n, Shoup{0, 0});
+    root[0] = make_shoup(1, p);
+    iroot[0] = make_shoup(1, p);
+    u64 f = psi, b = ipsi;
+    for (size_t i = 1; i < n; i++) {
+        root[reverse_bits((uint32_t)i, logn)] = make_shoup(f, p);
+        iroot[reverse_bits((uint32_t)(i - 1), logn) + 1] = make_shoup(b, p);
+        f = mul_mod(f, psi, p);
+        b = mul_mod(b, ipsi, p);
+    }
+    u64 ninv = inv_mod_checked(n % p, p);
+    inv_n = make_shoup(ninv, p);
+    iroot_last_scaled = make_shoup(mul_mod(iroot[n - 1].op, ninv, p), p);
+}
+
+void BaseConv::build(const std::vector<u64> &in_, const std::vector<u64> &out_) {
+    in = in_;
+    out = out_;
+    size_t ni = in.size(), no = out.size();
+    inv_punct.resize(ni);
+    mat.assign(no, std::vector<u64>(ni));
+    for (size_t i = 0; i < ni; i++) {
+        std::vector<u64> others;
+        for (size_t k = 0; k < ni; k++) if (k != i) others.push_back(in[k]);
+        inv_punct[i] = inv_mod_checked(product_mod(others, in[i]), in[i]);
+        for (size_t o = 0; o < no; o++) mat[o][i] = product_mod(others, out[o]);
+    }
+}
+
+void RnsLevel::build(u64 N, const std::vector<u64> &q_, u64 t_) {
+    q = q_;
+    t = t_;
+    size_t nq = q.size();
+    int t_bits = t ? 64 - __builtin_clzll(t) : 0;
+    size_t nB = nq;
+    if (32 + t_bits + bit_length_of_product(q) >= 61 * (int)nq + 61) nB++; // rns.cpp:610-615
+    auto aux = get_primes(2 * N, 61, nB + 2);                              // rns.cpp:629-635
+    m_sk = aux[0];
+    gamma = aux[1];
+    B.assign(aux.begin() + 2, aux.begin() + 2 + nB);
+    Bsk = B;
+    Bsk.push_back(m_sk);
+    q_to_Bsk.build(q, Bsk);
+    q_to_mtilde.build(q, {m_tilde});
+    B_to_q.build(B, q);
+    B_to_msk.build(B, {m_sk});
+    prod_B_mod_q.resize(nq);
+    for (size_t i = 0; i < nq; i++) prod_B_mod_q[i] = product_mod(B, q[i]);
+    size_t nb = Bsk.size();
+    prod_q_mod_Bsk.resize(nb);
+    inv_prod_q_mod_Bsk.resize(nb);
+    inv_mtilde_mod_Bsk.resize(nb);
+    for (size_t i = 0; i < nb; i++) {
+        prod_q_mod_Bsk[i] = product_mod(q, Bsk[i]);
+        inv_prod_q_mod_Bsk[i] = inv_mod_checked(prod_q_mod_Bsk[i], Bsk[i]);
+        inv_mtilde_mod_Bsk[i] = inv_mod_checked(m_tilde % Bsk[i], Bsk[i]);
+    }
+    inv_prod_B_mod_msk = inv_mod_checked(product_mod(B, m_sk), m_sk);
+    neg_inv_prod_q_mod_mtilde = (m_tilde - inv_mod_checked(product_mod(q, m_tilde), m_tilde)) % m_tilde;
+    inv_q_last_mod_q.resize(nq - 1);
+    for (size_t i = 0; i + 1 < nq; i++) inv_q_last_mod_q[i] = inv_mod_checked(q[nq - 1] % q[i], q[i]);
+    if (t) {
+        inv_q_last_mod_t = inv_mod_checked(q[nq - 1] % t, t);
+        q_last_mod_t = q[nq - 1] % t;
+        q_to_tgamma.build(q, {t, gamma});
+        inv_gamma_mod_t = inv_mod_checked(gamma % t, t);
+        prod_tgamma_mod_q.resize(nq);
+        for (size_t i = 0; i < nq; i++) prod_tgamma_mod_q[i] = mul_mod(t % q[i], gamma % q[i], q[i]);
+        neg_inv_q_mod_t = (t - inv_mod_checked(product_mod(q, t), t)) % t;
+        neg_inv_q_mod_gamma = (gamma - inv_mod_checked(product_mod(q, gamma), gamma)) % gamma;
+    }
+}
+
+} // namespace host
+} // namespace troyhip

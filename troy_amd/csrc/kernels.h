@@ -1,0 +1,79 @@
+// kernels.h -- launch interface of the gfx950 kernels (ntt.hip, poly.hip, behz.hip).
+#pragma once
+#include "device_types.h"
+
+namespace troyhip {
+
+// ---- ntt.hip ----
+void launch_ntt(u64 *data, const PrimeDesc *primes, const LimbMap &map, size_t rows, int logn, bool inverse, hipStream_t stream);
+
+// ---- poly.hip ----
+void launch_ew(int op, const u64 *a, const u64 *b, u64 *out, const PrimeDesc *primes, const LimbMap &map, int logn, u64 rows, hipStream_t s);
+void launch_mul_scalar(u64 *x, const PrimeDesc *primes, const LimbMap &map, const u64 *scalars, int logn, u64 rows, hipStream_t s);
+void launch_mul_plain(u64 *a, const u64 *plain, const PrimeDesc *primes, const LimbMap &map, int logn, u64 limbs, u64 rows, hipStream_t s);
+void launch_tensor(int s1, int s2, const u64 *a, const u64 *b, u64 *out, u64 a_bstride, u64 b_bstride, const PrimeDesc *primes, const LimbMap &map,
+                   int logn, u64 limbs, u64 batch, hipStream_t s);
+void launch_galois(bool ntt_form, const u64 *in, u64 *out, const PrimeDesc *primes, const LimbMap &map, int logn, uint32_t elt, u64 rows, hipStream_t s);
+
+struct ModSwitchArgs {
+    const PrimeDesc *primes;
+    LimbMap map;         // prime ids of the level's limbs (period = limbs)
+    Shoup inv_qlast[64]; // q_last^-1 mod q_l
+    u64 half, t_p, t_cr0, t_cr1, inv_qlast_mod_t;
+    int logn;
+    u64 limbs;           // limbs of the INPUT level
+    u64 polys;           // batch * size
+};
+void launch_modswitch(int kind, const u64 *in, u64 *out, const ModSwitchArgs &a, hipStream_t s);
+void launch_rescale_stepA(const u64 *last, u64 last_pstride, u64 *corr, const ModSwitchArgs &a, hipStream_t s);
+void launch_rescale_stepB(const u64 *in, const u64 *corr, u64 *out, const ModSwitchArgs &a, hipStream_t s);
+void launch_drop_last(const u64 *in, u64 *out, int logn, u64 limbs, u64 polys, hipStream_t s);
+void launch_gather_limb(const u64 *in, u64 *out, int logn, u64 pstride, u64 limb, u64 polys, hipStream_t s);
+
+struct KsArgs {
+    const PrimeDesc *primes;
+    uint8_t key_id[65];   // prime id of output index i (i < dl: i ; i == dl: special prime)
+    uint8_t key_limb[65]; // limb index inside the key of output index i
+    Shoup inv_qk[64];     // q_special^-1 mod q_j
+    u64 half;             // floor(q_special / 2)
+    u64 t_p, t_cr0, t_cr1, inv_qk_mod_t;
+    int logn;
+    u64 dl;               // decomposition limbs = ciphertext limbs
+    u64 K;                // key-level limbs
+    u64 batch;
+};
+void launch_ks_expand(const u64 *target, u64 t_bstride, u64 *D, const KsArgs &a, hipStream_t s);
+void launch_ks_mac(const u64 *D, const u64 *key, const u64 *ckks_target, u64 t_bstride, u64 *acc, const KsArgs &a, hipStream_t s);
+void launch_ks_moddown(int kind, const u64 *acc, u64 *ct, u64 ct_bstride, const KsArgs &a, hipStream_t s);
+void launch_ks_ckks_corr(const u64 *last, u64 *corr, const KsArgs &a, hipStream_t s);
+void launch_ks_ckks_combine(const u64 *acc, const u64 *corr, u64 *ct, u64 ct_bstride, const KsArgs &a, hipStream_t s);
+void launch_copy_strided(const u64 *src, u64 src_bstride, u64 *dst, u64 dst_bstride, u64 count, u64 batch, hipStream_t s);
+void launch_zero_strided(u64 *dst, u64 dst_bstride, u64 count, u64 batch, hipStream_t s);
+void launch_fill_uniform(u64 *out, const PrimeDesc *primes, const LimbMap &map, int logn, u64 seed, u64 row0, u64 rows, hipStream_t s);
+
+// ---- behz.hip ----
+// device-resident constants of one level (built by Context, see context.cpp)
+struct BehzDev {
+    int L, nB, nBsk;
+    uint8_t q_id[64], bsk_id[66];     // prime ids
+    // --- extension q -> Bsk (+ m_tilde) ---
+    const Shoup *ext_pre;             // [L]   (m_tilde * (q/q_l)^-1) mod q_l
+    const u64 *q2bsk;                 // [nBsk+1][L]  (q/q_l) mod Bsk_o ; last row mod m_tilde = 2^32
+    u64 neg_inv_q_mod_mt;             // -q^-1 mod 2^32
+    const u64 *prod_q_mod_bsk;        // [nBsk]
+    const Shoup *inv_mt_mod_bsk;      // [nBsk]
+    // --- floor + Shenoy-Kumaresan ---
+    const Shoup *floor_pre;           // [L]   (t * (q/q_l)^-1) mod q_l
+    const Shoup *t_mod_bsk;           // [nBsk]
+    const Shoup *inv_q_mod_bsk;       // [nBsk]
+    const Shoup *B_pre;               // [nB]  (B/B_b)^-1 mod B_b
+    const u64 *B2q;                   // [L][nB]   (B/B_b) mod q_l
+    const u64 *B2msk;                 // [nB]      (B/B_b) mod m_sk
+    Shoup inv_B_mod_msk;
+    const u64 *prod_B_mod_q;          // [L]
+};
+void launch_behz_extend(const u64 *in, u64 in_pstride, u64 *out, u64 out_pstride, const PrimeDesc *primes, const BehzDev &c, u64 N, u64 polys, hipStream_t s);
+void launch_behz_floor_sk(const u64 *dq, u64 dq_pstride, const u64 *db, u64 db_pstride, u64 *out, u64 out_pstride, const PrimeDesc *primes, const BehzDev &c, u64 N,
+                          u64 polys, hipStream_t s);
+
+} // namespace troyhip

@@ -1,0 +1,434 @@
+// poly.hip -- streaming polynomial kernels for gfx950: element-wise modular ops, ciphertext tensor,
+// Galois permutations, mod-switch / rescale, and the key-switch MAC / mod-down kernels.
+//
+// Replaces: gAdd/gSub/gNegatePolyCoeffmod, gDyadicProductCoeffmod,
+// gDyadicConvolutionCoeffmod, gMultiplyPolyScalarCoeffmod (src/kernelutils.cu:30-328, 495-535),
+// gApplyGalois / gApplyGaloisNtt (src/utils/galois_cuda.cu:139-196), gDivideAndRoundqLastInplace,
+// gDivideAndRoundqLastNttInplaceStepA/B, gModTAndDivideqLastInplace (src/utils/rns_cuda.cu:271-345,
+// 579-604) and gSwitchKeyInplaceUtilA..G (src/evaluator_cuda.cu:1012-1161).
+//
+// All of these are HBM-bound streams.  Unlike the reference (one thread per coefficient index with the
+// limb/poly loops inside the thread, 128 blocks in flight) every kernel here exposes the full
+// batch x limb x coefficient space to the grid, and consecutive lanes touch consecutive coefficients
+// (8-16 B per lane) so each wave issues full 512 B - 1 KiB transactions.
+#include "kernels.h"
+
+namespace troyhip {
+
+#define EW_THREADS 256
+
+__device__ __forceinline__ const PrimeDesc &prime_of(const PrimeDesc *primes, const LimbMap &m, u64 row) {
+    return primes[m.id[(row / m.inner) % m.period]];
+}
+
+// ---------------------------------------------------------------- element-wise
+// op: 0 add, 1 sub, 2 negate(a), 3 dyadic product a*b (Barrett-128)
+template <int OP> __global__ __launch_bounds__(EW_THREADS) void ew_kernel(const u64 *a, const u64 *b, u64 *out, const PrimeDesc *primes, LimbMap map, int logn, u64 total) {
+    u64 i = ((u64)blockIdx.x * EW_THREADS + threadIdx.x) * 2;
+    if (i >= total) return;
+    const PrimeDesc &pd = prime_of(primes, map, i >> logn);
+    const u64 p = pd.p;
+    ulonglong2 x = *reinterpret_cast<const ulonglong2 *>(a + i), y{0, 0}, r;
+    if (OP != 2) y = *reinterpret_cast<const ulonglong2 *>(b + i);
+    if (OP == 0) { r.x = addmod(x.x, y.x, p); r.y = addmod(x.y, y.y, p); }
+    else if (OP == 1) { r.x = submod(x.x, y.x, p); r.y = submod(x.y, y.y, p); }
+    else if (OP == 2) { r.x = negmod(x.x, p); r.y = negmod(x.y, p); }
+    else { const Mod m = mod_of(pd); r.x = mulmod(x.x, y.x, m); r.y = mulmod(x.y, y.y, m); }
+    *reinterpret_cast<ulonglong2 *>(out + i) = r;
+}
+void launch_ew(int op, const u64 *a, const u64 *b, u64 *out, const PrimeDesc *primes, const LimbMap &map, int logn, u64 rows, hipStream_t s) {
+    u64 total = rows << logn;
+    if (!total) return;
+    dim3 grid(ceil_div(total / 2 + (total & 1), EW_THREADS));
+    switch (op) {
+    case 0: TROY_LAUNCH(HIP_KERNEL_NAME(ew_kernel<0>), grid, dim3(EW_THREADS), 0, s, a, b, out, primes, map, logn, total); break;
+    case 1: TROY_LAUNCH(HIP_KERNEL_NAME(ew_kernel<1>), grid, dim3(EW_THREADS), 0, s, a, b, out, primes, map, logn, total); break;
+    case 2: TROY_LAUNCH(HIP_KERNEL_NAME(ew_kernel<2>), grid, dim3(EW_THREADS), 0, s, a, b, out, primes, map, logn, total); break;
+    default: TROY_LAUNCH(HIP_KERNEL_NAME(ew_kernel<3>), grid, dim3(EW_THREADS), 0, s, a, b, out, primes, map, logn, total); break;
+    }
+    launch_check("ew_kernel");
+}
+
+// x[row][n] *= scalar[row % limbs]  (scalars already reduced mod the limb's prime)
+struct ScalarArgs { u64 s[64]; };
+__global__ __launch_bounds__(EW_THREADS) void mul_scalar_kernel(u64 *x, const PrimeDesc *primes, LimbMap map, ScalarArgs sc, int logn, u64 total) {
+    u64 i = ((u64)blockIdx.x * EW_THREADS + threadIdx.x) * 2;
+    if (i >= total) return;
+    u64 row = i >> logn;
+    const PrimeDesc &pd = prime_of(primes, map, row);
+    const Mod m = mod_of(pd);
+    const u64 s = sc.s[(row / map.inner) % map.period];
+    ulonglong2 v = *reinterpret_cast<ulonglong2 *>(x + i);
+    v.x = mulmod(v.x, s, m);
+    v.y = mulmod(v.y, s, m);
+    *reinterpret_cast<ulonglong2 *>(x + i) = v;
+}
+void launch_mul_scalar(u64 *x, const PrimeDesc *primes, const LimbMap &map, const u64 *scalars, int logn, u64 rows, hipStream_t s) {
+    u64 total = rows << logn;
+    if (!total) return;
+    ScalarArgs sc;
+    for (unsigned i = 0; i < 64; i++) sc.s[i] = i < map.period ? scalars[i] : 0;
+    TROY_LAUNCH(mul_scalar_kernel, dim3(ceil_div(total / 2 + (total & 1), EW_THREADS)), dim3(EW_THREADS), 0, s, x, primes, map, sc, logn, total);
+    launch_check("mul_scalar_kernel");
+}
+
+// ct (x) plaintext in NTT form: out[b][i][l][n] = a[b][i][l][n] * plain[l][n]   (multiplyPlainNtt)
+__global__ __launch_bounds__(EW_THREADS) void mul_plain_kernel(u64 *a, const u64 *plain, const PrimeDesc *primes, LimbMap map, int logn, u64 limbs, u64 total) {
+    u64 i = ((u64)blockIdx.x * EW_THREADS + threadIdx.x) * 2;
+    if (i >= total) return;
+    u64 row = i >> logn, l = row % limbs, n = i & ((u64(1) << logn) - 1);
+    const Mod m = mod_of(prime_of(primes, map, row));
+    ulonglong2 v = *reinterpret_cast<ulonglong2 *>(a + i);
+    const ulonglong2 w = *reinterpret_cast<const ulonglong2 *>(plain + (l << logn) + n);
+    v.x = mulmod(v.x, w.x, m);
+    v.y = mulmod(v.y, w.y, m);
+    *reinterpret_cast<ulonglong2 *>(a + i) = v;
+}
+void launch_mul_plain(u64 *a, const u64 *plain, const PrimeDesc *primes, const LimbMap &map, int logn, u64 limbs, u64 rows, hipStream_t s) {
+    u64 total = rows << logn;
+    if (!total) return;
+    TROY_LAUNCH(mul_plain_kernel, dim3(ceil_div(total / 2 + (total & 1), EW_THREADS)), dim3(EW_THREADS), 0, s, a, plain, primes, map, logn, limbs, total);
+    launch_check("mul_plain_kernel");
+}
+
+// ---------------------------------------------------------------- ciphertext tensor (a-3 / A.7)
+// out[b][i][l][n] = sum_{j+k=i} a[b][j][l][n] * b[b][k][l][n] mod p_l.  Inputs may be lazy (< 4p).
+// One thread = one (b, l, n); all S1+S2 operands live in registers; 3..5 outputs.
+template <int S1, int S2> __global__ __launch_bounds__(EW_THREADS) void tensor_kernel(const u64 *a, const u64 *b, u64 *out, u64 a_bstride, u64 b_bstride,
+                                                                                       const PrimeDesc *primes, LimbMap map, int logn, u64 limbs, u64 total) {
+    u64 i = (u64)blockIdx.x * EW_THREADS + threadIdx.x; // over batch * limbs * N
+    if (i >= total) return;
+    const u64 N = u64(1) << logn;
+    u64 n = i & (N - 1), bl = i >> logn, l = bl % limbs, bb = bl / limbs;
+    const Mod m = mod_of(primes[map.id[l]]);
+    u64 x[S1], y[S2];
+#pragma unroll
+    for (int j = 0; j < S1; j++) x[j] = a[bb * a_bstride + (j * limbs + l) * N + n];
+#pragma unroll
+    for (int k = 0; k < S2; k++) y[k] = b[bb * b_bstride + (k * limbs + l) * N + n];
+#pragma unroll
+    for (int d = 0; d < S1 + S2 - 1; d++) {
+        U128 acc{0, 0};
+        u64 r = 0;
+#pragma unroll
+        for (int j = 0; j < S1; j++) {
+            const int k = d - j;
+            if (k >= 0 && k < S2) {
+                // lazy operands (< 2^63 each) can make one product ~2^126: reduce each term
+                r = addmod(r, mulmod(x[j], y[k], m), m.p);
+            }
+        }
+        (void)acc;
+        out[(bb * (S1 + S2 - 1) + d) * limbs * N + l * N + n] = r;
+    }
+}
+void launch_tensor(int s1, int s2, const u64 *a, const u64 *b, u64 *out, u64 a_bstride, u64 b_bstride, const PrimeDesc *primes, const LimbMap &map,
+                   int logn, u64 limbs, u64 batch, hipStream_t s) {
+    u64 total = (batch * limbs) << logn;
+    if (!total) return;
+    dim3 grid(ceil_div(total, EW_THREADS)), blk(EW_THREADS);
+#define TENSOR_CASE(A, B) if (s1 == A && s2 == B) { TROY_LAUNCH(HIP_KERNEL_NAME(tensor_kernel<A, B>), grid, blk, 0, s, a, b, out, a_bstride, b_bstride, primes, map, logn, limbs, total); launch_check("tensor_kernel"); return; }
+    TENSOR_CASE(2, 2) TENSOR_CASE(2, 3) TENSOR_CASE(3, 2) TENSOR_CASE(3, 3) TENSOR_CASE(1, 1) TENSOR_CASE(1, 2) TENSOR_CASE(2, 1) TENSOR_CASE(1, 3) TENSOR_CASE(3, 1)
+#undef TENSOR_CASE
+    throw Error(ST_INVALID_ARGUMENT, "ciphertext sizes above 3 are not supported by multiply");
+}
+
+// ---------------------------------------------------------------- Galois (a-6 / A.11)
+// coefficient form: out[(i*g) mod N] = +-in[i]   (src/utils/galois.cpp:143-162)
+__global__ __launch_bounds__(EW_THREADS) void galois_coeff_kernel(const u64 *in, u64 *out, const PrimeDesc *primes, LimbMap map, int logn, uint32_t elt, u64 total) {
+    u64 i = (u64)blockIdx.x * EW_THREADS + threadIdx.x;
+    if (i >= total) return;
+    const u64 N = u64(1) << logn;
+    u64 row = i >> logn, n = i & (N - 1);
+    const u64 p = prime_of(primes, map, row).p;
+    u64 raw = n * elt;
+    u64 idx = raw & (N - 1);
+    u64 v = in[i];
+    if ((raw >> logn) & 1) v = negmod(v, p);
+    out[(row << logn) + idx] = v;
+}
+// NTT form: out[i] = in[bitrev(((g * bitrev(i + N, logN+1)) >> 1) mod N, logN)]   (galois.cpp:18-35)
+__global__ __launch_bounds__(EW_THREADS) void galois_ntt_kernel(const u64 *in, u64 *out, int logn, uint32_t elt, u64 total) {
+    u64 i = (u64)blockIdx.x * EW_THREADS + threadIdx.x;
+    if (i >= total) return;
+    const u64 N = u64(1) << logn;
+    u64 row = i >> logn, n = i & (N - 1);
+    uint32_t rev = __brev((uint32_t)(n + N)) >> (32 - (logn + 1));
+    u64 raw = (((u64)elt * rev) >> 1) & (N - 1);
+    uint32_t src = logn ? (__brev((uint32_t)raw) >> (32 - logn)) : 0;
+    out[i] = in[(row << logn) + src];
+}
+void launch_galois(bool ntt_form, const u64 *in, u64 *out, const PrimeDesc *primes, const LimbMap &map, int logn, uint32_t elt, u64 rows, hipStream_t s) {
+    u64 total = rows << logn;
+    if (!total) return;
+    dim3 grid(ceil_div(total, EW_THREADS)), blk(EW_THREADS);
+    if (ntt_form) TROY_LAUNCH(galois_ntt_kernel, grid, blk, 0, s, in, out, logn, elt, total);
+    else TROY_LAUNCH(galois_coeff_kernel, grid, blk, 0, s, in, out, primes, map, logn, elt, total);
+    launch_check("galois_kernel");
+}
+
+// ---------------------------------------------------------------- mod-switch / rescale (a-4 / A.10)
+// kind 0: BFV divideAndRoundqLastInplace (rns.cpp:805-830); kind 2: BGV modTAndDivideqLastInplace (rns.cpp:1097-1140).
+// in [polys][limbs][N] -> out [polys][limbs-1][N]
+template <int KIND> __global__ __launch_bounds__(EW_THREADS) void modswitch_kernel(const u64 *in, u64 *out, ModSwitchArgs a) {
+    u64 i = (u64)blockIdx.x * EW_THREADS + threadIdx.x; // over polys * (limbs-1) * N
+    const u64 N = u64(1) << a.logn, nl = a.limbs - 1;
+    if (i >= a.polys * nl * N) return;
+    u64 n = i & (N - 1), pl = i >> a.logn, l = pl % nl, poly = pl / nl;
+    const PrimeDesc &pd = a.primes[a.map.id[l]];
+    const PrimeDesc &pq = a.primes[a.map.id[nl]];
+    const Mod m = mod_of(pd);
+    const u64 x = in[(poly * a.limbs + l) * N + n];
+    const u64 xl = in[(poly * a.limbs + nl) * N + n];
+    u64 r;
+    if (KIND == 0) {
+        u64 tl = addmod(xl, a.half, pq.p);                           // x_last + floor(q_last/2) mod q_last
+        u64 tmp = submod(barrett64(tl, m), barrett64(a.half, m), m.p);
+        r = mul_shoup(submod(x, tmp, m.p), a.inv_qlast[l], m.p);
+    } else {
+        const Mod tm{a.t_p, a.t_cr0, a.t_cr1};
+        u64 negc = negmod(barrett64(xl, tm), tm.p);
+        if (a.inv_qlast_mod_t != 1) negc = mulmod(negc, a.inv_qlast_mod_t, tm);
+        u64 delta = mulmod(barrett64(negc, m), barrett64(pq.p, m), m);
+        u64 v = x + 2 * m.p - barrett64(xl, m) - delta;
+        r = mul_shoup(v, a.inv_qlast[l], m.p);
+    }
+    out[(poly * nl + l) * N + n] = r;
+}
+// CKKS divideAndRoundqLastNttInplace (rns.cpp:832-877), around two NTT launches:
+//  step A: last[poly][n] (coefficient form, canonical) -> corr[poly][l][n] = ((last + half) mod q_last) mod q_l + (q_l - half mod q_l)
+//  (NTT of corr over the L-1 limbs)
+//  step B: out[poly][l][n] = (x[poly][l][n] + q_l - corr) * q_last^-1 mod q_l
+__global__ __launch_bounds__(EW_THREADS) void rescale_stepA_kernel(const u64 *last, u64 last_pstride, u64 *corr, ModSwitchArgs a) {
+    u64 i = (u64)blockIdx.x * EW_THREADS + threadIdx.x;
+    const u64 N = u64(1) << a.logn, nl = a.limbs - 1;
+    if (i >= a.polys * nl * N) return;
+    u64 n = i & (N - 1), pl = i >> a.logn, l = pl % nl, poly = pl / nl;
+    const PrimeDesc &pd = a.primes[a.map.id[l]];
+    const PrimeDesc &pq = a.primes[a.map.id[nl]];
+    const Mod m = mod_of(pd);
+    u64 tl = addmod(last[poly * last_pstride + n], a.half, pq.p);
+    corr[i] = barrett64(tl, m) + (m.p - barrett64(a.half, m));
+}
+__global__ __launch_bounds__(EW_THREADS) void rescale_stepB_kernel(const u64 *in, const u64 *corr, u64 *out, ModSwitchArgs a) {
+    u64 i = (u64)blockIdx.x * EW_THREADS + threadIdx.x;
+    const u64 N = u64(1) << a.logn, nl = a.limbs - 1;
+    if (i >= a.polys * nl * N) return;
+    u64 n = i & (N - 1), pl = i >> a.logn, l = pl % nl, poly = pl / nl;
+    const u64 p = a.primes[a.map.id[l]].p;
+    u64 x = in[(poly * a.limbs + l) * N + n];
+    out[i] = mul_shoup(x + p - corr[i], a.inv_qlast[l], p);
+}
+// drop the last limb: out[poly][l][n] = in[poly][l][n], l < limbs-1  (modSwitchDropToNext)
+__global__ __launch_bounds__(EW_THREADS) void drop_last_kernel(const u64 *in, u64 *out, int logn, u64 limbs, u64 total) {
+    u64 i = (u64)blockIdx.x * EW_THREADS + threadIdx.x;
+    if (i >= total) return;
+    const u64 N = u64(1) << logn, nl = limbs - 1;
+    u64 n = i & (N - 1), pl = i >> logn, l = pl % nl, poly = pl / nl;
+    out[i] = in[(poly * limbs + l) * N + n];
+}
+void launch_modswitch(int kind, const u64 *in, u64 *out, const ModSwitchArgs &a, hipStream_t s) {
+    u64 total = a.polys * (a.limbs - 1) << a.logn;
+    if (!total) return;
+    dim3 grid(ceil_div(total, EW_THREADS)), blk(EW_THREADS);
+    if (kind == 0) TROY_LAUNCH(HIP_KERNEL_NAME(modswitch_kernel<0>), grid, blk, 0, s, in, out, a);
+    else TROY_LAUNCH(HIP_KERNEL_NAME(modswitch_kernel<2>), grid, blk, 0, s, in, out, a);
+    launch_check("modswitch_kernel");
+}
+void launch_rescale_stepA(const u64 *last, u64 last_pstride, u64 *corr, const ModSwitchArgs &a, hipStream_t s) {
+    u64 total = a.polys * (a.limbs - 1) << a.logn;
+    if (!total) return;
+    TROY_LAUNCH(rescale_stepA_kernel, dim3(ceil_div(total, EW_THREADS)), dim3(EW_THREADS), 0, s, last, last_pstride, corr, a);
+    launch_check("rescale_stepA_kernel");
+}
+void launch_rescale_stepB(const u64 *in, const u64 *corr, u64 *out, const ModSwitchArgs &a, hipStream_t s) {
+    u64 total = a.polys * (a.limbs - 1) << a.logn;
+    if (!total) return;
+    TROY_LAUNCH(rescale_stepB_kernel, dim3(ceil_div(total, EW_THREADS)), dim3(EW_THREADS), 0, s, in, corr, out, a);
+    launch_check("rescale_stepB_kernel");
+}
+void launch_drop_last(const u64 *in, u64 *out, int logn, u64 limbs, u64 polys, hipStream_t s) {
+    u64 total = polys * (limbs - 1) << logn;
+    if (!total) return;
+    TROY_LAUNCH(drop_last_kernel, dim3(ceil_div(total, EW_THREADS)), dim3(EW_THREADS), 0, s, in, out, logn, limbs, total);
+    launch_check("drop_last_kernel");
+}
+// gather one limb out of every poly: out[poly][n] = in[poly*pstride + limb*N + n]
+__global__ __launch_bounds__(EW_THREADS) void gather_limb_kernel(const u64 *in, u64 *out, int logn, u64 pstride, u64 limb, u64 total) {
+    u64 i = (u64)blockIdx.x * EW_THREADS + threadIdx.x;
+    if (i >= total) return;
+    u64 n = i & ((u64(1) << logn) - 1), poly = i >> logn;
+    out[i] = in[poly * pstride + (limb << logn) + n];
+}
+void launch_gather_limb(const u64 *in, u64 *out, int logn, u64 pstride, u64 limb, u64 polys, hipStream_t s) {
+    u64 total = polys << logn;
+    if (!total) return;
+    TROY_LAUNCH(gather_limb_kernel, dim3(ceil_div(total, EW_THREADS)), dim3(EW_THREADS), 0, s, in, out, logn, pstride, limb, total);
+    launch_check("gather_limb_kernel");
+}
+
+// ---------------------------------------------------------------- key switching (a-5 / A.9)
+// D[b][i][j][n] = target[b][j][n] mod p_i   for i <= dl, j < dl   (evaluator.cpp:2432-2442; a copy when q_j <= p_i)
+__global__ __launch_bounds__(EW_THREADS) void ks_expand_kernel(const u64 *target, u64 t_bstride, u64 *D, KsArgs a) {
+    u64 idx = (u64)blockIdx.x * EW_THREADS + threadIdx.x; // over batch * dl * N (one input coefficient)
+    const u64 N = u64(1) << a.logn;
+    if (idx >= a.batch * a.dl * N) return;
+    u64 n = idx & (N - 1), bj = idx >> a.logn, j = bj % a.dl, b = bj / a.dl;
+    const u64 x = target[b * t_bstride + j * N + n];
+    for (u64 i = 0; i <= a.dl; i++) {
+        const Mod m = mod_of(a.primes[a.key_id[i]]);
+        D[((b * (a.dl + 1) + i) * a.dl + j) * N + n] = barrett64(x, m);
+    }
+}
+// acc[b][k][i][n] = sum_j opnd(b,i,j)[n] * key[j][k][limb(i)][n] mod p_i ; operands canonical (< 2^61)
+// ckks_target != nullptr: operand (i == j) comes from the NTT-form input itself (evaluator.cpp:2424-2427)
+__global__ __launch_bounds__(EW_THREADS) void ks_mac_kernel(const u64 *D, const u64 *key, const u64 *ckks_target, u64 t_bstride, u64 *acc, KsArgs a) {
+    u64 idx = (u64)blockIdx.x * EW_THREADS + threadIdx.x; // over batch * (dl+1) * N
+    const u64 N = u64(1) << a.logn, rl = a.dl + 1;
+    if (idx >= a.batch * rl * N) return;
+    u64 n = idx & (N - 1), bi = idx >> a.logn, i = bi % rl, b = bi / rl;
+    const Mod m = mod_of(a.primes[a.key_id[i]]);
+    const u64 kl = a.key_limb[i];
+    U128 s0{0, 0}, s1{0, 0};
+    for (u64 j = 0; j < a.dl; j++) {
+        u64 x = (ckks_target && i == j) ? ckks_target[b * t_bstride + j * N + n] : D[((b * rl + i) * a.dl + j) * N + n];
+        const u64 *kp = key + ((j * 2) * a.K + kl) * N + n;
+        mac128(s0, x, kp[0]);
+        mac128(s1, x, kp[a.K * N]);
+        if ((j & 127) == 127) { // 2^61 * 2^61 * 128 < 2^128: fold long sums (the reference folds every 256 terms)
+            s0.lo = barrett128(s0.lo, s0.hi, m); s0.hi = 0;
+            s1.lo = barrett128(s1.lo, s1.hi, m); s1.hi = 0;
+        }
+    }
+    acc[((b * 2 + 0) * rl + i) * N + n] = barrett128(s0.lo, s0.hi, m);
+    acc[((b * 2 + 1) * rl + i) * N + n] = barrett128(s1.lo, s1.hi, m);
+}
+// BFV (kind 0) / BGV (kind 2) mod-down, everything in coefficient form (evaluator.cpp:2528-2648):
+//   ct[b][k][j][n] += (acc_j - [t']_{q_j} + [half]_{q_j}) * qk^-1 mod q_j, t' = (acc_last + half) mod qk       (BFV)
+//   ct[b][k][j][n] += (acc_j - [acc_last]_{q_j} - [k_t]_{q_j} * qk) * qk^-1,  k_t = -acc_last * qk^-1 mod t     (BGV)
+template <int KIND> __global__ __launch_bounds__(EW_THREADS) void ks_moddown_kernel(const u64 *acc, u64 *ct, u64 ct_bstride, KsArgs a) {
+    u64 idx = (u64)blockIdx.x * EW_THREADS + threadIdx.x; // over batch * 2 * dl * N
+    const u64 N = u64(1) << a.logn, rl = a.dl + 1;
+    if (idx >= a.batch * 2 * a.dl * N) return;
+    u64 n = idx & (N - 1), r = idx >> a.logn, j = r % a.dl, bk = r / a.dl, k = bk & 1, b = bk >> 1;
+    const PrimeDesc &pj = a.primes[a.key_id[j]];
+    const PrimeDesc &pk = a.primes[a.key_id[a.dl]];
+    const Mod m = mod_of(pj);
+    const u64 aj = acc[((b * 2 + k) * rl + j) * N + n];
+    const u64 al = acc[((b * 2 + k) * rl + a.dl) * N + n];
+    u64 v;
+    if (KIND == 0) {
+        u64 tl = addmod(al, a.half, pk.p);
+        v = aj + (m.p - barrett64(tl, m)) + barrett64(a.half, m);
+    } else {
+        const Mod tm{a.t_p, a.t_cr0, a.t_cr1};
+        u64 kt = negmod(barrett64(al, tm), tm.p);
+        if (a.inv_qk_mod_t != 1) kt = mulmod(kt, a.inv_qk_mod_t, tm);
+        u64 delta = mulmod(barrett64(kt, m), barrett64(pk.p, m), m);
+        v = aj + 2 * m.p - (delta + barrett64(al, m));
+    }
+    v = mul_shoup(v, a.inv_qk[j], m.p);
+    u64 *c = ct + b * ct_bstride + (k * a.dl + j) * N + n;
+    *c = addmod(*c, v, m.p);
+}
+// CKKS mod-down, NTT form: step F builds the correction polynomial from the coefficient-form special limb
+//   corr[b][k][j][n] = [t']_{q_j} + (q_j - [half]_{q_j}),  t' = (last + half) mod qk
+// (NTT over corr), step G: ct += (acc_j + q_j - corr_j) * qk^-1 mod q_j
+__global__ __launch_bounds__(EW_THREADS) void ks_ckks_corr_kernel(const u64 *last /*[b*2][N]*/, u64 *corr, KsArgs a) {
+    u64 idx = (u64)blockIdx.x * EW_THREADS + threadIdx.x; // batch * 2 * dl * N
+    const u64 N = u64(1) << a.logn;
+    if (idx >= a.batch * 2 * a.dl * N) return;
+    u64 n = idx & (N - 1), r = idx >> a.logn, j = r % a.dl, bk = r / a.dl;
+    const Mod m = mod_of(a.primes[a.key_id[j]]);
+    const u64 qk = a.primes[a.key_id[a.dl]].p;
+    u64 tl = addmod(last[bk * N + n], a.half, qk);
+    corr[idx] = barrett64(tl, m) + (m.p - barrett64(a.half, m));
+}
+__global__ __launch_bounds__(EW_THREADS) void ks_ckks_combine_kernel(const u64 *acc, const u64 *corr, u64 *ct, u64 ct_bstride, KsArgs a) {
+    u64 idx = (u64)blockIdx.x * EW_THREADS + threadIdx.x;
+    const u64 N = u64(1) << a.logn, rl = a.dl + 1;
+    if (idx >= a.batch * 2 * a.dl * N) return;
+    u64 n = idx & (N - 1), r = idx >> a.logn, j = r % a.dl, bk = r / a.dl, k = bk & 1, b = bk >> 1;
+    const u64 p = a.primes[a.key_id[j]].p;
+    const u64 aj = acc[((b * 2 + k) * rl + j) * N + n];
+    u64 v = mul_shoup(aj + p - corr[idx], a.inv_qk[j], p);
+    u64 *c = ct + b * ct_bstride + (k * a.dl + j) * N + n;
+    *c = addmod(*c, v, p);
+}
+
+void launch_ks_expand(const u64 *target, u64 t_bstride, u64 *D, const KsArgs &a, hipStream_t s) {
+    u64 total = a.batch * a.dl << a.logn;
+    TROY_LAUNCH(ks_expand_kernel, dim3(ceil_div(total, EW_THREADS)), dim3(EW_THREADS), 0, s, target, t_bstride, D, a);
+    launch_check("ks_expand_kernel");
+}
+void launch_ks_mac(const u64 *D, const u64 *key, const u64 *ckks_target, u64 t_bstride, u64 *acc, const KsArgs &a, hipStream_t s) {
+    u64 total = a.batch * (a.dl + 1) << a.logn;
+    TROY_LAUNCH(ks_mac_kernel, dim3(ceil_div(total, EW_THREADS)), dim3(EW_THREADS), 0, s, D, key, ckks_target, t_bstride, acc, a);
+    launch_check("ks_mac_kernel");
+}
+void launch_ks_moddown(int kind, const u64 *acc, u64 *ct, u64 ct_bstride, const KsArgs &a, hipStream_t s) {
+    u64 total = a.batch * 2 * a.dl << a.logn;
+    dim3 grid(ceil_div(total, EW_THREADS)), blk(EW_THREADS);
+    if (kind == 0) TROY_LAUNCH(HIP_KERNEL_NAME(ks_moddown_kernel<0>), grid, blk, 0, s, acc, ct, ct_bstride, a);
+    else TROY_LAUNCH(HIP_KERNEL_NAME(ks_moddown_kernel<2>), grid, blk, 0, s, acc, ct, ct_bstride, a);
+    launch_check("ks_moddown_kernel");
+}
+void launch_ks_ckks_corr(const u64 *last, u64 *corr, const KsArgs &a, hipStream_t s) {
+    u64 total = a.batch * 2 * a.dl << a.logn;
+    TROY_LAUNCH(ks_ckks_corr_kernel, dim3(ceil_div(total, EW_THREADS)), dim3(EW_THREADS), 0, s, last, corr, a);
+    launch_check("ks_ckks_corr_kernel");
+}
+void launch_ks_ckks_combine(const u64 *acc, const u64 *corr, u64 *ct, u64 ct_bstride, const KsArgs &a, hipStream_t s) {
+    u64 total = a.batch * 2 * a.dl << a.logn;
+    TROY_LAUNCH(ks_ckks_combine_kernel, dim3(ceil_div(total, EW_THREADS)), dim3(EW_THREADS), 0, s, acc, corr, ct, ct_bstride, a);
+    launch_check("ks_ckks_combine_kernel");
+}
+
+// ---------------------------------------------------------------- strided copy / zero helpers
+// dst[b*dst_bstride + i] = src[b*src_bstride + i], i < count
+__global__ __launch_bounds__(EW_THREADS) void copy_strided_kernel(const u64 *src, u64 src_bstride, u64 *dst, u64 dst_bstride, u64 count, u64 batch) {
+    u64 idx = (u64)blockIdx.x * EW_THREADS + threadIdx.x;
+    if (idx >= batch * count) return;
+    u64 b = idx / count, i = idx % count;
+    dst[b * dst_bstride + i] = src[b * src_bstride + i];
+}
+void launch_copy_strided(const u64 *src, u64 src_bstride, u64 *dst, u64 dst_bstride, u64 count, u64 batch, hipStream_t s) {
+    if (!batch || !count) return;
+    TROY_LAUNCH(copy_strided_kernel, dim3(ceil_div(batch * count, EW_THREADS)), dim3(EW_THREADS), 0, s, src, src_bstride, dst, dst_bstride, count, batch);
+    launch_check("copy_strided_kernel");
+}
+__global__ __launch_bounds__(EW_THREADS) void zero_strided_kernel(u64 *dst, u64 dst_bstride, u64 count, u64 batch) {
+    u64 idx = (u64)blockIdx.x * EW_THREADS + threadIdx.x;
+    if (idx >= batch * count) return;
+    dst[(idx / count) * dst_bstride + idx % count] = 0;
+}
+void launch_zero_strided(u64 *dst, u64 dst_bstride, u64 count, u64 batch, hipStream_t s) {
+    if (!batch || !count) return;
+    TROY_LAUNCH(zero_strided_kernel, dim3(ceil_div(batch * count, EW_THREADS)), dim3(EW_THREADS), 0, s, dst, dst_bstride, count, batch);
+    launch_check("zero_strided_kernel");
+}
+
+// ---------------------------------------------------------------- synthetic data (bench / tests)
+// value(row, n) = splitmix64 stream seeded by (seed ^ row * 0xD1B54A32D192ED03), output n, reduced mod p_row
+__device__ __forceinline__ u64 splitmix64_at(u64 seed, u64 n) {
+    u64 z = seed + (n + 1) * 0x9E3779B97F4A7C15ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+__global__ __launch_bounds__(EW_THREADS) void fill_uniform_kernel(u64 *out, const PrimeDesc *primes, LimbMap map, int logn, u64 seed, u64 row0, u64 total) {
+    u64 i = (u64)blockIdx.x * EW_THREADS + threadIdx.x;
+    if (i >= total) return;
+    u64 row = i >> logn, n = i & ((u64(1) << logn) - 1);
+    const Mod m = mod_of(prime_of(primes, map, row));
+    u64 z = splitmix64_at(seed ^ ((row0 + row) * 0xD1B54A32D192ED03ULL), n);
+    out[i] = barrett64(z, m);
+}
+void launch_fill_uniform(u64 *out, const PrimeDesc *primes, const LimbMap &map, int logn, u64 seed, u64 row0, u64 rows, hipStream_t s) {
+    u64 total = rows << logn;
+    if (!total) return;
+    TROY_LAUNCH(fill_uniform_kernel, dim3(ceil_div(total, EW_THREADS)), dim3(EW_THREADS), 0, s, out, primes, map, logn, seed, row0, total);
+    launch_check("fill_uniform_kernel");
+}
+
+} // namespace troyhip

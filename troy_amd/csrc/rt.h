@@ -1,0 +1,49 @@
+// rt.h -- runtime layer of libtroyhip: HIP on gfx950.
+//
+// The product build (hipcc --offload-arch=gfx950) uses the HIP runtime directly.  A second,
+// TEST-ONLY build (-DTROYHIP_CPU_EMUL, see tests/emul/) compiles the very same kernel sources for
+// the host with a fiber-based SIMT emulator so that kernels can be run under sanitizers and debugged
+// in a container without a GPU.  The emulated library is never loaded by the troy_amd package
+// (troy_amd/capi.py refuses it) -- it is not a fallback path.
+#pragma once
+
+#include <cstddef>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+
+#ifdef TROYHIP_CPU_EMUL
+#include "hip_emul.h"
+#else
+#include <hip/hip_runtime.h>
+#define TROY_LAUNCH(kernel, grid, block, shmem, stream, ...) \
+    kernel<<<grid, block, shmem, stream>>>(__VA_ARGS__)
+#endif
+
+namespace troyhip {
+
+typedef uint64_t u64;
+typedef unsigned __int128 u128;
+
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, const std::string &m) : std::runtime_error(m), code(c) {}
+};
+
+// status codes of the C ABI (include/troyhip.h)
+enum { ST_OK = 0, ST_INVALID_ARGUMENT = 1, ST_LOGIC_ERROR = 2, ST_OUT_OF_RANGE = 3, ST_RUNTIME_ERROR = 4, ST_NOT_INITIALIZED = 5 };
+
+inline void hip_check(hipError_t e, const char *what) {
+    if (e != hipSuccess) throw Error(ST_RUNTIME_ERROR, std::string("HIP error: ") + hipGetErrorString(e) + " in " + what);
+}
+#define HIP_CHECK(x) ::troyhip::hip_check((x), #x)
+
+// checked after every launch (the reference never checks launches: SURVEY.md section 5)
+inline void launch_check(const char *name) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) throw Error(ST_RUNTIME_ERROR, std::string("kernel launch failed: ") + name + ": " + hipGetErrorString(e));
+}
+
+inline unsigned ceil_div(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
+
+} // namespace troyhip
