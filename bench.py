@@ -1,0 +1,229 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE metric: ciphertext x ciphertext multiply + relinearize ops/sec, BFV N=2^15 L=14
+(K=15 primes), on synthetic uniform ciphertexts resident in HBM, plus the NTT kernel's achieved bandwidth against
+the HBM roofline and the CPU path timed beside it.
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" = one pass of the hot path (multiply + relinearize) over one batch of --batch independent ciphertext pairs
+per GPU.  Batches shard embarrassingly over ranks (no data-path collective): every rank owns its own
+--batch pairs (weak scaling), keys and tables are replicated, only the timing is reduced (max over ranks).
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+WORKLOADS = {
+    # name: (scheme, N, prime bit sizes, plain-modulus bits)
+    "bfv_n32768_l14": (1, 32768, [60] + [58] * 13 + [60], 20),   # BASELINE.json metric config (configs[1] shape at headline size)
+    "bfv_n8192_l4": (1, 8192, [40, 36, 36, 36, 40], 20),         # BASELINE.json configs[1]
+}
+
+
+def shard_range(total, rank, world):
+    """contiguous block partition of `total` independent ciphertexts over `world` ranks"""
+    base, rem = divmod(total, world)
+    start = rank * base + min(rank, rem)
+    return start, start + base + (1 if rank < rem else 0)
+
+
+def _dist():
+    import torch.distributed as dist
+    return dist
+
+
+def max_over_ranks(x, backend="nccl"):
+    import torch
+    dist = _dist()
+    dev = "cuda" if backend == "nccl" else "cpu"
+    t = torch.tensor([float(x)], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def sum_over_ranks(x, backend="nccl"):
+    import torch
+    dist = _dist()
+    dev = "cuda" if backend == "nccl" else "cpu"
+    t = torch.tensor([int(x)], dtype=torch.int64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return int(t.item())
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=32, help="ciphertext pairs per GPU per step")
+    ap.add_argument("--workload", default="bfv_n32768_l14", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--ntt-reps", type=int, default=10)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = None
+    if world > 1:
+        import torch
+        dist = _dist()
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        try:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl")  # RCCL over xGMI; only used for the barrier and the timing reduction
+            backend = "nccl"
+        except Exception:
+            dist.init_process_group("gloo")
+            backend = "gloo"
+
+    import numpy as np
+
+    import troy_amd as ta
+    from troy_amd import capi
+
+    lib = capi.load()
+    ta.KernelProvider.initialize(local_rank)
+    scheme, N, bits, tbits = WORKLOADS[args.workload]
+    primes = ta.CoeffModulus.Create(N, bits)
+    t = ta.PlainModulus.Batching(N, tbits)
+    ctx = ta.SEALContext(scheme, N, primes, t)
+    K, L = len(primes), len(primes) - 1
+    B = args.batch
+    nbsk = len(ctx.behz_bases(L)[0])
+
+    # ---- synthetic inputs, generated on the device (fill_uniform_kernel == troy_amd.synth) ----
+    row0 = rank * B * 4 * L  # every rank owns different ciphertexts
+    a = ta.Ciphertext(ctx, B, 2, L)
+    b = ta.Ciphertext(ctx, B, 2, L)
+    out = ta.Ciphertext(ctx, B, 3, L, capacity=3)
+    ctx.fill_uniform(a.buf, B * 2 * L, primes[:L], seed=0x5EED, row0=row0)
+    ctx.fill_uniform(b.buf, B * 2 * L, primes[:L], seed=0x5EED, row0=row0 + B * 2 * L)
+    key = ta.DeviceBuffer((K - 1) * 2 * K * N)
+    ctx.fill_uniform(key, (K - 1) * 2 * K, primes, seed=0xC0FFEE)
+    ctx.reserve_scratch(max(ctx.scratch_words(0, L, B), ctx.scratch_words(1, L, B)))
+    ta.synchronize()
+
+    sa, sb = a.struct(), b.struct()
+
+    def step():
+        so = out.struct()
+        capi.check(lib, lib.troyhip_multiply(ctx.h, C.byref(sa), C.byref(sb), C.byref(so), C.c_uint64(B), None))
+        capi.check(lib, lib.troyhip_relinearize(ctx.h, C.byref(so), C.c_void_p(key.ptr), C.c_uint64(B), None))
+
+    def barrier():
+        ta.synchronize()
+        if world > 1:
+            _dist().barrier()
+        ta.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    ta.synchronize()
+    dt = time.perf_counter() - t0
+    barrier()
+    if world > 1:
+        dt = max_over_ranks(dt, backend)
+        total_ops = sum_over_ranks(B * args.steps, backend)
+    else:
+        total_ops = B * args.steps
+    value = total_ops / dt
+
+    # ---- roofline of the dominant kernel: the batched NTT (both passes of one transform = one "launch" unit) ----
+    # shape = the key-switch NTT of this very workload: rows = B * (L+1) * L limb-polynomials, prime index (r / L) % (L+1)
+    roofline = None
+    if rank == 0:
+        rows = B * (L + 1) * L
+        D = ta.DeviceBuffer(rows * N)
+        out_primes = primes[:L] + [primes[K - 1]]
+        ctx.fill_uniform(D, rows, out_primes, seed=1, inner=L)
+        pr = np.array(out_primes, dtype=np.uint64)
+        timer = C.c_void_p()
+        capi.check(lib, lib.troyhip_timer_create(C.byref(timer)))
+
+        def ntt_once(inv):
+            capi.check(lib, lib.troyhip_ntt(ctx.h, C.c_void_p(D.ptr), C.c_uint64(rows), pr.ctypes.data_as(C.c_void_p), len(pr), L, inv, None))
+        ntt_once(0)
+        ntt_once(1)
+        ta.synchronize()
+        capi.check(lib, lib.troyhip_timer_start(timer, None))
+        for i in range(args.ntt_reps):
+            ntt_once(i & 1)  # forward / inverse alternate so values stay canonical
+        capi.check(lib, lib.troyhip_timer_stop(timer, None))
+        ms = C.c_float()
+        capi.check(lib, lib.troyhip_timer_elapsed_ms(timer, C.byref(ms)))
+        capi.check(lib, lib.troyhip_timer_destroy(timer))
+        per_launch_s = ms.value / 1e3 / args.ntt_reps
+        algo_bytes = 16.0 * N * rows  # 16 B per coefficient per limb-transform
+        achieved = algo_bytes / per_launch_s / 1e9
+        roofline = {"bound": "hbm", "kernel": "ntt_pass_kernel (strided + contiguous pass = 1 transform)", "achieved": round(achieved, 1),
+                    "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                    "algorithmic_bytes_per_launch": algo_bytes, "launch_us": round(per_launch_s * 1e6, 2),
+                    "limb_transforms_per_launch": rows}
+        del D
+
+    # ---- CPU baseline on this box's host cores (rank 0, N=1 only) ----
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            cpu = cpu_baseline(scheme, N, primes, t, L)
+        except Exception as e:  # the baseline is informational; never let it kill the bench line
+            cpu = {"error": str(e)}
+
+    if rank == 0:
+        limb_transforms = 7 * (L + nbsk) + (L + 1) * L + 2 * (L + 1)
+        line = {
+            "metric": "ct x ct multiply+relinearize ops/sec, BFV N=2^15 L=14; achieved HBM GB/s vs peak",
+            "value": round(value, 2), "unit": "ops/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u64", "data": "synthetic",
+            "config": {"workload": args.workload, "scheme": "BFV", "N": N, "K": K, "L": L, "Bsk": nbsk, "batch_per_gpu": B,
+                       "limb_transforms_per_op": limb_transforms, "parallelism": f"batch-shard x{world}"},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        _dist().destroy_process_group()
+
+
+def cpu_baseline(scheme, N, primes, t, L):
+    """The reference's own CPU path (oracle/_ref, kind "reference") when the prebuilt library travelled here, else our
+    CPU port (kind "port").  Bounded sample: a handful of multiply+relinearize ops on the same synthetic inputs."""
+    import numpy as np
+
+    from troy_amd import synth
+    xa = synth.uniform_ct(0x5EED, primes[:L], 2, N)[0]
+    xb = synth.uniform_ct(0x5EEE, primes[:L], 2, N)[0]
+    rk = synth.uniform_kswitch_key(0xC0FFEE, primes, N)
+    from oracle import ref
+    reps = 6 if N >= 32768 else 60
+    if ref.available():
+        R = ref.Ref(scheme, N, primes, t)
+        R.set_kswitch_key(0, rk)
+        secs = R.time_mul_relin(ref.Ct(xa), ref.Ct(xb), reps)
+        return {"value": round(reps / secs, 3), "unit": "ops/s", "cores": 1, "kind": "reference",
+                "sample": f"{reps} multiply+relinearize ops, 1 thread, reference CPU path (src/troy_cpu.h) built -O2 into oracle/_ref"}
+    from oracle import oracle
+    O = oracle.Oracle(scheme, N, primes, t)
+    O.set_kswitch_key(0, rk)
+    secs = O.time_mul_relin(np.ascontiguousarray(xa), np.ascontiguousarray(xb), reps, 1)
+    return {"value": round(reps / secs, 3), "unit": "ops/s", "cores": 1, "kind": "port",
+            "sample": f"{reps} multiply+relinearize ops, 1 thread, scalar CPU port (oracle/troy_oracle.cpp, -O3)"}
+
+
+if __name__ == "__main__":
+    main()

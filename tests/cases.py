@@ -1,0 +1,231 @@
+"""Shared definition of the parity scenarios.
+
+One scenario = one encryption-parameter set + the op sequence of SURVEY.md section 8(a) run on inputs that are
+regenerated from (seed, shape) by troy_amd.synth.  The same scenario runs on three backends:
+  * RefBackend    -- the real reference CPU path (oracle/_ref), only in the build container: generates golden files
+  * OracleBackend -- our CPU restatement (oracle/troy_oracle.cpp)
+  * GpuBackend    -- the product: libtroyhip.so through the C ABI (troy_amd.api)
+and the tests compare their outputs limb-for-limb (bit-exact).
+"""
+import hashlib
+
+import numpy as np
+
+from troy_amd import synth
+
+BFV, CKKS, BGV = 1, 2, 3
+
+# name -> parameters.  Small ones are stored in full in tests/golden/, large ones as SHA-256 of the limbs.
+CONFIGS = {
+    # reference test-suite sized parameters (test/evaluator_cuda.cu uses N=64..128, 30-60 bit primes)
+    "bfv_n64_k3": dict(scheme=BFV, N=64, bits=[40, 40, 40], tbits=10),
+    "bfv_n128_k4": dict(scheme=BFV, N=128, bits=[40, 40, 40, 40], tbits=10),       # BFVRelinearize parameters
+    "bfv_n128_k5_60": dict(scheme=BFV, N=128, bits=[60, 60, 60, 60, 60], tbits=40),  # forces |B| = L+1 (rns.cpp:610-615)
+    "ckks_n128_k6": dict(scheme=CKKS, N=128, bits=[30] * 6, tbits=0),              # CKKSEncryptMultiplyRelinRescaleDecrypt
+    "bgv_n128_k4": dict(scheme=BGV, N=128, bits=[40, 36, 36, 40], tbits=10),
+    # BASELINE.json configs
+    "cfgA_bfv_n4096_k3": dict(scheme=BFV, N=4096, bits=[36, 36, 37], tbits=20),
+    "cfgB_bfv_n8192_k5": dict(scheme=BFV, N=8192, bits=[40, 36, 36, 36, 40], tbits=20),
+    "ckks_n4096_k4": dict(scheme=CKKS, N=4096, bits=[40, 30, 30, 40], tbits=0),
+    "bgv_n4096_k3": dict(scheme=BGV, N=4096, bits=[36, 36, 37], tbits=20),
+    "cfgNS_bfv_n32768_k15": dict(scheme=BFV, N=32768, bits=[60] + [58] * 13 + [60], tbits=20),
+    "cfgC_ckks_n32768_k15": dict(scheme=CKKS, N=32768, bits=[60] + [40] * 13 + [60], tbits=0),
+}
+SMALL = ["bfv_n64_k3", "bfv_n128_k4", "bfv_n128_k5_60", "ckks_n128_k6", "bgv_n128_k4"]
+MEDIUM = ["cfgA_bfv_n4096_k3", "cfgB_bfv_n8192_k5", "ckks_n4096_k4", "bgv_n4096_k3"]
+LARGE = ["cfgNS_bfv_n32768_k15", "cfgC_ckks_n32768_k15"]
+
+KEY_STEPS = (1, -1, 4)  # Galois keys present; rotations by 5 = naf [1, 4] and 3 = naf [-1, 4] exercise the NAF path
+SEED = 0x5EED
+
+
+def sha(arr):
+    return hashlib.sha256(np.ascontiguousarray(arr, dtype=np.uint64).tobytes()).hexdigest()
+
+
+class Meta:
+    def __init__(self, data, is_ntt, scale, cf):
+        self.data, self.is_ntt, self.scale, self.cf = np.asarray(data, dtype=np.uint64), bool(is_ntt), float(scale), int(cf)
+
+
+def scenario(backend, cfg, light=False):
+    """Runs the op list on `backend`; returns {name: Meta}.  `light` skips the per-level sweep (large N)."""
+    scheme, N = cfg["scheme"], cfg["N"]
+    primes = backend.primes
+    K = len(primes)
+    L = K - 1
+    ntt = scheme == CKKS
+    out = {}
+    backend.set_relin_key(synth.uniform_kswitch_key(SEED + 1, primes, N))
+    elts = [backend.elt_from_step(s) for s in KEY_STEPS] + [2 * N - 1]
+    for i, e in enumerate(elts):
+        backend.set_galois_key(e, synth.uniform_kswitch_key(SEED + 10 + i, primes, N))
+
+    levels = [L] if light else list(range(L, backend.last_limbs - 1, -1))
+    for limbs in levels:
+        q = primes[:limbs]
+        tag = f"l{limbs}"
+        xa = synth.uniform_ct(SEED + 100 + limbs, q, 2, N)[0]
+        xb = synth.uniform_ct(SEED + 200 + limbs, q, 2, N)[0]
+        x3 = synth.uniform_ct(SEED + 300 + limbs, q, 3, N)[0]
+        cfb = 3 if scheme == BGV else 1
+        a = lambda: backend.ct(xa, ntt)  # noqa: E731
+        b = lambda: backend.ct(xb, ntt, cf=cfb)  # noqa: E731
+        c3 = lambda: backend.ct(x3, ntt)  # noqa: E731
+        m = backend.multiply(a(), b())
+        out[f"{tag}/multiply"] = backend.export(m)
+        out[f"{tag}/relinearize"] = backend.export(backend.relinearize(m))
+        if light:
+            r = backend.relinearize(backend.multiply(a(), b()))
+            if scheme == CKKS and limbs > backend.last_limbs:
+                r = backend.rescale(r)
+                out[f"{tag}/mul_relin_rescale"] = backend.export(r)
+                out[f"{tag}/mul_relin_rescale_rotate1"] = backend.export(backend.rotate(r, 1))
+            else:
+                out[f"{tag}/rotate1"] = backend.export(backend.rotate(a(), 1))
+            continue
+        out[f"{tag}/add"] = backend.export(backend.add(a(), b()))
+        out[f"{tag}/sub"] = backend.export(backend.sub(a(), b()))
+        out[f"{tag}/negate"] = backend.export(backend.negate(a()))
+        out[f"{tag}/square"] = backend.export(backend.square(a()))
+        out[f"{tag}/add_size3"] = backend.export(backend.add(a(), c3()))
+        out[f"{tag}/sub_size3"] = backend.export(backend.sub(a(), c3()))
+        if limbs > backend.last_limbs:
+            out[f"{tag}/mod_switch"] = backend.export(backend.mod_switch(c3()))
+            if scheme == CKKS:
+                out[f"{tag}/rescale"] = backend.export(backend.rescale(a()))
+        out[f"{tag}/apply_galois"] = backend.export(backend.apply_galois(a(), elts[0]))
+        for s in (1, 5, 3):
+            out[f"{tag}/rotate{s}"] = backend.export(backend.rotate(a(), s))
+        out[f"{tag}/conjugate"] = backend.export(backend.conjugate(a()))
+        if not ntt:
+            out[f"{tag}/to_ntt"] = backend.export(backend.to_ntt(a()))
+        an = backend.ct(xa, True)
+        out[f"{tag}/from_ntt"] = backend.export(backend.from_ntt(an))
+        pl = synth.uniform_rows(SEED + 400 + limbs, q, limbs, N)
+        out[f"{tag}/multiply_plain_ntt"] = backend.export(backend.multiply_plain(backend.ct(xa, True), pl))
+    return out
+
+
+# ------------------------------------------------------------------ backends
+class _EvalBackend:
+    """RefBackend / OracleBackend: both expose the `eval(op, a, b, iarg)` surface of oracle/ref.py."""
+
+    def __init__(self, impl_module, cfg, primes, t):
+        from oracle import ref as R
+        self.R = R
+        cls = impl_module.Ref if hasattr(impl_module, "Ref") else impl_module.Oracle
+        self.impl = cls(cfg["scheme"], cfg["N"], primes, t)
+        self.cfg, self.primes = cfg, primes
+        self.last_limbs = self.impl.chain()[2]
+
+    def ct(self, data, ntt, cf=1):
+        return self.R.Ct(data, ntt, 1.0, cf)
+
+    def export(self, c):
+        return Meta(c.data, c.is_ntt, c.scale, c.correction_factor)
+
+    def set_relin_key(self, k):
+        self.impl.set_kswitch_key(0, k)
+
+    def set_galois_key(self, elt, k):
+        self.impl.set_kswitch_key(elt, k)
+
+    def elt_from_step(self, s):
+        return self.impl.elt_from_step(s)
+
+    def _e(self, op, a, b=None, iarg=0):
+        return self.impl.eval(op, a, b, iarg)
+
+    def add(self, a, b): return self._e(self.R.OP_ADD, a, b)
+    def sub(self, a, b): return self._e(self.R.OP_SUB, a, b)
+    def negate(self, a): return self._e(self.R.OP_NEGATE, a)
+    def multiply(self, a, b): return self._e(self.R.OP_MULTIPLY, a, b)
+    def square(self, a): return self._e(self.R.OP_SQUARE, a)
+    def relinearize(self, a): return self._e(self.R.OP_RELIN, a)
+    def mod_switch(self, a): return self._e(self.R.OP_MODSWITCH_NEXT, a)
+    def rescale(self, a): return self._e(self.R.OP_RESCALE_NEXT, a)
+    def apply_galois(self, a, elt): return self._e(self.R.OP_APPLY_GALOIS, a, iarg=elt)
+    def rotate(self, a, s): return self._e(self.R.OP_ROTATE_VECTOR if self.cfg["scheme"] == CKKS else self.R.OP_ROTATE_ROWS, a, iarg=s)
+    def conjugate(self, a): return self._e(self.R.OP_CONJUGATE if self.cfg["scheme"] == CKKS else self.R.OP_ROTATE_COLUMNS, a)
+    def to_ntt(self, a): return self._e(self.R.OP_TO_NTT, a)
+    def from_ntt(self, a): return self._e(self.R.OP_FROM_NTT, a)
+    def multiply_plain(self, a, pl): return self._e(self.R.OP_MULTIPLY_PLAIN_NTT, a, pl)
+
+
+def ref_backend(cfg):
+    from oracle import ref
+    primes = ref.coeff_modulus_create(cfg["N"], cfg["bits"])
+    t = ref.plain_batching(cfg["N"], cfg["tbits"]) if cfg["scheme"] != CKKS else 0
+    return _EvalBackend(ref, cfg, primes, t)
+
+
+def oracle_backend(cfg):
+    from oracle import oracle
+    primes = oracle.coeff_modulus_create(cfg["N"], cfg["bits"])
+    t = oracle.plain_batching(cfg["N"], cfg["tbits"]) if cfg["scheme"] != CKKS else 0
+    return _EvalBackend(oracle, cfg, primes, t)
+
+
+class GpuBackend:
+    """The product path: every op goes through libtroyhip.so's C ABI (troy_amd.api)."""
+
+    def __init__(self, cfg, batch=1):
+        from troy_amd import api
+        self.api, self.cfg, self.batch = api, cfg, batch
+        self.primes = api.CoeffModulus.Create(cfg["N"], cfg["bits"])
+        self.t = api.PlainModulus.Batching(cfg["N"], cfg["tbits"]) if cfg["scheme"] != CKKS else 0
+        self.ctx = api.SEALContext(cfg["scheme"], cfg["N"], self.primes, self.t)
+        self.ev = api.Evaluator(self.ctx)
+        self.last_limbs = self.ctx.last_limbs
+        self.rlk, self.gk = api.RelinKeys(self.ctx), api.GaloisKeys(self.ctx)
+
+    def ct(self, data, ntt, cf=1):
+        d = np.broadcast_to(np.asarray(data, dtype=np.uint64), (self.batch,) + data.shape)  # same ct in every batch slot
+        return self.api.Ciphertext.from_numpy(self.ctx, d, ntt, 1.0, cf, capacity=3)
+
+    def export(self, c):
+        d = c.cpu()
+        for b in range(1, d.shape[0]):
+            assert np.array_equal(d[b], d[0]), "batch items diverged"
+        return Meta(d[0], c.is_ntt_form, c.scale, c.correction_factor)
+
+    def set_relin_key(self, k): self.rlk.set(0, k)
+    def set_galois_key(self, elt, k): self.gk.set_elt(elt, k)
+    def elt_from_step(self, s): return self.ctx.galois_elt_from_step(s)
+    def add(self, a, b): self.ev.addInplace(a, b); return a
+    def sub(self, a, b): self.ev.subInplace(a, b); return a
+    def negate(self, a): self.ev.negateInplace(a); return a
+    def multiply(self, a, b): return self.ev.multiply(a, b)
+    def square(self, a): return self.ev.square(a)
+    def relinearize(self, a): return self.ev.relinearize(a, self.rlk)
+    def mod_switch(self, a): return self.ev.modSwitchToNext(a)
+    def rescale(self, a): return self.ev.rescaleToNext(a)
+    def apply_galois(self, a, elt): self.ev.applyGaloisInplace(a, elt, self.gk); return a
+
+    def rotate(self, a, s):
+        (self.ev.rotateVectorInplace if self.cfg["scheme"] == CKKS else self.ev.rotateRowsInplace)(a, s, self.gk)
+        return a
+
+    def conjugate(self, a):
+        (self.ev.complexConjugateInplace if self.cfg["scheme"] == CKKS else self.ev.rotateColumnsInplace)(a, self.gk)
+        return a
+
+    def to_ntt(self, a): self.ev.transformToNttInplace(a); return a
+    def from_ntt(self, a): self.ev.transformFromNttInplace(a); return a
+
+    def multiply_plain(self, a, pl):
+        self.ev.multiplyPlainInplace(a, self.api.DeviceBuffer.from_numpy(pl))
+        return a
+
+
+def compare(got, exp, names=None):
+    """bit-exact comparison of two scenario outputs; returns list of mismatching names"""
+    bad = []
+    for k in (names or exp.keys()):
+        g, e = got[k], exp[k]
+        ok = g.data.shape == e.data.shape and np.array_equal(g.data, e.data) and g.is_ntt == e.is_ntt and g.cf == e.cf \
+            and abs(g.scale - e.scale) <= 1e-12 * abs(e.scale)
+        if not ok:
+            bad.append(k)
+    return bad

@@ -1,0 +1,41 @@
+"""Batch sharding over ranks: world_size-2 gloo run of bench.py's partition + max-over-ranks logic on
+CPU.  No data-path collective exists: ranks own disjoint ciphertext ranges and only the timing is reduced."""
+import os
+import subprocess
+import sys
+
+from conftest import ROOT
+
+
+def test_shard_ranges_cover_batch():
+    sys.path.insert(0, ROOT)
+    import bench
+    for total in (1, 7, 8, 1024):
+        for world in (1, 2, 4, 8):
+            spans = [bench.shard_range(total, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            for (a0, a1), (b0, b1) in zip(spans, spans[1:]):
+                assert a1 == b0 and a0 <= a1
+            assert max(e - s for s, e in spans) - min(e - s for s, e in spans) <= 1
+
+
+def test_two_rank_gloo_reduction(tmp_path):
+    script = tmp_path / "w.py"
+    script.write_text(
+        "import sys; sys.path.insert(0, %r)\n"
+        "import bench, torch.distributed as dist, os\n"
+        "dist.init_process_group('gloo')\n"
+        "r = dist.get_rank()\n"
+        "t = bench.max_over_ranks(1.0 + r, backend='gloo')\n"
+        "assert abs(t - 2.0) < 1e-9, t\n"
+        "tot = bench.sum_over_ranks(3 + r, backend='gloo')\n"
+        "assert tot == 7, tot\n"
+        "s, e = bench.shard_range(9, r, 2)\n"
+        "assert (s, e) == ((0, 5) if r == 0 else (5, 9))\n"
+        "dist.barrier(); dist.destroy_process_group()\n"
+        "print('rank', r, 'ok')\n" % ROOT)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29577")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29577", str(script)], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "rank 0 ok" in out.stdout and "rank 1 ok" in out.stdout

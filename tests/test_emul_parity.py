@@ -1,0 +1,63 @@
+"""Development coverage without a GPU: the SAME kernel sources (troy_amd/csrc/*.hip), compiled for the host with the
+fiber SIMT emulator (tests/emul/hip_emul.h), are run against the golden files of the reference.  This exercises the
+host logic (precompute, evaluator orchestration, C ABI) and the kernels' index arithmetic; it is NOT the parity claim --
+that is tests/test_gpu_parity.py on real hardware -- and the emulated library is never used by the product."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import cases
+from conftest import GOLDEN, ROOT
+
+EMUL = os.path.join(ROOT, "tests", "emul", "libtroyhip_emul.so")
+
+
+@pytest.fixture(scope="module")
+def emul_api():
+    subprocess.check_call(["make", "-s", "-j8", "-C", os.path.join(ROOT, "troy_amd", "csrc"), "emul"])
+    from troy_amd import api, capi
+    lib = capi.load(EMUL)
+    old = api.KernelProvider._lib
+    api.KernelProvider.initialize(0, _lib=lib)
+    yield api
+    api.KernelProvider._lib = old
+
+
+@pytest.mark.parametrize("name", cases.SMALL + ["cfgA_bfv_n4096_k3"])
+def test_emulated_kernels_match_reference(name, emul_api, golden_hashes, golden_params):
+    cfg = cases.CONFIGS[name]
+    be = cases.GpuBackend(cfg, batch=2 if cfg["N"] <= 128 else 1)
+    gp = golden_params[name]
+    assert [str(p) for p in be.primes] == gp["primes"] and str(be.t) == gp["plain_modulus"]
+    for limbs, lv in gp["levels"].items():
+        bsk, gamma = be.ctx.behz_bases(int(limbs))
+        assert [str(x) for x in bsk] == lv["bsk"] and str(gamma) == lv["gamma"]
+    for p in be.primes:
+        t, g = be.ctx.ntt_tables(p), gp["tables"][str(p)]
+        for k in ("root_op", "root_quo", "inv_op", "inv_quo"):
+            assert cases.sha(t[k]) == g[k]
+    out = cases.scenario(be, cfg)
+    exp = golden_hashes[name]
+    assert set(out) == set(exp)
+    for k, m in out.items():
+        assert cases.sha(m.data) == exp[k]["sha256"], k
+        assert m.is_ntt == exp[k]["is_ntt"] and m.cf == exp[k]["cf"]
+
+
+@pytest.mark.parametrize("logn", [3, 6, 11, 12, 13, 15, 16, 17])
+def test_emulated_ntt_all_sizes(logn, emul_api, oracle_lib):
+    api = emul_api
+    from troy_amd import synth
+    N = 1 << logn
+    primes = api.CoeffModulus.Create(N, [50, 40])
+    ctx = api.SEALContext(api.CKKS, N, primes, 0)
+    x = synth.uniform_rows(logn, primes, 4, N)
+    buf = api.DeviceBuffer.from_numpy(x)
+    ctx.ntt(buf, 4, primes)
+    y = buf.to_numpy().reshape(4, N)
+    for r in range(4):
+        assert np.array_equal(y[r], oracle_lib.ntt_standalone(N, primes[r % 2], x[r], 1))
+    ctx.ntt(buf, 4, primes, inverse=True)
+    assert np.array_equal(buf.to_numpy().reshape(4, N), x)

@@ -1,0 +1,240 @@
+"""GPU parity tests (run on a real MI355X with `-m gpu`): the product path -- libtroyhip.so through the C ABI --
+against (a) the golden files generated from the real reference, (b) the CPU oracle on fresh seeded inputs, and
+(c) size-independent properties at the BASELINE sizes.  Everything is bit-exact (integer arithmetic)."""
+import os
+
+import numpy as np
+import pytest
+
+import cases
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import troy_amd as ta
+    from troy_amd import capi
+    capi.load()  # the gfx950 library or a loud failure -- never a fallback
+    ta.KernelProvider.initialize(0)
+    return ta
+
+
+def test_native_library_is_loaded(gpu):
+    from troy_amd import capi
+    assert capi.load().troyhip_build_info() == b"gfx950"
+    assert any("libtroyhip.so" in line for line in open("/proc/self/maps"))
+
+
+@pytest.mark.parametrize("name", cases.SMALL + cases.MEDIUM + cases.LARGE)
+def test_context_tables_match_reference(name, gpu, golden_params):
+    cfg, gp = cases.CONFIGS[name], golden_params[name]
+    be = cases.GpuBackend(cfg)
+    assert [str(p) for p in be.primes] == gp["primes"] and str(be.t) == gp["plain_modulus"]
+    assert [be.ctx.key_limbs - be.ctx.last_limbs + 1, be.ctx.first_limbs, be.ctx.last_limbs] == gp["chain"]
+    for limbs, lv in gp["levels"].items():
+        bsk, gamma = be.ctx.behz_bases(int(limbs))
+        assert [str(x) for x in bsk] == lv["bsk"] and str(gamma) == lv["gamma"]
+    for p in be.primes:
+        t, g = be.ctx.ntt_tables(p), gp["tables"][str(p)]
+        assert str(t["root"]) == g["root"] and [str(x) for x in t["inv_degree"]] == g["inv_degree"]
+        for k in ("root_op", "root_quo", "inv_op", "inv_quo"):
+            assert cases.sha(t[k]) == g[k]
+
+
+@pytest.mark.parametrize("name", cases.SMALL + cases.MEDIUM)
+def test_scenario_matches_reference(name, gpu, golden_hashes):
+    cfg = cases.CONFIGS[name]
+    out = cases.scenario(cases.GpuBackend(cfg, batch=3 if cfg["N"] <= 128 else 1), cfg)
+    exp = golden_hashes[name]
+    assert set(out) == set(exp)
+    bad = [k for k, m in out.items() if cases.sha(m.data) != exp[k]["sha256"] or m.is_ntt != exp[k]["is_ntt"] or m.cf != exp[k]["cf"]
+           or abs(m.scale - exp[k]["scale"]) > 1e-12 * abs(exp[k]["scale"])]
+    assert not bad, bad
+
+
+def test_full_limbs_n64(gpu):
+    name = "bfv_n64_k3"
+    full = np.load(os.path.join(GOLDEN, f"golden_full_{name}.npz"))
+    out = cases.scenario(cases.GpuBackend(cases.CONFIGS[name], batch=2), cases.CONFIGS[name])
+    for k in full.files:
+        assert np.array_equal(out[k].data, full[k]), k
+
+
+@pytest.mark.parametrize("name", cases.LARGE)
+def test_headline_configs_match_reference(name, gpu, golden_hashes):
+    """BFV N=2^15 L=14 multiply+relinearize (BASELINE metric) and the CKKS N=2^15 mul->relin->rescale->rotate chain"""
+    cfg = cases.CONFIGS[name]
+    out = cases.scenario(cases.GpuBackend(cfg), cfg, light=True)
+    bad = [k for k, m in out.items() if cases.sha(m.data) != golden_hashes[name][k]["sha256"]]
+    assert not bad, bad
+
+
+@pytest.mark.parametrize("name,batch", [("cfgA_bfv_n4096_k3", 5), ("cfgB_bfv_n8192_k5", 3), ("ckks_n4096_k4", 4), ("bgv_n4096_k3", 4)])
+def test_batched_mul_relin_vs_oracle(name, batch, gpu, oracle_lib):
+    """distinct ciphertexts in every batch slot, fresh seed: product vs CPU oracle"""
+    from oracle import ref
+    from troy_amd import synth
+    cfg = cases.CONFIGS[name]
+    be = cases.GpuBackend(cfg)
+    ob = cases.oracle_backend(cfg)
+    L, N, ntt = len(be.primes) - 1, cfg["N"], cfg["scheme"] == cases.CKKS
+    rk = synth.uniform_kswitch_key(777, be.primes, N)
+    be.set_relin_key(rk)
+    ob.set_relin_key(rk)
+    xa, xb = synth.uniform_ct(778, be.primes[:L], 2, N, batch), synth.uniform_ct(779, be.primes[:L], 2, N, batch)
+    a = gpu.Ciphertext.from_numpy(be.ctx, xa, ntt)
+    b = gpu.Ciphertext.from_numpy(be.ctx, xb, ntt)
+    r = be.ev.multiply(a, b)
+    be.ev.relinearizeInplace(r, be.rlk)
+    got = r.cpu()
+    for i in range(batch):
+        e = ob.relinearize(ob.multiply(ref.Ct(xa[i], ntt), ref.Ct(xb[i], ntt)))
+        assert np.array_equal(got[i], e.data), i
+
+
+@pytest.mark.parametrize("logn", list(range(1, 18)))
+def test_ntt_every_size(logn, gpu, oracle_lib):
+    from troy_amd import synth
+    N = 1 << logn
+    primes = gpu.CoeffModulus.Create(N, [50, 40, 60])
+    ctx = gpu.SEALContext(gpu.CKKS, N, primes, 0)
+    rows = 7  # ragged: not a multiple of the limb period
+    x = synth.uniform_rows(logn, primes, rows, N)
+    buf = gpu.DeviceBuffer.from_numpy(x)
+    ctx.ntt(buf, rows, primes)
+    y = buf.to_numpy().reshape(rows, N)
+    for r in range(rows):
+        assert np.array_equal(y[r], oracle_lib.ntt_standalone(N, primes[r % 3], x[r], 1)), r
+    ctx.ntt(buf, rows, primes, inverse=True)
+    assert np.array_equal(buf.to_numpy().reshape(rows, N), x)
+    # inverse on its own against the oracle
+    buf2 = gpu.DeviceBuffer.from_numpy(x)
+    ctx.ntt(buf2, rows, primes, inverse=True)
+    z = buf2.to_numpy().reshape(rows, N)
+    for r in range(rows):
+        assert np.array_equal(z[r], oracle_lib.ntt_standalone(N, primes[r % 3], x[r], 3)), r
+
+
+def test_ntt_properties_at_full_size(gpu):
+    """BASELINE size N=2^15, 15 primes, hundreds of rows: identities that need no oracle"""
+    from troy_amd import synth
+    cfg = cases.CONFIGS["cfgNS_bfv_n32768_k15"]
+    be = cases.GpuBackend(cfg)
+    N, primes = cfg["N"], be.primes
+    rows = 15 * 8
+    a = gpu.DeviceBuffer(rows * N)
+    b = gpu.DeviceBuffer(rows * N)
+    be.ctx.fill_uniform(a, rows, primes, seed=1)
+    be.ctx.fill_uniform(b, rows, primes, seed=2)
+    xa, xb = a.to_numpy().reshape(rows, N), b.to_numpy().reshape(rows, N)
+    assert np.array_equal(xa, synth.uniform_rows(1, primes, rows, N))  # device generator == documented generator
+    pcol = np.array([primes[r % 15] for r in range(rows)], dtype=np.uint64)[:, None]
+    s = gpu.DeviceBuffer.from_numpy((xa + xb) % pcol)
+    for buf in (a, b, s):
+        be.ctx.ntt(buf, rows, primes)
+    ya, yb, ys = (x.to_numpy().reshape(rows, N) for x in (a, b, s))
+    assert np.array_equal((ya + yb) % pcol, ys)                       # linearity
+    assert (ya < pcol).all()                                           # canonical outputs
+    be.ctx.ntt(a, rows, primes, inverse=True)
+    assert np.array_equal(a.to_numpy().reshape(rows, N), xa)           # round trip
+    d = np.zeros((rows, N), dtype=np.uint64)
+    d[:, 0] = 1
+    delta = gpu.DeviceBuffer.from_numpy(d)
+    be.ctx.ntt(delta, rows, primes)
+    assert (delta.to_numpy() == 1).all()                               # NTT(1) = (1, ..., 1)
+
+
+def test_cfgA_add_on_device(gpu):
+    f = np.load(os.path.join(GOLDEN, "cfgA_bfv_n4096_k3.npz"))
+    cfg = cases.CONFIGS["cfgA_bfv_n4096_k3"]
+    be = cases.GpuBackend(cfg)
+    assert be.primes == [int(x) for x in f["primes"]]
+    a = gpu.Ciphertext.from_numpy(be.ctx, f["ct1"])
+    be.ev.addInplace(a, gpu.Ciphertext.from_numpy(be.ctx, f["ct2"]))
+    assert cases.sha(a.cpu()[0]) == str(f["sum_sha256"])
+
+
+@pytest.mark.parametrize("nm", ["bfv", "bgv", "ckks"])
+def test_realkey_chain(nm, gpu, oracle_lib):
+    """keys made by the reference's KeyGenerator: multiply -> relinearize (-> rescale) -> rotate; bit-exact, and the
+    result decrypts (CPU oracle decryptor) to the expected plaintext"""
+    from oracle import oracle
+    f = np.load(os.path.join(GOLDEN, f"realkey_{nm}.npz"))
+    scheme = dict(bfv=gpu.BFV, bgv=gpu.BGV, ckks=gpu.CKKS)[nm]
+    primes, t = [int(x) for x in f["primes"]], int(f["t"])
+    ctx = gpu.SEALContext(scheme, 128, primes, t)
+    ev = gpu.Evaluator(ctx)
+    rlk, gk = gpu.RelinKeys(ctx), gpu.GaloisKeys(ctx)
+    rlk.set(0, f["relin_key"])
+    gk.set_elt(int(f["galois_elt"]), f["galois_key"])
+    if nm == "ckks":
+        a = gpu.Ciphertext.from_numpy(ctx, f["ct1"], True, float(f["in_scale"]))
+        b = gpu.Ciphertext.from_numpy(ctx, f["ct2"], True, float(f["in_scale"]))
+        r = ev.multiply(a, b)
+        ev.relinearizeInplace(r, rlk)
+        r = ev.rescaleToNext(r)
+        ev.rotateVectorInplace(r, 1, gk)
+        assert np.array_equal(r.cpu()[0], f["result"]) and r.scale == float(f["result_scale"])
+    else:
+        a = gpu.Ciphertext.from_numpy(ctx, f["ct1"], False, 1.0, int(f["ct1_cf"]))
+        b = gpu.Ciphertext.from_numpy(ctx, f["ct2"], False, 1.0, int(f["ct2_cf"]))
+        r = ev.multiply(a, b)
+        ev.relinearizeInplace(r, rlk)
+        ev.rotateRowsInplace(r, 1, gk)
+        assert np.array_equal(r.cpu()[0], f["result"]) and r.correction_factor == int(f["result_cf"])
+        from oracle import ref
+        O = oracle.Oracle(scheme, 128, primes, t)
+        dec = O.decrypt(ref.Ct(r.cpu()[0], False, 1.0, r.correction_factor), f["secret_key"])
+        assert np.array_equal(dec, f["decrypted"])
+
+
+def test_edge_values(gpu, oracle_lib):
+    """all-zero and all-(p-1) ciphertexts through multiply+relinearize"""
+    from oracle import ref
+    from troy_amd import synth
+    cfg = cases.CONFIGS["bfv_n128_k4"]
+    be, ob = cases.GpuBackend(cfg), cases.oracle_backend(cfg)
+    rk = synth.uniform_kswitch_key(5, be.primes, 128)
+    be.set_relin_key(rk)
+    ob.set_relin_key(rk)
+    q = be.primes[:3]
+    zero = np.zeros((2, 3, 128), dtype=np.uint64)
+    top = np.stack([np.stack([np.full(128, p - 1, dtype=np.uint64) for p in q])] * 2)
+    for x, y in ((zero, top), (top, top), (zero, zero)):
+        r = be.ev.multiply(be.ct(x, False), be.ct(y, False))
+        be.ev.relinearizeInplace(r, be.rlk)
+        e = ob.relinearize(ob.multiply(ref.Ct(x), ref.Ct(y)))
+        assert np.array_equal(r.cpu()[0], e.data)
+
+
+def test_error_conventions(gpu):
+    """std::invalid_argument / std::logic_error cases of the reference (evaluator_cuda.cu:285-286, 1174-1188, 2040-2060)"""
+    from troy_amd import capi, synth
+    cfg = cases.CONFIGS["bfv_n128_k4"]
+    be = cases.GpuBackend(cfg)
+    q3, q2 = be.primes[:3], be.primes[:2]
+    a3 = gpu.Ciphertext.from_numpy(be.ctx, synth.uniform_ct(1, q3, 2, 128))
+    a2 = gpu.Ciphertext.from_numpy(be.ctx, synth.uniform_ct(1, q2, 2, 128))
+    with pytest.raises(capi.InvalidArgument):
+        be.ev.addInplace(a3.copy(), a2)                      # level mismatch
+    ntt = gpu.Ciphertext.from_numpy(be.ctx, synth.uniform_ct(1, q3, 2, 128), True)
+    with pytest.raises(capi.InvalidArgument):
+        be.ev.multiply(ntt, ntt)                             # BFV operands cannot be in NTT form
+    with pytest.raises(capi.InvalidArgument):
+        be.ev.addInplace(a3.copy(), ntt)                     # NTT form mismatch
+    m = be.ev.multiply(a3, a3)
+    with pytest.raises(capi.InvalidArgument):
+        be.ev.relinearizeInplace(m, be.rlk)                  # no relinearization keys
+    with pytest.raises(capi.InvalidArgument):
+        be.ev.applyGaloisInplace(a3.copy(), 3, be.gk)        # Galois key not present
+    with pytest.raises(capi.LogicError):
+        be.ev.rotateVectorInplace(a3.copy(), 1, be.gk)       # unsupported scheme
+    a1 = gpu.Ciphertext.from_numpy(be.ctx, synth.uniform_ct(1, be.primes[:1], 2, 128))
+    with pytest.raises(capi.InvalidArgument):
+        be.ev.modSwitchToNext(a1)                            # end of the chain
+    with pytest.raises(capi.InvalidArgument):
+        gpu.SEALContext(gpu.BFV, 128, [be.primes[0], be.primes[0]], be.t)  # duplicate primes
+    with pytest.raises(capi.InvalidArgument):
+        gpu.SEALContext(gpu.BFV, 100, be.primes, be.t)       # N not a power of two
