@@ -162,6 +162,7 @@ template <class T> inline T __shfl_up(T v, unsigned d, int width = 64) { int l =
 inline uint64_t __umul64hi(uint64_t a, uint64_t b) { return (uint64_t)(((unsigned __int128)a * b) >> 64); }
 inline uint32_t __umulhi(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
 inline uint32_t __brev(uint32_t x) { uint32_t r = 0; for (int i = 0; i < 32; i++) r |= ((x >> i) & 1u) << (31 - i); return r; }
+template <class T> inline T __builtin_amdgcn_readfirstlane(T v) { return v; } // only used on wave-uniform values
 template <class T> inline T atomicAdd(T *p, T v) { T o = *p; *p += v; return o; }
 
 #define TROY_LAUNCH(kernel, grid, block, shmem, stream, ...) \

@@ -1,0 +1,184 @@
+// bfly.h -- hand-scheduled Harvey butterflies for gfx950, four at a time.
+//
+// gfx950 has no 64-bit integer multiplier and (measured, profiles/r01_microbench_valu.txt) every carry-propagating or
+// 64-bit VALU op costs ~1.5-1.8x a plain v_add_u32, so the NTT is bound by the NUMBER of VALU instructions per
+// butterfly.  hipcc's lowering of the textbook butterfly (ntt.hip) issues ~31; the formulation below issues ~20:
+//   * wider lazy ranges: forward values live in [0,8p), inverse values in [0,4p) (p < 2^61 so 8p < 2^64).  This
+//     admits a quotient estimate that drops the low x low partial product: q~ = floor(y*w'/2^64) - {0,1}, so the
+//     lazy product w*y - q~*p lies in [0,3p) and costs 3 v_mad_u64_u32 instead of 1 v_mul_hi + 3 v_mad + fix-ups;
+//   * the conditional subtraction uses the borrow of v_sub_co/v_subb directly (no v_cmp_u64);
+//   * w*y - q~*p is evaluated as w*y + q~*(2^64 - p): both products accumulate through v_mad_u64_u32's free 64-bit
+//     addend, which also absorbs the "+ u" of X' = u + v;  Y' = 2u + 3p - X';
+//   * every instruction is pinned with inline asm so LLVM cannot re-associate the limbs back into generic 64-bit
+//     multiplies (it does, and then emits multiplications by zero and ~8 v_mov per butterfly).
+// Every stage of every round has exactly FOUR independent butterflies per thread; the carry-chained pieces are
+// written for four butterflies at once and interleaved, because gfx940-class hardware needs 2 wait states between a
+// VALU instruction that writes a carry/mask SGPR (vcc) and a VALU instruction that reads it, and the compiler's hazard
+// recogniser does not look inside inline asm: interleaving the four chains satisfies the hazard with useful work
+// instead of s_nop.
+// All values stay congruent to the reference's butterflies (src/utils/dwthandler.h:88-372) modulo p; the caller
+// reduces stored results to [0,p), so outputs are bit-identical.
+#pragma once
+#include "modarith.h"
+
+namespace troyhip {
+
+struct PrimeConst { u64 p, two_p, three_p, four_p, negp; }; // negp = 2^64 - p
+__device__ __forceinline__ PrimeConst make_prime_const(u64 p) { return PrimeConst{p, 2 * p, 3 * p, 4 * p, 0 - p}; }
+
+__device__ __forceinline__ u32 lo32(u64 x) { return (u32)x; }
+__device__ __forceinline__ u32 hi32(u64 x) { return (u32)(x >> 32); }
+__device__ __forceinline__ u64 mk64(u32 lo, u32 hi) { return ((u64)hi << 32) | lo; }
+
+#ifdef TROYHIP_CPU_EMUL
+// x[i] = x[i] >= m ? x[i] - m : x[i]
+__device__ __forceinline__ void csub4(u64 (&x)[4], u64 m) { for (int i = 0; i < 4; i++) x[i] = x[i] >= m ? x[i] - m : x[i]; }
+__device__ __forceinline__ void sub4(u64 (&r)[4], const u64 (&a)[4], const u64 (&b)[4]) { for (int i = 0; i < 4; i++) r[i] = a[i] - b[i]; }
+__device__ __forceinline__ u64 mulhi_approx1(u64 y, u64 wq) { // floor(y*wq/2^64) - {0,1}: low x low product dropped
+    const u64 y0 = lo32(y), y1 = hi32(y), q0 = lo32(wq), q1 = hi32(wq);
+    const u128 s = (u128)(y1 * q0) + (u128)(y0 * q1);
+    return y1 * q1 + (u64)(s >> 32);
+}
+__device__ __forceinline__ void mulhi_approx4(u64 (&q)[4], const u64 (&y)[4], const Shoup (&w)[4]) { for (int i = 0; i < 4; i++) q[i] = mulhi_approx1(y[i], w[i].quo); }
+__device__ __forceinline__ u64 mul_acc(u64 acc, u64 y, u64 w, u64 q, u64 negp) { return acc + w * y + q * negp; }
+#else
+// x[i] = x[i] >= m ? x[i] - m : x[i]   (x < 2m).  m is wave-uniform; its high word must sit in a VGPR because
+// vcc + an SGPR would exceed the single constant-bus read a gfx9 VALU instruction may make.
+__device__ __forceinline__ void csub4(u64 (&x)[4], u64 m) {
+    u32 a0, a1, b0, b1, c0, c1, d0, d1;
+    u64 sb, sc, sd;
+    asm("v_subrev_co_u32 %0, vcc, %19, %11\n\t"
+        "v_subrev_co_u32 %2, %8, %19, %13\n\t"
+        "v_subrev_co_u32 %4, %9, %19, %15\n\t"
+        "v_subrev_co_u32 %6, %10, %19, %17\n\t"
+        "v_subbrev_co_u32 %1, vcc, %20, %12, vcc\n\t"
+        "v_subbrev_co_u32 %3, %8, %20, %14, %8\n\t"
+        "v_subbrev_co_u32 %5, %9, %20, %16, %9\n\t"
+        "v_subbrev_co_u32 %7, %10, %20, %18, %10\n\t"
+        "v_cndmask_b32 %0, %0, %11, vcc\n\t"
+        "v_cndmask_b32 %1, %1, %12, vcc\n\t"
+        "v_cndmask_b32 %2, %2, %13, %8\n\t"
+        "v_cndmask_b32 %3, %3, %14, %8\n\t"
+        "v_cndmask_b32 %4, %4, %15, %9\n\t"
+        "v_cndmask_b32 %5, %5, %16, %9\n\t"
+        "v_cndmask_b32 %6, %6, %17, %10\n\t"
+        "v_cndmask_b32 %7, %7, %18, %10"
+        : "=&v"(a0), "=&v"(a1), "=&v"(b0), "=&v"(b1), "=&v"(c0), "=&v"(c1), "=&v"(d0), "=&v"(d1), "=&s"(sb), "=&s"(sc), "=&s"(sd)
+        : "v"(lo32(x[0])), "v"(hi32(x[0])), "v"(lo32(x[1])), "v"(hi32(x[1])), "v"(lo32(x[2])), "v"(hi32(x[2])), "v"(lo32(x[3])), "v"(hi32(x[3])),
+          "s"(lo32(m)), "v"(hi32(m))
+        : "vcc");
+    x[0] = mk64(a0, a1); x[1] = mk64(b0, b1); x[2] = mk64(c0, c1); x[3] = mk64(d0, d1);
+}
+// r[i] = a[i] - b[i]
+__device__ __forceinline__ void sub4(u64 (&r)[4], const u64 (&a)[4], const u64 (&b)[4]) {
+    u32 r0, r1, r2, r3, r4, r5, r6, r7;
+    u64 sb, sc, sd;
+    asm("v_sub_co_u32 %0, vcc, %11, %19\n\t"
+        "v_sub_co_u32 %2, %8, %13, %21\n\t"
+        "v_sub_co_u32 %4, %9, %15, %23\n\t"
+        "v_sub_co_u32 %6, %10, %17, %25\n\t"
+        "v_subb_co_u32 %1, vcc, %12, %20, vcc\n\t"
+        "v_subb_co_u32 %3, %8, %14, %22, %8\n\t"
+        "v_subb_co_u32 %5, %9, %16, %24, %9\n\t"
+        "v_subb_co_u32 %7, %10, %18, %26, %10"
+        : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5), "=&v"(r6), "=&v"(r7), "=&s"(sb), "=&s"(sc), "=&s"(sd)
+        : "v"(lo32(a[0])), "v"(hi32(a[0])), "v"(lo32(a[1])), "v"(hi32(a[1])), "v"(lo32(a[2])), "v"(hi32(a[2])), "v"(lo32(a[3])), "v"(hi32(a[3])),
+          "v"(lo32(b[0])), "v"(hi32(b[0])), "v"(lo32(b[1])), "v"(hi32(b[1])), "v"(lo32(b[2])), "v"(hi32(b[2])), "v"(lo32(b[3])), "v"(hi32(b[3]))
+        : "vcc");
+    r[0] = mk64(r0, r1); r[1] = mk64(r2, r3); r[2] = mk64(r4, r5); r[3] = mk64(r6, r7);
+}
+// q~[i] = y1*q1 + floor((y1*q0 + y0*q1) / 2^32)  =  floor(y*wq/2^64) - {0,1}
+__device__ __forceinline__ void mulhi_approx4(u64 (&q)[4], const u64 (&y)[4], const Shoup (&w)[4]) {
+    u64 s0, s1, s2, s3, sb, sc, sd;
+    u32 c0, c1, c2, c3;
+    asm("v_mad_u64_u32 %0, vcc, %12, %13, 0\n\t"
+        "v_mad_u64_u32 %1, %8, %16, %17, 0\n\t"
+        "v_mad_u64_u32 %2, %9, %20, %21, 0\n\t"
+        "v_mad_u64_u32 %3, %10, %24, %25, 0\n\t"
+        "v_mad_u64_u32 %0, vcc, %11, %14, %0\n\t"
+        "v_mad_u64_u32 %1, %8, %15, %18, %1\n\t"
+        "v_mad_u64_u32 %2, %9, %19, %22, %2\n\t"
+        "v_mad_u64_u32 %3, %10, %23, %26, %3\n\t"
+        "v_cndmask_b32 %4, 0, 1, vcc\n\t"
+        "v_cndmask_b32 %5, 0, 1, %8\n\t"
+        "v_cndmask_b32 %6, 0, 1, %9\n\t"
+        "v_cndmask_b32 %7, 0, 1, %10"
+        : "=&v"(s0), "=&v"(s1), "=&v"(s2), "=&v"(s3), "=&v"(c0), "=&v"(c1), "=&v"(c2), "=&v"(c3), "=&s"(sb), "=&s"(sc), "=&s"(sd)
+        : "v"(lo32(y[0])), "v"(hi32(y[0])), "v"(lo32(w[0].quo)), "v"(hi32(w[0].quo)),
+          "v"(lo32(y[1])), "v"(hi32(y[1])), "v"(lo32(w[1].quo)), "v"(hi32(w[1].quo)),
+          "v"(lo32(y[2])), "v"(hi32(y[2])), "v"(lo32(w[2].quo)), "v"(hi32(w[2].quo)),
+          "v"(lo32(y[3])), "v"(hi32(y[3])), "v"(lo32(w[3].quo)), "v"(hi32(w[3].quo))
+        : "vcc");
+    const u64 s[4] = {s0, s1, s2, s3};
+    const u32 c[4] = {c0, c1, c2, c3};
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const u64 hs = mk64(hi32(s[i]), c[i]);
+        u64 d, sink;
+        asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(sink) : "v"(hi32(y[i])), "v"(hi32(w[i].quo)), "v"(hs));
+        q[i] = d;
+    }
+}
+// acc + w*y + q*negp (mod 2^64); no carry chains -> no hazards, one butterfly per block
+__device__ __forceinline__ u64 mul_acc(u64 acc, u64 y, u64 w, u64 q, u64 negp) {
+    const u32 y0 = lo32(y), y1 = hi32(y), w0 = lo32(w), w1 = hi32(w), d0 = lo32(q), d1 = hi32(q);
+    u64 a, r, sc0, sc1;
+    u32 m0, m1, m2, m3, c0, h;
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(a), "=s"(sc0) : "v"(w0), "v"(y0), "v"(acc));
+    asm("v_mul_lo_u32 %0, %1, %2" : "=v"(m0) : "v"(w0), "v"(y1));
+    asm("v_mul_lo_u32 %0, %1, %2" : "=v"(m1) : "v"(w1), "v"(y0));
+    asm("v_mul_lo_u32 %0, %1, %2" : "=v"(m2) : "v"(d0), "s"(hi32(negp)));
+    asm("v_mul_lo_u32 %0, %1, %2" : "=v"(m3) : "v"(d1), "s"(lo32(negp)));
+    asm("v_add3_u32 %0, %1, %2, %3" : "=v"(c0) : "v"(m0), "v"(m1), "v"(m2));
+    asm("v_add3_u32 %0, %1, %2, %3" : "=v"(h) : "v"(hi32(a)), "v"(c0), "v"(m3));
+    const u64 a2 = mk64(lo32(a), h);
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(r), "=s"(sc1) : "v"(d0), "s"(lo32(negp)), "v"(a2));
+    return r;
+}
+#endif
+
+// Four forward butterflies (Cooley-Tukey, src/utils/dwthandler.h:88-204): X,Y in [0,8p) -> [0,8p)
+__device__ __forceinline__ void ct_bfly4(u64 (&X)[4], u64 (&Y)[4], const Shoup (&w)[4], const PrimeConst &c) {
+    csub4(X, c.four_p);                                       // u in [0,4p)
+    u64 q[4], xn[4], t[4];
+    mulhi_approx4(q, Y, w);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        xn[i] = mul_acc(X[i], Y[i], w[i].op, q[i], c.negp);   // u + v, v in [0,3p) -> [0,7p)
+        t[i] = (X[i] << 1) + c.three_p;
+    }
+    sub4(Y, t, xn);                                           // u + 3p - v -> (0,7p)
+#pragma unroll
+    for (int i = 0; i < 4; i++) X[i] = xn[i];
+}
+// Four inverse butterflies (Gentleman-Sande, dwthandler.h:215-372): X,Y in [0,4p) -> [0,4p)
+__device__ __forceinline__ void gs_bfly4(u64 (&X)[4], u64 (&Y)[4], const Shoup (&w)[4], const PrimeConst &c) {
+    u64 s[4], t[4], d[4], q[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) { s[i] = X[i] + Y[i]; t[i] = X[i] + c.four_p; }
+    sub4(d, t, Y);                                            // u + 4p - v in (0,8p)
+    csub4(s, c.four_p);
+    mulhi_approx4(q, d, w);
+#pragma unroll
+    for (int i = 0; i < 4; i++) { X[i] = s[i]; Y[i] = mul_acc(0, d[i], w[i].op, q[i], c.negp); }
+}
+// last inverse stage with N^-1 folded in (dwthandler.h:289-330): -> [0,3p)
+__device__ __forceinline__ void gs_bfly4_last(u64 (&X)[4], u64 (&Y)[4], const Shoup (&w_scaled)[4], const Shoup inv_n, const PrimeConst &c) {
+    u64 s[4], t[4], d[4], q[4];
+    const Shoup wn[4] = {inv_n, inv_n, inv_n, inv_n};
+#pragma unroll
+    for (int i = 0; i < 4; i++) { s[i] = X[i] + Y[i]; t[i] = X[i] + c.four_p; }
+    sub4(d, t, Y);
+    csub4(s, c.four_p);
+    mulhi_approx4(q, s, wn);
+#pragma unroll
+    for (int i = 0; i < 4; i++) X[i] = mul_acc(0, s[i], inv_n.op, q[i], c.negp);
+    mulhi_approx4(q, d, w_scaled);
+#pragma unroll
+    for (int i = 0; i < 4; i++) Y[i] = mul_acc(0, d[i], w_scaled[i].op, q[i], c.negp);
+}
+// final normalisations to the canonical residue, four values at a time
+__device__ __forceinline__ void reduce4_from_8p(u64 (&x)[4], const PrimeConst &c) { csub4(x, c.four_p); csub4(x, c.two_p); csub4(x, c.p); }
+__device__ __forceinline__ void reduce4_from_4p(u64 (&x)[4], const PrimeConst &c) { csub4(x, c.two_p); csub4(x, c.p); }
+
+} // namespace troyhip

@@ -245,8 +245,13 @@ void Evaluator::switch_key(CtBatch &ct, const u64 *target, u64 t_bstride, const 
         ct_tb = dl * N;
     }
     // decompose + extend every limb to every output prime, then ONE batched NTT over all (L+1)*L rows
-    launch_ks_expand(coeff_target, ct_tb, D, a, s);
-    launch_ntt(D, c.d_desc, c.ids_map(out_ids, (uint32_t)dl), batch * rl * dl, c.logn, false, s);
+    if (ntt2_supported(c.logn)) {
+        // fused: the strided NTT pass reads the target and reduces it modulo each output prime on the fly
+        launch_ntt2(D, coeff_target, ct_tb, true, c.d_desc, c.ids_map(out_ids, (uint32_t)dl), batch * rl * dl, c.logn, false, s);
+    } else {
+        launch_ks_expand(coeff_target, ct_tb, D, a, s);
+        launch_ntt(D, c.d_desc, c.ids_map(out_ids, (uint32_t)dl), batch * rl * dl, c.logn, false, s);
+    }
     // inner products with the key (128-bit lazy accumulation, one reduction per output)
     launch_ks_mac(D, key.data, c.scheme == SCHEME_CKKS ? target : nullptr, t_bstride, acc, a, s);
 

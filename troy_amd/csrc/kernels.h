@@ -7,6 +7,11 @@ namespace troyhip {
 // ---- ntt.hip ----
 void launch_ntt(u64 *data, const PrimeDesc *primes, const LimbMap &map, size_t rows, int logn, bool inverse, hipStream_t stream);
 
+// ---- ntt2.hip (N >= 4096) ----
+bool ntt2_supported(int logn);
+void launch_ntt2(u64 *data, const u64 *src, u64 src_ostride, bool src_reduce, const PrimeDesc *primes, const LimbMap &map, size_t rows, int logn,
+                 bool inverse, hipStream_t stream);
+
 // ---- poly.hip ----
 void launch_ew(int op, const u64 *a, const u64 *b, u64 *out, const PrimeDesc *primes, const LimbMap &map, int logn, u64 rows, hipStream_t s);
 void launch_mul_scalar(u64 *x, const PrimeDesc *primes, const LimbMap &map, const u64 *scalars, int logn, u64 rows, hipStream_t s);

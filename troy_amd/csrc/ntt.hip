@@ -188,6 +188,10 @@ static void plan(int logn, int &k1, int &k2) {
 
 void launch_ntt(u64 *data, const PrimeDesc *primes, const LimbMap &map, size_t rows, int logn, bool inverse, hipStream_t stream) {
     if (rows == 0) return;
+    if (ntt2_supported(logn) && rows % ((size_t)map.period * map.inner) == 0) { // production path for N >= 4096
+        launch_ntt2(data, nullptr, 0, false, primes, map, rows, logn, inverse, stream);
+        return;
+    }
     int k1, k2;
     plan(logn, k1, k2);
     NttArgs a;

@@ -1,0 +1,385 @@
+// ntt2.hip -- the production NTT/INTT for N >= 4096 on gfx950 ("twiddle-stationary" two-pass transform).
+//
+// Same transform and tables as ntt.hip (which stays as the generic path for N < 4096); what changes is how a
+// pass is executed on a CU:
+//   * the stage plan is a template parameter (NS stages, LOGC column bits): every index, gap and LDS address of a
+//     round is a compile-time expression;
+//   * a 256-thread workgroup owns one 2048-coefficient tile POSITION and loops over up to `rows_per_wg` limb-rows
+//     that share the same prime (the polynomials of a batch, or the L digits of one key-switch output prime), so
+//     the twiddles of all rounds are loaded ONCE into registers/SGPRs and reused -- twiddle traffic (2x the data in
+//     the last stages, SURVEY section 7 "hard parts") drops by rows_per_wg;
+//   * the first round reads its 8 points per thread straight from HBM and the last round writes straight back
+//     (no staging pass through LDS); between rounds the tile is exchanged through LDS with an XOR swizzle
+//     addr = f ^ ((f>>3)&7) ^ (((f>>6)&3)<<3) that is bank-conflict-free for every butterfly distance;
+//   * LDS is double-buffered across rows: 2 barriers per row instead of one per stage;
+//   * the strided pass can read its input from another buffer and Barrett-reduce it modulo the row's prime on the
+//     fly: the digit decomposition of key switching (evaluator.cpp:2432-2442, the reference's kModuloPolyCoeffs +
+//     copy per (i,j)) costs no kernel and no HBM round trip of the (L+1)*L expanded limbs.
+#include "kernels.h"
+#include "bfly.h"
+#include <type_traits>
+
+namespace troyhip {
+
+#define N2_THREADS 256
+#define N2_LOGT 11
+#define N2_T 2048
+
+struct Ntt2Args {
+    u64 *data;            // destination (and source when src == nullptr): rows of N coefficients
+    const u64 *src;       // optional distinct source for the strided forward pass (key-switch fusion)
+    u64 src_ostride;      // words between consecutive `outer` items of src
+    const PrimeDesc *primes;
+    LimbMap map;          // row r = (o * period + i) * inner + k  has prime map.id[i]
+    int logn;
+    unsigned tiles_per_row_log;
+    unsigned m_total;     // outer * inner rows per prime slot
+    unsigned rows_per_wg; // R
+    unsigned chunks;      // ceil(m_total / R)
+    int src_reduce;       // reduce src values modulo the row prime (they are residues of another prime)
+};
+
+__device__ __forceinline__ unsigned swz(unsigned f) { return f ^ ((f >> 3) & 7u) ^ (((f >> 6) & 3u) << 3); }
+
+// global coefficient index of flattened tile index f
+template <int STRIDED, int NS, int LOGC> __device__ __forceinline__ unsigned g_index(unsigned tile, unsigned f, int logn) {
+    if (STRIDED) return ((f >> LOGC) << (logn - NS)) + (tile << LOGC) + (f & ((1u << LOGC) - 1));
+    return (tile << N2_LOGT) + f;
+}
+
+// One round = R consecutive stages on G = 8 >> R groups of 2^R register-resident points per thread.
+//   forward: local stages LS .. LS+R-1 (gaps shrink);  inverse: local stages LS .. LS+R-1 (gaps grow)
+__device__ __forceinline__ Shoup to_sgpr(const Shoup w) {
+#ifdef TROYHIP_CPU_EMUL
+    return w;
+#else
+    Shoup r;
+    r.op = mk64(__builtin_amdgcn_readfirstlane(lo32(w.op)), __builtin_amdgcn_readfirstlane(hi32(w.op)));
+    r.quo = mk64(__builtin_amdgcn_readfirstlane(lo32(w.quo)), __builtin_amdgcn_readfirstlane(hi32(w.quo)));
+    return r;
+#endif
+}
+
+template <int INV, int STRIDED, int NS, int LOGC, int LS, int R> struct Round {
+    static constexpr int G = 8 >> R;                       // groups per thread
+    static constexpr int NTW = (1 << R) - 1;               // twiddles per group
+    static constexpr int LOGPF = NS + LOGC;                // log2 flattened size of one sub-transform
+    // forward: first stage gap 2^LOGG, point distance 2^LOGD
+    static constexpr int LOGG = INV ? 0 : LOGPF - LS - 1;
+    static constexpr int LOGD = INV ? (LS + LOGC) : (LOGG - (R - 1));
+    static constexpr bool UNIFORM = LOGD >= 6;             // all lanes of a wave share the twiddles
+
+    __device__ static __forceinline__ unsigned base_of(unsigned q) {
+        const unsigned hi = q >> LOGD, lo = q & ((1u << LOGD) - 1);
+        return INV ? ((hi << (LOGD + R)) + lo) : ((hi << (LOGD + R)) + lo); // blocks of 2^(LOGD+R) points either way
+    }
+    __device__ static __forceinline__ unsigned elem(unsigned q, int e) { return base_of(q) + ((unsigned)e << LOGD); }
+
+    // twiddles of group u of this thread
+    __device__ static __forceinline__ void load_tw(Shoup (&tw)[G][NTW], const PrimeDesc &pd, unsigned tile, int logn, int s_first) {
+#pragma unroll
+        for (int u = 0; u < G; u++) {
+            const unsigned q = threadIdx.x + N2_THREADS * u;
+            unsigned j0 = g_index<STRIDED, NS, LOGC>(tile, base_of(q), logn);
+            if (!INV) {
+                const int s = s_first + LS;
+                unsigned idx1 = (1u << s) + (j0 >> (logn - s));
+                if (UNIFORM) idx1 = __builtin_amdgcn_readfirstlane(idx1);
+#pragma unroll
+                for (int st = 0; st < R; st++)
+#pragma unroll
+                    for (int blk = 0; blk < (1 << st); blk++) {
+                        const Shoup w = pd.root[(idx1 << st) + blk];
+                        tw[u][(1 << st) - 1 + blk] = UNIFORM ? to_sgpr(w) : w;
+                    }
+            } else {
+                const int s = s_first - LS; // global stage of the first (smallest gap) stage of the round
+                unsigned blk0 = j0 >> (logn - s);
+                if (UNIFORM) blk0 = __builtin_amdgcn_readfirstlane(blk0);
+                const unsigned n = 1u << logn;
+                int pos = 0;
+#pragma unroll
+                for (int st = 0; st < R; st++) {
+                    const int cs = s - st;
+                    const unsigned tbase = n - (2u << cs) + 1 + (blk0 >> st);
+#pragma unroll
+                    for (int blk = 0; blk < ((1 << R) >> (st + 1)); blk++) {
+                        // the very last inverse stage uses the N^-1 pre-scaled twiddle
+                        const Shoup w = (STRIDED && (LS + st == NS - 1)) ? pd.iroot_last_scaled : pd.iroot[tbase + blk];
+                        tw[u][pos++] = UNIFORM ? to_sgpr(w) : w;
+                    }
+                }
+            }
+        }
+    }
+    // every stage = exactly four independent butterflies per thread -> one ct_bfly4 / gs_bfly4 call
+    __device__ static __forceinline__ void compute(u64 (&x)[8], const Shoup (&tw)[G][NTW], const PrimeDesc &pd) {
+        const PrimeConst pc = make_prime_const(pd.p);
+#pragma unroll
+        for (int st = 0; st < R; st++) {
+            u64 X[4], Y[4];
+            Shoup w[4];
+            int ix[4], iy[4];
+            int n = 0;
+#pragma unroll
+            for (int u = 0; u < G; u++) {
+                if (!INV) {
+                    const int half = (1 << R) >> (st + 1);
+#pragma unroll
+                    for (int blk = 0; blk < (1 << st); blk++)
+#pragma unroll
+                        for (int k = 0; k < half; k++) {
+                            ix[n] = (u << R) + blk * 2 * half + k;
+                            iy[n] = ix[n] + half;
+                            w[n] = tw[u][(1 << st) - 1 + blk];
+                            n++;
+                        }
+                } else {
+                    const int dist = 1 << st;
+                    // twiddles of stage st start after those of the earlier stages: sum_{t<st} 2^(R-1-t)
+                    const int off = (1 << R) - ((1 << R) >> st);
+#pragma unroll
+                    for (int blk = 0; blk < ((1 << R) >> (st + 1)); blk++)
+#pragma unroll
+                        for (int k = 0; k < dist; k++) {
+                            ix[n] = (u << R) + blk * 2 * dist + k;
+                            iy[n] = ix[n] + dist;
+                            w[n] = tw[u][off + blk];
+                            n++;
+                        }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) { X[i] = x[ix[i]]; Y[i] = x[iy[i]]; }
+            if (!INV) ct_bfly4(X, Y, w, pc);
+            else if (STRIDED && (LS + st == NS - 1)) gs_bfly4_last(X, Y, w, pd.inv_n, pc);
+            else gs_bfly4(X, Y, w, pc);
+#pragma unroll
+            for (int i = 0; i < 4; i++) { x[ix[i]] = X[i]; x[iy[i]] = Y[i]; }
+        }
+    }
+    __device__ static __forceinline__ void lds_read(u64 (&x)[8], const u64 *lds) {
+#pragma unroll
+        for (int u = 0; u < G; u++)
+#pragma unroll
+            for (int e = 0; e < (1 << R); e++) x[(u << R) + e] = lds[swz(elem(threadIdx.x + N2_THREADS * u, e))];
+    }
+    __device__ static __forceinline__ void lds_write(const u64 (&x)[8], u64 *lds) {
+#pragma unroll
+        for (int u = 0; u < G; u++)
+#pragma unroll
+            for (int e = 0; e < (1 << R); e++) lds[swz(elem(threadIdx.x + N2_THREADS * u, e))] = x[(u << R) + e];
+    }
+    // global access; consecutive-element runs are moved 16 bytes at a time
+    template <int REDUCE> __device__ static __forceinline__ void g_read(u64 (&x)[8], const u64 *row, unsigned tile, int logn, const Mod &m) {
+#pragma unroll
+        for (int u = 0; u < G; u++) {
+            const unsigned q = threadIdx.x + N2_THREADS * u;
+            if (LOGD == 0) {
+#pragma unroll
+                for (int e = 0; e < (1 << R); e += 2) {
+                    const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(row + g_index<STRIDED, NS, LOGC>(tile, elem(q, e), logn));
+                    x[(u << R) + e] = v.x;
+                    x[(u << R) + e + 1] = v.y;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < (1 << R); e++) x[(u << R) + e] = row[g_index<STRIDED, NS, LOGC>(tile, elem(q, e), logn)];
+            }
+        }
+        if (REDUCE) {
+#pragma unroll
+            for (int e = 0; e < 8; e++) x[e] = barrett64(x[e], m);
+        }
+    }
+    // FINAL: 0 keep lazy range, 1 forward final ([0,8p) -> [0,p)), 2 inverse final ([0,4p) -> [0,p))
+    template <int FINAL> __device__ static __forceinline__ void g_write(u64 (&x)[8], u64 *row, unsigned tile, int logn, u64 p, u64 two_p) {
+        (void)two_p;
+        if (FINAL) {
+            const PrimeConst pc = make_prime_const(p);
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                u64 v[4] = {x[4 * h], x[4 * h + 1], x[4 * h + 2], x[4 * h + 3]};
+                if (FINAL == 1) reduce4_from_8p(v, pc); else reduce4_from_4p(v, pc);
+#pragma unroll
+                for (int i = 0; i < 4; i++) x[4 * h + i] = v[i];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < G; u++) {
+            const unsigned q = threadIdx.x + N2_THREADS * u;
+            if (LOGD == 0) {
+#pragma unroll
+                for (int e = 0; e < (1 << R); e += 2) {
+                    ulonglong2 v;
+                    v.x = x[(u << R) + e];
+                    v.y = x[(u << R) + e + 1];
+                    *reinterpret_cast<ulonglong2 *>(row + g_index<STRIDED, NS, LOGC>(tile, elem(q, e), logn)) = v;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < (1 << R); e++) row[g_index<STRIDED, NS, LOGC>(tile, elem(q, e), logn)] = x[(u << R) + e];
+            }
+        }
+    }
+};
+
+// stage split of a pass into rounds: up to four rounds R0..R3 (0 = unused)
+template <int NS> struct Plan;
+template <> struct Plan<3> { static constexpr int r[4] = {3, 0, 0, 0}; };
+template <> struct Plan<4> { static constexpr int r[4] = {3, 1, 0, 0}; };
+template <> struct Plan<5> { static constexpr int r[4] = {3, 2, 0, 0}; };
+template <> struct Plan<6> { static constexpr int r[4] = {3, 3, 0, 0}; };
+template <> struct Plan<7> { static constexpr int r[4] = {3, 3, 1, 0}; };
+template <> struct Plan<9> { static constexpr int r[4] = {3, 3, 3, 0}; };
+template <> struct Plan<10> { static constexpr int r[4] = {3, 3, 3, 1}; };
+template <> struct Plan<11> { static constexpr int r[4] = {3, 3, 3, 2}; };
+
+template <int INV, int STRIDED, int NS, int LOGC, int FINAL, int REDUCE>
+__global__ __launch_bounds__(N2_THREADS, 3) void ntt2_kernel(Ntt2Args a) {
+    __shared__ u64 lds[2][N2_T];
+    using P = Plan<NS>;
+    // inverse passes run the same round list but with growing gaps, so their local-stage offsets are the same sums
+    constexpr int R0 = P::r[0], R1 = P::r[1], R2 = P::r[2], R3 = P::r[3];
+    constexpr int NR = (R0 > 0) + (R1 > 0) + (R2 > 0) + (R3 > 0);
+    // forward executes rounds 0..NR-1 with shrinking gaps; inverse executes the reversed list (small rounds first keeps
+    // the radix-8 rounds on the large gaps, i.e. on the coalescing-friendly side)
+    constexpr int Q0 = INV ? P::r[NR - 1] : R0;
+    constexpr int Q1 = NR > 1 ? (INV ? P::r[NR - 2] : R1) : 0;
+    constexpr int Q2 = NR > 2 ? (INV ? P::r[NR - 3] : R2) : 0;
+    constexpr int Q3 = NR > 3 ? (INV ? P::r[NR - 4] : R3) : 0;
+    using Rd0 = Round<INV, STRIDED, NS, LOGC, 0, Q0>;
+    using Rd1 = Round<INV, STRIDED, NS, LOGC, Q0, Q1 ? Q1 : 1>;
+    using Rd2 = Round<INV, STRIDED, NS, LOGC, Q0 + Q1, Q2 ? Q2 : 1>;
+    using Rd3 = Round<INV, STRIDED, NS, LOGC, Q0 + Q1 + Q2, Q3 ? Q3 : 1>;
+
+    const unsigned tile = blockIdx.x & ((1u << a.tiles_per_row_log) - 1);
+    const unsigned grp = blockIdx.x >> a.tiles_per_row_log;
+    const unsigned slot = grp / a.chunks, chunk = grp % a.chunks;
+    const PrimeDesc pd = a.primes[a.map.id[slot]];
+    const Mod m = mod_of(pd);
+    const int logn = a.logn;
+    const int k1 = STRIDED ? NS : logn - NS;
+    const int s_first = INV ? (STRIDED ? k1 - 1 : logn - 1) : (STRIDED ? 0 : k1);
+
+    Shoup tw0[Rd0::G][Rd0::NTW], tw1[Rd1::G][Rd1::NTW], tw2[Rd2::G][Rd2::NTW], tw3[Rd3::G][Rd3::NTW];
+    Rd0::load_tw(tw0, pd, tile, logn, s_first);
+    if constexpr (NR > 1) Rd1::load_tw(tw1, pd, tile, logn, s_first);
+    if constexpr (NR > 2) Rd2::load_tw(tw2, pd, tile, logn, s_first);
+    if constexpr (NR > 3) Rd3::load_tw(tw3, pd, tile, logn, s_first);
+
+    const unsigned m_begin = chunk * a.rows_per_wg;
+    const unsigned m_end = (m_begin + a.rows_per_wg < a.m_total) ? m_begin + a.rows_per_wg : a.m_total;
+    const unsigned inner = a.map.inner, period = a.map.period;
+    for (unsigned mm = m_begin; mm < m_end; mm++) {
+        const unsigned o = mm / inner, k = mm - o * inner;
+        const u64 r = ((u64)o * period + slot) * inner + k;
+        u64 *row = a.data + (r << logn);
+        const u64 *in = (REDUCE || a.src) ? (a.src + (u64)o * a.src_ostride + ((u64)k << logn)) : row;
+        u64 *buf = lds[mm & 1];
+        u64 x[8];
+        Rd0::template g_read<REDUCE>(x, in, tile, logn, m);
+        Rd0::compute(x, tw0, pd);
+        if constexpr (NR == 1) {
+            Rd0::template g_write<FINAL>(x, row, tile, logn, pd.p, pd.two_p);
+        } else {
+            Rd0::lds_write(x, buf);
+            __syncthreads();
+            Rd1::lds_read(x, buf);
+            Rd1::compute(x, tw1, pd);
+            if constexpr (NR == 2) {
+                Rd1::template g_write<FINAL>(x, row, tile, logn, pd.p, pd.two_p);
+            } else {
+                Rd1::lds_write(x, buf);
+                __syncthreads();
+                Rd2::lds_read(x, buf);
+                Rd2::compute(x, tw2, pd);
+                if constexpr (NR == 3) {
+                    Rd2::template g_write<FINAL>(x, row, tile, logn, pd.p, pd.two_p);
+                } else {
+                    Rd2::lds_write(x, buf);
+                    __syncthreads();
+                    Rd3::lds_read(x, buf);
+                    Rd3::compute(x, tw3, pd);
+                    Rd3::template g_write<FINAL>(x, row, tile, logn, pd.p, pd.two_p);
+                }
+            }
+        }
+    }
+}
+
+// ---- host side ----
+bool ntt2_supported(int logn) { return logn >= 12 && logn <= 17; }
+
+template <int INV, int STRIDED, int NS, int LOGC, int FINAL, int REDUCE> static void launch_one(const Ntt2Args &a, unsigned blocks, hipStream_t s) {
+    TROY_LAUNCH(HIP_KERNEL_NAME(ntt2_kernel<INV, STRIDED, NS, LOGC, FINAL, REDUCE>), dim3(blocks), dim3(N2_THREADS), 0, s, a);
+    launch_check("ntt2_kernel");
+}
+template <int INV, int NS> static void launch_contig(const Ntt2Args &a, unsigned blocks, bool final_pass, hipStream_t s) {
+    if (final_pass) launch_one<INV, 0, NS, 0, INV ? 2 : 1, 0>(a, blocks, s);
+    else launch_one<INV, 0, NS, 0, 0, 0>(a, blocks, s);
+}
+template <int INV, int NS> static void launch_strided(const Ntt2Args &a, unsigned blocks, bool final_pass, bool reduce, hipStream_t s) {
+    constexpr int LOGC = N2_LOGT - NS;
+    if (INV) { // the strided pass is the last inverse pass
+        launch_one<1, 1, NS, LOGC, 2, 0>(a, blocks, s);
+    } else {
+        (void)final_pass;
+        if (reduce) launch_one<0, 1, NS, LOGC, 0, 1>(a, blocks, s);
+        else launch_one<0, 1, NS, LOGC, 0, 0>(a, blocks, s);
+    }
+}
+
+// rows are laid out r = (o * period + i) * inner + k; src (optional, forward only): item o, digit k at src + o*src_ostride + k*N
+void launch_ntt2(u64 *data, const u64 *src, u64 src_ostride, bool src_reduce, const PrimeDesc *primes, const LimbMap &map, size_t rows, int logn,
+                 bool inverse, hipStream_t stream) {
+    if (rows == 0) return;
+    if (!ntt2_supported(logn)) throw Error(ST_LOGIC_ERROR, "ntt2: unsupported size");
+    const size_t per_outer = (size_t)map.period * map.inner;
+    if (rows % per_outer) throw Error(ST_INVALID_ARGUMENT, "ntt2: row count must be a multiple of the limb pattern");
+    if (src && inverse) throw Error(ST_LOGIC_ERROR, "ntt2: out-of-place input is only supported by the forward transform");
+    int k2 = 9;
+    if (logn - k2 > 7) k2 = logn - 7;
+    const int k1 = logn - k2;
+    Ntt2Args a;
+    a.data = data;
+    a.src = nullptr;
+    a.src_ostride = 0;
+    a.primes = primes;
+    a.map = map;
+    a.logn = logn;
+    a.tiles_per_row_log = (unsigned)(logn - N2_LOGT);
+    a.m_total = (unsigned)(rows / per_outer * map.inner);
+    a.rows_per_wg = a.m_total < 8 ? a.m_total : (map.inner > 1 ? (map.inner <= 16 ? map.inner : 8) : 8);
+    a.chunks = (a.m_total + a.rows_per_wg - 1) / a.rows_per_wg;
+    a.src_reduce = 0;
+    const unsigned blocks = (unsigned)((map.period * a.chunks) << a.tiles_per_row_log);
+    auto contig = [&](auto inv_tag, bool final_pass) {
+        constexpr int INV = decltype(inv_tag)::value;
+        if (k2 == 9) launch_contig<INV, 9>(a, blocks, final_pass, stream);
+        else if (k2 == 10) launch_contig<INV, 10>(a, blocks, final_pass, stream);
+        else throw Error(ST_LOGIC_ERROR, "ntt2 plan");
+    };
+    auto strided = [&](auto inv_tag, const Ntt2Args &args, bool reduce) {
+        constexpr int INV = decltype(inv_tag)::value;
+        switch (k1) {
+        case 3: launch_strided<INV, 3>(args, blocks, false, reduce, stream); break;
+        case 4: launch_strided<INV, 4>(args, blocks, false, reduce, stream); break;
+        case 5: launch_strided<INV, 5>(args, blocks, false, reduce, stream); break;
+        case 6: launch_strided<INV, 6>(args, blocks, false, reduce, stream); break;
+        case 7: launch_strided<INV, 7>(args, blocks, false, reduce, stream); break;
+        default: throw Error(ST_LOGIC_ERROR, "ntt2 plan");
+        }
+    };
+    if (!inverse) {
+        Ntt2Args first = a;
+        if (src) { first.src = src; first.src_ostride = src_ostride; first.src_reduce = src_reduce; }
+        strided(std::integral_constant<int, 0>{}, first, src && src_reduce);
+        contig(std::integral_constant<int, 0>{}, true);
+    } else {
+        contig(std::integral_constant<int, 1>{}, false);
+        strided(std::integral_constant<int, 1>{}, a, false);
+    }
+}
+
+} // namespace troyhip

@@ -23,6 +23,7 @@
 namespace troyhip {
 
 typedef uint64_t u64;
+typedef uint32_t u32;
 typedef unsigned __int128 u128;
 
 struct Error : std::runtime_error {
