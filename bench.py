@@ -170,7 +170,7 @@ def main():
         per_launch_s = ms.value / 1e3 / args.ntt_reps
         algo_bytes = 16.0 * N * rows  # 16 B per coefficient per limb-transform
         achieved = algo_bytes / per_launch_s / 1e9
-        roofline = {"bound": "hbm", "kernel": "ntt_pass_kernel (strided + contiguous pass = 1 transform)", "achieved": round(achieved, 1),
+        roofline = {"bound": "hbm", "kernel": "ntt2_kernel (strided pass + contiguous pass = 1 limb-transform)", "achieved": round(achieved, 1),
                     "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
                     "algorithmic_bytes_per_launch": algo_bytes, "launch_us": round(per_launch_s * 1e6, 2),
                     "limb_transforms_per_launch": rows}

@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdint>
 #include <vector>
+#include "../troy_amd/csrc/bfly.h"
 
 #define ITERS 4096
 #define CHAINS 8
@@ -57,6 +58,38 @@ __global__ __launch_bounds__(256) void bfly_probe(uint64_t *out, uint64_t p, uin
     uint64_t r = 0;
     for (int i = 0; i < 8; i++) r ^= x[i] ^ y[i];
     out[t] = r;
+}
+
+// production butterflies (troy_amd/csrc/bfly.h): 8 values per thread, one radix-8 round per iteration (12 butterflies)
+__global__ __launch_bounds__(256) void bfly4_probe(uint64_t *out, uint64_t p, troyhip::Shoup w, long long *cyc) {
+    using namespace troyhip;
+    uint32_t t = threadIdx.x + blockIdx.x * 256;
+    u64 x[8];
+    const PrimeConst pc = make_prime_const(p);
+    for (int i = 0; i < 8; i++) x[i] = (t * 0x9E3779B97F4A7C15ull + i * 0xBF58476D1CE4E5B9ull) % p;
+    Shoup ww[4] = {w, w, w, w};
+    long long c0 = clock64();
+    for (int it = 0; it < ITERS / 16; it++) {
+#pragma unroll
+        for (int st = 0; st < 3; st++) {
+            const int half = 4 >> st;
+            u64 X[4], Y[4]; int n = 0, ix[4], iy[4];
+#pragma unroll
+            for (int blk = 0; blk < (1 << st); blk++)
+#pragma unroll
+                for (int k = 0; k < half; k++) { ix[n] = blk * 2 * half + k; iy[n] = ix[n] + half; n++; }
+#pragma unroll
+            for (int i = 0; i < 4; i++) { X[i] = x[ix[i]]; Y[i] = x[iy[i]]; }
+            ct_bfly4(X, Y, ww, pc);
+#pragma unroll
+            for (int i = 0; i < 4; i++) { x[ix[i]] = X[i]; x[iy[i]] = Y[i]; }
+        }
+    }
+    long long c1 = clock64();
+    uint64_t r = 0;
+    for (int i = 0; i < 8; i++) r ^= x[i];
+    out[t] = r;
+    if (t == 0) *cyc = c1 - c0;
 }
 
 int main() {
@@ -112,6 +145,26 @@ int main() {
         double per_s = bf / (best * 1e-3);
         printf("harvey butterfly   %8.3f ms  -> %.1f G butterflies/s chip-wide = %.2f cycles per wave-butterfly per SIMD; "
                "N=2^15 limb NTT compute floor %.3f us\n", best, per_s / 1e9, clk / (per_s / 64 / (cus * 4.0)), 245760.0 / per_s * 1e6);
+    }
+    {
+        uint64_t p = 0xffffffffffc0001ULL >> 3 | 1, w = 0x123456789abcdefULL % p;
+        troyhip::Shoup sw{w, (uint64_t)((((unsigned __int128)w) << 64) / p)};
+        long long *dcyc; hipMalloc(&dcyc, 8);
+        float best = 1e30f;
+        for (int rep = 0; rep < 3; rep++) {
+            hipEventRecord(e0);
+            bfly4_probe<<<blocks, 256>>>((uint64_t *)out, p, sw, dcyc);
+            hipEventRecord(e1);
+            hipEventSynchronize(e1);
+            float ms;
+            hipEventElapsedTime(&ms, e0, e1);
+            if (ms < best) best = ms;
+        }
+        long long hc; hipMemcpy(&hc, dcyc, 8, hipMemcpyDeviceToHost);
+        double bf = (double)blocks * 256 * (ITERS / 16) * 12;
+        double per_s = bf / (best * 1e-3);
+        printf("bfly.h ct_bfly4    %8.3f ms  -> %.1f G butterflies/s chip-wide; wave0 ran %lld shader cycles in %.3f ms => %.0f MHz effective; "
+               "N=2^15 limb NTT compute floor %.3f us\n", best, per_s / 1e9, hc, best, hc / (best * 1e-3) / 1e6, 245760.0 / per_s * 1e6);
     }
     return 0;
 }

@@ -21,8 +21,12 @@ struct LimbMap {
 };
 
 #ifdef TROYHIP_CPU_EMUL
+#define TROY_WAVE_SYNC() hip_emul::park(2) /* all live lanes of the wave arrive before any proceeds */
 #define TROY_DYN_LDS(type, name) static type name[160 * 1024 / sizeof(type)]
 #else
+// LDS operations of one wave execute in order, so intra-wave exchange needs no s_barrier; this only stops the
+// compiler from moving LDS accesses across the exchange point
+#define TROY_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
 #define TROY_DYN_LDS(type, name) extern __shared__ __attribute__((aligned(16))) type name[]
 #endif
 

@@ -68,6 +68,10 @@ template <int INV, int STRIDED, int NS, int LOGC, int LS, int R> struct Round {
     static constexpr int LOGG = INV ? 0 : LOGPF - LS - 1;
     static constexpr int LOGD = INV ? (LS + LOGC) : (LOGG - (R - 1));
     static constexpr bool UNIFORM = LOGD >= 6;             // all lanes of a wave share the twiddles
+    static constexpr bool LAST = INV ? (LS + R == NS) : (LS + R == NS);
+    // twiddles that live in SGPRs (wave-uniform) or belong to the last round are loaded once per workgroup; the
+    // few-distinct-values rounds in between are re-read from L1 per row, which frees ~28 VGPRs (one more wave per SIMD)
+    static constexpr bool HOIST = true; // measured: re-reading the middle rounds per row does not lower the allocation (asm temporaries dominate)
 
     __device__ static __forceinline__ unsigned base_of(unsigned q) {
         const unsigned hi = q >> LOGD, lo = q & ((1u << LOGD) - 1);
@@ -187,10 +191,7 @@ template <int INV, int STRIDED, int NS, int LOGC, int LS, int R> struct Round {
                 for (int e = 0; e < (1 << R); e++) x[(u << R) + e] = row[g_index<STRIDED, NS, LOGC>(tile, elem(q, e), logn)];
             }
         }
-        if (REDUCE) {
-#pragma unroll
-            for (int e = 0; e < 8; e++) x[e] = barrett64(x[e], m);
-        }
+        (void)m;
     }
     // FINAL: 0 keep lazy range, 1 forward final ([0,8p) -> [0,p)), 2 inverse final ([0,4p) -> [0,p))
     template <int FINAL> __device__ static __forceinline__ void g_write(u64 (&x)[8], u64 *row, unsigned tile, int logn, u64 p, u64 two_p) {
@@ -235,10 +236,23 @@ template <> struct Plan<9> { static constexpr int r[4] = {3, 3, 3, 0}; };
 template <> struct Plan<10> { static constexpr int r[4] = {3, 3, 3, 1}; };
 template <> struct Plan<11> { static constexpr int r[4] = {3, 3, 3, 2}; };
 
+#ifndef N2_MIN_WAVES
+#define N2_MIN_WAVES 4
+#endif
+#ifndef N2_PREFETCH
+#define N2_PREFETCH 0
+#endif
 template <int INV, int STRIDED, int NS, int LOGC, int FINAL, int REDUCE>
-__global__ __launch_bounds__(N2_THREADS, 3) void ntt2_kernel(Ntt2Args a) {
+__global__ __launch_bounds__(N2_THREADS, N2_MIN_WAVES) void ntt2_kernel(Ntt2Args a) {
     __shared__ u64 lds[2][N2_T];
     using P = Plan<NS>;
+    // NS == 9, contiguous: every 512-point sub-transform is owned by ONE wave in every round (thread t's points never
+    // leave [512*(t/64), 512*(t/64)+512), and the XOR swizzle only permutes address bits 0..4), so the LDS exchange
+    // needs no workgroup barrier at all: the four waves run fully decoupled and overlap each other's HBM phases.
+    constexpr bool WAVE_PRIVATE = !STRIDED && NS == 9;
+    auto round_sync = [&]() {
+        if (WAVE_PRIVATE) TROY_WAVE_SYNC(); else __syncthreads();
+    };
     // inverse passes run the same round list but with growing gaps, so their local-stage offsets are the same sums
     constexpr int R0 = P::r[0], R1 = P::r[1], R2 = P::r[2], R3 = P::r[3];
     constexpr int NR = (R0 > 0) + (R1 > 0) + (R2 > 0) + (R3 > 0);
@@ -263,47 +277,77 @@ __global__ __launch_bounds__(N2_THREADS, 3) void ntt2_kernel(Ntt2Args a) {
     const int s_first = INV ? (STRIDED ? k1 - 1 : logn - 1) : (STRIDED ? 0 : k1);
 
     Shoup tw0[Rd0::G][Rd0::NTW], tw1[Rd1::G][Rd1::NTW], tw2[Rd2::G][Rd2::NTW], tw3[Rd3::G][Rd3::NTW];
-    Rd0::load_tw(tw0, pd, tile, logn, s_first);
-    if constexpr (NR > 1) Rd1::load_tw(tw1, pd, tile, logn, s_first);
-    if constexpr (NR > 2) Rd2::load_tw(tw2, pd, tile, logn, s_first);
-    if constexpr (NR > 3) Rd3::load_tw(tw3, pd, tile, logn, s_first);
+    if constexpr (Rd0::HOIST) Rd0::load_tw(tw0, pd, tile, logn, s_first);
+    if constexpr (NR > 1 && Rd1::HOIST) Rd1::load_tw(tw1, pd, tile, logn, s_first);
+    if constexpr (NR > 2 && Rd2::HOIST) Rd2::load_tw(tw2, pd, tile, logn, s_first);
+    if constexpr (NR > 3 && Rd3::HOIST) Rd3::load_tw(tw3, pd, tile, logn, s_first);
 
     const unsigned m_begin = chunk * a.rows_per_wg;
     const unsigned m_end = (m_begin + a.rows_per_wg < a.m_total) ? m_begin + a.rows_per_wg : a.m_total;
     const unsigned inner = a.map.inner, period = a.map.period;
-    for (unsigned mm = m_begin; mm < m_end; mm++) {
+    // software pipeline over the rows of this group: the loads of row mm+1 are in flight while row mm is transformed
+    auto row_ptrs = [&](unsigned mm, u64 *&row, const u64 *&in) {
         const unsigned o = mm / inner, k = mm - o * inner;
         const u64 r = ((u64)o * period + slot) * inner + k;
-        u64 *row = a.data + (r << logn);
-        const u64 *in = (REDUCE || a.src) ? (a.src + (u64)o * a.src_ostride + ((u64)k << logn)) : row;
+        row = a.data + (r << logn);
+        in = (REDUCE || a.src) ? (a.src + (u64)o * a.src_ostride + ((u64)k << logn)) : row;
+    };
+    u64 x[8], nx[8];
+    {
+        u64 *row0; const u64 *in0;
+        row_ptrs(m_begin, row0, in0);
+        Rd0::template g_read<REDUCE>(x, in0, tile, logn, m);
+    }
+    for (unsigned mm = m_begin; mm < m_end; mm++) {
+        u64 *row; const u64 *in;
+        row_ptrs(mm, row, in);
+        if (N2_PREFETCH && mm + 1 < m_end) {
+            u64 *nrow; const u64 *nin;
+            row_ptrs(mm + 1, nrow, nin);
+            Rd0::template g_read<REDUCE>(nx, nin, tile, logn, m);
+        }
         u64 *buf = lds[mm & 1];
-        u64 x[8];
-        Rd0::template g_read<REDUCE>(x, in, tile, logn, m);
+        if (REDUCE) {
+#pragma unroll
+            for (int e = 0; e < 8; e++) x[e] = barrett64(x[e], m);
+        }
+        if constexpr (!Rd0::HOIST) Rd0::load_tw(tw0, pd, tile, logn, s_first);
         Rd0::compute(x, tw0, pd);
         if constexpr (NR == 1) {
             Rd0::template g_write<FINAL>(x, row, tile, logn, pd.p, pd.two_p);
         } else {
             Rd0::lds_write(x, buf);
-            __syncthreads();
+            round_sync();
+            if constexpr (!Rd1::HOIST) Rd1::load_tw(tw1, pd, tile, logn, s_first);
             Rd1::lds_read(x, buf);
             Rd1::compute(x, tw1, pd);
             if constexpr (NR == 2) {
                 Rd1::template g_write<FINAL>(x, row, tile, logn, pd.p, pd.two_p);
             } else {
                 Rd1::lds_write(x, buf);
-                __syncthreads();
+                round_sync();
+                if constexpr (!Rd2::HOIST) Rd2::load_tw(tw2, pd, tile, logn, s_first);
                 Rd2::lds_read(x, buf);
                 Rd2::compute(x, tw2, pd);
                 if constexpr (NR == 3) {
                     Rd2::template g_write<FINAL>(x, row, tile, logn, pd.p, pd.two_p);
                 } else {
                     Rd2::lds_write(x, buf);
-                    __syncthreads();
+                    round_sync();
+                    if constexpr (!Rd3::HOIST) Rd3::load_tw(tw3, pd, tile, logn, s_first);
                     Rd3::lds_read(x, buf);
                     Rd3::compute(x, tw3, pd);
                     Rd3::template g_write<FINAL>(x, row, tile, logn, pd.p, pd.two_p);
                 }
             }
+        }
+        if (N2_PREFETCH) {
+#pragma unroll
+            for (int e = 0; e < 8; e++) x[e] = nx[e];
+        } else if (mm + 1 < m_end) {
+            u64 *nrow; const u64 *nin;
+            row_ptrs(mm + 1, nrow, nin);
+            Rd0::template g_read<REDUCE>(x, nin, tile, logn, m);
         }
     }
 }
