@@ -170,8 +170,17 @@ def main():
         per_launch_s = ms.value / 1e3 / args.ntt_reps
         algo_bytes = 16.0 * N * rows  # 16 B per coefficient per limb-transform
         achieved = algo_bytes / per_launch_s / 1e9
+        # HBM bytes per launch from the committed PMC measurement of this kernel (profiles/ntt_traffic.json:
+        # FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 passes); null when the file does not match this workload
+        traffic = None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "ntt_traffic.json")))
+            if tj.get("N") == N:
+                traffic = round(tj["hbm_bytes_per_limb_transform"]["mean"] * rows)
+        except Exception:
+            traffic = None
         roofline = {"bound": "hbm", "kernel": "ntt2_kernel (strided pass + contiguous pass = 1 limb-transform)", "achieved": round(achieved, 1),
-                    "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                    "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                     "algorithmic_bytes_per_launch": algo_bytes, "launch_us": round(per_launch_s * 1e6, 2),
                     "limb_transforms_per_launch": rows}
         del D

@@ -154,14 +154,15 @@ void Context::upload_tables() {
         for (int l = 0; l < L; l++) c->q_id[l] = (uint8_t)l;
         for (int o = 0; o < nBsk; o++) c->bsk_id[o] = lv.bsk_ids[o];
         std::vector<Shoup> ext_pre(L), floor_pre(L), inv_mt(nBsk), t_bsk(nBsk), inv_q(nBsk), B_pre(nB);
-        std::vector<u64> q2bsk((size_t)(nBsk + 1) * L), B2q((size_t)L * nB), B2msk(nB);
+        auto split3 = [](u64 m) { return Mat3{(u32)(m & 0x1FFFFF), (u32)((m >> 21) & 0x1FFFFF), (u32)(m >> 42), 0}; };
+        std::vector<Mat3> q2bsk((size_t)(nBsk + 1) * L), B2q((size_t)L * nB), B2msk(nB);
         for (int l = 0; l < L; l++) {
             u64 ql = r.q[l], ip = r.q_to_Bsk.inv_punct[l];
             ext_pre[l] = make_shoup(host::mul_mod(r.m_tilde % ql, ip, ql), ql);
             floor_pre[l] = make_shoup(host::mul_mod(t % ql, ip, ql), ql);
-            for (int o = 0; o < nBsk; o++) q2bsk[(size_t)o * L + l] = r.q_to_Bsk.mat[o][l];
-            q2bsk[(size_t)nBsk * L + l] = r.q_to_mtilde.mat[0][l];
-            for (int b = 0; b < nB; b++) B2q[(size_t)l * nB + b] = r.B_to_q.mat[l][b];
+            for (int o = 0; o < nBsk; o++) q2bsk[(size_t)o * L + l] = split3(r.q_to_Bsk.mat[o][l]);
+            q2bsk[(size_t)nBsk * L + l] = split3(r.q_to_mtilde.mat[0][l]);
+            for (int b = 0; b < nB; b++) B2q[(size_t)l * nB + b] = split3(r.B_to_q.mat[l][b]);
         }
         for (int o = 0; o < nBsk; o++) {
             u64 p = r.Bsk[o];
@@ -171,10 +172,10 @@ void Context::upload_tables() {
         }
         for (int b = 0; b < nB; b++) {
             B_pre[b] = make_shoup(r.B_to_q.inv_punct[b], r.B[b]);
-            B2msk[b] = r.B_to_msk.mat[0][b];
+            B2msk[b] = split3(r.B_to_msk.mat[0][b]);
         }
         c->ext_pre = upload(ext_pre, lv.dev_blocks);
-        c->q2bsk = upload(q2bsk, lv.dev_blocks);
+        c->q2bsk3 = upload(q2bsk, lv.dev_blocks);
         c->neg_inv_q_mod_mt = r.neg_inv_prod_q_mod_mtilde;
         c->prod_q_mod_bsk = upload(r.prod_q_mod_Bsk, lv.dev_blocks);
         c->inv_mt_mod_bsk = upload(inv_mt, lv.dev_blocks);
@@ -182,8 +183,8 @@ void Context::upload_tables() {
         c->t_mod_bsk = upload(t_bsk, lv.dev_blocks);
         c->inv_q_mod_bsk = upload(inv_q, lv.dev_blocks);
         c->B_pre = upload(B_pre, lv.dev_blocks);
-        c->B2q = upload(B2q, lv.dev_blocks);
-        c->B2msk = upload(B2msk, lv.dev_blocks);
+        c->B2q3 = upload(B2q, lv.dev_blocks);
+        c->B2msk3 = upload(B2msk, lv.dev_blocks);
         c->inv_B_mod_msk = make_shoup(r.inv_prod_B_mod_msk, r.m_sk);
         c->prod_B_mod_q = upload(r.prod_B_mod_q, lv.dev_blocks);
         lv.behz = c;

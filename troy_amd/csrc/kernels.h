@@ -57,13 +57,16 @@ void launch_zero_strided(u64 *dst, u64 dst_bstride, u64 count, u64 batch, hipStr
 void launch_fill_uniform(u64 *out, const PrimeDesc *primes, const LimbMap &map, int logn, u64 seed, u64 row0, u64 rows, hipStream_t s);
 
 // ---- behz.hip ----
+// base-change matrix entry split into 21-bit limbs (m = m0 + m1 2^21 + m2 2^42): see behz.hip
+struct Mat3 { u32 m0, m1, m2, pad; };
+
 // device-resident constants of one level (built by Context, see context.cpp)
 struct BehzDev {
     int L, nB, nBsk;
     uint8_t q_id[64], bsk_id[66];     // prime ids
     // --- extension q -> Bsk (+ m_tilde) ---
     const Shoup *ext_pre;             // [L]   (m_tilde * (q/q_l)^-1) mod q_l
-    const u64 *q2bsk;                 // [nBsk+1][L]  (q/q_l) mod Bsk_o ; last row mod m_tilde = 2^32
+    const Mat3 *q2bsk3;               // [nBsk+1][L]  (q/q_l) mod Bsk_o ; last row mod m_tilde = 2^32
     u64 neg_inv_q_mod_mt;             // -q^-1 mod 2^32
     const u64 *prod_q_mod_bsk;        // [nBsk]
     const Shoup *inv_mt_mod_bsk;      // [nBsk]
@@ -72,8 +75,8 @@ struct BehzDev {
     const Shoup *t_mod_bsk;           // [nBsk]
     const Shoup *inv_q_mod_bsk;       // [nBsk]
     const Shoup *B_pre;               // [nB]  (B/B_b)^-1 mod B_b
-    const u64 *B2q;                   // [L][nB]   (B/B_b) mod q_l
-    const u64 *B2msk;                 // [nB]      (B/B_b) mod m_sk
+    const Mat3 *B2q3;                 // [L][nB]   (B/B_b) mod q_l
+    const Mat3 *B2msk3;               // [nB]      (B/B_b) mod m_sk
     Shoup inv_B_mod_msk;
     const u64 *prod_B_mod_q;          // [L]
 };
