@@ -69,21 +69,39 @@ def main():
     ap.add_argument("--workload", default="bfv_n32768_l14", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--ntt-reps", type=int, default=10)
+    ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed even for one rank (tests the RCCL path)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     backend = None
-    if world > 1:
+    device = local_rank
+    use_dist = world > 1 or args.force_dist
+    # RCCL prints a version banner on fd 1; keep stdout clean for the ONE JSON line by routing fd 1 to stderr until then
+    sys.stdout.flush()
+    saved_stdout_fd = os.dup(1)
+    os.dup2(2, 1)
+    if use_dist:
         import torch
         dist = _dist()
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        try:
-            torch.cuda.set_device(local_rank)
-            dist.init_process_group("nccl")  # RCCL over xGMI; only used for the barrier and the timing reduction
-            backend = "nccl"
-        except Exception:
+        os.environ.setdefault("MASTER_PORT", "29512")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        ndev = torch.cuda.device_count()  # does not initialise the GPU on this image
+        device = local_rank % max(ndev, 1)
+        if ndev >= world:
+            try:
+                torch.cuda.set_device(device)
+                dist.init_process_group("nccl")  # RCCL over xGMI; only used for the barrier and the timing reduction
+                max_over_ranks(0.0, "nccl")      # force communicator creation now, fall back if it cannot be built
+                backend = "nccl"
+            except Exception:
+                if dist.is_initialized():
+                    dist.destroy_process_group()
+                backend = None
+        if backend is None:  # fewer devices than ranks (development box) or RCCL unavailable: CPU rendezvous
             dist.init_process_group("gloo")
             backend = "gloo"
 
@@ -93,7 +111,7 @@ def main():
     from troy_amd import capi
 
     lib = capi.load()
-    ta.KernelProvider.initialize(local_rank)
+    ta.KernelProvider.initialize(device)
     scheme, N, bits, tbits = WORKLOADS[args.workload]
     primes = ta.CoeffModulus.Create(N, bits)
     t = ta.PlainModulus.Batching(N, tbits)
@@ -123,7 +141,7 @@ def main():
 
     def barrier():
         ta.synchronize()
-        if world > 1:
+        if use_dist:
             _dist().barrier()
         ta.synchronize()
 
@@ -136,7 +154,7 @@ def main():
     ta.synchronize()
     dt = time.perf_counter() - t0
     barrier()
-    if world > 1:
+    if use_dist:
         dt = max_over_ranks(dt, backend)
         total_ops = sum_over_ranks(B * args.steps, backend)
     else:
@@ -201,11 +219,14 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
             "config": {"workload": args.workload, "scheme": "BFV", "N": N, "K": K, "L": L, "Bsk": nbsk, "batch_per_gpu": B,
-                       "limb_transforms_per_op": limb_transforms, "parallelism": f"batch-shard x{world}"},
+                       "limb_transforms_per_op": limb_transforms, "parallelism": f"batch-shard x{world}", "rendezvous": backend},
             "roofline": roofline, "cpu_baseline": cpu,
         }
+        sys.stdout.flush()
+        os.dup2(saved_stdout_fd, 1)
         print(json.dumps(line), flush=True)
-    if world > 1:
+        os.dup2(2, 1)
+    if use_dist:
         _dist().destroy_process_group()
 
 

@@ -80,6 +80,9 @@ int troyhip_plain_modulus_batching(uint64_t poly_modulus_degree, int bit_size, u
  * mod-switch factors) for the whole modulus-switching chain; SecurityLevel::none semantics. */
 int troyhip_context_create(int scheme, uint64_t poly_modulus_degree, const uint64_t *coeff_modulus, int coeff_modulus_size,
                            uint64_t plain_modulus, troyhip_context **out);
+/* the same tables on the host only (no GPU touched, no troyhip_initialize needed): enough for the troyhip_host_* calls */
+int troyhip_context_create_host(int scheme, uint64_t poly_modulus_degree, const uint64_t *coeff_modulus, int coeff_modulus_size,
+                                uint64_t plain_modulus, troyhip_context **out);
 int troyhip_context_destroy(troyhip_context *ctx);
 int troyhip_context_info(const troyhip_context *ctx, troyhip_context_info_t *out);
 /* BEHZ auxiliary base of a level (RNSToolCuda, src/utils/rns_cuda.cu:206-269): bsk_out gets |Bsk| primes (B then m_sk) */
@@ -90,6 +93,22 @@ int troyhip_context_ntt_tables(const troyhip_context *ctx, uint64_t prime, uint6
 int troyhip_context_reserve_scratch(troyhip_context *ctx, size_t words);
 int troyhip_context_scratch_words(const troyhip_context *ctx, int op, int limbs, uint64_t batch, size_t *words); /* op: 0 multiply(2x2), 1 switch_key */
 int troyhip_galois_elt_from_step(const troyhip_context *ctx, int step, uint32_t *out);   /* GaloisToolCuda::getEltFromStep (galois_cuda.cu:44-86) */
+
+/* ---- CPU-side KeyGenerator / Encryptor / Decryptor (BASELINE config A plumbing; the reference runs these on the CPU too:
+ * src/keygenerator_cuda.cuh delegates to src/keygenerator.cpp).  ALL buffers are host memory.  Randomness: a ChaCha20
+ * stream keyed by (seed_lo, seed_hi) -- fresh ciphertexts are not bit-identical to the reference's Blake2xb-driven ones
+ * but decrypt to the same plaintext; decryption is deterministic and bit-exact. ----
+ * secret_key [K][N] (NTT form, src/secretkey.h), public_key [2][K][N] (src/publickey.h), kswitch keys [K-1][2][K][N]. */
+int troyhip_host_keygen(const troyhip_context *ctx, uint64_t seed_lo, uint64_t seed_hi, uint64_t *secret_key, uint64_t *public_key); /* KeyGenerator(ctx), createPublicKey */
+int troyhip_host_relin_key(const troyhip_context *ctx, uint64_t seed_lo, uint64_t seed_hi, const uint64_t *secret_key, uint64_t *out);  /* createRelinKeys */
+int troyhip_host_galois_key(const troyhip_context *ctx, uint64_t seed_lo, uint64_t seed_hi, const uint64_t *secret_key, uint32_t galois_elt, uint64_t *out); /* createGaloisKeys({elt}) */
+/* Encryptor::encrypt (public key).  BFV/BGV: plain = n_coeffs coefficients mod t -> ct [2][first_limbs][N];  CKKS: plain = [limbs][N] NTT-form RNS
+ * polynomial -> ct [2][limbs][N] NTT form */
+int troyhip_host_encrypt(const troyhip_context *ctx, uint64_t seed_lo, uint64_t seed_hi, const uint64_t *public_key, const uint64_t *plain,
+                         uint64_t n_coeffs, int limbs, uint64_t *ct_out);
+/* Decryptor::decrypt.  BFV/BGV: N plaintext coefficients;  CKKS: the [limbs][N] RNS plaintext (NTT form) */
+int troyhip_host_decrypt(const troyhip_context *ctx, const uint64_t *secret_key, const uint64_t *ct, int size, int limbs, int is_ntt_form,
+                         uint64_t correction_factor, uint64_t *plain_out);
 
 /* ---- kernel_util (src/kernelutils.cuh:562-672) ----
  * rows limb-polynomials of N coefficients at `data`; row r is reduced modulo row_primes[(r / inner) % period].

@@ -149,6 +149,14 @@ class Ref:
         e = np.array(list(galois_elts), dtype=np.uint32)
         self._chk(lib().ref_keygen(self.h, _p(e), len(e)))
 
+    def set_secret_key(self, sk):
+        sk = np.ascontiguousarray(sk, dtype=np.uint64)
+        self._chk(lib().ref_set_secret_key(self.h, _p(sk)))
+
+    def set_public_key(self, pk):
+        pk = np.ascontiguousarray(pk, dtype=np.uint64)
+        self._chk(lib().ref_set_public_key(self.h, _p(pk)))
+
     def secret_key(self):
         out = np.zeros((self.K, self.N), dtype=np.uint64)
         lib().ref_get_secret_key(self.h, _p(out))

@@ -37,6 +37,7 @@ struct Ref {
     RelinKeys rlk;
     GaloisKeys gk;
     bool has_pk = false;
+    std::unique_ptr<SecretKey> sk_override;
     size_t N = 0, K = 0;
     std::string err;
 };
@@ -243,6 +244,27 @@ int ref_keygen(void *h, const uint32_t *galois_elts, int n_elts) {
         }
     });
 }
+// install an externally generated secret key [K][N] (NTT form) / public key [2][K][N] so the reference's own
+// Decryptor / Encryptor can be run against material produced by the product's host-side key generator
+int ref_set_secret_key(void *h, const u64 *data) {
+    Ref *r = (Ref *)h;
+    return guarded(r, [&] {
+        r->sk_override.reset(new SecretKey());
+        r->sk_override->data().resize(r->K * r->N);
+        std::memcpy(r->sk_override->data().data(), data, sizeof(u64) * r->K * r->N);
+        r->sk_override->parmsID() = r->ctx->keyParmsID();
+    });
+}
+int ref_set_public_key(void *h, const u64 *data) {
+    Ref *r = (Ref *)h;
+    return guarded(r, [&] {
+        Ciphertext &c = r->pk.data();
+        c.resize(*r->ctx, r->ctx->keyParmsID(), 2);
+        std::memcpy(c.data(), data, sizeof(u64) * 2 * r->K * r->N);
+        c.isNttForm() = true;
+        r->has_pk = true;
+    });
+}
 // secret key: [K][N] NTT form at key level (src/keygenerator.cpp)
 int ref_get_secret_key(void *h, u64 *out) {
     Ref *r = (Ref *)h;
@@ -377,7 +399,7 @@ int ref_encrypt(void *h, const u64 *plain, int n_coeffs, RefCtDesc *od, u64 *out
 int ref_decrypt(void *h, const RefCtDesc *ad, const u64 *a, u64 *plain_out, int *budget) {
     Ref *r = (Ref *)h;
     return guarded(r, [&] {
-        Decryptor dec(*r->ctx, r->keygen->secretKey());
+        Decryptor dec(*r->ctx, r->sk_override ? *r->sk_override : r->keygen->secretKey());
         Ciphertext x = make_ct(r, ad->limbs, ad->size, a, ad->is_ntt, ad->scale, ad->correction_factor);
         Plaintext p;
         dec.decrypt(x, p);

@@ -1,0 +1,134 @@
+"""BASELINE config A: encrypt -> add -> decrypt plumbing on the CPU, no GPU involved.
+The product's host-side KeyGenerator / Encryptor / Decryptor (troy_amd/csrc/hostcrypto.cpp, C ABI troyhip_host_*) against
+the reference fixture (tests/golden/cfgA_*.npz), the CPU oracle, and -- where oracle/_ref is present -- the reference's
+own Encryptor / Decryptor.  Decryption must be bit-exact; fresh encryptions use our own sampler and must decrypt to the
+input everywhere."""
+import os
+
+import numpy as np
+import pytest
+
+import cases
+from conftest import GOLDEN
+from oracle import oracle, ref
+from troy_amd import synth
+
+
+@pytest.fixture(scope="module")
+def ta():
+    import troy_amd
+    return troy_amd  # host-only contexts need neither a GPU nor KernelProvider::initialize
+
+
+def negacyclic_mul(a, b, t):
+    n = len(a)
+    out = [0] * n
+    for i, x in enumerate(a):
+        if not x:
+            continue
+        for j, y in enumerate(b):
+            k = i + j
+            v = int(x) * int(y)
+            if k >= n:
+                out[k - n] = (out[k - n] - v) % t
+            else:
+                out[k] = (out[k] + v) % t
+    return np.array(out, dtype=np.uint64)
+
+
+def test_cfgA_decrypt_fixture_and_add(ta):
+    f = np.load(os.path.join(GOLDEN, "cfgA_bfv_n4096_k3.npz"))
+    primes, t = [int(x) for x in f["primes"]], int(f["t"])
+    ctx = ta.SEALContext(ta.BFV, 4096, primes, t, host_only=True)
+    dec = ta.Decryptor(ctx, f["secret_key"])
+    assert np.array_equal(dec.decrypt(f["ct1"]), f["plain1"])
+    assert np.array_equal(dec.decrypt(f["ct2"]), f["plain2"])
+    q = np.array(primes[:2], dtype=np.uint64)[None, :, None]
+    s = (f["ct1"] + f["ct2"]) % q                       # addInplace on the host (limb-wise modular add)
+    assert cases.sha(s) == str(f["sum_sha256"])
+    assert np.array_equal(dec.decrypt(s), f["decrypted"])
+
+
+def test_cfgA_encrypt_with_reference_public_key(ta):
+    f = np.load(os.path.join(GOLDEN, "cfgA_bfv_n4096_k3.npz"))
+    primes, t = [int(x) for x in f["primes"]], int(f["t"])
+    ctx = ta.SEALContext(ta.BFV, 4096, primes, t, host_only=True)
+    enc = ta.Encryptor(ctx, f["public_key"], seed=(11, 12))
+    c1, c2 = enc.encrypt(f["plain1"]), enc.encrypt(f["plain2"])
+    assert not np.array_equal(c1, f["ct1"])              # our sampler, not the reference's PRNG
+    dec = ta.Decryptor(ctx, f["secret_key"])
+    assert np.array_equal(dec.decrypt(c1), f["plain1"])
+    q = np.array(primes[:2], dtype=np.uint64)[None, :, None]
+    assert np.array_equal(dec.decrypt((c1 + c2) % q), f["decrypted"])
+    O = oracle.Oracle(oracle.BFV, 4096, primes, t)
+    assert np.array_equal(O.decrypt(ref.Ct(c1), f["secret_key"]), f["plain1"])
+    if ref.available():                                    # the reference's own Decryptor accepts our ciphertext
+        R = ref.Ref(ref.BFV, 4096, primes, t)
+        R.set_secret_key(f["secret_key"])
+        d, budget = R.decrypt(ref.Ct(c1))
+        assert np.array_equal(d, f["plain1"]) and budget > 20
+
+
+@pytest.mark.parametrize("scheme,bits,tbits", [(1, [40, 40, 40, 40], 10), (3, [40, 36, 36, 40], 10)])
+def test_own_keys_roundtrip_and_keyswitch(scheme, bits, tbits, ta):
+    """own KeyGenerator: encrypt/decrypt round trip; relinearization and Galois keys drive the (oracle) evaluator and the
+    results decrypt to the negacyclic product / the automorphism of the plaintext"""
+    N = 128
+    primes = ta.CoeffModulus.Create(N, bits)
+    t = ta.PlainModulus.Batching(N, tbits)
+    ctx = ta.SEALContext(scheme, N, primes, t, host_only=True)
+    kg = ta.KeyGenerator(ctx, seed=(5, 6))
+    sk, pk = kg.secretKey(), kg.createPublicKey()
+    enc, dec = ta.Encryptor(ctx, pk), ta.Decryptor(ctx, sk)
+    rng = np.random.default_rng(3)
+    m1, m2 = rng.integers(0, t, N, dtype=np.uint64), rng.integers(0, t, N, dtype=np.uint64)
+    c1, c2 = enc.encrypt(m1), enc.encrypt(m2)
+    assert np.array_equal(dec.decrypt(c1), m1) and np.array_equal(dec.decrypt(c2), m2)
+    O = oracle.Oracle(scheme, N, primes, t)
+    assert np.array_equal(O.decrypt(ref.Ct(c1), sk), m1)
+    O.set_kswitch_key(0, kg.createRelinKeys())
+    g = ctx.galois_elt_from_step(1)
+    O.set_kswitch_key(g, kg.createGaloisKeys([g])[g])
+    prod = O.eval(ref.OP_RELIN, O.eval(ref.OP_MULTIPLY, ref.Ct(c1), ref.Ct(c2)))
+    assert np.array_equal(dec.decrypt(prod.data, correction_factor=prod.correction_factor), negacyclic_mul(m1, m2, t))
+    rot = O.eval(ref.OP_APPLY_GALOIS, ref.Ct(c1), iarg=g)
+    expect = oracle.apply_galois(N, g, t, m1)                 # m(X) -> m(X^g) on the plaintext polynomial
+    assert np.array_equal(dec.decrypt(rot.data), expect)
+    if ref.available():
+        R = ref.Ref(scheme, N, primes, t)
+        R.set_secret_key(sk)
+        assert np.array_equal(R.decrypt(ref.Ct(c1))[0], m1)   # reference Decryptor on our ciphertext + our key
+        R.set_public_key(pk)
+        c3 = R.encrypt(m2)                                    # reference Encryptor with OUR public key
+        assert np.array_equal(dec.decrypt(c3.data, correction_factor=c3.correction_factor), m2)
+
+
+def test_ckks_roundtrip(ta):
+    N, bits = 128, [40, 30, 30, 40]
+    primes = ta.CoeffModulus.Create(N, bits)
+    ctx = ta.SEALContext(ta.CKKS, N, primes, 0, host_only=True)
+    kg = ta.KeyGenerator(ctx, seed=(7, 8))
+    enc, dec = ta.Encryptor(ctx, kg.createPublicKey()), ta.Decryptor(ctx, kg.secretKey())
+    rng = np.random.default_rng(5)
+    coeffs = rng.integers(-(1 << 25), 1 << 25, N)                   # scaled plaintext polynomial, coefficient form
+    limbs = 3
+    plain = np.stack([oracle.ntt_standalone(N, p, np.array([int(c) % p for c in coeffs], dtype=np.uint64), 1) for p in primes[:limbs]])
+    ct = enc.encrypt(plain)
+    back = dec.decrypt(ct)
+    for l in range(limbs):
+        p = primes[l]
+        got = oracle.ntt_standalone(N, p, back[l], 3).astype(object)
+        centred = np.array([int(v) - p if int(v) > p // 2 else int(v) for v in got])
+        assert np.max(np.abs(centred - coeffs)) < 1 << 12         # fresh-encryption noise only
+
+
+def test_argument_errors(ta):
+    from troy_amd import capi
+    N = 128
+    primes = ta.CoeffModulus.Create(N, [40])
+    ctx = ta.SEALContext(ta.BFV, N, primes, ta.PlainModulus.Batching(N, 10), host_only=True)
+    kg = ta.KeyGenerator(ctx)
+    with pytest.raises(capi.LogicError):
+        kg.createRelinKeys()                                         # K = 1: key switching unsupported (context.cpp using_keyswitching)
+    with pytest.raises(capi.InvalidArgument):
+        ta.Encryptor(ctx, kg.createPublicKey()).encrypt(np.zeros(N + 1, dtype=np.uint64))  # plain longer than N

@@ -101,14 +101,17 @@ class PlainModulus:
 class SEALContext:
     """SEALContextCuda (src/context_cuda.cuh:146-186); SecurityLevel::none semantics."""
 
-    def __init__(self, scheme, poly_modulus_degree, coeff_modulus, plain_modulus=0):
+    def __init__(self, scheme, poly_modulus_degree, coeff_modulus, plain_modulus=0, host_only=False):
+        """host_only=True builds the tables on the host only (no GPU needed): enough for KeyGenerator/Encryptor/Decryptor"""
         self.lib = KernelProvider.lib()
+        self.host_only = bool(host_only)
         self.scheme, self.N = scheme, int(poly_modulus_degree)
         self.coeff_modulus = [int(p) for p in coeff_modulus]
         self.plain_modulus = int(plain_modulus)
         arr = np.array(self.coeff_modulus, dtype=np.uint64)
         h = C.c_void_p()
-        capi.check(self.lib, self.lib.troyhip_context_create(scheme, C.c_uint64(self.N), _u64p(arr), len(arr), C.c_uint64(self.plain_modulus), C.byref(h)))
+        create = self.lib.troyhip_context_create_host if self.host_only else self.lib.troyhip_context_create
+        capi.check(self.lib, create(scheme, C.c_uint64(self.N), _u64p(arr), len(arr), C.c_uint64(self.plain_modulus), C.byref(h)))
         self.h = h
         info = capi.ContextInfo()
         capi.check(self.lib, self.lib.troyhip_context_info(self.h, C.byref(info)))
@@ -419,3 +422,84 @@ class Evaluator:
         st = a.struct()
         self._chk(self.lib.troyhip_multiply_plain_ntt(self.context.h, C.byref(st), C.c_void_p(plain_ntt.ptr), C.c_double(plain_scale), C.c_uint64(a.batch), self.stream))
         a._absorb(st)
+
+
+# ---------------------------------------------------------------- CPU-side keys / encryption / decryption (host buffers)
+class KeyGenerator:
+    """KeyGeneratorCuda delegates to the CPU KeyGenerator in the reference (src/keygenerator_cuda.cuh); so does this one
+    (troy_amd/csrc/hostcrypto.cpp).  Keys are numpy arrays in the reference's layouts."""
+
+    def __init__(self, context, seed=(1, 2)):
+        self.context, self.lib, self.seed = context, context.lib, (int(seed[0]), int(seed[1]))
+        K, N = context.key_limbs, context.N
+        self._sk = np.zeros((K, N), dtype=np.uint64)
+        self._pk = np.zeros((2, K, N), dtype=np.uint64)
+        capi.check(self.lib, self.lib.troyhip_host_keygen(context.h, C.c_uint64(self.seed[0]), C.c_uint64(self.seed[1]), _u64p(self._sk), _u64p(self._pk)))
+
+    def secretKey(self):
+        return self._sk
+
+    def createPublicKey(self):
+        return self._pk
+
+    def _ksk(self):
+        K, N = self.context.key_limbs, self.context.N
+        return np.zeros((K - 1, 2, K, N), dtype=np.uint64)
+
+    def createRelinKeys(self):
+        out = self._ksk()
+        capi.check(self.lib, self.lib.troyhip_host_relin_key(self.context.h, C.c_uint64(self.seed[0]), C.c_uint64(self.seed[1]), _u64p(self._sk), _u64p(out)))
+        return out
+
+    def createGaloisKeys(self, galois_elts):
+        """returns {elt: host key array}"""
+        keys = {}
+        for e in galois_elts:
+            out = self._ksk()
+            capi.check(self.lib, self.lib.troyhip_host_galois_key(self.context.h, C.c_uint64(self.seed[0]), C.c_uint64(self.seed[1]), _u64p(self._sk), C.c_uint32(e), _u64p(out)))
+            keys[int(e)] = out
+        return keys
+
+
+class Encryptor:
+    """Encryptor::encrypt with a public key (src/encryptor.cpp:88-260), on the CPU."""
+
+    def __init__(self, context, public_key, seed=(3, 4)):
+        self.context, self.lib = context, context.lib
+        self.pk = np.ascontiguousarray(public_key, dtype=np.uint64)
+        self.seed, self.counter = (int(seed[0]), int(seed[1])), 0
+
+    def encrypt(self, plain, limbs=None):
+        """BFV/BGV: plain = coefficients mod t (<= N of them) -> uint64 [2][first_limbs][N];
+        CKKS: plain = [limbs][N] NTT-form RNS polynomial -> [2][limbs][N]"""
+        ctx = self.context
+        plain = np.ascontiguousarray(plain, dtype=np.uint64)
+        if ctx.scheme == CKKS:
+            limbs = plain.shape[0]
+            n = ctx.N
+        else:
+            limbs = ctx.first_limbs
+            n = plain.size
+        out = np.zeros((2, limbs, ctx.N), dtype=np.uint64)
+        self.counter += 1
+        capi.check(self.lib, self.lib.troyhip_host_encrypt(ctx.h, C.c_uint64(self.seed[0] + self.counter), C.c_uint64(self.seed[1]), _u64p(self.pk), _u64p(plain),
+                                                           C.c_uint64(n), limbs, _u64p(out)))
+        return out
+
+
+class Decryptor:
+    """Decryptor::decrypt (src/decryptor.cpp:115-371), on the CPU; deterministic."""
+
+    def __init__(self, context, secret_key):
+        self.context, self.lib = context, context.lib
+        self.sk = np.ascontiguousarray(secret_key, dtype=np.uint64)
+
+    def decrypt(self, ct, is_ntt_form=None, correction_factor=1):
+        ctx = self.context
+        ct = np.ascontiguousarray(ct, dtype=np.uint64)
+        size, limbs, N = ct.shape
+        if is_ntt_form is None:
+            is_ntt_form = ctx.scheme == CKKS
+        out = np.zeros(limbs * N if ctx.scheme == CKKS else N, dtype=np.uint64)
+        capi.check(self.lib, self.lib.troyhip_host_decrypt(ctx.h, _u64p(self.sk), _u64p(ct), size, limbs, int(is_ntt_form), C.c_uint64(correction_factor), _u64p(out)))
+        return out.reshape(limbs, N) if ctx.scheme == CKKS else out

@@ -2,6 +2,7 @@
 #include "../../include/troyhip.h"
 #include "evaluator.h"
 #include "kernels.h"
+#include "hostcrypto.h"
 #include <atomic>
 #include <cstring>
 #include <string>
@@ -11,7 +12,7 @@ using namespace troyhip;
 struct troyhip_context {
     Context ctx;
     Evaluator ev;
-    troyhip_context(int scheme, u64 N, const std::vector<u64> &q, u64 t) : ctx(scheme, N, q, t), ev(ctx) {}
+    troyhip_context(int scheme, u64 N, const std::vector<u64> &q, u64 t, bool device = true) : ctx(scheme, N, q, t, device), ev(ctx) {}
 };
 
 namespace {
@@ -117,14 +118,20 @@ int troyhip_context_create(int scheme, uint64_t N, const uint64_t *coeff_modulus
         *out = new troyhip_context(scheme, N, std::vector<u64>(coeff_modulus, coeff_modulus + K), plain_modulus);
     });
 }
-int troyhip_context_destroy(troyhip_context *ctx) { return guard([&] { delete ctx; }); }
+int troyhip_context_create_host(int scheme, uint64_t N, const uint64_t *coeff_modulus, int K, uint64_t plain_modulus, troyhip_context **out) {
+    return guard([&] {
+        if (!coeff_modulus || !out || K < 1) throw Error(ST_INVALID_ARGUMENT, "coeff_modulus is invalid");
+        *out = new troyhip_context(scheme, N, std::vector<u64>(coeff_modulus, coeff_modulus + K), plain_modulus, false);
+    }, false);
+}
+int troyhip_context_destroy(troyhip_context *ctx) { return guard([&] { delete ctx; }, false); }
 int troyhip_context_info(const troyhip_context *ctx, troyhip_context_info_t *out) {
     return guard([&] {
         if (!ctx || !out) throw Error(ST_INVALID_ARGUMENT, "null");
         const Context &c = ctx->ctx;
         out->scheme = c.scheme; out->poly_modulus_degree = c.N; out->key_limbs = c.K;
         out->first_limbs = c.first_limbs; out->last_limbs = c.last_limbs; out->plain_modulus = c.t;
-    });
+    }, false);
 }
 int troyhip_context_behz_bases(const troyhip_context *ctx, int limbs, uint64_t *bsk_out, int *bsk_size, uint64_t *gamma) {
     return guard([&] {
@@ -132,7 +139,7 @@ int troyhip_context_behz_bases(const troyhip_context *ctx, int limbs, uint64_t *
         std::copy(r.Bsk.begin(), r.Bsk.end(), bsk_out);
         *bsk_size = (int)r.Bsk.size();
         *gamma = r.gamma;
-    });
+    }, false);
 }
 int troyhip_context_ntt_tables(const troyhip_context *ctx, uint64_t prime, uint64_t *rop, uint64_t *rquo, uint64_t *iop, uint64_t *iquo,
                                uint64_t *inv_degree2, uint64_t *root) {
@@ -142,7 +149,7 @@ int troyhip_context_ntt_tables(const troyhip_context *ctx, uint64_t prime, uint6
         for (u64 i = 0; i < c.N; i++) { rop[i] = t.root[i].op; rquo[i] = t.root[i].quo; iop[i] = t.iroot[i].op; iquo[i] = t.iroot[i].quo; }
         inv_degree2[0] = t.inv_n.op; inv_degree2[1] = t.inv_n.quo;
         *root = t.psi;
-    });
+    }, false);
 }
 int troyhip_context_reserve_scratch(troyhip_context *ctx, size_t words) { return guard([&] { ctx->ctx.arena.reset(); ctx->ctx.arena.reserve(words); }); }
 int troyhip_context_scratch_words(const troyhip_context *ctx, int op, int limbs, uint64_t batch, size_t *words) {
@@ -152,7 +159,43 @@ int troyhip_context_scratch_words(const troyhip_context *ctx, int op, int limbs,
     });
 }
 int troyhip_galois_elt_from_step(const troyhip_context *ctx, int step, uint32_t *out) {
-    return guard([&] { *out = host::galois_elt_from_step(ctx->ctx.N, step); });
+    return guard([&] { *out = host::galois_elt_from_step(ctx->ctx.N, step); }, false);
+}
+
+// ---- CPU-side key generation / encryption / decryption (hostcrypto.cpp); all buffers are HOST memory ----
+int troyhip_host_keygen(const troyhip_context *ctx, uint64_t seed_lo, uint64_t seed_hi, uint64_t *secret_key, uint64_t *public_key) {
+    return guard([&] {
+        hostcrypto::Rng rng(seed_lo, seed_hi);
+        hostcrypto::keygen_secret(ctx->ctx, rng, secret_key);
+        if (public_key) hostcrypto::keygen_public(ctx->ctx, rng, secret_key, public_key);
+    }, false);
+}
+int troyhip_host_relin_key(const troyhip_context *ctx, uint64_t seed_lo, uint64_t seed_hi, const uint64_t *secret_key, uint64_t *out) {
+    return guard([&] {
+        hostcrypto::Rng rng(seed_lo ^ 0x52454C494Eull, seed_hi);
+        std::vector<u64> src((size_t)ctx->ctx.K * ctx->ctx.N);
+        hostcrypto::relin_source(ctx->ctx, secret_key, src.data());
+        hostcrypto::keygen_kswitch(ctx->ctx, rng, secret_key, src.data(), out);
+    }, false);
+}
+int troyhip_host_galois_key(const troyhip_context *ctx, uint64_t seed_lo, uint64_t seed_hi, const uint64_t *secret_key, uint32_t galois_elt, uint64_t *out) {
+    return guard([&] {
+        hostcrypto::Rng rng(seed_lo ^ ((u64)galois_elt << 20), seed_hi ^ 0x47414C4Full);
+        std::vector<u64> src((size_t)ctx->ctx.K * ctx->ctx.N);
+        hostcrypto::galois_source(ctx->ctx, secret_key, galois_elt, src.data());
+        hostcrypto::keygen_kswitch(ctx->ctx, rng, secret_key, src.data(), out);
+    }, false);
+}
+int troyhip_host_encrypt(const troyhip_context *ctx, uint64_t seed_lo, uint64_t seed_hi, const uint64_t *public_key, const uint64_t *plain,
+                         uint64_t n_coeffs, int limbs, uint64_t *ct_out) {
+    return guard([&] {
+        hostcrypto::Rng rng(seed_lo, seed_hi ^ 0x454E43ull);
+        hostcrypto::encrypt(ctx->ctx, rng, public_key, plain, n_coeffs, limbs, ct_out);
+    }, false);
+}
+int troyhip_host_decrypt(const troyhip_context *ctx, const uint64_t *secret_key, const uint64_t *ct, int size, int limbs, int is_ntt_form,
+                         uint64_t correction_factor, uint64_t *plain_out) {
+    return guard([&] { hostcrypto::decrypt(ctx->ctx, secret_key, ct, size, limbs, is_ntt_form != 0, correction_factor, plain_out); }, false);
 }
 
 int troyhip_ntt(troyhip_context *ctx, uint64_t *data, uint64_t rows, const uint64_t *row_primes, int period, int inner, int inverse, void *stream) {

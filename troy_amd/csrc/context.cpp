@@ -55,7 +55,8 @@ int Context::prime_id(u64 p) const {
     throw Error(ST_INVALID_ARGUMENT, "prime is not part of the context");
 }
 
-Context::Context(int scheme_, u64 N_, const std::vector<u64> &key_primes, u64 t_) : scheme(scheme_), N(N_), t(scheme_ == SCHEME_CKKS ? 0 : t_) {
+Context::Context(int scheme_, u64 N_, const std::vector<u64> &key_primes, u64 t_, bool with_device)
+    : has_device(with_device), scheme(scheme_), N(N_), t(scheme_ == SCHEME_CKKS ? 0 : t_) {
     if (scheme < SCHEME_BFV || scheme > SCHEME_BGV) throw Error(ST_INVALID_ARGUMENT, "unsupported scheme");
     if (N < 2 || N > 131072 || (N & (N - 1))) throw Error(ST_INVALID_ARGUMENT, "poly_modulus_degree is invalid");
     logn = 63 - __builtin_clzll(N);
@@ -85,7 +86,7 @@ Context::Context(int scheme_, u64 N_, const std::vector<u64> &key_primes, u64 t_
         last_limbs = limbs;
     }
     if (!has_level(first_limbs)) throw Error(ST_INVALID_ARGUMENT, "encryption parameters are not valid");
-    upload_tables();
+    if (has_device) upload_tables();
 }
 
 Context::~Context() {

@@ -41,7 +41,9 @@ struct Level {
 
 class Context {
 public:
-    Context(int scheme, u64 N, const std::vector<u64> &primes, u64 t);
+    // with_device = false builds the host tables only (no HIP call): enough for hostcrypto (config A plumbing)
+    Context(int scheme, u64 N, const std::vector<u64> &primes, u64 t, bool with_device = true);
+    bool has_device = true;
     ~Context();
     Context(const Context &) = delete;
     Context &operator=(const Context &) = delete;

@@ -10,6 +10,7 @@ namespace troyhip {
 static inline u64 poly_words(const Context &c, int limbs) { return (u64)limbs * c.N; }
 
 void Evaluator::check_ct(const CtBatch &a) const {
+    if (!c.has_device) throw Error(ST_LOGIC_ERROR, "this context was created host-only (troyhip_context_create_host)");
     if (!a.data) throw Error(ST_INVALID_ARGUMENT, "encrypted is not valid for encryption parameters");
     if (!c.is_data_level(a.limbs)) throw Error(ST_INVALID_ARGUMENT, "encrypted is not valid for encryption parameters");
     if (a.size < 1 || a.size > 16) throw Error(ST_INVALID_ARGUMENT, "encrypted is not valid for encryption parameters");

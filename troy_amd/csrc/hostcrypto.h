@@ -1,0 +1,31 @@
+// hostcrypto.h -- CPU-side key generation / encryption / decryption (see hostcrypto.cpp).
+#pragma once
+#include "context.h"
+
+namespace troyhip {
+namespace hostcrypto {
+
+class Rng { // ChaCha20 keystream keyed by a 128-bit seed
+public:
+    Rng(u64 seed_lo, u64 seed_hi);
+    uint32_t next32();
+    u64 next64();
+    u64 uniform_below(u64 bound);
+private:
+    void refill();
+    uint32_t state[16], block[16];
+    int pos;
+};
+
+void ntt_forward(u64 *a, const host::NttTable &t);
+void ntt_inverse(u64 *a, const host::NttTable &t);
+void keygen_secret(const Context &c, Rng &rng, u64 *sk);                                   // [K][N] NTT form
+void keygen_public(const Context &c, Rng &rng, const u64 *sk, u64 *pk);                    // [2][K][N] NTT form
+void keygen_kswitch(const Context &c, Rng &rng, const u64 *sk, const u64 *new_key, u64 *out); // [K-1][2][K][N]
+void relin_source(const Context &c, const u64 *sk, u64 *out);
+void galois_source(const Context &c, const u64 *sk, uint32_t elt, u64 *out);
+void encrypt(const Context &c, Rng &rng, const u64 *pk, const u64 *plain, size_t n_coeffs, int limbs, u64 *ct);
+void decrypt(const Context &c, const u64 *sk, const u64 *ct, int size, int limbs, bool is_ntt, u64 correction_factor, u64 *out);
+
+} // namespace hostcrypto
+} // namespace troyhip
