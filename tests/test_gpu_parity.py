@@ -238,3 +238,37 @@ def test_error_conventions(gpu):
         gpu.SEALContext(gpu.BFV, 128, [be.primes[0], be.primes[0]], be.t)  # duplicate primes
     with pytest.raises(capi.InvalidArgument):
         gpu.SEALContext(gpu.BFV, 100, be.primes, be.t)       # N not a power of two
+
+
+@pytest.mark.parametrize("scheme,bits,tbits", [(1, [40, 40, 40, 40], 10), (3, [40, 36, 36, 40], 10)])
+def test_end_to_end_own_keys(scheme, bits, tbits, gpu):
+    """the whole chain with the product's own keys: host keygen/encrypt -> GPU multiply, relinearize, mod-switch, rotate ->
+    host decrypt == plaintext arithmetic (negacyclic product, automorphism)"""
+    from test_hostcrypto import negacyclic_mul
+    from oracle import oracle
+    N = 128
+    primes = gpu.CoeffModulus.Create(N, bits)
+    t = gpu.PlainModulus.Batching(N, tbits)
+    ctx = gpu.SEALContext(scheme, N, primes, t)
+    kg = gpu.KeyGenerator(ctx, seed=(21, 22))
+    enc, dec = gpu.Encryptor(ctx, kg.createPublicKey()), gpu.Decryptor(ctx, kg.secretKey())
+    rlk, gk = gpu.RelinKeys(ctx), gpu.GaloisKeys(ctx)
+    rlk.set(0, kg.createRelinKeys())
+    g = ctx.galois_elt_from_step(1)
+    gk.set_elt(g, kg.createGaloisKeys([g])[g])
+    rng = np.random.default_rng(9)
+    B = 3
+    m1 = rng.integers(0, t, (B, N), dtype=np.uint64)
+    m2 = rng.integers(0, t, (B, N), dtype=np.uint64)
+    a = gpu.Ciphertext.from_numpy(ctx, np.stack([enc.encrypt(m1[b]) for b in range(B)]))
+    b = gpu.Ciphertext.from_numpy(ctx, np.stack([enc.encrypt(m2[b]) for b in range(B)]))
+    ev = gpu.Evaluator(ctx)
+    r = ev.multiply(a, b)
+    ev.relinearizeInplace(r, rlk)
+    r = ev.modSwitchToNext(r)
+    ev.applyGaloisInplace(r, g, gk)
+    out = r.cpu()
+    for i in range(B):
+        prod = negacyclic_mul(m1[i], m2[i], t)
+        expect = oracle.apply_galois(N, g, t, prod)
+        assert np.array_equal(dec.decrypt(out[i], correction_factor=r.correction_factor), expect), i
