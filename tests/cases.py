@@ -30,10 +30,11 @@ CONFIGS = {
     "bgv_n4096_k3": dict(scheme=BGV, N=4096, bits=[36, 36, 37], tbits=20),
     "cfgNS_bfv_n32768_k15": dict(scheme=BFV, N=32768, bits=[60] + [58] * 13 + [60], tbits=20),
     "cfgC_ckks_n32768_k15": dict(scheme=CKKS, N=32768, bits=[60] + [40] * 13 + [60], tbits=0),
+    "cfgD_bgv_n65536_k15": dict(scheme=BGV, N=65536, bits=[60] + [50] * 13 + [60], tbits=20),  # relinearize + rotateRows
 }
 SMALL = ["bfv_n64_k3", "bfv_n128_k4", "bfv_n128_k5_60", "ckks_n128_k6", "bgv_n128_k4"]
 MEDIUM = ["cfgA_bfv_n4096_k3", "cfgB_bfv_n8192_k5", "ckks_n4096_k4", "bgv_n4096_k3"]
-LARGE = ["cfgNS_bfv_n32768_k15", "cfgC_ckks_n32768_k15"]
+LARGE = ["cfgNS_bfv_n32768_k15", "cfgC_ckks_n32768_k15", "cfgD_bgv_n65536_k15"]
 
 KEY_STEPS = (1, -1, 4)  # Galois keys present; rotations by 5 = naf [1, 4] and 3 = naf [-1, 4] exercise the NAF path
 SEED = 0x5EED

@@ -272,3 +272,32 @@ def test_end_to_end_own_keys(scheme, bits, tbits, gpu):
         prod = negacyclic_mul(m1[i], m2[i], t)
         expect = oracle.apply_galois(N, g, t, prod)
         assert np.array_equal(dec.decrypt(out[i], correction_factor=r.correction_factor), expect), i
+
+
+def test_cfgE_ckks_matmul_semantics(gpu, oracle_lib):
+    """BASELINE config E at evaluator level (app/LinearHelperCKKS.cuh:227-248): for every batch row b,
+    out[b][j] = sum_i multiplyPlain(a[b][i], W[i][j]) with addInplace, NTT form; the batch dimension is the shard axis"""
+    from oracle import ref
+    from troy_amd import synth
+    cfg = cases.CONFIGS["ckks_n4096_k4"]
+    be, ob = cases.GpuBackend(cfg), cases.oracle_backend(cfg)
+    N, q = cfg["N"], be.primes[:3]
+    B, I, J = 4, 3, 2
+    a = [synth.uniform_ct(900 + i, q, 2, N, B) for i in range(I)]                    # a[i]: batch of B ciphertexts
+    W = [[synth.uniform_rows(950 + i * J + j, q, 3, N) for j in range(J)] for i in range(I)]
+    for j in range(J):
+        acc = None
+        for i in range(I):
+            prod = gpu.Ciphertext.from_numpy(be.ctx, a[i], True)
+            be.ev.multiplyPlainInplace(prod, gpu.DeviceBuffer.from_numpy(W[i][j]))
+            if acc is None:
+                acc = prod
+            else:
+                be.ev.addInplace(acc, prod)
+        got = acc.cpu()
+        for b in range(B):
+            e = None
+            for i in range(I):
+                p = ob.multiply_plain(ref.Ct(a[i][b], True), W[i][j])
+                e = p if e is None else ob.add(e, p)
+            assert np.array_equal(got[b], e.data), (j, b)
