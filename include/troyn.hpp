@@ -1,0 +1,408 @@
+// troyn.hpp -- header-only C++ mirror of the reference's troyn:: interface (src/troy_cuda.cuh:20-43) over the C ABI
+// of libtroyhip.so (include/troyhip.h).  Same class and method names, argument meaning and exception classes as the
+// reference for the in-scope surface: user code written as
+//
+//     #include "troy_cuda.cuh"          ->   #include "troyn.hpp"
+//     using namespace troyn;
+//     KernelProvider::initialize();
+//     EncryptionParameters parms(SchemeType::bfv); ... SEALContext context(parms, true, SecurityLevel::none);
+//     KeyGenerator keygen(context); Encryptor encryptor(context, pk); Evaluator evaluator(context); ...
+//
+// compiles against it.  Key generation, encryption and decryption run on the CPU (as KeyGeneratorCuda does in the
+// reference, src/keygenerator_cuda.cuh); everything in EvaluatorCuda's hot path runs on the GPU.  Out of scope here
+// exactly as in SURVEY.md section 2: encoders (BatchEncoder/CKKSEncoder), serialization, symmetric encryption.
+// No HIP headers are needed: the ABI is plain pointers, sizes and status codes.
+#pragma once
+#include "troyhip.h"
+#include <algorithm>
+#include <cstdint>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+namespace troyn {
+
+inline void check(int rc) { // status -> the reference's exception classes
+    if (rc == TROYHIP_OK) return;
+    const std::string m = troyhip_last_error();
+    switch (rc) {
+    case TROYHIP_INVALID_ARGUMENT:
+    case TROYHIP_NOT_INITIALIZED: throw std::invalid_argument(m);
+    case TROYHIP_LOGIC_ERROR: throw std::logic_error(m);
+    case TROYHIP_OUT_OF_RANGE: throw std::out_of_range(m);
+    default: throw std::runtime_error(m); // "CUDA error." in the reference (src/kernelprovider.cuh:6-14)
+    }
+}
+
+enum class SchemeType : uint8_t { none = 0, bfv = 1, ckks = 2, bgv = 3 }; // src/encryptionparams.h
+enum class SecurityLevel : int { none = 0, tc128 = 128, tc192 = 192, tc256 = 256 };
+
+class KernelProvider { // src/kernelprovider.cuh:24-33
+public:
+    static void initialize(int device = 0) { check(troyhip_initialize(device)); }
+};
+
+class Modulus { // src/modulus.h:16-24 (value only; Barrett constants live inside the library)
+public:
+    Modulus(uint64_t v = 0) : value_(v) {}
+    uint64_t value() const { return value_; }
+    bool isZero() const { return value_ == 0; }
+private:
+    uint64_t value_;
+};
+
+struct CoeffModulus { // src/modulus.h:485
+    static std::vector<Modulus> Create(size_t poly_modulus_degree, std::vector<int> bit_sizes) {
+        std::vector<uint64_t> out(bit_sizes.size());
+        check(troyhip_coeff_modulus_create(poly_modulus_degree, bit_sizes.data(), (int)bit_sizes.size(), out.data()));
+        return std::vector<Modulus>(out.begin(), out.end());
+    }
+};
+struct PlainModulus { // src/modulus.h:528
+    static Modulus Batching(size_t poly_modulus_degree, int bit_size) {
+        uint64_t v;
+        check(troyhip_plain_modulus_batching(poly_modulus_degree, bit_size, &v));
+        return Modulus(v);
+    }
+};
+
+class EncryptionParameters { // src/encryptionparams_cuda.cuh:63-170
+public:
+    explicit EncryptionParameters(SchemeType s = SchemeType::none) : scheme_(s) {}
+    void setPolyModulusDegree(size_t n) { n_ = n; }
+    void setCoeffModulus(const std::vector<Modulus> &q) { q_ = q; }
+    void setPlainModulus(const Modulus &t) { t_ = t; }
+    void setPlainModulus(uint64_t t) { t_ = Modulus(t); }
+    SchemeType scheme() const { return scheme_; }
+    size_t polyModulusDegree() const { return n_; }
+    const std::vector<Modulus> &coeffModulus() const { return q_; }
+    const Modulus &plainModulus() const { return t_; }
+private:
+    SchemeType scheme_;
+    size_t n_ = 0;
+    std::vector<Modulus> q_;
+    Modulus t_;
+};
+
+using ParmsID = int; // the level is identified by its limb count (the reference hashes the parameters, src/encryptionparams.cpp:118-146)
+
+class SEALContext { // src/context_cuda.cuh:146-186
+public:
+    SEALContext(const EncryptionParameters &parms, bool expand_mod_chain = true, SecurityLevel sec = SecurityLevel::tc128) : parms_(parms) {
+        (void)expand_mod_chain;
+        (void)sec; // SecurityLevel::none semantics: parameter security is not policed
+        std::vector<uint64_t> q;
+        for (auto &m : parms.coeffModulus()) q.push_back(m.value());
+        troyhip_context *c = nullptr;
+        check(troyhip_context_create((int)parms.scheme(), parms.polyModulusDegree(), q.data(), (int)q.size(), parms.plainModulus().value(), &c));
+        ctx_.reset(c, [](troyhip_context *p) { troyhip_context_destroy(p); });
+        check(troyhip_context_info(c, &info_));
+    }
+    troyhip_context *handle() const { return ctx_.get(); }
+    const EncryptionParameters &parms() const { return parms_; }
+    ParmsID keyParmsID() const { return info_.key_limbs; }
+    ParmsID firstParmsID() const { return info_.first_limbs; }
+    ParmsID lastParmsID() const { return info_.last_limbs; }
+    size_t polyModulusDegree() const { return info_.poly_modulus_degree; }
+    size_t keyLimbs() const { return (size_t)info_.key_limbs; }
+private:
+    EncryptionParameters parms_;
+    std::shared_ptr<troyhip_context> ctx_;
+    troyhip_context_info_t info_{};
+};
+
+// DeviceArray<uint64_t> (src/utils/devicearray.cuh): deep copy on copy, steal on move
+class DeviceArray {
+public:
+    DeviceArray() = default;
+    explicit DeviceArray(size_t words) { resize(words); }
+    DeviceArray(const DeviceArray &o) { *this = o; }
+    DeviceArray(DeviceArray &&o) noexcept : p_(o.p_), n_(o.n_) { o.p_ = nullptr; o.n_ = 0; }
+    DeviceArray &operator=(const DeviceArray &o) {
+        if (this == &o) return *this;
+        resize(o.n_);
+        if (n_) check(troyhip_copy_d2d(p_, o.p_, n_ * 8, nullptr));
+        return *this;
+    }
+    DeviceArray &operator=(DeviceArray &&o) noexcept { std::swap(p_, o.p_); std::swap(n_, o.n_); return *this; }
+    ~DeviceArray() { if (p_) troyhip_free(p_); }
+    void resize(size_t words) {
+        if (words == n_) return;
+        uint64_t *np = nullptr;
+        if (words) check(troyhip_malloc((void **)&np, words * 8));
+        if (p_ && np) check(troyhip_copy_d2d(np, p_, std::min(words, n_) * 8, nullptr));
+        if (p_) { check(troyhip_stream_synchronize(nullptr)); troyhip_free(p_); }
+        p_ = np;
+        n_ = words;
+    }
+    uint64_t *get() const { return p_; }
+    size_t size() const { return n_; }
+private:
+    uint64_t *p_ = nullptr;
+    size_t n_ = 0;
+};
+
+class Plaintext { // src/plaintext.h: host coefficients (BFV/BGV: mod t; CKKS / NTT-form multiplyPlain: [limbs][N])
+public:
+    Plaintext() = default;
+    explicit Plaintext(const std::vector<uint64_t> &coeffs) : data_(coeffs) {}
+    // "1x^10 + 2"-style constructor of the reference is not reproduced; use setCoeff
+    void resize(size_t n) { data_.resize(n, 0); }
+    size_t coeffCount() const { return data_.size(); }
+    uint64_t *data() { return data_.data(); }
+    const uint64_t *data() const { return data_.data(); }
+    uint64_t &operator[](size_t i) { return data_[i]; }
+    const uint64_t &operator[](size_t i) const { return data_[i]; }
+    bool operator==(const Plaintext &o) const {
+        size_t n = std::max(data_.size(), o.data_.size());
+        for (size_t i = 0; i < n; i++)
+            if ((i < data_.size() ? data_[i] : 0) != (i < o.data_.size() ? o.data_[i] : 0)) return false;
+        return true;
+    }
+    double &scale() { return scale_; }
+private:
+    std::vector<uint64_t> data_;
+    double scale_ = 1.0;
+};
+
+class Ciphertext { // src/ciphertext_cuda.cuh:12-268
+public:
+    Ciphertext() = default;
+    explicit Ciphertext(const SEALContext &c) : n_(c.polyModulusDegree()) {}
+    size_t size() const { return (size_t)d_.size; }
+    size_t coeffModulusSize() const { return (size_t)d_.limbs; }
+    size_t polyModulusDegree() const { return n_; }
+    ParmsID parmsID() const { return d_.limbs; }
+    bool isNttForm() const { return d_.is_ntt_form != 0; }
+    bool &isNttFormRef() { ntt_shadow_ = d_.is_ntt_form != 0; return ntt_shadow_; }
+    double &scale() { return d_.scale; }
+    double scale() const { return d_.scale; }
+    uint64_t &correctionFactor() { return d_.correction_factor; }
+    uint64_t correctionFactor() const { return d_.correction_factor; }
+    // device storage is kept at capacity max(size, 3) polynomials so multiply / relinearize run in place
+    void resize(size_t n, size_t limbs, size_t size) {
+        n_ = n;
+        const size_t cap = std::max<size_t>(size, 3);
+        buf_.resize(cap * limbs * n);
+        d_.data = buf_.get();
+        d_.batch_stride = cap * limbs * n;
+        d_.size = (int)size;
+        d_.limbs = (int)limbs;
+    }
+    std::vector<uint64_t> toHost() const { // CiphertextCuda::cpu / toHost: [size][limbs][N]
+        std::vector<uint64_t> h(size() * coeffModulusSize() * n_);
+        if (!h.empty()) check(troyhip_copy_d2h(h.data(), d_.data, h.size() * 8, nullptr));
+        return h;
+    }
+    void fromHost(const std::vector<uint64_t> &h, size_t n, size_t limbs, size_t size, bool ntt, double scale = 1.0, uint64_t cf = 1) {
+        resize(n, limbs, size);
+        if (h.size() != size * limbs * n) throw std::invalid_argument("encrypted is not valid for encryption parameters");
+        check(troyhip_copy_h2d(d_.data, h.data(), h.size() * 8, nullptr));
+        d_.is_ntt_form = ntt; d_.scale = scale; d_.correction_factor = cf;
+    }
+    troyhip_ct *raw() { d_.data = buf_.get(); return &d_; }
+    const troyhip_ct *raw() const { return &d_; }
+    // value semantics: deep copy
+    Ciphertext(const Ciphertext &o) : buf_(o.buf_), d_(o.d_), n_(o.n_) { d_.data = buf_.get(); }
+    Ciphertext(Ciphertext &&o) noexcept = default;
+    Ciphertext &operator=(const Ciphertext &o) { buf_ = o.buf_; d_ = o.d_; n_ = o.n_; d_.data = buf_.get(); return *this; }
+    Ciphertext &operator=(Ciphertext &&o) noexcept = default;
+private:
+    DeviceArray buf_;
+    troyhip_ct d_{nullptr, 0, 0, 0, 0, 1.0, 1};
+    size_t n_ = 0;
+    bool ntt_shadow_ = false;
+};
+
+class SecretKey { public: std::vector<uint64_t> data; };  // [K][N] NTT form (host), src/secretkey.h
+class PublicKey { public: std::vector<uint64_t> data; };  // [2][K][N] NTT form (host), src/publickey.h
+
+class KSwitchKeys { // src/kswitchkeys_cuda.cuh:43-56: data()[index] on the device, uploaded from the host key
+public:
+    bool hasKeyIndex(size_t index) const { return keys_.count(index) != 0; }
+    const uint64_t *device(size_t index) const { return keys_.at(index)->get(); }
+    void upload(size_t index, const std::vector<uint64_t> &host) {
+        auto a = std::make_shared<DeviceArray>(host.size());
+        check(troyhip_copy_h2d(a->get(), host.data(), host.size() * 8, nullptr));
+        keys_[index] = a;
+    }
+    const std::map<size_t, std::shared_ptr<DeviceArray>> &all() const { return keys_; }
+protected:
+    std::map<size_t, std::shared_ptr<DeviceArray>> keys_;
+};
+class RelinKeys : public KSwitchKeys { // src/relinkeys_cuda.cuh:56-59
+public:
+    static size_t getIndex(size_t key_power) {
+        if (key_power < 2) throw std::invalid_argument("key_power cannot be less than 2");
+        return key_power - 2;
+    }
+    bool hasKey(size_t key_power) const { return hasKeyIndex(getIndex(key_power)); }
+};
+class GaloisKeys : public KSwitchKeys { // src/galoiskeys_cuda.cuh:74-77
+public:
+    static size_t getIndex(uint32_t galois_elt) { return (galois_elt - 1) >> 1; } // src/utils/galois_cuda.cuh:45-48
+    bool hasKey(uint32_t galois_elt) const { return hasKeyIndex(getIndex(galois_elt)); }
+};
+
+class KeyGenerator { // src/keygenerator_cuda.cuh: runs on the CPU
+public:
+    explicit KeyGenerator(const SEALContext &c, uint64_t seed_lo = 0x7472, uint64_t seed_hi = 0x6f79) : c_(c), lo_(seed_lo), hi_(seed_hi) {
+        const size_t K = c.keyLimbs(), N = c.polyModulusDegree();
+        sk_.data.resize(K * N);
+        pk_.data.resize(2 * K * N);
+        check(troyhip_host_keygen(c.handle(), lo_, hi_, sk_.data.data(), pk_.data.data()));
+    }
+    const SecretKey &secretKey() const { return sk_; }
+    void createPublicKey(PublicKey &pk) const { pk = pk_; }
+    PublicKey createPublicKey() const { return pk_; }
+    void createRelinKeys(RelinKeys &rlk) const {
+        std::vector<uint64_t> h(ksk_words());
+        check(troyhip_host_relin_key(c_.handle(), lo_, hi_, sk_.data.data(), h.data()));
+        rlk.upload(RelinKeys::getIndex(2), h);
+    }
+    RelinKeys createRelinKeys() const { RelinKeys r; createRelinKeys(r); return r; }
+    void createGaloisKeys(const std::vector<uint32_t> &galois_elts, GaloisKeys &gk) const {
+        for (uint32_t e : galois_elts) {
+            std::vector<uint64_t> h(ksk_words());
+            check(troyhip_host_galois_key(c_.handle(), lo_, hi_, sk_.data.data(), e, h.data()));
+            gk.upload(GaloisKeys::getIndex(e), h);
+        }
+    }
+    void createGaloisKeys(const std::vector<int> &steps, GaloisKeys &gk) const {
+        std::vector<uint32_t> elts;
+        for (int s : steps) { uint32_t e; check(troyhip_galois_elt_from_step(c_.handle(), s, &e)); elts.push_back(e); }
+        createGaloisKeys(elts, gk);
+    }
+private:
+    size_t ksk_words() const { const size_t K = c_.keyLimbs(); return (K - 1) * 2 * K * c_.polyModulusDegree(); }
+    const SEALContext &c_;
+    uint64_t lo_, hi_;
+    SecretKey sk_;
+    PublicKey pk_;
+};
+
+class Encryptor { // src/encryptor_cuda.cuh (public-key path), CPU sampling + upload
+public:
+    Encryptor(const SEALContext &c, const PublicKey &pk, uint64_t seed = 0x656e63) : c_(c), pk_(pk), seed_(seed) {}
+    void encrypt(const Plaintext &plain, Ciphertext &dst) const {
+        const size_t N = c_.polyModulusDegree();
+        const bool ckks = c_.parms().scheme() == SchemeType::ckks;
+        const int limbs = ckks ? (int)(plain.coeffCount() / N) : c_.firstParmsID();
+        std::vector<uint64_t> h((size_t)2 * limbs * N);
+        check(troyhip_host_encrypt(c_.handle(), seed_ + (++counter_), 0x70, pk_.data.data(), plain.data(), ckks ? N : plain.coeffCount(), limbs, h.data()));
+        dst.fromHost(h, N, limbs, 2, ckks, 1.0, 1);
+    }
+private:
+    const SEALContext &c_;
+    PublicKey pk_;
+    uint64_t seed_;
+    mutable uint64_t counter_ = 0;
+};
+
+class Decryptor { // src/decryptor_cuda.cuh: download + CPU decryption (deterministic)
+public:
+    Decryptor(const SEALContext &c, const SecretKey &sk) : c_(c), sk_(sk) {}
+    void decrypt(const Ciphertext &ct, Plaintext &dst) const {
+        const size_t N = c_.polyModulusDegree();
+        const bool ckks = c_.parms().scheme() == SchemeType::ckks;
+        std::vector<uint64_t> h = ct.toHost();
+        dst.resize(ckks ? ct.coeffModulusSize() * N : N);
+        check(troyhip_host_decrypt(c_.handle(), sk_.data.data(), h.data(), (int)ct.size(), (int)ct.coeffModulusSize(), ct.isNttForm(), ct.correctionFactor(), dst.data()));
+    }
+private:
+    const SEALContext &c_;
+    SecretKey sk_;
+};
+
+class Evaluator { // src/evaluator_cuda.cuh:13-361 -- every method const, non-copyable
+public:
+    explicit Evaluator(const SEALContext &c) : c_(c) {}
+    Evaluator(const Evaluator &) = delete;
+    Evaluator &operator=(const Evaluator &) = delete;
+
+    void negateInplace(Ciphertext &a) const { check(troyhip_negate(h(), a.raw(), 1, nullptr)); }
+    void negate(const Ciphertext &a, Ciphertext &d) const { d = a; negateInplace(d); }
+    void addInplace(Ciphertext &a, const Ciphertext &b) const { check(troyhip_add(h(), a.raw(), b.raw(), 1, nullptr)); }
+    void add(const Ciphertext &a, const Ciphertext &b, Ciphertext &d) const { d = a; addInplace(d, b); }
+    void addMany(const std::vector<Ciphertext> &v, Ciphertext &d) const {
+        if (v.empty()) throw std::invalid_argument("encrypteds cannot be empty");
+        d = v[0];
+        for (size_t i = 1; i < v.size(); i++) addInplace(d, v[i]);
+    }
+    void subInplace(Ciphertext &a, const Ciphertext &b) const { check(troyhip_sub(h(), a.raw(), b.raw(), 1, nullptr)); }
+    void sub(const Ciphertext &a, const Ciphertext &b, Ciphertext &d) const { d = a; subInplace(d, b); }
+    void multiplyInplace(Ciphertext &a, const Ciphertext &b) const {
+        grow(a, a.size() + b.size() - 1);
+        check(troyhip_multiply(h(), a.raw(), b.raw(), a.raw(), 1, nullptr));
+    }
+    void multiply(const Ciphertext &a, const Ciphertext &b, Ciphertext &d) const { d = a; multiplyInplace(d, b); }
+    void squareInplace(Ciphertext &a) const { multiplyInplace(a, a); }
+    void square(const Ciphertext &a, Ciphertext &d) const { d = a; squareInplace(d); }
+    void relinearizeInplace(Ciphertext &a, const RelinKeys &k) const {
+        if (a.size() > 2 && !k.hasKey(2)) throw std::invalid_argument("not enough relinearization keys");
+        check(troyhip_relinearize(h(), a.raw(), a.size() > 2 ? k.device(RelinKeys::getIndex(2)) : nullptr, 1, nullptr));
+    }
+    void relinearize(const Ciphertext &a, const RelinKeys &k, Ciphertext &d) const { d = a; relinearizeInplace(d, k); }
+    void modSwitchToNextInplace(Ciphertext &a) const { next(a, troyhip_mod_switch_to_next); }
+    void modSwitchToNext(const Ciphertext &a, Ciphertext &d) const { d = a; modSwitchToNextInplace(d); }
+    void modSwitchToInplace(Ciphertext &a, ParmsID parms_id) const {
+        if (parms_id > a.parmsID()) throw std::invalid_argument("cannot switch to higher level modulus");
+        while (a.parmsID() != parms_id) modSwitchToNextInplace(a);
+    }
+    void rescaleToNextInplace(Ciphertext &a) const { next(a, troyhip_rescale_to_next); }
+    void rescaleToNext(const Ciphertext &a, Ciphertext &d) const { d = a; rescaleToNextInplace(d); }
+    void rescaleToInplace(Ciphertext &a, ParmsID parms_id) const {
+        if (parms_id > a.parmsID()) throw std::invalid_argument("cannot switch to higher level modulus");
+        while (a.parmsID() != parms_id) rescaleToNextInplace(a);
+    }
+    void applyGaloisInplace(Ciphertext &a, uint32_t galois_elt, const GaloisKeys &gk) const {
+        if (!gk.hasKey(galois_elt)) throw std::invalid_argument("Galois key not present");
+        check(troyhip_apply_galois(h(), a.raw(), galois_elt, gk.device(GaloisKeys::getIndex(galois_elt)), 1, nullptr));
+    }
+    void rotateRowsInplace(Ciphertext &a, int steps, const GaloisKeys &gk) const { need(SchemeType::ckks, false); rotate(a, steps, 0, gk); }
+    void rotateColumnsInplace(Ciphertext &a, const GaloisKeys &gk) const { need(SchemeType::ckks, false); rotate(a, 0, 1, gk); }
+    void rotateVectorInplace(Ciphertext &a, int steps, const GaloisKeys &gk) const { need(SchemeType::ckks, true); rotate(a, steps, 0, gk); }
+    void complexConjugateInplace(Ciphertext &a, const GaloisKeys &gk) const { need(SchemeType::ckks, true); rotate(a, 0, 1, gk); }
+    void transformToNttInplace(Ciphertext &a) const { check(troyhip_transform_to_ntt(h(), a.raw(), 1, nullptr)); }
+    void transformFromNttInplace(Ciphertext &a) const { check(troyhip_transform_from_ntt(h(), a.raw(), 1, nullptr)); }
+    // NTT-form operands (multiplyPlainNtt, evaluator_cuda.cu:1824-1863); plain = [limbs][N] host coefficients in NTT form
+    void multiplyPlainInplace(Ciphertext &a, const Plaintext &plain_ntt) const {
+        DeviceArray p(plain_ntt.coeffCount());
+        check(troyhip_copy_h2d(p.get(), plain_ntt.data(), plain_ntt.coeffCount() * 8, nullptr));
+        check(troyhip_multiply_plain_ntt(h(), a.raw(), p.get(), const_cast<Plaintext &>(plain_ntt).scale(), 1, nullptr));
+        check(troyhip_stream_synchronize(nullptr));
+    }
+
+private:
+    troyhip_context *h() const { return c_.handle(); }
+    void need(SchemeType s, bool equal) const {
+        if ((c_.parms().scheme() == s) != equal) throw std::logic_error("unsupported scheme");
+    }
+    static void grow(Ciphertext &a, size_t size) { // keep device capacity >= size (and >= 3)
+        if (a.raw()->batch_stride < size * a.coeffModulusSize() * a.polyModulusDegree()) {
+            Ciphertext b;
+            b.resize(a.polyModulusDegree(), a.coeffModulusSize(), size);
+            check(troyhip_copy_d2d(b.raw()->data, a.raw()->data, a.size() * a.coeffModulusSize() * a.polyModulusDegree() * 8, nullptr));
+            troyhip_ct *rb = b.raw();
+            rb->size = a.raw()->size; rb->is_ntt_form = a.raw()->is_ntt_form; rb->scale = a.raw()->scale; rb->correction_factor = a.raw()->correction_factor;
+            a = std::move(b);
+        }
+    }
+    template <class F> void next(Ciphertext &a, F fn) const {
+        Ciphertext out;
+        out.resize(a.polyModulusDegree(), a.coeffModulusSize() > 1 ? a.coeffModulusSize() - 1 : 1, a.size());
+        check(fn(h(), a.raw(), out.raw(), 1, nullptr));
+        a = std::move(out);
+    }
+    void rotate(Ciphertext &a, int steps, int conj, const GaloisKeys &gk) const {
+        std::vector<uint32_t> elts;
+        std::vector<const uint64_t *> ptrs;
+        for (auto &kv : gk.all()) { elts.push_back((uint32_t)(2 * kv.first + 1)); ptrs.push_back(kv.second->get()); }
+        check(troyhip_rotate(h(), a.raw(), steps, conj, elts.data(), ptrs.data(), (int)elts.size(), 1, nullptr));
+    }
+    const SEALContext &c_;
+};
+
+} // namespace troyn

@@ -1,0 +1,159 @@
+// Drop-in check of include/troyn.hpp: user code written against the reference's troyn:: interface
+// (src/troy_cuda.cuh) -- KernelProvider::initialize, EncryptionParameters, SEALContext, KeyGenerator, Encryptor,
+// Evaluator, Decryptor -- compiled with plain g++ and linked to libtroyhip.so.  The scenarios follow the reference's
+// own evaluator tests (test/evaluator.cu style: encrypt, operate on the GPU, decrypt, compare with the plaintext
+// computation), with polynomial plaintexts because encoders are out of scope.
+#include "troyn.hpp"
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+
+using namespace troyn;
+
+static int failures = 0;
+#define EXPECT(cond, what)                                              \
+    do {                                                                \
+        if (!(cond)) { std::printf("FAIL %s (%s:%d)\n", what, __FILE__, __LINE__); failures++; } \
+        else std::printf("ok   %s\n", what);                            \
+    } while (0)
+
+using Poly = std::vector<uint64_t>;
+
+static Poly negacyclic_mul(const Poly &a, const Poly &b, uint64_t t) {
+    const size_t n = a.size();
+    Poly r(n, 0);
+    for (size_t i = 0; i < n; i++) {
+        if (!a[i]) continue;
+        for (size_t j = 0; j < n; j++) {
+            if (!b[j]) continue;
+            unsigned __int128 v = (unsigned __int128)a[i] * b[j] % t;
+            size_t k = i + j;
+            if (k >= n) { k -= n; v = (t - (uint64_t)v) % t; }
+            r[k] = (uint64_t)((r[k] + (uint64_t)v) % t);
+        }
+    }
+    return r;
+}
+static Poly automorphism(const Poly &a, uint32_t elt, uint64_t t) { // x -> x^elt in Z_t[x]/(x^n+1)
+    const size_t n = a.size();
+    Poly r(n, 0);
+    for (size_t i = 0; i < n; i++) {
+        size_t k = (size_t)((uint64_t)i * elt % (2 * n));
+        if (k >= n) r[k - n] = (t - a[i]) % t; else r[k] = a[i];
+    }
+    return r;
+}
+static Poly sparse_poly(size_t n, uint64_t t, unsigned seed, size_t terms) {
+    std::mt19937_64 g(seed);
+    Poly p(n, 0);
+    for (size_t i = 0; i < terms; i++) p[g() % n] = g() % t;
+    return p;
+}
+static Poly dense_poly(size_t n, uint64_t t, unsigned seed) {
+    std::mt19937_64 g(seed);
+    Poly p(n);
+    for (auto &x : p) x = g() % t;
+    return p;
+}
+
+static void scenario(SchemeType scheme, size_t n, std::vector<int> bits, int tbits) {
+    std::printf("-- scheme %d N=%zu K=%zu\n", (int)scheme, n, bits.size());
+    EncryptionParameters parms(scheme);
+    parms.setPolyModulusDegree(n);
+    parms.setCoeffModulus(CoeffModulus::Create(n, bits));
+    parms.setPlainModulus(PlainModulus::Batching(n, tbits));
+    SEALContext context(parms, true, SecurityLevel::none);
+    const uint64_t t = parms.plainModulus().value();
+
+    KeyGenerator keygen(context);
+    PublicKey pk = keygen.createPublicKey();
+    RelinKeys rlk = keygen.createRelinKeys();
+    GaloisKeys gk;
+    keygen.createGaloisKeys(std::vector<int>{1, -1, 4}, gk);
+    Encryptor encryptor(context, pk);
+    Decryptor decryptor(context, keygen.secretKey());
+    Evaluator evaluator(context);
+
+    const Poly va = dense_poly(n, t, 1), vb = sparse_poly(n, t, 2, 24);
+    Plaintext pa(va), pb(vb), out;
+    Ciphertext a, b, c;
+    encryptor.encrypt(pa, a);
+    encryptor.encrypt(pb, b);
+    decryptor.decrypt(a, out);
+    EXPECT(out == pa, "encrypt -> decrypt");
+
+    // add / sub / negate
+    evaluator.add(a, b, c);
+    decryptor.decrypt(c, out);
+    Poly want(n);
+    for (size_t i = 0; i < n; i++) want[i] = (pa[i] + pb[i]) % t;
+    EXPECT(out == Plaintext(want), "add");
+    evaluator.subInplace(c, b);
+    evaluator.negateInplace(c);
+    decryptor.decrypt(c, out);
+    for (size_t i = 0; i < n; i++) want[i] = (t - pa[i]) % t;
+    EXPECT(out == Plaintext(want), "sub, negate");
+
+    // multiply + relinearize (BASELINE config A: BFVRelinearize)
+    evaluator.multiply(a, b, c);
+    EXPECT(c.size() == 3, "multiply gives size 3");
+    Poly prod = negacyclic_mul(vb, va, t);
+    decryptor.decrypt(c, out);
+    EXPECT(out == Plaintext(prod), "decrypt size-3 product");
+    evaluator.relinearizeInplace(c, rlk);
+    EXPECT(c.size() == 2, "relinearize gives size 2");
+    decryptor.decrypt(c, out);
+    EXPECT(out == Plaintext(prod), "multiply + relinearize");
+
+    // mod switch keeps the plaintext
+    Ciphertext d;
+    evaluator.modSwitchToNext(c, d);
+    EXPECT(d.coeffModulusSize() + 1 == c.coeffModulusSize(), "modSwitchToNext drops a limb");
+    decryptor.decrypt(d, out);
+    EXPECT(out == Plaintext(prod), "modSwitchToNext");
+
+    // Galois automorphism and NAF rotation (steps 3 = 4 - 1 with keys {1,-1,4})
+    uint32_t e1 = 0;
+    check(troyhip_galois_elt_from_step(context.handle(), 1, &e1));
+    Ciphertext g = a;
+    evaluator.applyGaloisInplace(g, e1, gk);
+    decryptor.decrypt(g, out);
+    EXPECT(out == Plaintext(automorphism(va, e1, t)), "applyGalois");
+    Ciphertext r = a;
+    evaluator.rotateRowsInplace(r, 3, gk);
+    Poly w = va;
+    uint32_t e4 = 0, em1 = 0;
+    check(troyhip_galois_elt_from_step(context.handle(), 4, &e4));
+    check(troyhip_galois_elt_from_step(context.handle(), -1, &em1));
+    w = automorphism(automorphism(w, e4, t), em1, t);
+    decryptor.decrypt(r, out);
+    EXPECT(out == Plaintext(w), "rotateRows(3) by NAF");
+
+    // error behaviour: same exception classes as the reference
+    bool threw = false;
+    try { GaloisKeys none; evaluator.applyGaloisInplace(g, e1, none); } catch (const std::invalid_argument &) { threw = true; }
+    EXPECT(threw, "missing Galois key -> invalid_argument");
+    threw = false;
+    try { evaluator.rotateVectorInplace(g, 1, gk); } catch (const std::logic_error &) { threw = true; }
+    EXPECT(threw, "rotateVector on BFV/BGV -> logic_error");
+    threw = false;
+    try { evaluator.addInplace(c, d); } catch (const std::invalid_argument &) { threw = true; }
+    EXPECT(threw, "level mismatch -> invalid_argument");
+}
+
+int main() {
+    bool threw = false;
+    try {
+        EncryptionParameters p(SchemeType::bfv);
+        p.setPolyModulusDegree(4096);
+        p.setCoeffModulus(CoeffModulus::Create(4096, {40, 40, 40}));
+        p.setPlainModulus(PlainModulus::Batching(4096, 20));
+        SEALContext c(p, true, SecurityLevel::none);
+    } catch (const std::invalid_argument &) { threw = true; }
+    EXPECT(threw, "context before KernelProvider::initialize -> invalid_argument");
+    KernelProvider::initialize();
+    scenario(SchemeType::bfv, 4096, {40, 40, 40}, 20);   // BASELINE config A shape
+    scenario(SchemeType::bgv, 8192, {50, 40, 40, 50}, 20);
+    std::printf(failures ? "FAILED %d\n" : "ALL OK\n", failures);
+    return failures ? 1 : 0;
+}

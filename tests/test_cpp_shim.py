@@ -1,0 +1,36 @@
+"""include/troyn.hpp -- the C++ mirror of the reference's troyn:: interface (src/troy_cuda.cuh) -- compiled with plain g++
+from user-style code (tests/cpp/test_troyn.cpp).  CPU: linked against the emulator build of the same sources
+(host logic + ABI shape);  GPU: linked against libtroyhip.so and run on the device."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "tests", "cpp", "test_troyn.cpp")
+
+
+def _build(out, libdir, libfile):
+    cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), SRC, "-o", out,
+           os.path.join(libdir, libfile), "-Wl,-rpath," + libdir, "-Wl,-rpath-link,/opt/rocm/lib"]
+    subprocess.run(cmd, check=True, capture_output=True, text=True)
+
+
+def _run(exe):
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ALL OK" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "FAIL" not in r.stdout
+
+
+def test_troyn_header_on_emulator(tmp_path):
+    subprocess.check_call(["make", "-s", "-j8", "-C", os.path.join(ROOT, "troy_amd", "csrc"), "emul"])
+    exe = str(tmp_path / "test_troyn_emul")
+    _build(exe, os.path.join(ROOT, "tests", "emul"), "libtroyhip_emul.so")
+    _run(exe)
+
+
+@pytest.mark.gpu
+def test_troyn_header_on_gpu(tmp_path):
+    exe = str(tmp_path / "test_troyn")
+    _build(exe, os.path.join(ROOT, "troy_amd"), "libtroyhip.so")
+    _run(exe)
