@@ -21,6 +21,11 @@
 
 namespace troyhip {
 
+// tools/ntt_probe.sh builds throw-away variants with parts of the kernel removed to see what bounds it (results are
+// wrong by construction): bit0 no HBM traffic, bit1 no LDS exchange, bit2 no butterflies.  Always 0 in the product.
+#ifndef N2_EXP
+#define N2_EXP 0
+#endif
 #define N2_THREADS 256
 #define N2_LOGT 11
 #define N2_T 2048
@@ -118,6 +123,11 @@ template <int INV, int STRIDED, int NS, int LOGC, int LS, int R> struct Round {
     }
     // every stage = exactly four independent butterflies per thread -> one ct_bfly4 / gs_bfly4 call
     __device__ static __forceinline__ void compute(u64 (&x)[8], const Shoup (&tw)[G][NTW], const PrimeDesc &pd) {
+        if (N2_EXP & 4) {
+#pragma unroll
+            for (int u = 0; u < G; u++) x[u] ^= tw[u][0].op;
+            return;
+        }
         const PrimeConst pc = make_prime_const(pd.p);
 #pragma unroll
         for (int st = 0; st < R; st++) {
@@ -163,12 +173,14 @@ template <int INV, int STRIDED, int NS, int LOGC, int LS, int R> struct Round {
         }
     }
     __device__ static __forceinline__ void lds_read(u64 (&x)[8], const u64 *lds) {
+        if (N2_EXP & 2) return;
 #pragma unroll
         for (int u = 0; u < G; u++)
 #pragma unroll
             for (int e = 0; e < (1 << R); e++) x[(u << R) + e] = lds[swz(elem(threadIdx.x + N2_THREADS * u, e))];
     }
     __device__ static __forceinline__ void lds_write(const u64 (&x)[8], u64 *lds) {
+        if (N2_EXP & 2) return;
 #pragma unroll
         for (int u = 0; u < G; u++)
 #pragma unroll
@@ -176,6 +188,11 @@ template <int INV, int STRIDED, int NS, int LOGC, int LS, int R> struct Round {
     }
     // global access; consecutive-element runs are moved 16 bytes at a time
     template <int REDUCE> __device__ static __forceinline__ void g_read(u64 (&x)[8], const u64 *row, unsigned tile, int logn, const Mod &m) {
+        if (N2_EXP & 1) {
+#pragma unroll
+            for (int e = 0; e < 8; e++) x[e] = (u64)(uintptr_t)row + threadIdx.x * 8 + e;
+            return;
+        }
 #pragma unroll
         for (int u = 0; u < G; u++) {
             const unsigned q = threadIdx.x + N2_THREADS * u;
@@ -196,6 +213,13 @@ template <int INV, int STRIDED, int NS, int LOGC, int LS, int R> struct Round {
     // FINAL: 0 keep lazy range, 1 forward final ([0,8p) -> [0,p)), 2 inverse final ([0,4p) -> [0,p))
     template <int FINAL> __device__ static __forceinline__ void g_write(u64 (&x)[8], u64 *row, unsigned tile, int logn, u64 p, u64 two_p) {
         (void)two_p;
+        if (N2_EXP & 1) {
+            u64 acc = 0;
+#pragma unroll
+            for (int e = 0; e < 8; e++) acc ^= x[e];
+            if (acc == 0x123456789abcdefull) row[threadIdx.x] = acc; // never true in practice; keeps the work alive
+            return;
+        }
         if (FINAL) {
             const PrimeConst pc = make_prime_const(p);
 #pragma unroll
@@ -251,6 +275,7 @@ __global__ __launch_bounds__(N2_THREADS, N2_MIN_WAVES) void ntt2_kernel(Ntt2Args
     // needs no workgroup barrier at all: the four waves run fully decoupled and overlap each other's HBM phases.
     constexpr bool WAVE_PRIVATE = !STRIDED && NS == 9;
     auto round_sync = [&]() {
+        if (N2_EXP & 2) return;
         if (WAVE_PRIVATE) TROY_WAVE_SYNC(); else __syncthreads();
     };
     // inverse passes run the same round list but with growing gaps, so their local-stage offsets are the same sums
