@@ -28,7 +28,7 @@ def emul_api():
 @pytest.mark.parametrize("name", cases.SMALL + ["cfgA_bfv_n4096_k3"])
 def test_emulated_kernels_match_reference(name, emul_api, golden_hashes, golden_params):
     cfg = cases.CONFIGS[name]
-    be = cases.GpuBackend(cfg, batch=2 if cfg["N"] <= 128 else 1)
+    be = cases.GpuBackend(cfg, batch=5 if cfg["N"] <= 128 else 1)  # 5 = one blocked group of 4 + a remainder (ks_mac)
     gp = golden_params[name]
     assert [str(p) for p in be.primes] == gp["primes"] and str(be.t) == gp["plain_modulus"]
     for limbs, lv in gp["levels"].items():

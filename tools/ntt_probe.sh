@@ -18,5 +18,6 @@ for v in "$@"; do
         base) build base ;;
         exp*) build $v -DN2_EXP=${v#exp} ;;
         w*) build $v -DN2_MIN_WAVES=${v#w} ;;
+        *:*) build ${v%%:*} ${v#*:} ;;   # name:-Dflag -Dflag
     esac
 done

@@ -282,26 +282,74 @@ __global__ __launch_bounds__(EW_THREADS) void ks_expand_kernel(const u64 *target
 }
 // acc[b][k][i][n] = sum_j opnd(b,i,j)[n] * key[j][k][limb(i)][n] mod p_i ; operands canonical (< 2^61)
 // ckks_target != nullptr: operand (i == j) comes from the NTT-form input itself (evaluator.cpp:2424-2427)
-__global__ __launch_bounds__(EW_THREADS) void ks_mac_kernel(const u64 *D, const u64 *key, const u64 *ckks_target, u64 t_bstride, u64 *acc, KsArgs a) {
-    u64 idx = (u64)blockIdx.x * EW_THREADS + threadIdx.x; // over batch * (dl+1) * N
+// A thread owns V consecutive coefficients of NB consecutive batch items: every key word it loads is used NB times
+// (the key is re-read once per NB ciphertexts instead of once per ciphertext; it is the dominant L2 stream of this kernel).
+#ifndef KS_MAC_NB
+#define KS_MAC_NB 4
+#endif
+#ifndef KS_MAC_V
+#define KS_MAC_V 2
+#endif
+template <int NB, int V> __global__ __launch_bounds__(EW_THREADS) void ks_mac_kernel(const u64 *D, const u64 *key, const u64 *ckks_target, u64 t_bstride, u64 *acc, KsArgs a) {
+    const u64 idx = (u64)blockIdx.x * EW_THREADS + threadIdx.x; // over (batch / NB) * (dl+1) * (N / V)
     const u64 N = u64(1) << a.logn, rl = a.dl + 1;
-    if (idx >= a.batch * rl * N) return;
-    u64 n = idx & (N - 1), bi = idx >> a.logn, i = bi % rl, b = bi / rl;
+    const int logv = V == 2 ? 1 : 0;
+    if (idx >= (a.batch / NB) * rl << (a.logn - logv)) return;
+    const u64 n = (idx & ((N >> logv) - 1)) << logv, bi = idx >> (a.logn - logv), i = bi % rl, b0 = (bi / rl) * NB;
     const Mod m = mod_of(a.primes[a.key_id[i]]);
     const u64 kl = a.key_limb[i];
-    U128 s0{0, 0}, s1{0, 0};
+    U128 s0[NB][V], s1[NB][V];
+#pragma unroll
+    for (int b = 0; b < NB; b++)
+#pragma unroll
+        for (int v = 0; v < V; v++) s0[b][v] = s1[b][v] = U128{0, 0};
     for (u64 j = 0; j < a.dl; j++) {
-        u64 x = (ckks_target && i == j) ? ckks_target[b * t_bstride + j * N + n] : D[((b * rl + i) * a.dl + j) * N + n];
         const u64 *kp = key + ((j * 2) * a.K + kl) * N + n;
-        mac128(s0, x, kp[0]);
-        mac128(s1, x, kp[a.K * N]);
+        u64 k0[V], k1[V];
+        if (V == 2) {
+            const ulonglong2 t0 = *reinterpret_cast<const ulonglong2 *>(kp), t1 = *reinterpret_cast<const ulonglong2 *>(kp + a.K * N);
+            k0[0] = t0.x; k0[V - 1] = t0.y; k1[0] = t1.x; k1[V - 1] = t1.y;
+        } else {
+            k0[0] = kp[0]; k1[0] = kp[a.K * N];
+        }
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
+            const u64 *xp = (ckks_target && i == j) ? ckks_target + (b0 + b) * t_bstride + j * N + n : D + (((b0 + b) * rl + i) * a.dl + j) * N + n;
+            u64 x[V];
+            if (V == 2) {
+                const ulonglong2 t = *reinterpret_cast<const ulonglong2 *>(xp);
+                x[0] = t.x; x[V - 1] = t.y;
+            } else {
+                x[0] = xp[0];
+            }
+#pragma unroll
+            for (int v = 0; v < V; v++) { mac128(s0[b][v], x[v], k0[v]); mac128(s1[b][v], x[v], k1[v]); }
+        }
         if ((j & 127) == 127) { // 2^61 * 2^61 * 128 < 2^128: fold long sums (the reference folds every 256 terms)
-            s0.lo = barrett128(s0.lo, s0.hi, m); s0.hi = 0;
-            s1.lo = barrett128(s1.lo, s1.hi, m); s1.hi = 0;
+#pragma unroll
+            for (int b = 0; b < NB; b++)
+#pragma unroll
+                for (int v = 0; v < V; v++) {
+                    s0[b][v].lo = barrett128(s0[b][v].lo, s0[b][v].hi, m); s0[b][v].hi = 0;
+                    s1[b][v].lo = barrett128(s1[b][v].lo, s1[b][v].hi, m); s1[b][v].hi = 0;
+                }
         }
     }
-    acc[((b * 2 + 0) * rl + i) * N + n] = barrett128(s0.lo, s0.hi, m);
-    acc[((b * 2 + 1) * rl + i) * N + n] = barrett128(s1.lo, s1.hi, m);
+#pragma unroll
+    for (int b = 0; b < NB; b++) {
+        u64 r0[V], r1[V];
+#pragma unroll
+        for (int v = 0; v < V; v++) { r0[v] = barrett128(s0[b][v].lo, s0[b][v].hi, m); r1[v] = barrett128(s1[b][v].lo, s1[b][v].hi, m); }
+        u64 *o0 = acc + (((b0 + b) * 2 + 0) * rl + i) * N + n, *o1 = acc + (((b0 + b) * 2 + 1) * rl + i) * N + n;
+        if (V == 2) {
+            ulonglong2 t0, t1;
+            t0.x = r0[0]; t0.y = r0[V - 1]; t1.x = r1[0]; t1.y = r1[V - 1];
+            *reinterpret_cast<ulonglong2 *>(o0) = t0;
+            *reinterpret_cast<ulonglong2 *>(o1) = t1;
+        } else {
+            o0[0] = r0[0]; o1[0] = r1[0];
+        }
+    }
 }
 // BFV (kind 0) / BGV (kind 2) mod-down, everything in coefficient form (evaluator.cpp:2528-2648):
 //   ct[b][k][j][n] += (acc_j - [t']_{q_j} + [half]_{q_j}) * qk^-1 mod q_j, t' = (acc_last + half) mod qk       (BFV)
@@ -361,10 +409,26 @@ void launch_ks_expand(const u64 *target, u64 t_bstride, u64 *D, const KsArgs &a,
     TROY_LAUNCH(ks_expand_kernel, dim3(ceil_div(total, EW_THREADS)), dim3(EW_THREADS), 0, s, target, t_bstride, D, a);
     launch_check("ks_expand_kernel");
 }
-void launch_ks_mac(const u64 *D, const u64 *key, const u64 *ckks_target, u64 t_bstride, u64 *acc, const KsArgs &a, hipStream_t s) {
-    u64 total = a.batch * (a.dl + 1) << a.logn;
-    TROY_LAUNCH(ks_mac_kernel, dim3(ceil_div(total, EW_THREADS)), dim3(EW_THREADS), 0, s, D, key, ckks_target, t_bstride, acc, a);
+template <int NB, int V> static void launch_ks_mac_t(const u64 *D, const u64 *key, const u64 *ckks_target, u64 t_bstride, u64 *acc, const KsArgs &a, hipStream_t s) {
+    const u64 total = (a.batch / NB) * (a.dl + 1) << (a.logn - (V == 2 ? 1 : 0));
+    TROY_LAUNCH(HIP_KERNEL_NAME(ks_mac_kernel<NB, V>), dim3(ceil_div(total, EW_THREADS)), dim3(EW_THREADS), 0, s, D, key, ckks_target, t_bstride, acc, a);
     launch_check("ks_mac_kernel");
+}
+void launch_ks_mac(const u64 *D, const u64 *key, const u64 *ckks_target, u64 t_bstride, u64 *acc, const KsArgs &a, hipStream_t s) {
+    // batches that are not a multiple of the blocking factor: the blocked kernel takes the largest multiple, the rest goes one by one
+    const u64 nb_main = a.batch / KS_MAC_NB * KS_MAC_NB;
+    if (nb_main) {
+        KsArgs m = a;
+        m.batch = nb_main;
+        launch_ks_mac_t<KS_MAC_NB, KS_MAC_V>(D, key, ckks_target, t_bstride, acc, m, s);
+    }
+    if (nb_main < a.batch) {
+        KsArgs r = a;
+        r.batch = a.batch - nb_main;
+        const u64 rl = a.dl + 1, N = u64(1) << a.logn;
+        launch_ks_mac_t<1, KS_MAC_V>(D + nb_main * rl * a.dl * N, key, ckks_target ? ckks_target + nb_main * t_bstride : nullptr, t_bstride,
+                                     acc + nb_main * 2 * rl * N, r, s);
+    }
 }
 void launch_ks_moddown(int kind, const u64 *acc, u64 *ct, u64 ct_bstride, const KsArgs &a, hipStream_t s) {
     u64 total = a.batch * 2 * a.dl << a.logn;
