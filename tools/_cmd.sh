@@ -1,5 +1,7 @@
-for v in mac41 mac81 mac22 mac82; do
-cp tools/probe_libs/libtroyhip_$v.so troy_amd/libtroyhip.so
-(cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_$v -o p -- python3 $GRAFT_REPO_ROOT/bench.py --batch 16 --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1)
-echo $v; python tools/kstats.py gpurun_out/prof_$v/p_kernel_stats.csv 12 | grep ks_mac
-done
+python -m pytest tests/test_gpu_parity.py -q -x -m gpu 2>&1 | tail -2
+python tools/ntt_probe.py tools/probe_libs/libtroyhip_nocs.so 16 | tail -1
+python tools/ntt_probe.py troy_amd/libtroyhip.so 16 | tail -1
+python tools/ntt_probe.py tools/probe_libs/libtroyhip_exp6.so 16 | tail -1
+python tools/ntt_probe.py tools/probe_libs/libtroyhip_nocs.so 32 | tail -1
+python tools/ntt_probe.py troy_amd/libtroyhip.so 32 | tail -1
+python bench.py --batch 32 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('B32', d['value'], d['ms_per_step'], d['roofline']['achieved'])"

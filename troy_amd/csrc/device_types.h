@@ -23,7 +23,18 @@ struct LimbMap {
 #ifdef TROYHIP_CPU_EMUL
 #define TROY_WAVE_SYNC() hip_emul::park(2) /* all live lanes of the wave arrive before any proceeds */
 #define TROY_DYN_LDS(type, name) static type name[160 * 1024 / sizeof(type)]
+// LDS-DMA: lane l of the wave copies 16 bytes from its own global address to (wave-uniform LDS base) + 16*l
+#define TROY_GLDS16(gptr, lds_base) memcpy((char *)(lds_base) + 16 * (threadIdx.x & 63), (const void *)(gptr), 16)
+#define TROY_WAIT_VMEM() hip_emul::park(2) /* lanes run one after another here: every lane's copy must have happened */
+#define TROY_WAIT_LDS() hip_emul::park(2)  /* ... and every lane must have read before any lane overwrites */
 #else
+// global_load_lds_dwordx4 (gfx950): no VGPR round trip, completion is counted by vmcnt; hipcc does NOT order later LDS
+// reads after it, so every consumer waits explicitly (TROY_WAIT_VMEM) and every overwrite of a staging buffer is
+// issued only after the reads of its previous content returned (TROY_WAIT_LDS).
+#define TROY_GLDS16(gptr, lds_base)                                                                                      \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gptr), (__attribute__((address_space(3))) void *)(lds_base), 16, 0, 0)
+#define TROY_WAIT_VMEM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define TROY_WAIT_LDS() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 // LDS operations of one wave execute in order, so intra-wave exchange needs no s_barrier; this only stops the
 // compiler from moving LDS accesses across the exchange point
 #define TROY_WAVE_SYNC() __builtin_amdgcn_wave_barrier()

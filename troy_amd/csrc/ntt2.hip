@@ -26,6 +26,18 @@ namespace troyhip {
 #ifndef N2_EXP
 #define N2_EXP 0
 #endif
+#ifndef N2_MIN_WAVES
+#define N2_MIN_WAVES 4
+#endif
+#ifndef N2_PREFETCH
+#define N2_PREFETCH 0
+#endif
+#ifndef N2_DMA
+#define N2_DMA 1 // contiguous passes prefetch the next row with LDS-DMA
+#endif
+#ifndef N2_COALESCED_STORE
+#define N2_COALESCED_STORE 1 // forward contiguous pass: transpose the last round through LDS, store 1 KiB per instruction
+#endif
 #define N2_THREADS 256
 #define N2_LOGT 11
 #define N2_T 2048
@@ -186,6 +198,59 @@ template <int INV, int STRIDED, int NS, int LOGC, int LS, int R> struct Round {
 #pragma unroll
             for (int e = 0; e < (1 << R); e++) lds[swz(elem(threadIdx.x + N2_THREADS * u, e))] = x[(u << R) + e];
     }
+    // ---- LDS-DMA staging of the first round's input (contiguous passes): the next row streams into a wave-private
+    // 4 KiB staging area while the current row is being transformed, without holding VGPRs for it.  Every DMA
+    // instruction moves one CONTIGUOUS 1 KiB chunk (full 128-byte lines); the DMA destination is lane-linear, so any
+    // permutation is applied to which 16-byte unit of the chunk a lane fetches:
+    // forward (LOGD = 6): the wave reads lane + 64 e -> identity, staging is the sub-transform in natural order;
+    // inverse (LOGD = 0): thread t owns units 4t..4t+3 (chunk t/16); lane 16 j + a fetches unit 4a + j, so unit 4a + j
+    // sits in slot 16 j + a and the four ds_read_b128 of a thread hit slots (t % 16) + 16 j: the 16 lanes of every
+    // ds_read_b128 lane group see 16 different slots mod 16 (conflict-free).
+    __device__ static __forceinline__ unsigned unit_perm(unsigned lane) { return 4 * (lane & 15) + (lane >> 4); }
+    __device__ static __forceinline__ void stage_issue(const u64 *row, unsigned tile, u64 *wave_stage) {
+        static_assert(!STRIDED && NS == 9 && R == 3 && LS == 0, "staging is defined for the first round of the contiguous pass");
+        const unsigned lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        const u64 *src = row + ((size_t)tile << N2_LOGT) + 512 * w + 2 * (INV ? unit_perm(lane) : lane);
+#pragma unroll
+        for (int i = 0; i < 4; i++) TROY_GLDS16(src + 128 * i, wave_stage + 128 * i);
+    }
+    __device__ static __forceinline__ void stage_read(u64 (&x)[8], const u64 *wave_stage) {
+        const unsigned lane = threadIdx.x & 63;
+        if (INV) {
+            const u64 *mine = wave_stage + 128 * (lane >> 4) + 2 * (lane & 15);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(mine + 32 * j);
+                x[2 * j] = v.x;
+                x[2 * j + 1] = v.y;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; e++) x[e] = wave_stage[lane + 64 * e];
+        }
+    }
+    // Last round of the forward contiguous pass (LOGD = 0): thread t holds 64 contiguous bytes.  Written directly that
+    // is four stores of 16 bytes every 64 bytes (each touching all 32 lines of the wave's 4 KiB); instead the wave
+    // transposes through its private exchange area with the same unit permutation and issues four stores of one
+    // contiguous 1 KiB each.
+    __device__ static __forceinline__ void store_via_lds(const u64 (&x)[8], u64 *row, unsigned tile, u64 *wave_xchg) {
+        const unsigned lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        u64 *mine = wave_xchg + 128 * (lane >> 4) + 2 * (lane & 15);
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            ulonglong2 v;
+            v.x = x[2 * j];
+            v.y = x[2 * j + 1];
+            *reinterpret_cast<ulonglong2 *>(mine + 32 * j) = v;
+        }
+        TROY_WAVE_SYNC();
+        u64 *dst = row + ((size_t)tile << N2_LOGT) + 512 * w + 2 * unit_perm(lane);
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(wave_xchg + 128 * c + 2 * lane);
+            *reinterpret_cast<ulonglong2 *>(dst + 128 * c) = v;
+        }
+    }
     // global access; consecutive-element runs are moved 16 bytes at a time
     template <int REDUCE> __device__ static __forceinline__ void g_read(u64 (&x)[8], const u64 *row, unsigned tile, int logn, const Mod &m) {
         if (N2_EXP & 1) {
@@ -211,7 +276,7 @@ template <int INV, int STRIDED, int NS, int LOGC, int LS, int R> struct Round {
         (void)m;
     }
     // FINAL: 0 keep lazy range, 1 forward final ([0,8p) -> [0,p)), 2 inverse final ([0,4p) -> [0,p))
-    template <int FINAL> __device__ static __forceinline__ void g_write(u64 (&x)[8], u64 *row, unsigned tile, int logn, u64 p, u64 two_p) {
+    template <int FINAL> __device__ static __forceinline__ void g_write(u64 (&x)[8], u64 *row, unsigned tile, int logn, u64 p, u64 two_p, u64 *xchg = nullptr) {
         (void)two_p;
         if (N2_EXP & 1) {
             u64 acc = 0;
@@ -228,6 +293,13 @@ template <int INV, int STRIDED, int NS, int LOGC, int LS, int R> struct Round {
                 if (FINAL == 1) reduce4_from_8p(v, pc); else reduce4_from_4p(v, pc);
 #pragma unroll
                 for (int i = 0; i < 4; i++) x[4 * h + i] = v[i];
+            }
+        }
+        if constexpr (N2_COALESCED_STORE && !STRIDED && !INV && NS == 9 && R == 3 && LOGD == 0) {
+            if (xchg) {
+                TROY_WAVE_SYNC(); // the exchange area was last read by this round's lds_read
+                store_via_lds(x, row, tile, xchg + 512 * (threadIdx.x >> 6));
+                return;
             }
         }
 #pragma unroll
@@ -260,12 +332,6 @@ template <> struct Plan<9> { static constexpr int r[4] = {3, 3, 3, 0}; };
 template <> struct Plan<10> { static constexpr int r[4] = {3, 3, 3, 1}; };
 template <> struct Plan<11> { static constexpr int r[4] = {3, 3, 3, 2}; };
 
-#ifndef N2_MIN_WAVES
-#define N2_MIN_WAVES 4
-#endif
-#ifndef N2_PREFETCH
-#define N2_PREFETCH 0
-#endif
 template <int INV, int STRIDED, int NS, int LOGC, int FINAL, int REDUCE>
 __global__ __launch_bounds__(N2_THREADS, N2_MIN_WAVES) void ntt2_kernel(Ntt2Args a) {
     __shared__ u64 lds[2][N2_T];
@@ -317,21 +383,34 @@ __global__ __launch_bounds__(N2_THREADS, N2_MIN_WAVES) void ntt2_kernel(Ntt2Args
         row = a.data + (r << logn);
         in = (REDUCE || a.src) ? (a.src + (u64)o * a.src_ostride + ((u64)k << logn)) : row;
     };
+    constexpr bool DMA = N2_DMA && WAVE_PRIVATE && !(N2_EXP & 1);
+    u64 *const wave_stage = lds[1] + 512 * (threadIdx.x >> 6);
     u64 x[8], nx[8];
     {
         u64 *row0; const u64 *in0;
         row_ptrs(m_begin, row0, in0);
-        Rd0::template g_read<REDUCE>(x, in0, tile, logn, m);
+        if constexpr (DMA) Rd0::stage_issue(in0, tile, wave_stage);
+        else Rd0::template g_read<REDUCE>(x, in0, tile, logn, m);
     }
     for (unsigned mm = m_begin; mm < m_end; mm++) {
         u64 *row; const u64 *in;
         row_ptrs(mm, row, in);
-        if (N2_PREFETCH && mm + 1 < m_end) {
+        if constexpr (DMA) {
+            TROY_WAIT_VMEM();            // this wave's staged row has landed (and its previous stores are out)
+            Rd0::stage_read(x, wave_stage);
+            TROY_WAIT_LDS();             // ... and has been read before the next row overwrites it
+            if (mm + 1 < m_end) {
+                u64 *nrow; const u64 *nin;
+                row_ptrs(mm + 1, nrow, nin);
+                Rd0::stage_issue(nin, tile, wave_stage);
+            }
+        }
+        if (!DMA && N2_PREFETCH && mm + 1 < m_end) {
             u64 *nrow; const u64 *nin;
             row_ptrs(mm + 1, nrow, nin);
             Rd0::template g_read<REDUCE>(nx, nin, tile, logn, m);
         }
-        u64 *buf = lds[mm & 1];
+        u64 *buf = DMA ? lds[0] : lds[mm & 1];
         if (REDUCE) {
 #pragma unroll
             for (int e = 0; e < 8; e++) x[e] = barrett64(x[e], m);
@@ -355,7 +434,7 @@ __global__ __launch_bounds__(N2_THREADS, N2_MIN_WAVES) void ntt2_kernel(Ntt2Args
                 Rd2::lds_read(x, buf);
                 Rd2::compute(x, tw2, pd);
                 if constexpr (NR == 3) {
-                    Rd2::template g_write<FINAL>(x, row, tile, logn, pd.p, pd.two_p);
+                    Rd2::template g_write<FINAL>(x, row, tile, logn, pd.p, pd.two_p, WAVE_PRIVATE ? buf : nullptr);
                 } else {
                     Rd2::lds_write(x, buf);
                     round_sync();
@@ -366,7 +445,8 @@ __global__ __launch_bounds__(N2_THREADS, N2_MIN_WAVES) void ntt2_kernel(Ntt2Args
                 }
             }
         }
-        if (N2_PREFETCH) {
+        if constexpr (DMA) {
+        } else if (N2_PREFETCH) {
 #pragma unroll
             for (int e = 0; e < 8; e++) x[e] = nx[e];
         } else if (mm + 1 < m_end) {
