@@ -1,7 +1,4 @@
-python -m pytest tests/test_gpu_parity.py -q -x -m gpu 2>&1 | tail -2
-python tools/ntt_probe.py tools/probe_libs/libtroyhip_nocs.so 16 | tail -1
-python tools/ntt_probe.py troy_amd/libtroyhip.so 16 | tail -1
-python tools/ntt_probe.py tools/probe_libs/libtroyhip_exp6.so 16 | tail -1
-python tools/ntt_probe.py tools/probe_libs/libtroyhip_nocs.so 32 | tail -1
-python tools/ntt_probe.py troy_amd/libtroyhip.so 32 | tail -1
+python -m pytest tests -q -x -m gpu 2>&1 | tail -2
 python bench.py --batch 32 --no-cpu-baseline 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.read()); print('B32', d['value'], d['ms_per_step'], d['roofline']['achieved'])"
+cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_x -o p -- python3 $GRAFT_REPO_ROOT/bench.py --batch 16 --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+cd $GRAFT_REPO_ROOT && python tools/kstats.py gpurun_out/prof_x/p_kernel_stats.csv 12

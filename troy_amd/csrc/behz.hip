@@ -15,8 +15,10 @@
 //   * the base-change matrix entries are wave-uniform and are read with scalar loads, pre-split on the host into
 //     three 21-bit limbs: (32-bit half of the residue) x (21-bit limb) < 2^53, so up to 2^11 products accumulate in a
 //     plain 64-bit register -- one v_mad_u64_u32 per partial product, NO carry chains (6 per term instead of the
-//     ~14 instructions of a 128-bit multiply-add); the six column sums are recombined and Barrett-reduced once per
-//     output;
+//     ~14 instructions of a 128-bit multiply-add); the six column sums are recombined and reduced once per output;
+//   * every per-row factor of the reference's step sequence (m_tilde^-1, q^-1, t, (B/B_b)^-1) is folded into the matrix on
+//     the host, so an output is ONE mat-vec row and ONE 128-bit reduction (the reference reduces, multiplies and
+//     reduces again per step; the residues written to HBM are the same canonical values);
 //   * all Shoup quotients are precomputed on the host.
 #include "kernels.h"
 
@@ -68,20 +70,31 @@ __device__ __forceinline__ void add128(U128 &v, u64 x, u64 y) { // v += x*y
     v.hi += hi + (v.lo < lo);
 }
 
+// (lo, hi) mod p, canonical: the high word is folded with 2^64 mod p (one Shoup multiply, valid for ANY 64-bit hi), the low
+// word takes a single-word Barrett step; 17 32-bit multiplies instead of the 24 of the two-word Barrett reduction
+__device__ __forceinline__ u64 reduce128(const U128 v, const PrimeDesc &pd) {
+    const u64 a = mul_lazy(v.hi, pd.r64.op, pd.r64.quo, pd.p);   // [0, 2p)
+    const u64 b = v.lo - mulhi64(v.lo, pd.cr1) * pd.p;            // [0, 2p)
+    u64 s = a + b;                                                // [0, 4p), p < 2^61
+    s = s >= pd.two_p ? s - pd.two_p : s;
+    return s >= pd.p ? s - pd.p : s;
+}
+
 // in [polys][L][N] (canonical, coefficient form) -> out [polys][nBsk][N]
-// fastbconvmTilde (rns.cpp:1012-1037) fused with smMrq (rns.cpp:943-983)
+// fastbconvmTilde (rns.cpp:1012-1037) fused with smMrq (rns.cpp:943-983):
+//   out_o = (sum_l y_l (q/q_l) + q r~) m_tilde^-1 mod Bsk_o,  y_l = x_l m_tilde (q/q_l)^-1 mod q_l,
+//   r~ = the centred m_tilde residue  -(sum_l y_l (q/q_l)) q^-1 mod 2^32
+// m_tilde^-1 is folded into the matrix and into q (context.cpp), so each output costs one mat-vec row and ONE reduction.
 __global__ __launch_bounds__(BEHZ_THREADS) void behz_extend_kernel(const u64 *in, u64 in_pstride, u64 *out, u64 out_pstride, const PrimeDesc *primes, BehzDev c, u64 N) {
     TROY_DYN_LDS(u64, lds);
     u64 *y = lds;                               // [L][64]
-    u64 *rmt = lds + (u64)c.L * BEHZ_COEFFS;    // [64]  the m_tilde residue
-    u64 *sres = rmt + BEHZ_COEFFS;              // [nBsk][64]  q -> Bsk sums awaiting the Montgomery correction
     const unsigned lane = threadIdx.x & 63;
     const int w = BEHZ_UNIFORM((int)(threadIdx.x >> 6));
     const u64 n = (u64)blockIdx.x * BEHZ_COEFFS + lane;
     const u64 poly = blockIdx.y;
     const bool live = n < N;
     const u64 *x = in + poly * in_pstride;
-    const mat3_ptr mat = (mat3_ptr)c.q2bsk3;
+    const mat3_ptr mat = (mat3_ptr)c.ext_mat3;
     const cshoup_ptr ext_pre = (cshoup_ptr)c.ext_pre;
     for (int l = w; l < c.L; l += 4) {
         const u64 p = primes[c.q_id[l]].p;
@@ -89,9 +102,15 @@ __global__ __launch_bounds__(BEHZ_THREADS) void behz_extend_kernel(const u64 *in
         y[l * BEHZ_COEFFS + lane] = live ? mul_shoup(x[(u64)l * N + n], pre.op, pre.quo, p) : 0;
     }
     __syncthreads();
-    const int n_out = c.nBsk + 1; // Bsk limbs then m_tilde
-    // sweep: wave w owns outputs o = w + 4*i; the m_tilde row (o = nBsk) is produced in the FIRST sweep that contains it
-    for (int ob = 0; ob < n_out; ob += 4 * BEHZ_OPW) {
+    // the m_tilde residue only needs the low 32 bits of every term; each wave computes it for its own lanes
+    u32 rsum = 0;
+    {
+        const cu32_ptr mt = (cu32_ptr)c.ext_mt_row;
+        for (int l = 0; l < c.L; l++) rsum += (u32)y[l * BEHZ_COEFFS + lane] * mt[l];
+    }
+    const u64 r_mt = ((u64)rsum * c.neg_inv_q_mod_mt) & 0xFFFFFFFFull;
+    // sweep: wave w owns outputs o = ob + w + 4 i
+    for (int ob = 0; ob < c.nBsk; ob += 4 * BEHZ_OPW) {
         Acc6 acc[BEHZ_OPW];
         int o[BEHZ_OPW];
 #pragma unroll
@@ -101,41 +120,30 @@ __global__ __launch_bounds__(BEHZ_THREADS) void behz_extend_kernel(const u64 *in
             const u32 x0 = (u32)v, x1 = (u32)(v >> 32);
 #pragma unroll
             for (int i = 0; i < BEHZ_OPW; i++) {
-                const int oo = o[i] < n_out ? o[i] : n_out - 1; // clamp (result discarded)
+                const int oo = o[i] < c.nBsk ? o[i] : c.nBsk - 1; // clamp (result discarded)
                 acc_mac(acc[i], x0, x1, ld_mat3(mat + oo * c.L + l));
             }
         }
 #pragma unroll
         for (int i = 0; i < BEHZ_OPW; i++) {
-            if (o[i] == c.nBsk) rmt[lane] = acc_low32(acc[i]);
-        }
-#pragma unroll
-        for (int i = 0; i < BEHZ_OPW; i++) {
             if (o[i] < c.nBsk) {
-                const U128 v = acc_value(acc[i]);
-                sres[o[i] * BEHZ_COEFFS + lane] = barrett128(v.lo, v.hi, mod_of(primes[c.bsk_id[o[i]]]));
+                const PrimeDesc &pd = primes[c.bsk_id[o[i]]];
+                u64 temp = r_mt;                                   // centred representative of r (rns.cpp:966-975)
+                if (temp >= (u64(1) << 31)) temp += pd.p - (u64(1) << 32);
+                U128 v = acc_value(acc[i]);
+                add128(v, temp, ((cu64_ptr)c.ext_q)[o[i]]);       // < 2^126 + 2^122
+                const u64 r = reduce128(v, pd);
+                if (live) out[poly * out_pstride + (u64)o[i] * N + n] = r;
             }
         }
-    }
-    __syncthreads();
-    // Montgomery correction (smMrq): out_o = (sum_o + q * r) * m_tilde^-1 mod Bsk_o, r centred
-    const u64 r_mt = ((u64)(u32)rmt[lane] * c.neg_inv_q_mod_mt) & 0xFFFFFFFFull;
-    for (int oo = w; oo < c.nBsk; oo += 4) {
-        const PrimeDesc &pd = primes[c.bsk_id[oo]];
-        const Mod m = mod_of(pd);
-        u64 temp = r_mt;
-        if (temp >= (u64(1) << 31)) temp += m.p - (u64(1) << 32);
-        U128 a{sres[oo * BEHZ_COEFFS + lane], 0};
-        add128(a, temp, ((cu64_ptr)c.prod_q_mod_bsk)[oo]);
-        const u64 v = barrett128(a.lo, a.hi, m);
-        const Shoup im = ld_shoup(c.inv_mt_mod_bsk + oo);
-        if (live) out[poly * out_pstride + (u64)oo * N + n] = mul_shoup(v, im.op, im.quo, m.p);
     }
 }
 
 // dq [polys][L][N], db [polys][nBsk][N] (after the inverse NTT; any representative < 2^64) -> out [polys][L][N]
 // steps (6)-(8) of bfvMultiply (evaluator.cpp:575-623): multiply by t, fastFloor (rns.cpp:985-1010),
-// fastbconvSk (rns.cpp:879-941)
+// fastbconvSk (rns.cpp:879-941).  fastFloor:  z_o = (t db_o - conv_{q->Bsk}(t dq)_o) q^-1 mod Bsk_o  and the B part is
+// pre-scaled for the next conversion, u_b = z_b (B/B_b)^-1 mod B_b: with q^-1 (and (B/B_b)^-1) folded into the negated
+// matrix and into t, z / u is one mat-vec row over the L+1 inputs (y_0..y_{L-1}, db_o) and ONE reduction.
 __global__ __launch_bounds__(BEHZ_THREADS) void behz_floor_sk_kernel(const u64 *dq, u64 dq_pstride, const u64 *db, u64 db_pstride, u64 *out, u64 out_pstride,
                                                                       const PrimeDesc *primes, BehzDev c, u64 N) {
     TROY_DYN_LDS(u64, lds);
@@ -154,14 +162,20 @@ __global__ __launch_bounds__(BEHZ_THREADS) void behz_floor_sk_kernel(const u64 *
         y[l * BEHZ_COEFFS + lane] = live ? mul_shoup(dq[poly * dq_pstride + (u64)l * N + n], pre.op, pre.quo, p) : 0;
     }
     __syncthreads();
-    // fastFloor: z_o = (t*db_o - conv_{q->Bsk}(t*dq)_o) * q^-1 mod Bsk_o ; u_b = z_b * (B/B_b)^-1 mod B_b
     {
-        const mat3_ptr mat = (mat3_ptr)c.q2bsk3;
+        const mat3_ptr mat = (mat3_ptr)c.floor_mat3;
+        const mat3_ptr tmat = (mat3_ptr)c.floor_t3;
         for (int ob = 0; ob < c.nBsk; ob += 4 * BEHZ_OPW) {
             Acc6 acc[BEHZ_OPW];
             int o[BEHZ_OPW];
 #pragma unroll
-            for (int i = 0; i < BEHZ_OPW; i++) { acc_zero(acc[i]); o[i] = ob + w + 4 * i; }
+            for (int i = 0; i < BEHZ_OPW; i++) {
+                acc_zero(acc[i]);
+                o[i] = ob + w + 4 * i;
+                const int oo = o[i] < c.nBsk ? o[i] : c.nBsk - 1;
+                const u64 xb = live ? db[poly * db_pstride + (u64)oo * N + n] : 0;
+                acc_mac(acc[i], (u32)xb, (u32)(xb >> 32), ld_mat3(tmat + oo));
+            }
             for (int l = 0; l < c.L; l++) {
                 const u64 v = y[l * BEHZ_COEFFS + lane];
                 const u32 x0 = (u32)v, x1 = (u32)(v >> 32);
@@ -175,18 +189,9 @@ __global__ __launch_bounds__(BEHZ_THREADS) void behz_floor_sk_kernel(const u64 *
             for (int i = 0; i < BEHZ_OPW; i++) {
                 const int oo = o[i];
                 if (oo < c.nBsk) {
-                    const Mod m = mod_of(primes[c.bsk_id[oo]]);
-                    const U128 v = acc_value(acc[i]);
-                    const u64 conv = barrett128(v.lo, v.hi, m);
-                    const Shoup tb = ld_shoup(c.t_mod_bsk + oo), iq = ld_shoup(c.inv_q_mod_bsk + oo);
-                    const u64 xb = live ? mul_shoup(db[poly * db_pstride + (u64)oo * N + n], tb.op, tb.quo, m.p) : 0;
-                    const u64 z = mul_shoup(xb + (m.p - conv), iq.op, iq.quo, m.p);
-                    if (oo < c.nB) {
-                        const Shoup bp = ld_shoup(c.B_pre + oo);
-                        u[oo * BEHZ_COEFFS + lane] = mul_shoup(z, bp.op, bp.quo, m.p);
-                    } else {
-                        zsk[lane] = z;
-                    }
+                    const u64 r = reduce128(acc_value(acc[i]), primes[c.bsk_id[oo]]);
+                    if (oo < c.nB) u[oo * BEHZ_COEFFS + lane] = r;
+                    else zsk[lane] = r;
                 }
             }
         }
@@ -194,7 +199,6 @@ __global__ __launch_bounds__(BEHZ_THREADS) void behz_floor_sk_kernel(const u64 *
     __syncthreads();
     // Shenoy-Kumaresan: alpha = (conv_{B->m_sk}(z) - z_sk) * B^-1 mod m_sk (every wave recomputes it: nB terms)
     const PrimeDesc &psk = primes[c.bsk_id[c.nB]];
-    const Mod msk = mod_of(psk);
     u64 alpha;
     {
         Acc6 a;
@@ -204,11 +208,10 @@ __global__ __launch_bounds__(BEHZ_THREADS) void behz_floor_sk_kernel(const u64 *
             const u64 v = u[b * BEHZ_COEFFS + lane];
             acc_mac(a, (u32)v, (u32)(v >> 32), ld_mat3(mv + b));
         }
-        const U128 v = acc_value(a);
-        const u64 conv_sk = barrett128(v.lo, v.hi, msk);
-        alpha = mul_shoup(conv_sk + (msk.p - zsk[lane]), c.inv_B_mod_msk.op, c.inv_B_mod_msk.quo, msk.p);
+        const u64 conv_sk = reduce128(acc_value(a), psk);
+        alpha = mul_shoup(conv_sk + (psk.p - zsk[lane]), c.inv_B_mod_msk.op, c.inv_B_mod_msk.quo, psk.p);
     }
-    const bool neg = alpha > (msk.p >> 1);
+    const bool neg = alpha > (psk.p >> 1);
     {
         const mat3_ptr mat = (mat3_ptr)c.B2q3;
         for (int ob = 0; ob < c.L; ob += 4 * BEHZ_OPW) {
@@ -229,12 +232,12 @@ __global__ __launch_bounds__(BEHZ_THREADS) void behz_floor_sk_kernel(const u64 *
             for (int i = 0; i < BEHZ_OPW; i++) {
                 const int l = o[i];
                 if (l < c.L) {
-                    const Mod m = mod_of(primes[c.q_id[l]]);
+                    const PrimeDesc &pd = primes[c.q_id[l]];
                     U128 v = acc_value(acc[i]);
                     const u64 pb = ((cu64_ptr)c.prod_B_mod_q)[l];
-                    if (neg) add128(v, msk.p - alpha, pb);  // alpha represents a negative value
-                    else add128(v, alpha, m.p - pb);
-                    if (live) out[poly * out_pstride + (u64)l * N + n] = barrett128(v.lo, v.hi, m);
+                    if (neg) add128(v, psk.p - alpha, pb);  // alpha represents a negative value
+                    else add128(v, alpha, pd.p - pb);
+                    if (live) out[poly * out_pstride + (u64)l * N + n] = reduce128(v, pd);
                 }
             }
         }
@@ -243,7 +246,7 @@ __global__ __launch_bounds__(BEHZ_THREADS) void behz_floor_sk_kernel(const u64 *
 
 void launch_behz_extend(const u64 *in, u64 in_pstride, u64 *out, u64 out_pstride, const PrimeDesc *primes, const BehzDev &c, u64 N, u64 polys, hipStream_t s) {
     if (!polys) return;
-    size_t lds = (size_t)(c.L + 1 + c.nBsk) * BEHZ_COEFFS * sizeof(u64);
+    size_t lds = (size_t)c.L * BEHZ_COEFFS * sizeof(u64);
     for (u64 p0 = 0; p0 < polys; p0 += 65535) { // gridDim.y limit
         const u64 np = polys - p0 < 65535 ? polys - p0 : 65535;
         TROY_LAUNCH(behz_extend_kernel, dim3(ceil_div(N, BEHZ_COEFFS), (unsigned)np), dim3(BEHZ_THREADS), lds, s, in + p0 * in_pstride, in_pstride, out + p0 * out_pstride,

@@ -136,6 +136,7 @@ void Context::upload_tables() {
         PrimeDesc &d = h_desc[i];
         d.p = m.p; d.cr0 = m.cr0; d.cr1 = m.cr1; d.two_p = 2 * m.p;
         d.inv_n = tb.inv_n;
+        d.r64 = make_shoup((u64)((((u128)1) << 64) % m.p), m.p);
         d.iroot_last_scaled = tb.iroot_last_scaled;
         d.root = upload(tb.root, dev_allocs_);
         d.iroot = upload(tb.iroot, dev_allocs_);
@@ -154,36 +155,45 @@ void Context::upload_tables() {
         c->L = L; c->nB = nB; c->nBsk = nBsk;
         for (int l = 0; l < L; l++) c->q_id[l] = (uint8_t)l;
         for (int o = 0; o < nBsk; o++) c->bsk_id[o] = lv.bsk_ids[o];
-        std::vector<Shoup> ext_pre(L), floor_pre(L), inv_mt(nBsk), t_bsk(nBsk), inv_q(nBsk), B_pre(nB);
+        // Everything that multiplies a whole base-conversion row is folded into the matrix on the host, so the device does
+        // ONE reduction per output (the results are the same canonical residues: same value modulo the same prime):
+        //   extension  out_o = (sum_l y_l (q/q_l) + q r) m_tilde^-1        ->  E[o][l] = (q/q_l) m_tilde^-1,  ext_q[o] = q m_tilde^-1
+        //   fastFloor  u_o   = (t db_o - sum_l y_l (q/q_l)) q^-1 [Bpre_o]  ->  F[o][l] = -(q/q_l) q^-1 [Bpre_o], T[o] = t q^-1 [Bpre_o]
+        std::vector<Shoup> ext_pre(L), floor_pre(L);
         auto split3 = [](u64 m) { return Mat3{(u32)(m & 0x1FFFFF), (u32)((m >> 21) & 0x1FFFFF), (u32)(m >> 42), 0}; };
-        std::vector<Mat3> q2bsk((size_t)(nBsk + 1) * L), B2q((size_t)L * nB), B2msk(nB);
+        std::vector<Mat3> ext_mat((size_t)nBsk * L), floor_mat((size_t)nBsk * L), floor_t(nBsk), B2q((size_t)L * nB), B2msk(nB);
+        std::vector<u32> mt_row(L);
+        std::vector<u64> ext_q(nBsk);
         for (int l = 0; l < L; l++) {
             u64 ql = r.q[l], ip = r.q_to_Bsk.inv_punct[l];
             ext_pre[l] = make_shoup(host::mul_mod(r.m_tilde % ql, ip, ql), ql);
             floor_pre[l] = make_shoup(host::mul_mod(t % ql, ip, ql), ql);
-            for (int o = 0; o < nBsk; o++) q2bsk[(size_t)o * L + l] = split3(r.q_to_Bsk.mat[o][l]);
-            q2bsk[(size_t)nBsk * L + l] = split3(r.q_to_mtilde.mat[0][l]);
+            mt_row[l] = (u32)r.q_to_mtilde.mat[0][l];
             for (int b = 0; b < nB; b++) B2q[(size_t)l * nB + b] = split3(r.B_to_q.mat[l][b]);
         }
         for (int o = 0; o < nBsk; o++) {
-            u64 p = r.Bsk[o];
-            inv_mt[o] = make_shoup(r.inv_mtilde_mod_Bsk[o], p);
-            t_bsk[o] = make_shoup(t % p, p);
-            inv_q[o] = make_shoup(r.inv_prod_q_mod_Bsk[o], p);
+            const u64 p = r.Bsk[o];
+            const u64 inv_mt = r.inv_mtilde_mod_Bsk[o];
+            u64 fscale = r.inv_prod_q_mod_Bsk[o];                                      // q^-1
+            if (o < nB) fscale = host::mul_mod(fscale, r.B_to_q.inv_punct[o], p);     // ... * (B/B_o)^-1 for the B part
+            ext_q[o] = host::mul_mod(r.prod_q_mod_Bsk[o], inv_mt, p);
+            floor_t[o] = split3(host::mul_mod(t % p, fscale, p));
+            for (int l = 0; l < L; l++) {
+                const u64 m = r.q_to_Bsk.mat[o][l];
+                ext_mat[(size_t)o * L + l] = split3(host::mul_mod(m, inv_mt, p));
+                const u64 f = host::mul_mod(m, fscale, p);
+                floor_mat[(size_t)o * L + l] = split3(f ? p - f : 0);
+            }
         }
-        for (int b = 0; b < nB; b++) {
-            B_pre[b] = make_shoup(r.B_to_q.inv_punct[b], r.B[b]);
-            B2msk[b] = split3(r.B_to_msk.mat[0][b]);
-        }
+        for (int b = 0; b < nB; b++) B2msk[b] = split3(r.B_to_msk.mat[0][b]);
         c->ext_pre = upload(ext_pre, lv.dev_blocks);
-        c->q2bsk3 = upload(q2bsk, lv.dev_blocks);
+        c->ext_mat3 = upload(ext_mat, lv.dev_blocks);
+        c->ext_mt_row = upload(mt_row, lv.dev_blocks);
         c->neg_inv_q_mod_mt = r.neg_inv_prod_q_mod_mtilde;
-        c->prod_q_mod_bsk = upload(r.prod_q_mod_Bsk, lv.dev_blocks);
-        c->inv_mt_mod_bsk = upload(inv_mt, lv.dev_blocks);
+        c->ext_q = upload(ext_q, lv.dev_blocks);
         c->floor_pre = upload(floor_pre, lv.dev_blocks);
-        c->t_mod_bsk = upload(t_bsk, lv.dev_blocks);
-        c->inv_q_mod_bsk = upload(inv_q, lv.dev_blocks);
-        c->B_pre = upload(B_pre, lv.dev_blocks);
+        c->floor_mat3 = upload(floor_mat, lv.dev_blocks);
+        c->floor_t3 = upload(floor_t, lv.dev_blocks);
         c->B2q3 = upload(B2q, lv.dev_blocks);
         c->B2msk3 = upload(B2msk, lv.dev_blocks);
         c->inv_B_mod_msk = make_shoup(r.inv_prod_B_mod_msk, r.m_sk);

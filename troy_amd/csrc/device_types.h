@@ -9,6 +9,7 @@ struct PrimeDesc {
     u64 p, cr0, cr1, two_p;
     Shoup inv_n;             // N^-1 mod p
     Shoup iroot_last_scaled; // psi^-? of the last inverse stage pre-multiplied by N^-1
+    Shoup r64;               // 2^64 mod p (folds the high word of a 128-bit sum: reduce128 in behz.hip)
     const Shoup *root;       // [N] forward twiddles, bit-reversed order (src/utils/ntt.cpp:38-43)
     const Shoup *iroot;      // [N] inverse twiddles, scrambled order   (src/utils/ntt.cpp:49-54)
 };

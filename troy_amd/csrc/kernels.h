@@ -64,17 +64,16 @@ struct Mat3 { u32 m0, m1, m2, pad; };
 struct BehzDev {
     int L, nB, nBsk;
     uint8_t q_id[64], bsk_id[66];     // prime ids
-    // --- extension q -> Bsk (+ m_tilde) ---
+    // --- extension q -> Bsk with the m_tilde Montgomery correction (all row factors folded, see context.cpp) ---
     const Shoup *ext_pre;             // [L]   (m_tilde * (q/q_l)^-1) mod q_l
-    const Mat3 *q2bsk3;               // [nBsk+1][L]  (q/q_l) mod Bsk_o ; last row mod m_tilde = 2^32
+    const Mat3 *ext_mat3;             // [nBsk][L]  (q/q_l) * m_tilde^-1 mod Bsk_o
+    const u32 *ext_mt_row;            // [L]   (q/q_l) mod m_tilde = 2^32
     u64 neg_inv_q_mod_mt;             // -q^-1 mod 2^32
-    const u64 *prod_q_mod_bsk;        // [nBsk]
-    const Shoup *inv_mt_mod_bsk;      // [nBsk]
+    const u64 *ext_q;                 // [nBsk]  q * m_tilde^-1 mod Bsk_o
     // --- floor + Shenoy-Kumaresan ---
     const Shoup *floor_pre;           // [L]   (t * (q/q_l)^-1) mod q_l
-    const Shoup *t_mod_bsk;           // [nBsk]
-    const Shoup *inv_q_mod_bsk;       // [nBsk]
-    const Shoup *B_pre;               // [nB]  (B/B_b)^-1 mod B_b
+    const Mat3 *floor_mat3;           // [nBsk][L]  -(q/q_l) * q^-1 [* (B/B_o)^-1 for o < nB] mod Bsk_o
+    const Mat3 *floor_t3;             // [nBsk]     t * q^-1 [* (B/B_o)^-1] mod Bsk_o
     const Mat3 *B2q3;                 // [L][nB]   (B/B_b) mod q_l
     const Mat3 *B2msk3;               // [nB]      (B/B_b) mod m_sk
     Shoup inv_B_mod_msk;
