@@ -280,66 +280,132 @@ __global__ __launch_bounds__(EW_THREADS) void ks_expand_kernel(const u64 *target
         D[((b * (a.dl + 1) + i) * a.dl + j) * N + n] = barrett64(x, m);
     }
 }
-// acc[b][k][i][n] = sum_j opnd(b,i,j)[n] * key[j][k][limb(i)][n] mod p_i ; operands canonical (< 2^61)
+// ---- key-switch inner product ----
+// One 61 x 61-bit product accumulated without a carry chain across words: the aligned partial products (lo*lo at bit 0,
+// hi*hi at bit 64) go to accumulator A, the cross products (bit 32) to accumulator B; each v_mad_u64_u32 adds into a
+// 64-bit word and its carry-out is counted in a separate 32-bit register.  7 instructions per multiply-accumulate
+// (4 v_mad_u64_u32 + 3 v_addc) against ~27 for the compiler's 128-bit code.  Valid for < 64 terms of operands < 2^61.
+struct MacAcc {
+    u64 alo, ahi, blo;
+    u32 acnt, bhi;
+};
+__device__ __forceinline__ void mac_zero(MacAcc &a) { a.alo = a.ahi = a.blo = 0; a.acnt = a.bhi = 0; }
+__device__ __forceinline__ U128 mac_value(const MacAcc &a) {
+    U128 v{a.alo, a.ahi + a.acnt};
+    const u64 tlo = a.blo << 32, thi = (a.blo >> 32) | ((u64)a.bhi << 32);
+    v.lo += tlo;
+    v.hi += thi + (v.lo < tlo);
+    return v;
+}
+#ifdef TROYHIP_CPU_EMUL
+__device__ __forceinline__ void mac4(MacAcc (&a)[4], const u64 (&x)[4], const u64 (&k)[4]) {
+    for (int i = 0; i < 4; i++) {
+        const u64 xl = (u32)x[i], xh = x[i] >> 32, kl = (u32)k[i], kh = k[i] >> 32;
+        u64 t = a[i].alo + xl * kl;
+        a[i].acnt += t < a[i].alo;
+        a[i].alo = t;
+        t = a[i].blo + xl * kh;
+        a[i].bhi += t < a[i].blo;
+        a[i].blo = t;
+        t = a[i].blo + xh * kl;
+        a[i].bhi += t < a[i].blo;
+        a[i].blo = t;
+        a[i].ahi += xh * kh;
+    }
+}
+#else
+// four independent accumulators, instruction-interleaved: a carry writer and its reader are >= 3 instructions apart
+// (VALU carry -> VALU hazard, see bfly.h), carries in VCC + three SGPR pairs
+#define TROY_MAC4_COL(ACC, CNT, XW, KW)                                                                                   \
+    asm("v_mad_u64_u32 %0, vcc, %11, %15, %0\n\t"                                                                        \
+        "v_mad_u64_u32 %1, %8, %12, %16, %1\n\t"                                                                         \
+        "v_mad_u64_u32 %2, %9, %13, %17, %2\n\t"                                                                         \
+        "v_mad_u64_u32 %3, %10, %14, %18, %3\n\t"                                                                        \
+        "v_addc_co_u32 %4, vcc, 0, %4, vcc\n\t"                                                                          \
+        "v_addc_co_u32 %5, %8, 0, %5, %8\n\t"                                                                            \
+        "v_addc_co_u32 %6, %9, 0, %6, %9\n\t"                                                                            \
+        "v_addc_co_u32 %7, %10, 0, %7, %10"                                                                               \
+        : "+v"(a[0].ACC), "+v"(a[1].ACC), "+v"(a[2].ACC), "+v"(a[3].ACC), "+v"(a[0].CNT), "+v"(a[1].CNT), "+v"(a[2].CNT), "+v"(a[3].CNT),  \
+          "=&s"(sb), "=&s"(sc), "=&s"(sd)                                                                                 \
+        : "v"(XW(x[0])), "v"(XW(x[1])), "v"(XW(x[2])), "v"(XW(x[3])), "v"(KW(k[0])), "v"(KW(k[1])), "v"(KW(k[2])), "v"(KW(k[3]))          \
+        : "vcc")
+__device__ __forceinline__ u32 mac_lo32(u64 v) { return (u32)v; }
+__device__ __forceinline__ u32 mac_hi32(u64 v) { return (u32)(v >> 32); }
+__device__ __forceinline__ void mac4(MacAcc (&a)[4], const u64 (&x)[4], const u64 (&k)[4]) {
+    u64 sb, sc, sd;
+    TROY_MAC4_COL(alo, acnt, mac_lo32, mac_lo32);
+    TROY_MAC4_COL(blo, bhi, mac_lo32, mac_hi32);
+    TROY_MAC4_COL(blo, bhi, mac_hi32, mac_lo32);
+    asm("v_mad_u64_u32 %0, vcc, %7, %11, %0\n\t"
+        "v_mad_u64_u32 %1, %4, %8, %12, %1\n\t"
+        "v_mad_u64_u32 %2, %5, %9, %13, %2\n\t"
+        "v_mad_u64_u32 %3, %6, %10, %14, %3"
+        : "+v"(a[0].ahi), "+v"(a[1].ahi), "+v"(a[2].ahi), "+v"(a[3].ahi), "=&s"(sb), "=&s"(sc), "=&s"(sd)
+        : "v"(mac_hi32(x[0])), "v"(mac_hi32(x[1])), "v"(mac_hi32(x[2])), "v"(mac_hi32(x[3])), "v"(mac_hi32(k[0])), "v"(mac_hi32(k[1])), "v"(mac_hi32(k[2])),
+          "v"(mac_hi32(k[3]))
+        : "vcc");
+}
+#endif
+
+// acc[b][k][i][n] = sum_j opnd(b,i,j)[n] * key[j][k][limb(i)][n] mod p_i ; operands canonical (< 2^61), dl < 64
 // ckks_target != nullptr: operand (i == j) comes from the NTT-form input itself (evaluator.cpp:2424-2427)
-// A thread owns V consecutive coefficients of NB consecutive batch items: every key word it loads is used NB times
-// (the key is re-read once per NB ciphertexts instead of once per ciphertext; it is the dominant L2 stream of this kernel).
+// A thread owns V consecutive coefficients of NB consecutive batch items (NB * V = 4 accumulators per key component):
+// every key word it loads is used NB times.
 #ifndef KS_MAC_NB
 #define KS_MAC_NB 4
 #endif
-#ifndef KS_MAC_V
-#define KS_MAC_V 2
-#endif
 template <int NB, int V> __global__ __launch_bounds__(EW_THREADS) void ks_mac_kernel(const u64 *D, const u64 *key, const u64 *ckks_target, u64 t_bstride, u64 *acc, KsArgs a) {
-    const u64 idx = (u64)blockIdx.x * EW_THREADS + threadIdx.x; // over (batch / NB) * (dl+1) * (N / V)
+    static_assert(NB * V == 4, "mac4 works on four accumulators");
+    // block order: (output prime i, coefficient window, batch group) with the batch group FASTEST, so that the workgroups
+    // in flight at any moment share a narrow window of the key (it stays in L2 while every group passes over it)
     const u64 N = u64(1) << a.logn, rl = a.dl + 1;
     const int logv = V == 2 ? 1 : 0;
-    if (idx >= (a.batch / NB) * rl << (a.logn - logv)) return;
-    const u64 n = (idx & ((N >> logv) - 1)) << logv, bi = idx >> (a.logn - logv), i = bi % rl, b0 = (bi / rl) * NB;
+    const u64 groups = (a.batch + NB - 1) / NB;
+    const u64 g = blockIdx.x % groups, wi = blockIdx.x / groups;        // wi = i * windows + window
+    const u64 idx = wi * EW_THREADS + threadIdx.x;                       // over (dl+1) * (N / V)
+    if (idx >= rl << (a.logn - logv)) return;
+    const u64 n = (idx & ((N >> logv) - 1)) << logv, i = idx >> (a.logn - logv), b0 = g * NB;
     const Mod m = mod_of(a.primes[a.key_id[i]]);
     const u64 kl = a.key_limb[i];
-    U128 s0[NB][V], s1[NB][V];
+    MacAcc s0[4], s1[4];
 #pragma unroll
-    for (int b = 0; b < NB; b++)
-#pragma unroll
-        for (int v = 0; v < V; v++) s0[b][v] = s1[b][v] = U128{0, 0};
+    for (int t = 0; t < 4; t++) { mac_zero(s0[t]); mac_zero(s1[t]); }
     for (u64 j = 0; j < a.dl; j++) {
         const u64 *kp = key + ((j * 2) * a.K + kl) * N + n;
-        u64 k0[V], k1[V];
+        u64 k0[4], k1[4], x[4];
         if (V == 2) {
             const ulonglong2 t0 = *reinterpret_cast<const ulonglong2 *>(kp), t1 = *reinterpret_cast<const ulonglong2 *>(kp + a.K * N);
-            k0[0] = t0.x; k0[V - 1] = t0.y; k1[0] = t1.x; k1[V - 1] = t1.y;
+#pragma unroll
+            for (int b = 0; b < NB; b++) { k0[b * V] = t0.x; k0[b * V + V - 1] = t0.y; k1[b * V] = t1.x; k1[b * V + V - 1] = t1.y; }
         } else {
-            k0[0] = kp[0]; k1[0] = kp[a.K * N];
+            const u64 t0 = kp[0], t1 = kp[a.K * N];
+#pragma unroll
+            for (int b = 0; b < NB; b++) { k0[b] = t0; k1[b] = t1; }
         }
 #pragma unroll
         for (int b = 0; b < NB; b++) {
-            const u64 *xp = (ckks_target && i == j) ? ckks_target + (b0 + b) * t_bstride + j * N + n : D + (((b0 + b) * rl + i) * a.dl + j) * N + n;
-            u64 x[V];
+            const u64 bb = b0 + b < a.batch ? b0 + b : a.batch - 1; // ragged last group: recompute the last item, store nothing
+            const u64 *xp = (ckks_target && i == j) ? ckks_target + bb * t_bstride + j * N + n : D + ((bb * rl + i) * a.dl + j) * N + n;
             if (V == 2) {
                 const ulonglong2 t = *reinterpret_cast<const ulonglong2 *>(xp);
-                x[0] = t.x; x[V - 1] = t.y;
+                x[b * V] = t.x; x[b * V + V - 1] = t.y;
             } else {
-                x[0] = xp[0];
+                x[b] = xp[0];
             }
-#pragma unroll
-            for (int v = 0; v < V; v++) { mac128(s0[b][v], x[v], k0[v]); mac128(s1[b][v], x[v], k1[v]); }
         }
-        if ((j & 127) == 127) { // 2^61 * 2^61 * 128 < 2^128: fold long sums (the reference folds every 256 terms)
-#pragma unroll
-            for (int b = 0; b < NB; b++)
-#pragma unroll
-                for (int v = 0; v < V; v++) {
-                    s0[b][v].lo = barrett128(s0[b][v].lo, s0[b][v].hi, m); s0[b][v].hi = 0;
-                    s1[b][v].lo = barrett128(s1[b][v].lo, s1[b][v].hi, m); s1[b][v].hi = 0;
-                }
-        }
+        mac4(s0, x, k0);
+        mac4(s1, x, k1);
     }
 #pragma unroll
     for (int b = 0; b < NB; b++) {
+        if (b0 + b >= a.batch) break;
         u64 r0[V], r1[V];
 #pragma unroll
-        for (int v = 0; v < V; v++) { r0[v] = barrett128(s0[b][v].lo, s0[b][v].hi, m); r1[v] = barrett128(s1[b][v].lo, s1[b][v].hi, m); }
+        for (int v = 0; v < V; v++) {
+            const U128 v0 = mac_value(s0[b * V + v]), v1 = mac_value(s1[b * V + v]);
+            r0[v] = barrett128(v0.lo, v0.hi, m);
+            r1[v] = barrett128(v1.lo, v1.hi, m);
+        }
         u64 *o0 = acc + (((b0 + b) * 2 + 0) * rl + i) * N + n, *o1 = acc + (((b0 + b) * 2 + 1) * rl + i) * N + n;
         if (V == 2) {
             ulonglong2 t0, t1;
@@ -409,26 +475,12 @@ void launch_ks_expand(const u64 *target, u64 t_bstride, u64 *D, const KsArgs &a,
     TROY_LAUNCH(ks_expand_kernel, dim3(ceil_div(total, EW_THREADS)), dim3(EW_THREADS), 0, s, target, t_bstride, D, a);
     launch_check("ks_expand_kernel");
 }
-template <int NB, int V> static void launch_ks_mac_t(const u64 *D, const u64 *key, const u64 *ckks_target, u64 t_bstride, u64 *acc, const KsArgs &a, hipStream_t s) {
-    const u64 total = (a.batch / NB) * (a.dl + 1) << (a.logn - (V == 2 ? 1 : 0));
-    TROY_LAUNCH(HIP_KERNEL_NAME(ks_mac_kernel<NB, V>), dim3(ceil_div(total, EW_THREADS)), dim3(EW_THREADS), 0, s, D, key, ckks_target, t_bstride, acc, a);
-    launch_check("ks_mac_kernel");
-}
 void launch_ks_mac(const u64 *D, const u64 *key, const u64 *ckks_target, u64 t_bstride, u64 *acc, const KsArgs &a, hipStream_t s) {
-    // batches that are not a multiple of the blocking factor: the blocked kernel takes the largest multiple, the rest goes one by one
-    const u64 nb_main = a.batch / KS_MAC_NB * KS_MAC_NB;
-    if (nb_main) {
-        KsArgs m = a;
-        m.batch = nb_main;
-        launch_ks_mac_t<KS_MAC_NB, KS_MAC_V>(D, key, ckks_target, t_bstride, acc, m, s);
-    }
-    if (nb_main < a.batch) {
-        KsArgs r = a;
-        r.batch = a.batch - nb_main;
-        const u64 rl = a.dl + 1, N = u64(1) << a.logn;
-        launch_ks_mac_t<1, KS_MAC_V>(D + nb_main * rl * a.dl * N, key, ckks_target ? ckks_target + nb_main * t_bstride : nullptr, t_bstride,
-                                     acc + nb_main * 2 * rl * N, r, s);
-    }
+    if (a.dl >= 64) throw Error(ST_LOGIC_ERROR, "ks_mac: more than 63 digits");
+    constexpr int NB = KS_MAC_NB, V = 4 / KS_MAC_NB;
+    const u64 groups = (a.batch + NB - 1) / NB, per_group = (u64)(a.dl + 1) << (a.logn - (V == 2 ? 1 : 0));
+    TROY_LAUNCH(HIP_KERNEL_NAME(ks_mac_kernel<NB, V>), dim3(ceil_div(per_group, EW_THREADS) * groups), dim3(EW_THREADS), 0, s, D, key, ckks_target, t_bstride, acc, a);
+    launch_check("ks_mac_kernel");
 }
 void launch_ks_moddown(int kind, const u64 *acc, u64 *ct, u64 ct_bstride, const KsArgs &a, hipStream_t s) {
     u64 total = a.batch * 2 * a.dl << a.logn;
