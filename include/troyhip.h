@@ -139,6 +139,18 @@ int troyhip_rotate(troyhip_context *ctx, troyhip_ct *ct, int steps, int conjugat
 int troyhip_transform_to_ntt(troyhip_context *ctx, troyhip_ct *ct, uint64_t batch, void *stream);            /* transformToNttInplace(Ciphertext) */
 int troyhip_transform_from_ntt(troyhip_context *ctx, troyhip_ct *ct, uint64_t batch, void *stream);          /* transformFromNttInplace */
 int troyhip_multiply_plain_ntt(troyhip_context *ctx, troyhip_ct *ct, const uint64_t *plain, double plain_scale, uint64_t batch, void *stream); /* multiplyPlainInplace, NTT-form operands */
+/* ---- plaintext operands in coefficient form.  BFV/BGV: plain = plain_coeff_count coefficients mod t per item
+ * (device memory); plain_batch_stride = words between the plaintexts of consecutive batch items, 0 = one plaintext for all. ---- */
+/* addPlainInplace / subPlainInplace (src/evaluator_cuda.cu:1654-1720, src/utils/scalingvariant_cuda.cu:21-176).
+ * CKKS: plain is the RNS polynomial [limbs][N] (NTT form) at the level of ct, plain_scale must equal ct->scale. */
+int troyhip_add_plain(troyhip_context *ctx, troyhip_ct *ct, const uint64_t *plain, uint64_t plain_coeff_count, uint64_t plain_batch_stride, double plain_scale,
+                      int subtract, uint64_t batch, void *stream);
+/* multiplyPlainInplace for coefficient-form operands = multiplyPlainNormal (src/evaluator_cuda.cu:1757-1815), BFV/BGV */
+int troyhip_multiply_plain(troyhip_context *ctx, troyhip_ct *ct, const uint64_t *plain, uint64_t plain_coeff_count, uint64_t plain_batch_stride, uint64_t batch,
+                           void *stream);
+/* transformToNttInplace(Plaintext&, parms_id) (src/evaluator_cuda.cu:1866-1948): out [count][limbs][N], limbs identifies the level */
+int troyhip_plain_to_ntt(troyhip_context *ctx, const uint64_t *plain, uint64_t plain_coeff_count, uint64_t plain_batch_stride, int limbs, uint64_t *out,
+                         uint64_t count, void *stream);
 
 #ifdef __cplusplus
 }

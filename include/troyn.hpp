@@ -162,9 +162,14 @@ public:
         return true;
     }
     double &scale() { return scale_; }
+    double scale() const { return scale_; }
+    bool isNttForm() const { return ntt_limbs_ != 0; }
+    ParmsID parmsID() const { return ntt_limbs_; } // level of an NTT-form plaintext (0 = coefficient form, parms_id_zero)
+    void setNttForm(ParmsID limbs) { ntt_limbs_ = limbs; }
 private:
     std::vector<uint64_t> data_;
     double scale_ = 1.0;
+    ParmsID ntt_limbs_ = 0;
 };
 
 class Ciphertext { // src/ciphertext_cuda.cuh:12-268
@@ -367,16 +372,41 @@ public:
     void complexConjugateInplace(Ciphertext &a, const GaloisKeys &gk) const { need(SchemeType::ckks, true); rotate(a, 0, 1, gk); }
     void transformToNttInplace(Ciphertext &a) const { check(troyhip_transform_to_ntt(h(), a.raw(), 1, nullptr)); }
     void transformFromNttInplace(Ciphertext &a) const { check(troyhip_transform_from_ntt(h(), a.raw(), 1, nullptr)); }
-    // NTT-form operands (multiplyPlainNtt, evaluator_cuda.cu:1824-1863); plain = [limbs][N] host coefficients in NTT form
-    void multiplyPlainInplace(Ciphertext &a, const Plaintext &plain_ntt) const {
-        DeviceArray p(plain_ntt.coeffCount());
-        check(troyhip_copy_h2d(p.get(), plain_ntt.data(), plain_ntt.coeffCount() * 8, nullptr));
-        check(troyhip_multiply_plain_ntt(h(), a.raw(), p.get(), const_cast<Plaintext &>(plain_ntt).scale(), 1, nullptr));
+    // multiplyPlainInplace (evaluator_cuda.cu:1722-1755): NTT-form pair -> multiplyPlainNtt, coefficient-form pair -> multiplyPlainNormal
+    void multiplyPlainInplace(Ciphertext &a, const Plaintext &plain) const {
+        if (a.isNttForm() != plain.isNttForm() && c_.parms().scheme() != SchemeType::ckks) throw std::invalid_argument("NTT form mismatch");
+        DeviceArray p(plain.coeffCount());
+        check(troyhip_copy_h2d(p.get(), plain.data(), plain.coeffCount() * 8, nullptr));
+        if (a.isNttForm()) check(troyhip_multiply_plain_ntt(h(), a.raw(), p.get(), plain.scale(), 1, nullptr));
+        else check(troyhip_multiply_plain(h(), a.raw(), p.get(), plain.coeffCount(), 0, 1, nullptr));
         check(troyhip_stream_synchronize(nullptr));
+    }
+    void multiplyPlain(const Ciphertext &a, const Plaintext &plain, Ciphertext &d) const { d = a; multiplyPlainInplace(d, plain); }
+    // addPlainInplace / subPlainInplace (evaluator_cuda.cu:1654-1720)
+    void addPlainInplace(Ciphertext &a, const Plaintext &plain) const { plain_addsub(a, plain, 0); }
+    void subPlainInplace(Ciphertext &a, const Plaintext &plain) const { plain_addsub(a, plain, 1); }
+    void addPlain(const Ciphertext &a, const Plaintext &plain, Ciphertext &d) const { d = a; addPlainInplace(d, plain); }
+    void subPlain(const Ciphertext &a, const Plaintext &plain, Ciphertext &d) const { d = a; subPlainInplace(d, plain); }
+    // transformToNttInplace(Plaintext&, parms_id) (evaluator_cuda.cu:1866-1948)
+    void transformToNttInplace(Plaintext &plain, ParmsID parms_id) const {
+        if (plain.isNttForm()) throw std::invalid_argument("plain is already in NTT form");
+        const size_t n = c_.polyModulusDegree();
+        DeviceArray p(plain.coeffCount()), out((size_t)parms_id * n);
+        check(troyhip_copy_h2d(p.get(), plain.data(), plain.coeffCount() * 8, nullptr));
+        check(troyhip_plain_to_ntt(h(), p.get(), plain.coeffCount(), 0, parms_id, out.get(), 1, nullptr));
+        plain.resize((size_t)parms_id * n);
+        check(troyhip_copy_d2h(plain.data(), out.get(), (size_t)parms_id * n * 8, nullptr));
+        plain.setNttForm(parms_id);
     }
 
 private:
     troyhip_context *h() const { return c_.handle(); }
+    void plain_addsub(Ciphertext &a, const Plaintext &plain, int sub) const {
+        DeviceArray p(plain.coeffCount());
+        check(troyhip_copy_h2d(p.get(), plain.data(), plain.coeffCount() * 8, nullptr));
+        check(troyhip_add_plain(h(), a.raw(), p.get(), plain.coeffCount(), 0, plain.scale(), sub, 1, nullptr));
+        check(troyhip_stream_synchronize(nullptr));
+    }
     void need(SchemeType s, bool equal) const {
         if ((c_.parms().scheme() == s) != equal) throw std::logic_error("unsupported scheme");
     }

@@ -11,7 +11,7 @@ import subprocess
 import numpy as np
 
 from .ref import (BFV, BGV, CKKS, Ct, CtDesc, OP_ADD, OP_APPLY_GALOIS, OP_CONJUGATE, OP_FROM_NTT,  # noqa: F401
-                  OP_MODSWITCH_NEXT, OP_MULTIPLY, OP_MULTIPLY_PLAIN_NTT, OP_NEGATE, OP_RELIN, OP_RESCALE_NEXT,
+                  OP_MODSWITCH_NEXT, OP_MULTIPLY, OP_MULTIPLY_PLAIN_NTT, OP_ADD_PLAIN, OP_SUB_PLAIN, OP_MULTIPLY_PLAIN, OP_NEGATE, OP_RELIN, OP_RESCALE_NEXT,
                   OP_ROTATE_COLUMNS, OP_ROTATE_ROWS, OP_ROTATE_VECTOR, OP_SQUARE, OP_SUB, OP_TO_NTT,
                   ST_DIVROUND_QLAST, ST_DIVROUND_QLAST_NTT, ST_FASTBCONV_MTILDE, ST_FASTBCONV_SK, ST_FASTFLOOR,
                   ST_MODT_DIV_QLAST, ST_SMMRQ)
@@ -232,6 +232,12 @@ class Oracle:
         self._chk(lib().orc_eval(self.h, op, C.byref(ad), _p(a.data), bdp, bptr, C.c_int64(iarg), C.byref(od), _p(out)))
         n = od.size * od.limbs * self.N
         return Ct(out[:n].reshape(od.size, od.limbs, self.N).copy(), od.is_ntt, od.scale, od.correction_factor)
+
+    def plain_to_ntt(self, plain, limbs):
+        plain = np.ascontiguousarray(plain, dtype=np.uint64)
+        out = np.zeros((limbs, self.N), dtype=np.uint64)
+        self._chk(lib().orc_plain_to_ntt(self.h, _p(plain), len(plain), limbs, _p(out)))
+        return out
 
     def decrypt(self, ct, sk):
         sk = np.ascontiguousarray(sk, dtype=np.uint64)

@@ -16,7 +16,7 @@ _SO = os.path.join(_HERE, "_ref", "libtroyref_driver.so")
 BFV, CKKS, BGV = 1, 2, 3
 (OP_ADD, OP_SUB, OP_NEGATE, OP_MULTIPLY, OP_SQUARE, OP_RELIN, OP_MODSWITCH_NEXT, OP_RESCALE_NEXT,
  OP_APPLY_GALOIS, OP_ROTATE_ROWS, OP_ROTATE_COLUMNS, OP_ROTATE_VECTOR, OP_CONJUGATE, OP_TO_NTT,
- OP_FROM_NTT, OP_MULTIPLY_PLAIN_NTT) = range(16)
+ OP_FROM_NTT, OP_MULTIPLY_PLAIN_NTT, OP_ADD_PLAIN, OP_SUB_PLAIN, OP_MULTIPLY_PLAIN) = range(19)
 (ST_FASTBCONV_MTILDE, ST_SMMRQ, ST_FASTFLOOR, ST_FASTBCONV_SK, ST_DIVROUND_QLAST, ST_DIVROUND_QLAST_NTT,
  ST_MODT_DIV_QLAST) = range(7)
 
@@ -203,6 +203,12 @@ class Ref:
         self._chk(lib().ref_eval(self.h, op, C.byref(ad), _p(a.data), bdp, bptr, C.c_int64(iarg), C.byref(od), _p(out)))
         n = od.size * od.limbs * self.N
         return Ct(out[:n].reshape(od.size, od.limbs, self.N).copy(), od.is_ntt, od.scale, od.correction_factor)
+
+    def plain_to_ntt(self, plain, limbs):
+        plain = np.ascontiguousarray(plain, dtype=np.uint64)
+        out = np.zeros((limbs, self.N), dtype=np.uint64)
+        self._chk(lib().ref_plain_to_ntt(self.h, _p(plain), len(plain), limbs, _p(out)))
+        return out
 
     def encrypt(self, plain):
         plain = np.ascontiguousarray(plain, dtype=np.uint64)

@@ -317,7 +317,7 @@ int ref_set_kswitch_key(void *h, uint32_t which, const u64 *data) {
 // op codes
 enum { OP_ADD = 0, OP_SUB, OP_NEGATE, OP_MULTIPLY, OP_SQUARE, OP_RELIN, OP_MODSWITCH_NEXT, OP_RESCALE_NEXT,
        OP_APPLY_GALOIS, OP_ROTATE_ROWS, OP_ROTATE_COLUMNS, OP_ROTATE_VECTOR, OP_CONJUGATE, OP_TO_NTT, OP_FROM_NTT,
-       OP_MULTIPLY_PLAIN_NTT };
+       OP_MULTIPLY_PLAIN_NTT, OP_ADD_PLAIN, OP_SUB_PLAIN, OP_MULTIPLY_PLAIN };
 
 struct RefCtDesc { // mirrors python ctypes struct
     int limbs, size, is_ntt;
@@ -364,6 +364,24 @@ int ref_eval(void *h, int op, const RefCtDesc *ad, const u64 *a, const RefCtDesc
             ev.multiplyPlainInplace(x, p);
             break;
         }
+        case OP_ADD_PLAIN: case OP_SUB_PLAIN: case OP_MULTIPLY_PLAIN: {
+            // b: BFV/BGV iarg coefficients mod t;  CKKS (add/sub only): [limbs][N] NTT form at the level of x
+            Plaintext p;
+            if (r->ctx->keyContextData()->parms().scheme() == SchemeType::ckks) {
+                auto cd = level_data(r, ad->limbs);
+                p.resize(ad->limbs * r->N);
+                std::memcpy(p.data(), b, sizeof(u64) * ad->limbs * r->N);
+                p.parmsID() = cd->parmsID();
+                p.scale() = bd ? bd->scale : 1.0;
+            } else {
+                p.resize((size_t)iarg);
+                std::memcpy(p.data(), b, sizeof(u64) * (size_t)iarg);
+            }
+            if (op == OP_ADD_PLAIN) ev.addPlainInplace(x, p);
+            else if (op == OP_SUB_PLAIN) ev.subPlainInplace(x, p);
+            else ev.multiplyPlainInplace(x, p);
+            break;
+        }
         default: throw std::invalid_argument("op");
         }
         od->limbs = (int)x.coeffModulusSize();
@@ -375,6 +393,17 @@ int ref_eval(void *h, int op, const RefCtDesc *ad, const u64 *a, const RefCtDesc
     });
 }
 
+// Evaluator::transformToNttInplace(Plaintext&, parms_id) (src/evaluator.cpp:1972-2070): out [limbs][N]
+int ref_plain_to_ntt(void *h, const u64 *plain, int n_coeffs, int limbs, u64 *out) {
+    Ref *r = (Ref *)h;
+    return guarded(r, [&] {
+        auto cd = level_data(r, limbs);
+        Plaintext p((size_t)n_coeffs);
+        std::memcpy(p.data(), plain, sizeof(u64) * (size_t)n_coeffs);
+        r->ev->transformToNttInplace(p, cd->parmsID());
+        std::memcpy(out, p.data(), sizeof(u64) * (size_t)limbs * r->N);
+    });
+}
 uint32_t ref_galois_elt_from_step(void *h, int step) {
     Ref *r = (Ref *)h;
     return r->ctx->keyContextData()->galoisTool()->getEltFromStep(step);

@@ -1060,6 +1060,137 @@ struct Eval {
         if (o->scheme == ORC_CKKS && !scale_ok(a.scale, a.limbs)) throw std::invalid_argument("scale out of bounds");
     }
 
+    // ---- plaintext operands ----
+    // context.cpp:307-351: Delta_l = floor(q/t) mod q_l, q mod t, plain_upper_half_threshold = (t+1)/2.  floor(q/t) =
+    // (q - q mod t)/t, so modulo q_l (q = 0 there) Delta_l = -(q mod t) * t^-1; the reference divides the multi-word q.
+    struct PlainConsts {
+        std::vector<u64> delta;
+        u64 q_mod_t, thr;
+    };
+    PlainConsts plain_consts(int limbs) const {
+        PlainConsts c;
+        auto q = o->level_q(limbs);
+        c.q_mod_t = prod_mod(q, o->t);
+        c.thr = (o->t.p + 1) >> 1;
+        for (auto &m : q) c.delta.push_back(mulmod(negmod(barrett64(c.q_mod_t, m), m), invmod_or_throw(barrett64(o->t.p, m), m), m));
+        return c;
+    }
+    // evaluator.cpp:1791-1930 / 1972-2070 lifting of a plaintext coefficient m (mod t) to q_l: m if m < (t+1)/2, else
+    // m + (q - t).  fast lift (every q_l > t, context.cpp:299-305): m + (q_l - t), left unreduced for the lazy NTT;
+    // otherwise the multi-word sum is decomposed (rns.cpp decomposeArray).  Both are the residue returned here (q = 0 mod q_l),
+    // and everything downstream canonicalises (nttNegacyclicHarvey), so the stored limbs are identical.
+    void lift_plain(const u64 *plain, size_t n, int limbs, u64 *out) const {
+        const u64 thr = (o->t.p + 1) >> 1;
+        for (int l = 0; l < limbs; l++) {
+            const Mod &m = o->key_q[l];
+            const u64 t_mod = barrett64(o->t.p, m);
+            for (size_t j = 0; j < N; j++) {
+                u64 v = 0;
+                if (j < n) {
+                    v = barrett64(plain[j], m);
+                    if (plain[j] >= thr) v = submod(v, t_mod, m);
+                }
+                out[(size_t)l * N + j] = v;
+            }
+        }
+    }
+    void check_plain(const u64 *plain, size_t n) const {
+        if (n > N) throw std::invalid_argument("plain is not valid for encryption parameters");
+        for (size_t j = 0; j < n; j++)
+            if (plain[j] >= o->t.p) throw std::invalid_argument("plain is not valid for encryption parameters");
+    }
+    // evaluator.cpp:1603-1763 addPlainInplace / subPlainInplace; scalingvariant.cpp:17-134
+    void add_plain(Ct &a, const u64 *plain, size_t n, double pscale, bool sub) const {
+        check_level(a);
+        if (o->scheme == ORC_BFV && a.ntt) throw std::invalid_argument("BFV encrypted cannot be in NTT form");
+        if (o->scheme == ORC_CKKS && !a.ntt) throw std::invalid_argument("CKKS encrypted must be in NTT form");
+        if (o->scheme == ORC_BGV && a.ntt) throw std::invalid_argument("BGV encrypted cannot be in NTT form");
+        if (o->scheme == ORC_CKKS) { // plain: [limbs][N] NTT form at the same level
+            if (std::fabs(a.scale - pscale) >= std::ldexp(1.0, -23)) throw std::invalid_argument("scale mismatch");
+            for (int l = 0; l < a.limbs; l++) {
+                const Mod &m = o->key_q[l];
+                u64 *x = a.poly(0, N) + (size_t)l * N;
+                for (size_t j = 0; j < N; j++) x[j] = sub ? submod(x[j], plain[l * N + j], m) : addmod(x[j], plain[l * N + j], m);
+            }
+            return;
+        }
+        check_plain(plain, n);
+        if (o->scheme == ORC_BFV) { // multiplyAdd/SubPlainWithScalingVariant: round(q m / t) = Delta m + floor((q mod t) m + (t+1)/2) / t)
+            const PlainConsts c = plain_consts(a.limbs);
+            for (size_t j = 0; j < n; j++) {
+                const u128 num = (u128)plain[j] * c.q_mod_t + c.thr;
+                const u64 fix = (u64)(num / o->t.p);
+                for (int l = 0; l < a.limbs; l++) {
+                    const Mod &m = o->key_q[l];
+                    const u64 v = barrett128((u128)plain[j] * c.delta[l] + fix, m); // multiplyAddUintMod
+                    u64 &x = a.poly(0, N)[(size_t)l * N + j];
+                    x = sub ? submod(x, v, m) : addmod(x, v, m);
+                }
+            }
+        } else { // BGV: plain * correction_factor mod t, then add/subPlainWithoutScalingVariant
+            for (size_t j = 0; j < n; j++) {
+                const u64 pc = mulmod(plain[j], a.cf, o->t);
+                for (int l = 0; l < a.limbs; l++) {
+                    const Mod &m = o->key_q[l];
+                    const u64 v = barrett64(pc, m);
+                    u64 &x = a.poly(0, N)[(size_t)l * N + j];
+                    x = sub ? submod(x, v, m) : addmod(x, v, m);
+                }
+            }
+        }
+    }
+    // evaluator.cpp:1791-1930 multiplyPlainNormal (generic branch; the monomial branch gives the same canonical limbs)
+    // The CPU reference short-cuts a plaintext with ONE nonzero coefficient (evaluator.cpp:1816-1867): scalar multiply +
+    // negacyclic shift (polyarithsmallmod.h:271-279, .cpp:128-152), and in fast-lift mode it multiplies by the coefficient
+    // ITSELF even when it is in the upper half (no q - t adjustment), so those limbs differ from the generic branch by a
+    // multiple of t.  The reference's CUDA evaluator has no such branch (evaluator_cuda.cu:1757-1815): `generic_only`
+    // selects that behaviour (the drop-in target of the GPU product).
+    void multiply_plain_normal(Ct &a, const u64 *plain, size_t n, bool generic_only) const {
+        check_level(a);
+        if (a.ntt) throw std::invalid_argument("NTT form mismatch");
+        check_plain(plain, n);
+        size_t nonzero = 0, mono = 0;
+        for (size_t j = 0; j < n; j++)
+            if (plain[j]) { nonzero++; mono = j; }
+        if (nonzero == 1 && !generic_only) {
+            const u64 c = plain[mono], thr = (o->t.p + 1) >> 1;
+            bool fast = true;
+            for (int l = 0; l < a.limbs; l++) fast = fast && o->key_q[l].p > o->t.p;
+            std::vector<u64> tmp(N);
+            for (int i = 0; i < a.size; i++)
+                for (int l = 0; l < a.limbs; l++) {
+                    const Mod &m = o->key_q[l];
+                    u64 cl = barrett64(c, m);
+                    if (c >= thr && !fast) cl = submod(cl, barrett64(o->t.p, m), m); // (q - t + c) mod q_l
+                    u64 *x = a.poly(i, N) + (size_t)l * N;
+                    for (size_t j = 0; j < N; j++) tmp[j] = mulmod(x[j], cl, m);
+                    for (size_t j = 0; j < N; j++) {
+                        const size_t raw = j + mono, idx = raw & (N - 1);
+                        x[idx] = (!(raw & N) || !tmp[j]) ? tmp[j] : m.p - tmp[j];
+                    }
+                }
+            return;
+        }
+        std::vector<u64> temp((size_t)a.limbs * N);
+        lift_plain(plain, n, a.limbs, temp.data());
+        for (int l = 0; l < a.limbs; l++) ntt_fwd(temp.data() + (size_t)l * N, *o->key_tables[l]);
+        for (int i = 0; i < a.size; i++)
+            for (int l = 0; l < a.limbs; l++) {
+                const Mod &m = o->key_q[l];
+                u64 *x = a.poly(i, N) + (size_t)l * N;
+                ntt_fwd_lazy(x, *o->key_tables[l]);
+                for (size_t j = 0; j < N; j++) x[j] = mulmod(x[j], temp[(size_t)l * N + j], m);
+                ntt_inv(x, *o->key_tables[l]);
+            }
+    }
+    // evaluator.cpp:1972-2070 transformToNttInplace(Plaintext, parms_id): out [limbs][N]
+    void plain_to_ntt(const u64 *plain, size_t n, int limbs, u64 *out) const {
+        if (!o->level_exists(limbs) && limbs != (int)o->K) throw std::invalid_argument("parms_id is not valid for the current context");
+        check_plain(plain, n);
+        lift_plain(plain, n, limbs, out);
+        for (int l = 0; l < limbs; l++) ntt_fwd(out + (size_t)l * N, *o->key_tables[l]);
+    }
+
     // decryptor.cpp:284-371 dotProductCtSkArray + :115-153 bfvDecrypt / :185-222 bgvDecrypt / :155-183 ckks
     void decrypt(const Ct &c, const u64 *sk, u64 *out) const {
         size_t nl = c.limbs, K = o->K;
@@ -1285,11 +1416,18 @@ int orc_eval(void *h, int op, const orc_ct_desc *ad, const uint64_t *a, const or
         case ORC_OP_TO_NTT: ev.to_ntt(x); break;
         case ORC_OP_FROM_NTT: ev.from_ntt(x); break;
         case ORC_OP_MULTIPLY_PLAIN_NTT: ev.multiply_plain_ntt(x, b, bd ? bd->scale : 1.0); break;
+        case ORC_OP_ADD_PLAIN: ev.add_plain(x, b, (size_t)iarg, bd ? bd->scale : 1.0, false); break;
+        case ORC_OP_SUB_PLAIN: ev.add_plain(x, b, (size_t)iarg, bd ? bd->scale : 1.0, true); break;
+        case ORC_OP_MULTIPLY_PLAIN: ev.multiply_plain_normal(x, b, (size_t)(iarg & 0xFFFFFFFF), (iarg >> 32) & 1); break; // bit 32: CUDA-evaluator semantics
         default: throw std::invalid_argument("op");
         }
         od->limbs = x.limbs; od->size = x.size; od->is_ntt = x.ntt; od->scale = x.scale; od->correction_factor = x.cf;
         std::copy(x.d.begin(), x.d.begin() + (size_t)x.size * x.limbs * o->N, out);
     });
+}
+int orc_plain_to_ntt(void *h, const uint64_t *plain, int n_coeffs, int limbs, uint64_t *out) {
+    Orc *o = (Orc *)h;
+    return guarded(o, [&] { Eval(o).plain_to_ntt(plain, (size_t)n_coeffs, limbs, out); });
 }
 uint32_t orc_galois_elt_from_step(void *h, int step) {
     Orc *o = (Orc *)h;

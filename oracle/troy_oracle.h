@@ -30,7 +30,7 @@ enum { ORC_BFV = 1, ORC_CKKS = 2, ORC_BGV = 3 };
 enum { ORC_OP_ADD = 0, ORC_OP_SUB, ORC_OP_NEGATE, ORC_OP_MULTIPLY, ORC_OP_SQUARE, ORC_OP_RELIN,
        ORC_OP_MODSWITCH_NEXT, ORC_OP_RESCALE_NEXT, ORC_OP_APPLY_GALOIS, ORC_OP_ROTATE_ROWS,
        ORC_OP_ROTATE_COLUMNS, ORC_OP_ROTATE_VECTOR, ORC_OP_CONJUGATE, ORC_OP_TO_NTT, ORC_OP_FROM_NTT,
-       ORC_OP_MULTIPLY_PLAIN_NTT };
+       ORC_OP_MULTIPLY_PLAIN_NTT, ORC_OP_ADD_PLAIN, ORC_OP_SUB_PLAIN, ORC_OP_MULTIPLY_PLAIN };
 enum { ORC_ST_FASTBCONV_MTILDE = 0, ORC_ST_SMMRQ, ORC_ST_FASTFLOOR, ORC_ST_FASTBCONV_SK,
        ORC_ST_DIVROUND_QLAST, ORC_ST_DIVROUND_QLAST_NTT, ORC_ST_MODT_DIV_QLAST };
 
@@ -51,6 +51,9 @@ void orc_naf(int value, int *out, int *n_out);
 int orc_get_primes(uint64_t factor, int bits, int count, uint64_t *out);
 int orc_coeff_modulus_create(uint64_t N, const int *bits, int n, uint64_t *out);
 uint64_t orc_plain_batching(uint64_t N, int bits);
+
+/* transformToNttInplace(Plaintext, parms_id of `limbs`): plain = n_coeffs values mod t -> out [limbs][N] */
+int orc_plain_to_ntt(void *h, const uint64_t *plain, int n_coeffs, int limbs, uint64_t *out);
 
 void *orc_create(int scheme, uint64_t N, const uint64_t *primes, int K, uint64_t t);
 void orc_destroy(void *h);

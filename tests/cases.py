@@ -105,6 +105,21 @@ def scenario(backend, cfg, light=False):
         out[f"{tag}/from_ntt"] = backend.export(backend.from_ntt(an))
         pl = synth.uniform_rows(SEED + 400 + limbs, q, limbs, N)
         out[f"{tag}/multiply_plain_ntt"] = backend.export(backend.multiply_plain(backend.ct(xa, True), pl))
+        # plaintext operands in coefficient form: full, ragged (N-5 coefficients) and -- for add/sub -- a monomial
+        if scheme == CKKS:
+            out[f"{tag}/add_plain"] = backend.export(backend.add_plain(a(), pl, N))
+            out[f"{tag}/sub_plain"] = backend.export(backend.sub_plain(a(), pl, N))
+        else:
+            t = backend.t
+            for n in (N, N - 5):
+                pt = synth.uniform_rows(SEED + 500 + limbs + n, [t], 1, n)[0]
+                out[f"{tag}/add_plain{n}"] = backend.export(backend.add_plain(b(), pt, n))
+                out[f"{tag}/sub_plain{n}"] = backend.export(backend.sub_plain(b(), pt, n))
+                out[f"{tag}/multiply_plain{n}"] = backend.export(backend.multiply_plain_normal(b(), pt, n))
+                out[f"{tag}/plain_to_ntt{n}"] = Meta(backend.plain_to_ntt(pt, limbs)[None], True, 1.0, 1)
+            mono = np.zeros(7, dtype=np.uint64)
+            mono[6] = t - 1
+            out[f"{tag}/add_plain_mono"] = backend.export(backend.add_plain(b(), mono, 7))
     return out
 
 
@@ -152,6 +167,14 @@ class _EvalBackend:
     def to_ntt(self, a): return self._e(self.R.OP_TO_NTT, a)
     def from_ntt(self, a): return self._e(self.R.OP_FROM_NTT, a)
     def multiply_plain(self, a, pl): return self._e(self.R.OP_MULTIPLY_PLAIN_NTT, a, pl)
+    def add_plain(self, a, pl, n): return self._e(self.R.OP_ADD_PLAIN, a, pl, iarg=n)
+    def sub_plain(self, a, pl, n): return self._e(self.R.OP_SUB_PLAIN, a, pl, iarg=n)
+    def multiply_plain_normal(self, a, pl, n): return self._e(self.R.OP_MULTIPLY_PLAIN, a, pl, iarg=n)
+    def plain_to_ntt(self, pl, limbs): return self.impl.plain_to_ntt(pl, limbs)
+
+    @property
+    def t(self):
+        return self.impl.t
 
 
 def ref_backend(cfg):
@@ -219,6 +242,14 @@ class GpuBackend:
         self.ev.multiplyPlainInplace(a, self.api.DeviceBuffer.from_numpy(pl))
         return a
 
+    def add_plain(self, a, pl, n): self.ev.addPlainInplace(a, self.api.DeviceBuffer.from_numpy(pl), n); return a
+    def sub_plain(self, a, pl, n): self.ev.subPlainInplace(a, self.api.DeviceBuffer.from_numpy(pl), n); return a
+    def multiply_plain_normal(self, a, pl, n): self.ev.multiplyPlainNormalInplace(a, self.api.DeviceBuffer.from_numpy(pl), n); return a
+
+    def plain_to_ntt(self, pl, limbs):
+        out = self.ev.transformPlainToNtt(self.api.DeviceBuffer.from_numpy(pl), limbs, len(pl))
+        return out.to_numpy().reshape(limbs, self.cfg["N"])
+
 
 def compare(got, exp, names=None):
     """bit-exact comparison of two scenario outputs; returns list of mismatching names"""
@@ -230,3 +261,43 @@ def compare(got, exp, names=None):
         if not ok:
             bad.append(k)
     return bad
+
+
+def check_plain_monomial_and_batch(gpu_cfg_name):
+    """multiplyPlain by a one-coefficient plaintext follows the reference's CUDA evaluator (generic branch,
+    evaluator_cuda.cu:1757-1815; the CPU evaluator short-cuts it differently, oracle flag bit 32 selects the CUDA semantics),
+    and per-item plaintexts (plain_batch_stride != 0) give each batch row its own result."""
+    cfg = CONFIGS[gpu_cfg_name]
+    B = 3
+    be = GpuBackend(cfg, batch=B)
+    orc = oracle_backend(cfg)
+    N, L, t = cfg["N"], len(be.primes) - 1, be.t
+    q = be.primes[:L]
+    from oracle import ref as R
+    xs = synth.uniform_ct(991, q, 2, N, B)
+    mono = np.zeros(9, dtype=np.uint64)
+    mono[8] = t - 2
+    c = be.api.Ciphertext.from_numpy(be.ctx, xs, False, 1.0, 1, capacity=3)
+    be.ev.multiplyPlainNormalInplace(c, be.api.DeviceBuffer.from_numpy(mono), 9)
+    got = c.cpu()
+    for b in range(B):
+        exp = orc.impl.eval(R.OP_MULTIPLY_PLAIN, R.Ct(xs[b], False), mono, iarg=9 | (1 << 32))
+        assert np.array_equal(got[b], exp.data), b
+    # one plaintext per batch item
+    pts = synth.uniform_rows(992, [t], B, N - 3)
+    for name, op in (("add", R.OP_ADD_PLAIN), ("sub", R.OP_SUB_PLAIN), ("mul", R.OP_MULTIPLY_PLAIN)):
+        c = be.api.Ciphertext.from_numpy(be.ctx, xs, False, 1.0, 1, capacity=3)
+        buf = be.api.DeviceBuffer.from_numpy(pts)
+        if name == "add":
+            be.ev.addPlainInplace(c, buf, N - 3, per_item=True)
+        elif name == "sub":
+            be.ev.subPlainInplace(c, buf, N - 3, per_item=True)
+        else:
+            be.ev.multiplyPlainNormalInplace(c, buf, N - 3, per_item=True)
+        got = c.cpu()
+        for b in range(B):
+            exp = orc.impl.eval(op, R.Ct(xs[b], False), pts[b], iarg=N - 3)
+            assert np.array_equal(got[b], exp.data), (name, b)
+    ntt = be.ev.transformPlainToNtt(be.api.DeviceBuffer.from_numpy(pts), L, N - 3, count=B).to_numpy().reshape(B, L, N)
+    for b in range(B):
+        assert np.array_equal(ntt[b], orc.impl.plain_to_ntt(pts[b], L))

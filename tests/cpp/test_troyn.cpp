@@ -105,6 +105,28 @@ static void scenario(SchemeType scheme, size_t n, std::vector<int> bits, int tbi
     decryptor.decrypt(c, out);
     EXPECT(out == Plaintext(prod), "multiply + relinearize");
 
+    // plaintext operands: ct + pt, ct - pt, ct * pt (coefficient form), and ct_ntt * pt_ntt after transformToNtt
+    Ciphertext e;
+    evaluator.addPlain(a, pb, e);
+    decryptor.decrypt(e, out);
+    for (size_t i = 0; i < n; i++) want[i] = (va[i] + vb[i]) % t;
+    EXPECT(out == Plaintext(want), "addPlain");
+    evaluator.subPlainInplace(e, pb);
+    decryptor.decrypt(e, out);
+    EXPECT(out == pa, "subPlain");
+    evaluator.multiplyPlain(a, pb, e);
+    decryptor.decrypt(e, out);
+    EXPECT(out == Plaintext(prod), "multiplyPlain (coefficient form)");
+    {
+        Ciphertext antt = a;
+        Plaintext pbn = pb;
+        evaluator.transformToNttInplace(antt);
+        evaluator.transformToNttInplace(pbn, antt.parmsID());
+        evaluator.multiplyPlainInplace(antt, pbn);
+        evaluator.transformFromNttInplace(antt);
+        EXPECT(antt.toHost() == e.toHost(), "multiplyPlain NTT path == coefficient path (same limbs)");
+    }
+
     // mod switch keeps the plaintext
     Ciphertext d;
     evaluator.modSwitchToNext(c, d);

@@ -33,9 +33,13 @@ def test_two_rank_gloo_reduction(tmp_path):
         "s, e = bench.shard_range(9, r, 2)\n"
         "assert (s, e) == ((0, 5) if r == 0 else (5, 9))\n"
         "dist.barrier(); dist.destroy_process_group()\n"
-        "print('rank', r, 'ok')\n" % ROOT)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29577")
+        "os.write(1, ('rank %%d ok\\n' %% r).encode())\n" % ROOT)  # one write per rank: two ranks share the pipe
+    import socket
+    with socket.socket() as sk:  # a free port: a fixed one can still be in TIME_WAIT from an earlier run
+        sk.bind(("127.0.0.1", 0))
+        port = str(sk.getsockname()[1])
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                          "--master-port", "29577", str(script)], env=env, capture_output=True, text=True, timeout=300)
+                          "--master-port", port, str(script)], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "rank 0 ok" in out.stdout and "rank 1 ok" in out.stdout

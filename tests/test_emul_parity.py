@@ -61,3 +61,8 @@ def test_emulated_ntt_all_sizes(logn, emul_api, oracle_lib):
         assert np.array_equal(y[r], oracle_lib.ntt_standalone(N, primes[r % 2], x[r], 1))
     ctx.ntt(buf, 4, primes, inverse=True)
     assert np.array_equal(buf.to_numpy().reshape(4, N), x)
+
+
+@pytest.mark.parametrize("name", ["bfv_n64_k3", "bgv_n128_k4"])
+def test_emulated_plain_operands(name, emul_api, oracle_lib):
+    cases.check_plain_monomial_and_batch(name)

@@ -301,3 +301,11 @@ def test_cfgE_ckks_matmul_semantics(gpu, oracle_lib):
                 p = ob.multiply_plain(ref.Ct(a[i][b], True), W[i][j])
                 e = p if e is None else ob.add(e, p)
             assert np.array_equal(got[b], e.data), (j, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["cfgA_bfv_n4096_k3", "bgv_n4096_k3", "cfgB_bfv_n8192_k5"])
+def test_plain_operands_monomial_and_per_item(name, gpu, oracle_lib):
+    """addPlain / subPlain / multiplyPlain (coefficient form) / transformToNtt(Plaintext) with one plaintext per
+    batch row, and the one-coefficient plaintext under the CUDA evaluator's semantics; vs the CPU oracle, bit-exact"""
+    cases.check_plain_monomial_and_batch(name)

@@ -423,6 +423,39 @@ class Evaluator:
         self._chk(self.lib.troyhip_multiply_plain_ntt(self.context.h, C.byref(st), C.c_void_p(plain_ntt.ptr), C.c_double(plain_scale), C.c_uint64(a.batch), self.stream))
         a._absorb(st)
 
+    # ---- plaintext operands in coefficient form (evaluator_cuda.cu:1654-1948).  plain: DeviceBuffer holding either ONE
+    # plaintext (n_coeffs coefficients mod t; CKKS: [limbs][N] NTT rows) or one per batch item (per_item=True, back to back)
+    def _plain_stride(self, a, n_coeffs, per_item):
+        if not per_item:
+            return 0
+        return a.limbs * self.context.N if self.context.scheme == capi.CKKS else n_coeffs
+
+    def addPlainInplace(self, a, plain, n_coeffs=None, plain_scale=1.0, per_item=False, _sub=0):
+        n = self.context.N if n_coeffs is None else int(n_coeffs)
+        st = a.struct()
+        self._chk(self.lib.troyhip_add_plain(self.context.h, C.byref(st), C.c_void_p(plain.ptr), C.c_uint64(n), C.c_uint64(self._plain_stride(a, n, per_item)),
+                                             C.c_double(plain_scale), _sub, C.c_uint64(a.batch), self.stream))
+        a._absorb(st)
+
+    def subPlainInplace(self, a, plain, n_coeffs=None, plain_scale=1.0, per_item=False):
+        self.addPlainInplace(a, plain, n_coeffs, plain_scale, per_item, _sub=1)
+
+    def multiplyPlainNormalInplace(self, a, plain, n_coeffs=None, per_item=False):
+        """multiplyPlainInplace with coefficient-form operands (multiplyPlainNormal)."""
+        n = self.context.N if n_coeffs is None else int(n_coeffs)
+        st = a.struct()
+        self._chk(self.lib.troyhip_multiply_plain(self.context.h, C.byref(st), C.c_void_p(plain.ptr), C.c_uint64(n), C.c_uint64(self._plain_stride(a, n, per_item)),
+                                                  C.c_uint64(a.batch), self.stream))
+        a._absorb(st)
+
+    def transformPlainToNtt(self, plain, limbs, n_coeffs=None, count=1):
+        """transformToNttInplace(Plaintext, parms_id): returns a DeviceBuffer [count][limbs][N]."""
+        n = self.context.N if n_coeffs is None else int(n_coeffs)
+        out = DeviceBuffer(count * limbs * self.context.N)
+        self._chk(self.lib.troyhip_plain_to_ntt(self.context.h, C.c_void_p(plain.ptr), C.c_uint64(n), C.c_uint64(n if count > 1 else 0), int(limbs),
+                                                C.c_void_p(out.ptr), C.c_uint64(count), self.stream))
+        return out
+
 
 # ---------------------------------------------------------------- CPU-side keys / encryption / decryption (host buffers)
 class KeyGenerator:

@@ -281,5 +281,21 @@ int troyhip_transform_from_ntt(troyhip_context *ctx, troyhip_ct *ct, uint64_t ba
 int troyhip_multiply_plain_ntt(troyhip_context *ctx, troyhip_ct *ct, const uint64_t *plain, double plain_scale, uint64_t batch, void *stream) {
     return guard([&] { CtBatch x = view(ct); ctx->ev.multiply_plain_ntt(x, plain, plain_scale, batch, (hipStream_t)stream); store(x, ct); });
 }
+int troyhip_add_plain(troyhip_context *ctx, troyhip_ct *ct, const uint64_t *plain, uint64_t plain_coeff_count, uint64_t plain_batch_stride, double plain_scale,
+                      int subtract, uint64_t batch, void *stream) {
+    return guard([&] {
+        CtBatch x = view(ct);
+        ctx->ev.add_plain(x, plain, plain_coeff_count, plain_batch_stride, plain_scale, subtract != 0, batch, (hipStream_t)stream);
+        store(x, ct);
+    });
+}
+int troyhip_multiply_plain(troyhip_context *ctx, troyhip_ct *ct, const uint64_t *plain, uint64_t plain_coeff_count, uint64_t plain_batch_stride, uint64_t batch,
+                           void *stream) {
+    return guard([&] { CtBatch x = view(ct); ctx->ev.multiply_plain(x, plain, plain_coeff_count, plain_batch_stride, batch, (hipStream_t)stream); store(x, ct); });
+}
+int troyhip_plain_to_ntt(troyhip_context *ctx, const uint64_t *plain, uint64_t plain_coeff_count, uint64_t plain_batch_stride, int limbs, uint64_t *out,
+                         uint64_t count, void *stream) {
+    return guard([&] { ctx->ev.plain_to_ntt(plain, plain_coeff_count, plain_batch_stride, limbs, out, count, (hipStream_t)stream); });
+}
 
 } // extern "C"

@@ -414,4 +414,75 @@ void Evaluator::multiply_plain_ntt(CtBatch &ct, const u64 *plain, double plain_s
     ct.scale = new_scale;
 }
 
+// ---- plaintext operands ----
+static PlainArgs plain_args(Context &c, int limbs, u64 n_coeffs, u64 plain_bstride, u64 items, u64 cf) {
+    if (limbs < 1 || limbs > c.K) throw Error(ST_INVALID_ARGUMENT, "parms_id is not valid for the current context");
+    PlainArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.primes = c.d_desc;
+    a.map = c.ct_map(limbs);
+    a.logn = c.logn;
+    a.limbs = (u64)limbs;
+    a.n_coeffs = n_coeffs;
+    a.items = items;
+    a.plain_bstride = plain_bstride;
+    a.cf = cf;
+    if (c.t) {
+        const Mod tm = make_mod(c.t);
+        a.t_p = tm.p; a.t_cr0 = tm.cr0; a.t_cr1 = tm.cr1;
+        a.thr = (c.t + 1) >> 1;
+        std::vector<u64> q(c.primes.begin(), c.primes.begin() + limbs);
+        a.q_mod_t = host::product_mod(q, c.t);
+        // Delta_l = floor(q/t) mod q_l = -(q mod t) * t^-1 mod q_l  (context.cpp:307-331 divides the multi-word q)
+        for (int l = 0; l < limbs; l++) {
+            const Mod m = make_mod(q[l]);
+            a.delta[l] = mulmod(negmod(a.q_mod_t % m.p, m.p), host::inv_mod_checked(c.t % m.p, m.p), m);
+        }
+    }
+    return a;
+}
+// addPlainInplace / subPlainInplace (evaluator_cuda.cu:1654-1720)
+void Evaluator::add_plain(CtBatch &ct, const u64 *plain, u64 n_coeffs, u64 plain_bstride, double plain_scale, bool sub, u64 batch, hipStream_t s) {
+    check_ct(ct);
+    if (!plain) throw Error(ST_INVALID_ARGUMENT, "plain is not valid for encryption parameters");
+    if (c.scheme == SCHEME_BFV && ct.ntt) throw Error(ST_INVALID_ARGUMENT, "BFV encrypted cannot be in NTT form");
+    if (c.scheme == SCHEME_CKKS && !ct.ntt) throw Error(ST_INVALID_ARGUMENT, "CKKS encrypted must be in NTT form");
+    if (c.scheme == SCHEME_BGV && ct.ntt) throw Error(ST_INVALID_ARGUMENT, "BGV encrypted cannot be in NTT form");
+    if (c.scheme == SCHEME_CKKS) {
+        if (std::fabs(ct.scale - plain_scale) >= std::ldexp(1.0, -23)) throw Error(ST_INVALID_ARGUMENT, "scale mismatch");
+        const PlainArgs a = plain_args(c, ct.limbs, c.N, plain_bstride, batch, 1);
+        launch_add_plain(1, sub, ct.data, ct.bstride, plain, a, s);
+        return;
+    }
+    if (n_coeffs > c.N) throw Error(ST_INVALID_ARGUMENT, "plain is not valid for encryption parameters");
+    const PlainArgs a = plain_args(c, ct.limbs, n_coeffs, plain_bstride, batch, ct.cf);
+    launch_add_plain(c.scheme == SCHEME_BFV ? 0 : 2, sub, ct.data, ct.bstride, plain, a, s);
+}
+// transformToNttInplace(Plaintext, parms_id) (evaluator_cuda.cu:1866-1948): out [count][limbs][N]
+void Evaluator::plain_to_ntt(const u64 *plain, u64 n_coeffs, u64 plain_bstride, int limbs, u64 *out, u64 count, hipStream_t s) {
+    if (!plain || !out || n_coeffs > c.N || c.scheme == SCHEME_CKKS) throw Error(ST_INVALID_ARGUMENT, "plain is not valid for encryption parameters");
+    const PlainArgs a = plain_args(c, limbs, n_coeffs, plain_bstride, count, 1);
+    launch_plain_lift(plain, out, a, s);
+    launch_ntt(out, c.d_desc, c.ct_map(limbs), count * limbs, c.logn, false, s);
+}
+// multiplyPlainNormal (evaluator_cuda.cu:1757-1815): generic branch for every plaintext, exactly like the reference's CUDA
+// evaluator (its CPU twin short-cuts one-coefficient plaintexts, evaluator.cpp:1816-1867)
+void Evaluator::multiply_plain(CtBatch &ct, const u64 *plain, u64 n_coeffs, u64 plain_bstride, u64 batch, hipStream_t s) {
+    check_ct(ct);
+    if (ct.ntt) throw Error(ST_INVALID_ARGUMENT, "NTT form mismatch");
+    if (c.scheme == SCHEME_CKKS) throw Error(ST_INVALID_ARGUMENT, "CKKS encrypted must be in NTT form");
+    const u64 items = plain_bstride ? batch : 1, pw = poly_words(c, ct.limbs);
+    c.arena.reset();
+    c.arena.reserve(items * pw);
+    u64 *temp = c.arena.take(items * pw);
+    plain_to_ntt(plain, n_coeffs, plain_bstride, ct.limbs, temp, items, s);
+    transform_to_ntt(ct, batch, s);
+    const u64 words = (u64)ct.size * pw;
+    const LimbMap map = c.ct_map(ct.limbs);
+    const u64 rpi = plain_bstride ? (u64)ct.size * ct.limbs : 0;
+    if (ct.bstride == words) launch_mul_plain(ct.data, temp, c.d_desc, map, c.logn, ct.limbs, batch * ct.size * ct.limbs, s, rpi, pw);
+    else for (u64 b = 0; b < batch; b++) launch_mul_plain(ct.data + b * ct.bstride, temp + (plain_bstride ? b * pw : 0), c.d_desc, map, c.logn, ct.limbs, (u64)ct.size * ct.limbs, s);
+    transform_from_ntt(ct, batch, s);
+}
+
 } // namespace troyhip

@@ -31,6 +31,11 @@ public:
     Context &c;
 
     void add_sub(CtBatch &a, const CtBatch &b, u64 batch, bool sub, hipStream_t s);
+    // plaintext operands: BFV/BGV plain = n_coeffs coefficients mod t per item; CKKS add/sub: [limbs][N] NTT-form rows.
+    // plain_bstride = 0 broadcasts one plaintext to the whole batch
+    void add_plain(CtBatch &ct, const u64 *plain, u64 n_coeffs, u64 plain_bstride, double plain_scale, bool sub, u64 batch, hipStream_t s);
+    void multiply_plain(CtBatch &ct, const u64 *plain, u64 n_coeffs, u64 plain_bstride, u64 batch, hipStream_t s);
+    void plain_to_ntt(const u64 *plain, u64 n_coeffs, u64 plain_bstride, int limbs, u64 *out, u64 count, hipStream_t s);
     void negate(CtBatch &a, u64 batch, hipStream_t s);
     // out may alias a or b; out.size/limbs/... are set; out.data/out.bstride are the caller's
     void multiply(const CtBatch &a, const CtBatch &b, CtBatch &out, u64 batch, hipStream_t s);

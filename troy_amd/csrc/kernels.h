@@ -15,7 +15,26 @@ void launch_ntt2(u64 *data, const u64 *src, u64 src_ostride, bool src_reduce, co
 // ---- poly.hip ----
 void launch_ew(int op, const u64 *a, const u64 *b, u64 *out, const PrimeDesc *primes, const LimbMap &map, int logn, u64 rows, hipStream_t s);
 void launch_mul_scalar(u64 *x, const PrimeDesc *primes, const LimbMap &map, const u64 *scalars, int logn, u64 rows, hipStream_t s);
-void launch_mul_plain(u64 *a, const u64 *plain, const PrimeDesc *primes, const LimbMap &map, int logn, u64 limbs, u64 rows, hipStream_t s);
+void launch_mul_plain(u64 *a, const u64 *plain, const PrimeDesc *primes, const LimbMap &map, int logn, u64 limbs, u64 rows, hipStream_t s,
+                      u64 rows_per_item = 0, u64 plain_bstride = 0); // rows_per_item != 0: item b = row / rows_per_item uses plain + b * plain_bstride
+
+// plaintext operands (evaluator_cuda.cu:1654-1948, utils/scalingvariant_cuda.cu:21-176)
+struct PlainArgs {
+    const PrimeDesc *primes;
+    LimbMap map;          // prime ids of the level's limbs
+    u64 delta[64];        // BFV: floor(q/t) mod q_l
+    u64 t_p, t_cr0, t_cr1;
+    u64 q_mod_t, thr;     // q mod t, (t+1)/2
+    u64 cf;               // BGV correction factor of the ciphertext
+    int logn;
+    u64 limbs, n_coeffs;  // plaintext: n_coeffs coefficients mod t per item
+    u64 items;            // batch
+    u64 plain_bstride;    // words between the plaintexts of consecutive items (0: one plaintext for all)
+};
+// kind: 0 BFV scaling variant, 2 BGV (times correction factor), 1 rows (CKKS: plain is [limbs][N] like the ciphertext)
+void launch_add_plain(int kind, bool sub, u64 *ct0, u64 ct_bstride, const u64 *plain, const PlainArgs &a, hipStream_t s);
+// lifted[item][l][n] = plain coefficient as a residue of q_l (upper half shifted by q - t), zero beyond n_coeffs
+void launch_plain_lift(const u64 *plain, u64 *lifted, const PlainArgs &a, hipStream_t s);
 void launch_tensor(int s1, int s2, const u64 *a, const u64 *b, u64 *out, u64 a_bstride, u64 b_bstride, const PrimeDesc *primes, const LimbMap &map,
                    int logn, u64 limbs, u64 batch, hipStream_t s);
 void launch_galois(bool ntt_form, const u64 *in, u64 *out, const PrimeDesc *primes, const LimbMap &map, int logn, uint32_t elt, u64 rows, hipStream_t s);

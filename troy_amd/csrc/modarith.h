@@ -54,6 +54,19 @@ TROY_HD u64 barrett128(u64 lo, u64 hi, const Mod &m) {
     u64 r = lo - q * m.p;
     return r >= m.p ? r - m.p : r;
 }
+// floor((hi:lo) / p) for a value < p * 2^64 (the quotient fits one word): the Barrett quotient estimate, corrected once
+TROY_HD u64 div128(u64 lo, u64 hi, const Mod &m) {
+    u64 carry = mulhi64(lo, m.cr0);
+    u64 t2lo = lo * m.cr1, t2hi = mulhi64(lo, m.cr1);
+    u64 tmp1 = t2lo + carry;
+    u64 tmp3 = t2hi + (tmp1 < carry);
+    u64 t4lo = hi * m.cr0, t4hi = mulhi64(hi, m.cr0);
+    u64 tmp1b = tmp1 + t4lo;
+    u64 c2 = t4hi + (tmp1b < tmp1);
+    u64 q = hi * m.cr1 + tmp3 + c2;
+    u64 r = lo - q * m.p;
+    return r >= m.p ? q + 1 : q;
+}
 TROY_HD u64 mulmod(u64 a, u64 b, const Mod &m) { return barrett128(a * b, mulhi64(a, b), m); }
 TROY_HD u64 addmod(u64 a, u64 b, u64 p) { u64 s = a + b; return s >= p ? s - p : s; }
 TROY_HD u64 submod(u64 a, u64 b, u64 p) { return a >= b ? a - b : a + p - b; }

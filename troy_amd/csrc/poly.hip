@@ -72,23 +72,116 @@ void launch_mul_scalar(u64 *x, const PrimeDesc *primes, const LimbMap &map, cons
     launch_check("mul_scalar_kernel");
 }
 
-// ct (x) plaintext in NTT form: out[b][i][l][n] = a[b][i][l][n] * plain[l][n]   (multiplyPlainNtt)
-__global__ __launch_bounds__(EW_THREADS) void mul_plain_kernel(u64 *a, const u64 *plain, const PrimeDesc *primes, LimbMap map, int logn, u64 limbs, u64 total) {
+// ct (x) plaintext in NTT form: out[b][i][l][n] = a[b][i][l][n] * plain[(b)][l][n]   (multiplyPlainNtt)
+__global__ __launch_bounds__(EW_THREADS) void mul_plain_kernel(u64 *a, const u64 *plain, const PrimeDesc *primes, LimbMap map, int logn, u64 limbs, u64 total,
+                                                               u64 rows_per_item, u64 plain_bstride) {
     u64 i = ((u64)blockIdx.x * EW_THREADS + threadIdx.x) * 2;
     if (i >= total) return;
     u64 row = i >> logn, l = row % limbs, n = i & ((u64(1) << logn) - 1);
     const Mod m = mod_of(prime_of(primes, map, row));
+    const u64 *pl = rows_per_item ? plain + (row / rows_per_item) * plain_bstride : plain;
     ulonglong2 v = *reinterpret_cast<ulonglong2 *>(a + i);
-    const ulonglong2 w = *reinterpret_cast<const ulonglong2 *>(plain + (l << logn) + n);
+    const ulonglong2 w = *reinterpret_cast<const ulonglong2 *>(pl + (l << logn) + n);
     v.x = mulmod(v.x, w.x, m);
     v.y = mulmod(v.y, w.y, m);
     *reinterpret_cast<ulonglong2 *>(a + i) = v;
 }
-void launch_mul_plain(u64 *a, const u64 *plain, const PrimeDesc *primes, const LimbMap &map, int logn, u64 limbs, u64 rows, hipStream_t s) {
+void launch_mul_plain(u64 *a, const u64 *plain, const PrimeDesc *primes, const LimbMap &map, int logn, u64 limbs, u64 rows, hipStream_t s, u64 rows_per_item,
+                      u64 plain_bstride) {
     u64 total = rows << logn;
     if (!total) return;
-    TROY_LAUNCH(mul_plain_kernel, dim3(ceil_div(total / 2 + (total & 1), EW_THREADS)), dim3(EW_THREADS), 0, s, a, plain, primes, map, logn, limbs, total);
+    TROY_LAUNCH(mul_plain_kernel, dim3(ceil_div(total / 2 + (total & 1), EW_THREADS)), dim3(EW_THREADS), 0, s, a, plain, primes, map, logn, limbs, total, rows_per_item,
+                plain_bstride);
     launch_check("mul_plain_kernel");
+}
+
+// ---------------------------------------------------------------- plaintext operands
+// addPlain / subPlain on c0 (evaluator_cuda.cu:1654-1720):
+//   BFV  (scalingvariant_cuda.cu:21-176 multiplyAdd/SubPlainWithScalingVariant): c0_l[j] +-= m_j * Delta_l + floor((m_j (q mod t) + (t+1)/2) / t)
+//   BGV  (addPlainWithoutScalingVariant): c0_l[j] +-= (m_j * correction_factor mod t) mod q_l
+// one thread = one plaintext coefficient of one item, looping over the limbs (the 128/64 division is done once)
+template <int KIND, bool SUB> __global__ __launch_bounds__(EW_THREADS) void add_plain_kernel(u64 *ct0, u64 ct_bstride, const u64 *plain, PlainArgs a) {
+    const u64 idx = (u64)blockIdx.x * EW_THREADS + threadIdx.x;
+    if (idx >= a.items * a.n_coeffs) return;
+    const u64 b = idx / a.n_coeffs, j = idx % a.n_coeffs;
+    const u64 mval = plain[b * a.plain_bstride + j];
+    const Mod tm{a.t_p, a.t_cr0, a.t_cr1};
+    u64 fix = 0, pc = 0;
+    if (KIND == 0) {
+        u64 lo = mval * a.q_mod_t, hi = mulhi64(mval, a.q_mod_t);
+        lo += a.thr;
+        hi += lo < a.thr;
+        fix = div128(lo, hi, tm);
+    } else {
+        pc = a.cf == 1 ? mval : mulmod(mval, a.cf, tm);
+    }
+    u64 *c = ct0 + b * ct_bstride + j;
+    for (u64 l = 0; l < a.limbs; l++, c += u64(1) << a.logn) {
+        const Mod m = mod_of(a.primes[a.map.id[l]]);
+        u64 v;
+        if (KIND == 0) {
+            u64 lo = mval * a.delta[l], hi = mulhi64(mval, a.delta[l]);
+            lo += fix;
+            hi += lo < fix;
+            v = barrett128(lo, hi, m);
+        } else {
+            v = barrett64(pc, m);
+        }
+        *c = SUB ? submod(*c, v, m.p) : addmod(*c, v, m.p);
+    }
+}
+// CKKS: the plaintext is an RNS polynomial [limbs][N] in NTT form at the level of the ciphertext
+template <bool SUB> __global__ __launch_bounds__(EW_THREADS) void add_plain_rows_kernel(u64 *ct0, u64 ct_bstride, const u64 *plain, PlainArgs a) {
+    const u64 idx = (u64)blockIdx.x * EW_THREADS + threadIdx.x;
+    const u64 per = a.limbs << a.logn;
+    if (idx >= a.items * per) return;
+    const u64 b = idx / per, r = idx % per;
+    const u64 p = a.primes[a.map.id[r >> a.logn]].p;
+    u64 *c = ct0 + b * ct_bstride + r;
+    const u64 v = plain[b * a.plain_bstride + r];
+    *c = SUB ? submod(*c, v, p) : addmod(*c, v, p);
+}
+void launch_add_plain(int kind, bool sub, u64 *ct0, u64 ct_bstride, const u64 *plain, const PlainArgs &a, hipStream_t s) {
+    if (kind == 1) {
+        const u64 total = a.items * a.limbs << a.logn;
+        if (!total) return;
+        dim3 grid(ceil_div(total, EW_THREADS)), blk(EW_THREADS);
+        if (sub) TROY_LAUNCH(HIP_KERNEL_NAME(add_plain_rows_kernel<true>), grid, blk, 0, s, ct0, ct_bstride, plain, a);
+        else TROY_LAUNCH(HIP_KERNEL_NAME(add_plain_rows_kernel<false>), grid, blk, 0, s, ct0, ct_bstride, plain, a);
+    } else {
+        const u64 total = a.items * a.n_coeffs;
+        if (!total) return;
+        dim3 grid(ceil_div(total, EW_THREADS)), blk(EW_THREADS);
+        if (kind == 0 && !sub) TROY_LAUNCH(HIP_KERNEL_NAME(add_plain_kernel<0, false>), grid, blk, 0, s, ct0, ct_bstride, plain, a);
+        else if (kind == 0) TROY_LAUNCH(HIP_KERNEL_NAME(add_plain_kernel<0, true>), grid, blk, 0, s, ct0, ct_bstride, plain, a);
+        else if (!sub) TROY_LAUNCH(HIP_KERNEL_NAME(add_plain_kernel<2, false>), grid, blk, 0, s, ct0, ct_bstride, plain, a);
+        else TROY_LAUNCH(HIP_KERNEL_NAME(add_plain_kernel<2, true>), grid, blk, 0, s, ct0, ct_bstride, plain, a);
+    }
+    launch_check("add_plain_kernel");
+}
+// Lifting of plaintext coefficients to the ciphertext base (gMultiplyPlainNormalUtilA/B, evaluator_cuda.cu:1722-1755, and the
+// same step of transformToNttInplace(Plaintext)): m -> m for m < (t+1)/2, else m + (q - t).  Modulo q_l that is
+// m - t (q = 0 mod q_l); stored canonical -- the reference leaves m + (q_l - t) unreduced in fast-lift mode and feeds the
+// lazy NTT, whose output is canonical either way.
+__global__ __launch_bounds__(EW_THREADS) void plain_lift_kernel(const u64 *plain, u64 *lifted, PlainArgs a) {
+    const u64 idx = (u64)blockIdx.x * EW_THREADS + threadIdx.x;
+    const u64 per = a.limbs << a.logn;
+    if (idx >= a.items * per) return;
+    const u64 b = idx / per, r = idx % per, l = r >> a.logn, j = r & ((u64(1) << a.logn) - 1);
+    u64 v = 0;
+    if (j < a.n_coeffs) {
+        const Mod m = mod_of(a.primes[a.map.id[l]]);
+        const u64 mval = plain[b * a.plain_bstride + j];
+        v = barrett64(mval, m);
+        if (mval >= a.thr) v = submod(v, barrett64(a.t_p, m), m.p);
+    }
+    lifted[idx] = v;
+}
+void launch_plain_lift(const u64 *plain, u64 *lifted, const PlainArgs &a, hipStream_t s) {
+    const u64 total = a.items * a.limbs << a.logn;
+    if (!total) return;
+    TROY_LAUNCH(plain_lift_kernel, dim3(ceil_div(total, EW_THREADS)), dim3(EW_THREADS), 0, s, plain, lifted, a);
+    launch_check("plain_lift_kernel");
 }
 
 // ---------------------------------------------------------------- ciphertext tensor (a-3 / A.7)
