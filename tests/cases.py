@@ -301,3 +301,26 @@ def check_plain_monomial_and_batch(gpu_cfg_name):
     ntt = be.ev.transformPlainToNtt(be.api.DeviceBuffer.from_numpy(pts), L, N - 3, count=B).to_numpy().reshape(B, L, N)
     for b in range(B):
         assert np.array_equal(ntt[b], orc.impl.plain_to_ntt(pts[b], L))
+
+
+def check_dense_multiply(cfg_name, batch=3):
+    """BFV multiply consumes DENSE operands in place (extension and first NTT pass read them directly); strided operands
+    (capacity > size) go through a staging copy.  Both must give the oracle's product, and must leave the inputs untouched."""
+    cfg = CONFIGS[cfg_name]
+    be = GpuBackend(cfg, batch=batch)
+    orc = oracle_backend(cfg)
+    from oracle import ref as R
+    N, L = cfg["N"], len(be.primes) - 1
+    q = be.primes[:L]
+    xa, xb = synth.uniform_ct(881, q, 2, N, batch), synth.uniform_ct(882, q, 2, N, batch)
+    exp = [orc.impl.eval(R.OP_MULTIPLY, R.Ct(xa[i], False), R.Ct(xb[i], False)).data for i in range(batch)]
+    for cap in (None, 3):
+        a = be.api.Ciphertext.from_numpy(be.ctx, xa, False, 1.0, 1, capacity=cap)
+        b = be.api.Ciphertext.from_numpy(be.ctx, xb, False, 1.0, 1, capacity=cap)
+        m = be.ev.multiply(a, b).cpu()
+        for i in range(batch):
+            assert np.array_equal(m[i], exp[i]), (cap, i)
+        assert np.array_equal(a.cpu(), xa) and np.array_equal(b.cpu(), xb)
+        sq = be.ev.square(a).cpu()
+        for i in range(batch):
+            assert np.array_equal(sq[i], orc.impl.eval(R.OP_SQUARE, R.Ct(xa[i], False)).data), (cap, i)

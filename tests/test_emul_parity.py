@@ -66,3 +66,7 @@ def test_emulated_ntt_all_sizes(logn, emul_api, oracle_lib):
 @pytest.mark.parametrize("name", ["bfv_n64_k3", "bgv_n128_k4"])
 def test_emulated_plain_operands(name, emul_api, oracle_lib):
     cases.check_plain_monomial_and_batch(name)
+
+
+def test_emulated_dense_multiply(emul_api):
+    cases.check_dense_multiply("cfgA_bfv_n4096_k3", batch=2)

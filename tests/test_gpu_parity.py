@@ -309,3 +309,9 @@ def test_plain_operands_monomial_and_per_item(name, gpu, oracle_lib):
     """addPlain / subPlain / multiplyPlain (coefficient form) / transformToNtt(Plaintext) with one plaintext per
     batch row, and the one-coefficient plaintext under the CUDA evaluator's semantics; vs the CPU oracle, bit-exact"""
     cases.check_plain_monomial_and_batch(name)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["bfv_n128_k4", "cfgA_bfv_n4096_k3", "cfgB_bfv_n8192_k5"])
+def test_dense_and_strided_multiply(name, gpu):
+    cases.check_dense_multiply(name)

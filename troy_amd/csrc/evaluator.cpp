@@ -151,15 +151,30 @@ void Evaluator::multiply(const CtBatch &a, const CtBatch &b, CtBatch &out, u64 b
         const int sp = sa + sb;
         u64 *xq = c.arena.take(batch * sp * pw), *xb = c.arena.take(batch * sp * bw);
         u64 *dq = c.arena.take(batch * ds * pw), *db = c.arena.take(batch * ds * bw);
-        // BEHZ steps (1)-(3): copy, extend q -> Bsk, forward NTT in both bases
-        launch_copy_strided(a.data, a.bstride, xq, sp * pw, sa * pw, batch, s);
-        launch_copy_strided(b.data, b.bstride, xq + sa * pw, sp * pw, sb * pw, batch, s);
-        launch_behz_extend(xq, pw, xb, bw, c.d_desc, *lv.behz, N, batch * sp, s);
-        launch_ntt(xq, c.d_desc, qmap, batch * sp * L, c.logn, false, s);
-        launch_ntt(xb, c.d_desc, c.ids_map(lv.bsk_ids), batch * sp * nb, c.logn, false, s);
-        // (4) tensor in both bases
-        launch_tensor(sa, sb, xq, xq + sa * pw, dq, sp * pw, sp * pw, c.d_desc, qmap, c.logn, L, batch, s);
-        launch_tensor(sa, sb, xb, xb + sa * bw, db, sp * bw, sp * bw, c.d_desc, c.ids_map(lv.bsk_ids), c.logn, nb, batch, s);
+        // BEHZ steps (1)-(3): extend q -> Bsk, forward NTT in both bases
+        const LimbMap bmap = c.ids_map(lv.bsk_ids);
+        if (a.bstride == (u64)sa * pw && b.bstride == (u64)sb * pw) {
+            // dense operands are consumed in place: the extension reads them directly and the first NTT pass reads them
+            // as its out-of-place source, so no staging copy is made.  Scratch layout: [a-part | b-part] in each base.
+            u64 *xq_a = xq, *xq_b = xq + batch * sa * pw, *xb_a = xb, *xb_b = xb + batch * sa * bw;
+            launch_behz_extend(a.data, pw, xb_a, bw, c.d_desc, *lv.behz, N, batch * sa, s);
+            launch_behz_extend(b.data, pw, xb_b, bw, c.d_desc, *lv.behz, N, batch * sb, s);
+            launch_ntt_from(xq_a, a.data, c.d_desc, qmap, batch * sa * L, c.logn, s);
+            launch_ntt_from(xq_b, b.data, c.d_desc, qmap, batch * sb * L, c.logn, s);
+            launch_ntt(xb, c.d_desc, bmap, batch * sp * nb, c.logn, false, s);
+            // (4) tensor in both bases
+            launch_tensor(sa, sb, xq_a, xq_b, dq, sa * pw, sb * pw, c.d_desc, qmap, c.logn, L, batch, s);
+            launch_tensor(sa, sb, xb_a, xb_b, db, sa * bw, sb * bw, c.d_desc, bmap, c.logn, nb, batch, s);
+        } else {
+            launch_copy_strided(a.data, a.bstride, xq, sp * pw, sa * pw, batch, s);
+            launch_copy_strided(b.data, b.bstride, xq + sa * pw, sp * pw, sb * pw, batch, s);
+            launch_behz_extend(xq, pw, xb, bw, c.d_desc, *lv.behz, N, batch * sp, s);
+            launch_ntt(xq, c.d_desc, qmap, batch * sp * L, c.logn, false, s);
+            launch_ntt(xb, c.d_desc, bmap, batch * sp * nb, c.logn, false, s);
+            // (4) tensor in both bases
+            launch_tensor(sa, sb, xq, xq + sa * pw, dq, sp * pw, sp * pw, c.d_desc, qmap, c.logn, L, batch, s);
+            launch_tensor(sa, sb, xb, xb + sa * bw, db, sp * bw, sp * bw, c.d_desc, bmap, c.logn, nb, batch, s);
+        }
         // (5) inverse NTT
         launch_ntt(dq, c.d_desc, qmap, batch * ds * L, c.logn, true, s);
         launch_ntt(db, c.d_desc, c.ids_map(lv.bsk_ids), batch * ds * nb, c.logn, true, s);

@@ -6,11 +6,13 @@ namespace troyhip {
 
 // ---- ntt.hip ----
 void launch_ntt(u64 *data, const PrimeDesc *primes, const LimbMap &map, size_t rows, int logn, bool inverse, hipStream_t stream);
+// forward transform of `src` (same row layout, left untouched) into `data`
+void launch_ntt_from(u64 *data, const u64 *src, const PrimeDesc *primes, const LimbMap &map, size_t rows, int logn, hipStream_t stream);
 
 // ---- ntt2.hip (N >= 4096) ----
 bool ntt2_supported(int logn);
 void launch_ntt2(u64 *data, const u64 *src, u64 src_ostride, bool src_reduce, const PrimeDesc *primes, const LimbMap &map, size_t rows, int logn,
-                 bool inverse, hipStream_t stream);
+                 bool inverse, hipStream_t stream, bool src_same_layout = false);
 
 // ---- poly.hip ----
 void launch_ew(int op, const u64 *a, const u64 *b, u64 *out, const PrimeDesc *primes, const LimbMap &map, int logn, u64 rows, hipStream_t s);

@@ -186,6 +186,15 @@ static void plan(int logn, int &k1, int &k2) {
     k1 = logn - k2;
 }
 
+void launch_ntt_from(u64 *data, const u64 *src, const PrimeDesc *primes, const LimbMap &map, size_t rows, int logn, hipStream_t stream) {
+    if (rows == 0) return;
+    if (ntt2_supported(logn) && rows % ((size_t)map.period * map.inner) == 0) { // the first pass reads src, no copy
+        launch_ntt2(data, src, 0, false, primes, map, rows, logn, false, stream, true);
+        return;
+    }
+    HIP_CHECK(hipMemcpyAsync(data, src, (rows << logn) * sizeof(u64), hipMemcpyDeviceToDevice, stream));
+    launch_ntt(data, primes, map, rows, logn, false, stream);
+}
 void launch_ntt(u64 *data, const PrimeDesc *primes, const LimbMap &map, size_t rows, int logn, bool inverse, hipStream_t stream) {
     if (rows == 0) return;
     if (ntt2_supported(logn) && rows % ((size_t)map.period * map.inner) == 0) { // production path for N >= 4096

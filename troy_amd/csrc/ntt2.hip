@@ -54,6 +54,7 @@ struct Ntt2Args {
     unsigned rows_per_wg; // R
     unsigned chunks;      // ceil(m_total / R)
     int src_reduce;       // reduce src values modulo the row prime (they are residues of another prime)
+    int src_same_layout;  // src has the row layout of data (plain out-of-place transform) instead of the digit broadcast
 };
 
 __device__ __forceinline__ unsigned swz(unsigned f) { return f ^ ((f >> 3) & 7u) ^ (((f >> 6) & 3u) << 3); }
@@ -381,7 +382,7 @@ __global__ __launch_bounds__(N2_THREADS, N2_MIN_WAVES) void ntt2_kernel(Ntt2Args
         const unsigned o = mm / inner, k = mm - o * inner;
         const u64 r = ((u64)o * period + slot) * inner + k;
         row = a.data + (r << logn);
-        in = (REDUCE || a.src) ? (a.src + (u64)o * a.src_ostride + ((u64)k << logn)) : row;
+        in = (REDUCE || a.src) ? (a.src_same_layout ? a.src + (r << logn) : a.src + (u64)o * a.src_ostride + ((u64)k << logn)) : row;
     };
     constexpr bool DMA = N2_DMA && WAVE_PRIVATE && !(N2_EXP & 1);
     u64 *const wave_stage = lds[1] + 512 * (threadIdx.x >> 6);
@@ -481,7 +482,7 @@ template <int INV, int NS> static void launch_strided(const Ntt2Args &a, unsigne
 
 // rows are laid out r = (o * period + i) * inner + k; src (optional, forward only): item o, digit k at src + o*src_ostride + k*N
 void launch_ntt2(u64 *data, const u64 *src, u64 src_ostride, bool src_reduce, const PrimeDesc *primes, const LimbMap &map, size_t rows, int logn,
-                 bool inverse, hipStream_t stream) {
+                 bool inverse, hipStream_t stream, bool src_same_layout) {
     if (rows == 0) return;
     if (!ntt2_supported(logn)) throw Error(ST_LOGIC_ERROR, "ntt2: unsupported size");
     const size_t per_outer = (size_t)map.period * map.inner;
@@ -502,6 +503,7 @@ void launch_ntt2(u64 *data, const u64 *src, u64 src_ostride, bool src_reduce, co
     a.rows_per_wg = a.m_total < 8 ? a.m_total : (map.inner > 1 ? (map.inner <= 16 ? map.inner : 8) : 8);
     a.chunks = (a.m_total + a.rows_per_wg - 1) / a.rows_per_wg;
     a.src_reduce = 0;
+    a.src_same_layout = 0;
     const unsigned blocks = (unsigned)((map.period * a.chunks) << a.tiles_per_row_log);
     auto contig = [&](auto inv_tag, bool final_pass) {
         constexpr int INV = decltype(inv_tag)::value;
@@ -522,7 +524,7 @@ void launch_ntt2(u64 *data, const u64 *src, u64 src_ostride, bool src_reduce, co
     };
     if (!inverse) {
         Ntt2Args first = a;
-        if (src) { first.src = src; first.src_ostride = src_ostride; first.src_reduce = src_reduce; }
+        if (src) { first.src = src; first.src_ostride = src_ostride; first.src_reduce = src_reduce; first.src_same_layout = src_same_layout; }
         strided(std::integral_constant<int, 0>{}, first, src && src_reduce);
         contig(std::integral_constant<int, 0>{}, true);
     } else {
