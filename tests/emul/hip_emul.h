@@ -51,6 +51,7 @@ struct State {
     int cur = -1;
     const std::function<void()> *body = nullptr;
     uint64_t wave_buf[64 * 64]; // [wave][lane]
+    int8_t mfma_buf[64 * 64][32]; // [wave][lane]: 16 A bytes, 16 B bytes
 };
 inline State &S() {
     static State s;
@@ -145,6 +146,23 @@ template <class T> inline T wave_exchange(T v, int src_lane) {
     T out;
     memcpy(&out, &r, sizeof(T));
     return out;
+}
+// v_mfma_i32_32x32x32_i8 (layout verified on hardware by tools/mfma_probe.hip):
+//   A: lane l = row l % 32, k = 16 (l / 32) + 0..15;  B: lane l = column l % 32, same k;  D reg r: row 8 (r / 4) + 4 (l / 32) + r % 4, column l % 32
+inline void mfma_i32_32x32x32_i8(const int8_t (&a)[16], const int8_t (&b)[16], int32_t (&c)[16]) {
+    State &s = S();
+    const int w = wave_id(), l = lane_id();
+    memcpy(s.mfma_buf[w * 64 + l], a, 16);
+    memcpy(s.mfma_buf[w * 64 + l] + 16, b, 16);
+    park(2);
+    for (int r = 0; r < 16; r++) {
+        const int row = 8 * (r / 4) + 4 * (l / 32) + r % 4, col = l % 32;
+        int32_t acc = 0;
+        for (int k = 0; k < 32; k++)
+            acc += (int32_t)s.mfma_buf[w * 64 + row + 32 * (k / 16)][k % 16] * (int32_t)s.mfma_buf[w * 64 + col + 32 * (k / 16)][16 + k % 16];
+        c[r] += acc;
+    }
+    park(2);
 }
 } // namespace hip_emul
 

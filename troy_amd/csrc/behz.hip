@@ -21,6 +21,7 @@
 //     reduces again per step; the residues written to HBM are the same canonical values);
 //   * all Shoup quotients are precomputed on the host.
 #include "kernels.h"
+#include <cstdlib>
 
 namespace troyhip {
 
@@ -244,13 +245,188 @@ __global__ __launch_bounds__(BEHZ_THREADS) void behz_floor_sk_kernel(const u64 *
     }
 }
 
+
+// ================================================================ matrix-core path (MFMA int8)
+// The base conversion is a matrix product  S[c][o] = sum_l y[c][l] * M[o][l]  over the integers (then one reduction per
+// entry).  Written in balanced base-256 digits it becomes an int8 GEMM that v_mfma_i32_32x32x32_i8 computes exactly:
+//   * y_l (< 2^61) -> eight signed digits = bytes of (y + 0x80..80) ^ 0x80..80: TWO instructions per residue, and the
+//     64-bit register pair IS the 8 consecutive K-bytes of the B operand (K index = limb * 8 + digit);
+//   * M[o][l] is expanded on the host into 16 Toeplitz rows (o, s): row (o, s) . digits(y) = coefficient of 2^(8 s);
+//   * the product is taken transposed (rows = (output, shift), columns = coefficients), so after the 4 k-blocks a lane
+//     holds ALL 16 shift coefficients of ONE (coefficient, output) pair in its 16 accumulator registers: no cross-lane
+//     traffic; sum_s C_s 2^(8s) is recombined with 64/128-bit adds and reduced once.
+// K = 16 limbs x 8 digits = 128 (4 k-blocks), 16 output slots x 16 shifts = 256 rows (8 row-blocks): L <= 16, |Bsk| <= 16.
+// Per (coefficient, output) the VALU does ~70 instructions instead of 14 x 6 v_mad_u64_u32 + ~65; the 14 x 15 x 64
+// byte products run on the matrix cores (32 MFMA per 32 coefficients, 2 k cycles of the MFMA pipe per 32 coefficients).
+#define BEHZ_TILE 64
+__device__ __forceinline__ void mfma_zero(MfmaAcc &a) {
+#pragma unroll
+    for (int r = 0; r < 16; r++) a.v[r] = 0;
+}
+// sum_s C_s 2^(8 s), C_s signed 32-bit (|C_s| < 2^22); the total is known to be in [0, 2^126).
+// Four coefficients at a time fit 64 bits: W_j = (C_4j + C_4j+1 2^8) + (C_4j+2 + C_4j+3 2^8) 2^16 -- two 32-bit shift-adds
+// and one v_mad_i64_i32; then V = W_0 + W_1 2^32 + W_2 2^64 + W_3 2^96 word by word with sign words.
+__device__ __forceinline__ long long mad_i64_i32(int a, int b, long long c) {
+#ifdef TROYHIP_CPU_EMUL
+    return (long long)a * b + c;
+#else
+    long long d;
+    u64 sink;
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(sink) : "v"(a), "s"(b), "v"(c));
+    return d;
+#endif
+}
+__device__ __forceinline__ U128 mfma_recombine(const MfmaAcc &a) {
+    long long w[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int p01 = a.v[4 * j] + (a.v[4 * j + 1] << 8), p23 = a.v[4 * j + 2] + (a.v[4 * j + 3] << 8);
+        w[j] = mad_i64_i32(p23, 1 << 16, (long long)p01);
+    }
+    // lo = W0 + (W1 << 32) ; hi = sext(W0) + (W1 >> 32) + W2 + (W3 << 32) + carry   (all modulo 2^64: the result fits 128 bits)
+    const u64 w0 = (u64)w[0], t1 = (u64)w[1] << 32;
+    const u64 lo = w0 + t1;
+    u64 hi = (u64)(w[0] >> 63) + (u64)(w[1] >> 32) + (u64)w[2] + ((u64)w[3] << 32) + (lo < w0);
+    return U128{lo, hi};
+}
+__device__ __forceinline__ MfmaFrag ld_frag(const void *base, size_t idx) { return reinterpret_cast<const MfmaFrag *>(base)[idx]; }
+
+// per-output constants staged in LDS: with the transposed product the output index differs between the two halves of a
+// wave, so these are per-lane reads (LDS, not dependent global loads)
+struct BehzOutConst {
+    u64 p, cr1, two_p, r64_op, r64_quo, extra; // extra: ext_q[o] (extension)
+};
+__device__ __forceinline__ u64 reduce128c(const U128 v, const BehzOutConst &k) {
+    const u64 a = mul_lazy(v.hi, k.r64_op, k.r64_quo, k.p);
+    const u64 b = v.lo - mulhi64(v.lo, k.cr1) * k.p;
+    u64 s = a + b;
+    s = s >= k.two_p ? s - k.two_p : s;
+    return s >= k.p ? s - k.p : s;
+}
+
+// same contract as behz_extend_kernel; a 256-thread workgroup walks `tiles_per_wg` tiles of 64 coefficients of one
+// polynomial; wave w owns row-blocks w and w + 4 (outputs 2w, 2w+1, 2w+8, 2w+9) and keeps their A-fragments in registers
+template <int KB> __global__ __launch_bounds__(BEHZ_THREADS) void behz_extend_mfma_kernel(const u64 *in, u64 in_pstride, u64 *out, u64 out_pstride, const PrimeDesc *primes,
+                                                                                          BehzDev c, u64 N, unsigned tiles_per_wg) {
+    __shared__ __attribute__((aligned(16))) u64 ydig[8 * BEHZ_TILE * 2]; // [limb pair][coefficient] 16-byte units
+    __shared__ BehzOutConst oc[16];
+    const unsigned lane = threadIdx.x & 63, half = lane >> 5, cl = lane & 31;
+    const int w = BEHZ_UNIFORM((int)(threadIdx.x >> 6));
+    const u64 poly = blockIdx.y;
+    const u64 *x = in + poly * in_pstride;
+    const int RB = (c.nBsk + 1) >> 1;
+    const cshoup_ptr ext_pre = (cshoup_ptr)c.ext_pre;
+    if ((int)threadIdx.x < c.nBsk) {
+        const PrimeDesc &pd = primes[c.bsk_id[threadIdx.x]];
+        oc[threadIdx.x] = BehzOutConst{pd.p, pd.cr1, pd.two_p, pd.r64.op, pd.r64.quo, c.ext_q[threadIdx.x]};
+    }
+    MfmaFrag af[2][KB], am[KB];
+#pragma unroll
+    for (int kb = 0; kb < KB; kb++) {
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int rb = w + 4 * j < RB ? w + 4 * j : 0;
+            af[j][kb] = ld_frag(c.ext_frag, ((size_t)rb * 4 + kb) * 64 + lane);
+        }
+        am[kb] = ld_frag(c.ext_mt_frag, (size_t)kb * 64 + lane);
+    }
+    const u64 c80 = 0x8080808080808080ull;
+    // this wave converts limbs w, w+4, ...: their constants are wave-uniform and loaded once; the residues of the NEXT tile are
+    // fetched while the current one is multiplied (one exposed memory latency per workgroup instead of several per tile)
+    u64 qp[KB];
+    Shoup qpre[KB];
+#pragma unroll
+    for (int i = 0; i < KB; i++) {
+        const int l = w + 4 * i;
+        const int lc = l < c.L ? l : 0;
+        const unsigned id = BEHZ_UNIFORM((unsigned)c.q_id[lc]);
+        qp[i] = ((cu64_ptr)&primes[id])[0];
+        qpre[i] = ld_shoup(ext_pre + lc);
+    }
+    u64 xr[KB];
+    auto fetch = [&](unsigned t) {
+        const u64 n0 = ((u64)blockIdx.x * tiles_per_wg + t) * BEHZ_TILE;
+#pragma unroll
+        for (int i = 0; i < KB; i++) {
+            const int l = w + 4 * i;
+            xr[i] = (l < c.L && n0 + lane < N) ? x[(u64)l * N + n0 + lane] : 0;
+        }
+    };
+    fetch(0);
+    for (unsigned t = 0; t < tiles_per_wg; t++) {
+        const u64 n0 = ((u64)blockIdx.x * tiles_per_wg + t) * BEHZ_TILE;
+        if (n0 >= N) break;
+        // y_l = x_l * m_tilde * (q/q_l)^-1 mod q_l, stored as balanced digits; limbs L..4KB-1 are zero padding
+#pragma unroll
+        for (int i = 0; i < KB; i++) {
+            const int l = w + 4 * i;
+            u64 v = 0;
+            if (l < c.L && n0 + lane < N) v = (mul_shoup(xr[i], qpre[i].op, qpre[i].quo, qp[i]) + c80) ^ c80;
+            ydig[(((l >> 1) * BEHZ_TILE) + lane) * 2 + (l & 1)] = v;
+        }
+        if (t + 1 < tiles_per_wg) fetch(t + 1);
+        __syncthreads();
+#pragma unroll 1
+        for (int sub = 0; sub < BEHZ_TILE / 32; sub++) {
+            const unsigned cc = sub * 32 + cl;
+            MfmaFrag bf[KB];
+#pragma unroll
+            for (int kb = 0; kb < KB; kb++) bf[kb] = ld_frag(ydig, (size_t)(2 * kb + half) * BEHZ_TILE + cc);
+            // r = -(sum_l y_l (q/q_l)) q^-1 mod 2^32, from shifts 0..3 of the m_tilde row
+            MfmaAcc acc;
+            mfma_zero(acc);
+#pragma unroll
+            for (int kb = 0; kb < KB; kb++) TROY_MFMA_I8(am[kb], bf[kb], acc);
+            const u32 rsum = (u32)acc.v[0] + ((u32)acc.v[1] << 8) + ((u32)acc.v[2] << 16) + ((u32)acc.v[3] << 24);
+            const u64 r_mt = ((u64)rsum * c.neg_inv_q_mod_mt) & 0xFFFFFFFFull;
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                if (w + 4 * j >= RB) break;
+                mfma_zero(acc);
+#pragma unroll
+                for (int kb = 0; kb < KB; kb++) TROY_MFMA_I8(af[j][kb], bf[kb], acc);
+                const int o = 2 * (w + 4 * j) + (int)half;
+                if (o < c.nBsk) {
+                    const BehzOutConst k = oc[o];
+                    u64 temp = r_mt;                                   // centred representative of r (rns.cpp:966-975)
+                    if (temp >= (u64(1) << 31)) temp += k.p - (u64(1) << 32);
+                    U128 v = mfma_recombine(acc);
+                    add128(v, temp, k.extra);
+                    const u64 r = reduce128c(v, k);
+                    if (n0 + cc < N) out[poly * out_pstride + (u64)o * N + n0 + cc] = r;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// TROYHIP_BEHZ=valu forces the VALU kernels (they remain the path for L > 16 or |Bsk| > 16); read once
+static bool behz_use_mfma() {
+    static const bool v = [] { const char *e = getenv("TROYHIP_BEHZ"); return !(e && e[0] == 'v'); }();
+    return v;
+}
 void launch_behz_extend(const u64 *in, u64 in_pstride, u64 *out, u64 out_pstride, const PrimeDesc *primes, const BehzDev &c, u64 N, u64 polys, hipStream_t s) {
     if (!polys) return;
+    const bool mfma = c.ext_frag && behz_use_mfma();
+    const u64 tiles = ceil_div(N, (u64)BEHZ_TILE);
+    const unsigned tpw = tiles >= 64 ? 8 : 1; // amortise the A-fragment loads over 8 tiles when there are enough workgroups
     size_t lds = (size_t)c.L * BEHZ_COEFFS * sizeof(u64);
     for (u64 p0 = 0; p0 < polys; p0 += 65535) { // gridDim.y limit
         const u64 np = polys - p0 < 65535 ? polys - p0 : 65535;
-        TROY_LAUNCH(behz_extend_kernel, dim3(ceil_div(N, BEHZ_COEFFS), (unsigned)np), dim3(BEHZ_THREADS), lds, s, in + p0 * in_pstride, in_pstride, out + p0 * out_pstride,
-                    out_pstride, primes, c, N);
+        if (mfma) {
+            const dim3 grid((unsigned)ceil_div(tiles, (u64)tpw), (unsigned)np);
+            const u64 *pi = in + p0 * in_pstride;
+            u64 *po = out + p0 * out_pstride;
+            switch ((c.L + 3) / 4) {
+            case 1: TROY_LAUNCH(HIP_KERNEL_NAME(behz_extend_mfma_kernel<1>), grid, dim3(BEHZ_THREADS), 0, s, pi, in_pstride, po, out_pstride, primes, c, N, tpw); break;
+            case 2: TROY_LAUNCH(HIP_KERNEL_NAME(behz_extend_mfma_kernel<2>), grid, dim3(BEHZ_THREADS), 0, s, pi, in_pstride, po, out_pstride, primes, c, N, tpw); break;
+            case 3: TROY_LAUNCH(HIP_KERNEL_NAME(behz_extend_mfma_kernel<3>), grid, dim3(BEHZ_THREADS), 0, s, pi, in_pstride, po, out_pstride, primes, c, N, tpw); break;
+            default: TROY_LAUNCH(HIP_KERNEL_NAME(behz_extend_mfma_kernel<4>), grid, dim3(BEHZ_THREADS), 0, s, pi, in_pstride, po, out_pstride, primes, c, N, tpw); break;
+            }
+        } else
+            TROY_LAUNCH(behz_extend_kernel, dim3(ceil_div(N, BEHZ_COEFFS), (unsigned)np), dim3(BEHZ_THREADS), lds, s, in + p0 * in_pstride, in_pstride, out + p0 * out_pstride,
+                        out_pstride, primes, c, N);
     }
     launch_check("behz_extend_kernel");
 }

@@ -33,6 +33,51 @@ u64 *Arena::take(size_t count) {
     return p;
 }
 
+// ---- matrix-core operand packing (behz.hip) ----
+// A 61-bit entry M is written in eight BALANCED base-256 digits d_j in [-128, 127], M = sum d_j 2^(8j):
+// d = bytes of (M + 0x8080..80) xor 0x80 each (adding 128 to every byte position propagates the carries, the xor
+// recentres every byte).  Row (o, s) of the Toeplitz form holds, at k = (limb, i), the digit d_{s-i} of M[o][limb], so that
+// (row . digits of y) = the coefficient of 2^(8s) in sum_limb y_limb * M[o][limb].
+static inline int8_t balanced_digit(u64 m, int j) {
+    if (j < 0 || j > 7) return 0;
+    const u64 c80 = 0x8080808080808080ull;
+    return (int8_t)((((m + c80) ^ c80) >> (8 * j)) & 0xFF);
+}
+// entries[o * 16 + limb]; fragment layout [row-block][k-block][lane][16 bytes]: lane = (tile row m = lane % 32, k half = lane / 32);
+// tile row m -> output 2 rb + (m / 4) % 2, shift (m / 8) * 4 + m % 4  (so that lane l's accumulator register r is shift r of
+// output 2 rb + l / 32, see the D layout of the instruction)
+static std::vector<uint8_t> pack_mfma_rows(const std::vector<u64> &entries, int n_out) {
+    const int RB = (n_out + 1) / 2;
+    std::vector<uint8_t> f((size_t)RB * 4 * 64 * 16, 0);
+    for (int rb = 0; rb < RB; rb++)
+        for (int kb = 0; kb < 4; kb++)
+            for (int lane = 0; lane < 64; lane++) {
+                const int m = lane % 32, o = 2 * rb + (m / 4) % 2, s = (m / 8) * 4 + m % 4;
+                for (int t = 0; t < 16; t++) {
+                    const int k = 32 * kb + 16 * (lane / 32) + t, limb = k / 8, i = k % 8;
+                    int8_t v = 0;
+                    if (o < n_out) v = balanced_digit(entries[(size_t)o * 16 + limb], s - i);
+                    f[(((size_t)rb * 4 + kb) * 64 + lane) * 16 + t] = (uint8_t)v;
+                }
+            }
+    return f;
+}
+// the m_tilde row only needs the result modulo 2^32: tile rows m with m % 8 < 4 carry shift m % 4, the rest is zero
+static std::vector<uint8_t> pack_mfma_mt(const std::vector<u64> &row) {
+    std::vector<uint8_t> f((size_t)4 * 64 * 16, 0);
+    for (int kb = 0; kb < 4; kb++)
+        for (int lane = 0; lane < 64; lane++) {
+            const int m = lane % 32;
+            if (m >= 8) continue;
+            const int s = m % 4;
+            for (int t = 0; t < 16; t++) {
+                const int k = 32 * kb + 16 * (lane / 32) + t, limb = k / 8, i = k % 8;
+                f[((size_t)kb * 64 + lane) * 16 + t] = (uint8_t)balanced_digit(row[limb], s - i);
+            }
+        }
+    return f;
+}
+
 template <class T> T *Context::upload(const std::vector<T> &v, std::vector<void *> &owner) {
     if (v.empty()) return nullptr;
     T *d = nullptr;
@@ -191,6 +236,14 @@ void Context::upload_tables() {
         c->ext_mt_row = upload(mt_row, lv.dev_blocks);
         c->neg_inv_q_mod_mt = r.neg_inv_prod_q_mod_mtilde;
         c->ext_q = upload(ext_q, lv.dev_blocks);
+        if (L <= 16 && nBsk <= 16) { // matrix-core path (behz.hip): int8 balanced-digit Toeplitz form of the same matrices
+            std::vector<u64> em((size_t)nBsk * 16, 0), mt(16, 0);
+            for (int o = 0; o < nBsk; o++)
+                for (int l = 0; l < L; l++) em[(size_t)o * 16 + l] = host::mul_mod(r.q_to_Bsk.mat[o][l], r.inv_mtilde_mod_Bsk[o], r.Bsk[o]);
+            for (int l = 0; l < L; l++) mt[l] = mt_row[l];
+            c->ext_frag = upload(pack_mfma_rows(em, nBsk), lv.dev_blocks);
+            c->ext_mt_frag = upload(pack_mfma_mt(mt), lv.dev_blocks);
+        }
         c->floor_pre = upload(floor_pre, lv.dev_blocks);
         c->floor_mat3 = upload(floor_mat, lv.dev_blocks);
         c->floor_t3 = upload(floor_t, lv.dev_blocks);

@@ -26,12 +26,19 @@ struct LimbMap {
 #define TROY_DYN_LDS(type, name) static type name[160 * 1024 / sizeof(type)]
 // LDS-DMA: lane l of the wave copies 16 bytes from its own global address to (wave-uniform LDS base) + 16*l
 #define TROY_GLDS16(gptr, lds_base) memcpy((char *)(lds_base) + 16 * (threadIdx.x & 63), (const void *)(gptr), 16)
+// 32x32x32 int8 matrix-core product: c[16] += A-fragment x B-fragment (16 signed bytes per lane each)
+struct MfmaFrag { int8_t bytes[16]; };
+struct MfmaAcc { int32_t v[16]; };
+#define TROY_MFMA_I8(fa, fb, fc) hip_emul::mfma_i32_32x32x32_i8((fa).bytes, (fb).bytes, (fc).v)
 #define TROY_WAIT_VMEM() hip_emul::park(2) /* lanes run one after another here: every lane's copy must have happened */
 #define TROY_WAIT_LDS() hip_emul::park(2)  /* ... and every lane must have read before any lane overwrites */
 #else
 // global_load_lds_dwordx4 (gfx950): no VGPR round trip, completion is counted by vmcnt; hipcc does NOT order later LDS
 // reads after it, so every consumer waits explicitly (TROY_WAIT_VMEM) and every overwrite of a staging buffer is
 // issued only after the reads of its previous content returned (TROY_WAIT_LDS).
+struct MfmaFrag { int bytes __attribute__((ext_vector_type(4))); };
+struct MfmaAcc { int v __attribute__((ext_vector_type(16))); };
+#define TROY_MFMA_I8(fa, fb, fc) ((fc).v = __builtin_amdgcn_mfma_i32_32x32x32_i8((fa).bytes, (fb).bytes, (fc).v, 0, 0, 0))
 #define TROY_GLDS16(gptr, lds_base)                                                                                      \
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gptr), (__attribute__((address_space(3))) void *)(lds_base), 16, 0, 0)
 #define TROY_WAIT_VMEM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")

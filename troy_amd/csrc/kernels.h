@@ -91,6 +91,10 @@ struct BehzDev {
     const u32 *ext_mt_row;            // [L]   (q/q_l) mod m_tilde = 2^32
     u64 neg_inv_q_mod_mt;             // -q^-1 mod 2^32
     const u64 *ext_q;                 // [nBsk]  q * m_tilde^-1 mod Bsk_o
+    // matrix-core form of the same matrices (behz.hip, "MFMA path"): A-fragments of v_mfma_i32_32x32x32_i8, 16 bytes per
+    // lane, [row-block][k-block][lane]; a row-block is 2 outputs x 16 byte-shifts, a k-block is 4 input limbs x 8 digits
+    const void *ext_frag;             // [ceil(nBsk/2)][4][64]
+    const void *ext_mt_frag;          // [4][64]  the m_tilde row (shifts 0..3 only)
     // --- floor + Shenoy-Kumaresan ---
     const Shoup *floor_pre;           // [L]   (t * (q/q_l)^-1) mod q_l
     const Mat3 *floor_mat3;           // [nBsk][L]  -(q/q_l) * q^-1 [* (B/B_o)^-1 for o < nB] mod Bsk_o
