@@ -401,6 +401,158 @@ template <int KB> __global__ __launch_bounds__(BEHZ_THREADS) void behz_extend_mf
     }
 }
 
+
+// same contract as behz_floor_sk_kernel.  Two chained int8 GEMMs per tile of 64 coefficients:
+//   (1) rows of floor_frag1 x digits(y)  -> + db_o T_o -> u_b (b < |B|, as digits for the next product) and z_sk
+//   (2) rows of floor_frag2 x digits(u)  -> + alpha-term -> out_l ;  alpha comes from the B -> m_sk row, which every wave
+//       evaluates for its own lanes (one extra row-block instead of a broadcast and a barrier).
+// Stage-1 fragments live in registers, stage-2 fragments are shared through LDS (all four waves need different row-blocks of
+// the same 32 KiB, and 3 workgroups per CU must fit).
+template <int KB> __global__ __launch_bounds__(BEHZ_THREADS) void behz_floor_sk_mfma_kernel(const u64 *dq, u64 dq_pstride, const u64 *db, u64 db_pstride, u64 *out,
+                                                                                           u64 out_pstride, const PrimeDesc *primes, BehzDev c, u64 N,
+                                                                                           unsigned tiles_per_wg) {
+    TROY_DYN_LDS(u64, lds);
+    u64 *ydig = lds;                                          // [8 limb pairs][64] 16-byte units (8 KiB)
+    u64 *udig = ydig + 8 * BEHZ_TILE * 2;                     // same, for the B residues of the floor result
+    u64 *zsk = udig + 8 * BEHZ_TILE * 2;                      // [64]
+    BehzOutConst *oc1 = reinterpret_cast<BehzOutConst *>(zsk + BEHZ_TILE); // [16] Bsk outputs (extra = T_o)
+    BehzOutConst *oc2 = oc1 + 16;                             // [16] q outputs (extra = prod_B mod q_l)
+    u64 *frag2 = reinterpret_cast<u64 *>(oc2 + 16);           // [RB2 + 1][4][64] 16-byte fragments: floor_frag2 then floor_msk_frag
+    const unsigned lane = threadIdx.x & 63, half = lane >> 5, cl = lane & 31;
+    const int w = BEHZ_UNIFORM((int)(threadIdx.x >> 6));
+    const u64 poly = blockIdx.y;
+    const u64 *xq = dq + poly * dq_pstride, *xb = db + poly * db_pstride;
+    const int RB1 = (c.nBsk + 1) >> 1, RB2 = (c.L + 1) >> 1;
+    const PrimeDesc &psk = primes[c.bsk_id[c.nB]];
+    // ---- per-workgroup setup
+    if ((int)threadIdx.x < c.nBsk) {
+        const PrimeDesc &pd = primes[c.bsk_id[threadIdx.x]];
+        oc1[threadIdx.x] = BehzOutConst{pd.p, pd.cr1, pd.two_p, pd.r64.op, pd.r64.quo, c.floor_t[threadIdx.x]};
+    }
+    if ((int)threadIdx.x < c.L) {
+        const PrimeDesc &pd = primes[c.q_id[threadIdx.x]];
+        oc2[threadIdx.x] = BehzOutConst{pd.p, pd.cr1, pd.two_p, pd.r64.op, pd.r64.quo, c.prod_B_mod_q[threadIdx.x]};
+    }
+    for (unsigned i = threadIdx.x; i < 8 * BEHZ_TILE * 2; i += BEHZ_THREADS) udig[i] = 0; // padding limbs stay zero
+    {
+        const ulonglong2 *g2 = reinterpret_cast<const ulonglong2 *>(c.floor_frag2), *gm = reinterpret_cast<const ulonglong2 *>(c.floor_msk_frag);
+        ulonglong2 *f = reinterpret_cast<ulonglong2 *>(frag2);
+        for (unsigned i = threadIdx.x; i < (unsigned)RB2 * 256; i += BEHZ_THREADS) f[i] = g2[i];
+        for (unsigned i = threadIdx.x; i < 256; i += BEHZ_THREADS) f[RB2 * 256 + i] = gm[i];
+    }
+    MfmaFrag af[2][KB];
+#pragma unroll
+    for (int kb = 0; kb < KB; kb++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int rb = w + 4 * j < RB1 ? w + 4 * j : 0;
+            af[j][kb] = ld_frag(c.floor_frag1, ((size_t)rb * 4 + kb) * 64 + lane);
+        }
+    const cshoup_ptr floor_pre = (cshoup_ptr)c.floor_pre;
+    u64 qp[KB];
+    Shoup qpre[KB];
+#pragma unroll
+    for (int i = 0; i < KB; i++) {
+        const int l = w + 4 * i;
+        const int lc = l < c.L ? l : 0;
+        const unsigned id = BEHZ_UNIFORM((unsigned)c.q_id[lc]);
+        qp[i] = ((cu64_ptr)&primes[id])[0];
+        qpre[i] = ld_shoup(floor_pre + lc);
+    }
+    const u64 c80 = 0x8080808080808080ull;
+    u64 xr[KB];
+    auto fetch = [&](unsigned t) {
+        const u64 n0 = ((u64)blockIdx.x * tiles_per_wg + t) * BEHZ_TILE;
+#pragma unroll
+        for (int i = 0; i < KB; i++) {
+            const int l = w + 4 * i;
+            xr[i] = (l < c.L && n0 + lane < N) ? xq[(u64)l * N + n0 + lane] : 0;
+        }
+    };
+    fetch(0);
+    for (unsigned t = 0; t < tiles_per_wg; t++) {
+        const u64 n0 = ((u64)blockIdx.x * tiles_per_wg + t) * BEHZ_TILE;
+        if (n0 >= N) break;
+#pragma unroll
+        for (int i = 0; i < KB; i++) {
+            const int l = w + 4 * i;
+            u64 v = 0;
+            if (l < c.L && n0 + lane < N) v = (mul_shoup(xr[i], qpre[i].op, qpre[i].quo, qp[i]) + c80) ^ c80;
+            ydig[(((l >> 1) * BEHZ_TILE) + lane) * 2 + (l & 1)] = v;
+        }
+        // the Bsk residues this lane will need in the stage-1 epilogue: (sub, j) -> db[o = 2 (w + 4 j) + half][n0 + 32 sub + cl]
+        u64 dbv[2][2];
+#pragma unroll
+        for (int sub = 0; sub < 2; sub++)
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const int o = 2 * (w + 4 * j) + (int)half;
+                const u64 n = n0 + sub * 32 + cl;
+                dbv[sub][j] = (o < c.nBsk && n < N) ? xb[(u64)o * N + n] : 0;
+            }
+        if (t + 1 < tiles_per_wg) fetch(t + 1);
+        __syncthreads();
+        // ---- stage 1
+#pragma unroll
+        for (int sub = 0; sub < 2; sub++) {
+            const unsigned cc = sub * 32 + cl;
+            MfmaFrag bf[KB];
+#pragma unroll
+            for (int kb = 0; kb < KB; kb++) bf[kb] = ld_frag(ydig, (size_t)(2 * kb + half) * BEHZ_TILE + cc);
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                if (w + 4 * j >= RB1) break;
+                MfmaAcc acc;
+                mfma_zero(acc);
+#pragma unroll
+                for (int kb = 0; kb < KB; kb++) TROY_MFMA_I8(af[j][kb], bf[kb], acc);
+                const int o = 2 * (w + 4 * j) + (int)half;
+                if (o < c.nBsk) {
+                    const BehzOutConst k = oc1[o];
+                    U128 v = mfma_recombine(acc);
+                    add128(v, dbv[sub][j], k.extra);
+                    const u64 r = reduce128c(v, k);
+                    if (o < c.nB) udig[(((o >> 1) * BEHZ_TILE) + cc) * 2 + (o & 1)] = (r + c80) ^ c80;
+                    else zsk[cc] = r;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- stage 2: Shenoy-Kumaresan
+#pragma unroll 1
+        for (int sub = 0; sub < 2; sub++) {
+            const unsigned cc = sub * 32 + cl;
+            MfmaFrag bf[KB];
+#pragma unroll
+            for (int kb = 0; kb < KB; kb++) bf[kb] = ld_frag(udig, (size_t)(2 * kb + half) * BEHZ_TILE + cc);
+            MfmaAcc acc;
+            mfma_zero(acc);
+#pragma unroll
+            for (int kb = 0; kb < KB; kb++) TROY_MFMA_I8(ld_frag(frag2, ((size_t)RB2 * 4 + kb) * 64 + lane), bf[kb], acc);
+            const u64 conv_sk = reduce128(mfma_recombine(acc), psk);
+            const u64 alpha = mul_shoup(conv_sk + (psk.p - zsk[cc]), c.inv_B_mod_msk.op, c.inv_B_mod_msk.quo, psk.p);
+            const bool neg = alpha > (psk.p >> 1);
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                if (w + 4 * j >= RB2) break;
+                mfma_zero(acc);
+#pragma unroll
+                for (int kb = 0; kb < KB; kb++) TROY_MFMA_I8(ld_frag(frag2, ((size_t)(w + 4 * j) * 4 + kb) * 64 + lane), bf[kb], acc);
+                const int l = 2 * (w + 4 * j) + (int)half;
+                if (l < c.L) {
+                    const BehzOutConst k = oc2[l];
+                    U128 v = mfma_recombine(acc);
+                    if (neg) add128(v, psk.p - alpha, k.extra);  // alpha represents a negative value
+                    else add128(v, alpha, k.p - k.extra);
+                    const u64 r = reduce128c(v, k);
+                    if (n0 + cc < N) out[poly * out_pstride + (u64)l * N + n0 + cc] = r;
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // TROYHIP_BEHZ=valu forces the VALU kernels (they remain the path for L > 16 or |Bsk| > 16); read once
 static bool behz_use_mfma() {
     static const bool v = [] { const char *e = getenv("TROYHIP_BEHZ"); return !(e && e[0] == 'v'); }();
@@ -433,11 +585,28 @@ void launch_behz_extend(const u64 *in, u64 in_pstride, u64 *out, u64 out_pstride
 void launch_behz_floor_sk(const u64 *dq, u64 dq_pstride, const u64 *db, u64 db_pstride, u64 *out, u64 out_pstride, const PrimeDesc *primes, const BehzDev &c, u64 N,
                           u64 polys, hipStream_t s) {
     if (!polys) return;
+    const bool mfma = c.floor_frag1 && behz_use_mfma();
+    const u64 tiles = ceil_div(N, (u64)BEHZ_TILE);
+    const unsigned tpw = tiles >= 64 ? 8 : 1;
+    const int kb = ((c.L > c.nB ? c.L : c.nB) + 3) / 4;
+    const size_t lds_mfma = (size_t)(2 * 8 * BEHZ_TILE * 2 + BEHZ_TILE) * sizeof(u64) + 32 * sizeof(BehzOutConst) + (size_t)((c.L + 1) / 2 + 1) * 4 * 64 * 16;
     size_t lds = (size_t)(c.L + c.nB + 1) * BEHZ_COEFFS * sizeof(u64);
     for (u64 p0 = 0; p0 < polys; p0 += 65535) {
         const u64 np = polys - p0 < 65535 ? polys - p0 : 65535;
-        TROY_LAUNCH(behz_floor_sk_kernel, dim3(ceil_div(N, BEHZ_COEFFS), (unsigned)np), dim3(BEHZ_THREADS), lds, s, dq + p0 * dq_pstride, dq_pstride, db + p0 * db_pstride,
-                    db_pstride, out + p0 * out_pstride, out_pstride, primes, c, N);
+        const u64 *pq = dq + p0 * dq_pstride, *pb = db + p0 * db_pstride;
+        u64 *po = out + p0 * out_pstride;
+        if (mfma) {
+            const dim3 grid((unsigned)ceil_div(tiles, (u64)tpw), (unsigned)np);
+            switch (kb) {
+            case 1: TROY_LAUNCH(HIP_KERNEL_NAME(behz_floor_sk_mfma_kernel<1>), grid, dim3(BEHZ_THREADS), lds_mfma, s, pq, dq_pstride, pb, db_pstride, po, out_pstride, primes, c, N, tpw); break;
+            case 2: TROY_LAUNCH(HIP_KERNEL_NAME(behz_floor_sk_mfma_kernel<2>), grid, dim3(BEHZ_THREADS), lds_mfma, s, pq, dq_pstride, pb, db_pstride, po, out_pstride, primes, c, N, tpw); break;
+            case 3: TROY_LAUNCH(HIP_KERNEL_NAME(behz_floor_sk_mfma_kernel<3>), grid, dim3(BEHZ_THREADS), lds_mfma, s, pq, dq_pstride, pb, db_pstride, po, out_pstride, primes, c, N, tpw); break;
+            default: TROY_LAUNCH(HIP_KERNEL_NAME(behz_floor_sk_mfma_kernel<4>), grid, dim3(BEHZ_THREADS), lds_mfma, s, pq, dq_pstride, pb, db_pstride, po, out_pstride, primes, c, N, tpw); break;
+            }
+        } else {
+            TROY_LAUNCH(behz_floor_sk_kernel, dim3(ceil_div(N, BEHZ_COEFFS), (unsigned)np), dim3(BEHZ_THREADS), lds, s, pq, dq_pstride, pb, db_pstride, po, out_pstride, primes, c,
+                        N);
+        }
     }
     launch_check("behz_floor_sk_kernel");
 }

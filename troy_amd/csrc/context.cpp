@@ -247,6 +247,26 @@ void Context::upload_tables() {
         c->floor_pre = upload(floor_pre, lv.dev_blocks);
         c->floor_mat3 = upload(floor_mat, lv.dev_blocks);
         c->floor_t3 = upload(floor_t, lv.dev_blocks);
+        if (L <= 16 && nBsk <= 16 && nB <= 16) {
+            std::vector<u64> f1((size_t)nBsk * 16, 0), traw(nBsk), f2((size_t)L * 16, 0), fm(2 * 16, 0);
+            for (int o = 0; o < nBsk; o++) {
+                const u64 p = r.Bsk[o];
+                u64 fscale = r.inv_prod_q_mod_Bsk[o];
+                if (o < nB) fscale = host::mul_mod(fscale, r.B_to_q.inv_punct[o], p);
+                traw[o] = host::mul_mod(t % p, fscale, p);
+                for (int l = 0; l < L; l++) {
+                    const u64 f = host::mul_mod(r.q_to_Bsk.mat[o][l], fscale, p);
+                    f1[(size_t)o * 16 + l] = f ? p - f : 0;
+                }
+            }
+            for (int l = 0; l < L; l++)
+                for (int b = 0; b < nB; b++) f2[(size_t)l * 16 + b] = r.B_to_q.mat[l][b];
+            for (int b = 0; b < nB; b++) fm[b] = fm[16 + b] = r.B_to_msk.mat[0][b];
+            c->floor_frag1 = upload(pack_mfma_rows(f1, nBsk), lv.dev_blocks);
+            c->floor_t = upload(traw, lv.dev_blocks);
+            c->floor_frag2 = upload(pack_mfma_rows(f2, L), lv.dev_blocks);
+            c->floor_msk_frag = upload(pack_mfma_rows(fm, 2), lv.dev_blocks);
+        }
         c->B2q3 = upload(B2q, lv.dev_blocks);
         c->B2msk3 = upload(B2msk, lv.dev_blocks);
         c->inv_B_mod_msk = make_shoup(r.inv_prod_B_mod_msk, r.m_sk);

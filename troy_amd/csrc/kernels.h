@@ -101,6 +101,11 @@ struct BehzDev {
     const Mat3 *floor_t3;             // [nBsk]     t * q^-1 [* (B/B_o)^-1] mod Bsk_o
     const Mat3 *B2q3;                 // [L][nB]   (B/B_b) mod q_l
     const Mat3 *B2msk3;               // [nB]      (B/B_b) mod m_sk
+    // matrix-core form (behz_floor_sk_mfma_kernel): same fragment layout as ext_frag
+    const void *floor_frag1;          // [ceil(nBsk/2)][4][64]  rows of floor_mat3
+    const u64 *floor_t;               // [nBsk]  t * q^-1 [* (B/B_o)^-1] mod Bsk_o (the db_o term is one 64 x 64 product)
+    const void *floor_frag2;          // [ceil(L/2)][4][64]     rows of B2q3 (K runs over the B limbs)
+    const void *floor_msk_frag;       // [4][64]                the B -> m_sk row, in both halves of the tile
     Shoup inv_B_mod_msk;
     const u64 *prod_B_mod_q;          // [L]
 };
