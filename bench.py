@@ -65,7 +65,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=32, help="ciphertext pairs per GPU per step")
+    ap.add_argument("--batch", type=int, default=64, help="ciphertext pairs per GPU per step")
     ap.add_argument("--workload", default="bfv_n32768_l14", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--ntt-reps", type=int, default=10)

@@ -181,4 +181,92 @@ __device__ __forceinline__ void gs_bfly4_last(u64 (&X)[4], u64 (&Y)[4], const Sh
 __device__ __forceinline__ void reduce4_from_8p(u64 (&x)[4], const PrimeConst &c) { csub4(x, c.four_p); csub4(x, c.two_p); csub4(x, c.p); }
 __device__ __forceinline__ void reduce4_from_4p(u64 (&x)[4], const PrimeConst &c) { csub4(x, c.two_p); csub4(x, c.p); }
 
+
+// ---- 128-bit multiply-accumulate, four independent accumulators: acc[i] += x[i] * k[i]  (acc < 2^128 by the caller's bound)
+// 10 instructions per term (4 v_mad_u64_u32 + 6 carry adds); every carry is consumed by the next step of the same lane
+// group, and the four groups are interleaved so that a carry writer and its reader are 4 instructions apart.
+struct Acc128 { u32 a0, a1, a2, a3; };
+#ifdef TROYHIP_CPU_EMUL
+__device__ __forceinline__ void mac128x4(Acc128 (&acc)[4], const u64 (&x)[4], const u64 (&k)[4]) {
+    for (int i = 0; i < 4; i++) {
+        unsigned __int128 v = ((unsigned __int128)acc[i].a3 << 96) | ((unsigned __int128)acc[i].a2 << 64) | ((unsigned __int128)acc[i].a1 << 32) | acc[i].a0;
+        v += (unsigned __int128)x[i] * k[i];
+        acc[i].a0 = (u32)v; acc[i].a1 = (u32)(v >> 32); acc[i].a2 = (u32)(v >> 64); acc[i].a3 = (u32)(v >> 96);
+    }
+}
+#else
+__device__ __forceinline__ void mac128x4(Acc128 (&acc)[4], const u64 (&x)[4], const u64 (&k)[4]) {
+    u64 lo[4], hi[4], t[4];
+    u64 sb, sc, sd;
+#pragma unroll
+    for (int i = 0; i < 4; i++) { lo[i] = mk64(acc[i].a0, acc[i].a1); hi[i] = mk64(acc[i].a2, acc[i].a3); }
+    u32 a2[4], a3[4], a1[4], a0[4];
+    // S1: [a0:a1] += xl*kl -> carry ; S2: a2 += carry -> carry ; S3: a3 += carry
+    asm("v_mad_u64_u32 %0, vcc, %15, %19, %0\n\t"
+        "v_mad_u64_u32 %1, %12, %16, %20, %1\n\t"
+        "v_mad_u64_u32 %2, %13, %17, %21, %2\n\t"
+        "v_mad_u64_u32 %3, %14, %18, %22, %3\n\t"
+        "v_addc_co_u32 %4, vcc, 0, %4, vcc\n\t"
+        "v_addc_co_u32 %5, %12, 0, %5, %12\n\t"
+        "v_addc_co_u32 %6, %13, 0, %6, %13\n\t"
+        "v_addc_co_u32 %7, %14, 0, %7, %14\n\t"
+        "v_addc_co_u32 %8, vcc, 0, %8, vcc\n\t"
+        "v_addc_co_u32 %9, %12, 0, %9, %12\n\t"
+        "v_addc_co_u32 %10, %13, 0, %10, %13\n\t"
+        "v_addc_co_u32 %11, %14, 0, %11, %14"
+        : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]), "+v"(acc[0].a2), "+v"(acc[1].a2), "+v"(acc[2].a2), "+v"(acc[3].a2), "+v"(acc[0].a3), "+v"(acc[1].a3),
+          "+v"(acc[2].a3), "+v"(acc[3].a3), "=&s"(sb), "=&s"(sc), "=&s"(sd)
+        : "v"(lo32(x[0])), "v"(lo32(x[1])), "v"(lo32(x[2])), "v"(lo32(x[3])), "v"(lo32(k[0])), "v"(lo32(k[1])), "v"(lo32(k[2])), "v"(lo32(k[3]))
+        : "vcc");
+    // S4: t = xl*kh ; S5: t += xh*kl -> carry (weight 2^96) ; S6: a3 += carry
+    asm("v_mad_u64_u32 %0, vcc, %11, %19, 0\n\t"
+        "v_mad_u64_u32 %1, %8, %12, %20, 0\n\t"
+        "v_mad_u64_u32 %2, %9, %13, %21, 0\n\t"
+        "v_mad_u64_u32 %3, %10, %14, %22, 0\n\t"
+        "v_mad_u64_u32 %0, vcc, %15, %23, %0\n\t"
+        "v_mad_u64_u32 %1, %8, %16, %24, %1\n\t"
+        "v_mad_u64_u32 %2, %9, %17, %25, %2\n\t"
+        "v_mad_u64_u32 %3, %10, %18, %26, %3\n\t"
+        "v_addc_co_u32 %4, vcc, 0, %4, vcc\n\t"
+        "v_addc_co_u32 %5, %8, 0, %5, %8\n\t"
+        "v_addc_co_u32 %6, %9, 0, %6, %9\n\t"
+        "v_addc_co_u32 %7, %10, 0, %7, %10"
+        : "=&v"(t[0]), "=&v"(t[1]), "=&v"(t[2]), "=&v"(t[3]), "+v"(acc[0].a3), "+v"(acc[1].a3), "+v"(acc[2].a3), "+v"(acc[3].a3), "=&s"(sb), "=&s"(sc), "=&s"(sd)
+        : "v"(lo32(x[0])), "v"(lo32(x[1])), "v"(lo32(x[2])), "v"(lo32(x[3])), "v"(hi32(x[0])), "v"(hi32(x[1])), "v"(hi32(x[2])), "v"(hi32(x[3])), "v"(hi32(k[0])),
+          "v"(hi32(k[1])), "v"(hi32(k[2])), "v"(hi32(k[3])), "v"(lo32(k[0])), "v"(lo32(k[1])), "v"(lo32(k[2])), "v"(lo32(k[3]))
+        : "vcc");
+#pragma unroll
+    for (int i = 0; i < 4; i++) { a0[i] = lo32(lo[i]); a1[i] = hi32(lo[i]); }
+    // S7: a1 += t.lo -> carry ; S8: a2 += t.hi + carry -> carry ; S9: a3 += carry
+    asm("v_add_co_u32 %0, vcc, %0, %15\n\t"
+        "v_add_co_u32 %1, %12, %1, %16\n\t"
+        "v_add_co_u32 %2, %13, %2, %17\n\t"
+        "v_add_co_u32 %3, %14, %3, %18\n\t"
+        "v_addc_co_u32 %4, vcc, %4, %19, vcc\n\t"
+        "v_addc_co_u32 %5, %12, %5, %20, %12\n\t"
+        "v_addc_co_u32 %6, %13, %6, %21, %13\n\t"
+        "v_addc_co_u32 %7, %14, %7, %22, %14\n\t"
+        "v_addc_co_u32 %8, vcc, 0, %8, vcc\n\t"
+        "v_addc_co_u32 %9, %12, 0, %9, %12\n\t"
+        "v_addc_co_u32 %10, %13, 0, %10, %13\n\t"
+        "v_addc_co_u32 %11, %14, 0, %11, %14"
+        : "+v"(a1[0]), "+v"(a1[1]), "+v"(a1[2]), "+v"(a1[3]), "+v"(acc[0].a2), "+v"(acc[1].a2), "+v"(acc[2].a2), "+v"(acc[3].a2), "+v"(acc[0].a3), "+v"(acc[1].a3),
+          "+v"(acc[2].a3), "+v"(acc[3].a3), "=&s"(sb), "=&s"(sc), "=&s"(sd)
+        : "v"(lo32(t[0])), "v"(lo32(t[1])), "v"(lo32(t[2])), "v"(lo32(t[3])), "v"(hi32(t[0])), "v"(hi32(t[1])), "v"(hi32(t[2])), "v"(hi32(t[3]))
+        : "vcc");
+    // S10: [a2:a3] += xh*kh
+#pragma unroll
+    for (int i = 0; i < 4; i++) hi[i] = mk64(acc[i].a2, acc[i].a3);
+    asm("v_mad_u64_u32 %0, vcc, %7, %11, %0\n\t"
+        "v_mad_u64_u32 %1, %4, %8, %12, %1\n\t"
+        "v_mad_u64_u32 %2, %5, %9, %13, %2\n\t"
+        "v_mad_u64_u32 %3, %6, %10, %14, %3"
+        : "+v"(hi[0]), "+v"(hi[1]), "+v"(hi[2]), "+v"(hi[3]), "=&s"(sb), "=&s"(sc), "=&s"(sd)
+        : "v"(hi32(x[0])), "v"(hi32(x[1])), "v"(hi32(x[2])), "v"(hi32(x[3])), "v"(hi32(k[0])), "v"(hi32(k[1])), "v"(hi32(k[2])), "v"(hi32(k[3]))
+        : "vcc");
+#pragma unroll
+    for (int i = 0; i < 4; i++) { acc[i].a0 = a0[i]; acc[i].a1 = a1[i]; acc[i].a2 = lo32(hi[i]); acc[i].a3 = hi32(hi[i]); }
+}
+#endif
+
 } // namespace troyhip

@@ -3,6 +3,7 @@
 #include "kernels.h"
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 namespace troyhip {
@@ -217,6 +218,11 @@ size_t Evaluator::scratch_switch_key(int limbs, u64 batch) const {
     return batch * N * (dl /*t_target*/ + rl * dl /*D*/ + 2 * rl /*acc*/ + 2 * dl /*corr*/ + 2 /*last*/) + 512;
 }
 
+// TROYHIP_KS=split keeps the transforms and the inner product in separate kernels (tests, measurements); read once
+static bool ks_fused() {
+    static const bool v = [] { const char *e = getenv("TROYHIP_KS"); return !(e && e[0] == 's'); }();
+    return v;
+}
 // switchKeyInplace (evaluator_cuda.cu:1163-1362; CPU src/evaluator.cpp:2310-2653)
 void Evaluator::switch_key(CtBatch &ct, const u64 *target, u64 t_bstride, const KsKey &key, u64 batch, hipStream_t s) {
     check_ct(ct);
@@ -260,16 +266,23 @@ void Evaluator::switch_key(CtBatch &ct, const u64 *target, u64 t_bstride, const 
         coeff_target = tt;
         ct_tb = dl * N;
     }
-    // decompose + extend every limb to every output prime, then ONE batched NTT over all (L+1)*L rows
-    if (ntt2_supported(c.logn)) {
-        // fused: the strided NTT pass reads the target and reduces it modulo each output prime on the fly
-        launch_ntt2(D, coeff_target, ct_tb, true, c.d_desc, c.ids_map(out_ids, (uint32_t)dl), batch * rl * dl, c.logn, false, s);
+    // decompose + extend every limb to every output prime, ONE batched NTT over all (L+1)*L rows, inner product with the key
+    const u64 *mac_target = c.scheme == SCHEME_CKKS ? target : nullptr;
+    if (ntt2_supported(c.logn) && ks_fused()) {
+        // fused: the first NTT pass reads the target and reduces it modulo each output prime on the fly; the second pass keeps
+        // the transforms in registers and accumulates them against the key -- the expanded digits are never written back
+        launch_ntt2_ks_mac(D, coeff_target, ct_tb, c.d_desc, c.ids_map(out_ids, (uint32_t)dl), batch * rl * dl, c.logn, key.data, acc, a.key_limb, (unsigned)K,
+                           mac_target, t_bstride, s);
     } else {
-        launch_ks_expand(coeff_target, ct_tb, D, a, s);
-        launch_ntt(D, c.d_desc, c.ids_map(out_ids, (uint32_t)dl), batch * rl * dl, c.logn, false, s);
+        if (ntt2_supported(c.logn)) {
+            launch_ntt2(D, coeff_target, ct_tb, true, c.d_desc, c.ids_map(out_ids, (uint32_t)dl), batch * rl * dl, c.logn, false, s);
+        } else {
+            launch_ks_expand(coeff_target, ct_tb, D, a, s);
+            launch_ntt(D, c.d_desc, c.ids_map(out_ids, (uint32_t)dl), batch * rl * dl, c.logn, false, s);
+        }
+        // inner products with the key (128-bit lazy accumulation, one reduction per output)
+        launch_ks_mac(D, key.data, mac_target, t_bstride, acc, a, s);
     }
-    // inner products with the key (128-bit lazy accumulation, one reduction per output)
-    launch_ks_mac(D, key.data, c.scheme == SCHEME_CKKS ? target : nullptr, t_bstride, acc, a, s);
 
     if (c.scheme == SCHEME_CKKS) {
         // special-prime limb -> coefficient form, correction polynomial -> NTT form, combine

@@ -6,6 +6,9 @@ namespace troyhip {
 
 // ---- ntt.hip ----
 void launch_ntt(u64 *data, const PrimeDesc *primes, const LimbMap &map, size_t rows, int logn, bool inverse, hipStream_t stream);
+// key switching: transforms of all (digit, output prime) pairs + inner product with the key in one pair of launches (ntt2.hip)
+void launch_ntt2_ks_mac(u64 *D, const u64 *src, u64 src_ostride, const PrimeDesc *primes, const LimbMap &map, size_t rows, int logn, const u64 *key, u64 *acc,
+                        const uint8_t *key_limb, unsigned K, const u64 *ckks_target, u64 t_bstride, hipStream_t stream);
 // forward transform of `src` (same row layout, left untouched) into `data`
 void launch_ntt_from(u64 *data, const u64 *src, const PrimeDesc *primes, const LimbMap &map, size_t rows, int logn, hipStream_t stream);
 

@@ -17,6 +17,8 @@
 //     copy per (i,j)) costs no kernel and no HBM round trip of the (L+1)*L expanded limbs.
 #include "kernels.h"
 #include "bfly.h"
+#include <cstdlib>
+#include <cstring>
 #include <type_traits>
 
 namespace troyhip {
@@ -31,6 +33,12 @@ namespace troyhip {
 #endif
 #ifndef N2_PREFETCH
 #define N2_PREFETCH 0
+#endif
+#ifndef N2_MAC_WAVES
+#define N2_MAC_WAVES 2 // waves per SIMD of the key-switch fused kernel (16 x 128-bit accumulators per thread)
+#endif
+#ifndef N2_MAC_HOIST
+#define N2_MAC_HOIST 1 // keep the last round's twiddles in registers in that kernel
 #endif
 #ifndef N2_DMA
 #define N2_DMA 1 // contiguous passes prefetch the next row with LDS-DMA
@@ -55,6 +63,14 @@ struct Ntt2Args {
     unsigned chunks;      // ceil(m_total / R)
     int src_reduce;       // reduce src values modulo the row prime (they are residues of another prime)
     int src_same_layout;  // src has the row layout of data (plain out-of-place transform) instead of the digit broadcast
+    // key-switch inner product fused into the last forward pass (MAC = 1): the workgroup's rows are the dl digits of one
+    // (ciphertext o, output prime slot); instead of storing the transforms it accumulates  sum_k NTT(d_k) (.) key[k][c][slot]
+    const u64 *mac_key;     // [dl][2][K][N]
+    u64 *mac_acc;           // [outer][2][period][N]
+    const u64 *mac_target;  // CKKS: the NTT-form input supplies the (k == slot) operand (evaluator.cpp:2424-2427), else nullptr
+    u64 mac_tstride;
+    unsigned mac_K;
+    uint8_t mac_key_limb[65];
 };
 
 __device__ __forceinline__ unsigned swz(unsigned f) { return f ^ ((f >> 3) & 7u) ^ (((f >> 6) & 3u) << 3); }
@@ -78,7 +94,7 @@ __device__ __forceinline__ Shoup to_sgpr(const Shoup w) {
 #endif
 }
 
-template <int INV, int STRIDED, int NS, int LOGC, int LS, int R> struct Round {
+template <int INV, int STRIDED, int NS, int LOGC, int LS, int R, bool HOISTP = true> struct Round {
     static constexpr int G = 8 >> R;                       // groups per thread
     static constexpr int NTW = (1 << R) - 1;               // twiddles per group
     static constexpr int LOGPF = NS + LOGC;                // log2 flattened size of one sub-transform
@@ -89,7 +105,7 @@ template <int INV, int STRIDED, int NS, int LOGC, int LS, int R> struct Round {
     static constexpr bool LAST = INV ? (LS + R == NS) : (LS + R == NS);
     // twiddles that live in SGPRs (wave-uniform) or belong to the last round are loaded once per workgroup; the
     // few-distinct-values rounds in between are re-read from L1 per row, which frees ~28 VGPRs (one more wave per SIMD)
-    static constexpr bool HOIST = true; // measured: re-reading the middle rounds per row does not lower the allocation (asm temporaries dominate)
+    static constexpr bool HOIST = HOISTP; // false: twiddles are re-read (L1/L2) for every row instead of living in 28 VGPRs (the key-switch fused kernel needs them)
 
     __device__ static __forceinline__ unsigned base_of(unsigned q) {
         const unsigned hi = q >> LOGD, lo = q & ((1u << LOGD) - 1);
@@ -333,8 +349,8 @@ template <> struct Plan<9> { static constexpr int r[4] = {3, 3, 3, 0}; };
 template <> struct Plan<10> { static constexpr int r[4] = {3, 3, 3, 1}; };
 template <> struct Plan<11> { static constexpr int r[4] = {3, 3, 3, 2}; };
 
-template <int INV, int STRIDED, int NS, int LOGC, int FINAL, int REDUCE>
-__global__ __launch_bounds__(N2_THREADS, N2_MIN_WAVES) void ntt2_kernel(Ntt2Args a) {
+template <int INV, int STRIDED, int NS, int LOGC, int FINAL, int REDUCE, int MAC = 0>
+__global__ __launch_bounds__(N2_THREADS, MAC ? N2_MAC_WAVES : N2_MIN_WAVES) void ntt2_kernel(Ntt2Args a) {
     __shared__ u64 lds[2][N2_T];
     using P = Plan<NS>;
     // NS == 9, contiguous: every 512-point sub-transform is owned by ONE wave in every round (thread t's points never
@@ -356,7 +372,7 @@ __global__ __launch_bounds__(N2_THREADS, N2_MIN_WAVES) void ntt2_kernel(Ntt2Args
     constexpr int Q3 = NR > 3 ? (INV ? P::r[NR - 4] : R3) : 0;
     using Rd0 = Round<INV, STRIDED, NS, LOGC, 0, Q0>;
     using Rd1 = Round<INV, STRIDED, NS, LOGC, Q0, Q1 ? Q1 : 1>;
-    using Rd2 = Round<INV, STRIDED, NS, LOGC, Q0 + Q1, Q2 ? Q2 : 1>;
+    using Rd2 = Round<INV, STRIDED, NS, LOGC, Q0 + Q1, Q2 ? Q2 : 1, MAC == 0 || N2_MAC_HOIST>;
     using Rd3 = Round<INV, STRIDED, NS, LOGC, Q0 + Q1 + Q2, Q3 ? Q3 : 1>;
 
     const unsigned tile = blockIdx.x & ((1u << a.tiles_per_row_log) - 1);
@@ -385,6 +401,16 @@ __global__ __launch_bounds__(N2_THREADS, N2_MIN_WAVES) void ntt2_kernel(Ntt2Args
         in = (REDUCE || a.src) ? (a.src_same_layout ? a.src + (r << logn) : a.src + (u64)o * a.src_ostride + ((u64)k << logn)) : row;
     };
     constexpr bool DMA = N2_DMA && WAVE_PRIVATE && !(N2_EXP & 1);
+    static_assert(!MAC || (!INV && !STRIDED && NS == 9), "the inner product is fused into the forward contiguous pass");
+    Acc128 macc[2][2][4]; // [key component][group of four coefficients][coefficient]
+    if (MAC) {
+#pragma unroll
+        for (int cpt = 0; cpt < 2; cpt++)
+#pragma unroll
+            for (int g = 0; g < 2; g++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) macc[cpt][g][e] = Acc128{0, 0, 0, 0};
+    }
     u64 *const wave_stage = lds[1] + 512 * (threadIdx.x >> 6);
     u64 x[8], nx[8];
     {
@@ -404,6 +430,17 @@ __global__ __launch_bounds__(N2_THREADS, N2_MIN_WAVES) void ntt2_kernel(Ntt2Args
                 u64 *nrow; const u64 *nin;
                 row_ptrs(mm + 1, nrow, nin);
                 Rd0::stage_issue(nin, tile, wave_stage);
+            }
+        }
+        ulonglong2 kv[2][MAC ? 4 : 1]; // MAC: this row's key words, requested now, used after the three rounds (L2 latency hidden)
+        if constexpr (MAC) {
+            const unsigned ko = mm / inner, kk = mm - ko * inner;
+            const u64 *kp = a.mac_key + ((((u64)kk * 2) * a.mac_K + a.mac_key_limb[slot]) << logn) + ((u64)tile << N2_LOGT) + 8 * threadIdx.x;
+#pragma unroll
+            for (int cpt = 0; cpt < 2; cpt++) {
+                const ulonglong2 *kq = reinterpret_cast<const ulonglong2 *>(kp + ((u64)cpt * a.mac_K << logn));
+#pragma unroll
+                for (int e = 0; e < 4; e++) kv[cpt][MAC ? e : 0] = kq[e];
             }
         }
         if (!DMA && N2_PREFETCH && mm + 1 < m_end) {
@@ -434,7 +471,34 @@ __global__ __launch_bounds__(N2_THREADS, N2_MIN_WAVES) void ntt2_kernel(Ntt2Args
                 if constexpr (!Rd2::HOIST) Rd2::load_tw(tw2, pd, tile, logn, s_first);
                 Rd2::lds_read(x, buf);
                 Rd2::compute(x, tw2, pd);
-                if constexpr (NR == 3) {
+                if constexpr (NR == 3 && MAC) {
+                    // canonical transform of digit k of (o, slot) stays in registers: acc_c += x (.) key[k][c][limb(slot)]
+                    const PrimeConst pc = make_prime_const(pd.p);
+#pragma unroll
+                    for (int h = 0; h < 2; h++) {
+                        u64 v[4] = {x[4 * h], x[4 * h + 1], x[4 * h + 2], x[4 * h + 3]};
+                        reduce4_from_8p(v, pc);
+#pragma unroll
+                        for (int i = 0; i < 4; i++) x[4 * h + i] = v[i];
+                    }
+                    const unsigned o = mm / inner, k = mm - o * inner;
+                    const u64 pos = ((u64)tile << N2_LOGT) + 8 * threadIdx.x;
+                    if (a.mac_target && k == slot) {
+                        const ulonglong2 *tp = reinterpret_cast<const ulonglong2 *>(a.mac_target + (u64)o * a.mac_tstride + ((u64)k << logn) + pos);
+#pragma unroll
+                        for (int e = 0; e < 4; e++) { const ulonglong2 v = tp[e]; x[2 * e] = v.x; x[2 * e + 1] = v.y; }
+                    }
+#pragma unroll
+                    for (int cpt = 0; cpt < 2; cpt++) {
+#pragma unroll
+                        for (int g = 0; g < 2; g++) {
+                            const ulonglong2 k01 = kv[cpt][2 * g], k23 = kv[cpt][2 * g + 1];
+                            const u64 kk[4] = {k01.x, k01.y, k23.x, k23.y};
+                            const u64 xx[4] = {x[4 * g], x[4 * g + 1], x[4 * g + 2], x[4 * g + 3]};
+                            mac128x4(macc[cpt][g], xx, kk);
+                        }
+                    }
+                } else if constexpr (NR == 3) {
                     Rd2::template g_write<FINAL>(x, row, tile, logn, pd.p, pd.two_p, WAVE_PRIVATE ? buf : nullptr);
                 } else {
                     Rd2::lds_write(x, buf);
@@ -454,6 +518,22 @@ __global__ __launch_bounds__(N2_THREADS, N2_MIN_WAVES) void ntt2_kernel(Ntt2Args
             u64 *nrow; const u64 *nin;
             row_ptrs(mm + 1, nrow, nin);
             Rd0::template g_read<REDUCE>(x, nin, tile, logn, m);
+        }
+    }
+    if constexpr (MAC) { // one reduction per output coefficient; acc[o][c][slot][N]
+        const unsigned o = m_begin / inner;
+        const u64 pos = ((u64)tile << N2_LOGT) + 8 * threadIdx.x;
+#pragma unroll
+        for (int cpt = 0; cpt < 2; cpt++) {
+            ulonglong2 *op = reinterpret_cast<ulonglong2 *>(a.mac_acc + ((((u64)o * 2 + cpt) * period + slot) << logn) + pos);
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                ulonglong2 v;
+                const Acc128 &p0 = macc[cpt][e >> 1][2 * (e & 1)], &p1 = macc[cpt][e >> 1][2 * (e & 1) + 1];
+                v.x = barrett128(mk64(p0.a0, p0.a1), mk64(p0.a2, p0.a3), m);
+                v.y = barrett128(mk64(p1.a0, p1.a1), mk64(p1.a2, p1.a3), m);
+                op[e] = v;
+            }
         }
     }
 }
@@ -531,6 +611,42 @@ void launch_ntt2(u64 *data, const u64 *src, u64 src_ostride, bool src_reduce, co
         contig(std::integral_constant<int, 1>{}, false);
         strided(std::integral_constant<int, 1>{}, a, false);
     }
+}
+
+// Key switching: forward transform of every (digit, output prime) pair with the inner product against the key fused into the
+// second pass.  D receives only the first pass; acc [outer][2][period][N] the reduced sums.  Rows are grouped per (o, slot):
+// a workgroup takes all `inner` digits of one group, so its 16 accumulators see every term.
+void launch_ntt2_ks_mac(u64 *D, const u64 *src, u64 src_ostride, const PrimeDesc *primes, const LimbMap &map, size_t rows, int logn, const u64 *key, u64 *acc,
+                        const uint8_t *key_limb, unsigned K, const u64 *ckks_target, u64 t_bstride, hipStream_t stream) {
+    if (rows == 0) return;
+    if (!ntt2_supported(logn) || logn - 9 > 7 || logn - 9 < 3) throw Error(ST_LOGIC_ERROR, "ntt2 ks_mac: unsupported size");
+    const size_t per_outer = (size_t)map.period * map.inner;
+    if (rows % per_outer || map.inner > 63) throw Error(ST_INVALID_ARGUMENT, "ntt2 ks_mac: bad row pattern");
+    const int k1 = logn - 9;
+    Ntt2Args a;
+    std::memset(&a, 0, sizeof(a));
+    a.data = D;
+    a.primes = primes;
+    a.map = map;
+    a.logn = logn;
+    a.tiles_per_row_log = (unsigned)(logn - N2_LOGT);
+    a.m_total = (unsigned)(rows / per_outer * map.inner);
+    a.rows_per_wg = map.inner;
+    a.chunks = a.m_total / a.rows_per_wg;
+    const unsigned blocks = (unsigned)((map.period * a.chunks) << a.tiles_per_row_log);
+    Ntt2Args first = a;
+    first.src = src; first.src_ostride = src_ostride; first.src_reduce = 1;
+    switch (k1) {
+    case 3: launch_strided<0, 3>(first, blocks, false, true, stream); break;
+    case 4: launch_strided<0, 4>(first, blocks, false, true, stream); break;
+    case 5: launch_strided<0, 5>(first, blocks, false, true, stream); break;
+    case 6: launch_strided<0, 6>(first, blocks, false, true, stream); break;
+    default: launch_strided<0, 7>(first, blocks, false, true, stream); break;
+    }
+    a.mac_key = key; a.mac_acc = acc; a.mac_target = ckks_target; a.mac_tstride = t_bstride; a.mac_K = K;
+    std::memcpy(a.mac_key_limb, key_limb, map.period);
+    TROY_LAUNCH(HIP_KERNEL_NAME(ntt2_kernel<0, 0, 9, 0, 1, 0, 1>), dim3(blocks), dim3(N2_THREADS), 0, stream, a);
+    launch_check("ntt2_kernel(ks_mac)");
 }
 
 } // namespace troyhip
