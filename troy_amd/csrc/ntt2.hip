@@ -62,6 +62,7 @@ struct Ntt2Args {
     unsigned rows_per_wg; // R
     unsigned chunks;      // ceil(m_total / R)
     int src_reduce;       // reduce src values modulo the row prime (they are residues of another prime)
+    int slot_fastest;     // workgroup order, see the kernel
     int src_same_layout;  // src has the row layout of data (plain out-of-place transform) instead of the digit broadcast
     // key-switch inner product fused into the last forward pass (MAC = 1): the workgroup's rows are the dl digits of one
     // (ciphertext o, output prime slot); instead of storing the transforms it accumulates  sum_k NTT(d_k) (.) key[k][c][slot]
@@ -377,7 +378,9 @@ __global__ __launch_bounds__(N2_THREADS, MAC ? N2_MAC_WAVES : N2_MIN_WAVES) void
 
     const unsigned tile = blockIdx.x & ((1u << a.tiles_per_row_log) - 1);
     const unsigned grp = blockIdx.x >> a.tiles_per_row_log;
-    const unsigned slot = grp / a.chunks, chunk = grp % a.chunks;
+    // group order: prime slot major (workgroups in flight share the twiddles, and in the fused key-switch pass the key window),
+    // or slot FASTEST (the first key-switch pass: the L+1 readers of one source digit run together and hit in L2)
+    const unsigned slot = a.slot_fastest ? grp % a.map.period : grp / a.chunks, chunk = a.slot_fastest ? grp / a.map.period : grp % a.chunks;
     const PrimeDesc pd = a.primes[a.map.id[slot]];
     const Mod m = mod_of(pd);
     const int logn = a.logn;
@@ -584,6 +587,7 @@ void launch_ntt2(u64 *data, const u64 *src, u64 src_ostride, bool src_reduce, co
     a.chunks = (a.m_total + a.rows_per_wg - 1) / a.rows_per_wg;
     a.src_reduce = 0;
     a.src_same_layout = 0;
+    a.slot_fastest = 0;
     const unsigned blocks = (unsigned)((map.period * a.chunks) << a.tiles_per_row_log);
     auto contig = [&](auto inv_tag, bool final_pass) {
         constexpr int INV = decltype(inv_tag)::value;
@@ -604,7 +608,7 @@ void launch_ntt2(u64 *data, const u64 *src, u64 src_ostride, bool src_reduce, co
     };
     if (!inverse) {
         Ntt2Args first = a;
-        if (src) { first.src = src; first.src_ostride = src_ostride; first.src_reduce = src_reduce; first.src_same_layout = src_same_layout; }
+        if (src) { first.src = src; first.src_ostride = src_ostride; first.src_reduce = src_reduce; first.src_same_layout = src_same_layout; first.slot_fastest = src_reduce && !src_same_layout; }
         strided(std::integral_constant<int, 0>{}, first, src && src_reduce);
         contig(std::integral_constant<int, 0>{}, true);
     } else {
@@ -636,6 +640,7 @@ void launch_ntt2_ks_mac(u64 *D, const u64 *src, u64 src_ostride, const PrimeDesc
     const unsigned blocks = (unsigned)((map.period * a.chunks) << a.tiles_per_row_log);
     Ntt2Args first = a;
     first.src = src; first.src_ostride = src_ostride; first.src_reduce = 1;
+    first.slot_fastest = 1;
     switch (k1) {
     case 3: launch_strided<0, 3>(first, blocks, false, true, stream); break;
     case 4: launch_strided<0, 4>(first, blocks, false, true, stream); break;
