@@ -8,6 +8,17 @@
 
 namespace troyhip {
 
+// TROYHIP_TENSOR=split keeps the ciphertext tensor of the BEHZ multiply in its own kernel (tests, measurements); read once
+static bool tensor_fused() {
+    static const bool v = [] { const char *e = getenv("TROYHIP_TENSOR"); return !(e && e[0] == 's'); }();
+    return v;
+}
+// TROYHIP_KS=split keeps the transforms and the inner product in separate kernels (tests, measurements); read once
+static bool ks_fused() {
+    static const bool v = [] { const char *e = getenv("TROYHIP_KS"); return !(e && e[0] == 's'); }();
+    return v;
+}
+
 static inline u64 poly_words(const Context &c, int limbs) { return (u64)limbs * c.N; }
 
 void Evaluator::check_ct(const CtBatch &a) const {
@@ -160,12 +171,18 @@ void Evaluator::multiply(const CtBatch &a, const CtBatch &b, CtBatch &out, u64 b
             u64 *xq_a = xq, *xq_b = xq + batch * sa * pw, *xb_a = xb, *xb_b = xb + batch * sa * bw;
             launch_behz_extend(a.data, pw, xb_a, bw, c.d_desc, *lv.behz, N, batch * sa, s);
             launch_behz_extend(b.data, pw, xb_b, bw, c.d_desc, *lv.behz, N, batch * sb, s);
-            launch_ntt_from(xq_a, a.data, c.d_desc, qmap, batch * sa * L, c.logn, s);
-            launch_ntt_from(xq_b, b.data, c.d_desc, qmap, batch * sb * L, c.logn, s);
-            launch_ntt(xb, c.d_desc, bmap, batch * sp * nb, c.logn, false, s);
-            // (4) tensor in both bases
-            launch_tensor(sa, sb, xq_a, xq_b, dq, sa * pw, sb * pw, c.d_desc, qmap, c.logn, L, batch, s);
-            launch_tensor(sa, sb, xb_a, xb_b, db, sa * bw, sb * bw, c.d_desc, bmap, c.logn, nb, batch, s);
+            if (sa == 2 && sb == 2 && ntt2_tensor_supported(c.logn) && tensor_fused()) {
+                // (3)+(4) in one pass pair per base: the second NTT pass keeps a0, a1, b0, b1 in registers and stores d0, d1, d2
+                launch_ntt2_tensor(xq_a, a.data, xq_b, b.data, dq, c.d_desc, qmap, batch, c.logn, s);
+                launch_ntt2_tensor(xb_a, nullptr, xb_b, nullptr, db, c.d_desc, bmap, batch, c.logn, s);
+            } else {
+                launch_ntt_from(xq_a, a.data, c.d_desc, qmap, batch * sa * L, c.logn, s);
+                launch_ntt_from(xq_b, b.data, c.d_desc, qmap, batch * sb * L, c.logn, s);
+                launch_ntt(xb, c.d_desc, bmap, batch * sp * nb, c.logn, false, s);
+                // (4) tensor in both bases
+                launch_tensor(sa, sb, xq_a, xq_b, dq, sa * pw, sb * pw, c.d_desc, qmap, c.logn, L, batch, s);
+                launch_tensor(sa, sb, xb_a, xb_b, db, sa * bw, sb * bw, c.d_desc, bmap, c.logn, nb, batch, s);
+            }
         } else {
             launch_copy_strided(a.data, a.bstride, xq, sp * pw, sa * pw, batch, s);
             launch_copy_strided(b.data, b.bstride, xq + sa * pw, sp * pw, sb * pw, batch, s);
@@ -218,11 +235,6 @@ size_t Evaluator::scratch_switch_key(int limbs, u64 batch) const {
     return batch * N * (dl /*t_target*/ + rl * dl /*D*/ + 2 * rl /*acc*/ + 2 * dl /*corr*/ + 2 /*last*/) + 512;
 }
 
-// TROYHIP_KS=split keeps the transforms and the inner product in separate kernels (tests, measurements); read once
-static bool ks_fused() {
-    static const bool v = [] { const char *e = getenv("TROYHIP_KS"); return !(e && e[0] == 's'); }();
-    return v;
-}
 // switchKeyInplace (evaluator_cuda.cu:1163-1362; CPU src/evaluator.cpp:2310-2653)
 void Evaluator::switch_key(CtBatch &ct, const u64 *target, u64 t_bstride, const KsKey &key, u64 batch, hipStream_t s) {
     check_ct(ct);

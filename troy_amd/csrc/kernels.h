@@ -9,6 +9,10 @@ void launch_ntt(u64 *data, const PrimeDesc *primes, const LimbMap &map, size_t r
 // key switching: transforms of all (digit, output prime) pairs + inner product with the key in one pair of launches (ntt2.hip)
 void launch_ntt2_ks_mac(u64 *D, const u64 *src, u64 src_ostride, const PrimeDesc *primes, const LimbMap &map, size_t rows, int logn, const u64 *key, u64 *acc,
                         const uint8_t *key_limb, unsigned K, const u64 *ckks_target, u64 t_bstride, hipStream_t stream);
+// BEHZ multiply: forward transforms of two size-2 operands + ciphertext tensor in one pass pair (ntt2.hip)
+bool ntt2_tensor_supported(int logn);
+void launch_ntt2_tensor(u64 *xa, const u64 *src_a, u64 *xb, const u64 *src_b, u64 *out, const PrimeDesc *primes, const LimbMap &map, size_t batch, int logn,
+                        hipStream_t stream);
 // forward transform of `src` (same row layout, left untouched) into `data`
 void launch_ntt_from(u64 *data, const u64 *src, const PrimeDesc *primes, const LimbMap &map, size_t rows, int logn, hipStream_t stream);
 

@@ -66,6 +66,10 @@ struct Ntt2Args {
     int src_same_layout;  // src has the row layout of data (plain out-of-place transform) instead of the digit broadcast
     // key-switch inner product fused into the last forward pass (MAC = 1): the workgroup's rows are the dl digits of one
     // (ciphertext o, output prime slot); instead of storing the transforms it accumulates  sum_k NTT(d_k) (.) key[k][c][slot]
+    // MAC = 2: ciphertext tensor fused into the last forward pass: the workgroup's four rows are (a0, a1, b0, b1) of one
+    // (ciphertext, limb); their transforms stay in registers and only d0 = a0 b0, d1 = a0 b1 + a1 b0, d2 = a1 b1 are stored
+    u64 *tensor_b;          // second operand, same layout as data ([batch][2][period][N])
+    u64 *tensor_out;        // [batch][3][period][N]
     const u64 *mac_key;     // [dl][2][K][N]
     u64 *mac_acc;           // [outer][2][period][N]
     const u64 *mac_target;  // CKKS: the NTT-form input supplies the (k == slot) operand (evaluator.cpp:2424-2427), else nullptr
@@ -269,6 +273,51 @@ template <int INV, int STRIDED, int NS, int LOGC, int LS, int R, bool HOISTP = t
             *reinterpret_cast<ulonglong2 *>(dst + 128 * c) = v;
         }
     }
+    // MAC = 2 epilogue of the forward contiguous pass: virtual row vr = mm % 4 of (a0, a1, b0, b1); x is the lazy transform
+    // ([0, 8p)) of this thread's 8 consecutive coefficients.  Rows 0..2 are parked canonical in tx; row 3 completes the
+    // tensor (evaluator.cpp:626-702: every product reduced, the two middle products added modulo p).
+    __device__ static __forceinline__ void tensor_epilogue(u64 (&x)[8], u64 (&tx)[3][8], unsigned mm, u64 *out, unsigned period, unsigned slot, unsigned tile, int logn,
+                                                           const Mod &m) {
+        const PrimeConst pc = make_prime_const(m.p);
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            u64 v[4] = {x[4 * h], x[4 * h + 1], x[4 * h + 2], x[4 * h + 3]};
+            reduce4_from_8p(v, pc);
+#pragma unroll
+            for (int i = 0; i < 4; i++) x[4 * h + i] = v[i];
+        }
+        const unsigned vr = mm & 3;
+        if (vr < 3) {
+#pragma unroll
+            for (int i = 0; i < 3; i++)
+                if ((int)vr == i) {
+#pragma unroll
+                    for (int e = 0; e < 8; e++) tx[i][e] = x[e];
+                }
+            return;
+        }
+        const unsigned b = mm >> 2;
+        const u64 pos = ((u64)tile << N2_LOGT) + 8 * threadIdx.x;
+        u64 d[3][8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const u64 a0 = tx[0][e], a1 = tx[1][e], b0 = tx[2][e], b1 = x[e];
+            d[0][e] = mulmod(a0, b0, m);
+            d[1][e] = addmod(mulmod(a0, b1, m), mulmod(a1, b0, m), m.p);
+            d[2][e] = mulmod(a1, b1, m);
+        }
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            ulonglong2 *op = reinterpret_cast<ulonglong2 *>(out + ((((u64)b * 3 + i) * period + slot) << logn) + pos);
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                ulonglong2 v;
+                v.x = d[i][2 * e];
+                v.y = d[i][2 * e + 1];
+                op[e] = v;
+            }
+        }
+    }
     // global access; consecutive-element runs are moved 16 bytes at a time
     template <int REDUCE> __device__ static __forceinline__ void g_read(u64 (&x)[8], const u64 *row, unsigned tile, int logn, const Mod &m) {
         if (N2_EXP & 1) {
@@ -398,6 +447,12 @@ __global__ __launch_bounds__(N2_THREADS, MAC ? N2_MAC_WAVES : N2_MIN_WAVES) void
     const unsigned inner = a.map.inner, period = a.map.period;
     // software pipeline over the rows of this group: the loads of row mm+1 are in flight while row mm is transformed
     auto row_ptrs = [&](unsigned mm, u64 *&row, const u64 *&in) {
+        if constexpr (MAC == 2) { // virtual row mm = 4 b + vr: vr 0,1 -> a0, a1 ; 2,3 -> b0, b1
+            const unsigned b = mm >> 2, vr = mm & 3;
+            row = (vr < 2 ? a.data : a.tensor_b) + ((((u64)b * 2 + (vr & 1)) * period + slot) << logn);
+            in = row;
+            return;
+        }
         const unsigned o = mm / inner, k = mm - o * inner;
         const u64 r = ((u64)o * period + slot) * inner + k;
         row = a.data + (r << logn);
@@ -405,8 +460,9 @@ __global__ __launch_bounds__(N2_THREADS, MAC ? N2_MAC_WAVES : N2_MIN_WAVES) void
     };
     constexpr bool DMA = N2_DMA && WAVE_PRIVATE && !(N2_EXP & 1);
     static_assert(!MAC || (!INV && !STRIDED && NS == 9), "the inner product is fused into the forward contiguous pass");
+    u64 tx[MAC == 2 ? 3 : 1][8]; // MAC = 2: the transforms of a0, a1, b0 while b1 is being computed
     Acc128 macc[2][2][4]; // [key component][group of four coefficients][coefficient]
-    if (MAC) {
+    if (MAC == 1) {
 #pragma unroll
         for (int cpt = 0; cpt < 2; cpt++)
 #pragma unroll
@@ -435,15 +491,15 @@ __global__ __launch_bounds__(N2_THREADS, MAC ? N2_MAC_WAVES : N2_MIN_WAVES) void
                 Rd0::stage_issue(nin, tile, wave_stage);
             }
         }
-        ulonglong2 kv[2][MAC ? 4 : 1]; // MAC: this row's key words, requested now, used after the three rounds (L2 latency hidden)
-        if constexpr (MAC) {
+        ulonglong2 kv[2][MAC == 1 ? 4 : 1]; // MAC: this row's key words, requested now, used after the three rounds (L2 latency hidden)
+        if constexpr (MAC == 1) {
             const unsigned ko = mm / inner, kk = mm - ko * inner;
             const u64 *kp = a.mac_key + ((((u64)kk * 2) * a.mac_K + a.mac_key_limb[slot]) << logn) + ((u64)tile << N2_LOGT) + 8 * threadIdx.x;
 #pragma unroll
             for (int cpt = 0; cpt < 2; cpt++) {
                 const ulonglong2 *kq = reinterpret_cast<const ulonglong2 *>(kp + ((u64)cpt * a.mac_K << logn));
 #pragma unroll
-                for (int e = 0; e < 4; e++) kv[cpt][MAC ? e : 0] = kq[e];
+                for (int e = 0; e < 4; e++) kv[cpt][MAC == 1 ? e : 0] = kq[e];
             }
         }
         if (!DMA && N2_PREFETCH && mm + 1 < m_end) {
@@ -474,7 +530,9 @@ __global__ __launch_bounds__(N2_THREADS, MAC ? N2_MAC_WAVES : N2_MIN_WAVES) void
                 if constexpr (!Rd2::HOIST) Rd2::load_tw(tw2, pd, tile, logn, s_first);
                 Rd2::lds_read(x, buf);
                 Rd2::compute(x, tw2, pd);
-                if constexpr (NR == 3 && MAC) {
+                if constexpr (NR == 3 && MAC == 2) {
+                    Rd2::tensor_epilogue(x, tx, mm, a.tensor_out, period, slot, tile, logn, m);
+                } else if constexpr (NR == 3 && MAC == 1) {
                     // canonical transform of digit k of (o, slot) stays in registers: acc_c += x (.) key[k][c][limb(slot)]
                     const PrimeConst pc = make_prime_const(pd.p);
 #pragma unroll
@@ -523,7 +581,7 @@ __global__ __launch_bounds__(N2_THREADS, MAC ? N2_MAC_WAVES : N2_MIN_WAVES) void
             Rd0::template g_read<REDUCE>(x, nin, tile, logn, m);
         }
     }
-    if constexpr (MAC) { // one reduction per output coefficient; acc[o][c][slot][N]
+    if constexpr (MAC == 1) { // one reduction per output coefficient; acc[o][c][slot][N]
         const unsigned o = m_begin / inner;
         const u64 pos = ((u64)tile << N2_LOGT) + 8 * threadIdx.x;
 #pragma unroll
@@ -652,6 +710,52 @@ void launch_ntt2_ks_mac(u64 *D, const u64 *src, u64 src_ostride, const PrimeDesc
     std::memcpy(a.mac_key_limb, key_limb, map.period);
     TROY_LAUNCH(HIP_KERNEL_NAME(ntt2_kernel<0, 0, 9, 0, 1, 0, 1>), dim3(blocks), dim3(N2_THREADS), 0, stream, a);
     launch_check("ntt2_kernel(ks_mac)");
+}
+
+// BFV/BEHZ multiply, both bases: forward transforms of two size-2 operands with the ciphertext tensor fused into the second
+// pass.  xa / xb: [batch][2][limbs][N] scratch (transformed in place by the first pass; src_* != nullptr: the first pass reads
+// the operand from there instead -- dense ciphertexts are consumed in place); out: [batch][3][limbs][N] in NTT form.
+bool ntt2_tensor_supported(int logn) { return ntt2_supported(logn) && logn - 9 >= 3 && logn - 9 <= 7; }
+void launch_ntt2_tensor(u64 *xa, const u64 *src_a, u64 *xb, const u64 *src_b, u64 *out, const PrimeDesc *primes, const LimbMap &map, size_t batch, int logn,
+                        hipStream_t stream) {
+    if (!batch) return;
+    if (!ntt2_tensor_supported(logn) || map.inner != 1) throw Error(ST_LOGIC_ERROR, "ntt2 tensor: unsupported shape");
+    const int k1 = logn - 9;
+    for (int part = 0; part < 2; part++) { // first pass of both operands (rows = batch * 2 * limbs each)
+        Ntt2Args a;
+        std::memset(&a, 0, sizeof(a));
+        a.data = part ? xb : xa;
+        const u64 *src = part ? src_b : src_a;
+        a.primes = primes;
+        a.map = map;
+        a.logn = logn;
+        a.tiles_per_row_log = (unsigned)(logn - N2_LOGT);
+        a.m_total = (unsigned)(batch * 2);
+        a.rows_per_wg = a.m_total < 8 ? a.m_total : 8;
+        a.chunks = (a.m_total + a.rows_per_wg - 1) / a.rows_per_wg;
+        if (src) { a.src = src; a.src_same_layout = 1; }
+        const unsigned blocks = (unsigned)((map.period * a.chunks) << a.tiles_per_row_log);
+        switch (k1) {
+        case 3: launch_strided<0, 3>(a, blocks, false, false, stream); break;
+        case 4: launch_strided<0, 4>(a, blocks, false, false, stream); break;
+        case 5: launch_strided<0, 5>(a, blocks, false, false, stream); break;
+        case 6: launch_strided<0, 6>(a, blocks, false, false, stream); break;
+        default: launch_strided<0, 7>(a, blocks, false, false, stream); break;
+        }
+    }
+    Ntt2Args a;
+    std::memset(&a, 0, sizeof(a));
+    a.data = xa; a.tensor_b = xb; a.tensor_out = out;
+    a.primes = primes;
+    a.map = map;
+    a.logn = logn;
+    a.tiles_per_row_log = (unsigned)(logn - N2_LOGT);
+    a.m_total = (unsigned)(batch * 4);
+    a.rows_per_wg = 4;
+    a.chunks = (unsigned)batch;
+    const unsigned blocks = (unsigned)((map.period * a.chunks) << a.tiles_per_row_log);
+    TROY_LAUNCH(HIP_KERNEL_NAME(ntt2_kernel<0, 0, 9, 0, 1, 0, 2>), dim3(blocks), dim3(N2_THREADS), 0, stream, a);
+    launch_check("ntt2_kernel(tensor)");
 }
 
 } // namespace troyhip
