@@ -151,6 +151,11 @@ int troyhip_multiply_plain(troyhip_context *ctx, troyhip_ct *ct, const uint64_t 
 /* transformToNttInplace(Plaintext&, parms_id) (src/evaluator_cuda.cu:1866-1948): out [count][limbs][N], limbs identifies the level */
 int troyhip_plain_to_ntt(troyhip_context *ctx, const uint64_t *plain, uint64_t plain_coeff_count, uint64_t plain_batch_stride, int limbs, uint64_t *out,
                          uint64_t count, void *stream);
+/* ---- DecryptorCuda::decrypt (src/decryptor_cuda.cu:61-330; dotProductCtSkArray + decryptScaleAndRound / decryptModt,
+ * src/utils/rns_cuda.cu:510-621), SURVEY 8-f3.  secret_key: device [K][N] (NTT form, src/secretkey.h).  plain_out (device):
+ * BFV/BGV N coefficients mod t per item, items plain_batch_stride words apart; CKKS the RNS plaintext [limbs][N] (NTT form). */
+int troyhip_decrypt(troyhip_context *ctx, const troyhip_ct *ct, const uint64_t *secret_key, uint64_t *plain_out, uint64_t plain_batch_stride, uint64_t batch,
+                    void *stream);
 
 #ifdef __cplusplus
 }

@@ -324,3 +324,27 @@ def check_dense_multiply(cfg_name, batch=3):
         sq = be.ev.square(a).cpu()
         for i in range(batch):
             assert np.array_equal(sq[i], orc.impl.eval(R.OP_SQUARE, R.Ct(xa[i], False)).data), (cap, i)
+
+
+def check_gpu_decrypt(cfg_name, batch=3):
+    """SURVEY 8-f3: DecryptorCuda::decrypt on the device vs the CPU oracle (pinned on the reference's Decryptor), bit-exact:
+    uniform synthetic ciphertexts of size 2 and 3 at every level (decryption is plain arithmetic, it does not need a valid
+    encryption), BGV with a non-trivial correction factor."""
+    cfg = CONFIGS[cfg_name]
+    be = GpuBackend(cfg, batch=batch)
+    orc = oracle_backend(cfg)
+    from oracle import ref as R
+    N, K = cfg["N"], len(be.primes)
+    sk = synth.uniform_rows(771, be.primes, K, N)                      # any [K][N] residues serve as an NTT-form key
+    skd = be.api.DeviceBuffer.from_numpy(sk)
+    ntt = cfg["scheme"] == CKKS
+    for limbs in range(K - 1, be.last_limbs - 1, -1):
+        q = be.primes[:limbs]
+        for size in (2, 3):
+            for cf in ((1, 5) if cfg["scheme"] == BGV else (1,)):
+                xs = synth.uniform_ct(772 + limbs + size, q, size, N, batch)
+                c = be.api.Ciphertext.from_numpy(be.ctx, xs, ntt, 1.0, cf, capacity=3)
+                got = be.ev.decrypt(c, skd)
+                for b in range(batch):
+                    exp = orc.impl.decrypt(R.Ct(xs[b], ntt, 1.0, cf), sk)
+                    assert np.array_equal(got[b].reshape(-1), exp), (limbs, size, cf, b)

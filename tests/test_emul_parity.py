@@ -70,3 +70,8 @@ def test_emulated_plain_operands(name, emul_api, oracle_lib):
 
 def test_emulated_dense_multiply(emul_api):
     cases.check_dense_multiply("cfgA_bfv_n4096_k3", batch=2)
+
+
+@pytest.mark.parametrize("name", ["bfv_n128_k4", "bgv_n128_k4", "ckks_n128_k6"])
+def test_emulated_decrypt(name, emul_api):
+    cases.check_gpu_decrypt(name, batch=2)

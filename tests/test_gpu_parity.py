@@ -315,3 +315,36 @@ def test_plain_operands_monomial_and_per_item(name, gpu, oracle_lib):
 @pytest.mark.parametrize("name", ["bfv_n128_k4", "cfgA_bfv_n4096_k3", "cfgB_bfv_n8192_k5"])
 def test_dense_and_strided_multiply(name, gpu):
     cases.check_dense_multiply(name)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["bfv_n128_k4", "bfv_n128_k5_60", "bgv_n128_k4", "ckks_n128_k6", "cfgA_bfv_n4096_k3", "bgv_n4096_k3", "ckks_n4096_k4"])
+def test_gpu_decrypt_vs_oracle(name, gpu):
+    cases.check_gpu_decrypt(name)
+
+
+@pytest.mark.gpu
+def test_gpu_decrypt_end_to_end(gpu):
+    """host encrypt -> GPU multiply + relinearize -> GPU decrypt == plaintext product (BFV), own keys"""
+    from test_hostcrypto import negacyclic_mul
+    N = 4096
+    primes = gpu.CoeffModulus.Create(N, [36, 36, 37])
+    t = gpu.PlainModulus.Batching(N, 20)
+    ctx = gpu.SEALContext(1, N, primes, t)
+    kg = gpu.KeyGenerator(ctx, seed=(5, 6))
+    enc = gpu.Encryptor(ctx, kg.createPublicKey())
+    rlk = gpu.RelinKeys(ctx)
+    rlk.set(0, kg.createRelinKeys())
+    rng = np.random.default_rng(3)
+    B = 2
+    m1 = rng.integers(0, t, (B, N), dtype=np.uint64)
+    m2 = np.zeros((B, N), dtype=np.uint64)
+    m2[:, :9] = rng.integers(0, t, (B, 9), dtype=np.uint64)
+    a = gpu.Ciphertext.from_numpy(ctx, np.stack([enc.encrypt(m1[b]) for b in range(B)]))
+    b = gpu.Ciphertext.from_numpy(ctx, np.stack([enc.encrypt(m2[b]) for b in range(B)]))
+    ev = gpu.Evaluator(ctx)
+    r = ev.multiply(a, b)
+    ev.relinearizeInplace(r, rlk)
+    got = ev.decrypt(r, gpu.DeviceBuffer.from_numpy(kg.secretKey()))
+    for i in range(B):
+        assert np.array_equal(got[i], negacyclic_mul(m2[i], m1[i], t)), i  # sparse operand first: 9 x 4096 terms

@@ -448,6 +448,17 @@ class Evaluator:
                                                   C.c_uint64(a.batch), self.stream))
         a._absorb(st)
 
+    def decrypt(self, a, secret_key):
+        """DecryptorCuda::decrypt on the device: secret_key = DeviceBuffer [K][N] (NTT form).  Returns a numpy array
+        [batch][N] (BFV/BGV coefficients mod t) or [batch][limbs][N] (CKKS RNS plaintext, NTT form)."""
+        N = self.context.N
+        per = a.limbs * N if self.context.scheme == capi.CKKS else N
+        out = DeviceBuffer(a.batch * per)
+        st = a.struct()
+        self._chk(self.lib.troyhip_decrypt(self.context.h, C.byref(st), C.c_void_p(secret_key.ptr), C.c_void_p(out.ptr), C.c_uint64(per), C.c_uint64(a.batch), self.stream))
+        r = out.to_numpy()
+        return r.reshape(a.batch, a.limbs, N) if self.context.scheme == capi.CKKS else r.reshape(a.batch, N)
+
     def transformPlainToNtt(self, plain, limbs, n_coeffs=None, count=1):
         """transformToNttInplace(Plaintext, parms_id): returns a DeviceBuffer [count][limbs][N]."""
         n = self.context.N if n_coeffs is None else int(n_coeffs)

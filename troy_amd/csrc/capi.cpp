@@ -297,5 +297,9 @@ int troyhip_plain_to_ntt(troyhip_context *ctx, const uint64_t *plain, uint64_t p
                          uint64_t count, void *stream) {
     return guard([&] { ctx->ev.plain_to_ntt(plain, plain_coeff_count, plain_batch_stride, limbs, out, count, (hipStream_t)stream); });
 }
+int troyhip_decrypt(troyhip_context *ctx, const troyhip_ct *ct, const uint64_t *secret_key, uint64_t *plain_out, uint64_t plain_batch_stride, uint64_t batch,
+                    void *stream) {
+    return guard([&] { CtBatch x = view(ct); ctx->ev.decrypt(x, secret_key, plain_out, plain_batch_stride, batch, (hipStream_t)stream); });
+}
 
 } // extern "C"

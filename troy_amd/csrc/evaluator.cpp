@@ -525,4 +525,57 @@ void Evaluator::multiply_plain(CtBatch &ct, const u64 *plain, u64 n_coeffs, u64 
     transform_from_ntt(ct, batch, s);
 }
 
+// ---- decryption ----
+void Evaluator::decrypt(const CtBatch &ct, const u64 *sk, u64 *out, u64 out_bstride, u64 batch, hipStream_t s) {
+    check_ct(ct);
+    if (!sk || !out) throw Error(ST_INVALID_ARGUMENT, "secret key / destination");
+    if (ct.size < 2) throw Error(ST_INVALID_ARGUMENT, "encrypted is not valid for encryption parameters");
+    if (c.scheme == SCHEME_CKKS && !ct.ntt) throw Error(ST_INVALID_ARGUMENT, "CKKS encrypted must be in NTT form");
+    const u64 N = c.N, limbs = ct.limbs, pw = poly_words(c, ct.limbs), np = ct.size - 1;
+    const host::RnsLevel &r = c.level(ct.limbs).rns;
+    DecryptArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.primes = c.d_desc; a.map = c.ct_map(ct.limbs); a.logn = c.logn;
+    a.limbs = limbs; a.size = ct.size; a.batch = batch; a.ct_bstride = ct.bstride; a.out_bstride = out_bstride;
+    c.arena.reset();
+    c.arena.reserve(batch * np * pw + np * pw + batch * pw + 512);
+    u64 *x = c.arena.take(batch * np * pw), *spow = c.arena.take(np * pw), *acc = c.arena.take(batch * pw);
+    // c_1 .. c_{size-1} in NTT form
+    launch_copy_strided(ct.data + pw, ct.bstride, x, np * pw, np * pw, batch, s);
+    if (!ct.ntt) launch_ntt(x, c.d_desc, a.map, batch * np * limbs, c.logn, false, s);
+    // s, s^2, .. at this level (the key is stored at the key level: limb l of the key is limb l here)
+    HIP_CHECK(hipMemcpyAsync(spow, sk, pw * sizeof(u64), hipMemcpyDeviceToDevice, s));
+    for (u64 i = 1; i < np; i++) launch_ew(3, spow + (i - 1) * pw, sk, spow + i * pw, c.d_desc, a.map, c.logn, limbs, s);
+    launch_dot_sk(x, spow, acc, a, s);
+    if (!ct.ntt) launch_ntt(acc, c.d_desc, a.map, batch * limbs, c.logn, true, s);
+    launch_add_c0(ct.data, acc, a, s);
+    if (c.scheme == SCHEME_CKKS) {
+        launch_copy_strided(acc, pw, out, out_bstride, pw, batch, s);
+        return;
+    }
+    const Mod tm = make_mod(c.t);
+    a.t_p = tm.p; a.t_cr0 = tm.cr0; a.t_cr1 = tm.cr1;
+    if (c.scheme == SCHEME_BFV) {
+        const Mod gm = make_mod(r.gamma);
+        a.g_p = gm.p; a.g_cr0 = gm.cr0; a.g_cr1 = gm.cr1;
+        const host::BaseConv &bc = r.q_to_tgamma;
+        for (u64 l = 0; l < limbs; l++) {
+            const u64 ql = c.primes[l];
+            a.pre[l] = make_shoup(host::mul_mod(r.prod_tgamma_mod_q[l], bc.inv_punct[l], ql), ql);
+            a.mat_t[l] = bc.mat[0][l];
+            a.mat_g[l] = bc.mat[1][l];
+        }
+        a.neg_inv_q_mod_t = r.neg_inv_q_mod_t; a.neg_inv_q_mod_gamma = r.neg_inv_q_mod_gamma; a.inv_gamma_mod_t = r.inv_gamma_mod_t;
+    } else {
+        host::BaseConv bc;
+        std::vector<u64> q(c.primes.begin(), c.primes.begin() + limbs);
+        bc.build(q, {c.t});
+        for (u64 l = 0; l < limbs; l++) { a.pre[l] = make_shoup(bc.inv_punct[l], q[l]); a.mat_t[l] = bc.mat[0][l]; }
+        a.q_mod_t = host::product_mod(q, c.t);
+        a.inv_cf = 1;
+        if (ct.cf != 1 && !host::inv_mod(ct.cf, c.t, a.inv_cf)) throw Error(ST_LOGIC_ERROR, "invalid correction factor");
+    }
+    launch_decrypt_final(c.scheme, acc, out, a, s);
+}
+
 } // namespace troyhip

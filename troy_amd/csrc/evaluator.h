@@ -35,6 +35,9 @@ public:
     // plain_bstride = 0 broadcasts one plaintext to the whole batch
     void add_plain(CtBatch &ct, const u64 *plain, u64 n_coeffs, u64 plain_bstride, double plain_scale, bool sub, u64 batch, hipStream_t s);
     void multiply_plain(CtBatch &ct, const u64 *plain, u64 n_coeffs, u64 plain_bstride, u64 batch, hipStream_t s);
+    // DecryptorCuda::decrypt (decryptor_cuda.cu:61-330): sk [K][N] NTT form (device); out: BFV/BGV N coefficients mod t per item
+    // (stride out_bstride), CKKS the RNS plaintext [limbs][N] (NTT form)
+    void decrypt(const CtBatch &ct, const u64 *sk, u64 *out, u64 out_bstride, u64 batch, hipStream_t s);
     void plain_to_ntt(const u64 *plain, u64 n_coeffs, u64 plain_bstride, int limbs, u64 *out, u64 count, hipStream_t s);
     void negate(CtBatch &a, u64 batch, hipStream_t s);
     // out may alias a or b; out.size/limbs/... are set; out.data/out.bstride are the caller's

@@ -80,6 +80,26 @@ void launch_ks_mac(const u64 *D, const u64 *key, const u64 *ckks_target, u64 t_b
 void launch_ks_moddown(int kind, const u64 *acc, u64 *ct, u64 ct_bstride, const KsArgs &a, hipStream_t s);
 void launch_ks_ckks_corr(const u64 *last, u64 *corr, const KsArgs &a, hipStream_t s);
 void launch_ks_ckks_combine(const u64 *acc, const u64 *corr, u64 *ct, u64 ct_bstride, const KsArgs &a, hipStream_t s);
+// ---- decryption (decryptor_cuda.cu:61-330, rns_cuda.cu:510-621) ----
+struct DecryptArgs {
+    const PrimeDesc *primes;
+    LimbMap map;
+    int logn;
+    u64 limbs, size, batch;
+    u64 ct_bstride, out_bstride;
+    // BFV decryptScaleAndRound: y_l = x_l * (t gamma (q/q_l)^-1) mod q_l ; sums against (q/q_l) mod t and mod gamma
+    Shoup pre[64];
+    u64 mat_t[64], mat_g[64];
+    u64 t_p, t_cr0, t_cr1, g_p, g_cr0, g_cr1;
+    u64 neg_inv_q_mod_t, neg_inv_q_mod_gamma, inv_gamma_mod_t;
+    // BGV decryptModt: exact conversion to t with the double-precision rounding term, times correction_factor^-1
+    u64 q_mod_t, inv_cf;
+};
+// acc[b][l][n] = sum_{i>=1} x[b][i-1][l][n] * spow[i-1][l][n]  (x: the NTT-form polynomials c_1.., spow: s, s^2, ..)
+void launch_dot_sk(const u64 *x, const u64 *spow, u64 *acc, const DecryptArgs &a, hipStream_t s);
+// acc[b][l][n] += c0 of ciphertext b
+void launch_add_c0(const u64 *ct, u64 *acc, const DecryptArgs &a, hipStream_t s);
+void launch_decrypt_final(int scheme, const u64 *acc, u64 *out, const DecryptArgs &a, hipStream_t s);
 void launch_copy_strided(const u64 *src, u64 src_bstride, u64 *dst, u64 dst_bstride, u64 count, u64 batch, hipStream_t s);
 void launch_zero_strided(u64 *dst, u64 dst_bstride, u64 count, u64 batch, hipStream_t s);
 void launch_fill_uniform(u64 *out, const PrimeDesc *primes, const LimbMap &map, int logn, u64 seed, u64 row0, u64 rows, hipStream_t s);

@@ -593,6 +593,91 @@ void launch_ks_ckks_combine(const u64 *acc, const u64 *corr, u64 *ct, u64 ct_bst
     launch_check("ks_ckks_combine_kernel");
 }
 
+// ---------------------------------------------------------------- decryption
+// dotProductCtSkArray (decryptor_cuda.cu:284-330): every product reduced, then added modulo p
+__global__ __launch_bounds__(EW_THREADS) void dot_sk_kernel(const u64 *x, const u64 *spow, u64 *acc, DecryptArgs a) {
+    const u64 idx = (u64)blockIdx.x * EW_THREADS + threadIdx.x;
+    const u64 per = a.limbs << a.logn;
+    if (idx >= a.batch * per) return;
+    const u64 b = idx / per, r = idx % per;
+    const Mod m = mod_of(a.primes[a.map.id[r >> a.logn]]);
+    u64 s = 0;
+    for (u64 i = 0; i + 1 < a.size; i++) s = addmod(s, mulmod(x[(b * (a.size - 1) + i) * per + r], spow[i * per + r], m), m.p);
+    acc[idx] = s;
+}
+__global__ __launch_bounds__(EW_THREADS) void add_c0_kernel(const u64 *ct, u64 *acc, DecryptArgs a) {
+    const u64 idx = (u64)blockIdx.x * EW_THREADS + threadIdx.x;
+    const u64 per = a.limbs << a.logn;
+    if (idx >= a.batch * per) return;
+    const u64 b = idx / per, r = idx % per;
+    acc[idx] = addmod(acc[idx], ct[b * a.ct_bstride + r], a.primes[a.map.id[r >> a.logn]].p);
+}
+// BFV: decryptScaleAndRound (rns_cuda.cu:510-577, CPU rns.cpp:1039-1095): round(t/q * x) through the base {t, gamma}
+__global__ __launch_bounds__(EW_THREADS) void decrypt_bfv_kernel(const u64 *acc, u64 *out, DecryptArgs a) {
+    const u64 idx = (u64)blockIdx.x * EW_THREADS + threadIdx.x;
+    const u64 N = u64(1) << a.logn;
+    if (idx >= a.batch * N) return;
+    const u64 b = idx >> a.logn, n = idx & (N - 1);
+    const Mod tm{a.t_p, a.t_cr0, a.t_cr1}, gm{a.g_p, a.g_cr0, a.g_cr1};
+    U128 st{0, 0}, sg{0, 0};
+    for (u64 l = 0; l < a.limbs; l++) {
+        const u64 p = a.primes[a.map.id[l]].p;
+        const u64 v = mul_shoup(acc[(b * a.limbs + l) * N + n], a.pre[l], p);
+        mac128(st, v, a.mat_t[l]);
+        mac128(sg, v, a.mat_g[l]);
+        if ((l & 7) == 7) { st.lo = barrett128(st.lo, st.hi, tm); st.hi = 0; sg.lo = barrett128(sg.lo, sg.hi, gm); sg.hi = 0; }
+    }
+    const u64 vt = mulmod(barrett128(st.lo, st.hi, tm), a.neg_inv_q_mod_t, tm);
+    const u64 vg = mulmod(barrett128(sg.lo, sg.hi, gm), a.neg_inv_q_mod_gamma, gm);
+    u64 d;
+    if (vg > (gm.p >> 1)) d = addmod(vt, barrett64(gm.p - vg, tm), tm.p);
+    else d = submod(vt, barrett64(vg, tm), tm.p);
+    out[b * a.out_bstride + n] = d ? mulmod(d, a.inv_gamma_mod_t, tm) : 0;
+}
+// BGV: decryptModt = exactConvertArray to t (rns_cuda.cu:147-180: the rounding term is a double-precision sum taken in limb
+// order, exactly as the CPU path rns.cpp:462-548 does) times correction_factor^-1
+__global__ __launch_bounds__(EW_THREADS) void decrypt_bgv_kernel(const u64 *acc, u64 *out, DecryptArgs a) {
+    const u64 idx = (u64)blockIdx.x * EW_THREADS + threadIdx.x;
+    const u64 N = u64(1) << a.logn;
+    if (idx >= a.batch * N) return;
+    const u64 b = idx >> a.logn, n = idx & (N - 1);
+    const Mod tm{a.t_p, a.t_cr0, a.t_cr1};
+    double agg = 0.0;
+    U128 sum{0, 0};
+    for (u64 l = 0; l < a.limbs; l++) {
+        const u64 p = a.primes[a.map.id[l]].p;
+        const u64 v = mul_shoup(acc[(b * a.limbs + l) * N + n], a.pre[l], p);
+        agg += (double)v / (double)p;
+        mac128(sum, v, a.mat_t[l]);
+        if ((l & 7) == 7) { sum.lo = barrett128(sum.lo, sum.hi, tm); sum.hi = 0; }
+    }
+    agg += 0.5;
+    const u64 rounded = (u64)agg;
+    u64 d = submod(barrett128(sum.lo, sum.hi, tm), mulmod(barrett64(rounded, tm), a.q_mod_t, tm), tm.p);
+    if (a.inv_cf != 1) d = mulmod(d, a.inv_cf, tm);
+    out[b * a.out_bstride + n] = d;
+}
+void launch_dot_sk(const u64 *x, const u64 *spow, u64 *acc, const DecryptArgs &a, hipStream_t s) {
+    const u64 total = a.batch * a.limbs << a.logn;
+    if (!total) return;
+    TROY_LAUNCH(dot_sk_kernel, dim3(ceil_div(total, EW_THREADS)), dim3(EW_THREADS), 0, s, x, spow, acc, a);
+    launch_check("dot_sk_kernel");
+}
+void launch_add_c0(const u64 *ct, u64 *acc, const DecryptArgs &a, hipStream_t s) {
+    const u64 total = a.batch * a.limbs << a.logn;
+    if (!total) return;
+    TROY_LAUNCH(add_c0_kernel, dim3(ceil_div(total, EW_THREADS)), dim3(EW_THREADS), 0, s, ct, acc, a);
+    launch_check("add_c0_kernel");
+}
+void launch_decrypt_final(int scheme, const u64 *acc, u64 *out, const DecryptArgs &a, hipStream_t s) {
+    const u64 total = a.batch << a.logn;
+    if (!total) return;
+    dim3 grid(ceil_div(total, EW_THREADS)), blk(EW_THREADS);
+    if (scheme == 1 /* BFV */) TROY_LAUNCH(decrypt_bfv_kernel, grid, blk, 0, s, acc, out, a);
+    else TROY_LAUNCH(decrypt_bgv_kernel, grid, blk, 0, s, acc, out, a);
+    launch_check("decrypt_kernel");
+}
+
 // ---------------------------------------------------------------- strided copy / zero helpers
 // dst[b*dst_bstride + i] = src[b*src_bstride + i], i < count
 __global__ __launch_bounds__(EW_THREADS) void copy_strided_kernel(const u64 *src, u64 src_bstride, u64 *dst, u64 dst_bstride, u64 count, u64 batch) {
