@@ -306,19 +306,24 @@ private:
     mutable uint64_t counter_ = 0;
 };
 
-class Decryptor { // src/decryptor_cuda.cuh: download + CPU decryption (deterministic)
+class Decryptor { // src/decryptor_cuda.cuh:13-60: the secret key is uploaded once, decryption runs on the device
 public:
-    Decryptor(const SEALContext &c, const SecretKey &sk) : c_(c), sk_(sk) {}
+    Decryptor(const SEALContext &c, const SecretKey &sk) : c_(c), sk_(sk.data.size()) {
+        check(troyhip_copy_h2d(sk_.get(), sk.data.data(), sk.data.size() * 8, nullptr));
+    }
     void decrypt(const Ciphertext &ct, Plaintext &dst) const {
         const size_t N = c_.polyModulusDegree();
         const bool ckks = c_.parms().scheme() == SchemeType::ckks;
-        std::vector<uint64_t> h = ct.toHost();
-        dst.resize(ckks ? ct.coeffModulusSize() * N : N);
-        check(troyhip_host_decrypt(c_.handle(), sk_.data.data(), h.data(), (int)ct.size(), (int)ct.coeffModulusSize(), ct.isNttForm(), ct.correctionFactor(), dst.data()));
+        const size_t words = ckks ? ct.coeffModulusSize() * N : N;
+        DeviceArray out(words);
+        check(troyhip_decrypt(c_.handle(), ct.raw(), sk_.get(), out.get(), words, 1, nullptr));
+        dst.resize(words);
+        check(troyhip_copy_d2h(dst.data(), out.get(), words * 8, nullptr));
+        if (ckks) { dst.setNttForm(ct.parmsID()); dst.scale() = ct.scale(); }
     }
 private:
     const SEALContext &c_;
-    SecretKey sk_;
+    DeviceArray sk_;
 };
 
 class Evaluator { // src/evaluator_cuda.cuh:13-361 -- every method const, non-copyable
