@@ -283,8 +283,14 @@ void Evaluator::switch_key(CtBatch &ct, const u64 *target, u64 t_bstride, const 
     if (ntt2_supported(c.logn) && ks_fused()) {
         // fused: the first NTT pass reads the target and reduces it modulo each output prime on the fly; the second pass keeps
         // the transforms in registers and accumulates them against the key -- the expanded digits are never written back
+        // lazy accumulation is exact while dl * 8p * p < 2^128 for every output prime (CKKS replaces one operand by a canonical value)
+        bool lazy = true;
+        for (u64 i = 0; i < rl; i++) {
+            const long double p = (long double)c.primes[out_ids[i]];
+            lazy = lazy && (long double)dl * 8.0L * p * p < 3.0e38L; // 2^128 = 3.4e38
+        }
         launch_ntt2_ks_mac(D, coeff_target, ct_tb, c.d_desc, c.ids_map(out_ids, (uint32_t)dl), batch * rl * dl, c.logn, key.data, acc, a.key_limb, (unsigned)K,
-                           mac_target, t_bstride, s);
+                           mac_target, t_bstride, lazy, s);
     } else {
         if (ntt2_supported(c.logn)) {
             launch_ntt2(D, coeff_target, ct_tb, true, c.d_desc, c.ids_map(out_ids, (uint32_t)dl), batch * rl * dl, c.logn, false, s);

@@ -75,6 +75,7 @@ struct Ntt2Args {
     const u64 *mac_target;  // CKKS: the NTT-form input supplies the (k == slot) operand (evaluator.cpp:2424-2427), else nullptr
     u64 mac_tstride;
     unsigned mac_K;
+    int mac_lazy;           // every output prime p satisfies dl * 8p * p < 2^128: the transforms are accumulated unreduced
     uint8_t mac_key_limb[65];
 };
 
@@ -533,14 +534,17 @@ __global__ __launch_bounds__(N2_THREADS, MAC ? N2_MAC_WAVES : N2_MIN_WAVES) void
                 if constexpr (NR == 3 && MAC == 2) {
                     Rd2::tensor_epilogue(x, tx, mm, a.tensor_out, period, slot, tile, logn, m);
                 } else if constexpr (NR == 3 && MAC == 1) {
-                    // canonical transform of digit k of (o, slot) stays in registers: acc_c += x (.) key[k][c][limb(slot)]
-                    const PrimeConst pc = make_prime_const(pd.p);
+                    // the transform of digit k of (o, slot) stays in registers: acc_c += x (.) key[k][c][limb(slot)].  x is lazy, in
+                    // [0, 8p); it is only normalised when dl * 8p * p could overflow the 128-bit accumulator (mac_lazy == 0)
+                    if (!a.mac_lazy) {
+                        const PrimeConst pc = make_prime_const(pd.p);
 #pragma unroll
-                    for (int h = 0; h < 2; h++) {
-                        u64 v[4] = {x[4 * h], x[4 * h + 1], x[4 * h + 2], x[4 * h + 3]};
-                        reduce4_from_8p(v, pc);
+                        for (int h = 0; h < 2; h++) {
+                            u64 v[4] = {x[4 * h], x[4 * h + 1], x[4 * h + 2], x[4 * h + 3]};
+                            reduce4_from_8p(v, pc);
 #pragma unroll
-                        for (int i = 0; i < 4; i++) x[4 * h + i] = v[i];
+                            for (int i = 0; i < 4; i++) x[4 * h + i] = v[i];
+                        }
                     }
                     const unsigned o = mm / inner, k = mm - o * inner;
                     const u64 pos = ((u64)tile << N2_LOGT) + 8 * threadIdx.x;
@@ -679,7 +683,7 @@ void launch_ntt2(u64 *data, const u64 *src, u64 src_ostride, bool src_reduce, co
 // second pass.  D receives only the first pass; acc [outer][2][period][N] the reduced sums.  Rows are grouped per (o, slot):
 // a workgroup takes all `inner` digits of one group, so its 16 accumulators see every term.
 void launch_ntt2_ks_mac(u64 *D, const u64 *src, u64 src_ostride, const PrimeDesc *primes, const LimbMap &map, size_t rows, int logn, const u64 *key, u64 *acc,
-                        const uint8_t *key_limb, unsigned K, const u64 *ckks_target, u64 t_bstride, hipStream_t stream) {
+                        const uint8_t *key_limb, unsigned K, const u64 *ckks_target, u64 t_bstride, bool lazy, hipStream_t stream) {
     if (rows == 0) return;
     if (!ntt2_supported(logn) || logn - 9 > 7 || logn - 9 < 3) throw Error(ST_LOGIC_ERROR, "ntt2 ks_mac: unsupported size");
     const size_t per_outer = (size_t)map.period * map.inner;
@@ -707,6 +711,7 @@ void launch_ntt2_ks_mac(u64 *D, const u64 *src, u64 src_ostride, const PrimeDesc
     default: launch_strided<0, 7>(first, blocks, false, true, stream); break;
     }
     a.mac_key = key; a.mac_acc = acc; a.mac_target = ckks_target; a.mac_tstride = t_bstride; a.mac_K = K;
+    a.mac_lazy = lazy;
     std::memcpy(a.mac_key_limb, key_limb, map.period);
     TROY_LAUNCH(HIP_KERNEL_NAME(ntt2_kernel<0, 0, 9, 0, 1, 0, 1>), dim3(blocks), dim3(N2_THREADS), 0, stream, a);
     launch_check("ntt2_kernel(ks_mac)");
