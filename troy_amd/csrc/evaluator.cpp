@@ -420,10 +420,8 @@ void Evaluator::apply_galois(CtBatch &ct, uint32_t elt, const KsKey &key, u64 ba
     u64 *t0 = c.arena.take(batch * pw), *t1 = c.arena.take(batch * pw);
     LimbMap map = c.ct_map(L);
     const bool ntt_form = c.scheme == SCHEME_CKKS;
-    for (u64 b = 0; b < batch; b++) {
-        launch_galois(ntt_form, ct.data + b * ct.bstride, t0 + b * pw, c.d_desc, map, c.logn, elt, L, s);
-        launch_galois(ntt_form, ct.data + b * ct.bstride + pw, t1 + b * pw, c.d_desc, map, c.logn, elt, L, s);
-    }
+    launch_galois(ntt_form, ct.data, ct.bstride, t0, pw, c.d_desc, map, c.logn, elt, L, batch, s);
+    launch_galois(ntt_form, ct.data + pw, ct.bstride, t1, pw, c.d_desc, map, c.logn, elt, L, batch, s);
     launch_copy_strided(t0, pw, ct.data, ct.bstride, pw, batch, s);
     launch_zero_strided(ct.data + pw, ct.bstride, pw, batch, s);
     // switch_key resets the arena but never grows it now, so t1 (beyond its working set) stays intact

@@ -46,7 +46,8 @@ void launch_add_plain(int kind, bool sub, u64 *ct0, u64 ct_bstride, const u64 *p
 void launch_plain_lift(const u64 *plain, u64 *lifted, const PlainArgs &a, hipStream_t s);
 void launch_tensor(int s1, int s2, const u64 *a, const u64 *b, u64 *out, u64 a_bstride, u64 b_bstride, const PrimeDesc *primes, const LimbMap &map,
                    int logn, u64 limbs, u64 batch, hipStream_t s);
-void launch_galois(bool ntt_form, const u64 *in, u64 *out, const PrimeDesc *primes, const LimbMap &map, int logn, uint32_t elt, u64 rows, hipStream_t s);
+void launch_galois(bool ntt_form, const u64 *in, u64 in_bstride, u64 *out, u64 out_bstride, const PrimeDesc *primes, const LimbMap &map, int logn, uint32_t elt, u64 limbs,
+                   u64 batch, hipStream_t s);
 
 struct ModSwitchArgs {
     const PrimeDesc *primes;

@@ -227,36 +227,39 @@ void launch_tensor(int s1, int s2, const u64 *a, const u64 *b, u64 *out, u64 a_b
 }
 
 // ---------------------------------------------------------------- Galois (a-6 / A.11)
-// coefficient form: out[(i*g) mod N] = +-in[i]   (src/utils/galois.cpp:143-162)
-__global__ __launch_bounds__(EW_THREADS) void galois_coeff_kernel(const u64 *in, u64 *out, const PrimeDesc *primes, LimbMap map, int logn, uint32_t elt, u64 total) {
+// coefficient form: out[(i*g) mod N] = +-in[i]   (src/utils/galois.cpp:143-162).  One launch covers `batch` items of `limbs` rows
+// each; item b reads in + b * in_bstride and writes out + b * out_bstride.
+__global__ __launch_bounds__(EW_THREADS) void galois_coeff_kernel(const u64 *in, u64 in_bstride, u64 *out, u64 out_bstride, const PrimeDesc *primes, LimbMap map, int logn,
+                                                                  uint32_t elt, u64 limbs, u64 total) {
     u64 i = (u64)blockIdx.x * EW_THREADS + threadIdx.x;
     if (i >= total) return;
     const u64 N = u64(1) << logn;
-    u64 row = i >> logn, n = i & (N - 1);
-    const u64 p = prime_of(primes, map, row).p;
+    u64 row = i >> logn, n = i & (N - 1), b = row / limbs, l = row % limbs;
+    const u64 p = primes[map.id[l]].p;
     u64 raw = n * elt;
     u64 idx = raw & (N - 1);
-    u64 v = in[i];
+    u64 v = in[b * in_bstride + (l << logn) + n];
     if ((raw >> logn) & 1) v = negmod(v, p);
-    out[(row << logn) + idx] = v;
+    out[b * out_bstride + (l << logn) + idx] = v;
 }
 // NTT form: out[i] = in[bitrev(((g * bitrev(i + N, logN+1)) >> 1) mod N, logN)]   (galois.cpp:18-35)
-__global__ __launch_bounds__(EW_THREADS) void galois_ntt_kernel(const u64 *in, u64 *out, int logn, uint32_t elt, u64 total) {
+__global__ __launch_bounds__(EW_THREADS) void galois_ntt_kernel(const u64 *in, u64 in_bstride, u64 *out, u64 out_bstride, int logn, uint32_t elt, u64 limbs, u64 total) {
     u64 i = (u64)blockIdx.x * EW_THREADS + threadIdx.x;
     if (i >= total) return;
     const u64 N = u64(1) << logn;
-    u64 row = i >> logn, n = i & (N - 1);
+    u64 row = i >> logn, n = i & (N - 1), b = row / limbs, l = row % limbs;
     uint32_t rev = __brev((uint32_t)(n + N)) >> (32 - (logn + 1));
     u64 raw = (((u64)elt * rev) >> 1) & (N - 1);
     uint32_t src = logn ? (__brev((uint32_t)raw) >> (32 - logn)) : 0;
-    out[i] = in[(row << logn) + src];
+    out[b * out_bstride + (l << logn) + n] = in[b * in_bstride + (l << logn) + src];
 }
-void launch_galois(bool ntt_form, const u64 *in, u64 *out, const PrimeDesc *primes, const LimbMap &map, int logn, uint32_t elt, u64 rows, hipStream_t s) {
-    u64 total = rows << logn;
+void launch_galois(bool ntt_form, const u64 *in, u64 in_bstride, u64 *out, u64 out_bstride, const PrimeDesc *primes, const LimbMap &map, int logn, uint32_t elt, u64 limbs,
+                   u64 batch, hipStream_t s) {
+    u64 total = (batch * limbs) << logn;
     if (!total) return;
     dim3 grid(ceil_div(total, EW_THREADS)), blk(EW_THREADS);
-    if (ntt_form) TROY_LAUNCH(galois_ntt_kernel, grid, blk, 0, s, in, out, logn, elt, total);
-    else TROY_LAUNCH(galois_coeff_kernel, grid, blk, 0, s, in, out, primes, map, logn, elt, total);
+    if (ntt_form) TROY_LAUNCH(galois_ntt_kernel, grid, blk, 0, s, in, in_bstride, out, out_bstride, logn, elt, limbs, total);
+    else TROY_LAUNCH(galois_coeff_kernel, grid, blk, 0, s, in, in_bstride, out, out_bstride, primes, map, logn, elt, limbs, total);
     launch_check("galois_kernel");
 }
 
