@@ -67,6 +67,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=64, help="ciphertext pairs per GPU per step")
     ap.add_argument("--workload", default="bfv_n32768_l14", choices=sorted(WORKLOADS))
+    ap.add_argument("--streams", type=int, default=1, help="split the batch over this many HIP streams (one context each): kernels of different phases overlap")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--ntt-reps", type=int, default=10)
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed even for one rank (tests the RCCL path)")
@@ -121,29 +122,65 @@ def main():
     nbsk = len(ctx.behz_bases(L)[0])
 
     # ---- synthetic inputs, generated on the device (fill_uniform_kernel == troy_amd.synth) ----
+    # The batch is split over `streams` HIP streams, each with its own context (tables + scratch arena): the kernels of one
+    # half run concurrently with the kernels of the other, so VALU-bound phases (BEHZ, fused key-switch pass) overlap
+    # memory-bound ones (strided NTT passes).  streams = 1 is the plain single-stream batch.
+    S = max(1, min(args.streams, B))
     row0 = rank * B * 4 * L  # every rank owns different ciphertexts
-    a = ta.Ciphertext(ctx, B, 2, L)
-    b = ta.Ciphertext(ctx, B, 2, L)
-    out = ta.Ciphertext(ctx, B, 3, L, capacity=3)
-    ctx.fill_uniform(a.buf, B * 2 * L, primes[:L], seed=0x5EED, row0=row0)
-    ctx.fill_uniform(b.buf, B * 2 * L, primes[:L], seed=0x5EED, row0=row0 + B * 2 * L)
     key = ta.DeviceBuffer((K - 1) * 2 * K * N)
     ctx.fill_uniform(key, (K - 1) * 2 * K, primes, seed=0xC0FFEE)
-    ctx.reserve_scratch(max(ctx.scratch_words(0, L, B), ctx.scratch_words(1, L, B)))
+    lanes = []
+    done = 0
+    for i in range(S):
+        Bi = B // S + (1 if i < B % S else 0)
+        cx = ctx if i == 0 else ta.SEALContext(scheme, N, primes, t)
+        st = None
+        if S > 1:
+            h = C.c_void_p()
+            capi.check(lib, lib.troyhip_stream_create(C.byref(h)))
+            st = h
+        ai, bi = ta.Ciphertext(cx, Bi, 2, L), ta.Ciphertext(cx, Bi, 2, L)
+        oi = ta.Ciphertext(cx, Bi, 3, L, capacity=3)
+        cx.fill_uniform(ai.buf, Bi * 2 * L, primes[:L], seed=0x5EED, row0=row0 + done * 2 * L)
+        cx.fill_uniform(bi.buf, Bi * 2 * L, primes[:L], seed=0x5EED, row0=row0 + B * 2 * L + done * 2 * L)
+        cx.reserve_scratch(max(cx.scratch_words(0, L, Bi), cx.scratch_words(1, L, Bi)))
+        lanes.append((cx, st, Bi, ai.struct(), bi.struct(), oi, ai, bi))
+        done += Bi
     ta.synchronize()
 
-    sa, sb = a.struct(), b.struct()
+    # Odd lanes run half a step out of phase (their relinearize of the previous product is issued while the even lanes
+    # multiply): every lane still does exactly one multiply and one relinearize per step.
+    pending = {}
+
+    def mul(i):
+        cx, st, Bi, sa, sb, oi, _a, _b = lanes[i]
+        so = oi.struct()
+        capi.check(lib, lib.troyhip_multiply(cx.h, C.byref(sa), C.byref(sb), C.byref(so), C.c_uint64(Bi), st))
+        pending[i] = so
+
+    def relin(i):
+        cx, st, Bi = lanes[i][:3]
+        capi.check(lib, lib.troyhip_relinearize(cx.h, C.byref(pending.pop(i)), C.c_void_p(key.ptr), C.c_uint64(Bi), st))
+
+    for i in range(1, S, 2):
+        mul(i)  # prime the out-of-phase lanes (untimed)
 
     def step():
-        so = out.struct()
-        capi.check(lib, lib.troyhip_multiply(ctx.h, C.byref(sa), C.byref(sb), C.byref(so), C.c_uint64(B), None))
-        capi.check(lib, lib.troyhip_relinearize(ctx.h, C.byref(so), C.c_void_p(key.ptr), C.c_uint64(B), None))
+        for i in range(S):
+            (relin if i & 1 else mul)(i)
+        for i in range(S):
+            (mul if i & 1 else relin)(i)
+
+    def sync_all():
+        for _cx, st, *_ in lanes:
+            ta.synchronize(st)
+        ta.synchronize()
 
     def barrier():
-        ta.synchronize()
+        sync_all()
         if use_dist:
             _dist().barrier()
-        ta.synchronize()
+        sync_all()
 
     for _ in range(args.warmup):
         step()
@@ -151,7 +188,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    ta.synchronize()
+    sync_all()
     dt = time.perf_counter() - t0
     barrier()
     if use_dist:
@@ -219,7 +256,7 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
             "config": {"workload": args.workload, "scheme": "BFV", "N": N, "K": K, "L": L, "Bsk": nbsk, "batch_per_gpu": B,
-                       "limb_transforms_per_op": limb_transforms, "parallelism": f"batch-shard x{world}", "rendezvous": backend},
+                       "limb_transforms_per_op": limb_transforms, "parallelism": f"batch-shard x{world}", "streams_per_gpu": S, "rendezvous": backend},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         sys.stdout.flush()

@@ -63,6 +63,10 @@ int troyhip_copy_d2h(void *dst, const void *src, size_t bytes, void *stream);   
 int troyhip_copy_d2d(void *dst, const void *src, size_t bytes, void *stream);   /* KernelProvider::copyOnDevice */
 int troyhip_memset_zero(void *dst, size_t bytes, void *stream);                 /* KernelProvider::memsetZero */
 int troyhip_stream_synchronize(void *stream);
+/* every operation takes a stream (NULL = the default stream); one context may only be driven from ONE stream at a time (its
+ * scratch arena is not shared between concurrent operations) -- use one context per stream to overlap independent batches */
+int troyhip_stream_create(void **stream);
+int troyhip_stream_destroy(void *stream);
 int troyhip_mem_info(size_t *free_bytes, size_t *total_bytes);
 /* HIP-event timers on the caller's stream (bench.py roofline measurement) */
 int troyhip_timer_create(void **timer);

@@ -84,6 +84,10 @@ int troyhip_copy_d2d(void *dst, const void *src, size_t bytes, void *stream) {
 }
 int troyhip_memset_zero(void *dst, size_t bytes, void *stream) { return guard([&] { HIP_CHECK(hipMemsetAsync(dst, 0, bytes, (hipStream_t)stream)); }); }
 int troyhip_stream_synchronize(void *stream) { return guard([&] { HIP_CHECK(hipStreamSynchronize((hipStream_t)stream)); }); }
+int troyhip_stream_create(void **stream) {
+    return guard([&] { hipStream_t st; HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking)); *stream = (void *)st; });
+}
+int troyhip_stream_destroy(void *stream) { return guard([&] { HIP_CHECK(hipStreamDestroy((hipStream_t)stream)); }); }
 int troyhip_mem_info(size_t *free_bytes, size_t *total_bytes) { return guard([&] { HIP_CHECK(hipMemGetInfo(free_bytes, total_bytes)); }); }
 
 int troyhip_timer_create(void **timer) {
