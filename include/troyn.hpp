@@ -355,6 +355,29 @@ public:
         check(troyhip_relinearize(h(), a.raw(), a.size() > 2 ? k.device(RelinKeys::getIndex(2)) : nullptr, 1, nullptr));
     }
     void relinearize(const Ciphertext &a, const RelinKeys &k, Ciphertext &d) const { d = a; relinearizeInplace(d, k); }
+    // applyKeySwitchingInplace (evaluator_cuda.cu:1365-1378), negacyclicShiftInplace (:2342-2351)
+    void applyKeySwitchingInplace(Ciphertext &a, const KSwitchKeys &k) const {
+        if (k.all().size() != 1) throw std::invalid_argument("kswitch_keys.data().size() != 1");
+        check(troyhip_apply_key_switching(h(), a.raw(), k.all().begin()->second->get(), 1, nullptr));
+    }
+    void negacyclicShiftInplace(Ciphertext &a, size_t shift) const { check(troyhip_negacyclic_shift(h(), a.raw(), shift, 1, nullptr)); }
+    // multiplyMany / exponentiate (src/evaluator.cpp:1502-1601): pairwise products appended to the work list, each relinearized
+    void multiplyMany(const std::vector<Ciphertext> &v, const RelinKeys &rk, Ciphertext &d) const {
+        if (v.empty()) throw std::invalid_argument("encrypteds vector must not be empty");
+        need(SchemeType::ckks, false);
+        if (v.size() == 1) { d = v[0]; return; }
+        std::vector<Ciphertext> work;
+        for (size_t i = 0; i + 1 < v.size(); i += 2) { Ciphertext t; multiply(v[i], v[i + 1], t); relinearizeInplace(t, rk); work.push_back(std::move(t)); }
+        if (v.size() & 1) work.push_back(v.back());
+        for (size_t i = 0; i + 1 < work.size(); i += 2) { Ciphertext t; multiply(work[i], work[i + 1], t); relinearizeInplace(t, rk); work.push_back(std::move(t)); }
+        d = work.back();
+    }
+    void exponentiateInplace(Ciphertext &a, uint64_t exponent, const RelinKeys &rk) const {
+        if (exponent == 0) throw std::invalid_argument("exponent cannot be 0");
+        if (exponent == 1) return;
+        std::vector<Ciphertext> v((size_t)exponent, a);
+        multiplyMany(v, rk, a);
+    }
     void modSwitchToNextInplace(Ciphertext &a) const { next(a, troyhip_mod_switch_to_next); }
     void modSwitchToNext(const Ciphertext &a, Ciphertext &d) const { d = a; modSwitchToNextInplace(d); }
     void modSwitchToInplace(Ciphertext &a, ParmsID parms_id) const {

@@ -11,7 +11,7 @@ import subprocess
 import numpy as np
 
 from .ref import (BFV, BGV, CKKS, Ct, CtDesc, OP_ADD, OP_APPLY_GALOIS, OP_CONJUGATE, OP_FROM_NTT,  # noqa: F401
-                  OP_MODSWITCH_NEXT, OP_MULTIPLY, OP_MULTIPLY_PLAIN_NTT, OP_ADD_PLAIN, OP_SUB_PLAIN, OP_MULTIPLY_PLAIN, OP_NEGATE, OP_RELIN, OP_RESCALE_NEXT,
+                  OP_MODSWITCH_NEXT, OP_MULTIPLY, OP_MULTIPLY_PLAIN_NTT, OP_ADD_PLAIN, OP_SUB_PLAIN, OP_MULTIPLY_PLAIN, OP_APPLY_KEYSWITCH, OP_NEGACYCLIC_SHIFT, OP_NEGATE, OP_RELIN, OP_RESCALE_NEXT,
                   OP_ROTATE_COLUMNS, OP_ROTATE_ROWS, OP_ROTATE_VECTOR, OP_SQUARE, OP_SUB, OP_TO_NTT,
                   ST_DIVROUND_QLAST, ST_DIVROUND_QLAST_NTT, ST_FASTBCONV_MTILDE, ST_FASTBCONV_SK, ST_FASTFLOOR,
                   ST_MODT_DIV_QLAST, ST_SMMRQ)

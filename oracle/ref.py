@@ -16,7 +16,7 @@ _SO = os.path.join(_HERE, "_ref", "libtroyref_driver.so")
 BFV, CKKS, BGV = 1, 2, 3
 (OP_ADD, OP_SUB, OP_NEGATE, OP_MULTIPLY, OP_SQUARE, OP_RELIN, OP_MODSWITCH_NEXT, OP_RESCALE_NEXT,
  OP_APPLY_GALOIS, OP_ROTATE_ROWS, OP_ROTATE_COLUMNS, OP_ROTATE_VECTOR, OP_CONJUGATE, OP_TO_NTT,
- OP_FROM_NTT, OP_MULTIPLY_PLAIN_NTT, OP_ADD_PLAIN, OP_SUB_PLAIN, OP_MULTIPLY_PLAIN) = range(19)
+ OP_FROM_NTT, OP_MULTIPLY_PLAIN_NTT, OP_ADD_PLAIN, OP_SUB_PLAIN, OP_MULTIPLY_PLAIN, OP_APPLY_KEYSWITCH, OP_NEGACYCLIC_SHIFT) = range(21)
 (ST_FASTBCONV_MTILDE, ST_SMMRQ, ST_FASTFLOOR, ST_FASTBCONV_SK, ST_DIVROUND_QLAST, ST_DIVROUND_QLAST_NTT,
  ST_MODT_DIV_QLAST) = range(7)
 

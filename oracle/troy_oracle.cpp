@@ -1060,6 +1060,33 @@ struct Eval {
         if (o->scheme == ORC_CKKS && !scale_ok(a.scale, a.limbs)) throw std::invalid_argument("scale out of bounds");
     }
 
+    // EvaluatorCuda::applyKeySwitchingInplace (evaluator_cuda.cu:1365-1378; CUDA-only API): c1 becomes the key-switch target,
+    // c1 := 0, then switchKeyInplace with the single key of `kswitch_keys` (held in the relin-key slot here)
+    void apply_key_switching(Ct &a) const {
+        check_level(a);
+        if (a.size != 2) throw std::invalid_argument("encrypted.size() != 2");
+        std::vector<u64> target(a.poly(1, N), a.poly(1, N) + (size_t)a.limbs * N);
+        std::fill(a.poly(1, N), a.poly(1, N) + (size_t)a.limbs * N, 0);
+        switch_key(a, target.data(), o->relin_key);
+    }
+    // EvaluatorCuda::negacyclicShift (evaluator_cuda.cu:2342-2351) = util::negacyclicShiftPolyCoeffmod on every limb of every
+    // polynomial (polyarithsmallmod.cpp:128-152): result[(i + shift) mod N] = +-poly[i], negated on wrap-around, 0 stays 0
+    void negacyclic_shift(Ct &a, size_t shift) const {
+        check_level(a);
+        std::vector<u64> tmp(N);
+        for (int i = 0; i < a.size; i++)
+            for (int l = 0; l < a.limbs; l++) {
+                const Mod &m = o->key_q[l];
+                u64 *x = a.poly(i, N) + (size_t)l * N;
+                std::copy(x, x + N, tmp.begin());
+                if (shift == 0) continue;
+                for (size_t j = 0; j < N; j++) {
+                    const size_t raw = j + shift, idx = raw & (N - 1);
+                    x[idx] = (!(raw & N) || !tmp[j]) ? tmp[j] : m.p - tmp[j];
+                }
+            }
+    }
+
     // ---- plaintext operands ----
     // context.cpp:307-351: Delta_l = floor(q/t) mod q_l, q mod t, plain_upper_half_threshold = (t+1)/2.  floor(q/t) =
     // (q - q mod t)/t, so modulo q_l (q = 0 there) Delta_l = -(q mod t) * t^-1; the reference divides the multi-word q.
@@ -1416,6 +1443,8 @@ int orc_eval(void *h, int op, const orc_ct_desc *ad, const uint64_t *a, const or
         case ORC_OP_TO_NTT: ev.to_ntt(x); break;
         case ORC_OP_FROM_NTT: ev.from_ntt(x); break;
         case ORC_OP_MULTIPLY_PLAIN_NTT: ev.multiply_plain_ntt(x, b, bd ? bd->scale : 1.0); break;
+        case ORC_OP_APPLY_KEYSWITCH: ev.apply_key_switching(x); break;
+        case ORC_OP_NEGACYCLIC_SHIFT: ev.negacyclic_shift(x, (size_t)iarg); break;
         case ORC_OP_ADD_PLAIN: ev.add_plain(x, b, (size_t)iarg, bd ? bd->scale : 1.0, false); break;
         case ORC_OP_SUB_PLAIN: ev.add_plain(x, b, (size_t)iarg, bd ? bd->scale : 1.0, true); break;
         case ORC_OP_MULTIPLY_PLAIN: ev.multiply_plain_normal(x, b, (size_t)(iarg & 0xFFFFFFFF), (iarg >> 32) & 1); break; // bit 32: CUDA-evaluator semantics

@@ -30,7 +30,8 @@ enum { ORC_BFV = 1, ORC_CKKS = 2, ORC_BGV = 3 };
 enum { ORC_OP_ADD = 0, ORC_OP_SUB, ORC_OP_NEGATE, ORC_OP_MULTIPLY, ORC_OP_SQUARE, ORC_OP_RELIN,
        ORC_OP_MODSWITCH_NEXT, ORC_OP_RESCALE_NEXT, ORC_OP_APPLY_GALOIS, ORC_OP_ROTATE_ROWS,
        ORC_OP_ROTATE_COLUMNS, ORC_OP_ROTATE_VECTOR, ORC_OP_CONJUGATE, ORC_OP_TO_NTT, ORC_OP_FROM_NTT,
-       ORC_OP_MULTIPLY_PLAIN_NTT, ORC_OP_ADD_PLAIN, ORC_OP_SUB_PLAIN, ORC_OP_MULTIPLY_PLAIN };
+       ORC_OP_MULTIPLY_PLAIN_NTT, ORC_OP_ADD_PLAIN, ORC_OP_SUB_PLAIN, ORC_OP_MULTIPLY_PLAIN,
+       ORC_OP_APPLY_KEYSWITCH /* CUDA-only API: oracle only */, ORC_OP_NEGACYCLIC_SHIFT /* CUDA-only API: oracle only */ };
 enum { ORC_ST_FASTBCONV_MTILDE = 0, ORC_ST_SMMRQ, ORC_ST_FASTFLOOR, ORC_ST_FASTBCONV_SK,
        ORC_ST_DIVROUND_QLAST, ORC_ST_DIVROUND_QLAST_NTT, ORC_ST_MODT_DIV_QLAST };
 

@@ -348,3 +348,54 @@ def check_gpu_decrypt(cfg_name, batch=3):
                 for b in range(batch):
                     exp = orc.impl.decrypt(R.Ct(xs[b], ntt, 1.0, cf), sk)
                     assert np.array_equal(got[b].reshape(-1), exp), (limbs, size, cf, b)
+
+
+def check_api_compositions(cfg_name):
+    """applyKeySwitching, negacyclicShift (CUDA-only API of the reference, restated in the oracle from evaluator_cuda.cu) and
+    the host-level compositions multiplyMany / exponentiate / modSwitchTo in the reference's order of operations."""
+    cfg = CONFIGS[cfg_name]
+    B = 2
+    be = GpuBackend(cfg, batch=B)
+    orc = oracle_backend(cfg)
+    from oracle import ref as R
+    N, K = cfg["N"], len(be.primes)
+    L = K - 1
+    q = be.primes[:L]
+    key = synth.uniform_kswitch_key(55, be.primes, N)
+    be.rlk.set(0, key)
+    orc.impl.set_kswitch_key(0, key)
+    ntt = cfg["scheme"] == CKKS
+    xs = [synth.uniform_ct(60 + i, q, 2, N, B) for i in range(3)]
+    mk = lambda i: be.api.Ciphertext.from_numpy(be.ctx, xs[i], ntt, 1.0, 1, capacity=3)  # noqa: E731
+    ock = lambda i, b: R.Ct(xs[i][b], ntt)  # noqa: E731
+    # applyKeySwitching with a single-key KSwitchKeys object
+    ksk = be.api.KSwitchKeys(be.ctx)
+    ksk.set(0, key)
+    got = be.ev.applyKeySwitching(mk(0), ksk).cpu()
+    for b in range(B):
+        assert np.array_equal(got[b], orc.impl.eval(R.OP_APPLY_KEYSWITCH, ock(0, b)).data), b
+    # negacyclic shift
+    for shift in (0, 1, N // 2 + 3, N - 1):
+        got = be.ev.negacyclicShift(mk(1), shift).cpu()
+        for b in range(B):
+            assert np.array_equal(got[b], orc.impl.eval(R.OP_NEGACYCLIC_SHIFT, ock(1, b), iarg=shift).data), (shift, b)
+    if cfg["scheme"] == CKKS:
+        return
+    # multiplyMany over three ciphertexts = relin(relin(x0 x1) x2); exponentiate 3 = relin(relin(x x) x)
+    got = be.ev.multiplyMany([mk(0), mk(1), mk(2)], be.rlk).cpu()
+    for b in range(B):
+        e = orc.impl.eval(R.OP_RELIN, orc.impl.eval(R.OP_MULTIPLY, ock(0, b), ock(1, b)))
+        e = orc.impl.eval(R.OP_RELIN, orc.impl.eval(R.OP_MULTIPLY, e, ock(2, b)))
+        assert np.array_equal(got[b], e.data), b
+    got = be.ev.exponentiate(mk(0), 3, be.rlk).cpu()
+    for b in range(B):
+        e = orc.impl.eval(R.OP_RELIN, orc.impl.eval(R.OP_SQUARE, ock(0, b)))
+        e = orc.impl.eval(R.OP_RELIN, orc.impl.eval(R.OP_MULTIPLY, e, ock(0, b)))
+        assert np.array_equal(got[b], e.data), b
+    if L - 1 >= be.last_limbs:
+        got = be.ev.modSwitchTo(mk(0), be.last_limbs)
+        for b in range(B):
+            e = ock(0, b)
+            while e.limbs > be.last_limbs:
+                e = orc.impl.eval(R.OP_MODSWITCH_NEXT, e)
+            assert np.array_equal(got.cpu()[b], e.data), b

@@ -127,6 +127,20 @@ static void scenario(SchemeType scheme, size_t n, std::vector<int> bits, int tbi
         EXPECT(antt.toHost() == e.toHost(), "multiplyPlain NTT path == coefficient path (same limbs)");
     }
 
+    // exponentiate through multiplyMany (one level: the small test parameters have no noise budget for two)
+    {
+        Ciphertext c2 = b;
+        evaluator.exponentiateInplace(c2, 2, rlk);
+        decryptor.decrypt(c2, out);
+        EXPECT(out == Plaintext(negacyclic_mul(vb, vb, t)), "exponentiate(2)");
+        Ciphertext sh = a;
+        evaluator.negacyclicShiftInplace(sh, 5);
+        decryptor.decrypt(sh, out);
+        Poly x5(n, 0);
+        x5[5] = 1;
+        EXPECT(out == Plaintext(negacyclic_mul(x5, va, t)), "negacyclicShift(5) == times x^5");
+    }
+
     // mod switch keeps the plaintext
     Ciphertext d;
     evaluator.modSwitchToNext(c, d);

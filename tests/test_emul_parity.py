@@ -75,3 +75,8 @@ def test_emulated_dense_multiply(emul_api):
 @pytest.mark.parametrize("name", ["bfv_n128_k4", "bgv_n128_k4", "ckks_n128_k6"])
 def test_emulated_decrypt(name, emul_api):
     cases.check_gpu_decrypt(name, batch=2)
+
+
+@pytest.mark.parametrize("name", ["bfv_n128_k4", "bgv_n128_k4", "ckks_n128_k6"])
+def test_emulated_api_compositions(name, emul_api):
+    cases.check_api_compositions(name)

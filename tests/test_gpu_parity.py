@@ -348,3 +348,9 @@ def test_gpu_decrypt_end_to_end(gpu):
     got = ev.decrypt(r, gpu.DeviceBuffer.from_numpy(kg.secretKey()))
     for i in range(B):
         assert np.array_equal(got[i], negacyclic_mul(m2[i], m1[i], t)), i  # sparse operand first: 9 x 4096 terms
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["bfv_n128_k4", "bgv_n128_k4", "ckks_n128_k6", "cfgA_bfv_n4096_k3", "ckks_n4096_k4"])
+def test_api_compositions(name, gpu):
+    cases.check_api_compositions(name)

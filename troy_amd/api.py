@@ -344,10 +344,109 @@ class Evaluator:
         self.relinearizeInplace(r, relin_keys)
         return r
 
-    def applyKeySwitchingInplace(self, a, kswitch_keys, index=0):
-        """switchKeyInplace(a, a[1], keys[index]) after zeroing nothing: the reference's applyKeySwitchingInplace
-        (evaluator_cuda.cu:1365-1378) switches poly 1 of a size-2 ciphertext to a new key."""
-        raise NotImplementedError
+    def applyKeySwitchingInplace(self, a, kswitch_keys):
+        """applyKeySwitchingInplace (evaluator_cuda.cu:1365-1378): kswitch_keys must hold exactly one key; c1 of a size-2
+        ciphertext is switched to it."""
+        if len(kswitch_keys.keys) != 1:
+            raise capi.InvalidArgument(capi.INVALID_ARGUMENT, "kswitch_keys.data().size() != 1")
+        key = next(iter(kswitch_keys.keys.values()))
+        st = a.struct()
+        self._chk(self.lib.troyhip_apply_key_switching(self.context.h, C.byref(st), C.c_void_p(key.ptr), C.c_uint64(a.batch), self.stream))
+        a._absorb(st)
+
+    def applyKeySwitching(self, a, kswitch_keys):
+        r = a.copy()
+        self.applyKeySwitchingInplace(r, kswitch_keys)
+        return r
+
+    def negacyclicShiftInplace(self, a, shift):  # evaluator_cuda.cu:2342-2351
+        st = a.struct()
+        self._chk(self.lib.troyhip_negacyclic_shift(self.context.h, C.byref(st), C.c_uint64(shift), C.c_uint64(a.batch), self.stream))
+        a._absorb(st)
+
+    def negacyclicShift(self, a, shift):
+        r = a.copy()
+        self.negacyclicShiftInplace(r, shift)
+        return r
+
+    # -- compositions, in the reference's order of operations (src/evaluator.cpp)
+    def addMany(self, cts):  # evaluator.cpp addMany: left fold
+        if not cts:
+            raise capi.InvalidArgument(capi.INVALID_ARGUMENT, "encrypteds cannot be empty")
+        r = cts[0].copy()
+        for c in cts[1:]:
+            r = self.add(r, c) if c.size() > r.capacity else (self.addInplace(r, c) or r)
+        return r
+
+    def multiplyMany(self, cts, relin_keys):
+        """evaluator.cpp:1502-1572: pairwise products are appended to the work list until one ciphertext is left; every
+        product is relinearized (BFV / BGV only)."""
+        if not cts:
+            raise capi.InvalidArgument(capi.INVALID_ARGUMENT, "encrypteds vector must not be empty")
+        if self.context.scheme not in (BFV, BGV):
+            raise capi.LogicError(capi.LOGIC_ERROR, "unsupported scheme")
+        if len(cts) == 1:
+            return cts[0].copy()
+        work = []
+        for i in range(0, len(cts) - 1, 2):
+            t = self.multiply(cts[i], cts[i + 1])
+            self.relinearizeInplace(t, relin_keys)
+            work.append(t)
+        if len(cts) & 1:
+            work.append(cts[-1])
+        i = 0
+        while i < len(work) - 1:
+            t = self.multiply(work[i], work[i + 1])
+            self.relinearizeInplace(t, relin_keys)
+            work.append(t)
+            i += 2
+        return work[-1]
+
+    def exponentiate(self, a, exponent, relin_keys):  # evaluator.cpp:1574-1601
+        if exponent == 0:
+            raise capi.InvalidArgument(capi.INVALID_ARGUMENT, "exponent cannot be 0")
+        if exponent == 1:
+            return a.copy()
+        return self.multiplyMany([a] * int(exponent), relin_keys)
+
+    def exponentiateInplace(self, a, exponent, relin_keys):
+        a.__dict__.update(self.exponentiate(a, exponent, relin_keys).__dict__)
+
+    def modSwitchTo(self, a, limbs):
+        """modSwitchTo(encrypted, parms_id): parms_id is named by its limb count here."""
+        if limbs > a.limbs:
+            raise capi.InvalidArgument(capi.INVALID_ARGUMENT, "cannot switch to higher level modulus")
+        r = a
+        while r.limbs > limbs:
+            r = self.modSwitchToNext(r)
+        return r.copy() if r is a else r
+
+    def modSwitchToInplace(self, a, limbs):
+        a.__dict__.update(self.modSwitchTo(a, limbs).__dict__)
+
+    def rescaleTo(self, a, limbs):
+        if limbs > a.limbs:
+            raise capi.InvalidArgument(capi.INVALID_ARGUMENT, "cannot switch to higher level modulus")
+        r = a
+        while r.limbs > limbs:
+            r = self.rescaleToNext(r)
+        return r.copy() if r is a else r
+
+    def rescaleToInplace(self, a, limbs):
+        a.__dict__.update(self.rescaleTo(a, limbs).__dict__)
+
+    def _copy_then(self, fn, a, *args):
+        r = a.copy()
+        fn(r, *args)
+        return r
+
+    def applyGalois(self, a, galois_elt, galois_keys): return self._copy_then(self.applyGaloisInplace, a, galois_elt, galois_keys)
+    def rotateRows(self, a, steps, galois_keys): return self._copy_then(self.rotateRowsInplace, a, steps, galois_keys)
+    def rotateColumns(self, a, galois_keys): return self._copy_then(self.rotateColumnsInplace, a, galois_keys)
+    def rotateVector(self, a, steps, galois_keys): return self._copy_then(self.rotateVectorInplace, a, steps, galois_keys)
+    def complexConjugate(self, a, galois_keys): return self._copy_then(self.complexConjugateInplace, a, galois_keys)
+    def transformToNtt(self, a): return self._copy_then(self.transformToNttInplace, a)
+    def transformFromNtt(self, a): return self._copy_then(self.transformFromNttInplace, a)
 
     def applyGaloisInplace(self, a, galois_elt, galois_keys):
         idx = GaloisKeys.getIndex(galois_elt)

@@ -301,6 +301,12 @@ int troyhip_plain_to_ntt(troyhip_context *ctx, const uint64_t *plain, uint64_t p
                          uint64_t count, void *stream) {
     return guard([&] { ctx->ev.plain_to_ntt(plain, plain_coeff_count, plain_batch_stride, limbs, out, count, (hipStream_t)stream); });
 }
+int troyhip_apply_key_switching(troyhip_context *ctx, troyhip_ct *ct, const uint64_t *kswitch_key, uint64_t batch, void *stream) {
+    return guard([&] { CtBatch x = view(ct); ctx->ev.apply_key_switching(x, KsKey{kswitch_key}, batch, (hipStream_t)stream); store(x, ct); });
+}
+int troyhip_negacyclic_shift(troyhip_context *ctx, troyhip_ct *ct, uint64_t shift, uint64_t batch, void *stream) {
+    return guard([&] { CtBatch x = view(ct); ctx->ev.negacyclic_shift(x, shift, batch, (hipStream_t)stream); store(x, ct); });
+}
 int troyhip_decrypt(troyhip_context *ctx, const troyhip_ct *ct, const uint64_t *secret_key, uint64_t *plain_out, uint64_t plain_batch_stride, uint64_t batch,
                     void *stream) {
     return guard([&] { CtBatch x = view(ct); ctx->ev.decrypt(x, secret_key, plain_out, plain_batch_stride, batch, (hipStream_t)stream); });

@@ -529,6 +529,34 @@ void Evaluator::multiply_plain(CtBatch &ct, const u64 *plain, u64 n_coeffs, u64 
     transform_from_ntt(ct, batch, s);
 }
 
+// applyKeySwitchingInplace (evaluator_cuda.cu:1365-1378): c1 is the target, c1 := 0, switch with the given key
+void Evaluator::apply_key_switching(CtBatch &ct, const KsKey &key, u64 batch, hipStream_t s) {
+    check_ct(ct);
+    if (!key.data) throw Error(ST_INVALID_ARGUMENT, "kswitch_keys.data().size() != 1");
+    if (ct.size != 2) throw Error(ST_INVALID_ARGUMENT, "encrypted.size() != 2");
+    const u64 pw = poly_words(c, ct.limbs);
+    c.arena.reset();
+    const size_t ks = scratch_switch_key(ct.limbs, batch);
+    c.arena.reserve(ks + batch * pw + 128);
+    (void)c.arena.take(ks);
+    u64 *target = c.arena.take(batch * pw); // beyond switch_key's own working set, like apply_galois
+    launch_copy_strided(ct.data + pw, ct.bstride, target, pw, pw, batch, s);
+    launch_zero_strided(ct.data + pw, ct.bstride, pw, batch, s);
+    switch_key(ct, target, pw, key, batch, s);
+}
+// negacyclicShift (evaluator_cuda.cu:2342-2351): every limb of every polynomial is multiplied by x^shift
+void Evaluator::negacyclic_shift(CtBatch &ct, u64 shift, u64 batch, hipStream_t s) {
+    check_ct(ct);
+    if (shift >= c.N) throw Error(ST_INVALID_ARGUMENT, "shift");
+    if (shift == 0) return;
+    const u64 words = (u64)ct.size * poly_words(c, ct.limbs);
+    c.arena.reset();
+    c.arena.reserve(batch * words);
+    u64 *tmp = c.arena.take(batch * words);
+    launch_copy_strided(ct.data, ct.bstride, tmp, words, words, batch, s);
+    launch_negacyclic_shift(tmp, words, ct.data, ct.bstride, c.d_desc, c.ct_map(ct.limbs), c.logn, shift, (u64)ct.size * ct.limbs, ct.limbs, batch, s);
+}
+
 // ---- decryption ----
 void Evaluator::decrypt(const CtBatch &ct, const u64 *sk, u64 *out, u64 out_bstride, u64 batch, hipStream_t s) {
     check_ct(ct);

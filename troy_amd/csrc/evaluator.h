@@ -38,6 +38,9 @@ public:
     // DecryptorCuda::decrypt (decryptor_cuda.cu:61-330): sk [K][N] NTT form (device); out: BFV/BGV N coefficients mod t per item
     // (stride out_bstride), CKKS the RNS plaintext [limbs][N] (NTT form)
     void decrypt(const CtBatch &ct, const u64 *sk, u64 *out, u64 out_bstride, u64 batch, hipStream_t s);
+    // applyKeySwitchingInplace (evaluator_cuda.cu:1365-1378) and negacyclicShift (evaluator_cuda.cu:2342-2351)
+    void apply_key_switching(CtBatch &ct, const KsKey &key, u64 batch, hipStream_t s);
+    void negacyclic_shift(CtBatch &ct, u64 shift, u64 batch, hipStream_t s);
     void plain_to_ntt(const u64 *plain, u64 n_coeffs, u64 plain_bstride, int limbs, u64 *out, u64 count, hipStream_t s);
     void negate(CtBatch &a, u64 batch, hipStream_t s);
     // out may alias a or b; out.size/limbs/... are set; out.data/out.bstride are the caller's

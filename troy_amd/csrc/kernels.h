@@ -101,6 +101,8 @@ void launch_dot_sk(const u64 *x, const u64 *spow, u64 *acc, const DecryptArgs &a
 // acc[b][l][n] += c0 of ciphertext b
 void launch_add_c0(const u64 *ct, u64 *acc, const DecryptArgs &a, hipStream_t s);
 void launch_decrypt_final(int scheme, const u64 *acc, u64 *out, const DecryptArgs &a, hipStream_t s);
+void launch_negacyclic_shift(const u64 *in, u64 in_bstride, u64 *out, u64 out_bstride, const PrimeDesc *primes, const LimbMap &map, int logn, u64 shift, u64 rows_per_item,
+                             u64 limbs, u64 batch, hipStream_t s);
 void launch_copy_strided(const u64 *src, u64 src_bstride, u64 *dst, u64 dst_bstride, u64 count, u64 batch, hipStream_t s);
 void launch_zero_strided(u64 *dst, u64 dst_bstride, u64 count, u64 batch, hipStream_t s);
 void launch_fill_uniform(u64 *out, const PrimeDesc *primes, const LimbMap &map, int logn, u64 seed, u64 row0, u64 rows, hipStream_t s);

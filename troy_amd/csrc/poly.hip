@@ -242,6 +242,27 @@ __global__ __launch_bounds__(EW_THREADS) void galois_coeff_kernel(const u64 *in,
     if ((raw >> logn) & 1) v = negmod(v, p);
     out[b * out_bstride + (l << logn) + idx] = v;
 }
+// kNegacyclicShiftPolyCoeffmod (kernelutils.cu; CPU polyarithsmallmod.cpp:128-152): out[(i + shift) mod N] = +-in[i]
+__global__ __launch_bounds__(EW_THREADS) void negacyclic_shift_kernel(const u64 *in, u64 in_bstride, u64 *out, u64 out_bstride, const PrimeDesc *primes, LimbMap map, int logn,
+                                                                      u64 shift, u64 rows_per_item, u64 limbs, u64 total) {
+    u64 i = (u64)blockIdx.x * EW_THREADS + threadIdx.x;
+    if (i >= total) return;
+    const u64 N = u64(1) << logn;
+    u64 row = i >> logn, n = i & (N - 1), b = row / rows_per_item, r = row % rows_per_item;
+    const u64 p = primes[map.id[r % limbs]].p;
+    const u64 raw = n + shift, idx = raw & (N - 1);
+    u64 v = in[b * in_bstride + (r << logn) + n];
+    if ((raw & N) && v) v = p - v;
+    out[b * out_bstride + (r << logn) + idx] = v;
+}
+void launch_negacyclic_shift(const u64 *in, u64 in_bstride, u64 *out, u64 out_bstride, const PrimeDesc *primes, const LimbMap &map, int logn, u64 shift, u64 rows_per_item,
+                             u64 limbs, u64 batch, hipStream_t s) {
+    u64 total = (batch * rows_per_item) << logn;
+    if (!total) return;
+    TROY_LAUNCH(negacyclic_shift_kernel, dim3(ceil_div(total, EW_THREADS)), dim3(EW_THREADS), 0, s, in, in_bstride, out, out_bstride, primes, map, logn, shift, rows_per_item,
+                limbs, total);
+    launch_check("negacyclic_shift_kernel");
+}
 // NTT form: out[i] = in[bitrev(((g * bitrev(i + N, logN+1)) >> 1) mod N, logN)]   (galois.cpp:18-35)
 __global__ __launch_bounds__(EW_THREADS) void galois_ntt_kernel(const u64 *in, u64 in_bstride, u64 *out, u64 out_bstride, int logn, uint32_t elt, u64 limbs, u64 total) {
     u64 i = (u64)blockIdx.x * EW_THREADS + threadIdx.x;
