@@ -153,7 +153,6 @@ void Evaluator::multiply(const CtBatch &a, const CtBatch &b, CtBatch &out, u64 b
     double new_scale = a.scale;
     u64 new_cf = a.cf;
     const bool same = (a.data == b.data && a.bstride == b.bstride && sa == sb);
-    (void)same;
 
     if (c.scheme == SCHEME_BFV) {
         if (a.ntt || b.ntt) throw Error(ST_INVALID_ARGUMENT, "encrypted1 or encrypted2 cannot be in NTT form");
@@ -168,10 +167,13 @@ void Evaluator::multiply(const CtBatch &a, const CtBatch &b, CtBatch &out, u64 b
         if (a.bstride == (u64)sa * pw && b.bstride == (u64)sb * pw) {
             // dense operands are consumed in place: the extension reads them directly and the first NTT pass reads them
             // as its out-of-place source, so no staging copy is made.  Scratch layout: [a-part | b-part] in each base.
-            u64 *xq_a = xq, *xq_b = xq + batch * sa * pw, *xb_a = xb, *xb_b = xb + batch * sa * bw;
+            // squaring (same operand twice): extended and transformed once, the tensor reads it as both factors
+            const bool fused = sa == 2 && sb == 2 && ntt2_tensor_supported(c.logn) && tensor_fused();
+            const bool once = same && fused;
+            u64 *xq_a = xq, *xq_b = once ? xq : xq + batch * sa * pw, *xb_a = xb, *xb_b = once ? xb : xb + batch * sa * bw;
             launch_behz_extend(a.data, pw, xb_a, bw, c.d_desc, *lv.behz, N, batch * sa, s);
-            launch_behz_extend(b.data, pw, xb_b, bw, c.d_desc, *lv.behz, N, batch * sb, s);
-            if (sa == 2 && sb == 2 && ntt2_tensor_supported(c.logn) && tensor_fused()) {
+            if (!once) launch_behz_extend(b.data, pw, xb_b, bw, c.d_desc, *lv.behz, N, batch * sb, s);
+            if (fused) {
                 // (3)+(4) in one pass pair per base: the second NTT pass keeps a0, a1, b0, b1 in registers and stores d0, d1, d2
                 launch_ntt2_tensor(xq_a, a.data, xq_b, b.data, dq, c.d_desc, qmap, batch, c.logn, s);
                 launch_ntt2_tensor(xb_a, nullptr, xb_b, nullptr, db, c.d_desc, bmap, batch, c.logn, s);

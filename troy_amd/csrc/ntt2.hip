@@ -726,7 +726,8 @@ void launch_ntt2_tensor(u64 *xa, const u64 *src_a, u64 *xb, const u64 *src_b, u6
     if (!batch) return;
     if (!ntt2_tensor_supported(logn) || map.inner != 1) throw Error(ST_LOGIC_ERROR, "ntt2 tensor: unsupported shape");
     const int k1 = logn - 9;
-    for (int part = 0; part < 2; part++) { // first pass of both operands (rows = batch * 2 * limbs each)
+    const bool same = xa == xb; // squaring: one operand, transformed once
+    for (int part = 0; part < (same ? 1 : 2); part++) { // first pass of both operands (rows = batch * 2 * limbs each)
         Ntt2Args a;
         std::memset(&a, 0, sizeof(a));
         a.data = part ? xb : xa;
