@@ -11,10 +11,15 @@
 //   * the first round reads its 8 points per thread straight from HBM and the last round writes straight back
 //     (no staging pass through LDS); between rounds the tile is exchanged through LDS with an XOR swizzle
 //     addr = f ^ ((f>>3)&7) ^ (((f>>6)&3)<<3) that is bank-conflict-free for every butterfly distance;
-//   * LDS is double-buffered across rows: 2 barriers per row instead of one per stage;
-//   * the strided pass can read its input from another buffer and Barrett-reduce it modulo the row's prime on the
-//     fly: the digit decomposition of key switching (evaluator.cpp:2432-2442, the reference's kModuloPolyCoeffs +
-//     copy per (i,j)) costs no kernel and no HBM round trip of the (L+1)*L expanded limbs.
+//   * strided passes double-buffer the LDS exchange across rows (2 barriers per row instead of one per stage); contiguous
+//     passes need no workgroup barrier at all (every 512-point sub-transform stays in one wave) and stream the next row
+//     into a staging area with LDS-DMA (global_load_lds_dwordx4) while the current one is transformed;
+//   * the strided pass can read its input from another buffer: either the same rows of another allocation (operands are
+//     consumed in place) or the digit decomposition of key switching (evaluator.cpp:2432-2442, the reference's
+//     kModuloPolyCoeffs + copy per (i,j)), Barrett-reducing limb k modulo the row's prime on the fly;
+//   * the last forward pass has two fused epilogues (2 waves per SIMD): MAC = 1 accumulates the transforms of the L digits
+//     against the key-switching key (the expanded digits are never stored transformed), MAC = 2 keeps (a0, a1, b0, b1) and
+//     stores the BEHZ ciphertext tensor.
 #include "kernels.h"
 #include "bfly.h"
 #include <cstdlib>
@@ -30,9 +35,6 @@ namespace troyhip {
 #endif
 #ifndef N2_MIN_WAVES
 #define N2_MIN_WAVES 4
-#endif
-#ifndef N2_PREFETCH
-#define N2_PREFETCH 0
 #endif
 #ifndef N2_MAC_WAVES
 #define N2_MAC_WAVES 2 // waves per SIMD of the key-switch fused kernel (16 x 128-bit accumulators per thread)
@@ -472,7 +474,7 @@ __global__ __launch_bounds__(N2_THREADS, MAC ? N2_MAC_WAVES : N2_MIN_WAVES) void
                 for (int e = 0; e < 4; e++) macc[cpt][g][e] = Acc128{0, 0, 0, 0};
     }
     u64 *const wave_stage = lds[1] + 512 * (threadIdx.x >> 6);
-    u64 x[8], nx[8];
+    u64 x[8];
     {
         u64 *row0; const u64 *in0;
         row_ptrs(m_begin, row0, in0);
@@ -502,11 +504,6 @@ __global__ __launch_bounds__(N2_THREADS, MAC ? N2_MAC_WAVES : N2_MIN_WAVES) void
 #pragma unroll
                 for (int e = 0; e < 4; e++) kv[cpt][MAC == 1 ? e : 0] = kq[e];
             }
-        }
-        if (!DMA && N2_PREFETCH && mm + 1 < m_end) {
-            u64 *nrow; const u64 *nin;
-            row_ptrs(mm + 1, nrow, nin);
-            Rd0::template g_read<REDUCE>(nx, nin, tile, logn, m);
         }
         u64 *buf = DMA ? lds[0] : lds[mm & 1];
         if (REDUCE) {
@@ -575,14 +572,12 @@ __global__ __launch_bounds__(N2_THREADS, MAC ? N2_MAC_WAVES : N2_MIN_WAVES) void
                 }
             }
         }
-        if constexpr (DMA) {
-        } else if (N2_PREFETCH) {
-#pragma unroll
-            for (int e = 0; e < 8; e++) x[e] = nx[e];
-        } else if (mm + 1 < m_end) {
-            u64 *nrow; const u64 *nin;
-            row_ptrs(mm + 1, nrow, nin);
-            Rd0::template g_read<REDUCE>(x, nin, tile, logn, m);
+        if constexpr (!DMA) {
+            if (mm + 1 < m_end) {
+                u64 *nrow; const u64 *nin;
+                row_ptrs(mm + 1, nrow, nin);
+                Rd0::template g_read<REDUCE>(x, nin, tile, logn, m);
+            }
         }
     }
     if constexpr (MAC == 1) { // one reduction per output coefficient; acc[o][c][slot][N]
