@@ -238,6 +238,9 @@ def main():
                     "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                     "algorithmic_bytes_per_launch": algo_bytes, "launch_us": round(per_launch_s * 1e6, 2),
                     "limb_transforms_per_launch": rows}
+        if traffic:  # the two passes' REAL HBM traffic (PMC) over the same live launch time: what rocprof shows the memory system doing
+            roofline["hbm_traffic_gbps"] = round(traffic / per_launch_s / 1e9, 1)
+            roofline["hbm_traffic_frac"] = round(traffic / per_launch_s / 1e9 / HBM_PEAK_GBPS, 4)
         del D
 
     # ---- CPU baseline on this box's host cores (rank 0, N=1 only) ----
