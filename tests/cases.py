@@ -399,3 +399,32 @@ def check_api_compositions(cfg_name):
             while e.limbs > be.last_limbs:
                 e = orc.impl.eval(R.OP_MODSWITCH_NEXT, e)
             assert np.array_equal(got.cpu()[b], e.data), b
+
+
+def check_ckks_matmul_helper(N=4096, bits=(40, 30, 30, 40), batch=3, dims=(128, 128), seed=7):
+    """BASELINE config E through the reference's app API (app/LinearHelperCKKS.cuh MatmulHelper, troy_amd/app.py): encrypted
+    [batch x in] times plaintext [in x out], decrypted on the device; floating point: |error| < 1e-3 at scale 2^22 x 2^22."""
+    from troy_amd import api, app, capi
+    primes = api.CoeffModulus.Create(N, list(bits))
+    ctx = api.SEALContext(capi.CKKS, N, primes, 0)
+    kg = api.KeyGenerator(ctx, seed=(31, 32))
+    enc = api.Encryptor(ctx, kg.createPublicKey())
+    ev = api.Evaluator(ctx)
+    encoder = app.CKKSPolyEncoder(ctx)
+    L = len(primes) - 1
+    rng = np.random.default_rng(seed)
+    # encode / decode round trip, including negative and half-way values
+    v = rng.uniform(-4, 4, N)
+    v[:4] = [0.5, -0.5, 1.5, -2.5]
+    back = encoder.decodePolynomial(encoder.encodePolynomial(v, L, 2.0 ** 22), 2.0 ** 22)
+    assert np.max(np.abs(back - v)) < 2.0 ** -22
+    I, J = dims
+    X = rng.uniform(-1, 1, (batch, I))
+    W = rng.uniform(-1, 1, (I, J))
+    h = app.MatmulHelper(batch, I, J, N // 2)
+    assert h.blockHeight * h.blockWidth <= N and h.blockHeight >= 1
+    h.encodeWeights(encoder, L, W, 2.0 ** 22)
+    a = h.encryptInputs(enc, encoder, L, X, 2.0 ** 22)
+    out = h.matmul(ev, a)
+    got = h.decryptOutputs(ev, encoder, api.DeviceBuffer.from_numpy(kg.secretKey()), out)
+    assert np.max(np.abs(got - X @ W)) < 1e-3, np.max(np.abs(got - X @ W))

@@ -80,3 +80,7 @@ def test_emulated_decrypt(name, emul_api):
 @pytest.mark.parametrize("name", ["bfv_n128_k4", "bgv_n128_k4", "ckks_n128_k6"])
 def test_emulated_api_compositions(name, emul_api):
     cases.check_api_compositions(name)
+
+
+def test_emulated_ckks_matmul_helper(emul_api):
+    cases.check_ckks_matmul_helper(N=256, bits=(40, 30, 30, 40), batch=2, dims=(24, 20))

@@ -355,3 +355,8 @@ def test_gpu_decrypt_end_to_end(gpu):
 @pytest.mark.parametrize("name", ["bfv_n128_k4", "bgv_n128_k4", "ckks_n128_k6", "cfgA_bfv_n4096_k3", "ckks_n4096_k4"])
 def test_api_compositions(name, gpu):
     cases.check_api_compositions(name)
+
+
+@pytest.mark.gpu
+def test_cfgE_matmul_helper_128x128(gpu):
+    cases.check_ckks_matmul_helper()
