@@ -70,6 +70,7 @@ def main():
     ap.add_argument("--streams", type=int, default=1, help="split the batch over this many HIP streams (one context each): kernels of different phases overlap")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--ntt-reps", type=int, default=10)
+    ap.add_argument("--roofline-only", action="store_true", help="skip the timed steps: only the roofline NTT launches run (for the rocprofv3 summary of exactly that kernel)")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed even for one rank (tests the RCCL path)")
     args = ap.parse_args()
 
@@ -182,6 +183,8 @@ def main():
             _dist().barrier()
         sync_all()
 
+    if args.roofline_only:
+        args.steps = args.warmup = 0
     for _ in range(args.warmup):
         step()
     barrier()
@@ -189,7 +192,7 @@ def main():
     for _ in range(args.steps):
         step()
     sync_all()
-    dt = time.perf_counter() - t0
+    dt = max(time.perf_counter() - t0, 1e-9)
     barrier()
     if use_dist:
         dt = max_over_ranks(dt, backend)
@@ -256,7 +259,7 @@ def main():
         line = {
             "metric": "ct x ct multiply+relinearize ops/sec, BFV N=2^15 L=14; achieved HBM GB/s vs peak",
             "value": round(value, 2), "unit": "ops/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(dt / args.steps * 1e3, 3) if args.steps else None, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u64", "data": "synthetic",
             "config": {"workload": args.workload, "scheme": "BFV", "N": N, "K": K, "L": L, "Bsk": nbsk, "batch_per_gpu": B,
                        "limb_transforms_per_op": limb_transforms, "parallelism": f"batch-shard x{world}", "streams_per_gpu": S, "rendezvous": backend},
