@@ -157,8 +157,10 @@ int troyhip_plain_to_ntt(troyhip_context *ctx, const uint64_t *plain, uint64_t p
                          uint64_t count, void *stream);
 /* applyKeySwitchingInplace (src/evaluator_cuda.cu:1365-1378): size-2 ciphertext, c1 is switched to the key `kswitch_key` */
 int troyhip_apply_key_switching(troyhip_context *ctx, troyhip_ct *ct, const uint64_t *kswitch_key, uint64_t batch, void *stream);
-/* negacyclicShiftInplace (src/evaluator_cuda.cu:2342-2351): every polynomial times x^shift, 0 <= shift < N */
+/* negacyclicShiftInplace (src/evaluator_cuda.cu:2342-2351): every polynomial times x^shift, 0 <= shift < 2N (x^N = -1) */
 int troyhip_negacyclic_shift(troyhip_context *ctx, troyhip_ct *ct, uint64_t shift, uint64_t batch, void *stream);
+/* divideByPolyModulusDegreeInplace (src/evaluator_cuda.cu:2259-2273): every limb times N^-1 * mul modulo its prime (LWE packing) */
+int troyhip_divide_by_poly_modulus_degree(troyhip_context *ctx, troyhip_ct *ct, uint64_t mul, uint64_t batch, void *stream);
 /* ---- DecryptorCuda::decrypt (src/decryptor_cuda.cu:61-330; dotProductCtSkArray + decryptScaleAndRound / decryptModt,
  * src/utils/rns_cuda.cu:510-621), SURVEY 8-f3.  secret_key: device [K][N] (NTT form, src/secretkey.h).  plain_out (device):
  * BFV/BGV N coefficients mod t per item, items plain_batch_stride words apart; CKKS the RNS plaintext [limbs][N] (NTT form). */

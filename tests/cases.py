@@ -428,3 +428,42 @@ def check_ckks_matmul_helper(N=4096, bits=(40, 30, 30, 40), batch=3, dims=(128, 
     out = h.matmul(ev, a)
     got = h.decryptOutputs(ev, encoder, api.DeviceBuffer.from_numpy(kg.secretKey()), out)
     assert np.max(np.abs(got - X @ W)) < 1e-3, np.max(np.abs(got - X @ W))
+
+
+def check_lwe_pack(scheme=BFV, N=256, bits=(40, 40, 40, 40), tbits=14, n_lwe=5, batch=2):
+    """extractLWE / assembleLWE / packLWECiphertexts (CUDA-only API of the reference; verified by decryption): coefficient
+    `term` of a fresh encryption is extracted as an LWE sample and n of them are packed back into one ciphertext whose
+    coefficients j * N / n' hold the n messages (BFV/BGV: exactly; the factor N^-1 is applied by the packing)."""
+    from troy_amd import api
+    primes = api.CoeffModulus.Create(N, list(bits))
+    t = api.PlainModulus.Batching(N, tbits)
+    ctx = api.SEALContext(scheme, N, primes, t)
+    kg = api.KeyGenerator(ctx, seed=(41, 42))
+    enc = api.Encryptor(ctx, kg.createPublicKey())
+    dec = api.Decryptor(ctx, kg.secretKey())
+    ev = api.Evaluator(ctx)
+    gk = api.GaloisKeys(ctx)
+    l = 0
+    while (1 << l) < n_lwe:
+        l += 1
+    elts = sorted({(1 << k) + 1 for k in range(1, l + 1)} | {d + 1 for d in [N >> k for k in range(0, 20)] if d > (1 << l)})
+    for e, key in kg.createGaloisKeys(elts).items():
+        gk.set_elt(e, key)
+    rng = np.random.default_rng(5)
+    msgs = rng.integers(0, t, (n_lwe, batch, N), dtype=np.uint64)
+    terms = [int(x) for x in rng.integers(0, N, n_lwe)]
+    lwes = []
+    for i in range(n_lwe):
+        ct = api.Ciphertext.from_numpy(ctx, np.stack([enc.encrypt(msgs[i][b]) for b in range(batch)]), capacity=3)
+        lwe = ev.extractLWE(ct, terms[i])
+        # assemble back at term 0: coefficient 0 must decrypt to the extracted message
+        back = ev.assembleLWE(lwe, 0).cpu()
+        for b in range(batch):
+            assert dec.decrypt(back[b])[0] == msgs[i][b][terms[i]], (i, b)
+        lwes.append(lwe)
+    packed = ev.packLWECiphertexts(lwes, gk).cpu()
+    step = N >> l
+    for b in range(batch):
+        pt = dec.decrypt(packed[b])
+        for i in range(n_lwe):
+            assert pt[i * step] == msgs[i][b][terms[i]], (i, b, int(pt[i * step]), int(msgs[i][b][terms[i]]))

@@ -84,3 +84,7 @@ def test_emulated_api_compositions(name, emul_api):
 
 def test_emulated_ckks_matmul_helper(emul_api):
     cases.check_ckks_matmul_helper(N=256, bits=(40, 30, 30, 40), batch=2, dims=(24, 20))
+
+
+def test_emulated_lwe_pack(emul_api):
+    cases.check_lwe_pack(N=64, bits=(40, 40, 40, 40), tbits=10, n_lwe=3, batch=1)

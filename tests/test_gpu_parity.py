@@ -360,3 +360,9 @@ def test_api_compositions(name, gpu):
 @pytest.mark.gpu
 def test_cfgE_matmul_helper_128x128(gpu):
     cases.check_ckks_matmul_helper()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scheme", [1, 3])
+def test_lwe_extract_and_pack(scheme, gpu):
+    cases.check_lwe_pack(scheme=scheme)

@@ -186,6 +186,10 @@ class Ciphertext:
             data = full
         return cls(context, B, size, limbs, is_ntt_form, scale, correction_factor, cap, DeviceBuffer.from_numpy(data))
 
+    def cpu_poly_view(self):
+        """host copy [batch][size][limbs][N] (alias of cpu(), named for the LWE helpers)"""
+        return self.cpu()
+
     def cpu(self):  # CiphertextCuda::cpu / toHost
         n = self.batch * self.capacity * self.limbs * self.context.N
         a = self.buf.to_numpy(n).reshape(self.batch, self.capacity, self.limbs, self.context.N)
@@ -216,6 +220,14 @@ class Ciphertext:
 
     def copy(self):  # deep device copy (src/utils/devicearray.cuh:153-164)
         return Ciphertext(self.context, self.batch, self._size, self.limbs, self.is_ntt_form, self.scale, self.correction_factor, self.capacity, self.buf.copy())
+
+
+class LWECiphertext:
+    """LWECiphertextCuda (src/ciphertext_cuda.cuh): c1 = one polynomial per item (a size-1 batched Ciphertext, coefficient
+    form), c0 = one residue per limb per item (numpy [batch][limbs])."""
+
+    def __init__(self, c1, c0):
+        self.c1, self.c0 = c1, np.ascontiguousarray(c0, dtype=np.uint64)
 
 
 class KSwitchKeys:
@@ -434,6 +446,85 @@ class Evaluator:
 
     def rescaleToInplace(self, a, limbs):
         a.__dict__.update(self.rescaleTo(a, limbs).__dict__)
+
+    # ---- LWE extraction / packing (evaluator_cuda.cu:2178-2340; CUDA-only API of the reference).  Host-level compositions of
+    # negacyclicShift, add / sub, applyGalois and a per-limb scalar multiply; the batch dimension is carried through.
+    def divideByPolyModulusDegreeInplace(self, a, mul=1):
+        st = a.struct()
+        self._chk(self.lib.troyhip_divide_by_poly_modulus_degree(self.context.h, C.byref(st), C.c_uint64(mul), C.c_uint64(a.batch), self.stream))
+        a._absorb(st)
+
+    def extractLWE(self, a, term):
+        """LWE sample of coefficient `term`: c1 = x^(2N - term) * c1(x) (so that its constant-term inner product with the key is
+        coefficient `term` of c1 * s), c0 = coefficient `term` of c0(x)."""
+        if a.size() != 2:
+            raise capi.InvalidArgument(capi.INVALID_ARGUMENT, "Encrypted size must be 2 to be extracted.")
+        if a.is_ntt_form:
+            a = self.transformFromNtt(a)
+        N, L, B = self.context.N, a.limbs, a.batch
+        x = a.cpu_poly_view()
+        c1 = Ciphertext.from_numpy(a.context, x[:, 1:2], False, a.scale, a.correction_factor)
+        self.negacyclicShiftInplace(c1, 0 if term == 0 else 2 * N - term)
+        c0 = np.ascontiguousarray(x[:, 0, :, term])
+        return LWECiphertext(c1, c0)
+
+    def assembleLWE(self, lwe, term):
+        """RLWE ciphertext whose coefficient `term` decrypts to the LWE message (the other coefficients are noise-like)"""
+        c1 = lwe.c1.copy()
+        self.negacyclicShiftInplace(c1, term)
+        B, L, N = c1.batch, c1.limbs, self.context.N
+        data = np.zeros((B, 2, L, N), dtype=np.uint64)
+        data[:, 1] = c1.cpu()[:, 0]
+        data[:, 0, :, term] = lwe.c0
+        return Ciphertext.from_numpy(c1.context, data, False, c1.scale, c1.correction_factor, capacity=3)
+
+    def fieldTraceInplace(self, a, galois_keys, logn):
+        degree = self.context.N
+        while degree > (1 << logn):
+            t = self.applyGalois(a, degree + 1, galois_keys)
+            self.addInplace(a, t)
+            degree >>= 1
+
+    def packLWECiphertexts(self, lwes, galois_keys):
+        """evaluator_cuda.cu:2275-2340: n LWE samples -> one RLWE ciphertext whose coefficients 0, N/n', 2N/n', .. carry them
+        (n' = n rounded up to a power of two); needs the Galois keys of the elements 2^k + 1."""
+        if not lwes:
+            raise capi.InvalidArgument(capi.INVALID_ARGUMENT, "LWE ciphertexts must not be empty.")
+        N = self.context.N
+        ckks = self.context.scheme == CKKS
+        l = 0
+        while (1 << l) < len(lwes):
+            l += 1
+        zero = self.assembleLWE(lwes[0], 0)
+        zero.buf.zero()
+        rl = []
+        for i in range(1 << l):
+            idx = int(format(i, "0%db" % l)[::-1], 2) if l else 0
+            if idx < len(lwes):
+                c = self.assembleLWE(lwes[idx], 0)
+                self.divideByPolyModulusDegreeInplace(c)
+                rl.append(c)
+            else:
+                rl.append(zero.copy())
+        for layer in range(l):
+            gap, shift = 1 << layer, N >> (layer + 1)
+            for off in range(0, 1 << l, 2 * gap):
+                even, odd = rl[off], rl[off + gap]
+                temp = self.negacyclicShift(odd, shift)
+                new_odd = self.sub(even, temp)
+                self.addInplace(even, temp)
+                if ckks:
+                    self.transformToNttInplace(new_odd)
+                self.applyGaloisInplace(new_odd, (1 << (layer + 1)) + 1, galois_keys)
+                if ckks:
+                    self.transformFromNttInplace(new_odd)
+                self.addInplace(even, new_odd)
+                rl[off + gap] = new_odd
+        ret = rl[0]
+        self.fieldTraceInplace(ret, galois_keys, l)
+        if ckks:
+            self.transformToNttInplace(ret)
+        return ret
 
     def _copy_then(self, fn, a, *args):
         r = a.copy()

@@ -307,6 +307,9 @@ int troyhip_apply_key_switching(troyhip_context *ctx, troyhip_ct *ct, const uint
 int troyhip_negacyclic_shift(troyhip_context *ctx, troyhip_ct *ct, uint64_t shift, uint64_t batch, void *stream) {
     return guard([&] { CtBatch x = view(ct); ctx->ev.negacyclic_shift(x, shift, batch, (hipStream_t)stream); store(x, ct); });
 }
+int troyhip_divide_by_poly_modulus_degree(troyhip_context *ctx, troyhip_ct *ct, uint64_t mul, uint64_t batch, void *stream) {
+    return guard([&] { CtBatch x = view(ct); ctx->ev.divide_by_degree(x, mul, batch, (hipStream_t)stream); store(x, ct); });
+}
 int troyhip_decrypt(troyhip_context *ctx, const troyhip_ct *ct, const uint64_t *secret_key, uint64_t *plain_out, uint64_t plain_batch_stride, uint64_t batch,
                     void *stream) {
     return guard([&] { CtBatch x = view(ct); ctx->ev.decrypt(x, secret_key, plain_out, plain_batch_stride, batch, (hipStream_t)stream); });

@@ -549,7 +549,7 @@ void Evaluator::apply_key_switching(CtBatch &ct, const KsKey &key, u64 batch, hi
 // negacyclicShift (evaluator_cuda.cu:2342-2351): every limb of every polynomial is multiplied by x^shift
 void Evaluator::negacyclic_shift(CtBatch &ct, u64 shift, u64 batch, hipStream_t s) {
     check_ct(ct);
-    if (shift >= c.N) throw Error(ST_INVALID_ARGUMENT, "shift");
+    if (shift >= 2 * c.N) throw Error(ST_INVALID_ARGUMENT, "shift");  // x^(N+k) = -x^k: shifts up to 2N-1 (extractLWE uses 2N - term)
     if (shift == 0) return;
     const u64 words = (u64)ct.size * poly_words(c, ct.limbs);
     c.arena.reset();
@@ -557,6 +557,20 @@ void Evaluator::negacyclic_shift(CtBatch &ct, u64 shift, u64 batch, hipStream_t 
     u64 *tmp = c.arena.take(batch * words);
     launch_copy_strided(ct.data, ct.bstride, tmp, words, words, batch, s);
     launch_negacyclic_shift(tmp, words, ct.data, ct.bstride, c.d_desc, c.ct_map(ct.limbs), c.logn, shift, (u64)ct.size * ct.limbs, ct.limbs, batch, s);
+}
+
+// divideByPolyModulusDegreeInplace (evaluator_cuda.cu:2259-2273): every limb times N^-1 (times `mul`) modulo its prime
+void Evaluator::divide_by_degree(CtBatch &ct, u64 mul, u64 batch, hipStream_t s) {
+    check_ct(ct);
+    u64 sc[64];
+    for (int l = 0; l < ct.limbs; l++) {
+        const u64 p = c.primes[l];
+        sc[l] = host::mul_mod(host::inv_mod_checked(c.N % p, p), mul % p, p);
+    }
+    const LimbMap map = c.ct_map(ct.limbs);
+    const u64 words = (u64)ct.size * poly_words(c, ct.limbs);
+    if (ct.bstride == words) launch_mul_scalar(ct.data, c.d_desc, map, sc, c.logn, batch * ct.size * ct.limbs, s);
+    else for (u64 b = 0; b < batch; b++) launch_mul_scalar(ct.data + b * ct.bstride, c.d_desc, map, sc, c.logn, (u64)ct.size * ct.limbs, s);
 }
 
 // ---- decryption ----

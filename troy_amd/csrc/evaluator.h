@@ -41,6 +41,7 @@ public:
     // applyKeySwitchingInplace (evaluator_cuda.cu:1365-1378) and negacyclicShift (evaluator_cuda.cu:2342-2351)
     void apply_key_switching(CtBatch &ct, const KsKey &key, u64 batch, hipStream_t s);
     void negacyclic_shift(CtBatch &ct, u64 shift, u64 batch, hipStream_t s);
+    void divide_by_degree(CtBatch &ct, u64 mul, u64 batch, hipStream_t s);
     void plain_to_ntt(const u64 *plain, u64 n_coeffs, u64 plain_bstride, int limbs, u64 *out, u64 count, hipStream_t s);
     void negate(CtBatch &a, u64 batch, hipStream_t s);
     // out may alias a or b; out.size/limbs/... are set; out.data/out.bstride are the caller's
