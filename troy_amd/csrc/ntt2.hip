@@ -29,7 +29,8 @@
 namespace troyhip {
 
 // tools/ntt_probe.sh builds throw-away variants with parts of the kernel removed to see what bounds it (results are
-// wrong by construction): bit0 no HBM traffic, bit1 no LDS exchange, bit2 no butterflies.  Always 0 in the product.
+// wrong by construction): bit0 no HBM traffic, bit1 no LDS exchange, bit2 no butterflies, bit3 the contiguous pass reads an
+// L2-resident window instead of its rows.  Always 0 in the product.
 #ifndef N2_EXP
 #define N2_EXP 0
 #endif
@@ -460,6 +461,7 @@ __global__ __launch_bounds__(N2_THREADS, MAC ? N2_MAC_WAVES : N2_MIN_WAVES) void
         const u64 r = ((u64)o * period + slot) * inner + k;
         row = a.data + (r << logn);
         in = (REDUCE || a.src) ? (a.src_same_layout ? a.src + (r << logn) : a.src + (u64)o * a.src_ostride + ((u64)k << logn)) : row;
+        if ((N2_EXP & 8) && !STRIDED) in = a.data + ((r & 63) << logn); // probe: the contiguous pass reads a 16 MB window (L2-resident input)
     };
     constexpr bool DMA = N2_DMA && WAVE_PRIVATE && !(N2_EXP & 1);
     static_assert(!MAC || (!INV && !STRIDED && NS == 9), "the inner product is fused into the forward contiguous pass");
