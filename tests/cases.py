@@ -30,6 +30,7 @@ CONFIGS = {
     "bgv_n4096_k3": dict(scheme=BGV, N=4096, bits=[36, 36, 37], tbits=20),
     "cfgNS_bfv_n32768_k15": dict(scheme=BFV, N=32768, bits=[60] + [58] * 13 + [60], tbits=20),
     "cfgC_ckks_n32768_k15": dict(scheme=CKKS, N=32768, bits=[60] + [40] * 13 + [60], tbits=0),
+    "bfv_n131072_k3": dict(scheme=BFV, N=131072, bits=[50, 50, 50], tbits=20),       # largest N: 10-stage contiguous pass, unfused paths
     "cfgD_bgv_n65536_k15": dict(scheme=BGV, N=65536, bits=[60] + [50] * 13 + [60], tbits=20),  # relinearize + rotateRows
 }
 SMALL = ["bfv_n64_k3", "bfv_n128_k4", "bfv_n128_k5_60", "ckks_n128_k6", "bgv_n128_k4"]

@@ -282,7 +282,7 @@ void Evaluator::switch_key(CtBatch &ct, const u64 *target, u64 t_bstride, const 
     }
     // decompose + extend every limb to every output prime, ONE batched NTT over all (L+1)*L rows, inner product with the key
     const u64 *mac_target = c.scheme == SCHEME_CKKS ? target : nullptr;
-    if (ntt2_supported(c.logn) && ks_fused()) {
+    if (ntt2_ks_mac_supported(c.logn) && ks_fused()) {
         // fused: the first NTT pass reads the target and reduces it modulo each output prime on the fly; the second pass keeps
         // the transforms in registers and accumulates them against the key -- the expanded digits are never written back
         // lazy accumulation is exact while dl * 8p * p < 2^128 for every output prime (CKKS replaces one operand by a canonical value)

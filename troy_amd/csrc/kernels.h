@@ -11,6 +11,7 @@ void launch_ntt2_ks_mac(u64 *D, const u64 *src, u64 src_ostride, const PrimeDesc
                         const uint8_t *key_limb, unsigned K, const u64 *ckks_target, u64 t_bstride, bool lazy, hipStream_t stream);
 // BEHZ multiply: forward transforms of two size-2 operands + ciphertext tensor in one pass pair (ntt2.hip)
 bool ntt2_tensor_supported(int logn);
+bool ntt2_ks_mac_supported(int logn);
 void launch_ntt2_tensor(u64 *xa, const u64 *src_a, u64 *xb, const u64 *src_b, u64 *out, const PrimeDesc *primes, const LimbMap &map, size_t batch, int logn,
                         hipStream_t stream);
 // forward transform of `src` (same row layout, left untouched) into `data`

@@ -717,7 +717,8 @@ void launch_ntt2_ks_mac(u64 *D, const u64 *src, u64 src_ostride, const PrimeDesc
 // BFV/BEHZ multiply, both bases: forward transforms of two size-2 operands with the ciphertext tensor fused into the second
 // pass.  xa / xb: [batch][2][limbs][N] scratch (transformed in place by the first pass; src_* != nullptr: the first pass reads
 // the operand from there instead -- dense ciphertexts are consumed in place); out: [batch][3][limbs][N] in NTT form.
-bool ntt2_tensor_supported(int logn) { return ntt2_supported(logn) && logn - 9 >= 3 && logn - 9 <= 7; }
+bool ntt2_tensor_supported(int logn) { return ntt2_supported(logn) && logn - 9 >= 3 && logn - 9 <= 7; } // 9-stage second pass
+bool ntt2_ks_mac_supported(int logn) { return ntt2_tensor_supported(logn); }
 void launch_ntt2_tensor(u64 *xa, const u64 *src_a, u64 *xb, const u64 *src_b, u64 *out, const PrimeDesc *primes, const LimbMap &map, size_t batch, int logn,
                         hipStream_t stream) {
     if (!batch) return;
