@@ -30,6 +30,9 @@ CONFIGS = {
     "bgv_n4096_k3": dict(scheme=BGV, N=4096, bits=[36, 36, 37], tbits=20),
     "cfgNS_bfv_n32768_k15": dict(scheme=BFV, N=32768, bits=[60] + [58] * 13 + [60], tbits=20),
     "cfgC_ckks_n32768_k15": dict(scheme=CKKS, N=32768, bits=[60] + [40] * 13 + [60], tbits=0),
+    "bfv_n2048_k3": dict(scheme=BFV, N=2048, bits=[40, 40, 40], tbits=16),           # largest N of the generic (single LDS tile) NTT
+    "bfv_n16384_k4": dict(scheme=BFV, N=16384, bits=[50, 45, 45, 50], tbits=20),      # k1 = 5 strided pass
+    "ckks_n16384_k4": dict(scheme=CKKS, N=16384, bits=[50, 40, 40, 50], tbits=0),
     "bfv_n131072_k3": dict(scheme=BFV, N=131072, bits=[50, 50, 50], tbits=20),       # largest N: 10-stage contiguous pass, unfused paths
     "cfgD_bgv_n65536_k15": dict(scheme=BGV, N=65536, bits=[60] + [50] * 13 + [60], tbits=20),  # relinearize + rotateRows
 }

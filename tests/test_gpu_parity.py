@@ -71,7 +71,8 @@ def test_headline_configs_match_reference(name, gpu, golden_hashes):
     assert not bad, bad
 
 
-@pytest.mark.parametrize("name,batch", [("cfgA_bfv_n4096_k3", 5), ("cfgB_bfv_n8192_k5", 3), ("ckks_n4096_k4", 4), ("bgv_n4096_k3", 4), ("bfv_n131072_k3", 1)])
+@pytest.mark.parametrize("name,batch", [("cfgA_bfv_n4096_k3", 5), ("cfgB_bfv_n8192_k5", 3), ("ckks_n4096_k4", 4), ("bgv_n4096_k3", 4), ("bfv_n131072_k3", 1),
+                                        ("bfv_n2048_k3", 3), ("bfv_n16384_k4", 2), ("ckks_n16384_k4", 2)])
 def test_batched_mul_relin_vs_oracle(name, batch, gpu, oracle_lib):
     """distinct ciphertexts in every batch slot, fresh seed: product vs CPU oracle"""
     from oracle import ref
