@@ -94,6 +94,10 @@ int troyhip_context_behz_bases(const troyhip_context *ctx, int limbs, uint64_t *
 /* host copy of the NTT tables of one prime of the context (NTTTablesCuda, src/utils/ntt_cuda.cuh:81-100); each array N entries */
 int troyhip_context_ntt_tables(const troyhip_context *ctx, uint64_t prime, uint64_t *root_operand, uint64_t *root_quotient,
                                uint64_t *inv_root_operand, uint64_t *inv_root_quotient, uint64_t *inv_degree2, uint64_t *root);
+/* BLAKE2b (RFC 7693), unkeyed, 1..64 output bytes: the hash behind parms_id (src/utils/hash.h) */
+int troyhip_blake2b(void *out, size_t outlen, const void *in, size_t inlen);
+/* parms_id of the level with `limbs` primes: BLAKE2b-256 of (scheme, N, primes, plain modulus), src/encryptionparams.cpp:118-146 */
+int troyhip_context_parms_id(const troyhip_context *ctx, int limbs, uint64_t out[4]);
 int troyhip_context_reserve_scratch(troyhip_context *ctx, size_t words);
 int troyhip_context_scratch_words(const troyhip_context *ctx, int op, int limbs, uint64_t batch, size_t *words); /* op: 0 multiply(2x2), 1 switch_key */
 int troyhip_galois_elt_from_step(const troyhip_context *ctx, int step, uint32_t *out);   /* GaloisToolCuda::getEltFromStep (galois_cuda.cu:44-86) */

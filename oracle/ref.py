@@ -204,6 +204,11 @@ class Ref:
         n = od.size * od.limbs * self.N
         return Ct(out[:n].reshape(od.size, od.limbs, self.N).copy(), od.is_ntt, od.scale, od.correction_factor)
 
+    def parms_id(self, limbs):
+        out = np.zeros(4, dtype=np.uint64)
+        self._chk(lib().ref_parms_id(self.h, limbs, _p(out)))
+        return [int(x) for x in out]
+
     def plain_to_ntt(self, plain, limbs):
         plain = np.ascontiguousarray(plain, dtype=np.uint64)
         out = np.zeros((limbs, self.N), dtype=np.uint64)

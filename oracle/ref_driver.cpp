@@ -404,6 +404,15 @@ int ref_plain_to_ntt(void *h, const u64 *plain, int n_coeffs, int limbs, u64 *ou
         std::memcpy(out, p.data(), sizeof(u64) * (size_t)limbs * r->N);
     });
 }
+// parms_id of the level with `limbs` primes (src/encryptionparams.cpp:118-146: BLAKE2b-256 of the parameter words)
+int ref_parms_id(void *h, int limbs, u64 *out4) {
+    Ref *r = (Ref *)h;
+    return guarded(r, [&] {
+        auto cd = level_data(r, limbs);
+        auto id = cd->parmsID();
+        for (int i = 0; i < 4; i++) out4[i] = id[i];
+    });
+}
 uint32_t ref_galois_elt_from_step(void *h, int step) {
     Ref *r = (Ref *)h;
     return r->ctx->keyContextData()->galoisTool()->getEltFromStep(step);

@@ -88,3 +88,26 @@ def test_emulated_ckks_matmul_helper(emul_api):
 
 def test_emulated_lwe_pack(emul_api):
     cases.check_lwe_pack(N=64, bits=(40, 40, 40, 40), tbits=10, n_lwe=3, batch=1)
+
+
+def test_emulated_save_load_roundtrip(emul_api):
+    """CiphertextCuda::save / load wire format (src/ciphertext_cuda.cu:16-104): field layout, parms_id check, round trip"""
+    import io
+    import struct
+    api = emul_api
+    from troy_amd import synth
+    N = 64
+    primes = api.CoeffModulus.Create(N, [40, 40, 40])
+    ctx = api.SEALContext(api.CKKS, N, primes, 0)
+    x = synth.uniform_ct(3, primes[:2], 2, N, 2)
+    c = api.Ciphertext.from_numpy(ctx, x, True, 2.0 ** 20, 1)
+    s = io.BytesIO()
+    c.save(s, index=1)
+    blob = s.getvalue()
+    assert len(blob) == 32 + 1 + 8 * 3 + 8 + 8 + 8 + 1 + 8 + 2 * 2 * N * 8
+    assert struct.unpack_from("<?QQQd", blob, 32) == (True, 2, N, 2, 2.0 ** 20)
+    back = api.Ciphertext.load(ctx, io.BytesIO(blob))
+    assert np.array_equal(back.cpu()[0], x[1]) and back.is_ntt_form and back.scale == 2.0 ** 20
+    other = api.SEALContext(api.CKKS, N, api.CoeffModulus.Create(N, [40, 30, 40]), 0)
+    with pytest.raises(ValueError):
+        api.Ciphertext.load(other, io.BytesIO(blob))

@@ -90,3 +90,34 @@ def test_naf(oracle_lib):  # src/utils/numth.h:16-36
     assert oracle_lib.naf(-5) == [-1, -4]
     assert oracle_lib.naf(7) == [-1, 8]
     assert oracle_lib.naf(0) == []
+
+
+def test_blake2b_rfc7693_and_parms_id_vs_reference():
+    """the product's BLAKE2b (written from RFC 7693) on the RFC's "abc" vector, and parms_id of every level against the
+    reference's EncryptionParameters::computeParmsID (src/encryptionparams.cpp:118-146) through oracle/_ref"""
+    import ctypes as C
+    import os
+    import subprocess
+    from conftest import ROOT
+    from troy_amd import capi
+    subprocess.check_call(["make", "-s", "-j8", "-C", os.path.join(ROOT, "troy_amd", "csrc"), "emul"])
+    lib = capi.load(os.path.join(ROOT, "tests", "emul", "libtroyhip_emul.so"))
+    out = (C.c_uint8 * 64)()
+    assert lib.troyhip_blake2b(out, C.c_size_t(64), b"abc", C.c_size_t(3)) == 0
+    assert bytes(out).hex() == ("ba80a53f981c4d0d6a2797b69f12f6e94c212f14685ac4b74b12bb6fdbffa2d1"
+                                "7d87c5392aab792dc252d5de4533cc9518d38aa8dbf1925ab92386edd4009923")
+    from oracle import ref as R
+    if not R.available():
+        pytest.skip("oracle/_ref not built")
+    for scheme, N, bits, tb in ((1, 4096, [36, 36, 37], 20), (2, 256, [40, 40, 40], 0), (3, 128, [40, 36, 36, 40], 10)):
+        primes = R.coeff_modulus_create(N, bits)
+        t = R.plain_batching(N, tb) if tb else 0
+        r = R.Ref(scheme, N, primes, t)
+        arr = np.array(primes, dtype=np.uint64)
+        h = C.c_void_p()
+        assert lib.troyhip_context_create_host(scheme, C.c_uint64(N), arr.ctypes.data_as(C.c_void_p), len(primes), C.c_uint64(t), C.byref(h)) == 0
+        for limbs in range(len(primes), r.chain()[2] - 1, -1):
+            o = np.zeros(4, dtype=np.uint64)
+            assert lib.troyhip_context_parms_id(h, limbs, o.ctypes.data_as(C.c_void_p)) == 0
+            assert [int(x) for x in o] == r.parms_id(limbs), (scheme, limbs)
+        lib.troyhip_context_destroy(h)

@@ -186,6 +186,40 @@ class Ciphertext:
             data = full
         return cls(context, B, size, limbs, is_ntt_form, scale, correction_factor, cap, DeviceBuffer.from_numpy(data))
 
+    # ---- wire format of CiphertextCuda::save / load (src/ciphertext_cuda.cu:16-43, 82-104): a raw little-endian field dump
+    #   parms_id (4 x u64, BLAKE2b-256 of the level's parameters) | is_ntt_form (1 byte) | size, poly_modulus_degree,
+    #   coeff_modulus_size (u64 each) | scale (f64) | correction_factor (u64) | seed (u64, 0) | terms (1 byte, 0) |
+    #   data word count (u64) | data [size][limbs][N] u64
+    def save(self, stream, index=0):
+        """writes batch item `index` in the reference's format"""
+        import struct
+        ctx = self.context
+        pid = np.zeros(4, dtype=np.uint64)
+        capi.check(ctx.lib, ctx.lib.troyhip_context_parms_id(ctx.h, int(self.limbs), _u64p(pid)))
+        data = np.ascontiguousarray(self.cpu()[index])
+        stream.write(pid.tobytes())
+        stream.write(struct.pack("<?QQQdQQ?Q", bool(self.is_ntt_form), self._size, ctx.N, self.limbs, float(self.scale), int(self.correction_factor), 0, False, data.size))
+        stream.write(data.tobytes())
+
+    @classmethod
+    def load(cls, context, stream):
+        """reads one ciphertext; the parms_id must name a level of `context`"""
+        import struct
+        pid = np.frombuffer(stream.read(32), dtype=np.uint64)
+        ntt, size, n, limbs, scale, cf, seed, terms, words = struct.unpack("<?QQQdQQ?Q", stream.read(struct.calcsize("<?QQQdQQ?Q")))
+        if terms:
+            raise capi.InvalidArgument(capi.INVALID_ARGUMENT, "Trying to load a termed ciphertext, but indices is not specified")
+        if seed:
+            raise capi.InvalidArgument(capi.INVALID_ARGUMENT, "seed is not zero.")
+        mine = np.zeros(4, dtype=np.uint64)
+        if n != context.N or limbs < 1 or limbs > context.key_limbs or words != size * limbs * n:
+            raise capi.InvalidArgument(capi.INVALID_ARGUMENT, "encrypted is not valid for encryption parameters")
+        capi.check(context.lib, context.lib.troyhip_context_parms_id(context.h, int(limbs), _u64p(mine)))
+        if not np.array_equal(mine, pid):
+            raise capi.InvalidArgument(capi.INVALID_ARGUMENT, "encrypted is not valid for encryption parameters")
+        data = np.frombuffer(stream.read(8 * words), dtype=np.uint64).reshape(1, size, limbs, n)
+        return cls.from_numpy(context, data, ntt, scale, cf)
+
     def cpu_poly_view(self):
         """host copy [batch][size][limbs][N] (alias of cpu(), named for the LWE helpers)"""
         return self.cpu()

@@ -310,6 +310,18 @@ int troyhip_negacyclic_shift(troyhip_context *ctx, troyhip_ct *ct, uint64_t shif
 int troyhip_divide_by_poly_modulus_degree(troyhip_context *ctx, troyhip_ct *ct, uint64_t mul, uint64_t batch, void *stream) {
     return guard([&] { CtBatch x = view(ct); ctx->ev.divide_by_degree(x, mul, batch, (hipStream_t)stream); store(x, ct); });
 }
+int troyhip_blake2b(void *out, size_t outlen, const void *in, size_t inlen) {
+    return guard([&] {
+        if (!out || outlen == 0 || outlen > 64 || (!in && inlen)) throw Error(ST_INVALID_ARGUMENT, "blake2b");
+        host::blake2b(out, outlen, in, inlen);
+    }, false);
+}
+int troyhip_context_parms_id(const troyhip_context *ctx, int limbs, uint64_t out[4]) {
+    return guard([&] {
+        if (limbs < 1 || limbs > ctx->ctx.K) throw Error(ST_INVALID_ARGUMENT, "parms_id is not valid for the current context");
+        host::parms_id(ctx->ctx.scheme, ctx->ctx.N, ctx->ctx.primes, limbs, ctx->ctx.t, out);
+    }, false);
+}
 int troyhip_decrypt(troyhip_context *ctx, const troyhip_ct *ct, const uint64_t *secret_key, uint64_t *plain_out, uint64_t plain_batch_stride, uint64_t batch,
                     void *stream) {
     return guard([&] { CtBatch x = view(ct); ctx->ev.decrypt(x, secret_key, plain_out, plain_batch_stride, batch, (hipStream_t)stream); });

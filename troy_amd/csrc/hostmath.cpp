@@ -1,6 +1,7 @@
 // hostmath.cpp -- see hostmath.h.  Plain 128-bit integer arithmetic on the host; none of this is on
 // the hot path (it runs once per context).
 #include "hostmath.h"
+#include <cstring>
 #include <algorithm>
 #include <cstdlib>
 #include <map>
@@ -232,6 +233,74 @@ void RnsLevel::build(u64 N, const std::vector<u64> &q_, u64 t_) {
         neg_inv_q_mod_t = (t - inv_mod_checked(product_mod(q, t), t)) % t;
         neg_inv_q_mod_gamma = (gamma - inv_mod_checked(product_mod(q, gamma), gamma)) % gamma;
     }
+}
+
+
+// ---- BLAKE2b, written from RFC 7693 (section 3.2 compression function F, 3.3 padding / finalisation) ----
+static inline u64 rotr64(u64 x, int n) { return (x >> n) | (x << (64 - n)); }
+void blake2b(void *out, size_t outlen, const void *in, size_t inlen) {
+    static const u64 IV[8] = {0x6A09E667F3BCC908ULL, 0xBB67AE8584CAA73BULL, 0x3C6EF372FE94F82BULL, 0xA54FF53A5F1D36F1ULL,
+                              0x510E527FADE682D1ULL, 0x9B05688C2B3E6C1FULL, 0x1F83D9ABFB41BD6BULL, 0x5BE0CD19137E2179ULL};
+    static const uint8_t SIGMA[12][16] = {
+        {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15}, {14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3},
+        {11, 8, 12, 0, 5, 2, 15, 13, 10, 14, 3, 6, 7, 1, 9, 4}, {7, 9, 3, 1, 13, 12, 11, 14, 2, 6, 5, 10, 4, 0, 15, 8},
+        {9, 0, 5, 7, 2, 4, 10, 15, 14, 1, 11, 12, 6, 8, 3, 13}, {2, 12, 6, 10, 0, 11, 8, 3, 4, 13, 7, 5, 15, 14, 1, 9},
+        {12, 5, 1, 15, 14, 13, 4, 10, 0, 7, 6, 3, 9, 2, 8, 11}, {13, 11, 7, 14, 12, 1, 3, 9, 5, 0, 15, 4, 8, 6, 2, 10},
+        {6, 15, 14, 9, 11, 3, 0, 8, 12, 2, 13, 7, 1, 4, 10, 5}, {10, 2, 8, 4, 7, 6, 1, 5, 15, 11, 9, 14, 3, 12, 13, 0},
+        {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15}, {14, 10, 4, 8, 9, 15, 13, 6, 1, 12, 0, 2, 11, 7, 5, 3}};
+    u64 h[8];
+    for (int i = 0; i < 8; i++) h[i] = IV[i];
+    h[0] ^= 0x01010000ULL ^ (u64)outlen; // parameter block: digest length, key length 0, fanout 1, depth 1
+    const uint8_t *p = (const uint8_t *)in;
+    u128 t = 0;
+    auto compress = [&](const uint8_t *block, bool last) {
+        u64 m[16], v[16];
+        for (int i = 0; i < 16; i++) {
+            u64 w = 0;
+            for (int b = 0; b < 8; b++) w |= (u64)block[8 * i + b] << (8 * b);
+            m[i] = w;
+        }
+        for (int i = 0; i < 8; i++) { v[i] = h[i]; v[i + 8] = IV[i]; }
+        v[12] ^= (u64)t;
+        v[13] ^= (u64)(t >> 64);
+        if (last) v[14] = ~v[14];
+        auto G = [&](int a, int b, int c, int d, u64 x, u64 y) {
+            v[a] = v[a] + v[b] + x; v[d] = rotr64(v[d] ^ v[a], 32);
+            v[c] = v[c] + v[d];     v[b] = rotr64(v[b] ^ v[c], 24);
+            v[a] = v[a] + v[b] + y; v[d] = rotr64(v[d] ^ v[a], 16);
+            v[c] = v[c] + v[d];     v[b] = rotr64(v[b] ^ v[c], 63);
+        };
+        for (int r = 0; r < 12; r++) {
+            const uint8_t *s = SIGMA[r];
+            G(0, 4, 8, 12, m[s[0]], m[s[1]]);   G(1, 5, 9, 13, m[s[2]], m[s[3]]);
+            G(2, 6, 10, 14, m[s[4]], m[s[5]]);  G(3, 7, 11, 15, m[s[6]], m[s[7]]);
+            G(0, 5, 10, 15, m[s[8]], m[s[9]]);  G(1, 6, 11, 12, m[s[10]], m[s[11]]);
+            G(2, 7, 8, 13, m[s[12]], m[s[13]]); G(3, 4, 9, 14, m[s[14]], m[s[15]]);
+        }
+        for (int i = 0; i < 8; i++) h[i] ^= v[i] ^ v[i + 8];
+    };
+    while (inlen > 128) { // every block but the last
+        t += 128;
+        compress(p, false);
+        p += 128;
+        inlen -= 128;
+    }
+    uint8_t last[128] = {0};
+    std::memcpy(last, p, inlen);
+    t += inlen;
+    compress(last, true);
+    uint8_t digest[64];
+    for (int i = 0; i < 8; i++)
+        for (int b = 0; b < 8; b++) digest[8 * i + b] = (uint8_t)(h[i] >> (8 * b));
+    std::memcpy(out, digest, outlen);
+}
+void parms_id(int scheme, u64 N, const std::vector<u64> &primes, int limbs, u64 plain_modulus, u64 out[4]) {
+    std::vector<u64> w;
+    w.push_back((u64)scheme);
+    w.push_back(N);
+    for (int i = 0; i < limbs; i++) w.push_back(primes[i]);
+    w.push_back(plain_modulus); // Modulus always spans one word (0 for CKKS)
+    blake2b(out, 32, w.data(), w.size() * 8);
 }
 
 } // namespace host

@@ -23,6 +23,11 @@ bool minimal_primitive_root(u64 degree, u64 p, u64 &out);
 uint32_t reverse_bits(uint32_t x, int bits);
 int bit_length_of_product(const std::vector<u64> &v);
 u64 product_mod(const std::vector<u64> &v, u64 p);
+// BLAKE2b (RFC 7693), unkeyed, outlen bytes (<= 64): the reference's parms_id hash (src/utils/hash.h:25-32 calls blake2b with a
+// 32-byte digest over the parameter words, src/encryptionparams.cpp:118-146)
+void blake2b(void *out, size_t outlen, const void *in, size_t inlen);
+// parms_id of the level holding the first `limbs` primes: hash of (scheme, N, those primes, plain modulus)
+void parms_id(int scheme, u64 N, const std::vector<u64> &primes, int limbs, u64 plain_modulus, u64 out[4]);
 uint32_t galois_elt_from_step(u64 N, int step);
 std::vector<int> naf(int value);
 
