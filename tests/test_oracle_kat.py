@@ -4,6 +4,7 @@ import json
 import os
 
 import numpy as np
+import pytest
 
 from conftest import GOLDEN
 
