@@ -283,7 +283,7 @@ def cpu_baseline(scheme, N, primes, t, L):
     xb = synth.uniform_ct(0x5EEE, primes[:L], 2, N)[0]
     rk = synth.uniform_kswitch_key(0xC0FFEE, primes, N)
     from oracle import ref
-    reps = 6 if N >= 32768 else 60
+    reps = 60 if N >= 32768 else 2000  # about 12 s of single-core work at either size
     if ref.available():
         R = ref.Ref(scheme, N, primes, t)
         R.set_kswitch_key(0, rk)
