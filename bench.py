@@ -283,7 +283,7 @@ def cpu_baseline(scheme, N, primes, t, L):
     xb = synth.uniform_ct(0x5EEE, primes[:L], 2, N)[0]
     rk = synth.uniform_kswitch_key(0xC0FFEE, primes, N)
     from oracle import ref
-    reps = 60 if N >= 32768 else 2000  # about 12 s of single-core work at either size
+    reps = 60 if N >= 32768 else 400  # about 12 s of single-core work at either size (0.2 s / 0.03 s per op)
     if ref.available():
         R = ref.Ref(scheme, N, primes, t)
         R.set_kswitch_key(0, rk)
