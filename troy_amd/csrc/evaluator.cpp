@@ -280,6 +280,9 @@ void Evaluator::switch_key(CtBatch &ct, const u64 *target, u64 t_bstride, const 
         coeff_target = tt;
         ct_tb = dl * N;
     }
+    // the digits are canonical residues of the ciphertext primes: an output prime p with 8p above the largest of them needs no reduction
+    u64 src_bound = 0;
+    for (u64 j = 0; j < dl; j++) src_bound = std::max(src_bound, c.primes[j]);
     // decompose + extend every limb to every output prime, ONE batched NTT over all (L+1)*L rows, inner product with the key
     const u64 *mac_target = c.scheme == SCHEME_CKKS ? target : nullptr;
     if (ntt2_ks_mac_supported(c.logn) && ks_fused()) {
@@ -292,10 +295,10 @@ void Evaluator::switch_key(CtBatch &ct, const u64 *target, u64 t_bstride, const 
             lazy = lazy && (long double)dl * 8.0L * p * p < 3.0e38L; // 2^128 = 3.4e38
         }
         launch_ntt2_ks_mac(D, coeff_target, ct_tb, c.d_desc, c.ids_map(out_ids, (uint32_t)dl), batch * rl * dl, c.logn, key.data, acc, a.key_limb, (unsigned)K,
-                           mac_target, t_bstride, lazy, s);
+                           mac_target, t_bstride, lazy, src_bound, s);
     } else {
         if (ntt2_supported(c.logn)) {
-            launch_ntt2(D, coeff_target, ct_tb, true, c.d_desc, c.ids_map(out_ids, (uint32_t)dl), batch * rl * dl, c.logn, false, s);
+            launch_ntt2(D, coeff_target, ct_tb, true, c.d_desc, c.ids_map(out_ids, (uint32_t)dl), batch * rl * dl, c.logn, false, s, false, src_bound);
         } else {
             launch_ks_expand(coeff_target, ct_tb, D, a, s);
             launch_ntt(D, c.d_desc, c.ids_map(out_ids, (uint32_t)dl), batch * rl * dl, c.logn, false, s);

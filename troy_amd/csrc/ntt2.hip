@@ -65,6 +65,7 @@ struct Ntt2Args {
     unsigned rows_per_wg; // R
     unsigned chunks;      // ceil(m_total / R)
     int src_reduce;       // reduce src values modulo the row prime (they are residues of another prime)
+    u64 src_bound;        // exclusive upper bound of the src values (largest source prime): rows whose prime p has 8p > bound skip the reduction
     int slot_fastest;     // workgroup order, see the kernel
     int src_same_layout;  // src has the row layout of data (plain out-of-place transform) instead of the digit broadcast
     // key-switch inner product fused into the last forward pass (MAC = 1): the workgroup's rows are the dl digits of one
@@ -436,6 +437,7 @@ __global__ __launch_bounds__(N2_THREADS, MAC ? N2_MAC_WAVES : N2_MIN_WAVES) void
     const unsigned slot = a.slot_fastest ? grp % a.map.period : grp / a.chunks, chunk = a.slot_fastest ? grp / a.map.period : grp % a.chunks;
     const PrimeDesc pd = a.primes[a.map.id[slot]];
     const Mod m = mod_of(pd);
+    const bool need_reduce = REDUCE && (a.src_bound == 0 || (pd.p >> 61) != 0 || a.src_bound > 8 * pd.p);
     const int logn = a.logn;
     const int k1 = STRIDED ? NS : logn - NS;
     const int s_first = INV ? (STRIDED ? k1 - 1 : logn - 1) : (STRIDED ? 0 : k1);
@@ -508,7 +510,7 @@ __global__ __launch_bounds__(N2_THREADS, MAC ? N2_MAC_WAVES : N2_MIN_WAVES) void
             }
         }
         u64 *buf = DMA ? lds[0] : lds[mm & 1];
-        if (REDUCE) {
+        if (REDUCE && need_reduce) { // wave-uniform: the butterflies take any input below 8p (ct_bfly4), most prime sets never need this
 #pragma unroll
             for (int e = 0; e < 8; e++) x[e] = barrett64(x[e], m);
         }
@@ -624,7 +626,7 @@ template <int INV, int NS> static void launch_strided(const Ntt2Args &a, unsigne
 
 // rows are laid out r = (o * period + i) * inner + k; src (optional, forward only): item o, digit k at src + o*src_ostride + k*N
 void launch_ntt2(u64 *data, const u64 *src, u64 src_ostride, bool src_reduce, const PrimeDesc *primes, const LimbMap &map, size_t rows, int logn,
-                 bool inverse, hipStream_t stream, bool src_same_layout) {
+                 bool inverse, hipStream_t stream, bool src_same_layout, u64 src_bound) {
     if (rows == 0) return;
     if (!ntt2_supported(logn)) throw Error(ST_LOGIC_ERROR, "ntt2: unsupported size");
     const size_t per_outer = (size_t)map.period * map.inner;
@@ -667,7 +669,7 @@ void launch_ntt2(u64 *data, const u64 *src, u64 src_ostride, bool src_reduce, co
     };
     if (!inverse) {
         Ntt2Args first = a;
-        if (src) { first.src = src; first.src_ostride = src_ostride; first.src_reduce = src_reduce; first.src_same_layout = src_same_layout; first.slot_fastest = src_reduce && !src_same_layout; }
+        if (src) { first.src = src; first.src_ostride = src_ostride; first.src_reduce = src_reduce; first.src_bound = src_bound; first.src_same_layout = src_same_layout; first.slot_fastest = src_reduce && !src_same_layout; }
         strided(std::integral_constant<int, 0>{}, first, src && src_reduce);
         contig(std::integral_constant<int, 0>{}, true);
     } else {
@@ -680,7 +682,7 @@ void launch_ntt2(u64 *data, const u64 *src, u64 src_ostride, bool src_reduce, co
 // second pass.  D receives only the first pass; acc [outer][2][period][N] the reduced sums.  Rows are grouped per (o, slot):
 // a workgroup takes all `inner` digits of one group, so its 16 accumulators see every term.
 void launch_ntt2_ks_mac(u64 *D, const u64 *src, u64 src_ostride, const PrimeDesc *primes, const LimbMap &map, size_t rows, int logn, const u64 *key, u64 *acc,
-                        const uint8_t *key_limb, unsigned K, const u64 *ckks_target, u64 t_bstride, bool lazy, hipStream_t stream) {
+                        const uint8_t *key_limb, unsigned K, const u64 *ckks_target, u64 t_bstride, bool lazy, u64 src_bound, hipStream_t stream) {
     if (rows == 0) return;
     if (!ntt2_supported(logn) || logn - 9 > 7 || logn - 9 < 3) throw Error(ST_LOGIC_ERROR, "ntt2 ks_mac: unsupported size");
     const size_t per_outer = (size_t)map.period * map.inner;
@@ -698,7 +700,7 @@ void launch_ntt2_ks_mac(u64 *D, const u64 *src, u64 src_ostride, const PrimeDesc
     a.chunks = a.m_total / a.rows_per_wg;
     const unsigned blocks = (unsigned)((map.period * a.chunks) << a.tiles_per_row_log);
     Ntt2Args first = a;
-    first.src = src; first.src_ostride = src_ostride; first.src_reduce = 1;
+    first.src = src; first.src_ostride = src_ostride; first.src_reduce = 1; first.src_bound = src_bound;
     first.slot_fastest = 1;
     switch (k1) {
     case 3: launch_strided<0, 3>(first, blocks, false, true, stream); break;
