@@ -471,3 +471,36 @@ def check_lwe_pack(scheme=BFV, N=256, bits=(40, 40, 40, 40), tbits=14, n_lwe=5, 
         pt = dec.decrypt(packed[b])
         for i in range(n_lwe):
             assert pt[i * step] == msgs[i][b][terms[i]], (i, b, int(pt[i * step]), int(msgs[i][b][terms[i]]))
+
+
+def check_ckks_conv2d_helper(N=4096, bits=(40, 30, 30, 40), batch=2, image=(12, 12), kernel=(3, 3), channels=(5, 3), seed=11):
+    """app/LinearHelperCKKS.cuh Conv2dHelper through troy_amd/app.py: encrypted images x plaintext kernels (valid convolution,
+    i.e. cross-correlation with the flipped kernel as the reference packs it) vs numpy; |error| < 1e-3.  A second case forces the
+    blocked path (image larger than sqrt(N) per side)."""
+    from troy_amd import api, app, capi
+    primes = api.CoeffModulus.Create(N, list(bits))
+    ctx = api.SEALContext(capi.CKKS, N, primes, 0)
+    kg = api.KeyGenerator(ctx, seed=(51, 52))
+    enc = api.Encryptor(ctx, kg.createPublicKey())
+    ev = api.Evaluator(ctx)
+    encoder = app.CKKSPolyEncoder(ctx)
+    skd = api.DeviceBuffer.from_numpy(kg.secretKey())
+    L = len(primes) - 1
+    rng = np.random.default_rng(seed)
+    H, Wd = image
+    kh, kw = kernel
+    ic, oc = channels
+    X = rng.uniform(-1, 1, (batch, ic, H, Wd))
+    Wt = rng.uniform(-1, 1, (oc, ic, kh, kw))
+    h = app.Conv2dHelper(batch, H, Wd, kh, kw, ic, oc, N // 2)
+    h.encodeWeights(encoder, L, Wt, 2.0 ** 22)
+    a = h.encryptInputs(enc, encoder, L, X, 2.0 ** 22)
+    got = h.decryptOutputs(ev, encoder, skd, h.conv2d(ev, a))
+    exp = np.zeros((batch, oc, H - kh + 1, Wd - kw + 1))
+    for b in range(batch):
+        for o in range(oc):
+            for i in range(H - kh + 1):
+                for j in range(Wd - kw + 1):
+                    exp[b, o, i, j] = np.sum(X[b, :, i:i + kh, j:j + kw] * Wt[o])
+    assert np.max(np.abs(got - exp)) < 1e-3, np.max(np.abs(got - exp))
+    return h

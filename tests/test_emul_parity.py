@@ -111,3 +111,9 @@ def test_emulated_save_load_roundtrip(emul_api):
     other = api.SEALContext(api.CKKS, N, api.CoeffModulus.Create(N, [40, 30, 40]), 0)
     with pytest.raises(ValueError):
         api.Ciphertext.load(other, io.BytesIO(blob))
+
+
+def test_emulated_ckks_conv2d_helper(emul_api):
+    cases.check_ckks_conv2d_helper(N=256, batch=1, image=(6, 6), kernel=(3, 3), channels=(3, 2))
+    h = cases.check_ckks_conv2d_helper(N=256, batch=1, image=(20, 18), kernel=(3, 3), channels=(1, 1))  # blocked: 16 x 16 blocks
+    assert h.blocked and h.getTotalBatchSize() == 4

@@ -367,3 +367,10 @@ def test_cfgE_matmul_helper_128x128(gpu):
 @pytest.mark.parametrize("scheme", [1, 3])
 def test_lwe_extract_and_pack(scheme, gpu):
     cases.check_lwe_pack(scheme=scheme)
+
+
+@pytest.mark.gpu
+def test_conv2d_helper(gpu):
+    cases.check_ckks_conv2d_helper()
+    h = cases.check_ckks_conv2d_helper(batch=1, image=(70, 66), kernel=(3, 3), channels=(1, 2))  # blocked path: 64 x 64 blocks
+    assert h.blocked

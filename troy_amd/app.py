@@ -168,3 +168,111 @@ class MatmulHelper:
                 for j in range(li, ui):
                     dec[b, j] = buf[(j - li + 1) * interval - 1]
         return dec
+
+
+class Conv2dHelper:
+    """app/LinearHelperCKKS.cuh:362-716: valid (no padding, stride 1) 2-D convolution by polynomial multiplication.  An image block
+    (h x w) of channel k sits at degrees k*h*w + i*w + j; the flipped kernel of input channel j at slot (channelSlots-1-j);
+    the output pixel (i, j) of the block is read at degree (channelSlots-1)*h*w + (h-yh+i)*w + (w-yw+j).  Images larger than
+    sqrt(N) per side are cut into overlapping blocks, which multiplies the batch (`getTotalBatchSize`)."""
+
+    def __init__(self, batchSize, imageHeight, imageWidth, kernelHeight, kernelWidth, inputChannels, outputChannels, slotCount):
+        self.batchSize, self.imageHeight, self.imageWidth = batchSize, imageHeight, imageWidth
+        self.kernelHeight, self.kernelWidth = kernelHeight, kernelWidth
+        self.inputChannels, self.outputChannels, self.slotCount = inputChannels, outputChannels, slotCount
+        max_size = int(math.isqrt(slotCount * 2))
+        if imageHeight > max_size or imageWidth > max_size:
+            self.blockHeight = self.blockWidth = max_size
+            self.blocked = True
+        else:
+            self.blockHeight, self.blockWidth, self.blocked = imageHeight, imageWidth, False
+        self.encodedWeights = None
+
+    def _grid(self):
+        kh, kw = self.kernelHeight - 1, self.kernelWidth - 1
+        return _ceil_div(self.imageHeight - kh, self.blockHeight - kh), _ceil_div(self.imageWidth - kw, self.blockWidth - kw)
+
+    def getTotalBatchSize(self):
+        if not self.blocked:
+            return self.batchSize
+        sh, sw = self._grid()
+        return self.batchSize * sh * sw
+
+    def encodeWeights(self, encoder, limbs, weights, scale):
+        """weights [outputChannels][inputChannels][kh][kw] -> Plain2d [oc][input-channel group] of DeviceBuffer"""
+        W = np.asarray(weights, dtype=np.float64).reshape(self.outputChannels, self.inputChannels, self.kernelHeight, self.kernelWidth)
+        bs = self.blockHeight * self.blockWidth
+        cs = (self.slotCount * 2) // bs
+        rows = []
+        for oc in range(self.outputChannels):
+            row = []
+            for lic in range(0, self.inputChannels, cs):
+                uic = min(lic + cs, self.inputChannels)
+                spread = np.zeros((cs, self.blockHeight, self.blockWidth))
+                for j in range(lic, uic):
+                    spread[cs - 1 - (j - lic), : self.kernelHeight, : self.kernelWidth] = W[oc, j, ::-1, ::-1]
+                row.append(api.DeviceBuffer.from_numpy(encoder.encodePolynomial(spread.reshape(-1), limbs, scale)))
+            rows.append(row)
+        self.encodedWeights, self.weightScale = rows, scale
+        return rows
+
+    def _split(self, X):
+        if not self.blocked:
+            return X
+        kh, kw = self.kernelHeight - 1, self.kernelWidth - 1
+        sh, sw = self._grid()
+        out = np.zeros((self.batchSize * sh * sw, self.inputChannels, self.blockHeight, self.blockWidth))
+        for b in range(self.batchSize):
+            for i in range(sh):
+                for j in range(sw):
+                    si, sj = i * (self.blockHeight - kh), j * (self.blockWidth - kw)
+                    ui, uj = min(si + self.blockHeight, self.imageHeight), min(sj + self.blockWidth, self.imageWidth)
+                    out[b * sh * sw + i * sw + j, :, : ui - si, : uj - sj] = X[b, :, si:ui, sj:uj]
+        return out
+
+    def encryptInputs(self, encryptor, encoder, limbs, inputs, scale):
+        """inputs [batchSize][inputChannels][H][W] -> list over input-channel groups of ONE batched ciphertext (batch = total batch)"""
+        X = self._split(np.asarray(inputs, dtype=np.float64).reshape(self.batchSize, self.inputChannels, self.imageHeight, self.imageWidth))
+        total, interval = X.shape[0], self.blockHeight * self.blockWidth
+        cs = (self.slotCount * 2) // interval
+        ctx = encoder.context
+        out = []
+        for c0 in range(0, self.inputChannels, cs):
+            c1 = min(c0 + cs, self.inputChannels)
+            cts = np.stack([encryptor.encrypt(encoder.encodePolynomial(X[b, c0:c1].reshape(-1), limbs, scale)) for b in range(total)])
+            out.append(api.Ciphertext.from_numpy(ctx, cts, True, scale, 1))
+        return out
+
+    def conv2d(self, evaluator, a):
+        """-> list over output channels of one batched ciphertext (sum over input-channel groups in order)"""
+        outs = []
+        for oc in range(self.outputChannels):
+            acc = None
+            for i, ai in enumerate(a):
+                prod = ai.copy()
+                evaluator.multiplyPlainInplace(prod, self.encodedWeights[oc][i], self.weightScale)
+                if acc is None:
+                    acc = prod
+                else:
+                    evaluator.addInplace(acc, prod)
+            outs.append(acc)
+        return outs
+
+    def decryptOutputs(self, evaluator, encoder, secret_key_dev, outputs):
+        """-> [batchSize][outputChannels][H-kh+1][W-kw+1] doubles"""
+        interval = self.blockHeight * self.blockWidth
+        cs = (self.slotCount * 2) // interval
+        yh, yw = self.blockHeight - self.kernelHeight + 1, self.blockWidth - self.kernelWidth + 1
+        oyh, oyw = self.imageHeight - self.kernelHeight + 1, self.imageWidth - self.kernelWidth + 1
+        sh, sw = self._grid() if self.blocked else (1, 1)
+        ret = np.zeros((self.batchSize, self.outputChannels, oyh, oyw))
+        for c in range(self.outputChannels):
+            pts = evaluator.decrypt(outputs[c], secret_key_dev)
+            for b in range(pts.shape[0]):
+                buf = encoder.decodePolynomial(pts[b], outputs[c].scale)
+                blk = buf[(cs - 1) * interval: cs * interval].reshape(self.blockHeight, self.blockWidth)[self.blockHeight - yh:, self.blockWidth - yw:]
+                ob, si, sj = b // (sh * sw), (b % (sh * sw)) // sw, b % sw
+                i1, j1 = min(si * yh + yh, oyh), min(sj * yw + yw, oyw)
+                if si * yh < oyh and sj * yw < oyw:
+                    ret[ob, c, si * yh: i1, sj * yw: j1] = blk[: i1 - si * yh, : j1 - sj * yw]
+        return ret
