@@ -43,7 +43,8 @@ def test_code_object_is_gfx950():
 def test_product_loader_refuses_emulated_library():
     emul = os.path.join(ROOT, "tests", "emul", "libtroyhip_emul.so")
     if not os.path.exists(emul):
-        pytest.skip("emulated library not built")
+        import subprocess
+        subprocess.check_call(["make", "-s", "-j8", "-C", os.path.join(ROOT, "troy_amd", "csrc"), "emul"])
     lib = ctypes.CDLL(emul)
     lib.troyhip_build_info.restype = ctypes.c_char_p
     assert lib.troyhip_build_info() != b"gfx950"  # capi.load() only accepts "gfx950" for the product path
