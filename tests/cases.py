@@ -316,18 +316,19 @@ def check_dense_multiply(cfg_name, batch=3):
     from oracle import ref as R
     N, L = cfg["N"], len(be.primes) - 1
     q = be.primes[:L]
+    ntt = cfg["scheme"] == CKKS
     xa, xb = synth.uniform_ct(881, q, 2, N, batch), synth.uniform_ct(882, q, 2, N, batch)
-    exp = [orc.impl.eval(R.OP_MULTIPLY, R.Ct(xa[i], False), R.Ct(xb[i], False)).data for i in range(batch)]
+    exp = [orc.impl.eval(R.OP_MULTIPLY, R.Ct(xa[i], ntt), R.Ct(xb[i], ntt)).data for i in range(batch)]
     for cap in (None, 3):
-        a = be.api.Ciphertext.from_numpy(be.ctx, xa, False, 1.0, 1, capacity=cap)
-        b = be.api.Ciphertext.from_numpy(be.ctx, xb, False, 1.0, 1, capacity=cap)
+        a = be.api.Ciphertext.from_numpy(be.ctx, xa, ntt, 1.0, 1, capacity=cap)
+        b = be.api.Ciphertext.from_numpy(be.ctx, xb, ntt, 1.0, 1, capacity=cap)
         m = be.ev.multiply(a, b).cpu()
         for i in range(batch):
             assert np.array_equal(m[i], exp[i]), (cap, i)
         assert np.array_equal(a.cpu(), xa) and np.array_equal(b.cpu(), xb)
         sq = be.ev.square(a).cpu()
         for i in range(batch):
-            assert np.array_equal(sq[i], orc.impl.eval(R.OP_SQUARE, R.Ct(xa[i], False)).data), (cap, i)
+            assert np.array_equal(sq[i], orc.impl.eval(R.OP_SQUARE, R.Ct(xa[i], ntt)).data), (cap, i)
 
 
 def check_gpu_decrypt(cfg_name, batch=3):

@@ -68,8 +68,9 @@ def test_emulated_plain_operands(name, emul_api, oracle_lib):
     cases.check_plain_monomial_and_batch(name)
 
 
-def test_emulated_dense_multiply(emul_api):
-    cases.check_dense_multiply("cfgA_bfv_n4096_k3", batch=2)
+@pytest.mark.parametrize("name", ["cfgA_bfv_n4096_k3", "bgv_n4096_k3", "ckks_n4096_k4"])
+def test_emulated_dense_multiply(name, emul_api):
+    cases.check_dense_multiply(name, batch=2)
 
 
 @pytest.mark.parametrize("name", ["bfv_n128_k4", "bgv_n128_k4", "ckks_n128_k6"])

@@ -313,7 +313,8 @@ def test_plain_operands_monomial_and_per_item(name, gpu, oracle_lib):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name,batch", [("bfv_n128_k4", 3), ("cfgA_bfv_n4096_k3", 3), ("cfgB_bfv_n8192_k5", 3), ("bfv_n16384_k4", 2), ("cfgNS_bfv_n32768_k15", 2)])
+@pytest.mark.parametrize("name,batch", [("bfv_n128_k4", 3), ("cfgA_bfv_n4096_k3", 3), ("cfgB_bfv_n8192_k5", 3), ("bfv_n16384_k4", 2), ("cfgNS_bfv_n32768_k15", 2),
+                                        ("bgv_n4096_k3", 3), ("bgv_n128_k4", 2), ("ckks_n4096_k4", 3)])
 def test_dense_and_strided_multiply(name, batch, gpu):
     """the last case is the benchmark's own configuration and operand layout (dense, fused tensor pass) at full size"""
     cases.check_dense_multiply(name, batch)

@@ -210,19 +210,33 @@ void Evaluator::multiply(const CtBatch &a, const CtBatch &b, CtBatch &out, u64 b
         if (!(a.ntt && b.ntt)) throw Error(ST_INVALID_ARGUMENT, "encrypted1 or encrypted2 must be in NTT form");
         new_scale = a.scale * b.scale;
         if (!scale_ok(new_scale, L)) throw Error(ST_INVALID_ARGUMENT, "scale out of bounds");
-        u64 *d = c.arena.take(batch * ds * pw);
-        launch_tensor(sa, sb, a.data, b.data, d, a.bstride, b.bstride, c.d_desc, qmap, c.logn, L, batch, s);
-        launch_copy_strided(d, ds * pw, out.data, out.bstride, ds * pw, batch, s);
+        if (out.data != a.data && out.data != b.data && out.bstride == (u64)ds * pw) {
+            // a fresh dense destination: the tensor writes it directly
+            launch_tensor(sa, sb, a.data, b.data, out.data, a.bstride, b.bstride, c.d_desc, qmap, c.logn, L, batch, s);
+        } else {
+            u64 *d = c.arena.take(batch * ds * pw);
+            launch_tensor(sa, sb, a.data, b.data, d, a.bstride, b.bstride, c.d_desc, qmap, c.logn, L, batch, s);
+            launch_copy_strided(d, ds * pw, out.data, out.bstride, ds * pw, batch, s);
+        }
     } else {
         if (a.ntt || b.ntt) throw Error(ST_INVALID_ARGUMENT, "encryped1 or encrypted2 must be not in NTT form");
+        // BGV (evaluator_cuda.cu:463-500): NTT -> tensor -> INTT.  Dense size-2 operands go through the fused transform + tensor
+        // pass pair (consumed in place, like the q base of the BFV path); a fresh dense destination is written directly.
         const int sp = sa + sb;
-        u64 *x = c.arena.take(batch * sp * pw), *d = c.arena.take(batch * ds * pw);
-        launch_copy_strided(a.data, a.bstride, x, sp * pw, sa * pw, batch, s);
-        launch_copy_strided(b.data, b.bstride, x + sa * pw, sp * pw, sb * pw, batch, s);
-        launch_ntt(x, c.d_desc, qmap, batch * sp * L, c.logn, false, s);
-        launch_tensor(sa, sb, x, x + sa * pw, d, sp * pw, sp * pw, c.d_desc, qmap, c.logn, L, batch, s);
+        const bool direct_out = out.data != a.data && out.data != b.data && out.bstride == (u64)ds * pw;
+        u64 *d = direct_out ? out.data : c.arena.take(batch * ds * pw);
+        if (a.bstride == (u64)sa * pw && b.bstride == (u64)sb * pw && sa == 2 && sb == 2 && ntt2_tensor_supported(c.logn) && tensor_fused()) {
+            u64 *xa = c.arena.take(batch * sa * pw), *xb = same ? xa : c.arena.take(batch * sb * pw);
+            launch_ntt2_tensor(xa, a.data, xb, b.data, d, c.d_desc, qmap, batch, c.logn, s);
+        } else {
+            u64 *x = c.arena.take(batch * sp * pw);
+            launch_copy_strided(a.data, a.bstride, x, sp * pw, sa * pw, batch, s);
+            launch_copy_strided(b.data, b.bstride, x + sa * pw, sp * pw, sb * pw, batch, s);
+            launch_ntt(x, c.d_desc, qmap, batch * sp * L, c.logn, false, s);
+            launch_tensor(sa, sb, x, x + sa * pw, d, sp * pw, sp * pw, c.d_desc, qmap, c.logn, L, batch, s);
+        }
         launch_ntt(d, c.d_desc, qmap, batch * ds * L, c.logn, true, s);
-        launch_copy_strided(d, ds * pw, out.data, out.bstride, ds * pw, batch, s);
+        if (!direct_out) launch_copy_strided(d, ds * pw, out.data, out.bstride, ds * pw, batch, s);
         new_cf = host::mul_mod(a.cf % c.t, b.cf % c.t, c.t);
     }
     out.size = ds;

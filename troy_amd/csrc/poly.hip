@@ -189,37 +189,37 @@ void launch_plain_lift(const u64 *plain, u64 *lifted, const PlainArgs &a, hipStr
 // One thread = one (b, l, n); all S1+S2 operands live in registers; 3..5 outputs.
 template <int S1, int S2> __global__ __launch_bounds__(EW_THREADS) void tensor_kernel(const u64 *a, const u64 *b, u64 *out, u64 a_bstride, u64 b_bstride,
                                                                                        const PrimeDesc *primes, LimbMap map, int logn, u64 limbs, u64 total) {
-    u64 i = (u64)blockIdx.x * EW_THREADS + threadIdx.x; // over batch * limbs * N
+    u64 i = ((u64)blockIdx.x * EW_THREADS + threadIdx.x) * 2; // over batch * limbs * N, two coefficients (16 bytes) per thread
     if (i >= total) return;
     const u64 N = u64(1) << logn;
     u64 n = i & (N - 1), bl = i >> logn, l = bl % limbs, bb = bl / limbs;
     const Mod m = mod_of(primes[map.id[l]]);
-    u64 x[S1], y[S2];
+    ulonglong2 x[S1], y[S2];
 #pragma unroll
-    for (int j = 0; j < S1; j++) x[j] = a[bb * a_bstride + (j * limbs + l) * N + n];
+    for (int j = 0; j < S1; j++) x[j] = *reinterpret_cast<const ulonglong2 *>(a + bb * a_bstride + (j * limbs + l) * N + n);
 #pragma unroll
-    for (int k = 0; k < S2; k++) y[k] = b[bb * b_bstride + (k * limbs + l) * N + n];
+    for (int k = 0; k < S2; k++) y[k] = *reinterpret_cast<const ulonglong2 *>(b + bb * b_bstride + (k * limbs + l) * N + n);
 #pragma unroll
     for (int d = 0; d < S1 + S2 - 1; d++) {
-        U128 acc{0, 0};
-        u64 r = 0;
+        ulonglong2 r{0, 0};
 #pragma unroll
         for (int j = 0; j < S1; j++) {
             const int k = d - j;
             if (k >= 0 && k < S2) {
                 // lazy operands (< 2^63 each) can make one product ~2^126: reduce each term
-                r = addmod(r, mulmod(x[j], y[k], m), m.p);
+                r.x = addmod(r.x, mulmod(x[j].x, y[k].x, m), m.p);
+                r.y = addmod(r.y, mulmod(x[j].y, y[k].y, m), m.p);
             }
         }
-        (void)acc;
-        out[(bb * (S1 + S2 - 1) + d) * limbs * N + l * N + n] = r;
+        *reinterpret_cast<ulonglong2 *>(out + (bb * (S1 + S2 - 1) + d) * limbs * N + l * N + n) = r;
     }
 }
 void launch_tensor(int s1, int s2, const u64 *a, const u64 *b, u64 *out, u64 a_bstride, u64 b_bstride, const PrimeDesc *primes, const LimbMap &map,
                    int logn, u64 limbs, u64 batch, hipStream_t s) {
     u64 total = (batch * limbs) << logn;
     if (!total) return;
-    dim3 grid(ceil_div(total, EW_THREADS)), blk(EW_THREADS);
+    if (logn < 1) throw Error(ST_LOGIC_ERROR, "tensor: N < 2");
+    dim3 grid(ceil_div(total / 2, EW_THREADS)), blk(EW_THREADS);
 #define TENSOR_CASE(A, B) if (s1 == A && s2 == B) { TROY_LAUNCH(HIP_KERNEL_NAME(tensor_kernel<A, B>), grid, blk, 0, s, a, b, out, a_bstride, b_bstride, primes, map, logn, limbs, total); launch_check("tensor_kernel"); return; }
     TENSOR_CASE(2, 2) TENSOR_CASE(2, 3) TENSOR_CASE(3, 2) TENSOR_CASE(3, 3) TENSOR_CASE(1, 1) TENSOR_CASE(1, 2) TENSOR_CASE(2, 1) TENSOR_CASE(1, 3) TENSOR_CASE(3, 1)
 #undef TENSOR_CASE
