@@ -58,6 +58,10 @@ const char *troyhip_last_error(void);
 const char *troyhip_build_info(void);               /* "gfx950" for the product build */
 int troyhip_malloc(void **out, size_t bytes);       /* KernelProvider::malloc */
 int troyhip_free(void *p);                          /* KernelProvider::free */
+/* malloc/free go through a caching pool with the reference's MemoryPoolCuda policy (src/utils/memorypool_cuda.cuh:40-58): a freed
+ * block serves a later request of size <= block <= 2 * size.  Reuse is stream-ordered: do not free a buffer that work on ANOTHER
+ * stream still uses.  troyhip_pool_release synchronises the device and returns every cached block to the driver. */
+int troyhip_pool_release(void);
 int troyhip_copy_h2d(void *dst, const void *src, size_t bytes, void *stream);   /* KernelProvider::copy */
 int troyhip_copy_d2h(void *dst, const void *src, size_t bytes, void *stream);   /* KernelProvider::retrieve */
 int troyhip_copy_d2d(void *dst, const void *src, size_t bytes, void *stream);   /* KernelProvider::copyOnDevice */

@@ -52,7 +52,7 @@ class ContextInfo(C.Structure):
 # every symbol include/troyhip.h declares (tests/test_cabi_symbols.py checks the header against this list)
 SYMBOLS = [
     "troyhip_initialize", "troyhip_is_initialized", "troyhip_last_error", "troyhip_build_info", "troyhip_malloc",
-    "troyhip_free", "troyhip_copy_h2d", "troyhip_copy_d2h", "troyhip_copy_d2d", "troyhip_memset_zero",
+    "troyhip_free", "troyhip_pool_release", "troyhip_copy_h2d", "troyhip_copy_d2h", "troyhip_copy_d2d", "troyhip_memset_zero",
     "troyhip_stream_synchronize", "troyhip_stream_create", "troyhip_stream_destroy", "troyhip_mem_info", "troyhip_timer_create", "troyhip_timer_destroy",
     "troyhip_timer_start", "troyhip_timer_stop", "troyhip_timer_elapsed_ms", "troyhip_coeff_modulus_create",
     "troyhip_plain_modulus_batching", "troyhip_context_create", "troyhip_context_create_host", "troyhip_context_destroy",

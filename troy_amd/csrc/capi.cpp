@@ -4,6 +4,8 @@
 #include "kernels.h"
 #include "hostcrypto.h"
 #include <atomic>
+#include <map>
+#include <mutex>
 #include <cstring>
 #include <string>
 
@@ -71,8 +73,51 @@ const char *troyhip_build_info(void) {
     return "gfx950";
 #endif
 }
-int troyhip_malloc(void **out, size_t bytes) { return guard([&] { if (!out) throw Error(ST_INVALID_ARGUMENT, "null"); HIP_CHECK(hipMalloc(out, bytes ? bytes : 8)); }); }
-int troyhip_free(void *p) { return guard([&] { if (p) (void)hipFree(p); }); }
+// KernelProvider::malloc / free behind the reference's MemoryPoolCuda policy (src/utils/memorypool_cuda.cuh:40-58): a freed
+// block is kept and handed out again to a request of size <= block <= 2 * size; everything cached is released when the device
+// runs short.  hipMalloc / hipFree synchronise the device, a pooled pair does not; reuse is stream-ordered, so a block must not
+// be freed while work on ANOTHER stream still uses it (the reference's pool has the same contract).  Thread-safe.
+namespace {
+struct DevicePool {
+    std::mutex mu;
+    std::multimap<size_t, void *> free_blocks;
+    std::map<void *, size_t> live;
+    void *get(size_t bytes) {
+        std::lock_guard<std::mutex> g(mu);
+        auto it = free_blocks.lower_bound(bytes);
+        if (it != free_blocks.end() && it->first <= 2 * bytes) {
+            void *p = it->second;
+            live[p] = it->first;
+            free_blocks.erase(it);
+            return p;
+        }
+        void *p = nullptr;
+        if (hipMalloc(&p, bytes) != hipSuccess) { // release the cache and retry once
+            (void)hipGetLastError();
+            release_locked();
+            HIP_CHECK(hipMalloc(&p, bytes));
+        }
+        live[p] = bytes;
+        return p;
+    }
+    void put(void *p) {
+        std::lock_guard<std::mutex> g(mu);
+        auto it = live.find(p);
+        if (it == live.end()) { (void)hipFree(p); return; } // not ours (defensive)
+        free_blocks.emplace(it->second, p);
+        live.erase(it);
+    }
+    void release_locked() {
+        for (auto &kv : free_blocks) (void)hipFree(kv.second);
+        free_blocks.clear();
+    }
+    void release() { std::lock_guard<std::mutex> g(mu); release_locked(); }
+    static DevicePool &instance() { static DevicePool p; return p; }
+};
+} // namespace
+int troyhip_malloc(void **out, size_t bytes) { return guard([&] { if (!out) throw Error(ST_INVALID_ARGUMENT, "null"); *out = DevicePool::instance().get(bytes ? bytes : 8); }); }
+int troyhip_free(void *p) { return guard([&] { if (p) DevicePool::instance().put(p); }); }
+int troyhip_pool_release(void) { return guard([&] { HIP_CHECK(hipDeviceSynchronize()); DevicePool::instance().release(); }); }
 int troyhip_copy_h2d(void *dst, const void *src, size_t bytes, void *stream) {
     return guard([&] { HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream)); HIP_CHECK(hipStreamSynchronize((hipStream_t)stream)); });
 }
