@@ -10,12 +10,14 @@
 //
 // compiles against it.  Key generation, encryption and decryption run on the CPU (as KeyGeneratorCuda does in the
 // reference, src/keygenerator_cuda.cuh); everything in EvaluatorCuda's hot path runs on the GPU.  Out of scope here
-// exactly as in SURVEY.md section 2: encoders (BatchEncoder/CKKSEncoder), serialization, symmetric encryption.
+// exactly as in SURVEY.md section 2: encoders (BatchEncoder/CKKSEncoder), key serialization, symmetric encryption.
 // No HIP headers are needed: the ABI is plain pointers, sizes and status codes.
 #pragma once
 #include "troyhip.h"
 #include <algorithm>
 #include <cstdint>
+#include <istream>
+#include <ostream>
 #include <map>
 #include <memory>
 #include <stdexcept>
@@ -209,6 +211,12 @@ public:
     }
     troyhip_ct *raw() { d_.data = buf_.get(); return &d_; }
     const troyhip_ct *raw() const { return &d_; }
+    // wire format of CiphertextCuda::save / load / saveTerms / loadTerms (src/ciphertext_cuda.cu:16-143); the context supplies
+    // the 256-bit parms_id the reference object carries itself (defined after Evaluator below)
+    inline void save(std::ostream &stream, const SEALContext &context) const;
+    inline void load(std::istream &stream, const SEALContext &context);
+    inline void saveTerms(std::ostream &stream, const SEALContext &context, const class Evaluator &evaluator, const std::vector<size_t> &termIds) const;
+    inline void loadTerms(std::istream &stream, const SEALContext &context, const class Evaluator &evaluator, const std::vector<size_t> &termIds);
     // value semantics: deep copy
     Ciphertext(const Ciphertext &o) : buf_(o.buf_), d_(o.d_), n_(o.n_) { d_.data = buf_.get(); }
     Ciphertext(Ciphertext &&o) noexcept = default;
@@ -462,5 +470,85 @@ private:
     }
     const SEALContext &c_;
 };
+
+// ---- ciphertext serialization: a raw little-endian field dump (src/serialize.h savet/loadt)
+namespace wire {
+template <class T> inline void put(std::ostream &s, const T &v) { s.write(reinterpret_cast<const char *>(&v), sizeof(T)); }
+template <class T> inline T get(std::istream &s) {
+    T v{};
+    s.read(reinterpret_cast<char *>(&v), sizeof(T));
+    if (!s) throw std::invalid_argument("stream ended inside a ciphertext");
+    return v;
+}
+struct Header { bool ntt; size_t size, n, limbs; double scale; uint64_t cf, seed; bool terms; };
+inline void put_header(std::ostream &s, const SEALContext &c, const Ciphertext &ct, bool terms) {
+    uint64_t id[4];
+    check(troyhip_context_parms_id(c.handle(), (int)ct.coeffModulusSize(), id));
+    s.write(reinterpret_cast<const char *>(id), 32);
+    put<bool>(s, ct.isNttForm()); put<size_t>(s, ct.size()); put<size_t>(s, ct.polyModulusDegree()); put<size_t>(s, ct.coeffModulusSize());
+    put<double>(s, ct.scale()); put<uint64_t>(s, ct.correctionFactor()); put<uint64_t>(s, 0); put<bool>(s, terms);
+}
+inline Header get_header(std::istream &s, const SEALContext &c) {
+    uint64_t id[4], mine[4];
+    s.read(reinterpret_cast<char *>(id), 32);
+    Header h;
+    h.ntt = get<bool>(s); h.size = get<size_t>(s); h.n = get<size_t>(s); h.limbs = get<size_t>(s);
+    h.scale = get<double>(s); h.cf = get<uint64_t>(s); h.seed = get<uint64_t>(s); h.terms = get<bool>(s);
+    if (h.n != c.polyModulusDegree() || h.limbs < 1 || h.limbs > c.keyLimbs() || h.size < 1) throw std::invalid_argument("encrypted is not valid for encryption parameters");
+    check(troyhip_context_parms_id(c.handle(), (int)h.limbs, mine));
+    if (!std::equal(id, id + 4, mine)) throw std::invalid_argument("encrypted is not valid for encryption parameters");
+    if (h.seed) throw std::invalid_argument("seed is not zero.");
+    return h;
+}
+} // namespace wire
+
+inline void Ciphertext::save(std::ostream &stream, const SEALContext &context) const {
+    wire::put_header(stream, context, *this, false);
+    const std::vector<uint64_t> h = toHost();
+    wire::put<size_t>(stream, h.size());
+    stream.write(reinterpret_cast<const char *>(h.data()), (std::streamsize)(h.size() * 8));
+}
+inline void Ciphertext::load(std::istream &stream, const SEALContext &context) {
+    const wire::Header h = wire::get_header(stream, context);
+    if (h.terms) throw std::invalid_argument("Trying to load a termed ciphertext, but indices is not specified");
+    const size_t words = wire::get<size_t>(stream);
+    if (words != h.size * h.limbs * h.n) throw std::invalid_argument("encrypted is not valid for encryption parameters");
+    std::vector<uint64_t> host(words);
+    stream.read(reinterpret_cast<char *>(host.data()), (std::streamsize)(words * 8));
+    if (!stream) throw std::invalid_argument("stream ended inside a ciphertext");
+    fromHost(host, h.n, h.limbs, h.size, h.ntt, h.scale, h.cf);
+}
+inline void Ciphertext::saveTerms(std::ostream &stream, const SEALContext &context, const Evaluator &evaluator, const std::vector<size_t> &termIds) const {
+    std::vector<uint64_t> h;
+    if (isNttForm()) {
+        Ciphertext copy = *this;
+        evaluator.transformFromNttInplace(copy);
+        h = copy.toHost();
+    } else h = toHost();
+    wire::put_header(stream, context, *this, true);
+    const size_t n = polyModulusDegree(), limbs = coeffModulusSize();
+    for (size_t id : termIds) {
+        if (id >= n) throw std::invalid_argument("term index out of range");
+        for (size_t j = 0; j < limbs; j++) wire::put<uint64_t>(stream, h[j * n + id]);
+    }
+    const size_t offset = n * limbs;
+    wire::put<size_t>(stream, h.size() - offset);
+    stream.write(reinterpret_cast<const char *>(h.data() + offset), (std::streamsize)((h.size() - offset) * 8));
+}
+inline void Ciphertext::loadTerms(std::istream &stream, const SEALContext &context, const Evaluator &evaluator, const std::vector<size_t> &termIds) {
+    const wire::Header h = wire::get_header(stream, context);
+    if (!h.terms) throw std::invalid_argument("Trying to load a normal ciphertext, but term indices is specified");
+    std::vector<uint64_t> host(h.size * h.limbs * h.n, 0); // unlisted coefficients of c0: zero
+    for (size_t id : termIds) {
+        if (id >= h.n) throw std::invalid_argument("term index out of range");
+        for (size_t j = 0; j < h.limbs; j++) host[j * h.n + id] = wire::get<uint64_t>(stream);
+    }
+    const size_t offset = h.n * h.limbs, words = wire::get<size_t>(stream);
+    if (words != host.size() - offset) throw std::invalid_argument("encrypted is not valid for encryption parameters");
+    stream.read(reinterpret_cast<char *>(host.data() + offset), (std::streamsize)(words * 8));
+    if (!stream) throw std::invalid_argument("stream ended inside a ciphertext");
+    fromHost(host, h.n, h.limbs, h.size, false, h.scale, h.cf);
+    if (h.ntt) evaluator.transformToNttInplace(*this);
+}
 
 } // namespace troyn

@@ -431,8 +431,17 @@ def check_ckks_matmul_helper(N=4096, bits=(40, 30, 30, 40), batch=3, dims=(128, 
     h.encodeWeights(encoder, L, W, 2.0 ** 22)
     a = h.encryptInputs(enc, encoder, L, X, 2.0 ** 22)
     out = h.matmul(ev, a)
-    got = h.decryptOutputs(ev, encoder, api.DeviceBuffer.from_numpy(kg.secretKey()), out)
+    sk = api.DeviceBuffer.from_numpy(kg.secretKey())
+    got = h.decryptOutputs(ev, encoder, sk, out)
     assert np.max(np.abs(got - X @ W)) < 1e-3, np.max(np.abs(got - X @ W))
+    # serializeOutputs / deserializeOutputs (saveTerms / loadTerms): only the read coefficients of c0 travel, same answer
+    import io
+    stream = io.BytesIO()
+    h.serializeOutputs(ev, out, stream)
+    full = sum(2 * o.limbs * N * 8 * o.batch for o in out)
+    assert len(stream.getvalue()) < 0.6 * full + 200 * batch * len(out)
+    again = h.deserializeOutputs(ev, ctx, io.BytesIO(stream.getvalue()))
+    assert np.array_equal(h.decryptOutputs(ev, encoder, sk, again), got)
 
 
 def check_lwe_pack(scheme=BFV, N=256, bits=(40, 40, 40, 40), tbits=14, n_lwe=5, batch=2):
@@ -496,7 +505,13 @@ def check_ckks_conv2d_helper(N=4096, bits=(40, 30, 30, 40), batch=2, image=(12, 
     h = app.Conv2dHelper(batch, H, Wd, kh, kw, ic, oc, N // 2)
     h.encodeWeights(encoder, L, Wt, 2.0 ** 22)
     a = h.encryptInputs(enc, encoder, L, X, 2.0 ** 22)
-    got = h.decryptOutputs(ev, encoder, skd, h.conv2d(ev, a))
+    out = h.conv2d(ev, a)
+    got = h.decryptOutputs(ev, encoder, skd, out)
+    import io
+    stream = io.BytesIO()
+    h.serializeOutputs(ev, out, stream)  # saveTerms: the last channel slot of c0 only
+    again = h.deserializeOutputs(ev, ctx, io.BytesIO(stream.getvalue()))
+    assert np.array_equal(h.decryptOutputs(ev, encoder, skd, again), got)
     exp = np.zeros((batch, oc, H - kh + 1, Wd - kw + 1))
     for b in range(batch):
         for o in range(oc):

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <random>
+#include <sstream>
 
 using namespace troyn;
 
@@ -139,6 +140,29 @@ static void scenario(SchemeType scheme, size_t n, std::vector<int> bits, int tbi
         Poly x5(n, 0);
         x5[5] = 1;
         EXPECT(out == Plaintext(negacyclic_mul(x5, va, t)), "negacyclicShift(5) == times x^5");
+    }
+
+    // save / load and saveTerms / loadTerms (src/ciphertext_cuda.cu:16-143)
+    {
+        std::stringstream ss;
+        c.save(ss, context);
+        Ciphertext back;
+        back.load(ss, context);
+        EXPECT(back.toHost() == c.toHost() && back.size() == c.size() && back.isNttForm() == c.isNttForm(), "save -> load round trip");
+        std::stringstream st;
+        const std::vector<size_t> terms = {0, 7, n - 1};
+        c.saveTerms(st, context, evaluator, terms);
+        EXPECT(st.str().size() < ss.str().size(), "saveTerms writes less than save");
+        Ciphertext part;
+        part.loadTerms(st, context, evaluator, terms);
+        decryptor.decrypt(part, out);
+        bool ok = true;
+        for (size_t id : terms) ok = ok && out[id] == prod[id];
+        EXPECT(ok, "loadTerms keeps the listed coefficients of the plaintext");
+        bool threw2 = false;
+        std::stringstream again(ss.str());
+        try { part.loadTerms(again, context, evaluator, terms); } catch (const std::invalid_argument &) { threw2 = true; }
+        EXPECT(threw2, "loadTerms on a full ciphertext -> invalid_argument");
     }
 
     // mod switch keeps the plaintext

@@ -220,6 +220,66 @@ class Ciphertext:
         data = np.frombuffer(stream.read(8 * words), dtype=np.uint64).reshape(1, size, limbs, n)
         return cls.from_numpy(context, data, ntt, scale, cf)
 
+    # CiphertextCuda::saveTerms / loadTerms (src/ciphertext_cuda.cu:44-80, 106-143): the sender of a matmul/conv result keeps
+    # only the coefficients of c0 the receiver will read.  Same header with terms = 1; then, in coefficient form, c0 as
+    # [term][limb] words for the listed terms, the word count of the remaining polynomials, and c1.. in full.
+    def coeff_host(self, evaluator):
+        """host copy [batch][size][limbs][N] in coefficient form (what saveTerms writes from)"""
+        return (evaluator.transformFromNtt(self) if self.is_ntt_form else self).cpu()
+
+    def saveTerms(self, stream, evaluator, term_ids, index=0, coeff_host=None):
+        import struct
+        ctx = self.context
+        data = (self.coeff_host(evaluator) if coeff_host is None else coeff_host)[index]
+        pid = np.zeros(4, dtype=np.uint64)
+        capi.check(ctx.lib, ctx.lib.troyhip_context_parms_id(ctx.h, int(self.limbs), _u64p(pid)))
+        stream.write(pid.tobytes())
+        stream.write(struct.pack("<?QQQdQQ?", bool(self.is_ntt_form), self._size, ctx.N, self.limbs, float(self.scale), int(self.correction_factor), 0, True))
+        ids = np.asarray(list(term_ids), dtype=np.int64)
+        if ids.size and (ids.min() < 0 or ids.max() >= ctx.N):
+            raise capi.InvalidArgument(capi.INVALID_ARGUMENT, "term index out of range")
+        stream.write(np.ascontiguousarray(data[0][:, ids].T).tobytes())  # [term][limb]
+        rest = np.ascontiguousarray(data[1:])
+        stream.write(struct.pack("<Q", rest.size))
+        stream.write(rest.tobytes())
+
+    @classmethod
+    def loadTerms(cls, context, stream, evaluator, term_ids):
+        """the unlisted coefficients of c0 are zero (the reference leaves them unspecified)"""
+        data, ntt, scale, cf = cls.load_terms_host(context, stream, term_ids)
+        ct = cls.from_numpy(context, data, False, scale, cf)
+        if ntt:
+            evaluator.transformToNttInplace(ct)
+        return ct
+
+    @staticmethod
+    def load_terms_host(context, stream, term_ids):
+        """-> (coefficient-form data [1][size][limbs][N], is_ntt_form, scale, correction_factor)"""
+        import struct
+        pid = np.frombuffer(stream.read(32), dtype=np.uint64)
+        ntt, size, n, limbs, scale, cf, seed, terms = struct.unpack("<?QQQdQQ?", stream.read(struct.calcsize("<?QQQdQQ?")))
+        if not terms:
+            raise capi.InvalidArgument(capi.INVALID_ARGUMENT, "Trying to load a normal ciphertext, but term indices is specified")
+        if seed:
+            raise capi.InvalidArgument(capi.INVALID_ARGUMENT, "seed is not zero.")
+        if n != context.N or limbs < 1 or limbs > context.key_limbs or size < 1:
+            raise capi.InvalidArgument(capi.INVALID_ARGUMENT, "encrypted is not valid for encryption parameters")
+        mine = np.zeros(4, dtype=np.uint64)
+        capi.check(context.lib, context.lib.troyhip_context_parms_id(context.h, int(limbs), _u64p(mine)))
+        if not np.array_equal(mine, pid):
+            raise capi.InvalidArgument(capi.INVALID_ARGUMENT, "encrypted is not valid for encryption parameters")
+        ids = np.asarray(list(term_ids), dtype=np.int64)
+        if ids.size and (ids.min() < 0 or ids.max() >= n):
+            raise capi.InvalidArgument(capi.INVALID_ARGUMENT, "term index out of range")
+        data = np.zeros((1, size, limbs, n), dtype=np.uint64)
+        c0 = np.frombuffer(stream.read(8 * ids.size * limbs), dtype=np.uint64).reshape(ids.size, limbs)
+        data[0, 0][:, ids] = c0.T
+        (words,) = struct.unpack("<Q", stream.read(8))
+        if words != (size - 1) * limbs * n:
+            raise capi.InvalidArgument(capi.INVALID_ARGUMENT, "encrypted is not valid for encryption parameters")
+        data[0, 1:] = np.frombuffer(stream.read(8 * words), dtype=np.uint64).reshape(size - 1, limbs, n)
+        return data, ntt, scale, cf
+
     def cpu_poly_view(self):
         """host copy [batch][size][limbs][N] (alias of cpu(), named for the LWE helpers)"""
         return self.cpu()

@@ -89,6 +89,32 @@ def _ceil_div(a, b):
     return (a + b - 1) // b
 
 
+def _serialize_terms(evaluator, outputs, required_of, stream):
+    """stream order of the reference (batch outer, output block / channel inner); each batched ciphertext is brought to
+    coefficient form ONCE"""
+    hosts = [ct.coeff_host(evaluator) for ct in outputs]
+    for b in range(outputs[0].batch):
+        for cid, ct in enumerate(outputs):
+            ct.saveTerms(stream, evaluator, required_of(cid), index=b, coeff_host=hosts[cid])
+
+
+def _deserialize_terms(evaluator, context, batch, count, required_of, stream):
+    parts = [[None] * batch for _ in range(count)]
+    meta = [None] * count
+    for b in range(batch):
+        for cid in range(count):
+            data, ntt, scale, cf = api.Ciphertext.load_terms_host(context, stream, required_of(cid))
+            parts[cid][b], meta[cid] = data[0], (ntt, scale, cf)
+    outs = []
+    for cid in range(count):
+        ntt, scale, cf = meta[cid]
+        ct = api.Ciphertext.from_numpy(context, np.stack(parts[cid]), False, scale, cf)
+        if ntt:
+            evaluator.transformToNttInplace(ct)
+        outs.append(ct)
+    return outs
+
+
 class MatmulHelper:
     """app/LinearHelperCKKS.cuh:104-360, same packing: an input block of `blockHeight` entries is a polynomial x_0 + x_1 X + ..,
     a weight block (h x w) puts W[i][j] at degree j*h + h-1-i, so that coefficient (j+1)*h - 1 of the product is sum_i x_i W[i][j]."""
@@ -168,6 +194,18 @@ class MatmulHelper:
                 for j in range(li, ui):
                     dec[b, j] = buf[(j - li + 1) * interval - 1]
         return dec
+
+    def _required(self, cid):  # LinearHelperCKKS.cuh:326-337: coefficient (j+1)*blockHeight - 1 of output block cid
+        li = cid * self.blockWidth
+        ui = min(li + self.blockWidth, self.outputDims)
+        return [(j - li + 1) * self.blockHeight - 1 for j in range(li, ui)]
+
+    def serializeOutputs(self, evaluator, outputs, stream):
+        """LinearHelperCKKS.cuh:326-339: only the coefficients decryptOutputs reads travel (saveTerms)"""
+        _serialize_terms(evaluator, outputs, self._required, stream)
+
+    def deserializeOutputs(self, evaluator, context, stream):  # LinearHelperCKKS.cuh:341-358
+        return _deserialize_terms(evaluator, context, self.batchSize, _ceil_div(self.outputDims, self.blockWidth), self._required, stream)
 
 
 class Conv2dHelper:
@@ -276,3 +314,14 @@ class Conv2dHelper:
                 if si * yh < oyh and sj * yw < oyw:
                     ret[ob, c, si * yh: i1, sj * yw: j1] = blk[: i1 - si * yh, : j1 - sj * yw]
         return ret
+
+    def _required(self, cid):  # LinearHelperCKKS.cuh:684-690: the last channel slot of every output polynomial
+        interval = self.blockHeight * self.blockWidth
+        st = ((self.slotCount * 2) // interval - 1) * interval
+        return list(range(st, st + interval))
+
+    def serializeOutputs(self, evaluator, outputs, stream):  # LinearHelperCKKS.cuh:684-696
+        _serialize_terms(evaluator, outputs, self._required, stream)
+
+    def deserializeOutputs(self, evaluator, context, stream):  # LinearHelperCKKS.cuh:698-713
+        return _deserialize_terms(evaluator, context, self.getTotalBatchSize(), self.outputChannels, self._required, stream)
