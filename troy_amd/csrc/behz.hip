@@ -259,6 +259,25 @@ __global__ __launch_bounds__(BEHZ_THREADS) void behz_floor_sk_kernel(const u64 *
 // Per (coefficient, output) the VALU does ~70 instructions instead of 14 x 6 v_mad_u64_u32 + ~65; the 14 x 15 x 64
 // byte products run on the matrix cores (32 MFMA per 32 coefficients, 2 k cycles of the MFMA pipe per 32 coefficients).
 #define BEHZ_TILE 64
+// probe hooks (tools/behz_probe.sh builds throw-away variants): bit0 no HBM loads, bit1 no MFMA, bit2 no recombine/reduce
+// epilogue, bit3 no workgroup barriers, bit4 no HBM stores.  0 in the product.
+#ifndef BEHZ_TPW
+#define BEHZ_TPW 8 // tiles per workgroup
+#endif
+#ifndef BEHZ_EXP
+#define BEHZ_EXP 0
+#endif
+#define BEHZ_MFMA(fa, fb, fc)                                                                                             \
+    do {                                                                                                                 \
+        if (BEHZ_EXP & 2) (fc).v[0] += (fb).bytes[0] + (fa).bytes[0];                                                    \
+        else TROY_MFMA_I8(fa, fb, fc);                                                                                   \
+    } while (0)
+#define BEHZ_SYNC()                                                                                                       \
+    do {                                                                                                                 \
+        if (!(BEHZ_EXP & 8)) __syncthreads();                                                                            \
+    } while (0)
+#define BEHZ_LOAD(expr, fake) ((BEHZ_EXP & 1) ? (u64)(fake) : (expr))
+#define BEHZ_LIVE(cond, r) ((BEHZ_EXP & 16) ? (r) == ~0ull : (cond))
 __device__ __forceinline__ void mfma_zero(MfmaAcc &a) {
 #pragma unroll
     for (int r = 0; r < 16; r++) a.v[r] = 0;
@@ -304,6 +323,14 @@ __device__ __forceinline__ u64 reduce128c(const U128 v, const BehzOutConst &k) {
     return s >= k.p ? s - k.p : s;
 }
 
+// (sum of the 16 shift coefficients) + x * y, reduced: one output residue
+__device__ __forceinline__ u64 behz_finish(const MfmaAcc &acc, u64 x, u64 y, const BehzOutConst &k) {
+    if (BEHZ_EXP & 4) return (u64)(u32)acc.v[0] ^ x ^ ((u64)(u32)acc.v[15] << 32);
+    U128 v = mfma_recombine(acc);
+    add128(v, x, y);
+    return reduce128c(v, k);
+}
+
 // same contract as behz_extend_kernel; a 256-thread workgroup walks `tiles_per_wg` tiles of 64 coefficients of one
 // polynomial; wave w owns row-blocks w and w + 4 (outputs 2w, 2w+1, 2w+8, 2w+9) and keeps their A-fragments in registers
 template <int KB> __global__ __launch_bounds__(BEHZ_THREADS) void behz_extend_mfma_kernel(const u64 *in, u64 in_pstride, u64 *out, u64 out_pstride, const PrimeDesc *primes,
@@ -313,7 +340,10 @@ template <int KB> __global__ __launch_bounds__(BEHZ_THREADS) void behz_extend_mf
     const unsigned lane = threadIdx.x & 63, half = lane >> 5, cl = lane & 31;
     const int w = BEHZ_UNIFORM((int)(threadIdx.x >> 6));
     const u64 poly = blockIdx.y;
-    const u64 *x = in + poly * in_pstride;
+    // ragged edges (padding limbs, absent outputs, a short last tile) are handled by the buffer range check, not by branches
+    const BufRsrc rin = make_rsrc(in + poly * in_pstride, (u32)((u64)c.L * N * 8));
+    const BufRsrc rout = make_rsrc(out + poly * out_pstride, (u32)((u64)c.nBsk * N * 8));
+    const u32 n32 = (u32)N;
     const int RB = (c.nBsk + 1) >> 1;
     const cshoup_ptr ext_pre = (cshoup_ptr)c.ext_pre;
     if ((int)threadIdx.x < c.nBsk) {
@@ -344,29 +374,33 @@ template <int KB> __global__ __launch_bounds__(BEHZ_THREADS) void behz_extend_mf
         qpre[i] = ld_shoup(ext_pre + lc);
     }
     u64 xr[KB];
-    auto fetch = [&](unsigned t) {
-        const u64 n0 = ((u64)blockIdx.x * tiles_per_wg + t) * BEHZ_TILE;
+    auto fetch = [&](unsigned t) { // a tile beyond N, a padding limb: offset out of range, the load returns 0
+        const u32 n = (blockIdx.x * tiles_per_wg + t) * BEHZ_TILE + lane;
 #pragma unroll
         for (int i = 0; i < KB; i++) {
-            const int l = w + 4 * i;
-            xr[i] = (l < c.L && n0 + lane < N) ? x[(u64)l * N + n0 + lane] : 0;
+            const u32 l = (u32)(w + 4 * i);
+            xr[i] = BEHZ_LOAD(buf_load_u64(rin, (l < (u32)c.L && n < n32) ? (l * n32 + n) * 8u : TROY_BUF_OOB), (lane + n) * 0x9E3779B97F4Aull + l);
         }
     };
     fetch(0);
+    // the loop below waits for the prefetched residues with "all but the stores issued after them"; on entry no store is in
+    // flight yet, and the compiler merges both cases into a full drain (vmcnt(0)) unless the entry looks the same: four
+    // out-of-range stores (dropped by the range check) stand in for the previous tile's
+#pragma unroll
+    for (int i = 0; i < 4; i++) buf_store_u64(rout, TROY_BUF_OOB + 8 * i, 0);
     for (unsigned t = 0; t < tiles_per_wg; t++) {
-        const u64 n0 = ((u64)blockIdx.x * tiles_per_wg + t) * BEHZ_TILE;
-        if (n0 >= N) break;
-        // y_l = x_l * m_tilde * (q/q_l)^-1 mod q_l, stored as balanced digits; limbs L..4KB-1 are zero padding
+        const u32 n0 = (blockIdx.x * tiles_per_wg + t) * BEHZ_TILE;
+        if (n0 >= n32) break;
+        // y_l = x_l * m_tilde * (q/q_l)^-1 mod q_l, stored as balanced digits; limbs L..4KB-1 are zero padding (loaded as 0)
 #pragma unroll
         for (int i = 0; i < KB; i++) {
             const int l = w + 4 * i;
-            u64 v = 0;
-            if (l < c.L && n0 + lane < N) v = (mul_shoup(xr[i], qpre[i].op, qpre[i].quo, qp[i]) + c80) ^ c80;
+            const u64 v = (mul_shoup(xr[i], qpre[i].op, qpre[i].quo, qp[i]) + c80) ^ c80;
             ydig[(((l >> 1) * BEHZ_TILE) + lane) * 2 + (l & 1)] = v;
         }
-        if (t + 1 < tiles_per_wg) fetch(t + 1);
-        __syncthreads();
-#pragma unroll 1
+        fetch(t + 1 < tiles_per_wg ? t + 1 : 0x7FFFFFu); // past the last tile: out of range
+        BEHZ_SYNC();
+#pragma unroll
         for (int sub = 0; sub < BEHZ_TILE / 32; sub++) {
             const unsigned cc = sub * 32 + cl;
             MfmaFrag bf[KB];
@@ -376,28 +410,29 @@ template <int KB> __global__ __launch_bounds__(BEHZ_THREADS) void behz_extend_mf
             MfmaAcc acc;
             mfma_zero(acc);
 #pragma unroll
-            for (int kb = 0; kb < KB; kb++) TROY_MFMA_I8(am[kb], bf[kb], acc);
+            for (int kb = 0; kb < KB; kb++) BEHZ_MFMA(am[kb], bf[kb], acc);
             const u32 rsum = (u32)acc.v[0] + ((u32)acc.v[1] << 8) + ((u32)acc.v[2] << 16) + ((u32)acc.v[3] << 24);
             const u64 r_mt = ((u64)rsum * c.neg_inv_q_mod_mt) & 0xFFFFFFFFull;
 #pragma unroll
             for (int j = 0; j < 2; j++) {
-                if (w + 4 * j >= RB) break;
-                mfma_zero(acc);
+                // the store is issued on both sides of the (wave-uniform) branch, so the number of stores in flight is a constant
+                u64 r = 0;
+                u32 off = TROY_BUF_OOB;
+                if (w + 4 * j < RB) {
+                    mfma_zero(acc);
 #pragma unroll
-                for (int kb = 0; kb < KB; kb++) TROY_MFMA_I8(af[j][kb], bf[kb], acc);
-                const int o = 2 * (w + 4 * j) + (int)half;
-                if (o < c.nBsk) {
-                    const BehzOutConst k = oc[o];
+                    for (int kb = 0; kb < KB; kb++) BEHZ_MFMA(af[j][kb], bf[kb], acc);
+                    const u32 o = 2 * (u32)(w + 4 * j) + half;
+                    const BehzOutConst k = oc[o < (u32)c.nBsk ? o : 0];
                     u64 temp = r_mt;                                   // centred representative of r (rns.cpp:966-975)
                     if (temp >= (u64(1) << 31)) temp += k.p - (u64(1) << 32);
-                    U128 v = mfma_recombine(acc);
-                    add128(v, temp, k.extra);
-                    const u64 r = reduce128c(v, k);
-                    if (n0 + cc < N) out[poly * out_pstride + (u64)o * N + n0 + cc] = r;
+                    r = behz_finish(acc, temp, k.extra, k);
+                    if (BEHZ_LIVE(o < (u32)c.nBsk && n0 + cc < n32, r)) off = (o * n32 + n0 + cc) * 8u;
                 }
+                buf_store_u64(rout, off, r);
             }
         }
-        __syncthreads();
+        BEHZ_SYNC();
     }
 }
 
@@ -421,9 +456,18 @@ template <int KB> __global__ __launch_bounds__(BEHZ_THREADS) void behz_floor_sk_
     const unsigned lane = threadIdx.x & 63, half = lane >> 5, cl = lane & 31;
     const int w = BEHZ_UNIFORM((int)(threadIdx.x >> 6));
     const u64 poly = blockIdx.y;
-    const u64 *xq = dq + poly * dq_pstride, *xb = db + poly * db_pstride;
+    const BufRsrc rq = make_rsrc(dq + poly * dq_pstride, (u32)((u64)c.L * N * 8));
+    const BufRsrc rb = make_rsrc(db + poly * db_pstride, (u32)((u64)c.nBsk * N * 8));
+    const BufRsrc rout = make_rsrc(out + poly * out_pstride, (u32)((u64)c.L * N * 8));
+    const u32 n32 = (u32)N;
     const int RB1 = (c.nBsk + 1) >> 1, RB2 = (c.L + 1) >> 1;
-    const PrimeDesc &psk = primes[c.bsk_id[c.nB]];
+    // m_sk's constants: wave-uniform, read once with scalar loads (a PrimeDesc reference would be re-read with vector loads in
+    // the tile loop, and each of those drains the outstanding stores)
+    BehzOutConst psk;
+    {
+        const cu64_ptr pk = (cu64_ptr)&primes[BEHZ_UNIFORM((unsigned)c.bsk_id[c.nB])];
+        psk = BehzOutConst{pk[0], pk[2], pk[3], pk[8], pk[9], 0}; // PrimeDesc: p, cr0, cr1, two_p, inv_n, iroot_last_scaled, r64
+    }
     // ---- per-workgroup setup
     if ((int)threadIdx.x < c.nBsk) {
         const PrimeDesc &pd = primes[c.bsk_id[threadIdx.x]];
@@ -460,38 +504,41 @@ template <int KB> __global__ __launch_bounds__(BEHZ_THREADS) void behz_floor_sk_
         qpre[i] = ld_shoup(floor_pre + lc);
     }
     const u64 c80 = 0x8080808080808080ull;
-    u64 xr[KB];
-    auto fetch = [&](unsigned t) {
-        const u64 n0 = ((u64)blockIdx.x * tiles_per_wg + t) * BEHZ_TILE;
+    // both operands of a tile are fetched while the previous tile is computed: the q residues of this wave's limbs (xr) and the
+    // Bsk residues this lane needs in the stage-1 epilogue, (sub, j) -> db[o = 2 (w + 4 j) + half][n0 + 32 sub + cl] (dbn)
+    u64 xr[KB], dbn[2][2];
+    auto fetch = [&](unsigned t) { // out-of-range offsets (padding limb, absent output, tile beyond N) load 0
+        const u32 t0 = (blockIdx.x * tiles_per_wg + t) * BEHZ_TILE;
+        const u32 n = t0 + lane;
 #pragma unroll
         for (int i = 0; i < KB; i++) {
-            const int l = w + 4 * i;
-            xr[i] = (l < c.L && n0 + lane < N) ? xq[(u64)l * N + n0 + lane] : 0;
+            const u32 l = (u32)(w + 4 * i);
+            xr[i] = BEHZ_LOAD(buf_load_u64(rq, (l < (u32)c.L && n < n32) ? (l * n32 + n) * 8u : TROY_BUF_OOB), (lane + n) * 0x9E3779B97F4Aull + l);
         }
-    };
-    fetch(0);
-    for (unsigned t = 0; t < tiles_per_wg; t++) {
-        const u64 n0 = ((u64)blockIdx.x * tiles_per_wg + t) * BEHZ_TILE;
-        if (n0 >= N) break;
-#pragma unroll
-        for (int i = 0; i < KB; i++) {
-            const int l = w + 4 * i;
-            u64 v = 0;
-            if (l < c.L && n0 + lane < N) v = (mul_shoup(xr[i], qpre[i].op, qpre[i].quo, qp[i]) + c80) ^ c80;
-            ydig[(((l >> 1) * BEHZ_TILE) + lane) * 2 + (l & 1)] = v;
-        }
-        // the Bsk residues this lane will need in the stage-1 epilogue: (sub, j) -> db[o = 2 (w + 4 j) + half][n0 + 32 sub + cl]
-        u64 dbv[2][2];
 #pragma unroll
         for (int sub = 0; sub < 2; sub++)
 #pragma unroll
             for (int j = 0; j < 2; j++) {
-                const int o = 2 * (w + 4 * j) + (int)half;
-                const u64 n = n0 + sub * 32 + cl;
-                dbv[sub][j] = (o < c.nBsk && n < N) ? xb[(u64)o * N + n] : 0;
+                const u32 o = 2 * (u32)(w + 4 * j) + half;
+                const u32 n = t0 + sub * 32 + cl;
+                dbn[sub][j] = BEHZ_LOAD(buf_load_u64(rb, (o < (u32)c.nBsk && n < n32) ? (o * n32 + n) * 8u : TROY_BUF_OOB), (lane + n) * 0x9E3779B97F4Aull + o);
             }
-        if (t + 1 < tiles_per_wg) fetch(t + 1);
-        __syncthreads();
+    };
+    fetch(0);
+#pragma unroll
+    for (int i = 0; i < 4; i++) buf_store_u64(rout, TROY_BUF_OOB + 8 * i, 0); // see behz_extend_mfma_kernel: keeps the loop's waits counted
+    for (unsigned t = 0; t < tiles_per_wg; t++) {
+        const u32 n0 = (blockIdx.x * tiles_per_wg + t) * BEHZ_TILE;
+        if (n0 >= n32) break;
+#pragma unroll
+        for (int i = 0; i < KB; i++) {
+            const int l = w + 4 * i;
+            const u64 v = (mul_shoup(xr[i], qpre[i].op, qpre[i].quo, qp[i]) + c80) ^ c80;
+            ydig[(((l >> 1) * BEHZ_TILE) + lane) * 2 + (l & 1)] = v;
+        }
+        const u64 dbv[2][2] = {{dbn[0][0], dbn[0][1]}, {dbn[1][0], dbn[1][1]}};
+        fetch(t + 1 < tiles_per_wg ? t + 1 : 0x7FFFFFu); // past the last tile: out of range
+        BEHZ_SYNC();
         // ---- stage 1
 #pragma unroll
         for (int sub = 0; sub < 2; sub++) {
@@ -505,21 +552,19 @@ template <int KB> __global__ __launch_bounds__(BEHZ_THREADS) void behz_floor_sk_
                 MfmaAcc acc;
                 mfma_zero(acc);
 #pragma unroll
-                for (int kb = 0; kb < KB; kb++) TROY_MFMA_I8(af[j][kb], bf[kb], acc);
+                for (int kb = 0; kb < KB; kb++) BEHZ_MFMA(af[j][kb], bf[kb], acc);
                 const int o = 2 * (w + 4 * j) + (int)half;
                 if (o < c.nBsk) {
                     const BehzOutConst k = oc1[o];
-                    U128 v = mfma_recombine(acc);
-                    add128(v, dbv[sub][j], k.extra);
-                    const u64 r = reduce128c(v, k);
+                    const u64 r = behz_finish(acc, dbv[sub][j], k.extra, k);
                     if (o < c.nB) udig[(((o >> 1) * BEHZ_TILE) + cc) * 2 + (o & 1)] = (r + c80) ^ c80;
                     else zsk[cc] = r;
                 }
             }
         }
-        __syncthreads();
+        BEHZ_SYNC();
         // ---- stage 2: Shenoy-Kumaresan
-#pragma unroll 1
+#pragma unroll
         for (int sub = 0; sub < 2; sub++) {
             const unsigned cc = sub * 32 + cl;
             MfmaFrag bf[KB];
@@ -528,28 +573,28 @@ template <int KB> __global__ __launch_bounds__(BEHZ_THREADS) void behz_floor_sk_
             MfmaAcc acc;
             mfma_zero(acc);
 #pragma unroll
-            for (int kb = 0; kb < KB; kb++) TROY_MFMA_I8(ld_frag(frag2, ((size_t)RB2 * 4 + kb) * 64 + lane), bf[kb], acc);
-            const u64 conv_sk = reduce128(mfma_recombine(acc), psk);
+            for (int kb = 0; kb < KB; kb++) BEHZ_MFMA(ld_frag(frag2, ((size_t)RB2 * 4 + kb) * 64 + lane), bf[kb], acc);
+            const u64 conv_sk = reduce128c(mfma_recombine(acc), psk);
             const u64 alpha = mul_shoup(conv_sk + (psk.p - zsk[cc]), c.inv_B_mod_msk.op, c.inv_B_mod_msk.quo, psk.p);
             const bool neg = alpha > (psk.p >> 1);
 #pragma unroll
             for (int j = 0; j < 2; j++) {
-                if (w + 4 * j >= RB2) break;
-                mfma_zero(acc);
+                u64 r = 0;
+                u32 off = TROY_BUF_OOB;
+                if (w + 4 * j < RB2) {
+                    mfma_zero(acc);
 #pragma unroll
-                for (int kb = 0; kb < KB; kb++) TROY_MFMA_I8(ld_frag(frag2, ((size_t)(w + 4 * j) * 4 + kb) * 64 + lane), bf[kb], acc);
-                const int l = 2 * (w + 4 * j) + (int)half;
-                if (l < c.L) {
-                    const BehzOutConst k = oc2[l];
-                    U128 v = mfma_recombine(acc);
-                    if (neg) add128(v, psk.p - alpha, k.extra);  // alpha represents a negative value
-                    else add128(v, alpha, k.p - k.extra);
-                    const u64 r = reduce128c(v, k);
-                    if (n0 + cc < N) out[poly * out_pstride + (u64)l * N + n0 + cc] = r;
+                    for (int kb = 0; kb < KB; kb++) BEHZ_MFMA(ld_frag(frag2, ((size_t)(w + 4 * j) * 4 + kb) * 64 + lane), bf[kb], acc);
+                    const u32 l = 2 * (u32)(w + 4 * j) + half;
+                    const BehzOutConst k = oc2[l < (u32)c.L ? l : 0];
+                    // alpha > m_sk / 2 represents a negative value
+                    r = behz_finish(acc, neg ? psk.p - alpha : alpha, neg ? k.extra : k.p - k.extra, k);
+                    if (BEHZ_LIVE(l < (u32)c.L && n0 + cc < n32, r)) off = (l * n32 + n0 + cc) * 8u;
                 }
+                buf_store_u64(rout, off, r);
             }
         }
-        __syncthreads();
+        BEHZ_SYNC();
     }
 }
 
@@ -562,7 +607,7 @@ void launch_behz_extend(const u64 *in, u64 in_pstride, u64 *out, u64 out_pstride
     if (!polys) return;
     const bool mfma = c.ext_frag && behz_use_mfma();
     const u64 tiles = ceil_div(N, (u64)BEHZ_TILE);
-    const unsigned tpw = tiles >= 64 ? 8 : 1; // amortise the A-fragment loads over 8 tiles when there are enough workgroups
+    const unsigned tpw = tiles >= 64 ? BEHZ_TPW : 1; // amortise the A-fragment loads over several tiles when there are enough workgroups
     size_t lds = (size_t)c.L * BEHZ_COEFFS * sizeof(u64);
     for (u64 p0 = 0; p0 < polys; p0 += 65535) { // gridDim.y limit
         const u64 np = polys - p0 < 65535 ? polys - p0 : 65535;
@@ -587,7 +632,7 @@ void launch_behz_floor_sk(const u64 *dq, u64 dq_pstride, const u64 *db, u64 db_p
     if (!polys) return;
     const bool mfma = c.floor_frag1 && behz_use_mfma();
     const u64 tiles = ceil_div(N, (u64)BEHZ_TILE);
-    const unsigned tpw = tiles >= 64 ? 8 : 1;
+    const unsigned tpw = tiles >= 64 ? BEHZ_TPW : 1;
     const int kb = ((c.L > c.nB ? c.L : c.nB) + 3) / 4;
     const size_t lds_mfma = (size_t)(2 * 8 * BEHZ_TILE * 2 + BEHZ_TILE) * sizeof(u64) + 32 * sizeof(BehzOutConst) + (size_t)((c.L + 1) / 2 + 1) * 4 * 64 * 16;
     size_t lds = (size_t)(c.L + c.nB + 1) * BEHZ_COEFFS * sizeof(u64);

@@ -21,6 +21,7 @@ struct LimbMap {
     uint32_t period, inner;
 };
 
+#define TROY_BUF_OOB 0x80000000u // an offset no buffer range reaches (ranges are < 2^31 bytes)
 #ifdef TROYHIP_CPU_EMUL
 #define TROY_WAVE_SYNC() hip_emul::park(2) /* all live lanes of the wave arrive before any proceeds */
 #define TROY_DYN_LDS(type, name) static type name[160 * 1024 / sizeof(type)]
@@ -30,6 +31,11 @@ struct LimbMap {
 struct MfmaFrag { int8_t bytes[16]; };
 struct MfmaAcc { int32_t v[16]; };
 #define TROY_MFMA_I8(fa, fb, fc) hip_emul::mfma_i32_32x32x32_i8((fa).bytes, (fb).bytes, (fc).v)
+// bounds-checked buffer access: an offset beyond the range loads 0 / stores nothing, WITHOUT a branch
+struct BufRsrc { char *base; u32 bytes; };
+inline BufRsrc make_rsrc(const void *p, u32 bytes) { return BufRsrc{(char *)p, bytes}; }
+inline u64 buf_load_u64(BufRsrc r, u32 off) { u64 v = 0; if ((u64)off + 8 <= r.bytes) memcpy(&v, r.base + off, 8); return v; }
+inline void buf_store_u64(BufRsrc r, u32 off, u64 v) { if ((u64)off + 8 <= r.bytes) memcpy(r.base + off, &v, 8); }
 #define TROY_WAIT_VMEM() hip_emul::park(2) /* lanes run one after another here: every lane's copy must have happened */
 #define TROY_WAIT_LDS() hip_emul::park(2)  /* ... and every lane must have read before any lane overwrites */
 #else
@@ -39,6 +45,22 @@ struct MfmaAcc { int32_t v[16]; };
 struct MfmaFrag { int bytes __attribute__((ext_vector_type(4))); };
 struct MfmaAcc { int v __attribute__((ext_vector_type(16))); };
 #define TROY_MFMA_I8(fa, fb, fc) ((fc).v = __builtin_amdgcn_mfma_i32_32x32x32_i8((fa).bytes, (fb).bytes, (fc).v, 0, 0, 0))
+// raw buffer access through a V# (gfx9 encoding 0x00020000: 32-bit data format, no swizzle): the hardware drops lanes whose
+// offset is outside [0, bytes), so ragged edges cost no branch -- and straight-line code lets the compiler count the
+// outstanding stores exactly instead of draining them (s_waitcnt vmcnt(0)) before every use of a prefetched load
+typedef __amdgpu_buffer_rsrc_t BufRsrc;
+typedef unsigned int troy_v2u __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ BufRsrc make_rsrc(const void *p, u32 bytes) { return __builtin_amdgcn_make_buffer_rsrc((void *)p, 0, (int)bytes, 0x00020000); }
+__device__ __forceinline__ u64 buf_load_u64(BufRsrc r, u32 off) {
+    const troy_v2u v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)off, 0, 0);
+    return (u64)v.x | ((u64)v.y << 32);
+}
+__device__ __forceinline__ void buf_store_u64(BufRsrc r, u32 off, u64 v) {
+    troy_v2u d;
+    d.x = (u32)v;
+    d.y = (u32)(v >> 32);
+    __builtin_amdgcn_raw_buffer_store_b64(d, r, (int)off, 0, 0);
+}
 #define TROY_GLDS16(gptr, lds_base)                                                                                      \
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gptr), (__attribute__((address_space(3))) void *)(lds_base), 16, 0, 0)
 #define TROY_WAIT_VMEM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
