@@ -520,3 +520,20 @@ def check_ckks_conv2d_helper(N=4096, bits=(40, 30, 30, 40), batch=2, image=(12, 
                     exp[b, o, i, j] = np.sum(X[b, :, i:i + kh, j:j + kw] * Wt[o])
     assert np.max(np.abs(got - exp)) < 1e-3, np.max(np.abs(got - exp))
     return h
+
+
+def check_bfv_multiply_limb_count(K, N=256, batch=2, seed=900):
+    """BFV multiply (both BEHZ kernels) at L = K - 1 limbs against the oracle: L runs over every k-block count of the matrix-core
+    kernels and over the three forms of their epilogue (correction term folded into the product when L mod 4 is 1 or 2, else
+    added afterwards), and past 16 limbs over the VALU kernels"""
+    from troy_amd import api, synth
+    cfg = dict(scheme=BFV, N=N, bits=[45] + [40] * (K - 2) + [45], tbits=14)
+    be, ob = GpuBackend(cfg), oracle_backend(cfg)
+    L = K - 1
+    xa, xb = synth.uniform_ct(seed + K, be.primes[:L], 2, N, batch), synth.uniform_ct(seed + 50 + K, be.primes[:L], 2, N, batch)
+    r = be.ev.multiply(api.Ciphertext.from_numpy(be.ctx, xa, False), api.Ciphertext.from_numpy(be.ctx, xb, False))
+    got = r.cpu()
+    for i in range(batch):
+        e = ob.multiply(ob.ct(xa[i], False), ob.ct(xb[i], False))
+        assert np.array_equal(got[i], ob.export(e).data), (K, i)
+    return sha(got)

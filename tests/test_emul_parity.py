@@ -157,3 +157,9 @@ def test_emulated_ckks_conv2d_helper(emul_api):
     cases.check_ckks_conv2d_helper(N=256, batch=1, image=(6, 6), kernel=(3, 3), channels=(3, 2))
     h = cases.check_ckks_conv2d_helper(N=256, batch=1, image=(20, 18), kernel=(3, 3), channels=(1, 1))  # blocked: 16 x 16 blocks
     assert h.blocked and h.getTotalBatchSize() == 4
+
+
+@pytest.mark.parametrize("K", [3, 6, 8, 18])
+def test_emulated_bfv_multiply_limb_counts(K, emul_api):
+    """the three epilogue forms of the matrix-core BEHZ kernels (L mod 4 = 2, 1, other) and the VALU kernels (L = 17)"""
+    cases.check_bfv_multiply_limb_count(K, N=64, batch=1)

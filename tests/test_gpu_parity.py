@@ -375,3 +375,26 @@ def test_conv2d_helper(gpu):
     cases.check_ckks_conv2d_helper()
     h = cases.check_ckks_conv2d_helper(batch=1, image=(70, 66), kernel=(3, 3), channels=(1, 2))  # blocked path: 64 x 64 blocks
     assert h.blocked
+
+
+@pytest.mark.parametrize("K", list(range(2, 19)))
+def test_bfv_multiply_every_limb_count(K, gpu, oracle_lib):
+    """BEHZ kernels at L = 1 .. 17: every k-block count, folded / unfolded correction term, VALU kernels past 16 limbs"""
+    cases.check_bfv_multiply_limb_count(K)
+
+
+@pytest.mark.parametrize("env", [{"TROYHIP_BEHZ": "valu"}, {"TROYHIP_BEHZ_FOLD": "0"}])
+def test_behz_kernel_forms_agree(env, gpu, oracle_lib):
+    """the VALU kernels and the unfolded matrix-core epilogue are selected by environment switches that are read once per process:
+    a child process runs the same oracle comparison under each switch and must reproduce this process's result hashes"""
+    import subprocess
+    import sys
+    Ks = [3, 6, 8, 15]
+    here = [cases.check_bfv_multiply_limb_count(K) for K in Ks]
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import troy_amd as ta, cases\n"
+            "ta.KernelProvider.initialize(0)\n"
+            "print(' '.join(cases.check_bfv_multiply_limb_count(K) for K in %r))\n") % (os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__))), Ks)
+    out = subprocess.run([sys.executable, "-c", code], env={**os.environ, **env}, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.split()[-len(Ks):] == here

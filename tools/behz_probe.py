@@ -11,7 +11,7 @@ from troy_amd import api, capi  # noqa: E402
 
 path = os.path.abspath(sys.argv[1])
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 32
-lib = capi.load(path)
+lib = capi.load(path)  # TROYHIP_BEHZ_FOLD=0 in the environment keeps the unfolded epilogue
 api.KernelProvider.initialize(0, _lib=lib)
 N, bits = 32768, [60] + [58] * 13 + [60]
 primes = ta.CoeffModulus.Create(N, bits)

@@ -331,9 +331,33 @@ __device__ __forceinline__ u64 behz_finish(const MfmaAcc &acc, u64 x, u64 y, con
     return reduce128c(v, k);
 }
 
+// recombine + reduce only: the correction term and a non-negativity bias went through the matrix product (BehzDev::ext_fold / floor_fold)
+__device__ __forceinline__ u64 behz_finish_folded(const MfmaAcc &acc, const BehzOutConst &k) {
+    if (BEHZ_EXP & 4) return (u64)(u32)acc.v[0] ^ ((u64)(u32)acc.v[15] << 32);
+    return reduce128c(mfma_recombine(acc), k);
+}
+// The two limbs after the last real one (zero padding in LDS) become this coefficient's extra inputs: the eight balanced digits of a
+// signed value, and the constant 1.  Word `pos` of a lane's fragment of k-block kb is limb 4 kb + 2 half + pos, and the extra limbs
+// sit in the last k-block: FOLD = 2 (limb count = 2 mod 4) -> both words of the half-1 lanes; FOLD = 1 (1 mod 4) -> word 1 of the
+// half-0 lanes and word 0 of the half-1 lanes.
+template <int KB, int FOLD> __device__ __forceinline__ void behz_patch_fold(MfmaFrag (&bf)[KB], unsigned half, long long value) {
+    const u64 c80 = 0x8080808080808080ull;
+    const u64 digits = ((u64)value + c80) ^ c80;
+    MfmaFrag f = bf[KB - 1];
+    if (FOLD == 2) {
+        frag_set_word(f, 0, digits);
+        frag_set_word(f, 1, 1);
+        if (half) bf[KB - 1] = f;
+    } else {
+        if (half) frag_set_word(f, 0, 1);
+        else frag_set_word(f, 1, digits);
+        bf[KB - 1] = f;
+    }
+}
+
 // same contract as behz_extend_kernel; a 256-thread workgroup walks `tiles_per_wg` tiles of 64 coefficients of one
 // polynomial; wave w owns row-blocks w and w + 4 (outputs 2w, 2w+1, 2w+8, 2w+9) and keeps their A-fragments in registers
-template <int KB> __global__ __launch_bounds__(BEHZ_THREADS) void behz_extend_mfma_kernel(const u64 *in, u64 in_pstride, u64 *out, u64 out_pstride, const PrimeDesc *primes,
+template <int KB, int FOLD> __global__ __launch_bounds__(BEHZ_THREADS) void behz_extend_mfma_kernel(const u64 *in, u64 in_pstride, u64 *out, u64 out_pstride, const PrimeDesc *primes,
                                                                                           BehzDev c, u64 N, unsigned tiles_per_wg) {
     __shared__ __attribute__((aligned(16))) u64 ydig[8 * BEHZ_TILE * 2]; // [limb pair][coefficient] 16-byte units
     __shared__ BehzOutConst oc[16];
@@ -413,6 +437,8 @@ template <int KB> __global__ __launch_bounds__(BEHZ_THREADS) void behz_extend_mf
             for (int kb = 0; kb < KB; kb++) BEHZ_MFMA(am[kb], bf[kb], acc);
             const u32 rsum = (u32)acc.v[0] + ((u32)acc.v[1] << 8) + ((u32)acc.v[2] << 16) + ((u32)acc.v[3] << 24);
             const u64 r_mt = ((u64)rsum * c.neg_inv_q_mod_mt) & 0xFFFFFFFFull;
+            // centred representative of r (rns.cpp:966-975) as one more input of the product: out = (sum + r q) m_tilde^-1
+            if (FOLD) behz_patch_fold<KB, FOLD>(bf, half, (long long)r_mt - (long long)((r_mt >> 31) << 32));
 #pragma unroll
             for (int j = 0; j < 2; j++) {
                 // the store is issued on both sides of the (wave-uniform) branch, so the number of stores in flight is a constant
@@ -424,9 +450,12 @@ template <int KB> __global__ __launch_bounds__(BEHZ_THREADS) void behz_extend_mf
                     for (int kb = 0; kb < KB; kb++) BEHZ_MFMA(af[j][kb], bf[kb], acc);
                     const u32 o = 2 * (u32)(w + 4 * j) + half;
                     const BehzOutConst k = oc[o < (u32)c.nBsk ? o : 0];
-                    u64 temp = r_mt;                                   // centred representative of r (rns.cpp:966-975)
-                    if (temp >= (u64(1) << 31)) temp += k.p - (u64(1) << 32);
-                    r = behz_finish(acc, temp, k.extra, k);
+                    if (FOLD) r = behz_finish_folded(acc, k);
+                    else {
+                        u64 temp = r_mt;                               // centred: a negative r is represented by r + p
+                        if (temp >= (u64(1) << 31)) temp += k.p - (u64(1) << 32);
+                        r = behz_finish(acc, temp, k.extra, k);
+                    }
                     if (BEHZ_LIVE(o < (u32)c.nBsk && n0 + cc < n32, r)) off = (o * n32 + n0 + cc) * 8u;
                 }
                 buf_store_u64(rout, off, r);
@@ -443,7 +472,7 @@ template <int KB> __global__ __launch_bounds__(BEHZ_THREADS) void behz_extend_mf
 //       evaluates for its own lanes (one extra row-block instead of a broadcast and a barrier).
 // Stage-1 fragments live in registers, stage-2 fragments are shared through LDS (all four waves need different row-blocks of
 // the same 32 KiB, and 3 workgroups per CU must fit).
-template <int KB> __global__ __launch_bounds__(BEHZ_THREADS) void behz_floor_sk_mfma_kernel(const u64 *dq, u64 dq_pstride, const u64 *db, u64 db_pstride, u64 *out,
+template <int KB, int FOLD> __global__ __launch_bounds__(BEHZ_THREADS) void behz_floor_sk_mfma_kernel(const u64 *dq, u64 dq_pstride, const u64 *db, u64 db_pstride, u64 *out,
                                                                                            u64 out_pstride, const PrimeDesc *primes, BehzDev c, u64 N,
                                                                                            unsigned tiles_per_wg) {
     TROY_DYN_LDS(u64, lds);
@@ -576,7 +605,8 @@ template <int KB> __global__ __launch_bounds__(BEHZ_THREADS) void behz_floor_sk_
             for (int kb = 0; kb < KB; kb++) BEHZ_MFMA(ld_frag(frag2, ((size_t)RB2 * 4 + kb) * 64 + lane), bf[kb], acc);
             const u64 conv_sk = reduce128c(mfma_recombine(acc), psk);
             const u64 alpha = mul_shoup(conv_sk + (psk.p - zsk[cc]), c.inv_B_mod_msk.op, c.inv_B_mod_msk.quo, psk.p);
-            const bool neg = alpha > (psk.p >> 1);
+            const bool neg = alpha > (psk.p >> 1); // alpha > m_sk / 2 represents a negative value
+            if (FOLD) behz_patch_fold<KB, FOLD>(bf, half, (long long)(neg ? alpha - psk.p : alpha)); // out_l = sum - alpha (B mod q_l)
 #pragma unroll
             for (int j = 0; j < 2; j++) {
                 u64 r = 0;
@@ -587,8 +617,8 @@ template <int KB> __global__ __launch_bounds__(BEHZ_THREADS) void behz_floor_sk_
                     for (int kb = 0; kb < KB; kb++) BEHZ_MFMA(ld_frag(frag2, ((size_t)(w + 4 * j) * 4 + kb) * 64 + lane), bf[kb], acc);
                     const u32 l = 2 * (u32)(w + 4 * j) + half;
                     const BehzOutConst k = oc2[l < (u32)c.L ? l : 0];
-                    // alpha > m_sk / 2 represents a negative value
-                    r = behz_finish(acc, neg ? psk.p - alpha : alpha, neg ? k.extra : k.p - k.extra, k);
+                    if (FOLD) r = behz_finish_folded(acc, k);
+                    else r = behz_finish(acc, neg ? psk.p - alpha : alpha, neg ? k.extra : k.p - k.extra, k);
                     if (BEHZ_LIVE(l < (u32)c.L && n0 + cc < n32, r)) off = (l * n32 + n0 + cc) * 8u;
                 }
                 buf_store_u64(rout, off, r);
@@ -615,12 +645,22 @@ void launch_behz_extend(const u64 *in, u64 in_pstride, u64 *out, u64 out_pstride
             const dim3 grid((unsigned)ceil_div(tiles, (u64)tpw), (unsigned)np);
             const u64 *pi = in + p0 * in_pstride;
             u64 *po = out + p0 * out_pstride;
-            switch ((c.L + 3) / 4) {
-            case 1: TROY_LAUNCH(HIP_KERNEL_NAME(behz_extend_mfma_kernel<1>), grid, dim3(BEHZ_THREADS), 0, s, pi, in_pstride, po, out_pstride, primes, c, N, tpw); break;
-            case 2: TROY_LAUNCH(HIP_KERNEL_NAME(behz_extend_mfma_kernel<2>), grid, dim3(BEHZ_THREADS), 0, s, pi, in_pstride, po, out_pstride, primes, c, N, tpw); break;
-            case 3: TROY_LAUNCH(HIP_KERNEL_NAME(behz_extend_mfma_kernel<3>), grid, dim3(BEHZ_THREADS), 0, s, pi, in_pstride, po, out_pstride, primes, c, N, tpw); break;
-            default: TROY_LAUNCH(HIP_KERNEL_NAME(behz_extend_mfma_kernel<4>), grid, dim3(BEHZ_THREADS), 0, s, pi, in_pstride, po, out_pstride, primes, c, N, tpw); break;
+#define BEHZ_EXT_LAUNCH(KB_, F_) TROY_LAUNCH(HIP_KERNEL_NAME(behz_extend_mfma_kernel<KB_, F_>), grid, dim3(BEHZ_THREADS), 0, s, pi, in_pstride, po, out_pstride, primes, c, N, tpw)
+            switch (((c.L + 3) / 4) * 4 + c.ext_fold) { // k-blocks, fold form
+            case 4: BEHZ_EXT_LAUNCH(1, 0); break;
+            case 5: BEHZ_EXT_LAUNCH(1, 1); break;
+            case 6: BEHZ_EXT_LAUNCH(1, 2); break;
+            case 8: BEHZ_EXT_LAUNCH(2, 0); break;
+            case 9: BEHZ_EXT_LAUNCH(2, 1); break;
+            case 10: BEHZ_EXT_LAUNCH(2, 2); break;
+            case 12: BEHZ_EXT_LAUNCH(3, 0); break;
+            case 13: BEHZ_EXT_LAUNCH(3, 1); break;
+            case 14: BEHZ_EXT_LAUNCH(3, 2); break;
+            case 17: BEHZ_EXT_LAUNCH(4, 1); break;
+            case 18: BEHZ_EXT_LAUNCH(4, 2); break;
+            default: BEHZ_EXT_LAUNCH(4, 0); break;
             }
+#undef BEHZ_EXT_LAUNCH
         } else
             TROY_LAUNCH(behz_extend_kernel, dim3(ceil_div(N, BEHZ_COEFFS), (unsigned)np), dim3(BEHZ_THREADS), lds, s, in + p0 * in_pstride, in_pstride, out + p0 * out_pstride,
                         out_pstride, primes, c, N);
@@ -642,12 +682,23 @@ void launch_behz_floor_sk(const u64 *dq, u64 dq_pstride, const u64 *db, u64 db_p
         u64 *po = out + p0 * out_pstride;
         if (mfma) {
             const dim3 grid((unsigned)ceil_div(tiles, (u64)tpw), (unsigned)np);
-            switch (kb) {
-            case 1: TROY_LAUNCH(HIP_KERNEL_NAME(behz_floor_sk_mfma_kernel<1>), grid, dim3(BEHZ_THREADS), lds_mfma, s, pq, dq_pstride, pb, db_pstride, po, out_pstride, primes, c, N, tpw); break;
-            case 2: TROY_LAUNCH(HIP_KERNEL_NAME(behz_floor_sk_mfma_kernel<2>), grid, dim3(BEHZ_THREADS), lds_mfma, s, pq, dq_pstride, pb, db_pstride, po, out_pstride, primes, c, N, tpw); break;
-            case 3: TROY_LAUNCH(HIP_KERNEL_NAME(behz_floor_sk_mfma_kernel<3>), grid, dim3(BEHZ_THREADS), lds_mfma, s, pq, dq_pstride, pb, db_pstride, po, out_pstride, primes, c, N, tpw); break;
-            default: TROY_LAUNCH(HIP_KERNEL_NAME(behz_floor_sk_mfma_kernel<4>), grid, dim3(BEHZ_THREADS), lds_mfma, s, pq, dq_pstride, pb, db_pstride, po, out_pstride, primes, c, N, tpw); break;
+#define BEHZ_FLOOR_LAUNCH(KB_, F_)                                                                                         \
+    TROY_LAUNCH(HIP_KERNEL_NAME(behz_floor_sk_mfma_kernel<KB_, F_>), grid, dim3(BEHZ_THREADS), lds_mfma, s, pq, dq_pstride, pb, db_pstride, po, out_pstride, primes, c, N, tpw)
+            switch (kb * 4 + c.floor_fold) {
+            case 4: BEHZ_FLOOR_LAUNCH(1, 0); break;
+            case 5: BEHZ_FLOOR_LAUNCH(1, 1); break;
+            case 6: BEHZ_FLOOR_LAUNCH(1, 2); break;
+            case 8: BEHZ_FLOOR_LAUNCH(2, 0); break;
+            case 9: BEHZ_FLOOR_LAUNCH(2, 1); break;
+            case 10: BEHZ_FLOOR_LAUNCH(2, 2); break;
+            case 12: BEHZ_FLOOR_LAUNCH(3, 0); break;
+            case 13: BEHZ_FLOOR_LAUNCH(3, 1); break;
+            case 14: BEHZ_FLOOR_LAUNCH(3, 2); break;
+            case 17: BEHZ_FLOOR_LAUNCH(4, 1); break;
+            case 18: BEHZ_FLOOR_LAUNCH(4, 2); break;
+            default: BEHZ_FLOOR_LAUNCH(4, 0); break;
             }
+#undef BEHZ_FLOOR_LAUNCH
         } else {
             TROY_LAUNCH(behz_floor_sk_kernel, dim3(ceil_div(N, BEHZ_COEFFS), (unsigned)np), dim3(BEHZ_THREADS), lds, s, pq, dq_pstride, pb, db_pstride, po, out_pstride, primes, c,
                         N);

@@ -2,6 +2,7 @@
 #include "context.h"
 #include "kernels.h"
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 namespace troyhip {
@@ -46,9 +47,23 @@ static inline int8_t balanced_digit(u64 m, int j) {
 // entries[o * 16 + limb]; fragment layout [row-block][k-block][lane][16 bytes]: lane = (tile row m = lane % 32, k half = lane / 32);
 // tile row m -> output 2 rb + (m / 4) % 2, shift (m / 8) * 4 + m % 4  (so that lane l's accumulator register r is shift r of
 // output 2 rb + l / 32, see the D layout of the instruction)
-static std::vector<uint8_t> pack_mfma_rows(const std::vector<u64> &entries, int n_out) {
+// bias (optional): limb `bias_slot` is the constant input 1 (digit 0 = 1); its column holds the 16 balanced digits of bias[o], one per shift
+typedef unsigned __int128 u128;
+static std::vector<uint8_t> pack_mfma_rows(const std::vector<u64> &entries, int n_out, int bias_slot = -1, const std::vector<u128> *bias = nullptr) {
     const int RB = (n_out + 1) / 2;
     std::vector<uint8_t> f((size_t)RB * 4 * 64 * 16, 0);
+    std::vector<int8_t> bd((size_t)n_out * 16, 0);
+    if (bias)
+        for (int o = 0; o < n_out; o++) {
+            u128 v = (*bias)[o];
+            for (int s = 0; s < 16; s++) {
+                int d = (int)(v & 0xFF);
+                v >>= 8;
+                if (d >= 128) { d -= 256; v += 1; }
+                bd[(size_t)o * 16 + s] = (int8_t)d;
+            }
+            if (v != 0) throw Error(ST_LOGIC_ERROR, "BEHZ bias does not fit 16 balanced digits");
+        }
     for (int rb = 0; rb < RB; rb++)
         for (int kb = 0; kb < 4; kb++)
             for (int lane = 0; lane < 64; lane++) {
@@ -56,11 +71,24 @@ static std::vector<uint8_t> pack_mfma_rows(const std::vector<u64> &entries, int 
                 for (int t = 0; t < 16; t++) {
                     const int k = 32 * kb + 16 * (lane / 32) + t, limb = k / 8, i = k % 8;
                     int8_t v = 0;
-                    if (o < n_out) v = balanced_digit(entries[(size_t)o * 16 + limb], s - i);
+                    if (o < n_out) {
+                        if (limb == bias_slot) v = i == 0 ? bd[(size_t)o * 16 + s] : 0;
+                        else v = balanced_digit(entries[(size_t)o * 16 + limb], s - i);
+                    }
                     f[(((size_t)rb * 4 + kb) * 64 + lane) * 16 + t] = (uint8_t)v;
                 }
             }
     return f;
+}
+// TROYHIP_BEHZ_FOLD=0 keeps the correction term in the epilogue at every size (tests compare both forms); read at context creation
+static bool behz_fold_enabled() {
+    const char *e = getenv("TROYHIP_BEHZ_FOLD");
+    return !(e && e[0] == '0');
+}
+// a multiple of p in [2^bits, 2^(bits+1)): added to a sum that may be negative by less than 2^bits, it changes nothing modulo p
+static u128 bias_multiple(u64 p, int bits) {
+    int len = 64 - __builtin_clzll(p);
+    return (u128)p << (bits + 1 - len);
 }
 // the m_tilde row only needs the result modulo 2^32: tile rows m with m % 8 < 4 carry shift m % 4, the rest is zero
 static std::vector<uint8_t> pack_mfma_mt(const std::vector<u64> &row) {
@@ -241,7 +269,13 @@ void Context::upload_tables() {
             for (int o = 0; o < nBsk; o++)
                 for (int l = 0; l < L; l++) em[(size_t)o * 16 + l] = host::mul_mod(r.q_to_Bsk.mat[o][l], r.inv_mtilde_mod_Bsk[o], r.Bsk[o]);
             for (int l = 0; l < L; l++) mt[l] = mt_row[l];
-            c->ext_frag = upload(pack_mfma_rows(em, nBsk), lv.dev_blocks);
+            c->ext_fold = (behz_fold_enabled() && (L % 4 == 1 || L % 4 == 2)) ? L % 4 : 0; // the two limbs after the last one are padding of the last k-block
+            if (c->ext_fold) { // |r q m_tilde^-1| < 2^31 * 2^61
+                std::vector<u128> bias(nBsk);
+                for (int o = 0; o < nBsk; o++) { em[(size_t)o * 16 + L] = ext_q[o]; bias[o] = bias_multiple(r.Bsk[o], 93); }
+                c->ext_frag = upload(pack_mfma_rows(em, nBsk, L + 1, &bias), lv.dev_blocks);
+            } else
+                c->ext_frag = upload(pack_mfma_rows(em, nBsk), lv.dev_blocks);
             c->ext_mt_frag = upload(pack_mfma_mt(mt), lv.dev_blocks);
         }
         c->floor_pre = upload(floor_pre, lv.dev_blocks);
@@ -264,7 +298,17 @@ void Context::upload_tables() {
             for (int b = 0; b < nB; b++) fm[b] = fm[16 + b] = r.B_to_msk.mat[0][b];
             c->floor_frag1 = upload(pack_mfma_rows(f1, nBsk), lv.dev_blocks);
             c->floor_t = upload(traw, lv.dev_blocks);
-            c->floor_frag2 = upload(pack_mfma_rows(f2, L), lv.dev_blocks);
+            c->floor_fold = (behz_fold_enabled() && (nB % 4 == 1 || nB % 4 == 2) && (nB + 3) / 4 == (std::max(L, nB) + 3) / 4) ? nB % 4 : 0;
+            if (c->floor_fold) { // |alpha (B mod q_l)| < 2^60 * 2^60
+                std::vector<u128> bias(L);
+                for (int l = 0; l < L; l++) {
+                    const u64 pb = r.prod_B_mod_q[l] % r.q[l];
+                    f2[(size_t)l * 16 + nB] = pb ? r.q[l] - pb : 0;
+                    bias[l] = bias_multiple(r.q[l], 121);
+                }
+                c->floor_frag2 = upload(pack_mfma_rows(f2, L, nB + 1, &bias), lv.dev_blocks);
+            } else
+                c->floor_frag2 = upload(pack_mfma_rows(f2, L), lv.dev_blocks);
             c->floor_msk_frag = upload(pack_mfma_rows(fm, 2), lv.dev_blocks);
         }
         c->B2q3 = upload(B2q, lv.dev_blocks);

@@ -31,6 +31,7 @@ struct LimbMap {
 struct MfmaFrag { int8_t bytes[16]; };
 struct MfmaAcc { int32_t v[16]; };
 #define TROY_MFMA_I8(fa, fb, fc) hip_emul::mfma_i32_32x32x32_i8((fa).bytes, (fb).bytes, (fc).v)
+inline void frag_set_word(MfmaFrag &f, int pos, u64 v) { memcpy(f.bytes + 8 * pos, &v, 8); } // bytes 8 pos .. 8 pos + 7 of the fragment
 // bounds-checked buffer access: an offset beyond the range loads 0 / stores nothing, WITHOUT a branch
 struct BufRsrc { char *base; u32 bytes; };
 inline BufRsrc make_rsrc(const void *p, u32 bytes) { return BufRsrc{(char *)p, bytes}; }
@@ -45,6 +46,10 @@ inline void buf_store_u64(BufRsrc r, u32 off, u64 v) { if ((u64)off + 8 <= r.byt
 struct MfmaFrag { int bytes __attribute__((ext_vector_type(4))); };
 struct MfmaAcc { int v __attribute__((ext_vector_type(16))); };
 #define TROY_MFMA_I8(fa, fb, fc) ((fc).v = __builtin_amdgcn_mfma_i32_32x32x32_i8((fa).bytes, (fb).bytes, (fc).v, 0, 0, 0))
+__device__ __forceinline__ void frag_set_word(MfmaFrag &f, int pos, u64 v) { // bytes 8 pos .. 8 pos + 7 of the fragment
+    f.bytes[2 * pos] = (int)(u32)v;
+    f.bytes[2 * pos + 1] = (int)(u32)(v >> 32);
+}
 // raw buffer access through a V# (gfx9 encoding 0x00020000: 32-bit data format, no swizzle): the hardware drops lanes whose
 // offset is outside [0, bytes), so ragged edges cost no branch -- and straight-line code lets the compiler count the
 // outstanding stores exactly instead of draining them (s_waitcnt vmcnt(0)) before every use of a prefetched load

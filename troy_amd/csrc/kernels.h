@@ -126,6 +126,10 @@ struct BehzDev {
     // lane, [row-block][k-block][lane]; a row-block is 2 outputs x 16 byte-shifts, a k-block is 4 input limbs x 8 digits
     const void *ext_frag;             // [ceil(nBsk/2)][4][64]
     const void *ext_mt_frag;          // [4][64]  the m_tilde row (shifts 0..3 only)
+    // ext_fold / floor_fold: the padding limbs L, L+1 (nB, nB+1) of the last k-block carry the per-coefficient correction term as two
+    // more inputs -- the centred r (alpha) against the column q m_tilde^-1 (-(B mod q_l)), and the constant 1 against the digits of a
+    // multiple of the output prime that keeps the sum non-negative -- so the epilogue is recombine + reduce only
+    int ext_fold, floor_fold;         // 0: not folded; 1 / 2: limb count modulo 4 (selects where the two extra limbs sit in the fragment)
     // --- floor + Shenoy-Kumaresan ---
     const Shoup *floor_pre;           // [L]   (t * (q/q_l)^-1) mod q_l
     const Mat3 *floor_mat3;           // [nBsk][L]  -(q/q_l) * q^-1 [* (B/B_o)^-1 for o < nB] mod Bsk_o
