@@ -65,9 +65,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=64, help="ciphertext pairs per GPU per step")
+    ap.add_argument("--batch", type=int, default=128, help="ciphertext pairs per GPU per step")
     ap.add_argument("--workload", default="bfv_n32768_l14", choices=sorted(WORKLOADS))
-    ap.add_argument("--streams", type=int, default=1, help="split the batch over this many HIP streams (one context each): kernels of different phases overlap")
+    ap.add_argument("--streams", type=int, default=2, help="split the batch over this many HIP streams (one context each): kernels of different phases overlap")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--ntt-reps", type=int, default=10)
     ap.add_argument("--roofline-only", action="store_true", help="skip the timed steps: only the roofline NTT launches run (for the rocprofv3 summary of exactly that kernel)")
