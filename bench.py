@@ -163,8 +163,9 @@ def main():
         cx, st, Bi = lanes[i][:3]
         capi.check(lib, lib.troyhip_relinearize(cx.h, C.byref(pending.pop(i)), C.c_void_p(key.ptr), C.c_uint64(Bi), st))
 
-    for i in range(1, S, 2):
-        mul(i)  # prime the out-of-phase lanes (untimed)
+    if not args.roofline_only:
+        for i in range(1, S, 2):
+            mul(i)  # prime the out-of-phase lanes (untimed)
 
     def step():
         for i in range(S):
