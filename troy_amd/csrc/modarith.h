@@ -68,6 +68,22 @@ TROY_HD u64 div128(u64 lo, u64 hi, const Mod &m) {
     return r >= m.p ? q + 1 : q;
 }
 TROY_HD u64 mulmod(u64 a, u64 b, const Mod &m) { return barrett128(a * b, mulhi64(a, b), m); }
+// Barrett reduction specialised for x < 2 p^2 (a product of two residues, or the sum of two): with k = bit length of p,
+// q = floor(floor(x / 2^(k-1)) * floor(2^(63+k) / p) / 2^64) satisfies floor(x/p) - 2 <= q <= floor(x/p) for k <= 61, so one
+// 64 x 64 high product, one low product and two conditional subtractions give the canonical residue (the generic barrett128
+// above takes three high and three low products).  mu = floor(2^128 / p) >> (65 - k) is exactly floor(2^(63+k) / p).
+struct ProdMod { u64 p, two_p, mu; int shift; };
+TROY_HD ProdMod make_prod_mod(const Mod &m) {
+    const int k = 64 - __builtin_clzll(m.p);
+    const u128 cr = ((u128)m.cr1 << 64) | m.cr0;
+    return ProdMod{m.p, 2 * m.p, (u64)(cr >> (65 - k)), k - 1};
+}
+TROY_HD u64 reduce_prod(u128 x, const ProdMod &t) {
+    const u64 q = mulhi64((u64)(x >> t.shift), t.mu);
+    u64 r = (u64)x - q * t.p;
+    r = r >= t.two_p ? r - t.two_p : r;
+    return r >= t.p ? r - t.p : r;
+}
 TROY_HD u64 addmod(u64 a, u64 b, u64 p) { u64 s = a + b; return s >= p ? s - p : s; }
 TROY_HD u64 submod(u64 a, u64 b, u64 p) { return a >= b ? a - b : a + p - b; }
 TROY_HD u64 negmod(u64 a, u64 p) { return a ? p - a : 0; }

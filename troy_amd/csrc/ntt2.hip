@@ -282,7 +282,7 @@ template <int INV, int STRIDED, int NS, int LOGC, int LS, int R, bool HOISTP = t
     // ([0, 8p)) of this thread's 8 consecutive coefficients.  Rows 0..2 are parked canonical in tx; row 3 completes the
     // tensor (evaluator.cpp:626-702: every product reduced, the two middle products added modulo p).
     __device__ static __forceinline__ void tensor_epilogue(u64 (&x)[8], u64 (&tx)[3][8], unsigned mm, u64 *out, unsigned period, unsigned slot, unsigned tile, int logn,
-                                                           const Mod &m) {
+                                                           const Mod &m, u64 *xchg) {
         const PrimeConst pc = make_prime_const(m.p);
 #pragma unroll
         for (int h = 0; h < 2; h++) {
@@ -301,19 +301,27 @@ template <int INV, int STRIDED, int NS, int LOGC, int LS, int R, bool HOISTP = t
                 }
             return;
         }
+        // all four operands are canonical: every product is below p^2 and the middle sum below 2 p^2, which reduce_prod takes
+        // directly -- (a0 b1 + a1 b0) mod p is the same residue as the reference's add of the two reduced products
         const unsigned b = mm >> 2;
-        const u64 pos = ((u64)tile << N2_LOGT) + 8 * threadIdx.x;
+        const ProdMod pm = make_prod_mod(m);
         u64 d[3][8];
 #pragma unroll
         for (int e = 0; e < 8; e++) {
             const u64 a0 = tx[0][e], a1 = tx[1][e], b0 = tx[2][e], b1 = x[e];
-            d[0][e] = mulmod(a0, b0, m);
-            d[1][e] = addmod(mulmod(a0, b1, m), mulmod(a1, b0, m), m.p);
-            d[2][e] = mulmod(a1, b1, m);
+            d[0][e] = reduce_prod((u128)a0 * b0, pm);
+            d[1][e] = reduce_prod((u128)a0 * b1 + (u128)a1 * b0, pm);
+            d[2][e] = reduce_prod((u128)a1 * b1, pm);
         }
 #pragma unroll
         for (int i = 0; i < 3; i++) {
-            ulonglong2 *op = reinterpret_cast<ulonglong2 *>(out + ((((u64)b * 3 + i) * period + slot) << logn) + pos);
+            u64 *orow = out + ((((u64)b * 3 + i) * period + slot) << logn);
+            if (N2_COALESCED_STORE && xchg) { // 1 KiB-contiguous stores through the wave's exchange area, as the plain pass
+                TROY_WAVE_SYNC();
+                store_via_lds(d[i], orow, tile, xchg + 512 * (threadIdx.x >> 6));
+                continue;
+            }
+            ulonglong2 *op = reinterpret_cast<ulonglong2 *>(orow + ((u64)tile << N2_LOGT) + 8 * threadIdx.x);
 #pragma unroll
             for (int e = 0; e < 4; e++) {
                 ulonglong2 v;
@@ -533,7 +541,7 @@ __global__ __launch_bounds__(N2_THREADS, MAC ? N2_MAC_WAVES : N2_MIN_WAVES) void
                 Rd2::lds_read(x, buf);
                 Rd2::compute(x, tw2, pd);
                 if constexpr (NR == 3 && MAC == 2) {
-                    Rd2::tensor_epilogue(x, tx, mm, a.tensor_out, period, slot, tile, logn, m);
+                    Rd2::tensor_epilogue(x, tx, mm, a.tensor_out, period, slot, tile, logn, m, WAVE_PRIVATE ? buf : nullptr);
                 } else if constexpr (NR == 3 && MAC == 1) {
                     // the transform of digit k of (o, slot) stays in registers: acc_c += x (.) key[k][c][limb(slot)].  x is lazy, in
                     // [0, 8p); it is only normalised when dl * 8p * p could overflow the 128-bit accumulator (mac_lazy == 0)
