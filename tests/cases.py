@@ -537,3 +537,18 @@ def check_bfv_multiply_limb_count(K, N=256, batch=2, seed=900):
         e = ob.multiply(ob.ct(xa[i], False), ob.ct(xb[i], False))
         assert np.array_equal(got[i], ob.export(e).data), (K, i)
     return sha(got)
+
+
+def mul_relin_hash(name, batch=2, seed=4242):
+    """SHA-256 of multiply + relinearize on seeded inputs of config `name` (GPU backend): used to compare kernel variants that are
+    selected by environment switches in child processes"""
+    from troy_amd import api, synth
+    cfg = CONFIGS[name]
+    be = GpuBackend(cfg)
+    L, N, ntt = len(be.primes) - 1, cfg["N"], cfg["scheme"] == CKKS
+    be.set_relin_key(synth.uniform_kswitch_key(seed, be.primes, N))
+    xa, xb = synth.uniform_ct(seed + 1, be.primes[:L], 2, N, batch), synth.uniform_ct(seed + 2, be.primes[:L], 2, N, batch)
+    r = be.ev.multiply(api.Ciphertext.from_numpy(be.ctx, xa, ntt), api.Ciphertext.from_numpy(be.ctx, xb, ntt))
+    h1 = sha(r.cpu())
+    be.ev.relinearizeInplace(r, be.rlk)
+    return h1 + ":" + sha(r.cpu())

@@ -398,3 +398,21 @@ def test_behz_kernel_forms_agree(env, gpu, oracle_lib):
     out = subprocess.run([sys.executable, "-c", code], env={**os.environ, **env}, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     assert out.stdout.split()[-len(Ks):] == here
+
+
+@pytest.mark.parametrize("env", [{"TROYHIP_KS": "split"}, {"TROYHIP_TENSOR": "split"}, {"TROYHIP_BEHZ": "valu"}])
+def test_unfused_kernel_paths_agree(env, gpu):
+    """the unfused key-switch inner product, the unfused tensor and the VALU BEHZ kernels (environment switches, read once per
+    process) give the same limbs as the default path, which the tests above pin against the oracle and the golden files"""
+    import subprocess
+    import sys
+    names = ["cfgA_bfv_n4096_k3", "cfgB_bfv_n8192_k5", "bgv_n4096_k3", "ckks_n4096_k4", "bfv_n16384_k4"]
+    here = [cases.mul_relin_hash(n) for n in names]
+    tests_dir = os.path.dirname(os.path.abspath(__file__))
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import troy_amd as ta, cases\n"
+            "ta.KernelProvider.initialize(0)\n"
+            "print(' '.join(cases.mul_relin_hash(n) for n in %r))\n") % (tests_dir, os.path.dirname(tests_dir), names)
+    out = subprocess.run([sys.executable, "-c", code], env={**os.environ, **env}, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.split()[-len(names):] == here
