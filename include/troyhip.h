@@ -111,6 +111,9 @@ int troyhip_galois_elt_from_step(const troyhip_context *ctx, int step, uint32_t 
  * stream keyed by (seed_lo, seed_hi) -- fresh ciphertexts are not bit-identical to the reference's Blake2xb-driven ones
  * but decrypt to the same plaintext; decryption is deterministic and bit-exact. ----
  * secret_key [K][N] (NTT form, src/secretkey.h), public_key [2][K][N] (src/publickey.h), kswitch keys [K-1][2][K][N]. */
+/* n bytes from the operating system's entropy source (getrandom(2)); the mirrors seed KeyGenerator / Encryptor from it when the caller
+ * passes no seed, as the reference seeds its PRNG factory from std::random_device (src/randomgen.cpp:23,72) */
+int troyhip_random_bytes(void *out, size_t n);
 int troyhip_host_keygen(const troyhip_context *ctx, uint64_t seed_lo, uint64_t seed_hi, uint64_t *secret_key, uint64_t *public_key); /* KeyGenerator(ctx), createPublicKey */
 int troyhip_host_relin_key(const troyhip_context *ctx, uint64_t seed_lo, uint64_t seed_hi, const uint64_t *secret_key, uint64_t *out);  /* createRelinKeys */
 int troyhip_host_galois_key(const troyhip_context *ctx, uint64_t seed_lo, uint64_t seed_hi, const uint64_t *secret_key, uint32_t galois_elt, uint64_t *out); /* createGaloisKeys({elt}) */

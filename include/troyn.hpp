@@ -261,12 +261,16 @@ public:
 
 class KeyGenerator { // src/keygenerator_cuda.cuh: runs on the CPU
 public:
-    explicit KeyGenerator(const SEALContext &c, uint64_t seed_lo = 0x7472, uint64_t seed_hi = 0x6f79) : c_(c), lo_(seed_lo), hi_(seed_hi) {
-        const size_t K = c.keyLimbs(), N = c.polyModulusDegree();
-        sk_.data.resize(K * N);
-        pk_.data.resize(2 * K * N);
-        check(troyhip_host_keygen(c.handle(), lo_, hi_, sk_.data.data(), pk_.data.data()));
+    // KeyGenerator(context): the key stream is seeded from the operating system's entropy source, as the reference's default
+    // PRNG factory is (std::random_device, src/randomgen.cpp:23,72)
+    explicit KeyGenerator(const SEALContext &c) : c_(c) {
+        uint64_t s[2];
+        check(troyhip_random_bytes(s, sizeof(s)));
+        lo_ = s[0]; hi_ = s[1];
+        generate();
     }
+    // deterministic keys for tests and fixtures ONLY (the reference's counterpart: parms.setRandomGenerator with a fixed PRNGSeed)
+    KeyGenerator(const SEALContext &c, uint64_t seed_lo, uint64_t seed_hi) : c_(c), lo_(seed_lo), hi_(seed_hi) { generate(); }
     const SecretKey &secretKey() const { return sk_; }
     void createPublicKey(PublicKey &pk) const { pk = pk_; }
     PublicKey createPublicKey() const { return pk_; }
@@ -289,6 +293,12 @@ public:
         createGaloisKeys(elts, gk);
     }
 private:
+    void generate() {
+        const size_t K = c_.keyLimbs(), N = c_.polyModulusDegree();
+        sk_.data.resize(K * N);
+        pk_.data.resize(2 * K * N);
+        check(troyhip_host_keygen(c_.handle(), lo_, hi_, sk_.data.data(), pk_.data.data()));
+    }
     size_t ksk_words() const { const size_t K = c_.keyLimbs(); return (K - 1) * 2 * K * c_.polyModulusDegree(); }
     const SEALContext &c_;
     uint64_t lo_, hi_;
@@ -298,19 +308,25 @@ private:
 
 class Encryptor { // src/encryptor_cuda.cuh (public-key path), CPU sampling + upload
 public:
-    Encryptor(const SEALContext &c, const PublicKey &pk, uint64_t seed = 0x656e63) : c_(c), pk_(pk), seed_(seed) {}
+    // every encryption draws a fresh 128-bit seed for (u, e0, e1) from the operating system (src/randomgen.cpp:23,72)
+    Encryptor(const SEALContext &c, const PublicKey &pk) : c_(c), pk_(pk), seeded_(false), lo_(0), hi_(0) {}
+    // deterministic stream (seed, call counter) for tests ONLY
+    Encryptor(const SEALContext &c, const PublicKey &pk, uint64_t seed_lo, uint64_t seed_hi = 0) : c_(c), pk_(pk), seeded_(true), lo_(seed_lo), hi_(seed_hi) {}
     void encrypt(const Plaintext &plain, Ciphertext &dst) const {
         const size_t N = c_.polyModulusDegree();
         const bool ckks = c_.parms().scheme() == SchemeType::ckks;
         const int limbs = ckks ? (int)(plain.coeffCount() / N) : c_.firstParmsID();
         std::vector<uint64_t> h((size_t)2 * limbs * N);
-        check(troyhip_host_encrypt(c_.handle(), seed_ + (++counter_), 0x70, pk_.data.data(), plain.data(), ckks ? N : plain.coeffCount(), limbs, h.data()));
-        dst.fromHost(h, N, limbs, 2, ckks, 1.0, 1);
+        uint64_t s[2] = {lo_ + (++counter_), hi_};
+        if (!seeded_) check(troyhip_random_bytes(s, sizeof(s)));
+        check(troyhip_host_encrypt(c_.handle(), s[0], s[1], pk_.data.data(), plain.data(), ckks ? N : plain.coeffCount(), limbs, h.data()));
+        dst.fromHost(h, N, limbs, 2, ckks, ckks ? plain.scale() : 1.0, 1); // destination.scale() = plain.scale(): src/encryptor.cpp:235
     }
 private:
     const SEALContext &c_;
     PublicKey pk_;
-    uint64_t seed_;
+    bool seeded_;
+    uint64_t lo_, hi_;
     mutable uint64_t counter_ = 0;
 };
 

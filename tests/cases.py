@@ -552,3 +552,33 @@ def mul_relin_hash(name, batch=2, seed=4242):
     h1 = sha(r.cpu())
     be.ev.relinearizeInplace(r, be.rlk)
     return h1 + ":" + sha(r.cpu())
+
+
+def check_modswitch_as_first_op(cfg_name, batch=2):
+    """rescaleToNext / modSwitchToNext as the FIRST operation on a fresh context (nothing has sized the scratch arena
+    yet), with strided (capacity 3) and dense operands, then again at a larger batch.  Results against the oracle."""
+    cfg = CONFIGS[cfg_name]
+    orc = oracle_backend(cfg)
+    from oracle import ref as R
+    scheme, N = cfg["scheme"], cfg["N"]
+    ntt = scheme == CKKS
+    for cap, B in ((3, batch), (None, batch), (3, 3 * batch)):
+        be = GpuBackend(cfg, batch=B)      # fresh context: empty arena
+        L = len(be.primes) - 1
+        xs = synth.uniform_ct(771 + B, be.primes[:L], 2, N, B)
+        c = be.api.Ciphertext.from_numpy(be.ctx, xs, ntt, 1.0, 1, capacity=cap)
+        if scheme == CKKS:
+            got = be.ev.rescaleToNext(c).cpu()
+            op = R.OP_RESCALE_NEXT
+        else:
+            got = be.ev.modSwitchToNext(c).cpu()
+            op = R.OP_MODSWITCH_NEXT
+        for b in range(B):
+            assert np.array_equal(got[b], orc.impl.eval(op, R.Ct(xs[b], ntt)).data), (cap, B, b)
+        # and a second, larger op on the same context right after a small one
+        if cap is None:
+            xs2 = synth.uniform_ct(779, be.primes[:L], 2, N, 4 * B)
+            c2 = be.api.Ciphertext.from_numpy(be.ctx, xs2, ntt, 1.0, 1, capacity=3)
+            got2 = (be.ev.rescaleToNext(c2) if scheme == CKKS else be.ev.modSwitchToNext(c2)).cpu()
+            for b in range(4 * B):
+                assert np.array_equal(got2[b], orc.impl.eval(op, R.Ct(xs2[b], ntt)).data), ("grow", b)

@@ -83,6 +83,11 @@ def test_emulated_api_compositions(name, emul_api):
     cases.check_api_compositions(name)
 
 
+@pytest.mark.parametrize("name", ["ckks_n128_k6", "bfv_n128_k4", "bgv_n128_k4"])
+def test_emulated_modswitch_as_first_op(name, emul_api):
+    cases.check_modswitch_as_first_op(name)
+
+
 def test_emulated_ckks_matmul_helper(emul_api):
     cases.check_ckks_matmul_helper(N=256, bits=(40, 30, 30, 40), batch=2, dims=(24, 20))
 

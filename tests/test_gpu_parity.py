@@ -354,6 +354,12 @@ def test_gpu_decrypt_end_to_end(gpu):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name", ["ckks_n128_k6", "bfv_n128_k4", "bgv_n128_k4", "ckks_n4096_k4", "cfgB_bfv_n8192_k5"])
+def test_modswitch_as_first_op(name, gpu):
+    cases.check_modswitch_as_first_op(name)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name", ["bfv_n128_k4", "bgv_n128_k4", "ckks_n128_k6", "cfgA_bfv_n4096_k3", "ckks_n4096_k4"])
 def test_api_compositions(name, gpu):
     cases.check_api_compositions(name)

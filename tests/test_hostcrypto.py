@@ -3,6 +3,7 @@ The product's host-side KeyGenerator / Encryptor / Decryptor (troy_amd/csrc/host
 the reference fixture (tests/golden/cfgA_*.npz), the CPU oracle, and -- where oracle/_ref is present -- the reference's
 own Encryptor / Decryptor.  Decryption must be bit-exact; fresh encryptions use our own sampler and must decrypt to the
 input everywhere."""
+import ctypes as C
 import os
 
 import numpy as np
@@ -132,3 +133,26 @@ def test_argument_errors(ta):
         kg.createRelinKeys()                                         # K = 1: key switching unsupported (context.cpp using_keyswitching)
     with pytest.raises(capi.InvalidArgument):
         ta.Encryptor(ctx, kg.createPublicKey()).encrypt(np.zeros(N + 1, dtype=np.uint64))  # plain longer than N
+
+
+def test_default_seeds_come_from_os_entropy(ta):
+    """KeyGenerator(ctx) / Encryptor(ctx, pk) without a seed must not be deterministic -- the reference seeds
+    its PRNG from std::random_device (src/randomgen.cpp:23,72)."""
+    N = 256
+    primes = ta.CoeffModulus.Create(N, [40, 41])
+    t = ta.PlainModulus.Batching(N, 16)
+    ctx = ta.SEALContext(ta.BFV, N, primes, t, host_only=True)
+    k1, k2 = ta.KeyGenerator(ctx), ta.KeyGenerator(ctx)
+    assert not np.array_equal(k1.secretKey(), k2.secretKey())
+    assert np.array_equal(ta.KeyGenerator(ctx, seed=(9, 9)).secretKey(), ta.KeyGenerator(ctx, seed=(9, 9)).secretKey())  # explicit seed: test-only determinism
+    m = np.arange(N, dtype=np.uint64) % np.uint64(t)
+    e1, e2 = ta.Encryptor(ctx, k1.createPublicKey()), ta.Encryptor(ctx, k1.createPublicKey())
+    c1, c2, c3 = e1.encrypt(m), e2.encrypt(m), e1.encrypt(m)
+    assert not np.array_equal(c1, c2) and not np.array_equal(c1, c3)   # fresh (u, e0, e1) per instance and per call
+    dec = ta.Decryptor(ctx, k1.secretKey())
+    for c in (c1, c2, c3):
+        assert np.array_equal(dec.decrypt(c), m)
+    buf = (C.c_uint8 * 32)()
+    from troy_amd import capi
+    capi.check(ctx.lib, ctx.lib.troyhip_random_bytes(buf, 32))
+    assert any(buf)

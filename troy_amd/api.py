@@ -7,6 +7,8 @@ independent ciphertexts of identical shape (B = 1 is the reference's object).  T
 mirror is include/troy_cuda.cuh.  Everything runs through libtroyhip.so; there is no CPU path.
 """
 import ctypes as C
+import os
+import struct
 
 import numpy as np
 
@@ -757,7 +759,11 @@ class KeyGenerator:
     """KeyGeneratorCuda delegates to the CPU KeyGenerator in the reference (src/keygenerator_cuda.cuh); so does this one
     (troy_amd/csrc/hostcrypto.cpp).  Keys are numpy arrays in the reference's layouts."""
 
-    def __init__(self, context, seed=(1, 2)):
+    def __init__(self, context, seed=None):
+        """seed=None (the default): 128 bits from os.urandom, as the reference seeds its PRNG from std::random_device
+        (src/randomgen.cpp:23,72); an explicit (lo, hi) pair gives deterministic keys for tests ONLY."""
+        if seed is None:
+            seed = struct.unpack("<QQ", os.urandom(16))
         self.context, self.lib, self.seed = context, context.lib, (int(seed[0]), int(seed[1]))
         K, N = context.key_limbs, context.N
         self._sk = np.zeros((K, N), dtype=np.uint64)
@@ -792,10 +798,12 @@ class KeyGenerator:
 class Encryptor:
     """Encryptor::encrypt with a public key (src/encryptor.cpp:88-260), on the CPU."""
 
-    def __init__(self, context, public_key, seed=(3, 4)):
+    def __init__(self, context, public_key, seed=None):
+        """seed=None: every encrypt() draws a fresh 128-bit seed for (u, e0, e1) from os.urandom; an explicit (lo, hi) pair
+        gives the deterministic stream (seed, call counter) for tests ONLY."""
         self.context, self.lib = context, context.lib
         self.pk = np.ascontiguousarray(public_key, dtype=np.uint64)
-        self.seed, self.counter = (int(seed[0]), int(seed[1])), 0
+        self.seed, self.counter = (None if seed is None else (int(seed[0]), int(seed[1]))), 0
 
     def encrypt(self, plain, limbs=None):
         """BFV/BGV: plain = coefficients mod t (<= N of them) -> uint64 [2][first_limbs][N];
@@ -810,7 +818,8 @@ class Encryptor:
             n = plain.size
         out = np.zeros((2, limbs, ctx.N), dtype=np.uint64)
         self.counter += 1
-        capi.check(self.lib, self.lib.troyhip_host_encrypt(ctx.h, C.c_uint64(self.seed[0] + self.counter), C.c_uint64(self.seed[1]), _u64p(self.pk), _u64p(plain),
+        lo, hi = struct.unpack("<QQ", os.urandom(16)) if self.seed is None else ((self.seed[0] + self.counter) & (2**64 - 1), self.seed[1])
+        capi.check(self.lib, self.lib.troyhip_host_encrypt(ctx.h, C.c_uint64(lo), C.c_uint64(hi), _u64p(self.pk), _u64p(plain),
                                                            C.c_uint64(n), limbs, _u64p(out)))
         return out
 

@@ -177,6 +177,36 @@ __device__ __forceinline__ void gs_bfly4_last(u64 (&X)[4], u64 (&Y)[4], const Sh
 #pragma unroll
     for (int i = 0; i < 4; i++) Y[i] = mul_acc(0, d[i], w_scaled[i].op, q[i], c.negp);
 }
+// ---- guard-free ("lean") butterflies: no conditional subtraction at all; the CALLER tracks the value bound (in units of p) per
+// stage and inserts a reduction (barrett_lite4) only where the next stage could leave 64 bits.  For the primes the
+// reference's parameter generator produces below 2^58 (CoeffModulus::Create with <= 58-bit sizes) a whole 15-stage forward
+// transform needs none: every stage adds at most 3p to the bound (v = w*y mod p lazily in [0,3p)).
+// forward: X' = X + v, Y' = X + 3p - v; both outputs < bound(X) + 3p.  15 VALU instructions.
+__device__ __forceinline__ void ct_bfly4_ng(u64 (&X)[4], u64 (&Y)[4], const Shoup (&w)[4], const PrimeConst &c) {
+    u64 q[4], xn[4], t[4];
+    mulhi_approx4(q, Y, w);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        xn[i] = mul_acc(X[i], Y[i], w[i].op, q[i], c.negp);
+        t[i] = (X[i] << 1) + c.three_p;
+    }
+    sub4(Y, t, xn);
+#pragma unroll
+    for (int i = 0; i < 4; i++) X[i] = xn[i];
+}
+// inverse: X' = X + Y, Y' = (X + kp - Y) * w lazily in [0,3p); kp = a multiple of p that is >= bound(Y); the caller keeps
+// bound(X) + kp < 2^64.  16 VALU instructions.
+__device__ __forceinline__ void gs_bfly4_ng(u64 (&X)[4], u64 (&Y)[4], const Shoup (&w)[4], u64 kp, const PrimeConst &c) {
+    u64 t[4], d[4], q[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) t[i] = X[i] + kp;
+    sub4(d, t, Y);
+#pragma unroll
+    for (int i = 0; i < 4; i++) X[i] = X[i] + Y[i];
+    mulhi_approx4(q, d, w);
+#pragma unroll
+    for (int i = 0; i < 4; i++) Y[i] = mul_acc(0, d[i], w[i].op, q[i], c.negp);
+}
 // final normalisations to the canonical residue, four values at a time
 __device__ __forceinline__ void reduce4_from_8p(u64 (&x)[4], const PrimeConst &c) { csub4(x, c.four_p); csub4(x, c.two_p); csub4(x, c.p); }
 __device__ __forceinline__ void reduce4_from_4p(u64 (&x)[4], const PrimeConst &c) { csub4(x, c.two_p); csub4(x, c.p); }

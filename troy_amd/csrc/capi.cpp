@@ -1,4 +1,6 @@
 // capi.cpp -- extern "C" boundary of libtroyhip.so (include/troyhip.h).  No exceptions cross it.
+#include <sys/random.h>
+#include <cerrno>
 #include "../../include/troyhip.h"
 #include "evaluator.h"
 #include "kernels.h"
@@ -221,7 +223,7 @@ int troyhip_host_keygen(const troyhip_context *ctx, uint64_t seed_lo, uint64_t s
 }
 int troyhip_host_relin_key(const troyhip_context *ctx, uint64_t seed_lo, uint64_t seed_hi, const uint64_t *secret_key, uint64_t *out) {
     return guard([&] {
-        hostcrypto::Rng rng(seed_lo ^ 0x52454C494Eull, seed_hi);
+        hostcrypto::Rng rng(seed_lo, seed_hi, 1);
         std::vector<u64> src((size_t)ctx->ctx.K * ctx->ctx.N);
         hostcrypto::relin_source(ctx->ctx, secret_key, src.data());
         hostcrypto::keygen_kswitch(ctx->ctx, rng, secret_key, src.data(), out);
@@ -229,7 +231,7 @@ int troyhip_host_relin_key(const troyhip_context *ctx, uint64_t seed_lo, uint64_
 }
 int troyhip_host_galois_key(const troyhip_context *ctx, uint64_t seed_lo, uint64_t seed_hi, const uint64_t *secret_key, uint32_t galois_elt, uint64_t *out) {
     return guard([&] {
-        hostcrypto::Rng rng(seed_lo ^ ((u64)galois_elt << 20), seed_hi ^ 0x47414C4Full);
+        hostcrypto::Rng rng(seed_lo, seed_hi, ((u64)2 << 32) | galois_elt);
         std::vector<u64> src((size_t)ctx->ctx.K * ctx->ctx.N);
         hostcrypto::galois_source(ctx->ctx, secret_key, galois_elt, src.data());
         hostcrypto::keygen_kswitch(ctx->ctx, rng, secret_key, src.data(), out);
@@ -238,7 +240,7 @@ int troyhip_host_galois_key(const troyhip_context *ctx, uint64_t seed_lo, uint64
 int troyhip_host_encrypt(const troyhip_context *ctx, uint64_t seed_lo, uint64_t seed_hi, const uint64_t *public_key, const uint64_t *plain,
                          uint64_t n_coeffs, int limbs, uint64_t *ct_out) {
     return guard([&] {
-        hostcrypto::Rng rng(seed_lo, seed_hi ^ 0x454E43ull);
+        hostcrypto::Rng rng(seed_lo, seed_hi, (u64)3 << 32);
         hostcrypto::encrypt(ctx->ctx, rng, public_key, plain, n_coeffs, limbs, ct_out);
     }, false);
 }
@@ -354,6 +356,20 @@ int troyhip_negacyclic_shift(troyhip_context *ctx, troyhip_ct *ct, uint64_t shif
 }
 int troyhip_divide_by_poly_modulus_degree(troyhip_context *ctx, troyhip_ct *ct, uint64_t mul, uint64_t batch, void *stream) {
     return guard([&] { CtBatch x = view(ct); ctx->ev.divide_by_degree(x, mul, batch, (hipStream_t)stream); store(x, ct); });
+}
+int troyhip_random_bytes(void *out, size_t n) { // the reference seeds its PRNG from std::random_device (src/randomgen.cpp:23,72)
+    return guard([&] {
+        unsigned char *p = static_cast<unsigned char *>(out);
+        while (n) {
+            const ssize_t got = getrandom(p, n, 0);
+            if (got < 0) {
+                if (errno == EINTR) continue;
+                throw Error(ST_RUNTIME_ERROR, "getrandom failed");
+            }
+            p += got;
+            n -= (size_t)got;
+        }
+    }, false);
 }
 int troyhip_blake2b(void *out, size_t outlen, const void *in, size_t inlen) {
     return guard([&] {

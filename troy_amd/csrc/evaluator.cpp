@@ -371,6 +371,14 @@ void Evaluator::mod_switch_scale(const CtBatch &in, CtBatch &out, u64 batch, hip
 
     c.arena.reset();
     const bool dense_in = in.bstride == (u64)in.size * pw, dense_out = out.bstride == (u64)in.size * npw;
+    {   // everything this op carves, reserved up front: take() can only grow an EMPTY arena (a rescale as the first op on a fresh
+        // context, or at a larger batch than the ops before it, used to fail with "scratch arena exhausted inside an op")
+        size_t need = 4 * 32;
+        if (!dense_in) need += batch * in.size * pw;
+        if (!dense_out) need += batch * in.size * npw;
+        if (c.scheme == SCHEME_CKKS) need += batch * in.size * N + batch * in.size * npw;
+        c.arena.reserve(need);
+    }
     const u64 *src = in.data;
     if (!dense_in) {
         u64 *tmp = c.arena.take(batch * in.size * pw);

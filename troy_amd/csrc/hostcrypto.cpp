@@ -29,14 +29,14 @@ void Rng::refill() {
     if (++state[12] == 0) ++state[13];
     pos = 0;
 }
-Rng::Rng(u64 seed_lo, u64 seed_hi) {
+Rng::Rng(u64 seed_lo, u64 seed_hi, u64 stream) {
     static const uint32_t sigma[4] = {0x61707865, 0x3320646e, 0x79622d32, 0x6b206574};
     std::memcpy(state, sigma, 16);
     const u64 k[4] = {seed_lo, seed_hi, seed_lo ^ 0x9E3779B97F4A7C15ULL, seed_hi ^ 0xD1B54A32D192ED03ULL};
     std::memcpy(state + 4, k, 32);
     state[12] = state[13] = 0;
-    state[14] = 0x74726f79; // "troy"
-    state[15] = 0x68697031; // "hip1"
+    state[14] = 0x74726f79u ^ (uint32_t)stream;         // "troy" ^ nonce: independent keystreams for key generation,
+    state[15] = 0x68697031u ^ (uint32_t)(stream >> 32); // "hip1"          relin / Galois keys and every encryption
     pos = 16;
 }
 uint32_t Rng::next32() {

@@ -5,9 +5,9 @@
 namespace troyhip {
 namespace hostcrypto {
 
-class Rng { // ChaCha20 keystream keyed by a 128-bit seed
+class Rng { // ChaCha20 keystream keyed by a 128-bit seed; `stream` (the 64-bit nonce) separates the uses of one seed
 public:
-    Rng(u64 seed_lo, u64 seed_hi);
+    Rng(u64 seed_lo, u64 seed_hi, u64 stream = 0);
     uint32_t next32();
     u64 next64();
     u64 uniform_below(u64 bound);
