@@ -4,6 +4,7 @@
 the HBM roofline and the CPU path timed beside it.
 
     python bench.py --gpus 1 --steps 5 --warmup 2
+    python bench.py --gpus 8 --steps 5 --warmup 2          (starts the 8 ranks itself: self_launch)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 A "step" = one pass of the hot path (multiply + relinearize) over one batch of --batch independent ciphertext pairs
@@ -51,6 +52,38 @@ def max_over_ranks(x, backend="nccl"):
     return float(t.item())
 
 
+def gather_floats(x, backend="nccl"):
+    """every rank's value, in rank order (all_gather of one float64)"""
+    import torch
+    dist = _dist()
+    dev = "cuda" if backend == "nccl" else "cpu"
+    mine = torch.tensor([float(x)], dtype=torch.float64, device=dev)
+    out = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, mine)
+    return [float(t.item()) for t in out]
+
+
+def self_launch(n):
+    """`python bench.py --gpus N` without a launcher: the parent -- before ANY GPU or torch.cuda call, so it never re-execs a
+    GPU-initialised process -- starts N ranks as a child `python -m torch.distributed.run`, relays the child's stdout (rank 0's
+    ONE JSON line) and returns its exit code.  Fewer than N visible devices is an error, not a silent CPU rendezvous."""
+    import socket
+    import subprocess
+    import torch
+    ndev = torch.cuda.device_count()  # counting devices does not initialise the GPU on this image
+    if ndev < n and "--allow-gloo" not in sys.argv:
+        sys.stderr.write(f"bench.py: --gpus {n} but only {ndev} GPU(s) visible\n")
+        return 3
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
 def sum_over_ranks(x, backend="nccl"):
     import torch
     dist = _dist()
@@ -72,7 +105,11 @@ def main():
     ap.add_argument("--ntt-reps", type=int, default=10)
     ap.add_argument("--roofline-only", action="store_true", help="skip the timed steps: only the roofline NTT launches run (for the rocprofv3 summary of exactly that kernel)")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed even for one rank (tests the RCCL path)")
+    ap.add_argument("--allow-gloo", action="store_true", help="development only: rendezvous over gloo when fewer GPUs than ranks are visible (never the default)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -94,18 +131,15 @@ def main():
         ndev = torch.cuda.device_count()  # does not initialise the GPU on this image
         device = local_rank % max(ndev, 1)
         if ndev >= world:
-            try:
-                torch.cuda.set_device(device)
-                dist.init_process_group("nccl")  # RCCL over xGMI; only used for the barrier and the timing reduction
-                max_over_ranks(0.0, "nccl")      # force communicator creation now, fall back if it cannot be built
-                backend = "nccl"
-            except Exception:
-                if dist.is_initialized():
-                    dist.destroy_process_group()
-                backend = None
-        if backend is None:  # fewer devices than ranks (development box) or RCCL unavailable: CPU rendezvous
+            torch.cuda.set_device(device)
+            dist.init_process_group("nccl")  # RCCL over xGMI; only used for the barrier and the timing reductions
+            max_over_ranks(0.0, "nccl")      # builds the communicator now: a broken RCCL setup fails here, loudly
+            backend = "nccl"
+        elif args.allow_gloo:                # fewer devices than ranks on a development box: CPU rendezvous, opt-in only
             dist.init_process_group("gloo")
             backend = "gloo"
+        else:
+            raise SystemExit(f"bench.py: {world} ranks requested but only {ndev} GPU(s) visible (pass --allow-gloo on a development box)")
 
     import numpy as np
 
@@ -195,11 +229,16 @@ def main():
     sync_all()
     dt = max(time.perf_counter() - t0, 1e-9)
     barrier()
+    own_dt = dt
     if use_dist:
-        dt = max_over_ranks(dt, backend)
+        dt = max_over_ranks(own_dt, backend)
         total_ops = sum_over_ranks(B * args.steps, backend)
+        per_rank = gather_floats(B * args.steps / own_dt, backend)
+        world_seen = _dist().get_world_size()
     else:
         total_ops = B * args.steps
+        per_rank = [B * args.steps / own_dt]
+        world_seen = 1
     value = total_ops / dt
 
     # ---- roofline of the dominant kernel: the batched NTT (both passes of one transform = one "launch" unit) ----
@@ -264,6 +303,7 @@ def main():
             "dtype": "u64", "data": "synthetic",
             "config": {"workload": args.workload, "scheme": "BFV", "N": N, "K": K, "L": L, "Bsk": nbsk, "batch_per_gpu": B,
                        "limb_transforms_per_op": limb_transforms, "parallelism": f"batch-shard x{world}", "streams_per_gpu": S, "rendezvous": backend},
+            "ranks": world_seen, "per_rank_ops_per_s": [round(v, 2) for v in per_rank],
             "roofline": roofline, "cpu_baseline": cpu,
         }
         sys.stdout.flush()
@@ -298,14 +338,27 @@ def cpu_baseline(scheme, N, primes, t, L):
         out = {"value": round(reps / secs, 3), "unit": "ops/s", "cores": 1, "kind": "port",
                "sample": f"{reps} multiply+relinearize ops, 1 thread, scalar CPU port (oracle/troy_oracle.cpp, -O3)"}
     # the same work on all host cores, one evaluator per thread over disjoint ciphertexts (the port: its evaluators
-    # share nothing but read-only tables).  Bounded to 32 threads (about 70 MB of working set each at N = 2^15) and about 8 s.
-    threads = min(len(os.sched_getaffinity(0)), 32)
+    # share nothing but read-only tables), one thread per PHYSICAL core (about 70 MB of working set each at N = 2^15), about 8 s.
+    threads = physical_cores()
     if threads > 1:
         reps_all = threads * (30 if N >= 32768 else 200)
         secs = O.time_mul_relin(np.ascontiguousarray(xa), np.ascontiguousarray(xb), reps_all, threads)
         out["all_cores"] = {"value": round(reps_all / secs, 3), "unit": "ops/s", "cores": threads, "kind": "port", "cpu": _cpu_model(),
                             "sample": f"{reps_all} ops over {threads} threads, scalar CPU port (oracle/troy_oracle.cpp, -O3)"}
     return out
+
+
+def physical_cores():
+    """physical cores this process may run on (SMT siblings counted once): SURVEY.md 8(d) asks for all of them"""
+    allowed = os.sched_getaffinity(0)
+    cores = set()
+    for cpu in allowed:
+        try:
+            sib = open(f"/sys/devices/system/cpu/cpu{cpu}/topology/thread_siblings_list").read().strip()
+            cores.add(min(int(x) for part in sib.split(",") for x in part.split("-")))
+        except (OSError, ValueError):
+            cores.add(cpu)
+    return max(1, len(cores))
 
 
 def _cpu_model():

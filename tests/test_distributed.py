@@ -84,3 +84,16 @@ def test_two_rank_scatter_compute_gather(tmp_path):
                           "--master-port", port, str(script)], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
     assert "rank 0 ok" in out.stdout and "rank 1 ok" in out.stdout
+
+
+def test_bench_self_launch_refuses_missing_gpus():
+    """`python bench.py --gpus N` starts its own ranks (bench.self_launch); with fewer than N devices visible it must fail
+    loudly instead of falling back to a CPU rendezvous (VERDICT r1 #2 / ADVICE r1)."""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        import pytest
+        pytest.skip("this box has the GPUs; the refusal path needs fewer than 2")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 3, out.stdout + out.stderr
+    assert "--gpus 2 but only" in out.stderr and out.stdout.strip() == ""

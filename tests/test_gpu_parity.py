@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 import cases
-from conftest import GOLDEN
+from conftest import GOLDEN, ROOT
 
 pytestmark = pytest.mark.gpu
 
@@ -422,3 +422,72 @@ def test_unfused_kernel_paths_agree(env, gpu):
     out = subprocess.run([sys.executable, "-c", code], env={**os.environ, **env}, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     assert out.stdout.split()[-len(names):] == here
+
+
+def _run_bench(args, timeout=900):
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=timeout)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_bench_rccl_single_rank(gpu):
+    """the distributed code path of bench.py (RCCL barrier / reductions / all_gather) on one rank"""
+    line = _run_bench(["--gpus", "1", "--force-dist", "--steps", "1", "--warmup", "0", "--batch", "4", "--workload", "bfv_n8192_l4", "--no-cpu-baseline", "--ntt-reps", "1"])
+    assert line["n_gpus"] == 1 and line["ranks"] == 1 and line["config"]["rendezvous"] == "nccl" and len(line["per_rank_ops_per_s"]) == 1
+
+
+@pytest.mark.gpu
+def test_bench_self_launch_two_ranks(gpu):
+    """`python bench.py --gpus 2` (no launcher): two ranks over RCCL; needs two devices"""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs")
+    line = _run_bench(["--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "8", "--workload", "bfv_n8192_l4", "--no-cpu-baseline", "--ntt-reps", "1"])
+    assert line["n_gpus"] == 2 and line["ranks"] == 2 and line["config"]["rendezvous"] == "nccl" and len(line["per_rank_ops_per_s"]) == 2
+
+
+@pytest.mark.gpu
+def test_dist_scatter_gather_two_ranks_rccl(gpu, tmp_path):
+    """troy_amd/dist.py over RCCL on device views (no host bounce); needs two devices"""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs")
+    script = tmp_path / "w.py"
+    script.write_text(
+        "import sys, os; sys.path.insert(0, %r)\n"
+        "import numpy as np, torch, torch.distributed as dist\n"
+        "from troy_amd import api, capi, dist as tdist, synth\n"
+        "lr = int(os.environ['LOCAL_RANK']); torch.cuda.set_device(lr)\n"
+        "api.KernelProvider.initialize(lr)\n"
+        "dist.init_process_group('nccl')\n"
+        "r = dist.get_rank()\n"
+        "N = 4096\n"
+        "primes = api.CoeffModulus.Create(N, [40, 40, 40])\n"
+        "ctx = api.SEALContext(capi.CKKS, N, primes, 0)\n"
+        "full = synth.uniform_ct(9, primes[:2], 2, N, 5) if r == 0 else None\n"
+        "mine = tdist.scatter_batch(ctx, full, 5, 2, 2, is_ntt_form=True)\n"
+        "api.Evaluator(ctx).negateInplace(mine)\n"
+        "out = tdist.gather_batch(mine, 5)\n"
+        "if r == 0:\n"
+        "    p = np.array(primes[:2], dtype=np.uint64)[None, None, :, None]\n"
+        "    assert np.array_equal(out, np.where(full == 0, full, p - full))\n"
+        "dist.barrier(); dist.destroy_process_group()\n"
+        "os.write(1, ('rank %%d ok\\n' %% r).encode())\n" % ROOT)
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = str(sk.getsockname()[1])
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", port, str(script)], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+    assert "rank 0 ok" in out.stdout and "rank 1 ok" in out.stdout
