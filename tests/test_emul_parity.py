@@ -168,3 +168,38 @@ def test_emulated_ckks_conv2d_helper(emul_api):
 def test_emulated_bfv_multiply_limb_counts(K, emul_api):
     """the three epilogue forms of the matrix-core BEHZ kernels (L mod 4 = 2, 1, other) and the VALU kernels (L = 17)"""
     cases.check_bfv_multiply_limb_count(K, N=64, batch=1)
+
+
+def test_emulated_single_pass_ntt_row_loop_and_prime_classes(oracle_lib, tmp_path):
+    """ntt1.hip (N = 2^15, one HBM round trip): several limbs per workgroup (the prefetching row loop, forced by
+    TROYHIP_NTT1_RPW), ragged last chunk, primes of both butterfly classes (below 2^58: guard-free; 60 / 61 bits: guarded), against
+    the oracle and against the two-pass kernels.  Child processes: the row count per workgroup is read once per process."""
+    import subprocess
+    import sys
+    script = tmp_path / "w.py"
+    script.write_text(
+        "import sys, os; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import numpy as np\n"
+        "from troy_amd import api, capi, synth\n"
+        "from oracle import oracle\n"
+        "lib = capi.load(%r)\n"
+        "api.KernelProvider.initialize(0, _lib=lib)\n"
+        "N = 32768\n"
+        "kp = api.CoeffModulus.Create(N, [60, 50, 58, 40, 60])\n"
+        "ctx = api.SEALContext(api.BFV, N, kp, api.PlainModulus.Batching(N, 20))\n"
+        "primes = kp[:4] + [int(ctx.behz_bases(4)[0][0])]\n"   # + a 61-bit BEHZ prime (guarded butterflies)
+        "assert primes[-1] >> 60 == 1\n"
+        "rows = 5 * len(primes) * 2\n"
+        "x = synth.uniform_rows(7, primes, rows, N, inner=2)\n"
+        "buf = api.DeviceBuffer.from_numpy(x)\n"
+        "ctx.ntt(buf, rows, primes, inner=2)\n"
+        "y = buf.to_numpy().reshape(rows, N)\n"
+        "for r in range(rows):\n"
+        "    assert np.array_equal(y[r], oracle.ntt_standalone(N, primes[(r // 2) %% len(primes)], x[r], 1)), r\n"
+        "ctx.ntt(buf, rows, primes, inner=2, inverse=True)\n"
+        "assert np.array_equal(buf.to_numpy().reshape(rows, N), x)\n"
+        "print('ok')\n" % (ROOT, os.path.join(ROOT, 'tests'), EMUL))
+    for rpw in ("3", "1"):
+        env = dict(os.environ, TROYHIP_NTT1_RPW=rpw)
+        out = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0 and "ok" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]

@@ -41,6 +41,8 @@ __device__ __forceinline__ u64 mulhi_approx1(u64 y, u64 wq) { // floor(y*wq/2^64
 }
 __device__ __forceinline__ void mulhi_approx4(u64 (&q)[4], const u64 (&y)[4], const Shoup (&w)[4]) { for (int i = 0; i < 4; i++) q[i] = mulhi_approx1(y[i], w[i].quo); }
 __device__ __forceinline__ u64 mul_acc(u64 acc, u64 y, u64 w, u64 q, u64 negp) { return acc + w * y + q * negp; }
+__device__ __forceinline__ void mulhi_approx4_u(u64 (&q)[4], const u64 (&y)[4], const Shoup (&w)[4]) { mulhi_approx4(q, y, w); }
+__device__ __forceinline__ u64 mul_acc_u(u64 acc, u64 y, u64 w, u64 q, u64 negp) { return mul_acc(acc, y, w, q, negp); }
 #else
 // x[i] = x[i] >= m ? x[i] - m : x[i]   (x < 2m).  m is wave-uniform; its high word must sit in a VGPR because
 // vcc + an SGPR would exceed the single constant-bus read a gfx9 VALU instruction may make.
@@ -88,63 +90,70 @@ __device__ __forceinline__ void sub4(u64 (&r)[4], const u64 (&a)[4], const u64 (
     r[0] = mk64(r0, r1); r[1] = mk64(r2, r3); r[2] = mk64(r4, r5); r[3] = mk64(r6, r7);
 }
 // q~[i] = y1*q1 + floor((y1*q0 + y0*q1) / 2^32)  =  floor(y*wq/2^64) - {0,1}
-__device__ __forceinline__ void mulhi_approx4(u64 (&q)[4], const u64 (&y)[4], const Shoup (&w)[4]) {
-    u64 s0, s1, s2, s3, sb, sc, sd;
-    u32 c0, c1, c2, c3;
-    asm("v_mad_u64_u32 %0, vcc, %12, %13, 0\n\t"
-        "v_mad_u64_u32 %1, %8, %16, %17, 0\n\t"
-        "v_mad_u64_u32 %2, %9, %20, %21, 0\n\t"
-        "v_mad_u64_u32 %3, %10, %24, %25, 0\n\t"
-        "v_mad_u64_u32 %0, vcc, %11, %14, %0\n\t"
-        "v_mad_u64_u32 %1, %8, %15, %18, %1\n\t"
-        "v_mad_u64_u32 %2, %9, %19, %22, %2\n\t"
-        "v_mad_u64_u32 %3, %10, %23, %26, %3\n\t"
-        "v_cndmask_b32 %4, 0, 1, vcc\n\t"
-        "v_cndmask_b32 %5, 0, 1, %8\n\t"
-        "v_cndmask_b32 %6, 0, 1, %9\n\t"
-        "v_cndmask_b32 %7, 0, 1, %10"
-        : "=&v"(s0), "=&v"(s1), "=&v"(s2), "=&v"(s3), "=&v"(c0), "=&v"(c1), "=&v"(c2), "=&v"(c3), "=&s"(sb), "=&s"(sc), "=&s"(sd)
-        : "v"(lo32(y[0])), "v"(hi32(y[0])), "v"(lo32(w[0].quo)), "v"(hi32(w[0].quo)),
-          "v"(lo32(y[1])), "v"(hi32(y[1])), "v"(lo32(w[1].quo)), "v"(hi32(w[1].quo)),
-          "v"(lo32(y[2])), "v"(hi32(y[2])), "v"(lo32(w[2].quo)), "v"(hi32(w[2].quo)),
-          "v"(lo32(y[3])), "v"(hi32(y[3])), "v"(lo32(w[3].quo)), "v"(hi32(w[3].quo))
-        : "vcc");
-    const u64 s[4] = {s0, s1, s2, s3};
-    const u32 c[4] = {c0, c1, c2, c3};
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const u64 hs = mk64(hi32(s[i]), c[i]);
-        u64 d, sink;
-        asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(sink) : "v"(hi32(y[i])), "v"(hi32(w[i].quo)), "v"(hs));
-        q[i] = d;
+// TWC = "v": per-lane twiddles in VGPRs; TWC = "s": wave-uniform twiddles read straight from SGPRs (one scalar operand per
+// instruction, as the gfx9 constant bus allows) -- no v_mov copies and no VGPRs for them
+#define TROY_DEF_MULHI_APPROX4(NAME, TWC)                                                                                                     \
+    __device__ __forceinline__ void NAME(u64 (&q)[4], const u64 (&y)[4], const Shoup (&w)[4]) {                                               \
+        u64 s0, s1, s2, s3, sb, sc, sd;                                                                                                       \
+        u32 c0, c1, c2, c3;                                                                                                                   \
+        asm("v_mad_u64_u32 %0, vcc, %12, %13, 0\n\t"                                                                                          \
+            "v_mad_u64_u32 %1, %8, %16, %17, 0\n\t"                                                                                           \
+            "v_mad_u64_u32 %2, %9, %20, %21, 0\n\t"                                                                                           \
+            "v_mad_u64_u32 %3, %10, %24, %25, 0\n\t"                                                                                          \
+            "v_mad_u64_u32 %0, vcc, %11, %14, %0\n\t"                                                                                         \
+            "v_mad_u64_u32 %1, %8, %15, %18, %1\n\t"                                                                                          \
+            "v_mad_u64_u32 %2, %9, %19, %22, %2\n\t"                                                                                          \
+            "v_mad_u64_u32 %3, %10, %23, %26, %3\n\t"                                                                                         \
+            "v_cndmask_b32 %4, 0, 1, vcc\n\t"                                                                                                 \
+            "v_cndmask_b32 %5, 0, 1, %8\n\t"                                                                                                  \
+            "v_cndmask_b32 %6, 0, 1, %9\n\t"                                                                                                  \
+            "v_cndmask_b32 %7, 0, 1, %10"                                                                                                     \
+            : "=&v"(s0), "=&v"(s1), "=&v"(s2), "=&v"(s3), "=&v"(c0), "=&v"(c1), "=&v"(c2), "=&v"(c3), "=&s"(sb), "=&s"(sc), "=&s"(sd)         \
+            : "v"(lo32(y[0])), "v"(hi32(y[0])), TWC(lo32(w[0].quo)), TWC(hi32(w[0].quo)), "v"(lo32(y[1])), "v"(hi32(y[1])), TWC(lo32(w[1].quo)), \
+              TWC(hi32(w[1].quo)), "v"(lo32(y[2])), "v"(hi32(y[2])), TWC(lo32(w[2].quo)), TWC(hi32(w[2].quo)), "v"(lo32(y[3])), "v"(hi32(y[3])), \
+              TWC(lo32(w[3].quo)), TWC(hi32(w[3].quo))                                                                                        \
+            : "vcc");                                                                                                                         \
+        const u64 s[4] = {s0, s1, s2, s3};                                                                                                    \
+        const u32 c[4] = {c0, c1, c2, c3};                                                                                                    \
+        _Pragma("unroll") for (int i = 0; i < 4; i++) {                                                                                       \
+            const u64 hs = mk64(hi32(s[i]), c[i]);                                                                                            \
+            u64 d, sink;                                                                                                                      \
+            asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(sink) : "v"(hi32(y[i])), TWC(hi32(w[i].quo)), "v"(hs));                    \
+            q[i] = d;                                                                                                                         \
+        }                                                                                                                                     \
     }
-}
+TROY_DEF_MULHI_APPROX4(mulhi_approx4, "v")
+TROY_DEF_MULHI_APPROX4(mulhi_approx4_u, "s")
 // acc + w*y + q*negp (mod 2^64); no carry chains -> no hazards, one butterfly per block
-__device__ __forceinline__ u64 mul_acc(u64 acc, u64 y, u64 w, u64 q, u64 negp) {
-    const u32 y0 = lo32(y), y1 = hi32(y), w0 = lo32(w), w1 = hi32(w), d0 = lo32(q), d1 = hi32(q);
-    u64 a, r, sc0, sc1;
-    u32 m0, m1, m2, m3, c0, h;
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(a), "=s"(sc0) : "v"(w0), "v"(y0), "v"(acc));
-    asm("v_mul_lo_u32 %0, %1, %2" : "=v"(m0) : "v"(w0), "v"(y1));
-    asm("v_mul_lo_u32 %0, %1, %2" : "=v"(m1) : "v"(w1), "v"(y0));
-    asm("v_mul_lo_u32 %0, %1, %2" : "=v"(m2) : "v"(d0), "s"(hi32(negp)));
-    asm("v_mul_lo_u32 %0, %1, %2" : "=v"(m3) : "v"(d1), "s"(lo32(negp)));
-    asm("v_add3_u32 %0, %1, %2, %3" : "=v"(c0) : "v"(m0), "v"(m1), "v"(m2));
-    asm("v_add3_u32 %0, %1, %2, %3" : "=v"(h) : "v"(hi32(a)), "v"(c0), "v"(m3));
-    const u64 a2 = mk64(lo32(a), h);
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(r), "=s"(sc1) : "v"(d0), "s"(lo32(negp)), "v"(a2));
-    return r;
-}
+#define TROY_DEF_MUL_ACC(NAME, TWC)                                                                                                           \
+    __device__ __forceinline__ u64 NAME(u64 acc, u64 y, u64 w, u64 q, u64 negp) {                                                             \
+        const u32 y0 = lo32(y), y1 = hi32(y), w0 = lo32(w), w1 = hi32(w), d0 = lo32(q), d1 = hi32(q);                                         \
+        u64 a, r, sc0, sc1;                                                                                                                   \
+        u32 m0, m1, m2, m3, c0, h;                                                                                                            \
+        asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(a), "=s"(sc0) : TWC(w0), "v"(y0), "v"(acc));                                            \
+        asm("v_mul_lo_u32 %0, %1, %2" : "=v"(m0) : TWC(w0), "v"(y1));                                                                         \
+        asm("v_mul_lo_u32 %0, %1, %2" : "=v"(m1) : TWC(w1), "v"(y0));                                                                         \
+        asm("v_mul_lo_u32 %0, %1, %2" : "=v"(m2) : "v"(d0), "s"(hi32(negp)));                                                                 \
+        asm("v_mul_lo_u32 %0, %1, %2" : "=v"(m3) : "v"(d1), "s"(lo32(negp)));                                                                 \
+        asm("v_add3_u32 %0, %1, %2, %3" : "=v"(c0) : "v"(m0), "v"(m1), "v"(m2));                                                              \
+        asm("v_add3_u32 %0, %1, %2, %3" : "=v"(h) : "v"(hi32(a)), "v"(c0), "v"(m3));                                                          \
+        const u64 a2 = mk64(lo32(a), h);                                                                                                      \
+        asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(r), "=s"(sc1) : "v"(d0), "s"(lo32(negp)), "v"(a2));                                     \
+        return r;                                                                                                                             \
+    }
+TROY_DEF_MUL_ACC(mul_acc, "v")
+TROY_DEF_MUL_ACC(mul_acc_u, "s")
 #endif
 
 // Four forward butterflies (Cooley-Tukey, src/utils/dwthandler.h:88-204): X,Y in [0,8p) -> [0,8p)
-__device__ __forceinline__ void ct_bfly4(u64 (&X)[4], u64 (&Y)[4], const Shoup (&w)[4], const PrimeConst &c) {
+// UNI (all four forms below): the twiddles are wave-uniform and sit in SGPRs
+template <bool UNI = false> __device__ __forceinline__ void ct_bfly4(u64 (&X)[4], u64 (&Y)[4], const Shoup (&w)[4], const PrimeConst &c) {
     csub4(X, c.four_p);                                       // u in [0,4p)
     u64 q[4], xn[4], t[4];
-    mulhi_approx4(q, Y, w);
+    if (UNI) mulhi_approx4_u(q, Y, w); else mulhi_approx4(q, Y, w);
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        xn[i] = mul_acc(X[i], Y[i], w[i].op, q[i], c.negp);   // u + v, v in [0,3p) -> [0,7p)
+        xn[i] = UNI ? mul_acc_u(X[i], Y[i], w[i].op, q[i], c.negp) : mul_acc(X[i], Y[i], w[i].op, q[i], c.negp);   // u + v, v in [0,3p) -> [0,7p)
         t[i] = (X[i] << 1) + c.three_p;
     }
     sub4(Y, t, xn);                                           // u + 3p - v -> (0,7p)
@@ -152,42 +161,42 @@ __device__ __forceinline__ void ct_bfly4(u64 (&X)[4], u64 (&Y)[4], const Shoup (
     for (int i = 0; i < 4; i++) X[i] = xn[i];
 }
 // Four inverse butterflies (Gentleman-Sande, dwthandler.h:215-372): X,Y in [0,4p) -> [0,4p)
-__device__ __forceinline__ void gs_bfly4(u64 (&X)[4], u64 (&Y)[4], const Shoup (&w)[4], const PrimeConst &c) {
+template <bool UNI = false> __device__ __forceinline__ void gs_bfly4(u64 (&X)[4], u64 (&Y)[4], const Shoup (&w)[4], const PrimeConst &c) {
     u64 s[4], t[4], d[4], q[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) { s[i] = X[i] + Y[i]; t[i] = X[i] + c.four_p; }
     sub4(d, t, Y);                                            // u + 4p - v in (0,8p)
     csub4(s, c.four_p);
-    mulhi_approx4(q, d, w);
+    if (UNI) mulhi_approx4_u(q, d, w); else mulhi_approx4(q, d, w);
 #pragma unroll
-    for (int i = 0; i < 4; i++) { X[i] = s[i]; Y[i] = mul_acc(0, d[i], w[i].op, q[i], c.negp); }
+    for (int i = 0; i < 4; i++) { X[i] = s[i]; Y[i] = UNI ? mul_acc_u(0, d[i], w[i].op, q[i], c.negp) : mul_acc(0, d[i], w[i].op, q[i], c.negp); }
 }
 // last inverse stage with N^-1 folded in (dwthandler.h:289-330): -> [0,3p)
-__device__ __forceinline__ void gs_bfly4_last(u64 (&X)[4], u64 (&Y)[4], const Shoup (&w_scaled)[4], const Shoup inv_n, const PrimeConst &c) {
+template <bool UNI = false> __device__ __forceinline__ void gs_bfly4_last(u64 (&X)[4], u64 (&Y)[4], const Shoup (&w_scaled)[4], const Shoup inv_n, const PrimeConst &c) {
     u64 s[4], t[4], d[4], q[4];
     const Shoup wn[4] = {inv_n, inv_n, inv_n, inv_n};
 #pragma unroll
     for (int i = 0; i < 4; i++) { s[i] = X[i] + Y[i]; t[i] = X[i] + c.four_p; }
     sub4(d, t, Y);
     csub4(s, c.four_p);
-    mulhi_approx4(q, s, wn);
+    if (UNI) mulhi_approx4_u(q, s, wn); else mulhi_approx4(q, s, wn);
 #pragma unroll
-    for (int i = 0; i < 4; i++) X[i] = mul_acc(0, s[i], inv_n.op, q[i], c.negp);
-    mulhi_approx4(q, d, w_scaled);
+    for (int i = 0; i < 4; i++) X[i] = UNI ? mul_acc_u(0, s[i], inv_n.op, q[i], c.negp) : mul_acc(0, s[i], inv_n.op, q[i], c.negp);
+    if (UNI) mulhi_approx4_u(q, d, w_scaled); else mulhi_approx4(q, d, w_scaled);
 #pragma unroll
-    for (int i = 0; i < 4; i++) Y[i] = mul_acc(0, d[i], w_scaled[i].op, q[i], c.negp);
+    for (int i = 0; i < 4; i++) Y[i] = UNI ? mul_acc_u(0, d[i], w_scaled[i].op, q[i], c.negp) : mul_acc(0, d[i], w_scaled[i].op, q[i], c.negp);
 }
 // ---- guard-free ("lean") butterflies: no conditional subtraction at all; the CALLER tracks the value bound (in units of p) per
 // stage and inserts a reduction (barrett_lite4) only where the next stage could leave 64 bits.  For the primes the
 // reference's parameter generator produces below 2^58 (CoeffModulus::Create with <= 58-bit sizes) a whole 15-stage forward
 // transform needs none: every stage adds at most 3p to the bound (v = w*y mod p lazily in [0,3p)).
 // forward: X' = X + v, Y' = X + 3p - v; both outputs < bound(X) + 3p.  15 VALU instructions.
-__device__ __forceinline__ void ct_bfly4_ng(u64 (&X)[4], u64 (&Y)[4], const Shoup (&w)[4], const PrimeConst &c) {
+template <bool UNI = false> __device__ __forceinline__ void ct_bfly4_ng(u64 (&X)[4], u64 (&Y)[4], const Shoup (&w)[4], const PrimeConst &c) {
     u64 q[4], xn[4], t[4];
-    mulhi_approx4(q, Y, w);
+    if (UNI) mulhi_approx4_u(q, Y, w); else mulhi_approx4(q, Y, w);
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        xn[i] = mul_acc(X[i], Y[i], w[i].op, q[i], c.negp);
+        xn[i] = UNI ? mul_acc_u(X[i], Y[i], w[i].op, q[i], c.negp) : mul_acc(X[i], Y[i], w[i].op, q[i], c.negp);
         t[i] = (X[i] << 1) + c.three_p;
     }
     sub4(Y, t, xn);
@@ -196,16 +205,16 @@ __device__ __forceinline__ void ct_bfly4_ng(u64 (&X)[4], u64 (&Y)[4], const Shou
 }
 // inverse: X' = X + Y, Y' = (X + kp - Y) * w lazily in [0,3p); kp = a multiple of p that is >= bound(Y); the caller keeps
 // bound(X) + kp < 2^64.  16 VALU instructions.
-__device__ __forceinline__ void gs_bfly4_ng(u64 (&X)[4], u64 (&Y)[4], const Shoup (&w)[4], u64 kp, const PrimeConst &c) {
+template <bool UNI = false> __device__ __forceinline__ void gs_bfly4_ng(u64 (&X)[4], u64 (&Y)[4], const Shoup (&w)[4], u64 kp, const PrimeConst &c) {
     u64 t[4], d[4], q[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) t[i] = X[i] + kp;
     sub4(d, t, Y);
 #pragma unroll
     for (int i = 0; i < 4; i++) X[i] = X[i] + Y[i];
-    mulhi_approx4(q, d, w);
+    if (UNI) mulhi_approx4_u(q, d, w); else mulhi_approx4(q, d, w);
 #pragma unroll
-    for (int i = 0; i < 4; i++) Y[i] = mul_acc(0, d[i], w[i].op, q[i], c.negp);
+    for (int i = 0; i < 4; i++) Y[i] = UNI ? mul_acc_u(0, d[i], w[i].op, q[i], c.negp) : mul_acc(0, d[i], w[i].op, q[i], c.negp);
 }
 // final normalisations to the canonical residue, four values at a time
 __device__ __forceinline__ void reduce4_from_8p(u64 (&x)[4], const PrimeConst &c) { csub4(x, c.four_p); csub4(x, c.two_p); csub4(x, c.p); }

@@ -179,6 +179,7 @@ LimbMap Context::ct_map(int limbs) const {
     for (int i = 0; i < limbs; i++) m.id[i] = (uint8_t)i;
     m.period = (uint32_t)limbs;
     m.inner = 1;
+    for (int i = 0; i < limbs && i < 64; i++) m.lean |= (u64)(primes[i] >= (u64(1) << 33) && primes[i] < (u64(1) << 58)) << i;
     return m;
 }
 LimbMap Context::ids_map(const std::vector<uint8_t> &ids, uint32_t inner) const {
@@ -188,6 +189,7 @@ LimbMap Context::ids_map(const std::vector<uint8_t> &ids, uint32_t inner) const 
     for (size_t i = 0; i < ids.size(); i++) m.id[i] = ids[i];
     m.period = (uint32_t)ids.size();
     m.inner = inner;
+    for (size_t i = 0; i < ids.size(); i++) m.lean |= (u64)(primes[ids[i]] >= (u64(1) << 33) && primes[ids[i]] < (u64(1) << 58)) << i;
     return m;
 }
 LimbMap Context::single_map(int id) const { return ids_map({(uint8_t)id}); }

@@ -19,6 +19,7 @@ __host__ __device__ inline Mod mod_of(const PrimeDesc &d) { return Mod{d.p, d.cr
 struct LimbMap {
     uint8_t id[64];
     uint32_t period, inner;
+    uint64_t lean; // bit i: the prime of slot i lies in [2^33, 2^58) -- guard-free butterflies apply (bfly.h); host-side dispatch only
 };
 
 #define TROY_BUF_OOB 0x80000000u // an offset no buffer range reaches (ranges are < 2^31 bytes)

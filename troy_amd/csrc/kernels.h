@@ -22,6 +22,10 @@ bool ntt2_supported(int logn);
 void launch_ntt2(u64 *data, const u64 *src, u64 src_ostride, bool src_reduce, const PrimeDesc *primes, const LimbMap &map, size_t rows, int logn,
                  bool inverse, hipStream_t stream, bool src_same_layout = false, u64 src_bound = 0);
 
+// ---- ntt1.hip (N = 2^15: one HBM round trip per limb-transform) ----
+bool ntt1_supported(int logn, const LimbMap &map, size_t rows);
+void launch_ntt1(u64 *data, const u64 *src, const PrimeDesc *primes, const LimbMap &map, size_t rows, bool inverse, hipStream_t stream);
+
 // ---- poly.hip ----
 void launch_ew(int op, const u64 *a, const u64 *b, u64 *out, const PrimeDesc *primes, const LimbMap &map, int logn, u64 rows, hipStream_t s);
 void launch_mul_scalar(u64 *x, const PrimeDesc *primes, const LimbMap &map, const u64 *scalars, int logn, u64 rows, hipStream_t s);

@@ -1,0 +1,551 @@
+// ntt1.hip -- single-pass NTT / INTT for N = 2^15 on gfx950: ONE HBM round trip per limb-transform.
+//
+// Replaces the two launches of ntt2.hip (strided pass + contiguous pass, 32 B of HBM traffic per coefficient) for the plain
+// transforms of the reference (kNttNegacyclicHarvey / kInverseNttNegacyclicHarvey, src/kernelutils.cuh:578-632, host loops
+// src/kernelutils.cu:330-371, stage kernels :373-476, CPU twin src/utils/dwthandler.h:88-372).  Same transform, same tables,
+// canonical outputs: any exact evaluation order is bit-identical.
+//
+// A limb is 256 KiB; a CU has 512 KiB of vector registers and 160 KiB of LDS.  One 1024-thread workgroup (16 waves, 4 per
+// SIMD, <= 128 VGPRs) owns a whole limb:
+//   * round A (forward: the first 5 stages, gaps 2^14 .. 2^10) runs on 32 coefficients per thread, straight from HBM
+//     (512-byte contiguous runs per wave and instruction); every twiddle of these stages is workgroup-uniform (scalar loads);
+//   * the limb then splits into 32 independent 1024-point sub-transforms.  They go through LDS in two halves of 16 sub-blocks
+//     (128 KiB): each WAVE owns one sub-block of 1024 points = 16 per lane and runs its remaining 10 stages as radix-16,
+//     radix-16, radix-4 rounds IN PLACE in its own 8 KiB region (no workgroup barrier inside; LDS operations of a wave
+//     execute in order), with the XOR swizzle sw1() that is bank-conflict-free for every access pattern used (checked
+//     exhaustively against the LDS lane-group rules of MI355X_MICROARCH.md: tools/lds_banks.py);
+//   * the other half waits in registers (32 VGPRs) meanwhile; 4 workgroup barriers per limb in total;
+//   * the next limb's loads are issued as soon as registers are free and the butterflies that do not need them run first
+//     (forward: the radix-16 part of round A on the even registers; inverse: LDS-DMA staging during round A), so the CU
+//     streams from HBM while it computes;
+//   * the inverse runs the same schedule backwards (sub-blocks first, the cross-wave round last, N^-1 folded in).
+// Butterflies: bfly.h.  LEAN = primes below 2^58 (everything CoeffModulus::Create makes for sizes <= 58 bits): the forward
+// transform needs no range guard at all in 15 stages (bound 1 + 15 * 3 = 46 p < 2^64), 16 VALU instructions per butterfly
+// instead of 20; other primes keep the guarded forms.
+#include "kernels.h"
+#include "bfly.h"
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+namespace troyhip {
+
+#define N1_THREADS 1024
+#define N1_LOGN 15
+#define N1_N (1u << N1_LOGN)
+
+struct Ntt1Args {
+    u64 *data;            // rows of N coefficients, transformed in place ...
+    const u64 *src;       // ... or read from here (same row layout) when not null
+    const PrimeDesc *primes;
+    LimbMap map;          // row r = (o * period + i) * inner + k  has prime map.id[i]
+    unsigned m_total;     // outer * inner rows per prime slot
+    unsigned rows_per_wg;
+    unsigned chunks;      // ceil(m_total / rows_per_wg)
+    unsigned nslots;      // a launch covers the prime slots slots[0 .. nslots) of the pattern (one launch per prime class)
+    uint8_t slots[64];
+    u64 *dbg;             // development builds (-DN1_TIMING): s_memtime stamps of wave 0 of workgroup dbg_block
+    unsigned dbg_block;
+};
+#ifdef N1_TIMING
+#define N1_STAMP(i) do { if (a.dbg && threadIdx.x == 0 && blockIdx.x == a.dbg_block) a.dbg[(i) + 16 * (mm - m_begin)] = clock64(); } while (0)
+#else
+#define N1_STAMP(i)
+#endif
+
+// position of element j (0..1023) of a sub-block inside its 8 KiB LDS region.  Involution; keeps bit 0 (16-byte pairs stay
+// together).  Conflict-free for: j = 64 r + lane (rounds A/B, 8-byte accesses), j = 64 (lane / 4) + 4 r + lane % 4 (round C),
+// j = 256 g + 4 lane + {0, 2} (round D, 16-byte reads), j = 128 i + 2 lane (lane-linear 16-byte staging).
+__device__ __forceinline__ unsigned sw1(unsigned j) { return j ^ (((j >> 6) & 7u) << 2) ^ (((j >> 5) & 1u) << 1); }
+
+// twiddle loads.  The table pointers come out of a PrimeDesc that was itself loaded from memory, so the compiler would use flat
+// loads; the tables are read-only global memory: per-lane entries go through global loads, workgroup-/wave-uniform entries
+// through the scalar cache (constant address space), 16 bytes each
+#ifdef TROYHIP_CPU_EMUL
+__device__ __forceinline__ Shoup ld_tw(const Shoup *base, unsigned idx) { return base[idx]; }
+__device__ __forceinline__ Shoup ld_tw_uniform(const Shoup *p) { return *p; }
+#else
+typedef unsigned long long troy_v2ull __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ Shoup ld_tw(const Shoup *base, unsigned idx) { // base is wave-uniform (SGPR pair), idx per lane: saddr + 32-bit offset
+    const troy_v2ull v = ((const __attribute__((address_space(1))) troy_v2ull *)base)[idx];
+    return Shoup{v.x, v.y};
+}
+__device__ __forceinline__ Shoup ld_tw_uniform(const Shoup *p) {
+    const troy_v2ull v = *((const __attribute__((address_space(4))) troy_v2ull *)p);
+    return Shoup{v.x, v.y};
+}
+#endif
+
+// keeps the LDS / table address arithmetic of a sub-block inside the row loop: hoisted out of it, the ~40 lane-dependent
+// addresses of the three rounds would have to live (and be spilled) across the whole kernel; recomputing them costs a few XORs
+__device__ __forceinline__ unsigned opaque(unsigned v) {
+#ifndef TROYHIP_CPU_EMUL
+    asm volatile("" : "+v"(v));
+#endif
+    return v;
+}
+#ifdef TROYHIP_CPU_EMUL
+#define N1_SCHED_FENCE()
+#else
+#define N1_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
+
+__device__ __forceinline__ unsigned uniform_u32(unsigned v) {
+#ifdef TROYHIP_CPU_EMUL
+    return v;
+#else
+    return __builtin_amdgcn_readfirstlane(v);
+#endif
+}
+// data access with a wave-uniform base and a per-lane 32-bit element offset (global_load/store ... saddr form: no 64-bit address VGPRs)
+#ifdef TROYHIP_CPU_EMUL
+__device__ __forceinline__ u64 ld_g(const u64 *base, unsigned off) { return base[off]; }
+__device__ __forceinline__ void st_g(u64 *base, unsigned off, u64 v) { base[off] = v; }
+__device__ __forceinline__ ulonglong2 ld_g2(const u64 *base, unsigned off) { return *reinterpret_cast<const ulonglong2 *>(base + off); }
+__device__ __forceinline__ void st_g2(u64 *base, unsigned off, ulonglong2 v) { *reinterpret_cast<ulonglong2 *>(base + off) = v; }
+#else
+__device__ __forceinline__ u64 ld_g(const u64 *base, unsigned off) { return ((const __attribute__((address_space(1))) u64 *)base)[off]; }
+__device__ __forceinline__ void st_g(u64 *base, unsigned off, u64 v) { ((__attribute__((address_space(1))) u64 *)base)[off] = v; }
+__device__ __forceinline__ ulonglong2 ld_g2(const u64 *base, unsigned off) { // off even: 16 bytes
+    const troy_v2ull v = *(const __attribute__((address_space(1))) troy_v2ull *)(((const __attribute__((address_space(1))) u64 *)base) + off);
+    ulonglong2 r;
+    r.x = v.x;
+    r.y = v.y;
+    return r;
+}
+__device__ __forceinline__ void st_g2(u64 *base, unsigned off, ulonglong2 v) {
+    troy_v2ull w;
+    w.x = v.x;
+    w.y = v.y;
+    *(__attribute__((address_space(1))) troy_v2ull *)(((__attribute__((address_space(1))) u64 *)base) + off) = w;
+}
+#endif
+
+// ---- R forward stages on G groups of 2^R register-resident values; tw(st, g, blk) = twiddle of block blk of group g at stage st
+template <int G, int R, bool LEAN, bool UNI, class TW> __device__ __forceinline__ void fwd_stages(u64 (&y)[G << R], const TW &tw, const PrimeConst &pc) {
+#pragma unroll
+    for (int st = 0; st < R; st++) {
+        const int half = (1 << R) >> (st + 1);
+#pragma unroll
+        for (int c = 0; c < (G << (R - 1)) / 4; c++) {
+            u64 X[4], Y[4];
+            Shoup w[4];
+            int ix[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int b = 4 * c + i, g = b >> (R - 1), r = b & ((1 << (R - 1)) - 1);
+                const int blk = r / half, k = r % half;
+                ix[i] = (g << R) + blk * 2 * half + k;
+                X[i] = y[ix[i]];
+                Y[i] = y[ix[i] + half];
+                w[i] = tw(st, g, blk);
+            }
+            if (LEAN) ct_bfly4_ng<UNI>(X, Y, w, pc); else ct_bfly4<UNI>(X, Y, w, pc);
+#pragma unroll
+            for (int i = 0; i < 4; i++) { y[ix[i]] = X[i]; y[ix[i] + half] = Y[i]; }
+            N1_SCHED_FENCE(); // one group of four butterflies at a time: interleaving several only multiplies the temporaries (128-VGPR budget)
+        }
+    }
+}
+// ---- R inverse stages (gaps grow: 1, 2, ..); LAST: the final stage of the transform (N^-1 folded in, tw gives the scaled twiddle)
+template <int G, int R, bool LAST, bool UNI, class TW> __device__ __forceinline__ void inv_stages(u64 (&y)[G << R], const TW &tw, const Shoup inv_n, const PrimeConst &pc) {
+#pragma unroll
+    for (int st = 0; st < R; st++) {
+        const int dist = 1 << st;
+#pragma unroll
+        for (int c = 0; c < (G << (R - 1)) / 4; c++) {
+            u64 X[4], Y[4];
+            Shoup w[4];
+            int ix[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int b = 4 * c + i, g = b >> (R - 1), r = b & ((1 << (R - 1)) - 1);
+                const int blk = r / dist, k = r % dist;
+                ix[i] = (g << R) + blk * 2 * dist + k;
+                X[i] = y[ix[i]];
+                Y[i] = y[ix[i] + dist];
+                w[i] = tw(st, g, blk);
+            }
+            if (LAST && st == R - 1) gs_bfly4_last<UNI>(X, Y, w, inv_n, pc); else gs_bfly4<UNI>(X, Y, w, pc);
+#pragma unroll
+            for (int i = 0; i < 4; i++) { y[ix[i]] = X[i]; y[ix[i] + dist] = Y[i]; }
+            N1_SCHED_FENCE();
+        }
+    }
+}
+
+// the last 10 forward stages (5..14) of sub-block sb (coefficients 1024 sb .. 1024 sb + 1023), in place in the wave's region,
+// result canonical to `out` (the sub-block's 1024 coefficients in HBM)
+template <bool LEAN> __device__ __forceinline__ void fwd_subblock(u64 *R, const unsigned sb, const unsigned lane_in, const PrimeDesc &pd, const PrimeConst &pc, const Mod &m,
+                                                                  u64 *out, const Ntt1Args &a, const unsigned mm, const unsigned m_begin, const int stamp0) {
+    (void)a; (void)mm; (void)m_begin; (void)stamp0;
+    const unsigned lane = opaque(lane_in);
+    {   // round B: stages 5..8 on 16 values, registers = j9..j6, lane = j5..j0; twiddles depend on (sb, register) only: scalar loads
+        u64 y[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) y[r] = R[sw1(64 * r + lane)];
+        fwd_stages<1, 4, LEAN, true>(y, [&](int st, int, int blk) { return ld_tw_uniform(pd.root + (32u << st) + (sb << st) + blk); }, pc);
+#pragma unroll
+        for (int r = 0; r < 16; r++) R[sw1(64 * r + lane)] = y[r];
+    }
+    TROY_WAVE_SYNC();
+    N1_STAMP(stamp0);
+    N1_SCHED_FENCE(); // the twiddle loads below stay below: hoisted over round B they would not fit the register budget
+    {   // round C1: stages 9..11 on 8 values, registers = j5 j4 j3, lane = (j9..j6, j1 j0), iteration = j2; both iterations share
+        // the seven twiddles
+        const unsigned h = lane >> 2, low = lane & 3;
+        const unsigned b9 = 16 * sb + h;
+        const Shoup t9 = ld_tw(pd.root, 512 + b9);
+        Shoup t10[2], t11[4];
+#pragma unroll
+        for (int i = 0; i < 2; i++) t10[i] = ld_tw(pd.root, 1024 + 2 * b9 + i);
+#pragma unroll
+        for (int i = 0; i < 4; i++) t11[i] = ld_tw(pd.root, 2048 + 4 * b9 + i);
+#pragma unroll 1
+        for (unsigned it = 0; it < 2; it++) {
+            u64 y[8];
+#pragma unroll
+            for (int r = 0; r < 8; r++) y[r] = R[sw1(64 * h + 8 * r + 4 * it + low)];
+            fwd_stages<1, 3, LEAN, false>(y, [&](int st, int, int blk) { return st == 0 ? t9 : (st == 1 ? t10[blk] : t11[blk]); }, pc);
+#pragma unroll
+            for (int r = 0; r < 8; r++) R[sw1(64 * h + 8 * r + 4 * it + low)] = y[r];
+        }
+    }
+    TROY_WAVE_SYNC();
+    N1_STAMP(stamp0 + 1);
+    N1_SCHED_FENCE();
+    // round C2: stages 12..14 on 8 consecutive coefficients, u = j9..j3 = lane + 64 iteration
+#pragma unroll 1
+    for (unsigned it = 0; it < 2; it++) {
+        const unsigned u = lane + 64 * it;
+        u64 y[8];
+        const unsigned b12 = 128 * sb + u;
+        const Shoup t12 = ld_tw(pd.root, 4096 + b12);
+        Shoup t13[2], t14[4];
+#pragma unroll
+        for (int i = 0; i < 2; i++) t13[i] = ld_tw(pd.root, 8192 + 2 * b12 + i);
+#pragma unroll
+        for (int i = 0; i < 4; i++) t14[i] = ld_tw(pd.root, 16384 + 4 * b12 + i);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(R + sw1(8 * u + 2 * q));
+            y[2 * q] = v.x;
+            y[2 * q + 1] = v.y;
+        }
+        fwd_stages<1, 3, LEAN, false>(y, [&](int st, int, int blk) { return st == 0 ? t12 : (st == 1 ? t13[blk] : t14[blk]); }, pc);
+        if (LEAN) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) y[i] = barrett64(y[i], m);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                u64 v[4] = {y[4 * q], y[4 * q + 1], y[4 * q + 2], y[4 * q + 3]};
+                reduce4_from_8p(v, pc);
+#pragma unroll
+                for (int i = 0; i < 4; i++) y[4 * q + i] = v[i];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            ulonglong2 v;
+            v.x = y[2 * q];
+            v.y = y[2 * q + 1];
+            st_g2(out, 8 * u + 2 * q, v);
+        }
+    }
+}
+
+template <bool LEAN> __global__ __launch_bounds__(N1_THREADS) void ntt1_fwd_kernel(Ntt1Args a) {
+    // 16 regions of 8 KiB + 32 KiB in which four of the sixteen registers of the waiting half are parked (the other twelve stay in
+    // VGPRs): all 160 KiB of the CU
+    __shared__ __attribute__((aligned(16))) u64 lds[20 * 1024];
+    const unsigned tid = threadIdx.x, lane = tid & 63;
+#ifdef TROYHIP_CPU_EMUL
+    const unsigned wv = tid >> 6;
+#else
+    const unsigned wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+#endif
+    // the byte tables of the argument block are read with vector loads: tell the compiler the results are wave-uniform
+    const unsigned slot = uniform_u32(a.slots[blockIdx.x / a.chunks]), chunk = blockIdx.x % a.chunks;
+    const PrimeDesc pd = a.primes[uniform_u32(a.map.id[slot])];
+    const PrimeConst pc = make_prime_const(pd.p);
+    const Mod m = mod_of(pd);
+    const unsigned m_begin = chunk * a.rows_per_wg;
+    const unsigned m_end = (m_begin + a.rows_per_wg < a.m_total) ? m_begin + a.rows_per_wg : a.m_total;
+    const unsigned inner = a.map.inner, period = a.map.period;
+    auto row_of = [&](unsigned mm) -> u64 {
+        const unsigned o = mm / inner, k = mm - o * inner;
+        return (((u64)o * period + slot) * inner + k) << N1_LOGN;
+    };
+    const u64 *in_base = a.src ? a.src : a.data;
+    u64 *const region = lds + 1024 * wv;
+    // registers of round A: xe[r'] = coefficient 1024 (2 r') + tid, xo[r'] = coefficient 1024 (2 r' + 1) + tid
+    u64 xe[16], xo[16];
+    // loads and stores of round A: ONE wave-uniform base (the limb) plus a 32-bit per-thread offset (one v_add per access; 32
+    // uniform bases would not fit the scalar registers next to the twiddles)
+    auto load_half = [&](u64 (&x)[16], const u64 *rowp, unsigned odd) {
+        const unsigned t = opaque(tid); // the 16 offsets are formed here, next to the loads, not carried through the kernel
+#pragma unroll
+        for (int r = 0; r < 16; r++) x[r] = ld_g(rowp, t + 2048 * r + 1024 * odd);
+    };
+    load_half(xe, in_base + row_of(m_begin), 0);
+    load_half(xo, in_base + row_of(m_begin), 1);
+    u64 *const wlo = lds + sw1(tid), *const whi = wlo + 8 * 1024; // LDS addresses of this thread's element in regions 0..7 / 8..15
+    u64 *const park = lds + 16 * 1024 + tid;
+    for (unsigned mm = m_begin; mm < m_end; mm++) {
+        u64 *const out = a.data + row_of(mm);
+        N1_STAMP(0);
+        // round A: stages 0..3 on the even and on the odd registers (the odd ones were requested last), then stage 4 across
+        auto twA = [&](int st, int, int blk) { return ld_tw_uniform((pd.root + (1u << st) + blk)); };
+        fwd_stages<1, 4, LEAN, true>(xe, twA, pc);
+        fwd_stages<1, 4, LEAN, true>(xo, twA, pc);
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            u64 X[4], Y[4];
+            Shoup w[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) { X[i] = xe[4 * c + i]; Y[i] = xo[4 * c + i]; w[i] = ld_tw_uniform((pd.root + 16 + 4 * c + i)); }
+            if (LEAN) ct_bfly4_ng<true>(X, Y, w, pc); else ct_bfly4<true>(X, Y, w, pc);
+#pragma unroll
+            for (int i = 0; i < 4; i++) { xe[4 * c + i] = X[i]; xo[4 * c + i] = Y[i]; }
+            N1_SCHED_FENCE();
+        }
+        N1_STAMP(1);
+        // sub-block 2 r' (2 r' + 1) = xe[r'] (xo[r']) of all threads; half hf = sub-blocks 16 hf .. 16 hf + 15
+#pragma unroll
+        for (int hf = 0; hf < 2; hf++) {
+            if (hf == 1 || mm != m_begin) __syncthreads(); // every wave is done with the regions' previous content
+            N1_STAMP(2 + 6 * hf);
+            if (hf == 1) {
+#pragma unroll
+                for (int r = 0; r < 2; r++) { xe[14 + r] = park[2048 * r]; xo[14 + r] = park[2048 * r + 1024]; }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                wlo[1024 * (2 * r)] = xe[8 * hf + r];
+                wlo[1024 * (2 * r + 1)] = xo[8 * hf + r];
+                whi[1024 * (2 * r)] = xe[8 * hf + 4 + r];
+                whi[1024 * (2 * r + 1)] = xo[8 * hf + 4 + r];
+            }
+            if (hf == 0) {
+#pragma unroll
+                for (int r = 0; r < 2; r++) { park[2048 * r] = xe[14 + r]; park[2048 * r + 1024] = xo[14 + r]; }
+            }
+            __syncthreads();
+            N1_STAMP(3 + 6 * hf);
+            if (hf == 1 && mm + 1 < m_end) load_half(xe, in_base + row_of(mm + 1), 0); // all 32 registers are free now: request the next limb's even half
+            fwd_subblock<LEAN>(region, 16 * hf + wv, lane, pd, pc, m, out + 1024 * (16 * hf + wv), a, mm, m_begin, 4 + 6 * hf);
+            N1_STAMP(7 + 6 * hf);
+        }
+        if (mm + 1 < m_end) load_half(xo, in_base + row_of(mm + 1), 1);
+    }
+}
+
+// the first 10 inverse stages (14..5) of sub-block sb: input y (this lane's coefficients 8 u + r, u = lane + 64 i, in y[8 i + r]),
+// result left in the wave's region (position sw1(j))
+__device__ __forceinline__ void inv_subblock(u64 (&yin)[16], u64 *R, const unsigned sb, const unsigned lane_in, const PrimeDesc &pd, const PrimeConst &pc) {
+    const Shoup none{0, 0};
+    const unsigned lane = opaque(lane_in);
+    // round D': stages 14, 13, 12 on 8 consecutive coefficients
+#pragma unroll
+    for (int it = 0; it < 2; it++) {
+        const unsigned u = lane + 64 * it;
+        u64 y[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) y[r] = yin[8 * it + r];
+        const unsigned b12 = 128 * sb + u;
+        Shoup t14[4], t13[2];
+#pragma unroll
+        for (int i = 0; i < 4; i++) t14[i] = ld_tw(pd.iroot, 1 + 4 * b12 + i);
+#pragma unroll
+        for (int i = 0; i < 2; i++) t13[i] = ld_tw(pd.iroot, 16385 + 2 * b12 + i);
+        const Shoup t12 = ld_tw(pd.iroot, 24577 + b12);
+        inv_stages<1, 3, false, false>(y, [&](int st, int, int blk) { return st == 0 ? t14[blk] : (st == 1 ? t13[blk] : t12); }, none, pc);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            ulonglong2 v;
+            v.x = y[2 * q];
+            v.y = y[2 * q + 1];
+            *reinterpret_cast<ulonglong2 *>(R + sw1(8 * u + 2 * q)) = v;
+        }
+        N1_SCHED_FENCE();
+    }
+    TROY_WAVE_SYNC();
+    {   // round C': stages 11, 10, 9, registers = j3 j4 j5 (bit 0 = j3)
+        const unsigned h = lane >> 2, low = lane & 3;
+        const unsigned b9 = 16 * sb + h;
+        Shoup t11[4], t10[2];
+#pragma unroll
+        for (int i = 0; i < 4; i++) t11[i] = ld_tw(pd.iroot, 28673 + 4 * b9 + i);
+#pragma unroll
+        for (int i = 0; i < 2; i++) t10[i] = ld_tw(pd.iroot, 30721 + 2 * b9 + i);
+        const Shoup t9 = ld_tw(pd.iroot, 31745 + b9);
+#pragma unroll 1
+        for (unsigned it = 0; it < 2; it++) {
+            u64 y[8];
+#pragma unroll
+            for (int r = 0; r < 8; r++) y[r] = R[sw1(64 * h + 8 * r + 4 * it + low)];
+            inv_stages<1, 3, false, false>(y, [&](int st, int, int blk) { return st == 0 ? t11[blk] : (st == 1 ? t10[blk] : t9); }, none, pc);
+#pragma unroll
+            for (int r = 0; r < 8; r++) R[sw1(64 * h + 8 * r + 4 * it + low)] = y[r];
+        }
+    }
+    TROY_WAVE_SYNC();
+    {   // round B': stages 8..5, registers = j6..j9 (bit 0 = j6); twiddles depend on (sb, register) only
+        u64 y[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) y[r] = R[sw1(64 * r + lane)];
+        inv_stages<1, 4, false, true>(y, [&](int st, int, int blk) { return ld_tw_uniform(pd.iroot + (N1_N - (512u >> st) + 1) + ((8 * sb) >> st) + blk); }, none, pc);
+#pragma unroll
+        for (int r = 0; r < 16; r++) R[sw1(64 * r + lane)] = y[r];
+    }
+}
+
+__global__ __launch_bounds__(N1_THREADS) void ntt1_inv_kernel(Ntt1Args a) {
+    __shared__ __attribute__((aligned(16))) u64 lds[16 * 1024];
+    const unsigned tid = threadIdx.x, lane = tid & 63;
+#ifdef TROYHIP_CPU_EMUL
+    const unsigned wv = tid >> 6;
+#else
+    const unsigned wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+#endif
+    // the byte tables of the argument block are read with vector loads: tell the compiler the results are wave-uniform
+    const unsigned slot = uniform_u32(a.slots[blockIdx.x / a.chunks]), chunk = blockIdx.x % a.chunks;
+    const PrimeDesc pd = a.primes[uniform_u32(a.map.id[slot])];
+    const PrimeConst pc = make_prime_const(pd.p);
+    const unsigned m_begin = chunk * a.rows_per_wg;
+    const unsigned m_end = (m_begin + a.rows_per_wg < a.m_total) ? m_begin + a.rows_per_wg : a.m_total;
+    const unsigned inner = a.map.inner, period = a.map.period;
+    auto row_of = [&](unsigned mm) -> u64 {
+        const unsigned o = mm / inner, k = mm - o * inner;
+        return (((u64)o * period + slot) * inner + k) << N1_LOGN;
+    };
+    u64 *const region = lds + 1024 * wv;
+    // LDS-DMA staging of a sub-block into the wave's region, already in sw1 order: instruction i fills bytes [1024 i, 1024 i + 1024)
+    // of the region lane-linearly, so lane l fetches the 16-byte unit that belongs at position 128 i + 2 l (sw1 is an involution)
+    auto stage_issue = [&](const u64 *sub) {
+        const unsigned l = opaque(lane);
+#pragma unroll
+        for (int i = 0; i < 8; i++) TROY_GLDS16(sub + sw1(128 * i + 2 * l), region + 128 * i);
+    };
+    auto load16 = [&](u64 (&y)[16], const u64 *sub) { // y[8 i + r] = coefficient 8 (lane + 64 i) + r
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const ulonglong2 v = ld_g2(sub, 8 * (lane + 64 * i) + 2 * q);
+                y[8 * i + 2 * q] = v.x;
+                y[8 * i + 2 * q + 1] = v.y;
+            }
+    };
+    stage_issue(a.data + row_of(m_begin) + 1024 * wv);
+    const u64 *const rlo = lds + sw1(tid), *const rhi = rlo + 8 * 1024;
+    for (unsigned mm = m_begin; mm < m_end; mm++) {
+        u64 *const row = a.data + row_of(mm);
+        u64 x[32]; // x[r] = coefficient tid of sub-block r after its 10 stages
+        u64 y[16], y1[16];
+        load16(y1, row + 1024 * (16 + wv)); // second half's input: in flight while the first half is transformed
+        TROY_WAIT_VMEM();                   // the staged first half has landed (vmcnt counts in order: this also waits for y1 -- see below)
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(region + sw1(8 * (lane + 64 * i) + 2 * q));
+                y[8 * i + 2 * q] = v.x;
+                y[8 * i + 2 * q + 1] = v.y;
+            }
+        TROY_WAVE_SYNC();
+#pragma unroll
+        for (int hf = 0; hf < 2; hf++) {
+            inv_subblock(hf ? y1 : y, region, 16 * hf + wv, lane, pd, pc);
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 8; r++) { x[16 * hf + r] = rlo[1024 * r]; x[16 * hf + 8 + r] = rhi[1024 * r]; }
+            __syncthreads();
+        }
+        if (mm + 1 < m_end) stage_issue(a.data + row_of(mm + 1) + 1024 * wv); // the regions are free during round A'
+        // round A': stages 4..0 across the 32 sub-blocks, N^-1 folded into the last one
+        inv_stages<1, 5, true, true>(x, [&](int st, int, int blk) { return st == 4 ? pd.iroot_last_scaled : ld_tw_uniform((pd.iroot + (N1_N - (32u >> st) + 1) + blk)); }, pd.inv_n, pc);
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            u64 v[4] = {x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]};
+            reduce4_from_4p(v, pc);
+#pragma unroll
+            for (int i = 0; i < 4; i++) x[4 * q + i] = v[i];
+        }
+        {
+            const unsigned t = opaque(tid);
+#pragma unroll
+            for (int r = 0; r < 32; r++) st_g(row, t + 1024 * r, x[r]);
+        }
+    }
+}
+
+// ---- host side ----
+static bool ntt1_enabled() {
+    static const bool on = [] { const char *e = std::getenv("TROYHIP_NTT"); return !(e && std::strcmp(e, "twopass") == 0); }();
+    return on;
+}
+bool ntt1_supported(int logn, const LimbMap &map, size_t rows) {
+    return ntt1_enabled() && logn == N1_LOGN && rows && rows % ((size_t)map.period * map.inner) == 0;
+}
+// rows laid out r = (o * period + i) * inner + k, prime map.id[i].  The forward transform is launched once per prime class:
+// guard-free butterflies for the slots in map.lean, guarded ones for the rest.
+void launch_ntt1(u64 *data, const u64 *src, const PrimeDesc *primes, const LimbMap &map, size_t rows, bool inverse, hipStream_t stream) {
+    if (rows == 0) return;
+    const size_t per_outer = (size_t)map.period * map.inner;
+    if (rows % per_outer) throw Error(ST_INVALID_ARGUMENT, "ntt1: row count must be a multiple of the limb pattern");
+    if (src && inverse) throw Error(ST_LOGIC_ERROR, "ntt1: out-of-place input is only supported by the forward transform");
+    Ntt1Args a;
+    std::memset(&a, 0, sizeof(a));
+    a.data = data;
+    a.src = src;
+    a.primes = primes;
+    a.map = map;
+    a.m_total = (unsigned)(rows / per_outer * map.inner);
+    // about three workgroups per CU and launch, at most 8 limbs per workgroup (they share the prime: twiddles stay in L1/L2)
+    unsigned rpw = (unsigned)((size_t)a.m_total * map.period / 768);
+    rpw = rpw < 1 ? 1 : (rpw > 8 ? 8 : rpw);
+    static const unsigned forced_rpw = [] { const char *e = std::getenv("TROYHIP_NTT1_RPW"); return e ? (unsigned)std::atoi(e) : 0u; }(); // tests: row loop at small batches
+    if (forced_rpw) rpw = forced_rpw;
+    a.rows_per_wg = rpw;
+    a.chunks = (a.m_total + rpw - 1) / rpw;
+    if (inverse) {
+        a.nslots = map.period;
+        for (unsigned i = 0; i < map.period; i++) a.slots[i] = (uint8_t)i;
+        TROY_LAUNCH(HIP_KERNEL_NAME(ntt1_inv_kernel), dim3(a.nslots * a.chunks), dim3(N1_THREADS), 0, stream, a);
+        launch_check("ntt1_inv_kernel");
+        return;
+    }
+#ifdef N1_TIMING
+    static u64 *dbg = nullptr;
+    if (!dbg) HIP_CHECK(hipMalloc((void **)&dbg, 16 * 8 * 8));
+    a.dbg = dbg;
+    a.dbg_block = (map.period * a.chunks) / 2 + 3;
+#endif
+    static const bool no_lean = [] { const char *e = std::getenv("TROYHIP_BFLY"); return e && std::strcmp(e, "guarded") == 0; }();
+    for (int lean = 1; lean >= 0; lean--) {
+        a.nslots = 0;
+        for (unsigned i = 0; i < map.period; i++)
+            if ((int)(!no_lean && ((map.lean >> i) & 1)) == lean) a.slots[a.nslots++] = (uint8_t)i;
+        if (!a.nslots) continue;
+        if (lean) TROY_LAUNCH(HIP_KERNEL_NAME(ntt1_fwd_kernel<true>), dim3(a.nslots * a.chunks), dim3(N1_THREADS), 0, stream, a);
+        else TROY_LAUNCH(HIP_KERNEL_NAME(ntt1_fwd_kernel<false>), dim3(a.nslots * a.chunks), dim3(N1_THREADS), 0, stream, a);
+        launch_check("ntt1_fwd_kernel");
+#ifdef N1_TIMING
+        if (lean) {
+            u64 h[16 * 8];
+            HIP_CHECK(hipStreamSynchronize(stream));
+            HIP_CHECK(hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost));
+            for (unsigned r = 0; r < a.rows_per_wg && r < 8; r++) {
+                fprintf(stderr, "n1 fwd row %u:", r);
+                for (int i = 1; i < 14; i++) fprintf(stderr, " %lld", (long long)(h[16 * r + i] - h[16 * r + i - 1]));
+                if (r + 1 < a.rows_per_wg && r + 1 < 8) fprintf(stderr, " | next %lld", (long long)(h[16 * (r + 1)] - h[16 * r + 13]));
+                fprintf(stderr, "\n");
+            }
+        }
+#endif
+    }
+}
+
+} // namespace troyhip
