@@ -173,13 +173,18 @@ const Level &Context::level(int limbs) const {
     return it->second;
 }
 
+// TROYHIP_BFLY=guarded: no prime is treated as "lean" (tests / A-B runs of the guard-free butterflies)
+static bool lean_allowed() {
+    static const bool on = [] { const char *e = std::getenv("TROYHIP_BFLY"); return !(e && std::strcmp(e, "guarded") == 0); }();
+    return on;
+}
 LimbMap Context::ct_map(int limbs) const {
     LimbMap m;
     std::memset(&m, 0, sizeof(m));
     for (int i = 0; i < limbs; i++) m.id[i] = (uint8_t)i;
     m.period = (uint32_t)limbs;
     m.inner = 1;
-    for (int i = 0; i < limbs && i < 64; i++) m.lean |= (u64)(primes[i] >= (u64(1) << 33) && primes[i] < (u64(1) << 58)) << i;
+    for (int i = 0; lean_allowed() && i < limbs && i < 64; i++) m.lean |= (u64)(primes[i] >= (u64(1) << 33) && primes[i] < (u64(1) << 58)) << i;
     return m;
 }
 LimbMap Context::ids_map(const std::vector<uint8_t> &ids, uint32_t inner) const {
@@ -189,7 +194,7 @@ LimbMap Context::ids_map(const std::vector<uint8_t> &ids, uint32_t inner) const 
     for (size_t i = 0; i < ids.size(); i++) m.id[i] = ids[i];
     m.period = (uint32_t)ids.size();
     m.inner = inner;
-    for (size_t i = 0; i < ids.size(); i++) m.lean |= (u64)(primes[ids[i]] >= (u64(1) << 33) && primes[ids[i]] < (u64(1) << 58)) << i;
+    for (size_t i = 0; lean_allowed() && i < ids.size(); i++) m.lean |= (u64)(primes[ids[i]] >= (u64(1) << 33) && primes[ids[i]] < (u64(1) << 58)) << i;
     return m;
 }
 LimbMap Context::single_map(int id) const { return ids_map({(uint8_t)id}); }

@@ -302,13 +302,16 @@ void Evaluator::switch_key(CtBatch &ct, const u64 *target, u64 t_bstride, const 
     if (ntt2_ks_mac_supported(c.logn) && ks_fused()) {
         // fused: the first NTT pass reads the target and reduces it modulo each output prime on the fly; the second pass keeps
         // the transforms in registers and accumulates them against the key -- the expanded digits are never written back
-        // lazy accumulation is exact while dl * 8p * p < 2^128 for every output prime (CKKS replaces one operand by a canonical value)
+        // lazy accumulation is exact while dl * (bound of the lazy transform) * p < 2^128 for every output prime (CKKS replaces one
+        // operand by a canonical value): the bound is 8p with guarded butterflies, 59p with the guard-free ones (primes below 2^58)
+        const LimbMap ks_map = c.ids_map(out_ids, (uint32_t)dl);
         bool lazy = true;
         for (u64 i = 0; i < rl; i++) {
             const long double p = (long double)c.primes[out_ids[i]];
-            lazy = lazy && (long double)dl * 8.0L * p * p < 3.0e38L; // 2^128 = 3.4e38
+            const long double bound = ((ks_map.lean >> i) & 1) ? 59.0L : 8.0L;
+            lazy = lazy && (long double)dl * bound * p * p < 3.0e38L; // 2^128 = 3.4e38
         }
-        launch_ntt2_ks_mac(D, coeff_target, ct_tb, c.d_desc, c.ids_map(out_ids, (uint32_t)dl), batch * rl * dl, c.logn, key.data, acc, a.key_limb, (unsigned)K,
+        launch_ntt2_ks_mac(D, coeff_target, ct_tb, c.d_desc, ks_map, batch * rl * dl, c.logn, key.data, acc, a.key_limb, (unsigned)K,
                            mac_target, t_bstride, lazy, src_bound, s);
     } else {
         if (ntt2_supported(c.logn)) {

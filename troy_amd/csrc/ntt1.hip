@@ -47,6 +47,14 @@ struct Ntt1Args {
     u64 *dbg;             // development builds (-DN1_TIMING): s_memtime stamps of wave 0 of workgroup dbg_block
     unsigned dbg_block;
 };
+// wave priority by progress: a wave that is ahead of the others in a barrier-to-barrier segment lowers its own priority, so the
+// four waves of a SIMD advance together (the arbiter otherwise serves the oldest wave first and the segment ends with one wave
+// per SIMD running alone)
+#if defined(N1_PRIO_ON) && !defined(TROYHIP_CPU_EMUL)
+#define N1_PRIO(k) __builtin_amdgcn_s_setprio(k)
+#else
+#define N1_PRIO(k)
+#endif
 #ifdef N1_TIMING
 #define N1_STAMP(i) do { if (a.dbg && threadIdx.x == 0 && blockIdx.x == a.dbg_block) a.dbg[(i) + 16 * (mm - m_begin)] = clock64(); } while (0)
 #else
@@ -177,9 +185,10 @@ template <int G, int R, bool LAST, bool UNI, class TW> __device__ __forceinline_
 // the last 10 forward stages (5..14) of sub-block sb (coefficients 1024 sb .. 1024 sb + 1023), in place in the wave's region,
 // result canonical to `out` (the sub-block's 1024 coefficients in HBM)
 template <bool LEAN> __device__ __forceinline__ void fwd_subblock(u64 *R, const unsigned sb, const unsigned lane_in, const PrimeDesc &pd, const PrimeConst &pc, const Mod &m,
-                                                                  u64 *out, const Ntt1Args &a, const unsigned mm, const unsigned m_begin, const int stamp0) {
-    (void)a; (void)mm; (void)m_begin; (void)stamp0;
+                                                                  u64 *out, const Ntt1Args &a, const unsigned mm, const unsigned m_begin, const int stamp0, const bool hf_last) {
+    (void)a; (void)mm; (void)m_begin; (void)stamp0; (void)hf_last;
     const unsigned lane = opaque(lane_in);
+    N1_PRIO(3);
     {   // round B: stages 5..8 on 16 values, registers = j9..j6, lane = j5..j0; twiddles depend on (sb, register) only: scalar loads
         u64 y[16];
 #pragma unroll
@@ -191,6 +200,7 @@ template <bool LEAN> __device__ __forceinline__ void fwd_subblock(u64 *R, const 
     TROY_WAVE_SYNC();
     N1_STAMP(stamp0);
     N1_SCHED_FENCE(); // the twiddle loads below stay below: hoisted over round B they would not fit the register budget
+    N1_PRIO(2);
     {   // round C1: stages 9..11 on 8 values, registers = j5 j4 j3, lane = (j9..j6, j1 j0), iteration = j2; both iterations share
         // the seven twiddles
         const unsigned h = lane >> 2, low = lane & 3;
@@ -214,6 +224,7 @@ template <bool LEAN> __device__ __forceinline__ void fwd_subblock(u64 *R, const 
     TROY_WAVE_SYNC();
     N1_STAMP(stamp0 + 1);
     N1_SCHED_FENCE();
+    if (hf_last) { N1_PRIO(2); } else { N1_PRIO(1); }
     // round C2: stages 12..14 on 8 consecutive coefficients, u = j9..j3 = lane + 64 iteration
 #pragma unroll 1
     for (unsigned it = 0; it < 2; it++) {
@@ -297,7 +308,9 @@ template <bool LEAN> __global__ __launch_bounds__(N1_THREADS) void ntt1_fwd_kern
         N1_STAMP(0);
         // round A: stages 0..3 on the even and on the odd registers (the odd ones were requested last), then stage 4 across
         auto twA = [&](int st, int, int blk) { return ld_tw_uniform((pd.root + (1u << st) + blk)); };
+        N1_PRIO(1);
         fwd_stages<1, 4, LEAN, true>(xe, twA, pc);
+        N1_PRIO(0);
         fwd_stages<1, 4, LEAN, true>(xo, twA, pc);
 #pragma unroll
         for (int c = 0; c < 4; c++) {
@@ -334,7 +347,7 @@ template <bool LEAN> __global__ __launch_bounds__(N1_THREADS) void ntt1_fwd_kern
             __syncthreads();
             N1_STAMP(3 + 6 * hf);
             if (hf == 1 && mm + 1 < m_end) load_half(xe, in_base + row_of(mm + 1), 0); // all 32 registers are free now: request the next limb's even half
-            fwd_subblock<LEAN>(region, 16 * hf + wv, lane, pd, pc, m, out + 1024 * (16 * hf + wv), a, mm, m_begin, 4 + 6 * hf);
+            fwd_subblock<LEAN>(region, 16 * hf + wv, lane, pd, pc, m, out + 1024 * (16 * hf + wv), a, mm, m_begin, 4 + 6 * hf, hf == 1);
             N1_STAMP(7 + 6 * hf);
         }
         if (mm + 1 < m_end) load_half(xo, in_base + row_of(mm + 1), 1);
@@ -523,7 +536,7 @@ void launch_ntt1(u64 *data, const u64 *src, const PrimeDesc *primes, const LimbM
     a.dbg = dbg;
     a.dbg_block = (map.period * a.chunks) / 2 + 3;
 #endif
-    static const bool no_lean = [] { const char *e = std::getenv("TROYHIP_BFLY"); return e && std::strcmp(e, "guarded") == 0; }();
+    const bool no_lean = false; // TROYHIP_BFLY=guarded already clears map.lean (context.cpp)
     for (int lean = 1; lean >= 0; lean--) {
         a.nslots = 0;
         for (unsigned i = 0; i < map.period; i++)

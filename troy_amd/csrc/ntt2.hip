@@ -161,7 +161,9 @@ template <int INV, int STRIDED, int NS, int LOGC, int LS, int R, bool HOISTP = t
         }
     }
     // every stage = exactly four independent butterflies per thread -> one ct_bfly4 / gs_bfly4 call
-    __device__ static __forceinline__ void compute(u64 (&x)[8], const Shoup (&tw)[G][NTW], const PrimeDesc &pd) {
+    // lean (forward only, wave-uniform): the prime is below 2^58 -- guard-free butterflies, every stage adds at most 3p to the
+    // value bound (8p at the input of the first pass + 3p * 17 stages at most = 59p < 2^64); the caller reduces with barrett64
+    __device__ static __forceinline__ void compute(u64 (&x)[8], const Shoup (&tw)[G][NTW], const PrimeDesc &pd, const bool lean = false) {
         if (N2_EXP & 4) {
 #pragma unroll
             for (int u = 0; u < G; u++) x[u] ^= tw[u][0].op;
@@ -204,9 +206,10 @@ template <int INV, int STRIDED, int NS, int LOGC, int LS, int R, bool HOISTP = t
             }
 #pragma unroll
             for (int i = 0; i < 4; i++) { X[i] = x[ix[i]]; Y[i] = x[iy[i]]; }
-            if (!INV) ct_bfly4(X, Y, w, pc);
-            else if (STRIDED && (LS + st == NS - 1)) gs_bfly4_last(X, Y, w, pd.inv_n, pc);
-            else gs_bfly4(X, Y, w, pc);
+            if (!INV) {
+                if (lean) ct_bfly4_ng<UNIFORM>(X, Y, w, pc); else ct_bfly4<UNIFORM>(X, Y, w, pc);
+            } else if (STRIDED && (LS + st == NS - 1)) gs_bfly4_last<UNIFORM>(X, Y, w, pd.inv_n, pc);
+            else gs_bfly4<UNIFORM>(X, Y, w, pc);
 #pragma unroll
             for (int i = 0; i < 4; i++) { x[ix[i]] = X[i]; x[iy[i]] = Y[i]; }
         }
@@ -282,14 +285,19 @@ template <int INV, int STRIDED, int NS, int LOGC, int LS, int R, bool HOISTP = t
     // ([0, 8p)) of this thread's 8 consecutive coefficients.  Rows 0..2 are parked canonical in tx; row 3 completes the
     // tensor (evaluator.cpp:626-702: every product reduced, the two middle products added modulo p).
     __device__ static __forceinline__ void tensor_epilogue(u64 (&x)[8], u64 (&tx)[3][8], unsigned mm, u64 *out, unsigned period, unsigned slot, unsigned tile, int logn,
-                                                           const Mod &m, u64 *xchg) {
+                                                           const Mod &m, u64 *xchg, const bool lean) {
         const PrimeConst pc = make_prime_const(m.p);
+        if (lean) { // guard-free transform: values below 59p
 #pragma unroll
-        for (int h = 0; h < 2; h++) {
-            u64 v[4] = {x[4 * h], x[4 * h + 1], x[4 * h + 2], x[4 * h + 3]};
-            reduce4_from_8p(v, pc);
+            for (int e = 0; e < 8; e++) x[e] = barrett64(x[e], m);
+        } else {
 #pragma unroll
-            for (int i = 0; i < 4; i++) x[4 * h + i] = v[i];
+            for (int h = 0; h < 2; h++) {
+                u64 v[4] = {x[4 * h], x[4 * h + 1], x[4 * h + 2], x[4 * h + 3]};
+                reduce4_from_8p(v, pc);
+#pragma unroll
+                for (int i = 0; i < 4; i++) x[4 * h + i] = v[i];
+            }
         }
         const unsigned vr = mm & 3;
         if (vr < 3) {
@@ -356,8 +364,8 @@ template <int INV, int STRIDED, int NS, int LOGC, int LS, int R, bool HOISTP = t
         (void)m;
     }
     // FINAL: 0 keep lazy range, 1 forward final ([0,8p) -> [0,p)), 2 inverse final ([0,4p) -> [0,p))
-    template <int FINAL> __device__ static __forceinline__ void g_write(u64 (&x)[8], u64 *row, unsigned tile, int logn, u64 p, u64 two_p, u64 *xchg = nullptr) {
-        (void)two_p;
+    template <int FINAL> __device__ static __forceinline__ void g_write(u64 (&x)[8], u64 *row, unsigned tile, int logn, const Mod &m, const bool lean, u64 *xchg = nullptr) {
+        const u64 p = m.p;
         if (N2_EXP & 1) {
             u64 acc = 0;
 #pragma unroll
@@ -365,7 +373,10 @@ template <int INV, int STRIDED, int NS, int LOGC, int LS, int R, bool HOISTP = t
             if (acc == 0x123456789abcdefull) row[threadIdx.x] = acc; // never true in practice; keeps the work alive
             return;
         }
-        if (FINAL) {
+        if (FINAL == 1 && lean) { // guard-free forward transform: values below 59p
+#pragma unroll
+            for (int e = 0; e < 8; e++) x[e] = barrett64(x[e], m);
+        } else if (FINAL) {
             const PrimeConst pc = make_prime_const(p);
 #pragma unroll
             for (int h = 0; h < 2; h++) {
@@ -446,6 +457,7 @@ __global__ __launch_bounds__(N2_THREADS, MAC ? N2_MAC_WAVES : N2_MIN_WAVES) void
     const PrimeDesc pd = a.primes[a.map.id[slot]];
     const Mod m = mod_of(pd);
     const bool need_reduce = REDUCE && (a.src_bound == 0 || (pd.p >> 61) != 0 || a.src_bound > 8 * pd.p);
+    const bool lean = !INV && ((a.map.lean >> slot) & 1); // wave-uniform: prime below 2^58 -> guard-free forward butterflies (bfly.h)
     const int logn = a.logn;
     const int k1 = STRIDED ? NS : logn - NS;
     const int s_first = INV ? (STRIDED ? k1 - 1 : logn - 1) : (STRIDED ? 0 : k1);
@@ -523,29 +535,32 @@ __global__ __launch_bounds__(N2_THREADS, MAC ? N2_MAC_WAVES : N2_MIN_WAVES) void
             for (int e = 0; e < 8; e++) x[e] = barrett64(x[e], m);
         }
         if constexpr (!Rd0::HOIST) Rd0::load_tw(tw0, pd, tile, logn, s_first);
-        Rd0::compute(x, tw0, pd);
+        Rd0::compute(x, tw0, pd, lean);
         if constexpr (NR == 1) {
-            Rd0::template g_write<FINAL>(x, row, tile, logn, pd.p, pd.two_p);
+            Rd0::template g_write<FINAL>(x, row, tile, logn, m, lean);
         } else {
             Rd0::lds_write(x, buf);
             round_sync();
             if constexpr (!Rd1::HOIST) Rd1::load_tw(tw1, pd, tile, logn, s_first);
             Rd1::lds_read(x, buf);
-            Rd1::compute(x, tw1, pd);
+            Rd1::compute(x, tw1, pd, lean);
             if constexpr (NR == 2) {
-                Rd1::template g_write<FINAL>(x, row, tile, logn, pd.p, pd.two_p);
+                Rd1::template g_write<FINAL>(x, row, tile, logn, m, lean);
             } else {
                 Rd1::lds_write(x, buf);
                 round_sync();
                 if constexpr (!Rd2::HOIST) Rd2::load_tw(tw2, pd, tile, logn, s_first);
                 Rd2::lds_read(x, buf);
-                Rd2::compute(x, tw2, pd);
+                Rd2::compute(x, tw2, pd, lean);
                 if constexpr (NR == 3 && MAC == 2) {
-                    Rd2::tensor_epilogue(x, tx, mm, a.tensor_out, period, slot, tile, logn, m, WAVE_PRIVATE ? buf : nullptr);
+                    Rd2::tensor_epilogue(x, tx, mm, a.tensor_out, period, slot, tile, logn, m, WAVE_PRIVATE ? buf : nullptr, lean);
                 } else if constexpr (NR == 3 && MAC == 1) {
                     // the transform of digit k of (o, slot) stays in registers: acc_c += x (.) key[k][c][limb(slot)].  x is lazy, in
                     // [0, 8p); it is only normalised when dl * 8p * p could overflow the 128-bit accumulator (mac_lazy == 0)
-                    if (!a.mac_lazy) {
+                    if (!a.mac_lazy && lean) {
+#pragma unroll
+                        for (int e = 0; e < 8; e++) x[e] = barrett64(x[e], m);
+                    } else if (!a.mac_lazy) {
                         const PrimeConst pc = make_prime_const(pd.p);
 #pragma unroll
                         for (int h = 0; h < 2; h++) {
@@ -573,14 +588,14 @@ __global__ __launch_bounds__(N2_THREADS, MAC ? N2_MAC_WAVES : N2_MIN_WAVES) void
                         }
                     }
                 } else if constexpr (NR == 3) {
-                    Rd2::template g_write<FINAL>(x, row, tile, logn, pd.p, pd.two_p, WAVE_PRIVATE ? buf : nullptr);
+                    Rd2::template g_write<FINAL>(x, row, tile, logn, m, lean, WAVE_PRIVATE ? buf : nullptr);
                 } else {
                     Rd2::lds_write(x, buf);
                     round_sync();
                     if constexpr (!Rd3::HOIST) Rd3::load_tw(tw3, pd, tile, logn, s_first);
                     Rd3::lds_read(x, buf);
-                    Rd3::compute(x, tw3, pd);
-                    Rd3::template g_write<FINAL>(x, row, tile, logn, pd.p, pd.two_p);
+                    Rd3::compute(x, tw3, pd, lean);
+                    Rd3::template g_write<FINAL>(x, row, tile, logn, m, lean);
                 }
             }
         }
