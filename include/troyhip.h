@@ -140,7 +140,10 @@ int troyhip_sub(troyhip_context *ctx, troyhip_ct *a, const troyhip_ct *b, uint64
 /* multiply / multiplyInplace / square: out->data, out->batch_stride are inputs (may alias a or b), the rest of *out is set */
 int troyhip_multiply(troyhip_context *ctx, const troyhip_ct *a, const troyhip_ct *b, troyhip_ct *out, uint64_t batch, void *stream);
 /* key-switching keys: device array [K-1][2][K][N] (NTT form): KSwitchKeysCuda::data()[index] (src/kswitchkeys_cuda.cuh:43-56) */
-int troyhip_relinearize(troyhip_context *ctx, troyhip_ct *ct, const uint64_t *relin_key, uint64_t batch, void *stream);      /* relinearizeInplace */
+int troyhip_relinearize(troyhip_context *ctx, troyhip_ct *ct, const uint64_t *relin_key, uint64_t batch, void *stream);      /* relinearizeInplace, size 3 */
+/* relinearizeInplace from any size <= 16 (relinearizeInternal, src/evaluator_cuda.cu:703-744): relin_keys[i] = device key of index i
+ * (RelinKeys::getIndex(i + 2)), n_keys >= size - 2; the step sequence is the reference's, see evaluator.cpp */
+int troyhip_relinearize_keys(troyhip_context *ctx, troyhip_ct *ct, const uint64_t *const *relin_keys, int n_keys, uint64_t batch, void *stream);
 int troyhip_switch_key(troyhip_context *ctx, troyhip_ct *ct, const uint64_t *target, uint64_t target_batch_stride,
                        const uint64_t *kswitch_key, uint64_t batch, void *stream);                            /* applyKeySwitchingInplace / switchKeyInplace */
 int troyhip_mod_switch_to_next(troyhip_context *ctx, const troyhip_ct *in, troyhip_ct *out, uint64_t batch, void *stream);   /* modSwitchToNext */

@@ -374,9 +374,14 @@ public:
     void multiply(const Ciphertext &a, const Ciphertext &b, Ciphertext &d) const { d = a; multiplyInplace(d, b); }
     void squareInplace(Ciphertext &a) const { multiplyInplace(a, a); }
     void square(const Ciphertext &a, Ciphertext &d) const { d = a; squareInplace(d); }
-    void relinearizeInplace(Ciphertext &a, const RelinKeys &k) const {
-        if (a.size() > 2 && !k.hasKey(2)) throw std::invalid_argument("not enough relinearization keys");
-        check(troyhip_relinearize(h(), a.raw(), a.size() > 2 ? k.device(RelinKeys::getIndex(2)) : nullptr, 1, nullptr));
+    void relinearizeInplace(Ciphertext &a, const RelinKeys &k) const { // to size 2 from any size <= 16 (src/evaluator_cuda.cu:703-744)
+        const size_t need = a.size() > 2 ? a.size() - 2 : 0;
+        std::vector<const uint64_t *> keys(need ? need : 1, nullptr);
+        for (size_t i = 0; i < need; i++) {
+            if (!k.hasKey(i + 2)) throw std::invalid_argument("not enough relinearization keys");
+            keys[i] = k.device(RelinKeys::getIndex(i + 2));
+        }
+        check(troyhip_relinearize_keys(h(), a.raw(), keys.data(), (int)need, 1, nullptr));
     }
     void relinearize(const Ciphertext &a, const RelinKeys &k, Ciphertext &d) const { d = a; relinearizeInplace(d, k); }
     // applyKeySwitchingInplace (evaluator_cuda.cu:1365-1378), negacyclicShiftInplace (:2342-2351)

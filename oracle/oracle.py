@@ -227,7 +227,7 @@ class Oracle:
         else:
             bdp, bptr = None, None
         od = CtDesc()
-        osz = max(a.size, b.size if isinstance(b, Ct) else 0) + 1
+        osz = a.size + (b.size if isinstance(b, Ct) else 1)  # a product has a.size + b.size - 1 polynomials
         out = np.zeros((osz + 1) * a.limbs * self.N, dtype=np.uint64)
         self._chk(lib().orc_eval(self.h, op, C.byref(ad), _p(a.data), bdp, bptr, C.c_int64(iarg), C.byref(od), _p(out)))
         n = od.size * od.limbs * self.N

@@ -293,7 +293,7 @@ int ref_get_galois_key(void *h, uint32_t elt, u64 *out) {
     return 0;
 }
 // Install synthetic key material (uniform limbs) so the key-switch arithmetic can be compared on
-// arbitrary inputs.  which: 0 = relin key (power 2), else Galois element.
+// arbitrary inputs.  which: 0 = relin key (power 2), 0x80000000 | i = relin key of index i (power i + 2), else Galois element.
 int ref_set_kswitch_key(void *h, uint32_t which, const u64 *data) {
     Ref *r = (Ref *)h;
     return guarded(r, [&] {
@@ -305,8 +305,9 @@ int ref_set_kswitch_key(void *h, uint32_t which, const u64 *data) {
             std::memcpy(c.data(), data + j * stride, sizeof(u64) * stride);
             c.isNttForm() = true;
         }
-        KSwitchKeys &ks = which == 0 ? static_cast<KSwitchKeys &>(r->rlk) : static_cast<KSwitchKeys &>(r->gk);
-        size_t index = which == 0 ? RelinKeys::getIndex(2) : GaloisKeys::getIndex(which);
+        const bool relin = which == 0 || (which & 0x80000000u);
+        KSwitchKeys &ks = relin ? static_cast<KSwitchKeys &>(r->rlk) : static_cast<KSwitchKeys &>(r->gk);
+        size_t index = relin ? RelinKeys::getIndex(2 + (which & 0xFFFFu)) : GaloisKeys::getIndex(which);
         if (ks.data().size() <= index) ks.data().resize(index + 1);
         ks.data()[index] = std::move(kv);
         ks.parmsID() = r->ctx->keyParmsID();

@@ -597,7 +597,8 @@ struct Orc {
     std::vector<const NttTable *> key_tables;
     std::map<int, std::unique_ptr<RnsTool>> tools; // by limb count
     int first_limbs = 0, last_limbs = 0, n_levels = 0;
-    std::vector<u64> relin_key;
+    std::vector<u64> relin_key;                  // index 0 (power 2)
+    std::map<int, std::vector<u64>> relin_keys_hi; // index >= 1 (power index + 2)
     std::map<uint32_t, std::vector<u64>> galois_keys;
     std::string err;
 
@@ -956,13 +957,22 @@ struct Eval {
             }
         }
     }
-    void relinearize(Ct &a) const { // evaluator.cpp:1113-1163 (destination size 2)
+    // evaluator.cpp:1113-1163 relinearizeInternal, destination size 2.  As in the reference, `encrypted_iter` keeps pointing at the LAST
+    // polynomial through all relins_needed steps (evaluator.cpp:1149-1156): step i switches that same polynomial with the key of
+    // index getIndex(size - 1 - i) = size - 3 - i, and the polynomials 2 .. size-2 are dropped by the final resize.
+    void relinearize(Ct &a) const {
         check_level(a);
         if (a.size == 2) return;
-        if (a.size != 3) throw std::invalid_argument("only size-3 relinearization is supported");
-        if (o->relin_key.empty()) throw std::invalid_argument("not enough relinearization keys");
-        std::vector<u64> target(a.poly(2, N), a.poly(2, N) + (size_t)a.limbs * N);
-        switch_key(a, target.data(), o->relin_key);
+        const int size = a.size;
+        auto key_of = [&](int index) -> const std::vector<u64> & {
+            if (index == 0) { if (o->relin_key.empty()) throw std::invalid_argument("not enough relinearization keys"); return o->relin_key; }
+            auto it = o->relin_keys_hi.find(index);
+            if (it == o->relin_keys_hi.end()) throw std::invalid_argument("not enough relinearization keys");
+            return it->second;
+        };
+        for (int i = 0; i < size - 2; i++) key_of(i); // relin_keys.size() >= size - 2 (evaluator.cpp:1134)
+        std::vector<u64> target(a.poly(size - 1, N), a.poly(size - 1, N) + (size_t)a.limbs * N);
+        for (int i = 0; i < size - 2; i++) switch_key(a, target.data(), key_of(size - 3 - i));
         a.size = 2;
         a.d.resize((size_t)2 * a.limbs * N);
     }
@@ -1408,7 +1418,8 @@ int orc_rns_stage(void *h, int limbs, int stage, const uint64_t *in, uint64_t *o
 int orc_set_kswitch_key(void *h, uint32_t which, const uint64_t *data) {
     Orc *o = (Orc *)h;
     size_t n = (o->K - 1) * 2 * o->K * o->N;
-    if (which == 0) o->relin_key.assign(data, data + n);
+    if (which == 0 || which == 0x80000000u) o->relin_key.assign(data, data + n);
+    else if (which & 0x80000000u) o->relin_keys_hi[(int)(which & 0xFFFFu)].assign(data, data + n);
     else o->galois_keys[which].assign(data, data + n);
     return 0;
 }

@@ -39,6 +39,7 @@ CONFIGS = {
 SMALL = ["bfv_n64_k3", "bfv_n128_k4", "bfv_n128_k5_60", "ckks_n128_k6", "bgv_n128_k4"]
 MEDIUM = ["cfgA_bfv_n4096_k3", "cfgB_bfv_n8192_k5", "ckks_n4096_k4", "bgv_n4096_k3"]
 LARGE = ["cfgNS_bfv_n32768_k15", "cfgC_ckks_n32768_k15", "cfgD_bgv_n65536_k15"]
+SIZES = ["bfv_n64_k3", "bfv_n128_k5_60", "ckks_n128_k6", "bgv_n128_k4", "cfgA_bfv_n4096_k3", "ckks_n4096_k4", "bgv_n4096_k3"]  # scenario_sizes
 
 KEY_STEPS = (1, -1, 4)  # Galois keys present; rotations by 5 = naf [1, 4] and 3 = naf [-1, 4] exercise the NAF path
 SEED = 0x5EED
@@ -127,6 +128,35 @@ def scenario(backend, cfg, light=False):
     return out
 
 
+RELIN_KEY = 0x80000000  # set_kswitch_key(RELIN_KEY | i, ..): relinearization key of index i (power i + 2)
+
+
+def scenario_sizes(backend, cfg):
+    """General ciphertext sizes: 3x2, 3x3 multiply, square of a size-3 ciphertext, relinearize 4 -> 2 and 5 -> 2
+    with the keys of index 0..2 (src/evaluator_cuda.cu:283-501, 703-744), at the first data level.  Returns {name: Meta}."""
+    scheme, N = cfg["scheme"], cfg["N"]
+    primes = backend.primes
+    L = len(primes) - 1
+    ntt = scheme == CKKS
+    for i in range(3):
+        backend.set_relin_key(synth.uniform_kswitch_key(SEED + 1 + 7 * i, primes, N), index=i)  # index 0 = the scenario() key
+    q = primes[:L]
+    xa = synth.uniform_ct(SEED + 100 + L, q, 2, N)[0]
+    x3 = synth.uniform_ct(SEED + 300 + L, q, 3, N)[0]
+    y3 = synth.uniform_ct(SEED + 600 + L, q, 3, N)[0]
+    cfb = 3 if scheme == BGV else 1
+    out = {}
+    m32 = backend.multiply(backend.ct(x3, ntt), backend.ct(xa, ntt, cf=cfb))
+    out["sizes/multiply_3x2"] = backend.export(m32)
+    out["sizes/relin_4to2"] = backend.export(backend.relinearize(m32))
+    m33 = backend.multiply(backend.ct(x3, ntt), backend.ct(y3, ntt, cf=cfb))
+    out["sizes/multiply_3x3"] = backend.export(m33)
+    out["sizes/relin_5to2"] = backend.export(backend.relinearize(m33))
+    out["sizes/square_3"] = backend.export(backend.square(backend.ct(x3, ntt)))
+    out["sizes/multiply_2x3"] = backend.export(backend.multiply(backend.ct(xa, ntt), backend.ct(y3, ntt, cf=cfb)))
+    return out
+
+
 # ------------------------------------------------------------------ backends
 class _EvalBackend:
     """RefBackend / OracleBackend: both expose the `eval(op, a, b, iarg)` surface of oracle/ref.py."""
@@ -145,8 +175,8 @@ class _EvalBackend:
     def export(self, c):
         return Meta(c.data, c.is_ntt, c.scale, c.correction_factor)
 
-    def set_relin_key(self, k):
-        self.impl.set_kswitch_key(0, k)
+    def set_relin_key(self, k, index=0):
+        self.impl.set_kswitch_key(0 if index == 0 else (RELIN_KEY | index), k)
 
     def set_galois_key(self, elt, k):
         self.impl.set_kswitch_key(elt, k)
@@ -218,7 +248,7 @@ class GpuBackend:
             assert np.array_equal(d[b], d[0]), "batch items diverged"
         return Meta(d[0], c.is_ntt_form, c.scale, c.correction_factor)
 
-    def set_relin_key(self, k): self.rlk.set(0, k)
+    def set_relin_key(self, k, index=0): self.rlk.set(index, k)
     def set_galois_key(self, elt, k): self.gk.set_elt(elt, k)
     def elt_from_step(self, s): return self.ctx.galois_elt_from_step(s)
     def add(self, a, b): self.ev.addInplace(a, b); return a
@@ -582,3 +612,45 @@ def check_modswitch_as_first_op(cfg_name, batch=2):
             got2 = (be.ev.rescaleToNext(c2) if scheme == CKKS else be.ev.modSwitchToNext(c2)).cpu()
             for b in range(4 * B):
                 assert np.array_equal(got2[b], orc.impl.eval(op, R.Ct(xs2[b], ntt)).data), ("grow", b)
+
+
+def check_general_sizes(cfg_name, batch=2):
+    """GPU product against golden_sizes.json (generated from the reference itself)"""
+    import json
+    import os
+    exp = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_sizes.json")))[cfg_name]
+    cfg = CONFIGS[cfg_name]
+    out = scenario_sizes(GpuBackend(cfg, batch=batch), cfg)
+    assert set(out) == set(exp)
+    for k, m in out.items():
+        assert sha(m.data) == exp[k]["sha256"] and list(m.data.shape) == exp[k]["shape"], k
+        assert m.is_ntt == exp[k]["is_ntt"] and m.cf == exp[k]["cf"] and abs(m.scale - exp[k]["scale"]) <= 1e-12 * abs(exp[k]["scale"]), k
+
+
+def check_size_limits(cfg_name):
+    from troy_amd import capi
+    from oracle import ref as R
+    cfg = CONFIGS[cfg_name]
+    be = GpuBackend(cfg, batch=1)
+    orc = oracle_backend(cfg)
+    N, L = cfg["N"], len(be.primes) - 1
+    ntt = cfg["scheme"] == CKKS
+    x9 = synth.uniform_ct(1234, be.primes[:L], 9, N)[0]
+    y8 = synth.uniform_ct(1235, be.primes[:L], 8, N)[0]
+    a = be.api.Ciphertext.from_numpy(be.ctx, x9[None], ntt, 1.0, 1, capacity=9)
+    b = be.api.Ciphertext.from_numpy(be.ctx, y8[None], ntt, 1.0, 1, capacity=8)
+    got = be.ev.multiply(a, b)
+    assert got.size() == 16
+    assert np.array_equal(got.cpu()[0], orc.impl.eval(R.OP_MULTIPLY, R.Ct(x9, ntt), R.Ct(y8, ntt)).data)
+    try:
+        be.ev.multiply(a, be.api.Ciphertext.from_numpy(be.ctx, x9[None], ntt, 1.0, 1, capacity=9), destination=be.api.Ciphertext(be.ctx, 1, 17, L, capacity=17))
+        raise AssertionError("9 x 9 must be rejected")
+    except capi.InvalidArgument as e:
+        assert "invalid size" in str(e)
+    rl = be.api.RelinKeys(be.ctx)
+    rl.set(0, synth.uniform_kswitch_key(5, be.primes, N))
+    try:
+        be.ev.relinearizeInplace(got, rl)
+        raise AssertionError("relinearize from size 16 with one key must be rejected")
+    except capi.InvalidArgument as e:
+        assert "not enough relinearization keys" in str(e)

@@ -8,6 +8,7 @@ Outputs (data only -- inputs are regenerated from seeds by troy_amd.synth, see t
   golden_full_<cfg>.npz   every scenario output limb-for-limb (small N)
   golden_hashes.json      SHA-256 of every scenario output + metadata, for all configs incl. N=32768
   golden_params.json      primes, plain modulus, BEHZ bases, psi, table hashes per config
+  golden_sizes.json       SHA-256 of the general-size scenario (3x2 / 3x3 multiply, relinearize 4->2 / 5->2), cases.scenario_sizes
   cfgA_bfv_n4096_k3.npz   BASELINE config A: seeded keys, two encryptions, their sum, the decryption
   realkey_<scheme>.npz    one decrypt-verified real-key case per scheme (N=128)
 """
@@ -29,8 +30,19 @@ def meta_dict(m):
     return dict(sha256=cases.sha(m.data), shape=list(m.data.shape), is_ntt=m.is_ntt, scale=m.scale, cf=m.cf)
 
 
+def sizes_only():
+    sizes = {}
+    for name in cases.SIZES:
+        cfg = cases.CONFIGS[name]
+        sizes[name] = {k: meta_dict(v) for k, v in cases.scenario_sizes(cases.ref_backend(cfg), cfg).items()}
+        print("sizes", name)
+    json.dump(sizes, open(os.path.join(HERE, "golden_sizes.json"), "w"), indent=1, sort_keys=True)
+
+
 def main():
-    hashes, params = {}, {}
+    if "--sizes-only" in sys.argv:  # same content as the full run writes into golden_sizes.json
+        return sizes_only()
+    hashes, params, sizes = {}, {}, {}
     for name in cases.SMALL + cases.MEDIUM + cases.LARGE:
         cfg = cases.CONFIGS[name]
         be = cases.ref_backend(cfg)
@@ -38,6 +50,8 @@ def main():
         light = name in cases.LARGE
         out = cases.scenario(be, cfg, light=light)
         hashes[name] = {k: meta_dict(v) for k, v in out.items()}
+        if name in cases.SIZES:
+            sizes[name] = {k: meta_dict(v) for k, v in cases.scenario_sizes(cases.ref_backend(cfg), cfg).items()}
         K = len(be.primes)
         p = dict(primes=[str(x) for x in be.primes], plain_modulus=str(R.t), chain=list(R.chain()), levels={}, tables={})
         for limbs in range(R.chain()[2], K + 1):
@@ -55,6 +69,7 @@ def main():
         print("done", name, len(out), "outputs")
     json.dump(hashes, open(os.path.join(HERE, "golden_hashes.json"), "w"), indent=1, sort_keys=True)
     json.dump(params, open(os.path.join(HERE, "golden_params.json"), "w"), indent=1, sort_keys=True)
+    json.dump(sizes, open(os.path.join(HERE, "golden_sizes.json"), "w"), indent=1, sort_keys=True)
 
     # ---- cfgA: BFV N=4096 K=3 encrypt -> add -> decrypt on the reference CPU path
     cfg = cases.CONFIGS["cfgA_bfv_n4096_k3"]

@@ -88,6 +88,16 @@ def test_emulated_modswitch_as_first_op(name, emul_api):
     cases.check_modswitch_as_first_op(name)
 
 
+@pytest.mark.parametrize("name", ["bfv_n64_k3", "bfv_n128_k5_60", "ckks_n128_k6", "bgv_n128_k4"])
+def test_emulated_general_sizes(name, emul_api):
+    cases.check_general_sizes(name, batch=2)
+
+
+def test_emulated_size_limits(emul_api):
+    cases.check_size_limits("bfv_n64_k3")
+    cases.check_size_limits("ckks_n128_k6")
+
+
 def test_emulated_ckks_matmul_helper(emul_api):
     cases.check_ckks_matmul_helper(N=256, bits=(40, 30, 30, 40), batch=2, dims=(24, 20))
 

@@ -354,6 +354,20 @@ def test_gpu_decrypt_end_to_end(gpu):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name", cases.SIZES)
+def test_general_ciphertext_sizes(name, gpu):
+    """3x2 / 3x3 / 2x3 multiply, size-3 square, relinearize 4 -> 2 and 5 -> 2 against the reference's own outputs"""
+    cases.check_general_sizes(name, batch=3)
+
+
+@pytest.mark.gpu
+def test_general_sizes_limits(gpu):
+    """destination size 16 is the limit (SEAL_CIPHERTEXT_SIZE_MAX); 9 x 8 works and matches the oracle, 9 x 9 is 'invalid size'"""
+    cases.check_size_limits("bfv_n64_k3")
+    cases.check_size_limits("ckks_n128_k6")
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name", ["ckks_n128_k6", "bfv_n128_k4", "bgv_n128_k4", "ckks_n4096_k4", "cfgB_bfv_n8192_k5"])
 def test_modswitch_as_first_op(name, gpu):
     cases.check_modswitch_as_first_op(name)

@@ -90,3 +90,17 @@ def test_realkey_chain(nm, oracle_lib):
         r = O.eval(ref.OP_ROTATE_ROWS, O.eval(ref.OP_RELIN, O.eval(ref.OP_MULTIPLY, c1, c2)), iarg=1)
         assert np.array_equal(r.data, f["result"]) and r.correction_factor == int(f["result_cf"])
         assert np.array_equal(O.decrypt(r, f["secret_key"]), f["decrypted"])
+
+
+@pytest.mark.parametrize("name", cases.SIZES)
+def test_oracle_general_sizes(name, oracle_lib):
+    """3x2 / 3x3 / 2x3 multiply, size-3 square, relinearize 4 -> 2 and 5 -> 2 (reference: src/evaluator.cpp:385-794, 1113-1163;
+    note the reference never advances its `encrypted_iter`): the oracle against the reference's outputs (golden_sizes.json)"""
+    import json
+    exp = json.load(open(os.path.join(GOLDEN, "golden_sizes.json")))[name]
+    cfg = cases.CONFIGS[name]
+    out = cases.scenario_sizes(cases.oracle_backend(cfg), cfg)
+    assert set(out) == set(exp)
+    for k, m in out.items():
+        assert cases.sha(m.data) == exp[k]["sha256"] and list(m.data.shape) == exp[k]["shape"], k
+        assert m.is_ntt == exp[k]["is_ntt"] and m.cf == exp[k]["cf"] and abs(m.scale - exp[k]["scale"]) <= 1e-12 * abs(exp[k]["scale"])

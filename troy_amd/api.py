@@ -439,12 +439,14 @@ class Evaluator:
 
     # -- key switching
     def relinearizeInplace(self, a, relin_keys):
-        idx = RelinKeys.getIndex(2)
-        if a.size() > 2 and not relin_keys.hasKey(idx):
-            raise capi.InvalidArgument(capi.INVALID_ARGUMENT, "not enough relinearization keys")
+        """relinearizeInternal to size 2 from any size <= 16 (src/evaluator_cuda.cu:703-744): needs the keys of index 0 .. size-3"""
+        need = max(a.size() - 2, 0)
+        for idx in range(need):
+            if not relin_keys.hasKey(idx):
+                raise capi.InvalidArgument(capi.INVALID_ARGUMENT, "not enough relinearization keys")
         st = a.struct()
-        key = relin_keys.keys[idx].ptr if relin_keys.hasKey(idx) else None
-        self._chk(self.lib.troyhip_relinearize(self.context.h, C.byref(st), C.c_void_p(key), C.c_uint64(a.batch), self.stream))
+        ptrs = (C.c_void_p * max(need, 1))(*[relin_keys.keys[i].ptr for i in range(need)])
+        self._chk(self.lib.troyhip_relinearize_keys(self.context.h, C.byref(st), ptrs, need, C.c_uint64(a.batch), self.stream))
         a._absorb(st)
 
     def relinearize(self, a, relin_keys):

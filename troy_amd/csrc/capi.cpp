@@ -283,6 +283,16 @@ int troyhip_relinearize(troyhip_context *ctx, troyhip_ct *ct, const uint64_t *re
         store(x, ct);
     });
 }
+int troyhip_relinearize_keys(troyhip_context *ctx, troyhip_ct *ct, const uint64_t *const *relin_keys, int n_keys, uint64_t batch, void *stream) {
+    return guard([&] {
+        if (n_keys < 0 || n_keys > 14 || (n_keys && !relin_keys)) throw Error(ST_INVALID_ARGUMENT, "not enough relinearization keys");
+        KsKey keys[14];
+        for (int i = 0; i < n_keys; i++) keys[i] = KsKey{relin_keys[i]};
+        CtBatch x = view(ct);
+        ctx->ev.relinearize(x, keys, n_keys, batch, (hipStream_t)stream);
+        store(x, ct);
+    });
+}
 int troyhip_switch_key(troyhip_context *ctx, troyhip_ct *ct, const uint64_t *target, uint64_t target_batch_stride, const uint64_t *kswitch_key,
                        uint64_t batch, void *stream) {
     return guard([&] { CtBatch x = view(ct); ctx->ev.switch_key(x, target, target_batch_stride, KsKey{kswitch_key}, batch, (hipStream_t)stream); store(x, ct); });

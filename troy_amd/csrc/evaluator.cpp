@@ -146,7 +146,7 @@ void Evaluator::multiply(const CtBatch &a, const CtBatch &b, CtBatch &out, u64 b
     const int L = a.limbs, sa = a.size, sb = b.size, ds = sa + sb - 1;
     const u64 N = c.N, pw = poly_words(c, L);
     if (!out.data || out.bstride < (u64)ds * pw) throw Error(ST_INVALID_ARGUMENT, "destination batch stride too small for the result size");
-    if (ds > 5 || sa > 3 || sb > 3) throw Error(ST_INVALID_ARGUMENT, "ciphertext sizes above 3 are not supported by multiply");
+    if (ds > 16) throw Error(ST_INVALID_ARGUMENT, "invalid size"); // Ciphertext::resize beyond SEAL_CIPHERTEXT_SIZE_MAX (src/ciphertext.h:441, defines.h:34)
     LimbMap qmap = c.ct_map(L);
     c.arena.reset();
     c.arena.reserve(scratch_multiply(sa, sb, L, batch));
@@ -338,15 +338,23 @@ void Evaluator::switch_key(CtBatch &ct, const u64 *target, u64 t_bstride, const 
     }
 }
 
-// relinearizeInternal (evaluator_cuda.cu:703-744), destination size 2
-void Evaluator::relinearize(CtBatch &ct, const KsKey &key, u64 batch, hipStream_t s) {
+// relinearizeInternal (evaluator_cuda.cu:703-744), destination size 2, from any size up to SEAL_CIPHERTEXT_SIZE_MAX.  Exactly as
+// the reference does it: `encrypted_iter` is set to the LAST polynomial once (:729) and not advanced, so each of the size - 2
+// steps switches that same polynomial, step i with the key of index getIndex(size - 1 - i) = size - 3 - i (:731-735); the
+// polynomials 2 .. size-2 are dropped by the final resize (:742).  Bit-exact parity means reproducing this, not "fixing" it.
+void Evaluator::relinearize(CtBatch &ct, const KsKey *keys, int n_keys, u64 batch, hipStream_t s) {
     check_ct(ct);
     if (ct.size == 2) return;
-    if (ct.size != 3) throw Error(ST_INVALID_ARGUMENT, "only size-3 ciphertexts can be relinearized");
+    if (ct.size < 2 || ct.size > 16) throw Error(ST_INVALID_ARGUMENT, "destination_size must be at least 2 and less than or equal to current count");
+    const int size = ct.size;
+    if (n_keys < size - 2) throw Error(ST_INVALID_ARGUMENT, "not enough relinearization keys");
+    for (int i = 0; i < size - 2; i++)
+        if (!keys[i].data) throw Error(ST_INVALID_ARGUMENT, "not enough relinearization keys");
     const u64 pw = poly_words(c, ct.limbs);
-    switch_key(ct, ct.data + 2 * pw, ct.bstride, key, batch, s);
+    for (int i = 0; i < size - 2; i++) switch_key(ct, ct.data + (u64)(size - 1) * pw, ct.bstride, keys[size - 3 - i], batch, s);
     ct.size = 2;
 }
+void Evaluator::relinearize(CtBatch &ct, const KsKey &key, u64 batch, hipStream_t s) { relinearize(ct, &key, 1, batch, s); }
 
 // modSwitchScaleToNext (evaluator_cuda.cu:749-824)
 void Evaluator::mod_switch_scale(const CtBatch &in, CtBatch &out, u64 batch, hipStream_t s) {

@@ -48,6 +48,7 @@ public:
     void multiply(const CtBatch &a, const CtBatch &b, CtBatch &out, u64 batch, hipStream_t s);
     void switch_key(CtBatch &ct, const u64 *target, u64 t_bstride, const KsKey &key, u64 batch, hipStream_t s);
     void relinearize(CtBatch &ct, const KsKey &key, u64 batch, hipStream_t s);
+    void relinearize(CtBatch &ct, const KsKey *keys, int n_keys, u64 batch, hipStream_t s); // keys[i]: relin key of index i (power i + 2)
     void mod_switch_to_next(const CtBatch &in, CtBatch &out, u64 batch, hipStream_t s);
     void rescale_to_next(const CtBatch &in, CtBatch &out, u64 batch, hipStream_t s);
     void apply_galois(CtBatch &ct, uint32_t elt, const KsKey &key, u64 batch, hipStream_t s);

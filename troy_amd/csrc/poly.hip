@@ -214,6 +214,28 @@ template <int S1, int S2> __global__ __launch_bounds__(EW_THREADS) void tensor_k
         *reinterpret_cast<ulonglong2 *>(out + (bb * (S1 + S2 - 1) + d) * limbs * N + l * N + n) = r;
     }
 }
+// any sizes (destination up to SEAL_CIPHERTEXT_SIZE_MAX = 16 polynomials, evaluator_cuda.cu:342-364 / :407-423): operands are re-read per
+// output polynomial (they sit in L1/L2); the register-resident forms above cover the sizes real circuits use
+__global__ __launch_bounds__(EW_THREADS) void tensor_any_kernel(const u64 *a, const u64 *b, u64 *out, u64 a_bstride, u64 b_bstride, int s1, int s2, const PrimeDesc *primes,
+                                                                LimbMap map, int logn, u64 limbs, u64 total) {
+    u64 i = ((u64)blockIdx.x * EW_THREADS + threadIdx.x) * 2;
+    if (i >= total) return;
+    const u64 N = u64(1) << logn;
+    u64 n = i & (N - 1), bl = i >> logn, l = bl % limbs, bb = bl / limbs;
+    const Mod m = mod_of(primes[map.id[l]]);
+    const int ds = s1 + s2 - 1;
+    for (int d = 0; d < ds; d++) {
+        ulonglong2 r{0, 0};
+        const int j0 = d - (s2 - 1) > 0 ? d - (s2 - 1) : 0, j1 = d < s1 - 1 ? d : s1 - 1;
+        for (int j = j0; j <= j1; j++) {
+            const ulonglong2 x = *reinterpret_cast<const ulonglong2 *>(a + bb * a_bstride + (j * limbs + l) * N + n);
+            const ulonglong2 y = *reinterpret_cast<const ulonglong2 *>(b + bb * b_bstride + ((d - j) * limbs + l) * N + n);
+            r.x = addmod(r.x, mulmod(x.x, y.x, m), m.p);
+            r.y = addmod(r.y, mulmod(x.y, y.y, m), m.p);
+        }
+        *reinterpret_cast<ulonglong2 *>(out + (bb * ds + d) * limbs * N + l * N + n) = r;
+    }
+}
 void launch_tensor(int s1, int s2, const u64 *a, const u64 *b, u64 *out, u64 a_bstride, u64 b_bstride, const PrimeDesc *primes, const LimbMap &map,
                    int logn, u64 limbs, u64 batch, hipStream_t s) {
     u64 total = (batch * limbs) << logn;
@@ -223,7 +245,9 @@ void launch_tensor(int s1, int s2, const u64 *a, const u64 *b, u64 *out, u64 a_b
 #define TENSOR_CASE(A, B) if (s1 == A && s2 == B) { TROY_LAUNCH(HIP_KERNEL_NAME(tensor_kernel<A, B>), grid, blk, 0, s, a, b, out, a_bstride, b_bstride, primes, map, logn, limbs, total); launch_check("tensor_kernel"); return; }
     TENSOR_CASE(2, 2) TENSOR_CASE(2, 3) TENSOR_CASE(3, 2) TENSOR_CASE(3, 3) TENSOR_CASE(1, 1) TENSOR_CASE(1, 2) TENSOR_CASE(2, 1) TENSOR_CASE(1, 3) TENSOR_CASE(3, 1)
 #undef TENSOR_CASE
-    throw Error(ST_INVALID_ARGUMENT, "ciphertext sizes above 3 are not supported by multiply");
+    if (s1 < 1 || s2 < 1 || s1 + s2 - 1 > 16) throw Error(ST_INVALID_ARGUMENT, "invalid size");
+    TROY_LAUNCH(tensor_any_kernel, grid, blk, 0, s, a, b, out, a_bstride, b_bstride, s1, s2, primes, map, logn, limbs, total);
+    launch_check("tensor_any_kernel");
 }
 
 // ---------------------------------------------------------------- Galois (a-6 / A.11)
