@@ -7,10 +7,18 @@ the HBM roofline and the CPU path timed beside it.
     python bench.py --gpus 8 --steps 5 --warmup 2          (starts the 8 ranks itself: self_launch)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-A "step" = one pass of the hot path (multiply + relinearize) over one batch of --batch independent ciphertext pairs
-per GPU.  Batches shard embarrassingly over ranks (no data-path collective): every rank owns its own
---batch pairs (weak scaling), keys and tables are replicated, only the timing is reduced (max over ranks).
-Rank 0 prints ONE JSON line.
+A "step" = one pass of the hot path over one batch of --batch independent ciphertexts per GPU.  Batches shard
+embarrassingly over ranks (no data-path collective): every rank owns its own --batch units (weak scaling),
+keys and tables are replicated, only the timing is reduced (max over ranks).  Rank 0 prints ONE JSON line.
+
+--workload selects the BASELINE.json configuration (default: the metric's own, `bfv_n32768_l14`):
+    bfv_n32768_l14         ct x ct multiply + relinearize, BFV N=2^15 K=15            (the headline metric)
+    bfv_n8192_l4           the same at BASELINE configs[1] (N=8192, 5 primes)
+    ckks_n32768_chain      configs[2]: CKKS N=32768 L=14, multiply -> relinearize -> rescale -> rotate(1), chained to depth 3
+    bgv_n65536_relin_rot   configs[3]: BGV N=65536, size-3 ciphertexts, relinearize + rotateRows(1)
+    ckks_matmul_128        configs[4]: CKKS 128x128 matmul of app/LinearHelperCKKS.cuh (MatmulHelper), one input row per batch item
+Every line carries `roofline` (dominant kernel, algorithmic bytes per SURVEY.md 8d, live HIP-event time), `roofline.per_kernel`
+(every kernel of one step, timed by the library's per-launch HIP events) and -- on one rank -- `cpu_baseline`.
 """
 import argparse
 import ctypes as C
@@ -23,11 +31,20 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+BFV, CKKS, BGV = 1, 2, 3
 
 WORKLOADS = {
-    # name: (scheme, N, prime bit sizes, plain-modulus bits)
-    "bfv_n32768_l14": (1, 32768, [60] + [58] * 13 + [60], 20),   # BASELINE.json metric config (configs[1] shape at headline size)
-    "bfv_n8192_l4": (1, 8192, [40, 36, 36, 36, 40], 20),         # BASELINE.json configs[1]
+    # name: scheme, N, prime bit sizes, plain-modulus bits, kind, default batch per GPU, default streams
+    "bfv_n32768_l14": dict(scheme=BFV, N=32768, bits=[60] + [58] * 13 + [60], tbits=20, kind="mul_relin", batch=128, streams=2,
+                           metric="ct x ct multiply+relinearize ops/sec, BFV N=2^15 L=14; achieved HBM GB/s vs peak"),
+    "bfv_n8192_l4": dict(scheme=BFV, N=8192, bits=[40, 36, 36, 36, 40], tbits=20, kind="mul_relin", batch=1024, streams=2,
+                         metric="ct x ct multiply+relinearize ops/sec, BFV N=8192 L=4 (BASELINE configs[1]); achieved HBM GB/s vs peak"),
+    "ckks_n32768_chain": dict(scheme=CKKS, N=32768, bits=[60] + [40] * 13 + [60], tbits=0, kind="ckks_chain", batch=32, streams=1, depth=3,
+                              metric="multiply->relinearize->rescale->rotate steps/sec, CKKS N=32768 L=14, chained to depth 3 (BASELINE configs[2])"),
+    "bgv_n65536_relin_rot": dict(scheme=BGV, N=65536, bits=[60] + [50] * 13 + [60], tbits=20, kind="relin_rot", batch=32, streams=1,
+                                 metric="relinearize+rotateRows ops/sec on size-3 ciphertexts, BGV N=65536 L=14 (BASELINE configs[3])"),
+    "ckks_matmul_128": dict(scheme=CKKS, N=8192, bits=[60, 40, 40, 60], tbits=0, kind="matmul", batch=256, streams=1, dims=(128, 128),
+                            metric="128x128 HE matmul rows/sec, CKKS N=8192 (app/LinearHelperCKKS.cuh MatmulHelper, BASELINE configs[4])"),
 }
 
 
@@ -93,16 +110,321 @@ def sum_over_ranks(x, backend="nccl"):
     return int(t.item())
 
 
+# ---------------------------------------------------------------- workloads: setup -> (step, sync streams, units per step)
+class Workload:
+    """device-resident synthetic inputs + one `step()` = one pass of the hot path over the rank's batch"""
+
+    def __init__(self, ta, capi, lib, wl, B, streams, rank):
+        self.ta, self.capi, self.lib, self.wl, self.B, self.rank = ta, capi, lib, wl, B, rank
+        self.scheme, self.N = wl["scheme"], wl["N"]
+        self.primes = ta.CoeffModulus.Create(self.N, wl["bits"])
+        self.t = ta.PlainModulus.Batching(self.N, wl["tbits"]) if wl["tbits"] else 0
+        self.K, self.L = len(self.primes), len(self.primes) - 1
+        self.ctx = ta.SEALContext(self.scheme, self.N, self.primes, self.t)
+        self.streams = []
+        self.units_per_step = B
+        getattr(self, "_setup_" + wl["kind"])(max(1, min(streams, B)))
+        ta.synchronize()
+
+    def _key(self, ctx, seed):
+        K, N = self.K, self.N
+        key = self.ta.DeviceBuffer((K - 1) * 2 * K * N)
+        ctx.fill_uniform(key, (K - 1) * 2 * K, self.primes, seed=seed)
+        return key
+
+    def _ct(self, ctx, batch, size, limbs, seed, row0, ntt, capacity=None, scale=1.0):
+        c = self.ta.Ciphertext(ctx, batch, size, limbs, ntt, scale, 1, capacity=capacity or size)
+        ctx.fill_uniform(c.buf, batch * size * limbs, self.primes[:limbs], seed=seed, row0=row0)
+        return c
+
+    # ---- BFV multiply + relinearize (the headline metric): the batch is split over `S` HIP streams, each with its own context
+    # (tables + scratch arena): the kernels of one half run concurrently with the kernels of the other.  Odd lanes run half a
+    # step out of phase; every lane still does exactly one multiply and one relinearize per step.
+    def _setup_mul_relin(self, S):
+        ta, capi, lib, B, L, N = self.ta, self.capi, self.lib, self.B, self.L, self.N
+        row0 = self.rank * B * 4 * L  # every rank owns different ciphertexts
+        self.key = self._key(self.ctx, 0xC0FFEE)
+        lanes, done = [], 0
+        for i in range(S):
+            Bi = B // S + (1 if i < B % S else 0)
+            cx = self.ctx if i == 0 else ta.SEALContext(self.scheme, N, self.primes, self.t)
+            st = None
+            if S > 1:
+                h = C.c_void_p()
+                capi.check(lib, lib.troyhip_stream_create(C.byref(h)))
+                st = h
+            ai = self._ct(cx, Bi, 2, L, 0x5EED, row0 + done * 2 * L, False)
+            bi = self._ct(cx, Bi, 2, L, 0x5EED, row0 + B * 2 * L + done * 2 * L, False)
+            oi = ta.Ciphertext(cx, Bi, 3, L, capacity=3)
+            cx.reserve_scratch(max(cx.scratch_words(0, L, Bi), cx.scratch_words(1, L, Bi)))
+            lanes.append((cx, st, Bi, ai.struct(), bi.struct(), oi, ai, bi))
+            done += Bi
+        self.lanes, self.streams = lanes, [ln[1] for ln in lanes]
+        pending = {}
+
+        def mul(i):
+            cx, st, Bi, sa, sb, oi = lanes[i][:6]
+            so = oi.struct()
+            capi.check(lib, lib.troyhip_multiply(cx.h, C.byref(sa), C.byref(sb), C.byref(so), C.c_uint64(Bi), st))
+            pending[i] = so
+
+        def relin(i):
+            cx, st, Bi = lanes[i][:3]
+            capi.check(lib, lib.troyhip_relinearize(cx.h, C.byref(pending.pop(i)), C.c_void_p(self.key.ptr), C.c_uint64(Bi), st))
+
+        def step():
+            for i in range(S):
+                (relin if i & 1 else mul)(i)
+            for i in range(S):
+                (mul if i & 1 else relin)(i)
+
+        def prime():
+            for i in range(1, S, 2):
+                mul(i)  # the out-of-phase lanes start with a product to relinearize (untimed)
+
+        def one_lane_step():  # lane 0 alone, in order: what roofline.per_kernel times
+            mul(0)
+            relin(0)
+
+        self.step, self.prime, self.profile_step, self.profile_units = step, prime, one_lane_step, lanes[0][2]
+
+    # ---- CKKS multiply -> relinearize -> rescale -> rotate(1), chained `depth` times (levels L .. L-depth+1)
+    def _setup_ckks_chain(self, S):
+        ta, B, L = self.ta, self.B, self.L
+        self.ev = ta.Evaluator(self.ctx)
+        scale = float(self.primes[1])  # ~2^40: the product rescales back to ~2^40 at every level
+        depth = self.wl["depth"]
+        self.x0 = self._ct(self.ctx, B, 2, L, 0x5EED, self.rank * B * 4 * L, True, capacity=3, scale=scale)
+        self.bs = [self._ct(self.ctx, B, 2, L - d, 0x7EED + d, self.rank * B * 4 * L, True, scale=scale) for d in range(depth)]
+        self.rlk, self.gk = ta.RelinKeys(self.ctx), ta.GaloisKeys(self.ctx)
+        self.rlk.keys[0] = self._key(self.ctx, 0xC0FFEE)
+        self.gk.keys[ta.GaloisKeys.getIndex(self.ctx.galois_elt_from_step(1))] = self._key(self.ctx, 0xC0FFEF)
+        self.units_per_step = B * depth
+
+        def step():
+            ev, x = self.ev, self.x0
+            for d in range(depth):
+                m = ev.multiply(x, self.bs[d])
+                ev.relinearizeInplace(m, self.rlk)
+                x = ev.rescaleToNext(m)
+                x.scale = self.bs[0].scale  # synthetic data: keep the bookkeeping scale at 2^40 exactly (the primes differ from it by < 2^-20)
+                ev.rotateVectorInplace(x, 1, self.gk)
+            self.last = x
+
+        self.step, self.prime, self.profile_step, self.profile_units = step, (lambda: None), step, B * depth
+
+    # ---- BGV relinearize + rotateRows(1) on size-3 ciphertexts
+    def _setup_relin_rot(self, S):
+        ta, B, L = self.ta, self.B, self.L
+        self.ev = ta.Evaluator(self.ctx)
+        self.x3 = self._ct(self.ctx, B, 3, L, 0x5EED, self.rank * B * 3 * L, False, capacity=3)
+        self.rlk, self.gk = ta.RelinKeys(self.ctx), ta.GaloisKeys(self.ctx)
+        self.rlk.keys[0] = self._key(self.ctx, 0xC0FFEE)
+        self.gk.keys[ta.GaloisKeys.getIndex(self.ctx.galois_elt_from_step(1))] = self._key(self.ctx, 0xC0FFEF)
+
+        def step():
+            w = self.x3.copy()  # relinearize consumes its operand: every step starts from the same size-3 batch (device copy, part of the step)
+            self.ev.relinearizeInplace(w, self.rlk)
+            self.ev.rotateRowsInplace(w, 1, self.gk)
+            self.last = w
+
+        self.step, self.prime, self.profile_step, self.profile_units = step, (lambda: None), step, B
+
+    # ---- CKKS 128x128 matmul (MatmulHelper): batch item = one input row; weights encoded once (untimed), inputs synthetic ciphertexts
+    def _setup_matmul(self, S):
+        import numpy as np
+        from troy_amd import app
+        B, L, N = self.B, self.L, self.N
+        self.ev = self.ta.Evaluator(self.ctx)
+        din, dout = self.wl["dims"]
+        self.helper = app.MatmulHelper(B, din, dout, N // 2)
+        enc = app.CKKSPolyEncoder(self.ctx)
+        scale = float(self.primes[1])
+        rng = np.random.default_rng(1)
+        self.helper.encodeWeights(enc, L, rng.uniform(-1, 1, (din, dout)), scale)
+        nblk = (din + self.helper.blockHeight - 1) // self.helper.blockHeight
+        self.inputs = [self._ct(self.ctx, B, 2, L, 0x5EED + i, self.rank * B * 2 * L, True, scale=scale) for i in range(nblk)]
+
+        def step():
+            self.last = self.helper.matmul(self.ev, self.inputs)
+
+        self.step, self.prime, self.profile_step, self.profile_units = step, (lambda: None), step, B
+
+    def sync_all(self):
+        for st in self.streams:
+            if st is not None:
+                self.ta.synchronize(st)
+        self.ta.synchronize()
+
+
+# ---------------------------------------------------------------- roofline
+def ntt_roofline(ta, capi, lib, w, reps):
+    """the batched NTT at the key-switch shape of this workload (rows = B * (L+1) * L limb-polynomials, prime (r / L) % (L+1)),
+    forward / inverse alternating, timed with HIP events on the launch stream; algorithmic bytes = 16 B per coefficient per
+    limb-transform"""
+    import numpy as np
+    B, L, K, N, primes = min(w.B, 128), w.L, w.K, w.N, w.primes
+    if N > 32768:
+        B = min(B, 32)
+    rows = B * (L + 1) * L
+    D = ta.DeviceBuffer(rows * N)
+    out_primes = primes[:L] + [primes[K - 1]]
+    w.ctx.fill_uniform(D, rows, out_primes, seed=1, inner=L)
+    pr = np.array(out_primes, dtype=np.uint64)
+    timer = C.c_void_p()
+    capi.check(lib, lib.troyhip_timer_create(C.byref(timer)))
+
+    def ntt_once(inv):
+        capi.check(lib, lib.troyhip_ntt(w.ctx.h, C.c_void_p(D.ptr), C.c_uint64(rows), pr.ctypes.data_as(C.c_void_p), len(pr), L, inv, None))
+
+    ntt_once(0)
+    ntt_once(1)
+    ta.synchronize()
+    capi.check(lib, lib.troyhip_ktime_enable(1))
+    ntt_once(0)
+    ntt_once(1)
+    kernels = ktime_report(capi, lib)
+    capi.check(lib, lib.troyhip_ktime_enable(0))
+    capi.check(lib, lib.troyhip_timer_start(timer, None))
+    for i in range(reps):
+        ntt_once(i & 1)  # forward / inverse alternate so values stay canonical
+    capi.check(lib, lib.troyhip_timer_stop(timer, None))
+    ms = C.c_float()
+    capi.check(lib, lib.troyhip_timer_elapsed_ms(timer, C.byref(ms)))
+    capi.check(lib, lib.troyhip_timer_destroy(timer))
+    per_launch_s = ms.value / 1e3 / max(reps, 1)
+    algo_bytes = 16.0 * N * rows
+    achieved = algo_bytes / per_launch_s / 1e9
+    single = any("ntt1_" in k["name"] for k in kernels)
+    roof = {"bound": "hbm", "kernel": ("ntt1_fwd_kernel / ntt1_inv_kernel (single pass: one launch = one limb-transform per row)" if single else
+                                      "ntt2_kernel (strided pass + contiguous pass = one limb-transform per row)"),
+            "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+            "algorithmic_bytes_per_launch": algo_bytes, "launch_us": round(per_launch_s * 1e6, 2), "limb_transforms_per_launch": rows,
+            "launch_kernels": [{"name": k["name"], "us": round(k["total_us"] / k["calls"], 1)} for k in kernels]}
+    traffic = load_traffic()
+    if traffic and traffic.get("N") == N:
+        per_row = traffic.get("hbm_bytes_per_limb_transform", {}).get("ntt1" if single else "ntt2")
+        if per_row:
+            roof["traffic"] = round(per_row * rows)
+            roof["traffic_ratio"] = round(per_row / (16.0 * N), 3)
+            roof["traffic_source"] = traffic.get("source")
+    del D
+    return roof
+
+
+def load_traffic():
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
+    except Exception:
+        return None
+
+
+def ktime_report(capi, lib):
+    buf = C.create_string_buffer(1 << 16)
+    capi.check(lib, lib.troyhip_ktime_report(buf, C.c_size_t(len(buf))))
+    out = json.loads(buf.value.decode())
+    for k in out:
+        n = k["name"].strip()
+        if n.startswith("HIP_KERNEL_NAME(") and n.endswith(")"):
+            n = n[len("HIP_KERNEL_NAME("):-1]
+        k["name"] = n
+    return out
+
+
+def per_kernel(ta, capi, lib, w):
+    """every kernel of ONE step of one lane, by the library's per-launch HIP events; algorithmic bytes (compulsory reads + writes
+    of the stage) where the table below knows the kernel; HBM traffic from profiles/r02_traffic.json (rocprofv3 PMC)"""
+    w.sync_all()
+    capi.check(lib, lib.troyhip_ktime_enable(1))
+    w.profile_step()
+    w.sync_all()
+    ks = ktime_report(capi, lib)
+    capi.check(lib, lib.troyhip_ktime_enable(0))
+    algo = algorithmic_bytes(w, w.profile_units)
+    tinfo = load_traffic() or {}
+    traffic = tinfo.get("per_kernel", {})
+    out = []
+    for k in ks:
+        e = {"name": k["name"], "calls": k["calls"], "us": round(k["total_us"], 1)}
+        ab = algo.get(k["name"])
+        if ab:
+            e["algorithmic_bytes"] = int(ab)
+            e["frac"] = round(ab / (k["total_us"] * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4)
+        tr = traffic.get(k["name"])
+        if tr and ab and w.B == tinfo.get("batch") and w.N == tinfo.get("N"):  # PMC bytes of the same launches at the same batch, scaled to this lane
+            e["traffic"] = int(tr["hbm_bytes"] * w.profile_units / tinfo["batch"])
+            e["traffic_ratio"] = round(e["traffic"] / ab, 3)
+        out.append(e)
+    return out
+
+
+def algorithmic_bytes(w, B):
+    """compulsory HBM bytes per kernel NAME over one step of B units (each stage reads its inputs and writes its outputs once;
+    the key is read once per launch).  Only the BFV multiply+relinearize path is tabulated: SURVEY.md 8d's 545 MB per op at cfgNS."""
+    if w.wl["kind"] != "mul_relin":
+        return {}
+    N, L = w.N, w.L
+    nb = len(w.ctx.behz_bases(L)[0])
+    P = 8.0 * N
+    logn = N.bit_length() - 1
+    t = {}
+
+    def add(name, b):
+        t[name] = t.get(name, 0) + b
+
+    two_pass = logn != 15 or os.environ.get("TROYHIP_NTT") == "twopass"
+    k1 = logn - 9 if logn - 9 <= 7 else 7
+    logc = 11 - k1
+    # multiply: extension of 4 polynomials, forward first passes (q: consumed in place, Bsk), tensor passes, inverse, floor/SK
+    add("behz_extend_mfma_kernel<4, 2>", 2 * 2 * B * (L + nb) * P)
+    add(f"ntt2_kernel<0, 1, {k1}, {logc}, 0, 0, 0>", 2 * (2 * B * L) * 2 * P + 2 * (2 * B * nb) * 2 * P)
+    add("ntt2_kernel<0, 0, 9, 0, 1, 0, 2>", 7 * B * (L + nb) * P)
+    inv_rows = 3 * B * (L + nb) + 2 * B * (L + 1)
+    if two_pass:
+        add("ntt2_kernel<1, 0, 9, 0, 0, 0, 0>", inv_rows * 2 * P)
+        add(f"ntt2_kernel<1, 1, {k1}, {logc}, 2, 0, 0>", inv_rows * 2 * P)
+    else:
+        add("ntt1_inv_kernel", inv_rows * 2 * P)
+    add("behz_floor_sk_mfma_kernel<4, 2>", 3 * B * (2 * L + nb) * P)
+    # relinearize: digit decomposition + first pass, second pass with the inner product against the key, inverse, mod-down
+    add(f"ntt2_kernel<0, 1, {k1}, {logc}, 0, 1, 0>", B * L * P + B * (L + 1) * L * P)
+    add("ntt2_kernel<0, 0, 9, 0, 1, 0, 1>", B * (L + 1) * L * P + 2 * (L + 1) * L * P + 2 * B * (L + 1) * P)
+    add("ks_moddown_kernel<0>", B * (2 * (L + 1) + 4 * L) * P)
+    return t
+
+
+def matmul_roofline(ta, capi, lib, w):
+    """configs[4]: the dominant kernel is the plaintext multiply (mul_plain_kernel: reads the ciphertext and the plaintext, writes
+    the ciphertext = (2 + 2) B + 1 limb-polynomials per product); timed live by the library's per-launch events over one step"""
+    w.sync_all()
+    capi.check(lib, lib.troyhip_ktime_enable(1))
+    w.step()
+    w.sync_all()
+    ks = ktime_report(capi, lib)
+    capi.check(lib, lib.troyhip_ktime_enable(0))
+    k = max(ks, key=lambda e: e["total_us"])
+    P = 8.0 * w.N * w.L
+    per_call = (4 * w.B + 1) * P if "mul_plain" in k["name"] else None
+    us = k["total_us"] / k["calls"]
+    roof = {"bound": "hbm", "kernel": k["name"], "peak": HBM_PEAK_GBPS, "unit": "GB/s", "traffic": None, "launch_us": round(us, 2), "calls_per_step": k["calls"]}
+    if per_call:
+        roof.update(achieved=round(per_call / (us * 1e-6) / 1e9, 1), frac=round(per_call / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4), algorithmic_bytes_per_launch=per_call)
+    return roof
+
+
+# ---------------------------------------------------------------- main
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=128, help="ciphertext pairs per GPU per step")
+    ap.add_argument("--batch", type=int, default=0, help="units (ciphertext pairs / ciphertexts / input rows) per GPU per step; 0 = the workload's default")
     ap.add_argument("--workload", default="bfv_n32768_l14", choices=sorted(WORKLOADS))
-    ap.add_argument("--streams", type=int, default=2, help="split the batch over this many HIP streams (one context each): kernels of different phases overlap")
+    ap.add_argument("--streams", type=int, default=0, help="split the batch over this many HIP streams (one context each); 0 = the workload's default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-per-kernel", action="store_true")
     ap.add_argument("--ntt-reps", type=int, default=10)
+    ap.add_argument("--no-roofline", action="store_true", help="skip the roofline launches (PMC passes over the timed step only)")
     ap.add_argument("--roofline-only", action="store_true", help="skip the timed steps: only the roofline NTT launches run (for the rocprofv3 summary of exactly that kernel)")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed even for one rank (tests the RCCL path)")
     ap.add_argument("--allow-gloo", action="store_true", help="development only: rendezvous over gloo when fewer GPUs than ranks are visible (never the default)")
@@ -141,169 +463,75 @@ def main():
         else:
             raise SystemExit(f"bench.py: {world} ranks requested but only {ndev} GPU(s) visible (pass --allow-gloo on a development box)")
 
-    import numpy as np
-
     import troy_amd as ta
     from troy_amd import capi
 
     lib = capi.load()
     ta.KernelProvider.initialize(device)
-    scheme, N, bits, tbits = WORKLOADS[args.workload]
-    primes = ta.CoeffModulus.Create(N, bits)
-    t = ta.PlainModulus.Batching(N, tbits)
-    ctx = ta.SEALContext(scheme, N, primes, t)
-    K, L = len(primes), len(primes) - 1
-    B = args.batch
-    nbsk = len(ctx.behz_bases(L)[0])
-
-    # ---- synthetic inputs, generated on the device (fill_uniform_kernel == troy_amd.synth) ----
-    # The batch is split over `streams` HIP streams, each with its own context (tables + scratch arena): the kernels of one
-    # half run concurrently with the kernels of the other, so VALU-bound phases (BEHZ, fused key-switch pass) overlap
-    # memory-bound ones (strided NTT passes).  streams = 1 is the plain single-stream batch.
-    S = max(1, min(args.streams, B))
-    row0 = rank * B * 4 * L  # every rank owns different ciphertexts
-    key = ta.DeviceBuffer((K - 1) * 2 * K * N)
-    ctx.fill_uniform(key, (K - 1) * 2 * K, primes, seed=0xC0FFEE)
-    lanes = []
-    done = 0
-    for i in range(S):
-        Bi = B // S + (1 if i < B % S else 0)
-        cx = ctx if i == 0 else ta.SEALContext(scheme, N, primes, t)
-        st = None
-        if S > 1:
-            h = C.c_void_p()
-            capi.check(lib, lib.troyhip_stream_create(C.byref(h)))
-            st = h
-        ai, bi = ta.Ciphertext(cx, Bi, 2, L), ta.Ciphertext(cx, Bi, 2, L)
-        oi = ta.Ciphertext(cx, Bi, 3, L, capacity=3)
-        cx.fill_uniform(ai.buf, Bi * 2 * L, primes[:L], seed=0x5EED, row0=row0 + done * 2 * L)
-        cx.fill_uniform(bi.buf, Bi * 2 * L, primes[:L], seed=0x5EED, row0=row0 + B * 2 * L + done * 2 * L)
-        cx.reserve_scratch(max(cx.scratch_words(0, L, Bi), cx.scratch_words(1, L, Bi)))
-        lanes.append((cx, st, Bi, ai.struct(), bi.struct(), oi, ai, bi))
-        done += Bi
-    ta.synchronize()
-
-    # Odd lanes run half a step out of phase (their relinearize of the previous product is issued while the even lanes
-    # multiply): every lane still does exactly one multiply and one relinearize per step.
-    pending = {}
-
-    def mul(i):
-        cx, st, Bi, sa, sb, oi, _a, _b = lanes[i]
-        so = oi.struct()
-        capi.check(lib, lib.troyhip_multiply(cx.h, C.byref(sa), C.byref(sb), C.byref(so), C.c_uint64(Bi), st))
-        pending[i] = so
-
-    def relin(i):
-        cx, st, Bi = lanes[i][:3]
-        capi.check(lib, lib.troyhip_relinearize(cx.h, C.byref(pending.pop(i)), C.c_void_p(key.ptr), C.c_uint64(Bi), st))
-
+    wl = WORKLOADS[args.workload]
+    B = args.batch or wl["batch"]
+    w = Workload(ta, capi, lib, wl, B, args.streams or wl["streams"], rank)
     if not args.roofline_only:
-        for i in range(1, S, 2):
-            mul(i)  # prime the out-of-phase lanes (untimed)
-
-    def step():
-        for i in range(S):
-            (relin if i & 1 else mul)(i)
-        for i in range(S):
-            (mul if i & 1 else relin)(i)
-
-    def sync_all():
-        for _cx, st, *_ in lanes:
-            ta.synchronize(st)
-        ta.synchronize()
+        w.prime()
 
     def barrier():
-        sync_all()
+        w.sync_all()
         if use_dist:
             _dist().barrier()
-        sync_all()
+        w.sync_all()
 
     if args.roofline_only:
         args.steps = args.warmup = 0
     for _ in range(args.warmup):
-        step()
+        w.step()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
-    sync_all()
+        w.step()
+    w.sync_all()
     dt = max(time.perf_counter() - t0, 1e-9)
     barrier()
     own_dt = dt
+    units = w.units_per_step * args.steps
     if use_dist:
         dt = max_over_ranks(own_dt, backend)
-        total_ops = sum_over_ranks(B * args.steps, backend)
-        per_rank = gather_floats(B * args.steps / own_dt, backend)
+        total_units = sum_over_ranks(units, backend)
+        per_rank = gather_floats(units / own_dt, backend)
         world_seen = _dist().get_world_size()
     else:
-        total_ops = B * args.steps
-        per_rank = [B * args.steps / own_dt]
+        total_units = units
+        per_rank = [units / own_dt]
         world_seen = 1
-    value = total_ops / dt
+    value = total_units / dt
 
-    # ---- roofline of the dominant kernel: the batched NTT (both passes of one transform = one "launch" unit) ----
-    # shape = the key-switch NTT of this very workload: rows = B * (L+1) * L limb-polynomials, prime index (r / L) % (L+1)
     roofline = None
-    if rank == 0:
-        rows = B * (L + 1) * L
-        D = ta.DeviceBuffer(rows * N)
-        out_primes = primes[:L] + [primes[K - 1]]
-        ctx.fill_uniform(D, rows, out_primes, seed=1, inner=L)
-        pr = np.array(out_primes, dtype=np.uint64)
-        timer = C.c_void_p()
-        capi.check(lib, lib.troyhip_timer_create(C.byref(timer)))
+    if rank == 0 and not args.no_roofline:
+        if wl["kind"] == "matmul":
+            roofline = matmul_roofline(ta, capi, lib, w)
+        else:
+            roofline = ntt_roofline(ta, capi, lib, w, args.ntt_reps)
+        if not args.no_per_kernel and not args.roofline_only:
+            roofline["per_kernel"] = per_kernel(ta, capi, lib, w)
 
-        def ntt_once(inv):
-            capi.check(lib, lib.troyhip_ntt(ctx.h, C.c_void_p(D.ptr), C.c_uint64(rows), pr.ctypes.data_as(C.c_void_p), len(pr), L, inv, None))
-        ntt_once(0)
-        ntt_once(1)
-        ta.synchronize()
-        capi.check(lib, lib.troyhip_timer_start(timer, None))
-        for i in range(args.ntt_reps):
-            ntt_once(i & 1)  # forward / inverse alternate so values stay canonical
-        capi.check(lib, lib.troyhip_timer_stop(timer, None))
-        ms = C.c_float()
-        capi.check(lib, lib.troyhip_timer_elapsed_ms(timer, C.byref(ms)))
-        capi.check(lib, lib.troyhip_timer_destroy(timer))
-        per_launch_s = ms.value / 1e3 / args.ntt_reps
-        algo_bytes = 16.0 * N * rows  # 16 B per coefficient per limb-transform
-        achieved = algo_bytes / per_launch_s / 1e9
-        # HBM bytes per launch from the committed PMC measurement of this kernel (profiles/ntt_traffic.json:
-        # FETCH_SIZE x2 + WRITE_SIZE, separate rocprofv3 passes); null when the file does not match this workload
-        traffic = None
-        try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "ntt_traffic.json")))
-            if tj.get("N") == N:
-                traffic = round(tj["hbm_bytes_per_limb_transform"]["mean"] * rows)
-        except Exception:
-            traffic = None
-        roofline = {"bound": "hbm", "kernel": "ntt2_kernel (strided pass + contiguous pass = 1 limb-transform)", "achieved": round(achieved, 1),
-                    "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                    "algorithmic_bytes_per_launch": algo_bytes, "launch_us": round(per_launch_s * 1e6, 2),
-                    "limb_transforms_per_launch": rows}
-        if traffic:  # the two passes' REAL HBM traffic (PMC) over the same live launch time: what rocprof shows the memory system doing
-            roofline["hbm_traffic_gbps"] = round(traffic / per_launch_s / 1e9, 1)
-            roofline["hbm_traffic_frac"] = round(traffic / per_launch_s / 1e9 / HBM_PEAK_GBPS, 4)
-        del D
-
-    # ---- CPU baseline on this box's host cores (rank 0, N=1 only) ----
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
-            cpu = cpu_baseline(scheme, N, primes, t, L)
+            cpu = cpu_baseline(w)
         except Exception as e:  # the baseline is informational; never let it kill the bench line
             cpu = {"error": str(e)}
 
     if rank == 0:
-        limb_transforms = 7 * (L + nbsk) + (L + 1) * L + 2 * (L + 1)
+        L, K, N = w.L, w.K, w.N
+        cfg = {"workload": args.workload, "scheme": {BFV: "BFV", CKKS: "CKKS", BGV: "BGV"}[w.scheme], "N": N, "K": K, "L": L, "batch_per_gpu": B,
+               "parallelism": f"batch-shard x{world}", "streams_per_gpu": len(w.streams) or 1, "rendezvous": backend}
+        if wl["kind"] == "mul_relin":
+            nbsk = len(w.ctx.behz_bases(L)[0])
+            cfg.update(Bsk=nbsk, limb_transforms_per_op=7 * (L + nbsk) + (L + 1) * L + 2 * (L + 1))
         line = {
-            "metric": "ct x ct multiply+relinearize ops/sec, BFV N=2^15 L=14; achieved HBM GB/s vs peak",
-            "value": round(value, 2), "unit": "ops/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "metric": wl["metric"], "value": round(value, 2), "unit": {"mul_relin": "ops/s", "ckks_chain": "steps/s", "relin_rot": "ops/s", "matmul": "rows/s"}[wl["kind"]],
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3) if args.steps else None, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u64", "data": "synthetic",
-            "config": {"workload": args.workload, "scheme": "BFV", "N": N, "K": K, "L": L, "Bsk": nbsk, "batch_per_gpu": B,
-                       "limb_transforms_per_op": limb_transforms, "parallelism": f"batch-shard x{world}", "streams_per_gpu": S, "rendezvous": backend},
-            "ranks": world_seen, "per_rank_ops_per_s": [round(v, 2) for v in per_rank],
+            "dtype": "u64", "data": "synthetic", "config": cfg, "ranks": world_seen, "per_rank_ops_per_s": [round(v, 2) for v in per_rank],
             "roofline": roofline, "cpu_baseline": cpu,
         }
         sys.stdout.flush()
@@ -314,38 +542,85 @@ def main():
         _dist().destroy_process_group()
 
 
-def cpu_baseline(scheme, N, primes, t, L):
-    """The reference's own CPU path (oracle/_ref, kind "reference") when the prebuilt library travelled here, else our
-    CPU port (kind "port").  Bounded sample: a handful of multiply+relinearize ops on the same synthetic inputs."""
+def cpu_baseline(w):
+    """The reference's own CPU path (oracle/_ref, kind "reference") when the prebuilt library travelled here, else our CPU port
+    (kind "port"), on a BOUNDED sample of the same workload (about 10-20 s), 1 thread; plus -- for the multiply+relinearize
+    workloads -- the port on all physical cores."""
     import numpy as np
-
-    from troy_amd import synth
-    xa = synth.uniform_ct(0x5EED, primes[:L], 2, N)[0]
-    xb = synth.uniform_ct(0x5EEE, primes[:L], 2, N)[0]
-    rk = synth.uniform_kswitch_key(0xC0FFEE, primes, N)
     from oracle import oracle, ref
-    reps = 60 if N >= 32768 else 400  # about 12 s of single-core work at either size (0.2 s / 0.03 s per op)
-    O = oracle.Oracle(scheme, N, primes, t)
-    O.set_kswitch_key(0, rk)
-    if ref.available():
-        R = ref.Ref(scheme, N, primes, t)
-        R.set_kswitch_key(0, rk)
-        secs = R.time_mul_relin(ref.Ct(xa), ref.Ct(xb), reps)
-        out = {"value": round(reps / secs, 3), "unit": "ops/s", "cores": 1, "kind": "reference",
-               "sample": f"{reps} multiply+relinearize ops, 1 thread, reference CPU path (src/troy_cpu.h) built -O2 into oracle/_ref"}
-    else:
-        secs = O.time_mul_relin(np.ascontiguousarray(xa), np.ascontiguousarray(xb), reps, 1)
-        out = {"value": round(reps / secs, 3), "unit": "ops/s", "cores": 1, "kind": "port",
-               "sample": f"{reps} multiply+relinearize ops, 1 thread, scalar CPU port (oracle/troy_oracle.cpp, -O3)"}
-    # SURVEY 8(d): the same work on all host cores, one evaluator per thread over disjoint ciphertexts (the port: its evaluators
-    # share nothing but read-only tables), one thread per PHYSICAL core (about 70 MB of working set each at N = 2^15), about 8 s.
-    threads = physical_cores()
-    if threads > 1:
-        reps_all = threads * (30 if N >= 32768 else 200)
-        secs = O.time_mul_relin(np.ascontiguousarray(xa), np.ascontiguousarray(xb), reps_all, threads)
-        out["all_cores"] = {"value": round(reps_all / secs, 3), "unit": "ops/s", "cores": threads, "kind": "port", "cpu": _cpu_model(),
-                            "sample": f"{reps_all} ops over {threads} threads, scalar CPU port (oracle/troy_oracle.cpp, -O3)"}
-    return out
+    from troy_amd import synth
+    scheme, N, primes, t, L, kind = w.scheme, w.N, w.primes, w.t, w.L, w.wl["kind"]
+    use_ref = ref.available()
+    E = (ref.Ref if use_ref else oracle.Oracle)(scheme, N, primes, t)
+    what = "reference CPU path (src/troy_cpu.h) built -O2 into oracle/_ref" if use_ref else "scalar CPU port (oracle/troy_oracle.cpp, -O3)"
+    knd = "reference" if use_ref else "port"
+    rk = synth.uniform_kswitch_key(0xC0FFEE, primes, N)
+    E.set_kswitch_key(0, rk)
+    R, Ct = ref, ref.Ct
+    if kind == "mul_relin":
+        xa = synth.uniform_ct(0x5EED, primes[:L], 2, N)[0]
+        xb = synth.uniform_ct(0x5EEE, primes[:L], 2, N)[0]
+        reps = 60 if N >= 32768 else 400  # about 12 s of single-core work at either size (0.2 s / 0.03 s per op)
+        if use_ref:
+            secs = E.time_mul_relin(Ct(xa), Ct(xb), reps)
+        else:
+            secs = E.time_mul_relin(np.ascontiguousarray(xa), np.ascontiguousarray(xb), reps, 1)
+        out = {"value": round(reps / secs, 3), "unit": "ops/s", "cores": 1, "kind": knd, "sample": f"{reps} multiply+relinearize ops, 1 thread, {what}"}
+        # SURVEY 8(d): the same work on all host cores, one evaluator per thread over disjoint ciphertexts (the port: its evaluators
+        # share nothing but read-only tables), one thread per PHYSICAL core (about 70 MB of working set each at N = 2^15), about 8 s.
+        threads = physical_cores()
+        if threads > 1:
+            O = oracle.Oracle(scheme, N, primes, t)
+            O.set_kswitch_key(0, rk)
+            reps_all = threads * (30 if N >= 32768 else 200)
+            secs = O.time_mul_relin(np.ascontiguousarray(xa), np.ascontiguousarray(xb), reps_all, threads)
+            out["all_cores"] = {"value": round(reps_all / secs, 3), "unit": "ops/s", "cores": threads, "kind": "port", "cpu": _cpu_model(),
+                                "sample": f"{reps_all} ops over {threads} threads (one per physical core), scalar CPU port (oracle/troy_oracle.cpp, -O3)"}
+        return out
+    if kind == "ckks_chain":
+        scale = float(primes[1])
+        E.set_kswitch_key(E.elt_from_step(1), synth.uniform_kswitch_key(0xC0FFEF, primes, N))
+        depth = w.wl["depth"]
+        x = Ct(synth.uniform_ct(0x5EED, primes[:L], 2, N)[0], True, scale)
+        bs = [Ct(synth.uniform_ct(0x7EED + d, primes[:L - d], 2, N)[0], True, scale) for d in range(depth)]
+        t0, n = time.perf_counter(), 0
+        while time.perf_counter() - t0 < 12.0:
+            y = x
+            for d in range(depth):
+                y = E.eval(R.OP_RESCALE_NEXT, E.eval(R.OP_RELIN, E.eval(R.OP_MULTIPLY, y, bs[d])))
+                y.scale = scale
+                y = E.eval(R.OP_ROTATE_VECTOR, y, iarg=1)
+                n += 1
+        secs = time.perf_counter() - t0
+        return {"value": round(n / secs, 3), "unit": "steps/s", "cores": 1, "kind": knd,
+                "sample": f"{n} multiply->relinearize->rescale->rotate steps ({n // depth} chains of depth {depth}), 1 thread, {what}"}
+    if kind == "relin_rot":
+        E.set_kswitch_key(E.elt_from_step(1), synth.uniform_kswitch_key(0xC0FFEF, primes, N))
+        x3 = Ct(synth.uniform_ct(0x5EED, primes[:L], 3, N)[0], False)
+        t0, n = time.perf_counter(), 0
+        while time.perf_counter() - t0 < 12.0:
+            E.eval(R.OP_ROTATE_ROWS, E.eval(R.OP_RELIN, x3), iarg=1)
+            n += 1
+        secs = time.perf_counter() - t0
+        return {"value": round(n / secs, 3), "unit": "ops/s", "cores": 1, "kind": knd, "sample": f"{n} relinearize+rotateRows ops on one size-3 ciphertext, 1 thread, {what}"}
+    if kind == "matmul":
+        # one input row = ceil(in/h) x ceil(out/w) multiplyPlain (NTT form) + the additions, as MatmulHelper::matmul does it
+        scale = float(primes[1])
+        h = w.helper
+        rows_blk, cols_blk = len(h.encodedWeights), len(h.encodedWeights[0])
+        xs = [Ct(synth.uniform_ct(0x5EED + i, primes[:L], 2, N)[0], True, scale) for i in range(rows_blk)]
+        pl = synth.uniform_rows(0x9999, primes[:L], L, N)
+        t0, n = time.perf_counter(), 0
+        while time.perf_counter() - t0 < 10.0:
+            for j in range(cols_blk):
+                acc = None
+                for i in range(rows_blk):
+                    p = E.eval(R.OP_MULTIPLY_PLAIN_NTT, xs[i], pl)
+                    acc = p if acc is None else E.eval(R.OP_ADD, acc, p)
+            n += 1
+        secs = time.perf_counter() - t0
+        return {"value": round(n / secs, 3), "unit": "rows/s", "cores": 1, "kind": knd, "sample": f"{n} input rows ({rows_blk}x{cols_blk} multiplyPlain + adds each), 1 thread, {what}"}
+    return None
 
 
 def physical_cores():

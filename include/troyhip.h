@@ -73,6 +73,10 @@ int troyhip_stream_create(void **stream);
 int troyhip_stream_destroy(void *stream);
 int troyhip_mem_info(size_t *free_bytes, size_t *total_bytes);
 /* HIP-event timers on the caller's stream (bench.py roofline measurement) */
+/* per-kernel timing: while enabled every kernel launch is bracketed by HIP events on its own stream; the report is JSON text
+ * [{"name", "calls", "total_us"}, ...] in first-launch order and clears the log (bench.py: roofline.per_kernel) */
+int troyhip_ktime_enable(int on);
+int troyhip_ktime_report(char *out, size_t capacity);
 int troyhip_timer_create(void **timer);
 int troyhip_timer_destroy(void *timer);
 int troyhip_timer_start(void *timer, void *stream);

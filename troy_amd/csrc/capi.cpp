@@ -6,6 +6,10 @@
 #include "kernels.h"
 #include "hostcrypto.h"
 #include <atomic>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
 #include <map>
 #include <mutex>
 #include <cstring>
@@ -57,6 +61,57 @@ LimbMap map_from_primes(const Context &c, const u64 *row_primes, int period, int
 }
 struct Timer { hipEvent_t a, b; };
 } // namespace
+
+#ifndef TROYHIP_CPU_EMUL
+namespace troyhip { namespace ktime {
+bool enabled = false;
+thread_local const char *tag = nullptr;
+namespace {
+struct Rec { std::string name; hipEvent_t a, b; };
+std::vector<Rec> recs;
+std::mutex kmu;
+}
+void begin(const char *name, hipStream_t s) {
+    std::lock_guard<std::mutex> g(kmu);
+    Rec r;
+    r.name = tag ? tag : name;
+    tag = nullptr;
+    HIP_CHECK(hipEventCreate(&r.a));
+    HIP_CHECK(hipEventCreate(&r.b));
+    HIP_CHECK(hipEventRecord(r.a, s));
+    recs.push_back(r);
+}
+void end(hipStream_t s) {
+    std::lock_guard<std::mutex> g(kmu);
+    if (!recs.empty()) HIP_CHECK(hipEventRecord(recs.back().b, s));
+}
+static std::string report() {
+    std::lock_guard<std::mutex> g(kmu);
+    std::map<std::string, std::pair<unsigned, double>> agg; // name -> (calls, total microseconds)
+    std::vector<std::string> order;
+    for (Rec &r : recs) {
+        float ms = 0;
+        HIP_CHECK(hipEventSynchronize(r.b));
+        HIP_CHECK(hipEventElapsedTime(&ms, r.a, r.b));
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+        if (!agg.count(r.name)) order.push_back(r.name);
+        agg[r.name].first++;
+        agg[r.name].second += ms * 1e3;
+    }
+    recs.clear();
+    std::string out = "[";
+    for (size_t i = 0; i < order.size(); i++) {
+        char buf[96];
+        std::snprintf(buf, sizeof(buf), "\", \"calls\": %u, \"total_us\": %.3f}", agg[order[i]].first, agg[order[i]].second);
+        std::string nm;
+        for (char ch : order[i]) if (ch != '"' && ch != '\\') nm += ch;
+        out += (i ? ", {\"name\": \"" : "{\"name\": \"") + nm + buf;
+    }
+    return out + "]";
+}
+} }
+#endif
 
 extern "C" {
 
@@ -137,6 +192,27 @@ int troyhip_stream_create(void **stream) {
 int troyhip_stream_destroy(void *stream) { return guard([&] { HIP_CHECK(hipStreamDestroy((hipStream_t)stream)); }); }
 int troyhip_mem_info(size_t *free_bytes, size_t *total_bytes) { return guard([&] { HIP_CHECK(hipMemGetInfo(free_bytes, total_bytes)); }); }
 
+/* per-kernel timing (rt.h): enable, run the launches to be measured, then fetch the report (JSON text, launch order; resets) */
+int troyhip_ktime_enable(int on) {
+#ifndef TROYHIP_CPU_EMUL
+    return guard([&] { ktime::enabled = on != 0; });
+#else
+    (void)on;
+    return ST_OK;
+#endif
+}
+int troyhip_ktime_report(char *out, size_t capacity) {
+    return guard([&] {
+        if (!out || !capacity) throw Error(ST_INVALID_ARGUMENT, "report buffer");
+#ifndef TROYHIP_CPU_EMUL
+        const std::string r = ktime::report();
+#else
+        const std::string r = "[]";
+#endif
+        if (r.size() + 1 > capacity) throw Error(ST_OUT_OF_RANGE, "report buffer too small");
+        std::memcpy(out, r.c_str(), r.size() + 1);
+    });
+}
 int troyhip_timer_create(void **timer) {
     return guard([&] {
         Timer *t = new Timer();

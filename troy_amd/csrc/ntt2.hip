@@ -22,6 +22,7 @@
 //     stores the BEHZ ciphertext tensor.
 #include "kernels.h"
 #include "bfly.h"
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <type_traits>
@@ -628,7 +629,13 @@ __global__ __launch_bounds__(N2_THREADS, MAC ? N2_MAC_WAVES : N2_MIN_WAVES) void
 // ---- host side ----
 bool ntt2_supported(int logn) { return logn >= 12 && logn <= 17; }
 
+#ifndef TROYHIP_CPU_EMUL
+#define N2_KTAG(...) do { if (ktime::enabled) { static thread_local char tagbuf[112]; std::snprintf(tagbuf, sizeof(tagbuf), __VA_ARGS__); ktime::tag = tagbuf; } } while (0)
+#else
+#define N2_KTAG(...)
+#endif
 template <int INV, int STRIDED, int NS, int LOGC, int FINAL, int REDUCE> static void launch_one(const Ntt2Args &a, unsigned blocks, hipStream_t s) {
+    N2_KTAG("ntt2_kernel<%d, %d, %d, %d, %d, %d, 0>", INV, STRIDED, NS, LOGC, FINAL, REDUCE); // the instance's name as rocprofv3 prints it
     TROY_LAUNCH(HIP_KERNEL_NAME(ntt2_kernel<INV, STRIDED, NS, LOGC, FINAL, REDUCE>), dim3(blocks), dim3(N2_THREADS), 0, s, a);
     launch_check("ntt2_kernel");
 }
@@ -735,6 +742,7 @@ void launch_ntt2_ks_mac(u64 *D, const u64 *src, u64 src_ostride, const PrimeDesc
     a.mac_key = key; a.mac_acc = acc; a.mac_target = ckks_target; a.mac_tstride = t_bstride; a.mac_K = K;
     a.mac_lazy = lazy;
     std::memcpy(a.mac_key_limb, key_limb, map.period);
+    N2_KTAG("ntt2_kernel<0, 0, 9, 0, 1, 0, 1>");
     TROY_LAUNCH(HIP_KERNEL_NAME(ntt2_kernel<0, 0, 9, 0, 1, 0, 1>), dim3(blocks), dim3(N2_THREADS), 0, stream, a);
     launch_check("ntt2_kernel(ks_mac)");
 }
@@ -783,6 +791,7 @@ void launch_ntt2_tensor(u64 *xa, const u64 *src_a, u64 *xb, const u64 *src_b, u6
     a.rows_per_wg = 4;
     a.chunks = (unsigned)batch;
     const unsigned blocks = (unsigned)((map.period * a.chunks) << a.tiles_per_row_log);
+    N2_KTAG("ntt2_kernel<0, 0, 9, 0, 1, 0, 2>");
     TROY_LAUNCH(HIP_KERNEL_NAME(ntt2_kernel<0, 0, 9, 0, 1, 0, 2>), dim3(blocks), dim3(N2_THREADS), 0, stream, a);
     launch_check("ntt2_kernel(tensor)");
 }

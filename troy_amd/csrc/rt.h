@@ -16,8 +16,21 @@
 #include "hip_emul.h"
 #else
 #include <hip/hip_runtime.h>
-#define TROY_LAUNCH(kernel, grid, block, shmem, stream, ...) \
-    kernel<<<grid, block, shmem, stream>>>(__VA_ARGS__)
+// Per-kernel timing on demand (troyhip_ktime_enable / troyhip_ktime_report, capi.cpp): when enabled, every launch is bracketed by
+// HIP events on ITS OWN stream and accumulated under the kernel's name -- bench.py's roofline.per_kernel comes from here, live.
+// Disabled (the default) it costs one predictable branch per launch.
+namespace troyhip { namespace ktime {
+extern bool enabled;
+extern thread_local const char *tag; // optional name for the next launch (template instances share one source text)
+void begin(const char *name, hipStream_t s);
+void end(hipStream_t s);
+} }
+#define TROY_LAUNCH(kernel, grid, block, shmem, stream, ...)                          \
+    do {                                                                              \
+        if (::troyhip::ktime::enabled) ::troyhip::ktime::begin(#kernel, stream);      \
+        kernel<<<grid, block, shmem, stream>>>(__VA_ARGS__);                          \
+        if (::troyhip::ktime::enabled) ::troyhip::ktime::end(stream);                 \
+    } while (0)
 #endif
 
 namespace troyhip {
