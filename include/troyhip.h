@@ -73,6 +73,11 @@ int troyhip_stream_create(void **stream);
 int troyhip_stream_destroy(void *stream);
 int troyhip_mem_info(size_t *free_bytes, size_t *total_bytes);
 /* HIP-event timers on the caller's stream (bench.py roofline measurement) */
+/* TEST SUPPORT: runs one primitive of the device arithmetic (kernelutils.cuh:94-404 counterparts in modarith.h / bfly.h) on n device
+ * operands.  op: 0 barrett64(a), 1 barrett128(a = lo, b = hi), 2 mulmod(a, b), 3 mul_shoup(a, w = b, quotient c), 4 mul_lazy (result
+ * in [0, 2p)), 5 reduce_prod(a * b), 6 / 7 / 11 / 12 forward butterflies (guarded, guard-free, SGPR-twiddle forms; X = a, Y = b,
+ * twiddle c; out = canonical X', Y' interleaved), 8 / 13 inverse butterflies, 9 last inverse stage (aux = N^-1), 10 128-bit MAC */
+int troyhip_test_modarith(int op, const uint64_t *a, const uint64_t *b, const uint64_t *c, uint64_t p, uint64_t aux, uint64_t *out, uint64_t n, void *stream);
 /* per-kernel timing: while enabled every kernel launch is bracketed by HIP events on its own stream; the report is JSON text
  * [{"name", "calls", "total_us"}, ...] in first-launch order and clears the log (bench.py: roofline.per_kernel) */
 int troyhip_ktime_enable(int on);

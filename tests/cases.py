@@ -39,6 +39,7 @@ CONFIGS = {
 SMALL = ["bfv_n64_k3", "bfv_n128_k4", "bfv_n128_k5_60", "ckks_n128_k6", "bgv_n128_k4"]
 MEDIUM = ["cfgA_bfv_n4096_k3", "cfgB_bfv_n8192_k5", "ckks_n4096_k4", "bgv_n4096_k3"]
 LARGE = ["cfgNS_bfv_n32768_k15", "cfgC_ckks_n32768_k15", "cfgD_bgv_n65536_k15"]
+CHAIN = ["ckks_n128_k6", "ckks_n4096_k4", "cfgC_ckks_n32768_k15"]  # scenario_chain (depth 3; ckks_n4096_k4 has 3 data levels: depth 2 there)
 SIZES = ["bfv_n64_k3", "bfv_n128_k5_60", "ckks_n128_k6", "bgv_n128_k4", "cfgA_bfv_n4096_k3", "ckks_n4096_k4", "bgv_n4096_k3"]  # scenario_sizes
 
 KEY_STEPS = (1, -1, 4)  # Galois keys present; rotations by 5 = naf [1, 4] and 3 = naf [-1, 4] exercise the NAF path
@@ -654,3 +655,362 @@ def check_size_limits(cfg_name):
         raise AssertionError("relinearize from size 16 with one key must be rejected")
     except capi.InvalidArgument as e:
         assert "not enough relinearization keys" in str(e)
+
+
+# ------------------------------------------------------------------ LWE extraction / packing: oracle restatement (limb for limb)
+def _orc_shift(orc, ct, shift):
+    from oracle import ref as R
+    return orc.impl.eval(R.OP_NEGACYCLIC_SHIFT, ct, iarg=shift)
+
+
+def oracle_extract_lwe(orc, ct, term):
+    """EvaluatorCuda::extractLWE (src/evaluator_cuda.cu:2213-2246) on the CPU oracle: (c1 shifted by 2N - term, coefficient `term` of c0)"""
+    from oracle import ref as R
+    N = ct.data.shape[2]
+    if ct.is_ntt:
+        ct = orc.impl.eval(R.OP_FROM_NTT, ct)
+    c1 = _orc_shift(orc, R.Ct(ct.data[1:2], False, ct.scale, ct.correction_factor), 0 if term == 0 else 2 * N - term)
+    return c1.data[0].copy(), ct.data[0, :, term].copy(), ct.scale, ct.correction_factor
+
+
+def oracle_assemble_lwe(orc, lwe, term):
+    """EvaluatorCuda::assembleLWE (:2185-2206)"""
+    from oracle import ref as R
+    c1, c0, scale, cf = lwe
+    L, N = c1.shape
+    sh = _orc_shift(orc, R.Ct(c1[None], False, scale, cf), term).data[0]
+    data = np.zeros((2, L, N), dtype=np.uint64)
+    data[1] = sh
+    data[0, :, term] = c0
+    return R.Ct(data, False, scale, cf)
+
+
+def oracle_pack_lwes(orc, lwes, scheme, primes):
+    """EvaluatorCuda::packLWECiphertexts + fieldTraceInplace + divideByPolyModulusDegreeInplace (:2248-2340), composed from the
+    oracle's negacyclic shift / add / sub / applyGalois / transform ops exactly in the reference's order"""
+    from oracle import ref as R
+    E = orc.impl
+    L, N = lwes[0][0].shape
+    ell = 0
+    while (1 << ell) < len(lwes):
+        ell += 1
+    zero = oracle_assemble_lwe(orc, lwes[0], 0)
+    zero = R.Ct(np.zeros_like(zero.data), False, zero.scale, zero.correction_factor)
+
+    def div_n(ct):  # kMultiplyInvPolyDegreeCoeffmod: every limb times N^-1 mod q_l
+        d = ct.data.copy()
+        for l in range(L):
+            p = int(primes[l])
+            inv = pow(N, -1, p)
+            d[:, l] = np.array([(int(v) * inv) % p for v in d[:, l].reshape(-1)], dtype=np.uint64).reshape(d[:, l].shape)
+        return R.Ct(d, ct.is_ntt, ct.scale, ct.correction_factor)
+
+    rl = []
+    for i in range(1 << ell):
+        idx = int(format(i, "0%db" % ell)[::-1], 2) if ell else 0
+        rl.append(div_n(oracle_assemble_lwe(orc, lwes[idx], 0)) if idx < len(lwes) else zero)
+    for layer in range(ell):
+        gap, shift = 1 << layer, N >> (layer + 1)
+        for off in range(0, 1 << ell, 2 * gap):
+            even, odd = rl[off], rl[off + gap]
+            temp = _orc_shift(orc, odd, shift)
+            new_odd = E.eval(R.OP_SUB, even, temp)
+            even = E.eval(R.OP_ADD, even, temp)
+            if scheme == CKKS:
+                new_odd = E.eval(R.OP_TO_NTT, new_odd)
+            new_odd = E.eval(R.OP_APPLY_GALOIS, new_odd, iarg=(1 << (layer + 1)) + 1)
+            if scheme == CKKS:
+                new_odd = E.eval(R.OP_FROM_NTT, new_odd)
+            rl[off] = E.eval(R.OP_ADD, even, new_odd)
+            rl[off + gap] = new_odd
+    ret = rl[0]
+    degree = N
+    while degree > (1 << ell):  # fieldTraceInplace (:2248-2257): applyGalois on `ret` as it is -- for CKKS `ret` is in coefficient form
+        t = E.eval(R.OP_APPLY_GALOIS, ret, iarg=degree + 1)  # here, so the reference (and the oracle, and the product) reject it
+        ret = E.eval(R.OP_ADD, ret, t)
+        degree >>= 1
+    if scheme == CKKS:
+        ret = E.eval(R.OP_TO_NTT, ret)
+    return ret
+
+
+def check_lwe_limbs(cfg_name, n_lwe=3, batch=2):
+    """extractLWE / assembleLWE / packLWECiphertexts / fieldTrace of the product, LIMB FOR LIMB against the oracle
+    restatement above (synthetic uniform ciphertexts and Galois keys: the arithmetic is oblivious to key validity)."""
+    from oracle import ref as R
+    cfg = CONFIGS[cfg_name]
+    scheme, N = cfg["scheme"], cfg["N"]
+    be = GpuBackend(cfg, batch=batch)
+    orc = oracle_backend(cfg)
+    primes = be.primes
+    L = len(primes) - 1
+    ell = 0
+    while (1 << ell) < n_lwe:
+        ell += 1
+    elts = sorted({(1 << k) + 1 for k in range(1, ell + 1)} | {d + 1 for d in [N >> k for k in range(0, 20)] if d > (1 << ell)})
+    for i, e in enumerate(elts):
+        key = synth.uniform_kswitch_key(SEED + 900 + i, primes, N)
+        be.set_galois_key(e, key)
+        orc.set_galois_key(e, key)
+    ntt = scheme == CKKS
+    xs = [synth.uniform_ct(SEED + 800 + i, primes[:L], 2, N, batch) for i in range(n_lwe)]
+    terms = [(7 * i + 3) % N for i in range(n_lwe)]
+    g_lwes, o_lwes = [], [[] for _ in range(batch)]
+    for i in range(n_lwe):
+        ct = be.api.Ciphertext.from_numpy(be.ctx, xs[i], ntt, 1.0, 1, capacity=3)
+        lwe = be.ev.extractLWE(ct, terms[i])
+        g_lwes.append(lwe)
+        c1 = lwe.c1.cpu()
+        for b in range(batch):
+            o = oracle_extract_lwe(orc, R.Ct(xs[i][b], ntt), terms[i])
+            assert np.array_equal(c1[b, 0], o[0]) and np.array_equal(np.asarray(lwe.c0)[b], o[1]), ("extract", i, b)
+            o_lwes[b].append(o)
+        back = be.ev.assembleLWE(lwe, 5).cpu()
+        for b in range(batch):
+            assert np.array_equal(back[b][:2], oracle_assemble_lwe(orc, o_lwes[b][i], 5).data), ("assemble", i, b)
+    if scheme == CKKS:
+        # the reference's fieldTraceInplace hands a coefficient-form CKKS ciphertext to applyGalois -> switchKeyInplace, which throws
+        # invalid_argument("CKKS encrypted must be in NTT form") (src/evaluator_cuda.cu:1185): same behaviour on all three
+        from troy_amd import capi
+        for fn, exc in ((lambda: be.ev.packLWECiphertexts(g_lwes, be.gk), capi.InvalidArgument), (lambda: oracle_pack_lwes(orc, o_lwes[0], scheme, primes), Exception)):
+            try:
+                fn()
+                raise AssertionError("packLWECiphertexts must reject the CKKS field trace like the reference")
+            except exc as e:
+                assert "NTT form" in str(e), str(e)
+        return
+    packed = be.ev.packLWECiphertexts(g_lwes, be.gk)
+    got = packed.cpu()
+    for b in range(batch):
+        exp = oracle_pack_lwes(orc, o_lwes[b], scheme, primes)
+        assert np.array_equal(got[b][:2], exp.data), ("pack", b)
+        assert packed.is_ntt_form == exp.is_ntt
+
+
+def scenario_chain(backend, cfg, depth=3):
+    """BASELINE configs[2] as SURVEY.md 8d states it: multiply -> relinearize -> rescale -> rotate(1) chained to depth >= 3, limbs
+    exported after EVERY op.  CKKS only."""
+    N = cfg["N"]
+    primes = backend.primes
+    L = len(primes) - 1
+    backend.set_relin_key(synth.uniform_kswitch_key(SEED + 1, primes, N))
+    backend.set_galois_key(backend.elt_from_step(1), synth.uniform_kswitch_key(SEED + 10, primes, N))
+    x = backend.ct(synth.uniform_ct(SEED + 100 + L, primes[:L], 2, N)[0], True)
+    out = {}
+    depth = min(depth, L - backend.last_limbs)
+    for d in range(depth):
+        limbs = L - d
+        b = backend.ct(synth.uniform_ct(SEED + 200 + limbs, primes[:limbs], 2, N)[0], True)
+        x = backend.multiply(x, b)
+        out[f"chain{d}/multiply"] = backend.export(x)
+        x = backend.relinearize(x)
+        out[f"chain{d}/relinearize"] = backend.export(x)
+        x = backend.rescale(x)
+        out[f"chain{d}/rescale"] = backend.export(x)
+        x = backend.rotate(x, 1)
+        out[f"chain{d}/rotate1"] = backend.export(x)
+    return out
+
+
+def check_chain(cfg_name, batch=1, depth=3):
+    import json
+    import os
+    exp = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_chain.json")))[cfg_name]
+    cfg = CONFIGS[cfg_name]
+    out = scenario_chain(GpuBackend(cfg, batch=batch), cfg, depth)
+    assert set(out) == set(exp)
+    for k, m in out.items():
+        assert sha(m.data) == exp[k]["sha256"] and list(m.data.shape) == exp[k]["shape"], k
+        assert m.is_ntt == exp[k]["is_ntt"] and abs(m.scale - exp[k]["scale"]) <= 1e-9 * abs(exp[k]["scale"]), k
+
+
+def check_distinct_batch_relin_rotate(cfg_name, batch=8):
+    """BASELINE configs[3] shape: `batch` DISTINCT size-3 ciphertexts, relinearize + rotateRows(1), every item against the oracle"""
+    from oracle import ref as R
+    cfg = CONFIGS[cfg_name]
+    be = GpuBackend(cfg, batch=batch)
+    orc = oracle_backend(cfg)
+    N, primes = cfg["N"], be.primes
+    L = len(primes) - 1
+    rk = synth.uniform_kswitch_key(SEED + 1, primes, N)
+    gk = synth.uniform_kswitch_key(SEED + 10, primes, N)
+    e1 = be.elt_from_step(1)
+    be.set_relin_key(rk)
+    be.set_galois_key(e1, gk)
+    orc.set_relin_key(rk)
+    orc.set_galois_key(e1, gk)
+    ntt = cfg["scheme"] == CKKS
+    xs = synth.uniform_ct(SEED + 1234, primes[:L], 3, N, batch)
+    c = be.api.Ciphertext.from_numpy(be.ctx, xs, ntt, 1.0, 1, capacity=3)
+    be.ev.relinearizeInplace(c, be.rlk)
+    be.rotate(c, 1)
+    got = c.cpu()
+    op = R.OP_ROTATE_VECTOR if ntt else R.OP_ROTATE_ROWS
+    for b in range(batch):
+        exp = orc.impl.eval(op, orc.impl.eval(R.OP_RELIN, R.Ct(xs[b], ntt)), iarg=1)
+        assert np.array_equal(got[b][:2], exp.data), b
+
+
+# ------------------------------------------------------------------ device-side scalar arithmetic (SURVEY 8 a-1)
+def check_device_modarith(api, kat):
+    """modarith.h / bfly.h on the device through troyhip_test_modarith: the reference's own known-answer vectors
+    (tests/golden/kat_reference_tests.json, test/utils/uintarithsmallmod.cpp) and edge values -- operands 0, 1, p-1, lazy inputs
+    2p-1 / 4p-1 / 8p-1, primes of 36, 58, 60 and 61 bits -- against exact integer arithmetic."""
+    import ctypes as C
+    from troy_amd import capi
+    lib = api.KernelProvider._lib if getattr(api.KernelProvider, "_lib", None) is not None else capi.load()
+
+    def run(op, a, b, c, p, n_out, aux=1):
+        bufs = [api.DeviceBuffer.from_numpy(np.array(v, dtype=np.uint64)) if v is not None else None for v in (a, b, c)]
+        out = api.DeviceBuffer(n_out)
+        capi.check(lib, lib.troyhip_test_modarith(op, *[C.c_void_p(x.ptr) if x is not None else None for x in bufs], C.c_uint64(p), C.c_uint64(aux),
+                                                  C.c_void_p(out.ptr), C.c_uint64(len(a)), None))
+        return [int(v) for v in out.to_numpy()]
+
+    # --- reference KATs
+    for p, lo, hi, exp in kat["barrett_reduce_128"]["cases"]:
+        if int(p) >> 61:
+            continue
+        assert run(1, [int(lo)], [int(hi)], None, int(p), 1) == [int(exp)]
+    for p, x, y, exp in kat["multiply_uint_mod"]["cases"]:
+        assert run(2, [int(x)], [int(y)], None, int(p), 1) == [int(exp)]
+    for p, x, w, exp in kat["multiply_uint_mod_lazy"]["cases"]:
+        p, x, w = int(p), int(x), int(w)
+        r = run(4, [x], [w], [(w << 64) // p], p, 1)[0]
+        assert r == int(exp)  # the exact lazy value of the reference's multiplyUIntModLazy (in [0, 2p))
+    # --- edge values
+    rng = np.random.default_rng(11)
+    M64 = (1 << 64) - 1
+    for p in (2305843009213554689, 1152921504606830593, 288230376150630401, 68718428161, 1152921504606584833):
+        assert p < 1 << 61
+        lazy = [0, 1, p - 1, p, p + 1, 2 * p - 1, 2 * p, 4 * p - 1, 4 * p, min(8 * p - 1, M64), M64, M64 - 1] + [int(v) for v in rng.integers(0, 1 << 63, 20, dtype=np.uint64) * 2 + 1]
+        lazy = [v & M64 for v in lazy]
+        res = [v % p for v in lazy]
+        assert run(0, lazy, None, None, p, len(lazy)) == res
+        pairs = [(x % p, y % p) for x in lazy[:12] for y in (0, 1, p - 1, (p - 1) // 2, lazy[14] % p)]
+        xs, ys = [a for a, _ in pairs], [b for _, b in pairs]
+        assert run(2, xs, ys, None, p, len(xs)) == [(a * b) % p for a, b in pairs]
+        assert run(5, xs, ys, None, p, len(xs)) == [(a * b) % p for a, b in pairs]
+        prods = [a * b + (p - 1) * (p - 1) for a, b in pairs]  # up to 2 p^2: the lazy-sum range of barrett128 callers
+        assert run(1, [v & M64 for v in prods], [v >> 64 for v in prods], None, p, len(prods)) == [v % p for v in prods]
+        ws = [w for w in (0, 1, p - 1, p // 3, lazy[15] % p)]
+        for w in ws:
+            q = (w << 64) // p
+            got = run(3, lazy, [w] * len(lazy), [q] * len(lazy), p, len(lazy))
+            assert got == [(x * w) % p for x in lazy], (p, w)
+            gl = run(4, lazy, [w] * len(lazy), [q] * len(lazy), p, len(lazy))
+            assert all(g % p == (x * w) % p and g < 2 * p for g, x in zip(gl, lazy))
+        # butterflies: forward inputs below 8p (4p for the 61-bit class is 2^63 > ...: 8p < 2^64 always), inverse below 4p
+        top = min(8 * p - 1, M64)
+        fx = [0, p - 1, 2 * p - 1, 4 * p - 1, top, 4 * p, p, 1] + [int(v) % (8 * p) & M64 for v in rng.integers(0, 1 << 63, 24, dtype=np.uint64) * 2]
+        fy = fx[::-1]
+        tw = [(7 * i * i + 3) % p for i in range(len(fx))]
+        tw[0], tw[1], tw[2] = p - 1, 1, 0
+        expf = []
+        for x, y, w in zip(fx, fy, tw):
+            expf += [(x + w * y) % p, (x - w * y) % p]
+        assert run(6, fx, fy, tw, p, 2 * len(fx)) == expf, ("ct_bfly4", p)
+        uni = [(x + tw[3] * y) % p if j == 0 else (x - tw[3] * y) % p for x, y in zip(fx, fy) for j in range(2)]
+        assert run(11, fx, fy, [tw[3]] + tw[1:], p, 2 * len(fx)) == uni, ("ct_bfly4<uniform>", p)
+        if p < 1 << 58:
+            big = [v % (56 * p) for v in rng.integers(0, 1 << 63, len(fx), dtype=np.uint64).astype(object) * 2]  # guard-free: inputs up to 56p, outputs + 3p < 2^64
+            big = [int(v) for v in big]
+            expn = []
+            for x, y, w in zip(big, big[::-1], tw):
+                expn += [(x + w * y) % p, (x - w * y) % p]
+            assert run(7, big, big[::-1], tw, p, 2 * len(fx)) == expn, ("ct_bfly4_ng", p)
+            unn = [(x + tw[3] * y) % p if j == 0 else (x - tw[3] * y) % p for x, y in zip(big, big[::-1]) for j in range(2)]
+            assert run(12, big, big[::-1], [tw[3]] + tw[1:], p, 2 * len(fx)) == unn, ("ct_bfly4_ng<uniform>", p)
+            g8 = [v % (8 * p) for v in big]
+            expg = []
+            for x, y, w in zip(g8, g8[::-1], tw):
+                expg += [(x + y) % p, ((x - y) * w) % p]
+            assert run(13, g8, g8[::-1], tw, p, 2 * len(fx)) == expg, ("gs_bfly4_ng", p)
+        ix = [v % (4 * p) for v in fx]
+        iy = ix[::-1]
+        expi = []
+        for x, y, w in zip(ix, iy, tw):
+            expi += [(x + y) % p, ((x - y) * w) % p]
+        assert run(8, ix, iy, tw, p, 2 * len(ix)) == expi, ("gs_bfly4", p)
+        ninv = pow(32768, -1, p)
+        expl = []
+        for x, y, w in zip(ix, iy, tw):
+            expl += [((x + y) * ninv) % p, ((x - y) * w) % p]
+        assert run(9, ix, iy, tw, p, 2 * len(ix), aux=ninv) == expl, ("gs_bfly4_last", p)
+        # 128-bit multiply-accumulate: 7 terms per accumulator, lazy operands below 8p where 7 * 8p * p < 2^128 (the evaluator's
+        # `lazy` condition, evaluator.cpp switch_key), canonical ones for the 61-bit class
+        n = 28
+        bound = 8 * p if p < (1 << 60) else p
+        ma = [int(v) % bound for v in rng.integers(0, 1 << 63, n, dtype=np.uint64).astype(object) * 2]
+        mb = [int(v) % p for v in rng.integers(0, 1 << 62, n, dtype=np.uint64)]
+        ma[:4] = [bound - 1] * 4
+        mb[:4] = [p - 1] * 4
+        assert run(10, ma, mb, None, p, 1) == [sum(x * y for x, y in zip(ma, mb)) % p], ("mac128x4", p)
+
+
+def check_save_load(api):
+    """CiphertextCuda::save / load wire format (src/ciphertext_cuda.cu:16-104): field layout, parms_id check, round trip"""
+    import io
+    import struct
+    N = 64
+    primes = api.CoeffModulus.Create(N, [40, 40, 40])
+    ctx = api.SEALContext(api.CKKS, N, primes, 0)
+    x = synth.uniform_ct(3, primes[:2], 2, N, 2)
+    c = api.Ciphertext.from_numpy(ctx, x, True, 2.0 ** 20, 1)
+    s = io.BytesIO()
+    c.save(s, index=1)
+    blob = s.getvalue()
+    assert len(blob) == 32 + 1 + 8 * 3 + 8 + 8 + 8 + 1 + 8 + 2 * 2 * N * 8
+    assert struct.unpack_from("<?QQQd", blob, 32) == (True, 2, N, 2, 2.0 ** 20)
+    back = api.Ciphertext.load(ctx, io.BytesIO(blob))
+    assert np.array_equal(back.cpu()[0], x[1]) and back.is_ntt_form and back.scale == 2.0 ** 20
+    other = api.SEALContext(api.CKKS, N, api.CoeffModulus.Create(N, [40, 30, 40]), 0)
+    try:
+        api.Ciphertext.load(other, io.BytesIO(blob))
+        raise AssertionError("a blob of other parameters must be rejected")
+    except ValueError:
+        pass
+
+
+def check_save_terms(api):
+    """CiphertextCuda::saveTerms / loadTerms (src/ciphertext_cuda.cu:44-80, 106-143): c0 keeps only the listed coefficients (in
+    coefficient form, [term][limb]), c1 travels whole; NTT-form ciphertexts are transformed on both sides"""
+    import io
+    import struct
+    N = 64
+    primes = api.CoeffModulus.Create(N, [40, 40, 40])
+    ctx = api.SEALContext(api.CKKS, N, primes, 0)
+    ev = api.Evaluator(ctx)
+    x = synth.uniform_ct(5, primes[:2], 2, N, 1)
+    c = api.Ciphertext.from_numpy(ctx, x, True, 2.0 ** 20, 1)
+    terms = [0, 3, 17, 63]
+    s = io.BytesIO()
+    c.saveTerms(s, ev, terms)
+    blob = s.getvalue()
+    head = 32 + 1 + 8 * 3 + 8 + 8 + 8 + 1
+    assert len(blob) == head + len(terms) * 2 * 8 + 8 + 2 * N * 8
+    assert blob[head - 1] == 1  # terms flag
+    coeff = ev.transformFromNtt(c).cpu()[0]
+    assert np.array_equal(np.frombuffer(blob[head:head + 16], dtype=np.uint64), coeff[0][:, 0])
+    assert struct.unpack_from("<Q", blob, head + len(terms) * 16) == (2 * N,)
+    back = api.Ciphertext.loadTerms(ctx, io.BytesIO(blob), ev, terms)
+    assert back.is_ntt_form and back.scale == 2.0 ** 20 and back.size() == 2
+    got = ev.transformFromNtt(back).cpu()[0]
+    assert np.array_equal(got[1], coeff[1])
+    assert np.array_equal(got[0][:, terms], coeff[0][:, terms])
+    mask = np.ones(N, dtype=bool)
+    mask[terms] = False
+    assert not got[0][:, mask].any()
+    for bad in (lambda: api.Ciphertext.load(ctx, io.BytesIO(blob)),):  # a termed stream needs the indices
+        try:
+            bad()
+            raise AssertionError("expected ValueError")
+        except ValueError:
+            pass
+    full = io.BytesIO()
+    c.save(full)
+    try:
+        api.Ciphertext.loadTerms(ctx, io.BytesIO(full.getvalue()), ev, terms)
+        raise AssertionError("expected ValueError")
+    except ValueError:
+        pass

@@ -8,6 +8,7 @@ Outputs (data only -- inputs are regenerated from seeds by troy_amd.synth, see t
   golden_full_<cfg>.npz   every scenario output limb-for-limb (small N)
   golden_hashes.json      SHA-256 of every scenario output + metadata, for all configs incl. N=32768
   golden_params.json      primes, plain modulus, BEHZ bases, psi, table hashes per config
+  golden_chain.json       SHA-256 after every op of the CKKS multiply -> relinearize -> rescale -> rotate chain at depth 3 (cases.scenario_chain)
   golden_sizes.json       SHA-256 of the general-size scenario (3x2 / 3x3 multiply, relinearize 4->2 / 5->2), cases.scenario_sizes
   cfgA_bfv_n4096_k3.npz   BASELINE config A: seeded keys, two encryptions, their sum, the decryption
   realkey_<scheme>.npz    one decrypt-verified real-key case per scheme (N=128)
@@ -37,11 +38,23 @@ def sizes_only():
         sizes[name] = {k: meta_dict(v) for k, v in cases.scenario_sizes(cases.ref_backend(cfg), cfg).items()}
         print("sizes", name)
     json.dump(sizes, open(os.path.join(HERE, "golden_sizes.json"), "w"), indent=1, sort_keys=True)
+    chain_only()
+
+
+def chain_only():
+    out = {}
+    for name in cases.CHAIN:
+        cfg = cases.CONFIGS[name]
+        out[name] = {k: meta_dict(v) for k, v in cases.scenario_chain(cases.ref_backend(cfg), cfg).items()}
+        print("chain", name)
+    json.dump(out, open(os.path.join(HERE, "golden_chain.json"), "w"), indent=1, sort_keys=True)
 
 
 def main():
     if "--sizes-only" in sys.argv:  # same content as the full run writes into golden_sizes.json
         return sizes_only()
+    if "--chain-only" in sys.argv:  # ... golden_chain.json
+        return chain_only()
     hashes, params, sizes = {}, {}, {}
     for name in cases.SMALL + cases.MEDIUM + cases.LARGE:
         cfg = cases.CONFIGS[name]
@@ -70,6 +83,7 @@ def main():
     json.dump(hashes, open(os.path.join(HERE, "golden_hashes.json"), "w"), indent=1, sort_keys=True)
     json.dump(params, open(os.path.join(HERE, "golden_params.json"), "w"), indent=1, sort_keys=True)
     json.dump(sizes, open(os.path.join(HERE, "golden_sizes.json"), "w"), indent=1, sort_keys=True)
+    chain_only()
 
     # ---- cfgA: BFV N=4096 K=3 encrypt -> add -> decrypt on the reference CPU path
     cfg = cases.CONFIGS["cfgA_bfv_n4096_k3"]

@@ -107,77 +107,30 @@ def test_emulated_lwe_pack(emul_api):
 
 
 def test_emulated_save_load_roundtrip(emul_api):
-    """CiphertextCuda::save / load wire format (src/ciphertext_cuda.cu:16-104): field layout, parms_id check, round trip"""
-    import io
-    import struct
-    api = emul_api
-    from troy_amd import synth
-    N = 64
-    primes = api.CoeffModulus.Create(N, [40, 40, 40])
-    ctx = api.SEALContext(api.CKKS, N, primes, 0)
-    x = synth.uniform_ct(3, primes[:2], 2, N, 2)
-    c = api.Ciphertext.from_numpy(ctx, x, True, 2.0 ** 20, 1)
-    s = io.BytesIO()
-    c.save(s, index=1)
-    blob = s.getvalue()
-    assert len(blob) == 32 + 1 + 8 * 3 + 8 + 8 + 8 + 1 + 8 + 2 * 2 * N * 8
-    assert struct.unpack_from("<?QQQd", blob, 32) == (True, 2, N, 2, 2.0 ** 20)
-    back = api.Ciphertext.load(ctx, io.BytesIO(blob))
-    assert np.array_equal(back.cpu()[0], x[1]) and back.is_ntt_form and back.scale == 2.0 ** 20
-    other = api.SEALContext(api.CKKS, N, api.CoeffModulus.Create(N, [40, 30, 40]), 0)
-    with pytest.raises(ValueError):
-        api.Ciphertext.load(other, io.BytesIO(blob))
+    cases.check_save_load(emul_api)
 
 
 def test_emulated_save_terms_roundtrip(emul_api):
-    """CiphertextCuda::saveTerms / loadTerms (src/ciphertext_cuda.cu:44-80, 106-143): c0 keeps only the listed coefficients (in
-    coefficient form, [term][limb]), c1 travels whole; NTT-form ciphertexts are transformed on both sides"""
-    import io
-    import struct
-    api = emul_api
-    from troy_amd import synth
-    N = 64
-    primes = api.CoeffModulus.Create(N, [40, 40, 40])
-    ctx = api.SEALContext(api.CKKS, N, primes, 0)
-    ev = api.Evaluator(ctx)
-    x = synth.uniform_ct(5, primes[:2], 2, N, 1)
-    c = api.Ciphertext.from_numpy(ctx, x, True, 2.0 ** 20, 1)
-    terms = [0, 3, 17, 63]
-    s = io.BytesIO()
-    c.saveTerms(s, ev, terms)
-    blob = s.getvalue()
-    head = 32 + 1 + 8 * 3 + 8 + 8 + 8 + 1
-    assert len(blob) == head + len(terms) * 2 * 8 + 8 + 2 * N * 8
-    assert blob[head - 1] == 1  # terms flag
-    coeff = ev.transformFromNtt(c).cpu()[0]
-    assert np.array_equal(np.frombuffer(blob[head:head + 16], dtype=np.uint64), coeff[0][:, 0])
-    assert struct.unpack_from("<Q", blob, head + len(terms) * 16) == (2 * N,)
-    back = api.Ciphertext.loadTerms(ctx, io.BytesIO(blob), ev, terms)
-    assert back.is_ntt_form and back.scale == 2.0 ** 20 and back.size() == 2
-    got = ev.transformFromNtt(back).cpu()[0]
-    assert np.array_equal(got[1], coeff[1])
-    assert np.array_equal(got[0][:, terms], coeff[0][:, terms])
-    mask = np.ones(N, dtype=bool)
-    mask[terms] = False
-    assert not got[0][:, mask].any()
-    with pytest.raises(ValueError):
-        api.Ciphertext.load(ctx, io.BytesIO(blob))  # a termed stream needs the indices
-    full = io.BytesIO()
-    c.save(full)
-    with pytest.raises(ValueError):
-        api.Ciphertext.loadTerms(ctx, io.BytesIO(full.getvalue()), ev, terms)
+    cases.check_save_terms(emul_api)
 
 
-def test_emulated_ckks_conv2d_helper(emul_api):
-    cases.check_ckks_conv2d_helper(N=256, batch=1, image=(6, 6), kernel=(3, 3), channels=(3, 2))
-    h = cases.check_ckks_conv2d_helper(N=256, batch=1, image=(20, 18), kernel=(3, 3), channels=(1, 1))  # blocked: 16 x 16 blocks
-    assert h.blocked and h.getTotalBatchSize() == 4
+@pytest.mark.parametrize("name", ["bfv_n128_k4", "ckks_n128_k6", "bgv_n128_k4"])
+def test_emulated_lwe_limbs_vs_oracle(name, emul_api):
+    cases.check_lwe_limbs(name, n_lwe=3, batch=2)
 
 
-@pytest.mark.parametrize("K", [3, 6, 8, 18])
-def test_emulated_bfv_multiply_limb_counts(K, emul_api):
-    """the three epilogue forms of the matrix-core BEHZ kernels (L mod 4 = 2, 1, other) and the VALU kernels (L = 17)"""
-    cases.check_bfv_multiply_limb_count(K, N=64, batch=1)
+def test_emulated_ckks_chain_depth3(emul_api):
+    cases.check_chain("ckks_n128_k6", batch=2)
+
+
+def test_emulated_distinct_batch_relin_rotate(emul_api):
+    cases.check_distinct_batch_relin_rotate("bgv_n128_k4", batch=5)
+    cases.check_distinct_batch_relin_rotate("ckks_n128_k6", batch=3)
+
+
+def test_emulated_device_modarith(emul_api):
+    import json
+    cases.check_device_modarith(emul_api, json.load(open(os.path.join(GOLDEN, "kat_reference_tests.json"))))
 
 
 def test_emulated_single_pass_ntt_row_loop_and_prime_classes(oracle_lib, tmp_path):

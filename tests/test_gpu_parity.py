@@ -354,6 +354,39 @@ def test_gpu_decrypt_end_to_end(gpu):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("name", cases.CHAIN)
+def test_ckks_chain_depth3_every_op(name, gpu):
+    """configs[2]: multiply -> relinearize -> rescale -> rotate(1) chained to depth 3, limbs after every op vs the reference (golden_chain.json)"""
+    cases.check_chain(name, batch=2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,batch", [("bgv_n128_k4", 5), ("ckks_n128_k6", 3), ("bgv_n4096_k3", 8), ("cfgD_bgv_n65536_k15", 8)])
+def test_distinct_batch_relinearize_rotate(name, batch, gpu):
+    """configs[3] shape: a batch of DISTINCT size-3 ciphertexts, relinearize + rotateRows(1), every item against the oracle"""
+    cases.check_distinct_batch_relin_rotate(name, batch=batch)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["bfv_n128_k4", "ckks_n128_k6", "bgv_n128_k4", "cfgA_bfv_n4096_k3", "ckks_n4096_k4"])
+def test_lwe_extract_pack_limbs_vs_oracle(name, gpu):
+    """extractLWE / assembleLWE / packLWECiphertexts / fieldTrace limb for limb against the oracle restatement of src/evaluator_cuda.cu:2178-2351"""
+    cases.check_lwe_limbs(name, n_lwe=3, batch=2)
+
+
+@pytest.mark.gpu
+def test_wire_format_on_device(gpu):
+    cases.check_save_load(gpu.api if hasattr(gpu, "api") else __import__("troy_amd").api)
+    cases.check_save_terms(gpu.api if hasattr(gpu, "api") else __import__("troy_amd").api)
+
+
+@pytest.mark.gpu
+def test_device_modarith_edge_values_and_reference_kats(gpu):
+    import json
+    cases.check_device_modarith(__import__("troy_amd").api, json.load(open(os.path.join(GOLDEN, "kat_reference_tests.json"))))
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("name", cases.SIZES)
 def test_general_ciphertext_sizes(name, gpu):
     """3x2 / 3x3 / 2x3 multiply, size-3 square, relinearize 4 -> 2 and 5 -> 2 against the reference's own outputs"""

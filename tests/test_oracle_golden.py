@@ -104,3 +104,16 @@ def test_oracle_general_sizes(name, oracle_lib):
     for k, m in out.items():
         assert cases.sha(m.data) == exp[k]["sha256"] and list(m.data.shape) == exp[k]["shape"], k
         assert m.is_ntt == exp[k]["is_ntt"] and m.cf == exp[k]["cf"] and abs(m.scale - exp[k]["scale"]) <= 1e-12 * abs(exp[k]["scale"])
+
+
+@pytest.mark.parametrize("name", cases.CHAIN)
+def test_oracle_ckks_chain_depth3(name, oracle_lib):
+    """multiply -> relinearize -> rescale -> rotate(1) chained to depth 3 (BASELINE configs[2] as SURVEY.md 8d states it), limbs after
+    EVERY op against the reference's own outputs (golden_chain.json), incl. N = 2^15 K = 15"""
+    import json
+    exp = json.load(open(os.path.join(GOLDEN, "golden_chain.json")))[name]
+    cfg = cases.CONFIGS[name]
+    out = cases.scenario_chain(cases.oracle_backend(cfg), cfg)
+    assert set(out) == set(exp)
+    for k, m in out.items():
+        assert cases.sha(m.data) == exp[k]["sha256"], k

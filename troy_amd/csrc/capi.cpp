@@ -192,6 +192,13 @@ int troyhip_stream_create(void **stream) {
 int troyhip_stream_destroy(void *stream) { return guard([&] { HIP_CHECK(hipStreamDestroy((hipStream_t)stream)); }); }
 int troyhip_mem_info(size_t *free_bytes, size_t *total_bytes) { return guard([&] { HIP_CHECK(hipMemGetInfo(free_bytes, total_bytes)); }); }
 
+/* device-side probes of the scalar modular arithmetic and the butterfly forms (selftest.hip); all pointers are DEVICE buffers */
+int troyhip_test_modarith(int op, const uint64_t *a, const uint64_t *b, const uint64_t *c, uint64_t p, uint64_t aux, uint64_t *out, uint64_t n, void *stream) {
+    return guard([&] {
+        if (!a || !out || p < 2 || (p >> 61)) throw Error(ST_INVALID_ARGUMENT, "modarith probe arguments");
+        launch_modarith_probe(op, a, b, c, p, aux, out, n, (hipStream_t)stream);
+    });
+}
 /* per-kernel timing (rt.h): enable, run the launches to be measured, then fetch the report (JSON text, launch order; resets) */
 int troyhip_ktime_enable(int on) {
 #ifndef TROYHIP_CPU_EMUL

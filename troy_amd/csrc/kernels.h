@@ -112,6 +112,9 @@ void launch_copy_strided(const u64 *src, u64 src_bstride, u64 *dst, u64 dst_bstr
 void launch_zero_strided(u64 *dst, u64 dst_bstride, u64 count, u64 batch, hipStream_t s);
 void launch_fill_uniform(u64 *out, const PrimeDesc *primes, const LimbMap &map, int logn, u64 seed, u64 row0, u64 rows, hipStream_t s);
 
+// ---- selftest.hip (test support) ----
+void launch_modarith_probe(int op, const u64 *a, const u64 *b, const u64 *c, u64 p, u64 aux_value, u64 *out, u64 n, hipStream_t s);
+
 // ---- behz.hip ----
 // base-change matrix entry split into 21-bit limbs (m = m0 + m1 2^21 + m2 2^42): see behz.hip
 struct Mat3 { u32 m0, m1, m2, pad; };
