@@ -111,6 +111,10 @@ int troyhip_context_ntt_tables(const troyhip_context *ctx, uint64_t prime, uint6
 int troyhip_blake2b(void *out, size_t outlen, const void *in, size_t inlen);
 /* parms_id of the level with `limbs` primes: BLAKE2b-256 of (scheme, N, primes, plain modulus), src/encryptionparams.cpp:118-146 */
 int troyhip_context_parms_id(const troyhip_context *ctx, int limbs, uint64_t out[4]);
+/* A context (its scratch arena) is owned by the stream of the first operation that uses it; an operation on ANOTHER stream is refused
+ * with TROYHIP_LOGIC_ERROR until the owner is released -- call this after synchronising the owning stream.  One context per stream is
+ * the intended use (bench.py: one context per lane). */
+int troyhip_context_release_stream(troyhip_context *ctx);
 int troyhip_context_reserve_scratch(troyhip_context *ctx, size_t words);
 int troyhip_context_scratch_words(const troyhip_context *ctx, int op, int limbs, uint64_t batch, size_t *words); /* op: 0 multiply(2x2), 1 switch_key */
 int troyhip_galois_elt_from_step(const troyhip_context *ctx, int step, uint32_t *out);   /* GaloisToolCuda::getEltFromStep (galois_cuda.cu:44-86) */

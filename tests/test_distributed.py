@@ -68,6 +68,12 @@ def test_two_rank_scatter_compute_gather(tmp_path):
         "assert mine.batch == (3 if r == 0 else 2)\n"
         "api.Evaluator(ctx).negateInplace(mine)\n"
         "out = tdist.gather_batch(mine, 5)\n"
+        "dev_full = api.Ciphertext.from_numpy(ctx, full, True) if r == 0 else None\n"   # device-resident batch on rank 0: scattered from views
+        "mine2 = tdist.scatter_batch(ctx, dev_full, 5, 2, 2, is_ntt_form=True)\n"
+        "assert np.array_equal(mine2.cpu()[:mine.batch], np.where(mine.cpu() == 0, 0, np.array(primes[:2], dtype=np.uint64)[None, None, :, None] - mine.cpu()))\n"
+        "back = tdist.gather_batch_device(mine2, 5)\n"
+        "assert (back is None) == (r != 0)\n"
+        "if r == 0: assert np.array_equal(back.cpu(), full)\n"
         "key = api.DeviceBuffer.from_numpy(np.arange(100, dtype=np.uint64) * (7 if r == 0 else 1))\n"
         "tdist.broadcast(key)\n"
         "assert np.array_equal(key.to_numpy(), np.arange(100, dtype=np.uint64) * 7)\n"

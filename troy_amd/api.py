@@ -64,6 +64,10 @@ class DeviceBuffer:
         capi.check(self.lib, self.lib.troyhip_copy_d2d(C.c_void_p(b.ptr), C.c_void_p(self.ptr), C.c_size_t(self.words * 8), None))
         return b
 
+    def copy_from(self, src, words, src_offset_words=0, dst_offset_words=0):
+        """device-to-device copy of `words` u64 out of another buffer"""
+        capi.check(self.lib, self.lib.troyhip_copy_d2d(C.c_void_p(self.ptr + 8 * dst_offset_words), C.c_void_p(src.ptr + 8 * src_offset_words), C.c_size_t(int(words) * 8), None))
+
     def zero(self):
         capi.check(self.lib, self.lib.troyhip_memset_zero(C.c_void_p(self.ptr), C.c_size_t(self.words * 8), None))
 

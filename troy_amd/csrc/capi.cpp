@@ -5,6 +5,7 @@
 #include "evaluator.h"
 #include "kernels.h"
 #include "hostcrypto.h"
+#include <algorithm>
 #include <atomic>
 #include <cstdio>
 #include <cstring>
@@ -132,18 +133,37 @@ const char *troyhip_build_info(void) {
 }
 // KernelProvider::malloc / free behind the reference's MemoryPoolCuda policy (src/utils/memorypool_cuda.cuh:40-58): a freed
 // block is kept and handed out again to a request of size <= block <= 2 * size; everything cached is released when the device
-// runs short.  hipMalloc / hipFree synchronise the device, a pooled pair does not; reuse is stream-ordered, so a block must not
-// be freed while work on ANOTHER stream still uses it (the reference's pool has the same contract).  Thread-safe.
+// runs short.  hipMalloc / hipFree synchronise the device, a pooled pair does not.  troyhip_free carries no stream, so reuse is
+// made safe for ANY stream: a freed block is stamped with an event on the default stream and on every stream created through
+// troyhip_stream_create, and is handed out again only once all of them have passed (a block dropped by the host while a kernel
+// on some stream still reads it is therefore never overwritten; the reference's pool leaves this to the caller).  Thread-safe.
 namespace {
 struct DevicePool {
+    struct Block { void *p; std::vector<hipEvent_t> pending; };
     std::mutex mu;
-    std::multimap<size_t, void *> free_blocks;
+    std::multimap<size_t, Block> free_blocks;
     std::map<void *, size_t> live;
+    std::vector<hipStream_t> streams;   // the non-default streams handed out by troyhip_stream_create
+    std::vector<hipEvent_t> spare_events;
+    hipEvent_t new_event() {
+        if (!spare_events.empty()) { hipEvent_t e = spare_events.back(); spare_events.pop_back(); return e; }
+        hipEvent_t e;
+        HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        return e;
+    }
+    bool quiescent(Block &b) { // every stream has passed the point at which the block was freed
+        while (!b.pending.empty()) {
+            if (hipEventQuery(b.pending.back()) != hipSuccess) { (void)hipGetLastError(); return false; }
+            spare_events.push_back(b.pending.back());
+            b.pending.pop_back();
+        }
+        return true;
+    }
     void *get(size_t bytes) {
         std::lock_guard<std::mutex> g(mu);
-        auto it = free_blocks.lower_bound(bytes);
-        if (it != free_blocks.end() && it->first <= 2 * bytes) {
-            void *p = it->second;
+        for (auto it = free_blocks.lower_bound(bytes); it != free_blocks.end() && it->first <= 2 * bytes; ++it) {
+            if (!quiescent(it->second)) continue;
+            void *p = it->second.p;
             live[p] = it->first;
             free_blocks.erase(it);
             return p;
@@ -161,14 +181,31 @@ struct DevicePool {
         std::lock_guard<std::mutex> g(mu);
         auto it = live.find(p);
         if (it == live.end()) { (void)hipFree(p); return; } // not ours (defensive)
-        free_blocks.emplace(it->second, p);
+        Block b{p, {}};
+#ifndef TROYHIP_CPU_EMUL
+        for (size_t i = 0; i <= streams.size(); i++) {
+            hipEvent_t e = new_event();
+            HIP_CHECK(hipEventRecord(e, i ? streams[i - 1] : (hipStream_t) nullptr));
+            b.pending.push_back(e);
+        }
+#endif
+        free_blocks.emplace(it->second, std::move(b));
         live.erase(it);
     }
-    void release_locked() {
-        for (auto &kv : free_blocks) (void)hipFree(kv.second);
+    void release_locked() { // callers have synchronised the device (or are out of memory: hipFree synchronises)
+        for (auto &kv : free_blocks) {
+            for (hipEvent_t e : kv.second.pending) spare_events.push_back(e);
+            (void)hipFree(kv.second.p);
+        }
         free_blocks.clear();
     }
     void release() { std::lock_guard<std::mutex> g(mu); release_locked(); }
+    void add_stream(hipStream_t s) { std::lock_guard<std::mutex> g(mu); streams.push_back(s); }
+    void remove_stream(hipStream_t s) {
+        std::lock_guard<std::mutex> g(mu);
+        for (auto &kv : free_blocks) quiescent(kv.second); // events recorded on the dying stream must be retired before it goes
+        streams.erase(std::remove(streams.begin(), streams.end(), s), streams.end());
+    }
     static DevicePool &instance() { static DevicePool p; return p; }
 };
 } // namespace
@@ -187,9 +224,15 @@ int troyhip_copy_d2d(void *dst, const void *src, size_t bytes, void *stream) {
 int troyhip_memset_zero(void *dst, size_t bytes, void *stream) { return guard([&] { HIP_CHECK(hipMemsetAsync(dst, 0, bytes, (hipStream_t)stream)); }); }
 int troyhip_stream_synchronize(void *stream) { return guard([&] { HIP_CHECK(hipStreamSynchronize((hipStream_t)stream)); }); }
 int troyhip_stream_create(void **stream) {
-    return guard([&] { hipStream_t st; HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking)); *stream = (void *)st; });
+    return guard([&] { hipStream_t st; HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking)); DevicePool::instance().add_stream(st); *stream = (void *)st; });
 }
-int troyhip_stream_destroy(void *stream) { return guard([&] { HIP_CHECK(hipStreamDestroy((hipStream_t)stream)); }); }
+int troyhip_stream_destroy(void *stream) {
+    return guard([&] {
+        HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+        DevicePool::instance().remove_stream((hipStream_t)stream);
+        HIP_CHECK(hipStreamDestroy((hipStream_t)stream));
+    });
+}
 int troyhip_mem_info(size_t *free_bytes, size_t *total_bytes) { return guard([&] { HIP_CHECK(hipMemGetInfo(free_bytes, total_bytes)); }); }
 
 /* device-side probes of the scalar modular arithmetic and the butterfly forms (selftest.hip); all pointers are DEVICE buffers */
@@ -285,6 +328,7 @@ int troyhip_context_ntt_tables(const troyhip_context *ctx, uint64_t prime, uint6
         *root = t.psi;
     }, false);
 }
+int troyhip_context_release_stream(troyhip_context *ctx) { return guard([&] { ctx->ctx.arena.release_owner(); }); }
 int troyhip_context_reserve_scratch(troyhip_context *ctx, size_t words) { return guard([&] { ctx->ctx.arena.reset(); ctx->ctx.arena.reserve(words); }); }
 int troyhip_context_scratch_words(const troyhip_context *ctx, int op, int limbs, uint64_t batch, size_t *words) {
     return guard([&] {

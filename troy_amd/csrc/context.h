@@ -23,11 +23,24 @@ public:
     // carve `count` u64 from the arena for the current op; valid until reset()
     u64 *take(size_t count);
     void reset() { used_ = 0; }
+    // every operation that carves scratch opens with begin(stream): the arena (and with it the context) belongs to ONE stream at
+    // a time -- two streams on one context would silently overwrite each other's scratch, so the second one is refused until the
+    // owner is released (troyhip_context_release_stream, after the caller has synchronised the first stream)
+    void begin(hipStream_t s) {
+        if (owned_ && owner_ != s)
+            throw Error(ST_LOGIC_ERROR, "this context is in use on another stream: one context (scratch arena) per stream, or troyhip_context_release_stream after synchronising");
+        owner_ = s;
+        owned_ = true;
+        used_ = 0;
+    }
+    void release_owner() { owned_ = false; }
     void reserve(size_t count);
     size_t capacity() const { return cap_; }
 private:
     u64 *base_ = nullptr;
     size_t cap_ = 0, used_ = 0;
+    hipStream_t owner_ = nullptr;
+    bool owned_ = false;
     std::vector<u64 *> retired_; // blocks replaced by a larger one; freed with the context
 };
 

@@ -86,7 +86,7 @@ void Evaluator::add_sub(CtBatch &a, const CtBatch &b_in, u64 batch, bool sub, hi
     if (!(a.scale == b_in.scale || std::fabs(a.scale - b_in.scale) < std::ldexp(std::max(std::fabs(a.scale), 1.0), -40))) throw Error(ST_INVALID_ARGUMENT, "scale mismatch");
     const u64 pw = poly_words(c, a.limbs);
     CtBatch b = b_in;
-    c.arena.reset();
+    c.arena.begin(s);
     if (a.cf != b.cf) {
         // BGV: balance the correction factors first (evaluator_cuda.cu:170-190)
         u64 f, e1, e2;
@@ -148,7 +148,7 @@ void Evaluator::multiply(const CtBatch &a, const CtBatch &b, CtBatch &out, u64 b
     if (!out.data || out.bstride < (u64)ds * pw) throw Error(ST_INVALID_ARGUMENT, "destination batch stride too small for the result size");
     if (ds > 16) throw Error(ST_INVALID_ARGUMENT, "invalid size"); // Ciphertext::resize beyond SEAL_CIPHERTEXT_SIZE_MAX (src/ciphertext.h:441, defines.h:34)
     LimbMap qmap = c.ct_map(L);
-    c.arena.reset();
+    c.arena.begin(s);
     c.arena.reserve(scratch_multiply(sa, sb, L, batch));
     double new_scale = a.scale;
     u64 new_cf = a.cf;
@@ -279,7 +279,7 @@ void Evaluator::switch_key(CtBatch &ct, const u64 *target, u64 t_bstride, const 
     }
     a.logn = c.logn; a.dl = dl; a.K = K; a.batch = batch;
 
-    c.arena.reset();
+    c.arena.begin(s);
     c.arena.reserve(scratch_switch_key((int)dl, batch));
     u64 *D = c.arena.take(batch * rl * dl * N);
     u64 *acc = c.arena.take(batch * 2 * rl * N);
@@ -380,7 +380,7 @@ void Evaluator::mod_switch_scale(const CtBatch &in, CtBatch &out, u64 batch, hip
     }
     a.logn = c.logn; a.limbs = L; a.polys = batch * in.size;
 
-    c.arena.reset();
+    c.arena.begin(s);
     const bool dense_in = in.bstride == (u64)in.size * pw, dense_out = out.bstride == (u64)in.size * npw;
     {   // everything this op carves, reserved up front: take() can only grow an EMPTY arena (a rescale as the first op on a fresh
         // context, or at a larger batch than the ops before it, used to fail with "scratch arena exhausted inside an op")
@@ -451,7 +451,7 @@ void Evaluator::apply_galois(CtBatch &ct, uint32_t elt, const KsKey &key, u64 ba
     const int L = ct.limbs;
     // sigma(c0), sigma(c1) into dense temporaries; they must outlive switch_key's own scratch, so they are
     // carved from the arena tail after reserving the key-switch working set
-    c.arena.reset();
+    c.arena.begin(s);
     const size_t ks = scratch_switch_key(L, batch);
     c.arena.reserve(ks + 2 * batch * pw + 128);
     (void)c.arena.take(ks);
@@ -554,7 +554,7 @@ void Evaluator::multiply_plain(CtBatch &ct, const u64 *plain, u64 n_coeffs, u64 
     if (ct.ntt) throw Error(ST_INVALID_ARGUMENT, "NTT form mismatch");
     if (c.scheme == SCHEME_CKKS) throw Error(ST_INVALID_ARGUMENT, "CKKS encrypted must be in NTT form");
     const u64 items = plain_bstride ? batch : 1, pw = poly_words(c, ct.limbs);
-    c.arena.reset();
+    c.arena.begin(s);
     c.arena.reserve(items * pw);
     u64 *temp = c.arena.take(items * pw);
     plain_to_ntt(plain, n_coeffs, plain_bstride, ct.limbs, temp, items, s);
@@ -573,7 +573,7 @@ void Evaluator::apply_key_switching(CtBatch &ct, const KsKey &key, u64 batch, hi
     if (!key.data) throw Error(ST_INVALID_ARGUMENT, "kswitch_keys.data().size() != 1");
     if (ct.size != 2) throw Error(ST_INVALID_ARGUMENT, "encrypted.size() != 2");
     const u64 pw = poly_words(c, ct.limbs);
-    c.arena.reset();
+    c.arena.begin(s);
     const size_t ks = scratch_switch_key(ct.limbs, batch);
     c.arena.reserve(ks + batch * pw + 128);
     (void)c.arena.take(ks);
@@ -588,7 +588,7 @@ void Evaluator::negacyclic_shift(CtBatch &ct, u64 shift, u64 batch, hipStream_t 
     if (shift >= 2 * c.N) throw Error(ST_INVALID_ARGUMENT, "shift");  // x^(N+k) = -x^k: shifts up to 2N-1 (extractLWE uses 2N - term)
     if (shift == 0) return;
     const u64 words = (u64)ct.size * poly_words(c, ct.limbs);
-    c.arena.reset();
+    c.arena.begin(s);
     c.arena.reserve(batch * words);
     u64 *tmp = c.arena.take(batch * words);
     launch_copy_strided(ct.data, ct.bstride, tmp, words, words, batch, s);
@@ -621,7 +621,7 @@ void Evaluator::decrypt(const CtBatch &ct, const u64 *sk, u64 *out, u64 out_bstr
     std::memset(&a, 0, sizeof(a));
     a.primes = c.d_desc; a.map = c.ct_map(ct.limbs); a.logn = c.logn;
     a.limbs = limbs; a.size = ct.size; a.batch = batch; a.ct_bstride = ct.bstride; a.out_bstride = out_bstride;
-    c.arena.reset();
+    c.arena.begin(s);
     c.arena.reserve(batch * np * pw + np * pw + batch * pw + 512);
     u64 *x = c.arena.take(batch * np * pw), *spow = c.arena.take(np * pw), *acc = c.arena.take(batch * pw);
     // c_1 .. c_{size-1} in NTT form

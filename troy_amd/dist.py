@@ -60,39 +60,74 @@ def broadcast(buf, src=0):
     return buf
 
 
+def _shard_tensor(ct, count):
+    """torch view of the first `count` ciphertexts of a batched Ciphertext as ONE contiguous int64 tensor (RCCL path): the device
+    buffer itself when the batch is dense (capacity == size), else a device-side compaction (torch slice on the strided view)"""
+    per_cap = ct.capacity * ct.limbs * ct.context.N
+    per = ct.size() * ct.limbs * ct.context.N
+    t = _tensor(ct.buf, count * per_cap)
+    if per_cap == per:
+        return t
+    return t.view(count, per_cap)[:, :per].contiguous().view(-1)
+
+
 def scatter_batch(context, full, batch_total, size, limbs, is_ntt_form=False, scale=1.0, correction_factor=1, src=0):
-    """`full` (rank `src` only): numpy [batch_total][size][limbs][N].  Returns this rank's shard as a batched Ciphertext."""
+    """Rank `src` holds the whole batch -- a numpy array [batch_total][size][limbs][N] or a device-resident dense `api.Ciphertext` --
+    and every rank gets its contiguous shard as a batched Ciphertext.  RCCL: isend straight from device views (a host array is
+    staged shard by shard, never as a whole); gloo: through host arrays."""
     dist = _dist()
     rank, world = dist.get_rank(), dist.get_world_size()
     lo, hi = shard_range(batch_total, rank, world)
-    mine = api.Ciphertext(context, max(hi - lo, 1), size, limbs, is_ntt_form, scale, correction_factor, capacity=size)
     per = size * limbs * context.N
     if rank == src:
-        full = np.ascontiguousarray(full, dtype=np.uint64).reshape(batch_total, per)
-        staged = api.DeviceBuffer.from_numpy(full) if _is_nccl() else None
-        reqs = []
+        on_device = isinstance(full, api.Ciphertext)
+        if on_device:
+            if full.capacity != full.size() or full.size() != size or full.limbs != limbs:
+                raise ValueError("scatter_batch: the device batch must be dense [batch][size][limbs][N]")
+        else:
+            full = np.ascontiguousarray(full, dtype=np.uint64).reshape(batch_total, per)
+        reqs, keep = [], []
+        mine = None
         for r in range(world):
             rlo, rhi = shard_range(batch_total, r, world)
             if rhi == rlo:
                 continue
             if r == src:
-                mine = api.Ciphertext.from_numpy(context, full[rlo:rhi].reshape(rhi - rlo, size, limbs, context.N), is_ntt_form, scale, correction_factor)
+                if on_device:
+                    mine = api.Ciphertext(context, rhi - rlo, size, limbs, is_ntt_form, scale, correction_factor, capacity=size)
+                    mine.buf.copy_from(full.buf, (rhi - rlo) * per, src_offset_words=rlo * per)
+                else:
+                    mine = api.Ciphertext.from_numpy(context, full[rlo:rhi].reshape(rhi - rlo, size, limbs, context.N), is_ntt_form, scale, correction_factor)
                 continue
-            import torch
-            t = _tensor(staged, (rhi - rlo) * per, rlo * per) if staged else torch.from_numpy(full[rlo:rhi].reshape(-1).view(np.int64).copy())
+            if _is_nccl():
+                if on_device:
+                    t = _tensor(full.buf, (rhi - rlo) * per, rlo * per)
+                else:
+                    staged = api.DeviceBuffer.from_numpy(full[rlo:rhi])  # shard-sized staging, alive until the send completed
+                    keep.append(staged)
+                    t = _tensor(staged, (rhi - rlo) * per)
+            else:
+                import torch
+                host = full.cpu().reshape(-1)[rlo * per:rhi * per] if on_device else full[rlo:rhi].reshape(-1)
+                t = torch.from_numpy(np.ascontiguousarray(host).view(np.int64).copy())
             reqs.append(dist.isend(t, dst=r))
         for q in reqs:
             q.wait()
-    elif hi > lo:
-        t = _tensor(mine.buf, (hi - lo) * per)
-        dist.recv(t, src=src)
-        _store(mine.buf, t, (hi - lo) * per)
+        if mine is None:
+            mine = api.Ciphertext(context, 1, size, limbs, is_ntt_form, scale, correction_factor, capacity=size)
+    else:
+        mine = api.Ciphertext(context, max(hi - lo, 1), size, limbs, is_ntt_form, scale, correction_factor, capacity=size)
+        if hi > lo:
+            t = _tensor(mine.buf, (hi - lo) * per)
+            dist.recv(t, src=src)
+            _store(mine.buf, t, (hi - lo) * per)
     api.synchronize()
     return mine
 
 
-def gather_batch(ct, batch_total, dst=0):
-    """inverse of scatter_batch: rank `dst` returns numpy [batch_total][size][limbs][N], the others None"""
+def gather_batch_device(ct, batch_total, dst=0):
+    """inverse of scatter_batch, result left on the device: rank `dst` returns a dense batched Ciphertext of all `batch_total` items
+    (received straight into its buffer over RCCL), the others None"""
     dist = _dist()
     rank, world = dist.get_rank(), dist.get_world_size()
     lo, hi = shard_range(batch_total, rank, world)
@@ -101,20 +136,32 @@ def gather_batch(ct, batch_total, dst=0):
     api.synchronize()
     if rank != dst:
         if hi > lo:
-            dense = api.DeviceBuffer.from_numpy(ct.cpu()[: hi - lo])  # dense [shard][size][limbs][N]
-            dist.send(_tensor(dense, (hi - lo) * per), dst=dst)
+            if _is_nccl():
+                dist.send(_shard_tensor(ct, hi - lo), dst=dst)  # device view (or device-side compaction): no host bounce
+            else:
+                import torch
+                dist.send(torch.from_numpy(np.ascontiguousarray(ct.cpu()[: hi - lo]).reshape(-1).view(np.int64).copy()), dst=dst)
         return None
-    out = np.zeros((batch_total, size, limbs, N), dtype=np.uint64)
+    out = api.Ciphertext(ct.context, batch_total, size, limbs, ct.is_ntt_form, ct.scale, ct.correction_factor, capacity=size)
     for r in range(world):
         rlo, rhi = shard_range(batch_total, r, world)
         if rhi == rlo:
             continue
         if r == dst:
-            out[rlo:rhi] = ct.cpu()[: rhi - rlo]
+            if ct.capacity == size:
+                out.buf.copy_from(ct.buf, (rhi - rlo) * per, dst_offset_words=rlo * per)
+            else:
+                part = api.DeviceBuffer.from_numpy(ct.cpu()[: rhi - rlo])
+                out.buf.copy_from(part, (rhi - rlo) * per, dst_offset_words=rlo * per)
             continue
-        tmp = api.DeviceBuffer((rhi - rlo) * per)
-        t = _tensor(tmp, (rhi - rlo) * per)
+        t = _tensor(out.buf, (rhi - rlo) * per, rlo * per)
         dist.recv(t, src=r)
-        _store(tmp, t, (rhi - rlo) * per)
-        out[rlo:rhi] = tmp.to_numpy().reshape(rhi - rlo, size, limbs, N)
+        _store(out.buf, t, (rhi - rlo) * per, rlo * per)
+    api.synchronize()
     return out
+
+
+def gather_batch(ct, batch_total, dst=0):
+    """as gather_batch_device, downloaded: rank `dst` returns numpy [batch_total][size][limbs][N], the others None"""
+    out = gather_batch_device(ct, batch_total, dst)
+    return None if out is None else out.cpu()
