@@ -134,6 +134,10 @@ int troyhip_host_galois_key(const troyhip_context *ctx, uint64_t seed_lo, uint64
  * polynomial -> ct [2][limbs][N] NTT form */
 int troyhip_host_encrypt(const troyhip_context *ctx, uint64_t seed_lo, uint64_t seed_hi, const uint64_t *public_key, const uint64_t *plain,
                          uint64_t n_coeffs, int limbs, uint64_t *ct_out);
+/* Encryptor::encryptSymmetric (secret key; src/encryptor.cpp:88-148 with is_asymmetric false, src/utils/rlwe.cpp:234-345): same
+ * operand and result layout as troyhip_host_encrypt, (c0, c1) = (-(a s + e) + message, a) sampled at the plaintext's own level */
+int troyhip_host_encrypt_symmetric(const troyhip_context *ctx, uint64_t seed_lo, uint64_t seed_hi, const uint64_t *secret_key, const uint64_t *plain,
+                                   uint64_t n_coeffs, int limbs, uint64_t *ct_out);
 /* Decryptor::decrypt.  BFV/BGV: N plaintext coefficients;  CKKS: the [limbs][N] RNS plaintext (NTT form) */
 int troyhip_host_decrypt(const troyhip_context *ctx, const uint64_t *secret_key, const uint64_t *ct, int size, int limbs, int is_ntt_form,
                          uint64_t correction_factor, uint64_t *plain_out);

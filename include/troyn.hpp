@@ -15,6 +15,8 @@
 #pragma once
 #include "troyhip.h"
 #include <algorithm>
+#include <array>
+#include <cmath>
 #include <cstdint>
 #include <istream>
 #include <ostream>
@@ -88,10 +90,22 @@ private:
     Modulus t_;
 };
 
-using ParmsID = int; // the level is identified by its limb count (the reference hashes the parameters, src/encryptionparams.cpp:118-146)
+// ParmsID (src/encryptionparams.h: util::HashFunction::hash_block_type = std::array<uint64_t, 4>): the BLAKE2b-256 hash of
+// the level's parameters (src/encryptionparams.cpp:118-146), computed by the library (troyhip_context_parms_id).  The shim
+// also carries the level's limb count, which is what the C ABI identifies a level by; comparisons are on the hash.
+struct ParmsID : std::array<uint64_t, 4> {
+    int limbs = 0;
+    ParmsID() : std::array<uint64_t, 4>{{0, 0, 0, 0}} {}
+    bool operator==(const ParmsID &o) const { return static_cast<const std::array<uint64_t, 4> &>(*this) == static_cast<const std::array<uint64_t, 4> &>(o); }
+    bool operator!=(const ParmsID &o) const { return !(*this == o); }
+};
+static const ParmsID parmsIDZero{}; // src/encryptionparams.h: parmsIDZero
+
+class ContextData; // below
 
 class SEALContext { // src/context_cuda.cuh:146-186
 public:
+    using ContextDataCuda = ContextData; // the nested name user code spells (src/context_cuda.cuh:20)
     SEALContext(const EncryptionParameters &parms, bool expand_mod_chain = true, SecurityLevel sec = SecurityLevel::tc128) : parms_(parms) {
         (void)expand_mod_chain;
         (void)sec; // SecurityLevel::none semantics: parameter security is not policed
@@ -101,19 +115,88 @@ public:
         check(troyhip_context_create((int)parms.scheme(), parms.polyModulusDegree(), q.data(), (int)q.size(), parms.plainModulus().value(), &c));
         ctx_.reset(c, [](troyhip_context *p) { troyhip_context_destroy(p); });
         check(troyhip_context_info(c, &info_));
+        auto ids = std::make_shared<std::vector<ParmsID>>((size_t)info_.key_limbs + 1);
+        for (int l = info_.last_limbs; l <= info_.key_limbs; l++) {
+            if (l != info_.key_limbs && l > info_.first_limbs) continue;
+            ParmsID id;
+            check(troyhip_context_parms_id(c, l, id.data()));
+            id.limbs = l;
+            (*ids)[(size_t)l] = id;
+        }
+        ids_ = ids;
     }
     troyhip_context *handle() const { return ctx_.get(); }
     const EncryptionParameters &parms() const { return parms_; }
-    ParmsID keyParmsID() const { return info_.key_limbs; }
-    ParmsID firstParmsID() const { return info_.first_limbs; }
-    ParmsID lastParmsID() const { return info_.last_limbs; }
+    const ParmsID &keyParmsID() const { return (*ids_)[(size_t)info_.key_limbs]; }
+    const ParmsID &firstParmsID() const { return (*ids_)[(size_t)info_.first_limbs]; }
+    const ParmsID &lastParmsID() const { return (*ids_)[(size_t)info_.last_limbs]; }
+    // the ParmsID of the level with `limbs` primes (parmsIDZero if there is no such level)
+    const ParmsID &parmsIDOfLimbs(size_t limbs) const { return limbs < ids_->size() ? (*ids_)[limbs] : parmsIDZero; }
+    std::shared_ptr<const std::vector<ParmsID>> levelIDs() const { return ids_; }
+    // getContextData / firstContextData / keyContextData / lastContextData (src/context_cuda.cuh:146-186): nullptr for an unknown id
+    inline std::shared_ptr<const ContextData> getContextData(const ParmsID &parms_id) const;
+    std::shared_ptr<const ContextData> keyContextData() const { return getContextData(keyParmsID()); }
+    std::shared_ptr<const ContextData> firstContextData() const { return getContextData(firstParmsID()); }
+    std::shared_ptr<const ContextData> lastContextData() const { return getContextData(lastParmsID()); }
+    bool using_keyswitching() const { return info_.key_limbs > 1; }
     size_t polyModulusDegree() const { return info_.poly_modulus_degree; }
     size_t keyLimbs() const { return (size_t)info_.key_limbs; }
+    size_t firstLimbs() const { return (size_t)info_.first_limbs; }
+    size_t lastLimbs() const { return (size_t)info_.last_limbs; }
 private:
     EncryptionParameters parms_;
     std::shared_ptr<troyhip_context> ctx_;
     troyhip_context_info_t info_{};
+    std::shared_ptr<std::vector<ParmsID>> ids_;
 };
+
+// SEALContextCuda::ContextDataCuda (src/context_cuda.cuh:20-140), the members user code reads: the level's parameters, its id,
+// its position in the chain (chain_index counts down to 0 at the last level, src/context.cpp:522-529) and its neighbours
+class ContextData {
+public:
+    ContextData(const SEALContext &c, size_t limbs) : c_(&c), limbs_(limbs), parms_(c.parms().scheme()) {
+        parms_.setPolyModulusDegree(c.parms().polyModulusDegree());
+        parms_.setPlainModulus(c.parms().plainModulus());
+        std::vector<Modulus> q(c.parms().coeffModulus().begin(), c.parms().coeffModulus().begin() + (long)limbs);
+        parms_.setCoeffModulus(q);
+    }
+    const EncryptionParameters &parms() const { return parms_; }
+    const ParmsID &parmsID() const { return c_->parmsIDOfLimbs(limbs_); }
+    // the product of the level's primes as little-endian words, one per prime (ContextData::totalCoeffModulus, src/context.h)
+    std::vector<uint64_t> totalCoeffModulus() const {
+        std::vector<uint64_t> q(limbs_, 0);
+        q[0] = 1;
+        for (auto &m : parms_.coeffModulus()) {
+            unsigned __int128 carry = 0;
+            for (auto &w : q) { unsigned __int128 t = (unsigned __int128)w * m.value() + carry; w = (uint64_t)t; carry = t >> 64; }
+        }
+        return q;
+    }
+    int totalCoeffModulusBitCount() const {
+        const std::vector<uint64_t> q = totalCoeffModulus();
+        for (size_t i = q.size(); i-- > 0;)
+            if (q[i]) return (int)(64 * i) + 64 - __builtin_clzll(q[i]);
+        return 0;
+    }
+    size_t chainIndex() const { return limbs_ == c_->keyLimbs() ? (c_->using_keyswitching() ? c_->firstLimbs() - c_->lastLimbs() + 1 : 0) : limbs_ - c_->lastLimbs(); }
+    std::shared_ptr<const ContextData> nextContextData() const { // one prime fewer; none below the last level
+        if (limbs_ == c_->keyLimbs() && c_->using_keyswitching()) return c_->firstContextData();
+        return limbs_ > c_->lastLimbs() ? c_->getContextData(c_->parmsIDOfLimbs(limbs_ - 1)) : nullptr;
+    }
+    std::shared_ptr<const ContextData> prevContextData() const {
+        if (limbs_ == c_->keyLimbs()) return nullptr;
+        return limbs_ == c_->firstLimbs() ? c_->keyContextData() : c_->getContextData(c_->parmsIDOfLimbs(limbs_ + 1));
+    }
+private:
+    const SEALContext *c_;
+    size_t limbs_;
+    EncryptionParameters parms_;
+};
+inline std::shared_ptr<const ContextData> SEALContext::getContextData(const ParmsID &parms_id) const {
+    for (const ParmsID &id : *ids_)
+        if (id.limbs && id == parms_id) return std::make_shared<const ContextData>(*this, (size_t)id.limbs);
+    return nullptr;
+}
 
 // DeviceArray<uint64_t> (src/utils/devicearray.cuh): deep copy on copy, steal on move
 class DeviceArray {
@@ -151,11 +234,11 @@ public:
     Plaintext() = default;
     explicit Plaintext(const std::vector<uint64_t> &coeffs) : data_(coeffs) {}
     // "1x^10 + 2"-style constructor of the reference is not reproduced; use setCoeff
-    void resize(size_t n) { data_.resize(n, 0); }
+    void resize(size_t n) { dev_.reset(); data_.resize(n, 0); }
     size_t coeffCount() const { return data_.size(); }
-    uint64_t *data() { return data_.data(); }
+    uint64_t *data() { dev_.reset(); return data_.data(); }
     const uint64_t *data() const { return data_.data(); }
-    uint64_t &operator[](size_t i) { return data_[i]; }
+    uint64_t &operator[](size_t i) { dev_.reset(); return data_[i]; }
     const uint64_t &operator[](size_t i) const { return data_[i]; }
     bool operator==(const Plaintext &o) const {
         size_t n = std::max(data_.size(), o.data_.size());
@@ -165,36 +248,55 @@ public:
     }
     double &scale() { return scale_; }
     double scale() const { return scale_; }
-    bool isNttForm() const { return ntt_limbs_ != 0; }
-    ParmsID parmsID() const { return ntt_limbs_; } // level of an NTT-form plaintext (0 = coefficient form, parms_id_zero)
-    void setNttForm(ParmsID limbs) { ntt_limbs_ = limbs; }
+    bool isNttForm() const { return parms_id_.limbs != 0; }
+    const ParmsID &parmsID() const { return parms_id_; } // level of an NTT-form plaintext (parmsIDZero = coefficient form)
+    void setNttForm(const ParmsID &id) { parms_id_ = id; }
+    // PlaintextCuda keeps its coefficients in device memory; here the device copy is a mirror of the host vector, made on first use by
+    // an Evaluator call and dropped by any mutable access, so a weight plaintext that is multiplied many times is uploaded once
+    const uint64_t *device() const {
+        if (!dev_) {
+            dev_ = std::make_shared<DeviceArray>(data_.size());
+            if (!data_.empty()) check(troyhip_copy_h2d(dev_->get(), data_.data(), data_.size() * 8, nullptr));
+        }
+        return dev_->get();
+    }
+    void adoptDevice(std::shared_ptr<DeviceArray> d) { dev_ = std::move(d); } // the encoder hands over the buffer it transformed
 private:
     std::vector<uint64_t> data_;
     double scale_ = 1.0;
-    ParmsID ntt_limbs_ = 0;
+    ParmsID parms_id_;
+    mutable std::shared_ptr<DeviceArray> dev_;
 };
 
 class Ciphertext { // src/ciphertext_cuda.cuh:12-268
 public:
     Ciphertext() = default;
-    explicit Ciphertext(const SEALContext &c) : n_(c.polyModulusDegree()) {}
+    explicit Ciphertext(const SEALContext &c) : n_(c.polyModulusDegree()), ids_(c.levelIDs()) {}
     size_t size() const { return (size_t)d_.size; }
     size_t coeffModulusSize() const { return (size_t)d_.limbs; }
     size_t polyModulusDegree() const { return n_; }
-    ParmsID parmsID() const { return d_.limbs; }
+    // the 256-bit id of the ciphertext's level (parmsIDZero before the object has met a context)
+    const ParmsID &parmsID() const { return ids_ && (size_t)d_.limbs < ids_->size() ? (*ids_)[(size_t)d_.limbs] : parmsIDZero; }
+    void bind(const SEALContext &c) { ids_ = c.levelIDs(); }
+    void bind(const Ciphertext &o) { ids_ = o.ids_; }
     bool isNttForm() const { return d_.is_ntt_form != 0; }
     bool &isNttFormRef() { ntt_shadow_ = d_.is_ntt_form != 0; return ntt_shadow_; }
     double &scale() { return d_.scale; }
     double scale() const { return d_.scale; }
     uint64_t &correctionFactor() { return d_.correction_factor; }
     uint64_t correctionFactor() const { return d_.correction_factor; }
-    // device storage is kept at capacity max(size, 3) polynomials so multiply / relinearize run in place
+    // a ciphertext that owns its storage keeps capacity max(size, 3) polynomials so multiply / relinearize run in place
     void resize(size_t n, size_t limbs, size_t size) {
         n_ = n;
-        const size_t cap = std::max<size_t>(size, 3);
-        buf_.resize(cap * limbs * n);
-        d_.data = buf_.get();
-        d_.batch_stride = cap * limbs * n;
+        const size_t words = std::max<size_t>(size, 3) * limbs * n;
+        if (!store_ || !own_ || store_->size() != words) {
+            auto fresh = std::make_shared<DeviceArray>(words);
+            if (store_ && d_.data && d_.batch_stride) check(troyhip_copy_d2d(fresh->get(), d_.data, std::min<size_t>(words, d_.batch_stride) * 8, nullptr));
+            store_ = std::move(fresh);
+            own_ = true;
+        }
+        d_.data = store_->get();
+        d_.batch_stride = words;
         d_.size = (int)size;
         d_.limbs = (int)limbs;
     }
@@ -209,7 +311,52 @@ public:
         check(troyhip_copy_h2d(d_.data, h.data(), h.size() * 8, nullptr));
         d_.is_ntt_form = ntt; d_.scale = scale; d_.correction_factor = cf;
     }
-    troyhip_ct *raw() { d_.data = buf_.get(); return &d_; }
+    // ---- batch slabs (no counterpart in the reference, whose every CiphertextCuda is its own allocation): `count` ciphertexts of
+    // one shape carved out of ONE device allocation, dense [count][size][limbs][N] -- the layout the library's batched entry points
+    // take -- each still an ordinary Ciphertext.  A member that has to grow, or is copied, moves to storage of its own.
+    static std::vector<Ciphertext> allocateBatch(size_t count, const Ciphertext &like) {
+        const size_t stride = like.size() * like.coeffModulusSize() * like.n_;
+        auto slab = std::make_shared<DeviceArray>(count * stride);
+        std::vector<Ciphertext> out(count);
+        for (size_t b = 0; b < count; b++) {
+            Ciphertext &c = out[b];
+            c.store_ = slab;
+            c.own_ = false;
+            c.d_ = like.d_;
+            c.d_.data = slab->get() + b * stride;
+            c.d_.batch_stride = stride;
+            c.n_ = like.n_;
+            c.ids_ = like.ids_;
+        }
+        return out;
+    }
+    // the same ciphertexts, moved into one slab (device-to-device); they must agree in shape and metadata
+    static std::vector<Ciphertext> packBatch(const std::vector<Ciphertext> &items) {
+        if (items.empty()) return {};
+        std::vector<Ciphertext> out = allocateBatch(items.size(), items[0]);
+        for (size_t b = 0; b < items.size(); b++) {
+            if (!items[b].sameShape(items[0])) throw std::invalid_argument("packBatch: ciphertexts of different shape");
+            check(troyhip_copy_d2d(out[b].d_.data, items[b].d_.data, out[b].d_.batch_stride * 8, nullptr));
+        }
+        return out;
+    }
+    // do these ciphertexts, in this order, form a dense run of one slab?
+    static bool isBatch(const std::vector<const Ciphertext *> &items) {
+        if (items.empty() || !items[0]->store_ || items[0]->own_) return false;
+        const Ciphertext &head = *items[0];
+        if (head.d_.batch_stride != head.size() * head.coeffModulusSize() * head.n_) return false;
+        for (size_t b = 1; b < items.size(); b++) {
+            const Ciphertext &c = *items[b];
+            if (c.store_ != head.store_ || c.own_ || !c.sameShape(head) || c.d_.data != head.d_.data + b * head.d_.batch_stride) return false;
+        }
+        return true;
+    }
+    bool sameShape(const Ciphertext &o) const {
+        return n_ == o.n_ && d_.size == o.d_.size && d_.limbs == o.d_.limbs && d_.is_ntt_form == o.d_.is_ntt_form && d_.scale == o.d_.scale &&
+               d_.correction_factor == o.d_.correction_factor;
+    }
+    void copyMeta(const troyhip_ct &m) { d_.size = m.size; d_.limbs = m.limbs; d_.is_ntt_form = m.is_ntt_form; d_.scale = m.scale; d_.correction_factor = m.correction_factor; }
+    troyhip_ct *raw() { return &d_; }
     const troyhip_ct *raw() const { return &d_; }
     // wire format of CiphertextCuda::save / load / saveTerms / loadTerms (src/ciphertext_cuda.cu:16-143); the context supplies
     // the 256-bit parms_id the reference object carries itself (defined after Evaluator below)
@@ -217,16 +364,38 @@ public:
     inline void load(std::istream &stream, const SEALContext &context);
     inline void saveTerms(std::ostream &stream, const SEALContext &context, const class Evaluator &evaluator, const std::vector<size_t> &termIds) const;
     inline void loadTerms(std::istream &stream, const SEALContext &context, const class Evaluator &evaluator, const std::vector<size_t> &termIds);
-    // value semantics: deep copy
-    Ciphertext(const Ciphertext &o) : buf_(o.buf_), d_(o.d_), n_(o.n_) { d_.data = buf_.get(); }
+    // the reference's own signatures (src/ciphertext_cuda.cuh:183-187): the context is the one the object is bound to (save), none
+    // (load(stream): fields taken as they come, as there), or the evaluator's (saveTerms / loadTerms)
+    inline void save(std::ostream &stream) const;
+    inline void load(std::istream &stream);
+    inline void saveTerms(std::ostream &stream, const class Evaluator &evaluator, const std::vector<size_t> &termIds) const;
+    inline void loadTerms(std::istream &stream, const class Evaluator &evaluator, const std::vector<size_t> &termIds);
+    // value semantics: a copy gets storage of its own (also when the source is a slab member)
+    Ciphertext(const Ciphertext &o) : d_(o.d_), n_(o.n_), ids_(o.ids_) { clone(o); }
     Ciphertext(Ciphertext &&o) noexcept = default;
-    Ciphertext &operator=(const Ciphertext &o) { buf_ = o.buf_; d_ = o.d_; n_ = o.n_; d_.data = buf_.get(); return *this; }
+    Ciphertext &operator=(const Ciphertext &o) {
+        if (this != &o) { d_ = o.d_; n_ = o.n_; ids_ = o.ids_; clone(o); }
+        return *this;
+    }
     Ciphertext &operator=(Ciphertext &&o) noexcept = default;
 private:
-    DeviceArray buf_;
+    void clone(const Ciphertext &o) {
+        store_.reset();
+        own_ = true;
+        d_.data = nullptr;
+        if (!o.store_) return;
+        const size_t used = o.size() * o.coeffModulusSize() * o.n_, words = std::max<size_t>(o.size(), 3) * o.coeffModulusSize() * o.n_;
+        store_ = std::make_shared<DeviceArray>(words);
+        d_.data = store_->get();
+        d_.batch_stride = words;
+        if (used) check(troyhip_copy_d2d(d_.data, o.d_.data, used * 8, nullptr));
+    }
+    std::shared_ptr<DeviceArray> store_;
+    bool own_ = true;
     troyhip_ct d_{nullptr, 0, 0, 0, 0, 1.0, 1};
     size_t n_ = 0;
     bool ntt_shadow_ = false;
+    std::shared_ptr<const std::vector<ParmsID>> ids_;
 };
 
 class SecretKey { public: std::vector<uint64_t> data; };  // [K][N] NTT form (host), src/secretkey.h
@@ -259,6 +428,27 @@ public:
     bool hasKey(uint32_t galois_elt) const { return hasKeyIndex(getIndex(galois_elt)); }
 };
 
+// LWECiphertextCuda (src/lwe_cuda.cuh): the LWE sample (c1: one polynomial [limbs][N] in coefficient form, c0: one word per limb)
+// that extractLWE cuts out of an RLWE ciphertext
+class LWECiphertext {
+public:
+    const ParmsID &parmsID() const { return parms_id_; }
+    size_t polyModulusDegree() const { return n_; }
+    size_t coeffModulusSize() const { return limbs_; }
+    double scale() const { return scale_; }
+    uint64_t correctionFactor() const { return cf_; }
+    const DeviceArray &c1() const { return c1_; }
+    const std::vector<uint64_t> &c0() const { return c0_; }
+private:
+    friend class Evaluator;
+    ParmsID parms_id_;
+    size_t n_ = 0, limbs_ = 0;
+    double scale_ = 1.0;
+    uint64_t cf_ = 1;
+    DeviceArray c1_;
+    std::vector<uint64_t> c0_;
+};
+
 class KeyGenerator { // src/keygenerator_cuda.cuh: runs on the CPU
 public:
     // KeyGenerator(context): the key stream is seeded from the operating system's entropy source, as the reference's default
@@ -287,6 +477,22 @@ public:
             gk.upload(GaloisKeys::getIndex(e), h);
         }
     }
+    // every key rotate / conjugate can ask for: X -> X^(2N-1) and X -> X^(3^(2^i)), X^(3^-(2^i)) (GaloisTool::getEltsAll,
+    // src/utils/galois.cpp:101-126)
+    void createGaloisKeys(GaloisKeys &gk) const {
+        const uint64_t m = 2 * (uint64_t)c_.polyModulusDegree();
+        std::vector<uint32_t> elts{(uint32_t)(m - 1)};
+        uint64_t pos = 3, neg = 1;
+        while (neg * 3 % m != 1) neg += 2; // 3^-1 mod 2N
+        for (uint64_t span = 2; span < m / 2; span <<= 1) {
+            elts.push_back((uint32_t)pos);
+            elts.push_back((uint32_t)neg);
+            pos = pos * pos % m;
+            neg = neg * neg % m;
+        }
+        createGaloisKeys(elts, gk);
+    }
+    GaloisKeys createGaloisKeys() const { GaloisKeys g; createGaloisKeys(g); return g; }
     void createGaloisKeys(const std::vector<int> &steps, GaloisKeys &gk) const {
         std::vector<uint32_t> elts;
         for (int s : steps) { uint32_t e; check(troyhip_galois_elt_from_step(c_.handle(), s, &e)); elts.push_back(e); }
@@ -306,27 +512,46 @@ private:
     PublicKey pk_;
 };
 
-class Encryptor { // src/encryptor_cuda.cuh (public-key path), CPU sampling + upload
+class Encryptor { // src/encryptor_cuda.cuh:20-300, CPU sampling + upload
 public:
-    // every encryption draws a fresh 128-bit seed for (u, e0, e1) from the operating system (src/randomgen.cpp:23,72)
-    Encryptor(const SEALContext &c, const PublicKey &pk) : c_(c), pk_(pk), seeded_(false), lo_(0), hi_(0) {}
+    // every encryption draws a fresh 128-bit seed for its samples from the operating system (src/randomgen.cpp:23,72)
+    Encryptor(const SEALContext &c, const PublicKey &pk) : c_(c), pk_(pk) {}
+    Encryptor(const SEALContext &c, const SecretKey &sk) : c_(c), sk_(sk) {}
+    Encryptor(const SEALContext &c, const PublicKey &pk, const SecretKey &sk) : c_(c), pk_(pk), sk_(sk) {}
     // deterministic stream (seed, call counter) for tests ONLY
     Encryptor(const SEALContext &c, const PublicKey &pk, uint64_t seed_lo, uint64_t seed_hi = 0) : c_(c), pk_(pk), seeded_(true), lo_(seed_lo), hi_(seed_hi) {}
+    void setPublicKey(const PublicKey &pk) { pk_ = pk; }
+    void setSecretKey(const SecretKey &sk) { sk_ = sk; }
     void encrypt(const Plaintext &plain, Ciphertext &dst) const {
+        if (pk_.data.empty()) throw std::logic_error("public key is not set"); // src/encryptor.cpp:157-160
+        run(troyhip_host_encrypt, pk_.data, plain, dst);
+    }
+    Ciphertext encrypt(const Plaintext &plain) const { Ciphertext d; encrypt(plain, d); return d; }
+    // encryptSymmetric (src/encryptor_cuda.cuh:259-290): (-(a s + e) + m, a) at the plaintext's own level
+    void encryptSymmetric(const Plaintext &plain, Ciphertext &dst) const {
+        if (sk_.data.empty()) throw std::logic_error("secret key is not set"); // src/encryptor.cpp:164-167
+        run(troyhip_host_encrypt_symmetric, sk_.data, plain, dst);
+    }
+    Ciphertext encryptSymmetric(const Plaintext &plain) const { Ciphertext d; encryptSymmetric(plain, d); return d; }
+private:
+    template <class F> void run(F fn, const std::vector<uint64_t> &key, const Plaintext &plain, Ciphertext &dst) const {
         const size_t N = c_.polyModulusDegree();
         const bool ckks = c_.parms().scheme() == SchemeType::ckks;
-        const int limbs = ckks ? (int)(plain.coeffCount() / N) : c_.firstParmsID();
+        if (ckks && !plain.isNttForm()) throw std::invalid_argument("plain must be in NTT form");  // src/encryptor.cpp:216-219
+        if (!ckks && plain.isNttForm()) throw std::invalid_argument("plain cannot be in NTT form"); // src/encryptor.cpp:202-205
+        const int limbs = ckks ? (int)(plain.coeffCount() / N) : (int)c_.firstLimbs();
         std::vector<uint64_t> h((size_t)2 * limbs * N);
         uint64_t s[2] = {lo_ + (++counter_), hi_};
         if (!seeded_) check(troyhip_random_bytes(s, sizeof(s)));
-        check(troyhip_host_encrypt(c_.handle(), s[0], s[1], pk_.data.data(), plain.data(), ckks ? N : plain.coeffCount(), limbs, h.data()));
+        check(fn(c_.handle(), s[0], s[1], key.data(), plain.data(), ckks ? N : plain.coeffCount(), limbs, h.data()));
         dst.fromHost(h, N, limbs, 2, ckks, ckks ? plain.scale() : 1.0, 1); // destination.scale() = plain.scale(): src/encryptor.cpp:235
+        dst.bind(c_);
     }
-private:
     const SEALContext &c_;
     PublicKey pk_;
-    bool seeded_;
-    uint64_t lo_, hi_;
+    SecretKey sk_;
+    bool seeded_ = false;
+    uint64_t lo_ = 0, hi_ = 0;
     mutable uint64_t counter_ = 0;
 };
 
@@ -343,16 +568,158 @@ public:
         check(troyhip_decrypt(c_.handle(), ct.raw(), sk_.get(), out.get(), words, 1, nullptr));
         dst.resize(words);
         check(troyhip_copy_d2h(dst.data(), out.get(), words * 8, nullptr));
-        if (ckks) { dst.setNttForm(ct.parmsID()); dst.scale() = ct.scale(); }
+        dst.setNttForm(ckks ? ct.parmsID() : parmsIDZero);
+        if (ckks) dst.scale() = ct.scale();
     }
 private:
     const SEALContext &c_;
     DeviceArray sk_;
 };
 
+// CKKSEncoderCuda (src/ckks_cuda.cuh:13-113), the coefficient packing app/LinearHelperCKKS.cuh is built on: encodePolynomial puts
+// round(value * scale) into the polynomial's COEFFICIENTS (no canonical embedding) and leaves the plaintext in NTT form at the
+// chosen level; decodePolynomial inverts it.  The per-coefficient integer work runs here on the host exactly as the reference's
+// kernels define it (ckks_cuda.cu:211-330, 793-831); the transforms run on the GPU (troyhip_ntt).
+class CKKSEncoder {
+public:
+    explicit CKKSEncoder(const SEALContext &c) : c_(c), slots_(c.polyModulusDegree() / 2) {
+        if (c.parms().scheme() != SchemeType::ckks) throw std::invalid_argument("unsupported scheme"); // src/ckks.cpp:22-25
+    }
+    size_t slotCount() const noexcept { return slots_; }
+
+    // ckks_cuda.cu:455-575 encodePolynomialInternal
+    void encodePolynomial(const std::vector<double> &values, const ParmsID &parms_id, double scale, Plaintext &destination) const {
+        auto level = c_.getContextData(parms_id);
+        if (!level) throw std::invalid_argument("parms_id is not valid for encryption parameters");
+        const size_t n = slots_ * 2;
+        if (values.size() > n) throw std::invalid_argument("values_size is too large");
+        const auto &q = level->parms().coeffModulus();
+        const size_t limbs = q.size();
+        std::vector<double> scaled(n, 0.0);
+        double largest = 0;
+        for (size_t i = 0; i < values.size(); i++) {
+            scaled[i] = values[i] * scale;
+            largest = std::max(largest, std::fabs(scaled[i]));
+        }
+        // one more bit for the sign; nothing below 1.0 goes through log2 (ckks_cuda.cu:516-521)
+        const int bits = (int)std::ceil(std::log2(std::max(largest, 1.0))) + 1;
+        if (bits >= level->totalCoeffModulusBitCount()) throw std::invalid_argument("encoded values are too large");
+        std::vector<uint64_t> rns(limbs * n);
+        for (size_t i = 0; i < n; i++) {
+            const double r = std::round(scaled[i]);
+            const bool negative = r < 0;
+            // |r| = mant * 2^shift exactly (mant < 2^64): the three magnitude ranges of the reference (<= 64, <= 128, more bits)
+            // all reduce this same integer, so one exact path serves them
+            int e = 0;
+            const double frac = std::frexp(std::fabs(r), &e);
+            const int shift = e > 64 ? e - 64 : 0;
+            const uint64_t mant = (uint64_t)std::ldexp(frac, e - shift);
+            for (size_t j = 0; j < limbs; j++) {
+                const uint64_t p = q[j].value();
+                uint64_t v = mant % p;
+                if (shift) v = (uint64_t)((unsigned __int128)v * pow2_mod((unsigned)shift, p) % p);
+                rns[j * n + i] = negative && v ? p - v : v;
+            }
+        }
+        auto dev = std::make_shared<DeviceArray>(limbs * n);
+        std::vector<uint64_t> primes;
+        for (auto &m : q) primes.push_back(m.value());
+        check(troyhip_copy_h2d(dev->get(), rns.data(), rns.size() * 8, nullptr));
+        check(troyhip_ntt(c_.handle(), dev->get(), limbs, primes.data(), (int)limbs, 1, 0, nullptr));
+        destination.resize(limbs * n);
+        check(troyhip_copy_d2h(destination.data(), dev->get(), limbs * n * 8, nullptr));
+        destination.adoptDevice(dev); // the transformed buffer doubles as the plaintext's device copy
+        destination.setNttForm(parms_id);
+        destination.scale() = scale;
+    }
+    void encodePolynomial(const std::vector<double> &values, double scale, Plaintext &destination) const {
+        encodePolynomial(values, c_.firstParmsID(), scale, destination);
+    }
+
+    // ckks_cuda.cu:983-1049 decodePolynomialInternal: inverse NTT, CRT composition, centred lift, times 1/scale -- the double
+    // arithmetic word by word in the order of gDecodeInternal (ckks_cuda.cu:793-831) so the doubles come out the same
+    void decodePolynomial(const Plaintext &plain, std::vector<double> &destination) const {
+        if (!plain.isNttForm()) throw std::invalid_argument("plain is not in NTT form");
+        auto level = c_.getContextData(plain.parmsID());
+        if (!level) throw std::invalid_argument("plain is not valid for encryption parameters");
+        const size_t n = slots_ * 2;
+        const auto &q = level->parms().coeffModulus();
+        const size_t limbs = q.size();
+        if (plain.coeffCount() != limbs * n) throw std::invalid_argument("plain is not valid for encryption parameters");
+        if (plain.scale() <= 0 || (int)std::log2(plain.scale()) >= level->totalCoeffModulusBitCount()) throw std::invalid_argument("scale out of bounds");
+        std::vector<uint64_t> primes;
+        for (auto &m : q) primes.push_back(m.value());
+        DeviceArray dev(limbs * n);
+        check(troyhip_copy_d2d(dev.get(), plain.device(), limbs * n * 8, nullptr));
+        check(troyhip_ntt(c_.handle(), dev.get(), limbs, primes.data(), (int)limbs, 1, 1, nullptr));
+        std::vector<uint64_t> rns(limbs * n);
+        check(troyhip_copy_d2h(rns.data(), dev.get(), rns.size() * 8, nullptr));
+
+        const std::vector<uint64_t> total = level->totalCoeffModulus();
+        std::vector<uint64_t> half = total; // upper_half_threshold = (Q + 1) >> 1 (src/context.cpp:383-388)
+        for (size_t w = 0, carry = 1; w < limbs && carry; w++) carry = ++half[w] == 0;
+        for (size_t w = 0; w < limbs; w++) half[w] = (half[w] >> 1) | (w + 1 < limbs ? half[w + 1] << 63 : 0);
+        // mixed-radix constants: inv[i][j] = (q_j)^-1 mod q_i for j < i
+        std::vector<std::vector<uint64_t>> inv(limbs);
+        for (size_t i = 0; i < limbs; i++)
+            for (size_t j = 0; j < i; j++) inv[i].push_back(inv_mod(primes[j] % primes[i], primes[i]));
+
+        destination.assign(n, 0.0);
+        const double inv_scale = 1.0 / plain.scale(), two_pow_64 = std::pow(2.0, 64);
+        std::vector<uint64_t> digit(limbs), word(limbs);
+        for (size_t k = 0; k < n; k++) {
+            // Garner: x = d0 + q0 (d1 + q1 (d2 + ...)), digits d_i in [0, q_i)
+            for (size_t i = 0; i < limbs; i++) {
+                const uint64_t p = primes[i];
+                uint64_t v = rns[i * n + k];
+                for (size_t j = 0; j < i; j++) {
+                    const uint64_t dj = digit[j] % p;
+                    v = (uint64_t)((unsigned __int128)(v >= dj ? v - dj : v + p - dj) * inv[i][j] % p);
+                }
+                digit[i] = v;
+            }
+            std::fill(word.begin(), word.end(), 0); // the composed integer in base 2^64 (what composeArray leaves, rns_cuda.cu)
+            for (size_t i = limbs; i-- > 0;) {
+                unsigned __int128 carry = digit[i];
+                for (auto &w : word) { unsigned __int128 t = (unsigned __int128)w * primes[i] + carry; w = (uint64_t)t; carry = t >> 64; }
+            }
+            int cmp = 0;
+            for (size_t w = limbs; w-- > 0 && !cmp;) cmp = word[w] < half[w] ? -1 : word[w] > half[w] ? 1 : 0;
+            double acc = 0, unit = inv_scale;
+            for (size_t w = 0; w < limbs; w++, unit *= two_pow_64) {
+                if (cmp < 0) {
+                    acc += word[w] ? (double)word[w] * unit : 0.0;
+                } else if (word[w] > total[w]) {
+                    acc += (double)(word[w] - total[w]) * unit;
+                } else {
+                    const uint64_t diff = total[w] - word[w];
+                    acc -= diff ? (double)diff * unit : 0.0;
+                }
+            }
+            destination[k] = acc;
+        }
+    }
+private:
+    static uint64_t pow2_mod(unsigned e, uint64_t p) {
+        unsigned __int128 r = 1, b = 2 % p;
+        for (; e; e >>= 1, b = b * b % p)
+            if (e & 1) r = r * b % p;
+        return (uint64_t)r;
+    }
+    static uint64_t inv_mod(uint64_t a, uint64_t p) { // p prime
+        unsigned __int128 r = 1, b = a % p;
+        for (uint64_t e = p - 2; e; e >>= 1, b = b * b % p)
+            if (e & 1) r = r * b % p;
+        return (uint64_t)r;
+    }
+    const SEALContext &c_;
+    size_t slots_;
+};
+
 class Evaluator { // src/evaluator_cuda.cuh:13-361 -- every method const, non-copyable
 public:
     explicit Evaluator(const SEALContext &c) : c_(c) {}
+    const SEALContext &context() const { return c_; }
     Evaluator(const Evaluator &) = delete;
     Evaluator &operator=(const Evaluator &) = delete;
 
@@ -409,14 +776,16 @@ public:
     }
     void modSwitchToNextInplace(Ciphertext &a) const { next(a, troyhip_mod_switch_to_next); }
     void modSwitchToNext(const Ciphertext &a, Ciphertext &d) const { d = a; modSwitchToNextInplace(d); }
-    void modSwitchToInplace(Ciphertext &a, ParmsID parms_id) const {
-        if (parms_id > a.parmsID()) throw std::invalid_argument("cannot switch to higher level modulus");
+    void modSwitchToInplace(Ciphertext &a, const ParmsID &parms_id) const {
+        if (!c_.getContextData(parms_id)) throw std::invalid_argument("parms_id is not valid for encryption parameters");
+        if (parms_id.limbs > a.parmsID().limbs) throw std::invalid_argument("cannot switch to higher level modulus");
         while (a.parmsID() != parms_id) modSwitchToNextInplace(a);
     }
     void rescaleToNextInplace(Ciphertext &a) const { next(a, troyhip_rescale_to_next); }
     void rescaleToNext(const Ciphertext &a, Ciphertext &d) const { d = a; rescaleToNextInplace(d); }
-    void rescaleToInplace(Ciphertext &a, ParmsID parms_id) const {
-        if (parms_id > a.parmsID()) throw std::invalid_argument("cannot switch to higher level modulus");
+    void rescaleToInplace(Ciphertext &a, const ParmsID &parms_id) const {
+        if (!c_.getContextData(parms_id)) throw std::invalid_argument("parms_id is not valid for encryption parameters");
+        if (parms_id.limbs > a.parmsID().limbs) throw std::invalid_argument("cannot switch to higher level modulus");
         while (a.parmsID() != parms_id) rescaleToNextInplace(a);
     }
     void applyGaloisInplace(Ciphertext &a, uint32_t galois_elt, const GaloisKeys &gk) const {
@@ -432,37 +801,149 @@ public:
     // multiplyPlainInplace (evaluator_cuda.cu:1722-1755): NTT-form pair -> multiplyPlainNtt, coefficient-form pair -> multiplyPlainNormal
     void multiplyPlainInplace(Ciphertext &a, const Plaintext &plain) const {
         if (a.isNttForm() != plain.isNttForm() && c_.parms().scheme() != SchemeType::ckks) throw std::invalid_argument("NTT form mismatch");
-        DeviceArray p(plain.coeffCount());
-        check(troyhip_copy_h2d(p.get(), plain.data(), plain.coeffCount() * 8, nullptr));
-        if (a.isNttForm()) check(troyhip_multiply_plain_ntt(h(), a.raw(), p.get(), plain.scale(), 1, nullptr));
-        else check(troyhip_multiply_plain(h(), a.raw(), p.get(), plain.coeffCount(), 0, 1, nullptr));
-        check(troyhip_stream_synchronize(nullptr));
+        if (a.isNttForm() && plain.isNttForm() && a.parmsID() != plain.parmsID()) throw std::invalid_argument("encrypted_ntt and plain_ntt parameter mismatch");
+        if (a.isNttForm()) check(troyhip_multiply_plain_ntt(h(), a.raw(), plain.device(), plain.scale(), 1, nullptr));
+        else check(troyhip_multiply_plain(h(), a.raw(), plain.device(), plain.coeffCount(), 0, 1, nullptr));
     }
     void multiplyPlain(const Ciphertext &a, const Plaintext &plain, Ciphertext &d) const { d = a; multiplyPlainInplace(d, plain); }
+    // ---- batched forms over slab members (Ciphertext::allocateBatch / packBatch): ONE library launch for the whole run of
+    // ciphertexts, the same plaintext against each (no counterpart in the reference, which loops; used by troyn_app.hpp)
+    std::vector<Ciphertext> multiplyPlainBatch(const std::vector<const Ciphertext *> &column, const Plaintext &plain) const {
+        if (!Ciphertext::isBatch(column)) throw std::invalid_argument("multiplyPlainBatch: the ciphertexts are not a dense run of one slab");
+        const Ciphertext &head = *column[0];
+        if (head.isNttForm() != plain.isNttForm() && c_.parms().scheme() != SchemeType::ckks) throw std::invalid_argument("NTT form mismatch");
+        if (head.isNttForm() && plain.isNttForm() && head.parmsID() != plain.parmsID()) throw std::invalid_argument("encrypted_ntt and plain_ntt parameter mismatch");
+        const size_t count = column.size();
+        std::vector<Ciphertext> out = Ciphertext::allocateBatch(count, head);
+        check(troyhip_copy_d2d(out[0].raw()->data, head.raw()->data, count * head.raw()->batch_stride * 8, nullptr));
+        troyhip_ct t = *out[0].raw();
+        if (head.isNttForm()) check(troyhip_multiply_plain_ntt(h(), &t, plain.device(), plain.scale(), count, nullptr));
+        else check(troyhip_multiply_plain(h(), &t, plain.device(), plain.coeffCount(), 0, count, nullptr));
+        for (auto &c : out) c.copyMeta(t);
+        return out;
+    }
+    void addInplaceBatch(std::vector<Ciphertext> &acc, const std::vector<Ciphertext> &x) const {
+        if (acc.size() != x.size()) throw std::invalid_argument("Size incorrect.");
+        std::vector<const Ciphertext *> pa, px;
+        for (auto &c : acc) pa.push_back(&c);
+        for (auto &c : x) px.push_back(&c);
+        if (!Ciphertext::isBatch(pa) || !Ciphertext::isBatch(px)) {
+            for (size_t b = 0; b < acc.size(); b++) addInplace(acc[b], x[b]);
+            return;
+        }
+        troyhip_ct t = *acc[0].raw();
+        check(troyhip_add(h(), &t, x[0].raw(), acc.size(), nullptr));
+        for (auto &c : acc) c.copyMeta(t);
+    }
     // addPlainInplace / subPlainInplace (evaluator_cuda.cu:1654-1720)
     void addPlainInplace(Ciphertext &a, const Plaintext &plain) const { plain_addsub(a, plain, 0); }
     void subPlainInplace(Ciphertext &a, const Plaintext &plain) const { plain_addsub(a, plain, 1); }
     void addPlain(const Ciphertext &a, const Plaintext &plain, Ciphertext &d) const { d = a; addPlainInplace(d, plain); }
     void subPlain(const Ciphertext &a, const Plaintext &plain, Ciphertext &d) const { d = a; subPlainInplace(d, plain); }
     // transformToNttInplace(Plaintext&, parms_id) (evaluator_cuda.cu:1866-1948)
-    void transformToNttInplace(Plaintext &plain, ParmsID parms_id) const {
+    void transformToNttInplace(Plaintext &plain, const ParmsID &parms_id) const {
         if (plain.isNttForm()) throw std::invalid_argument("plain is already in NTT form");
-        const size_t n = c_.polyModulusDegree();
-        DeviceArray p(plain.coeffCount()), out((size_t)parms_id * n);
+        if (!c_.getContextData(parms_id)) throw std::invalid_argument("parms_id is not valid for the current context");
+        const size_t n = c_.polyModulusDegree(), limbs = (size_t)parms_id.limbs;
+        DeviceArray p(plain.coeffCount()), out(limbs * n);
         check(troyhip_copy_h2d(p.get(), plain.data(), plain.coeffCount() * 8, nullptr));
-        check(troyhip_plain_to_ntt(h(), p.get(), plain.coeffCount(), 0, parms_id, out.get(), 1, nullptr));
-        plain.resize((size_t)parms_id * n);
-        check(troyhip_copy_d2h(plain.data(), out.get(), (size_t)parms_id * n * 8, nullptr));
+        check(troyhip_plain_to_ntt(h(), p.get(), plain.coeffCount(), 0, (int)limbs, out.get(), 1, nullptr));
+        plain.resize(limbs * n);
+        check(troyhip_copy_d2h(plain.data(), out.get(), limbs * n * 8, nullptr));
         plain.setNttForm(parms_id);
+    }
+
+    void negacyclicShift(const Ciphertext &a, size_t shift, Ciphertext &d) const { d = a; negacyclicShiftInplace(d, shift); }
+    // divideByPolyModulusDegreeInplace (src/evaluator_cuda.cu:2262-2276): every limb times N^-1 (times `mul`)
+    void divideByPolyModulusDegreeInplace(Ciphertext &a, uint64_t mul = 1) const { check(troyhip_divide_by_poly_modulus_degree(h(), a.raw(), mul, 1, nullptr)); }
+    // extractLWE / assembleLWE / fieldTraceInplace / packLWECiphertexts (src/evaluator_cuda.cu:2178-2340), composed exactly as there
+    LWECiphertext extractLWE(const Ciphertext &encrypted, size_t term) const {
+        if (encrypted.size() != 2) throw std::invalid_argument("Encrypted size must be 2 to be extracted.");
+        if (encrypted.isNttForm()) { Ciphertext t = encrypted; transformFromNttInplace(t); return extractLWE(t, term); }
+        const size_t N = c_.polyModulusDegree(), L = encrypted.coeffModulusSize();
+        Ciphertext c1;
+        c1.resize(N, L, 1);
+        c1.bind(c_);
+        check(troyhip_copy_d2d(c1.raw()->data, encrypted.raw()->data + L * N, L * N * 8, nullptr));
+        troyhip_ct *r = c1.raw();
+        r->is_ntt_form = 0; r->scale = encrypted.scale(); r->correction_factor = encrypted.correctionFactor();
+        negacyclicShiftInplace(c1, term == 0 ? 0 : 2 * N - term);
+        LWECiphertext out;
+        out.parms_id_ = encrypted.parmsID(); out.n_ = N; out.limbs_ = L; out.scale_ = encrypted.scale(); out.cf_ = encrypted.correctionFactor();
+        out.c1_.resize(L * N);
+        check(troyhip_copy_d2d(out.c1_.get(), c1.raw()->data, L * N * 8, nullptr));
+        const std::vector<uint64_t> host = encrypted.toHost();
+        out.c0_.resize(L);
+        for (size_t l = 0; l < L; l++) out.c0_[l] = host[l * N + term];
+        return out;
+    }
+    Ciphertext assembleLWE(const LWECiphertext &lwe, size_t term) const {
+        const size_t N = lwe.n_, L = lwe.limbs_;
+        Ciphertext c1;
+        c1.resize(N, L, 1);
+        c1.bind(c_);
+        check(troyhip_copy_d2d(c1.raw()->data, lwe.c1_.get(), L * N * 8, nullptr));
+        troyhip_ct *r = c1.raw();
+        r->is_ntt_form = 0; r->scale = lwe.scale_; r->correction_factor = lwe.cf_;
+        negacyclicShiftInplace(c1, term);
+        std::vector<uint64_t> host(2 * L * N, 0), sh = c1.toHost();
+        std::copy(sh.begin(), sh.end(), host.begin() + (long)(L * N));
+        for (size_t l = 0; l < L; l++) host[l * N + term] = lwe.c0_[l];
+        Ciphertext out;
+        out.fromHost(host, N, L, 2, false, lwe.scale_, lwe.cf_);
+        out.bind(c_);
+        return out;
+    }
+    void fieldTraceInplace(Ciphertext &encrypted, const GaloisKeys &automorphism_keys, size_t logn) const {
+        size_t poly_degree = c_.polyModulusDegree();
+        while (poly_degree > (size_t(1) << logn)) {
+            Ciphertext temp = encrypted;
+            applyGaloisInplace(temp, (uint32_t)(poly_degree + 1), automorphism_keys);
+            addInplace(encrypted, temp);
+            poly_degree >>= 1;
+        }
+    }
+    Ciphertext packLWECiphertexts(const std::vector<LWECiphertext> &lwes, const GaloisKeys &automorphism_keys) const {
+        if (lwes.empty()) throw std::invalid_argument("LWE ciphertexts must not be empty.");
+        for (const LWECiphertext &w : lwes)
+            if (w.parmsID() != lwes[0].parmsID()) throw std::invalid_argument("LWE ciphertexts must have same parmsID.");
+        const size_t N = c_.polyModulusDegree();
+        const bool ckks = c_.parms().scheme() == SchemeType::ckks;
+        size_t l = 0;
+        while ((size_t(1) << l) < lwes.size()) l++;
+        Ciphertext zero = assembleLWE(lwes[0], 0);
+        check(troyhip_memset_zero(zero.raw()->data, 2 * zero.coeffModulusSize() * N * 8, nullptr));
+        std::vector<Ciphertext> rl(size_t(1) << l);
+        for (size_t i = 0; i < rl.size(); i++) {
+            size_t index = 0;
+            for (size_t b = 0; b < l; b++) index |= ((i >> b) & 1) << (l - 1 - b);
+            if (index < lwes.size()) { rl[i] = assembleLWE(lwes[index], 0); divideByPolyModulusDegreeInplace(rl[i]); }
+            else rl[i] = zero;
+        }
+        for (size_t layer = 0; layer < l; layer++) {
+            const size_t gap = size_t(1) << layer, shift = N >> (layer + 1);
+            for (size_t offset = 0; offset < rl.size(); offset += 2 * gap) {
+                Ciphertext &even = rl[offset], &odd = rl[offset + gap];
+                Ciphertext temp;
+                negacyclicShift(odd, shift, temp);
+                sub(even, temp, odd);
+                addInplace(even, temp);
+                if (ckks) transformToNttInplace(odd);
+                applyGaloisInplace(odd, (uint32_t)((size_t(1) << (layer + 1)) + 1), automorphism_keys);
+                if (ckks) transformFromNttInplace(odd);
+                addInplace(even, odd);
+            }
+        }
+        Ciphertext ret = std::move(rl[0]);
+        fieldTraceInplace(ret, automorphism_keys, l);
+        if (ckks) transformToNttInplace(ret);
+        return ret;
     }
 
 private:
     troyhip_context *h() const { return c_.handle(); }
     void plain_addsub(Ciphertext &a, const Plaintext &plain, int sub) const {
-        DeviceArray p(plain.coeffCount());
-        check(troyhip_copy_h2d(p.get(), plain.data(), plain.coeffCount() * 8, nullptr));
-        check(troyhip_add_plain(h(), a.raw(), p.get(), plain.coeffCount(), 0, plain.scale(), sub, 1, nullptr));
-        check(troyhip_stream_synchronize(nullptr));
+        check(troyhip_add_plain(h(), a.raw(), plain.device(), plain.coeffCount(), 0, plain.scale(), sub, 1, nullptr));
     }
     void need(SchemeType s, bool equal) const {
         if ((c_.parms().scheme() == s) != equal) throw std::logic_error("unsupported scheme");
@@ -474,6 +955,7 @@ private:
             check(troyhip_copy_d2d(b.raw()->data, a.raw()->data, a.size() * a.coeffModulusSize() * a.polyModulusDegree() * 8, nullptr));
             troyhip_ct *rb = b.raw();
             rb->size = a.raw()->size; rb->is_ntt_form = a.raw()->is_ntt_form; rb->scale = a.raw()->scale; rb->correction_factor = a.raw()->correction_factor;
+            b.bind(a);
             a = std::move(b);
         }
     }
@@ -481,6 +963,7 @@ private:
         Ciphertext out;
         out.resize(a.polyModulusDegree(), a.coeffModulusSize() > 1 ? a.coeffModulusSize() - 1 : 1, a.size());
         check(fn(h(), a.raw(), out.raw(), 1, nullptr));
+        out.bind(a);
         a = std::move(out);
     }
     void rotate(Ciphertext &a, int steps, int conj, const GaloisKeys &gk) const {
@@ -502,9 +985,7 @@ template <class T> inline T get(std::istream &s) {
     return v;
 }
 struct Header { bool ntt; size_t size, n, limbs; double scale; uint64_t cf, seed; bool terms; };
-inline void put_header(std::ostream &s, const SEALContext &c, const Ciphertext &ct, bool terms) {
-    uint64_t id[4];
-    check(troyhip_context_parms_id(c.handle(), (int)ct.coeffModulusSize(), id));
+inline void put_header(std::ostream &s, const uint64_t *id, const Ciphertext &ct, bool terms) {
     s.write(reinterpret_cast<const char *>(id), 32);
     put<bool>(s, ct.isNttForm()); put<size_t>(s, ct.size()); put<size_t>(s, ct.polyModulusDegree()); put<size_t>(s, ct.coeffModulusSize());
     put<double>(s, ct.scale()); put<uint64_t>(s, ct.correctionFactor()); put<uint64_t>(s, 0); put<bool>(s, terms);
@@ -520,6 +1001,11 @@ inline Header get_header(std::istream &s, const SEALContext &c) {
     if (!std::equal(id, id + 4, mine)) throw std::invalid_argument("encrypted is not valid for encryption parameters");
     if (h.seed) throw std::invalid_argument("seed is not zero.");
     return h;
+}
+inline void put_header(std::ostream &s, const SEALContext &c, const Ciphertext &ct, bool terms) {
+    uint64_t id[4];
+    check(troyhip_context_parms_id(c.handle(), (int)ct.coeffModulusSize(), id));
+    put_header(s, id, ct, terms);
 }
 } // namespace wire
 
@@ -538,6 +1024,7 @@ inline void Ciphertext::load(std::istream &stream, const SEALContext &context) {
     stream.read(reinterpret_cast<char *>(host.data()), (std::streamsize)(words * 8));
     if (!stream) throw std::invalid_argument("stream ended inside a ciphertext");
     fromHost(host, h.n, h.limbs, h.size, h.ntt, h.scale, h.cf);
+    bind(context);
 }
 inline void Ciphertext::saveTerms(std::ostream &stream, const SEALContext &context, const Evaluator &evaluator, const std::vector<size_t> &termIds) const {
     std::vector<uint64_t> h;
@@ -569,7 +1056,34 @@ inline void Ciphertext::loadTerms(std::istream &stream, const SEALContext &conte
     stream.read(reinterpret_cast<char *>(host.data() + offset), (std::streamsize)(words * 8));
     if (!stream) throw std::invalid_argument("stream ended inside a ciphertext");
     fromHost(host, h.n, h.limbs, h.size, false, h.scale, h.cf);
+    bind(context);
     if (h.ntt) evaluator.transformToNttInplace(*this);
 }
+inline void Ciphertext::save(std::ostream &stream) const {
+    if (parmsID() == parmsIDZero) throw std::logic_error("the ciphertext has not met a context"); // nothing to put in the parms_id field
+    wire::put_header(stream, parmsID().data(), *this, false);
+    const std::vector<uint64_t> h = toHost();
+    wire::put<size_t>(stream, h.size());
+    stream.write(reinterpret_cast<const char *>(h.data()), (std::streamsize)(h.size() * 8));
+}
+inline void Ciphertext::load(std::istream &stream) { // src/ciphertext_cuda.cu:65-88: no validation without a context
+    uint64_t id[4];
+    stream.read(reinterpret_cast<char *>(id), 32);
+    const bool ntt = wire::get<bool>(stream);
+    const size_t size = wire::get<size_t>(stream), n = wire::get<size_t>(stream), limbs = wire::get<size_t>(stream);
+    const double scale = wire::get<double>(stream);
+    const uint64_t cf = wire::get<uint64_t>(stream), seed = wire::get<uint64_t>(stream);
+    const bool terms = wire::get<bool>(stream);
+    if (seed) throw std::invalid_argument("seed is not zero.");
+    if (terms) throw std::invalid_argument("Trying to load a termed ciphertext, but indices is not specified");
+    const size_t words = wire::get<size_t>(stream);
+    if (words != size * limbs * n) throw std::invalid_argument("encrypted is not valid for encryption parameters");
+    std::vector<uint64_t> host(words);
+    stream.read(reinterpret_cast<char *>(host.data()), (std::streamsize)(words * 8));
+    if (!stream) throw std::invalid_argument("stream ended inside a ciphertext");
+    fromHost(host, n, limbs, size, ntt, scale, cf);
+}
+inline void Ciphertext::saveTerms(std::ostream &stream, const Evaluator &evaluator, const std::vector<size_t> &termIds) const { saveTerms(stream, evaluator.context(), evaluator, termIds); }
+inline void Ciphertext::loadTerms(std::istream &stream, const Evaluator &evaluator, const std::vector<size_t> &termIds) { loadTerms(stream, evaluator.context(), evaluator, termIds); }
 
 } // namespace troyn

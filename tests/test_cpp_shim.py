@@ -8,10 +8,11 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "tests", "cpp", "test_troyn.cpp")
+APP = os.path.join(ROOT, "tests", "cpp", "test_troyn_app.cpp")  # include/troyn_app.hpp: the flows of the reference's test/app/linear_ckks.cu
 
 
-def _build(out, libdir, libfile):
-    cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), SRC, "-o", out,
+def _build(out, libdir, libfile, src=SRC):
+    cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), src, "-o", out,
            os.path.join(libdir, libfile), "-Wl,-rpath," + libdir, "-Wl,-rpath-link,/opt/rocm/lib"]
     subprocess.run(cmd, check=True, capture_output=True, text=True)
 
@@ -33,4 +34,18 @@ def test_troyn_header_on_emulator(tmp_path):
 def test_troyn_header_on_gpu(tmp_path):
     exe = str(tmp_path / "test_troyn")
     _build(exe, os.path.join(ROOT, "troy_amd"), "libtroyhip.so")
+    _run(exe)
+
+
+def test_troyn_app_on_emulator(tmp_path):
+    subprocess.check_call(["make", "-s", "-j8", "-C", os.path.join(ROOT, "troy_amd", "csrc"), "emul"])
+    exe = str(tmp_path / "test_troyn_app_emul")
+    _build(exe, os.path.join(ROOT, "tests", "emul"), "libtroyhip_emul.so", APP)
+    _run(exe)
+
+
+@pytest.mark.gpu
+def test_troyn_app_on_gpu(tmp_path):
+    exe = str(tmp_path / "test_troyn_app")
+    _build(exe, os.path.join(ROOT, "troy_amd"), "libtroyhip.so", APP)
     _run(exe)

@@ -156,3 +156,54 @@ def test_default_seeds_come_from_os_entropy(ta):
     from troy_amd import capi
     capi.check(ctx.lib, ctx.lib.troyhip_random_bytes(buf, 32))
     assert any(buf)
+
+
+@pytest.mark.parametrize("scheme,bits,tbits", [(1, [40, 40, 40, 40], 10), (3, [40, 36, 36, 40], 10)])
+def test_encrypt_symmetric_roundtrip(scheme, bits, tbits, ta):
+    """Encryptor::encryptSymmetric (src/encryptor.cpp:88-148 with is_asymmetric false, src/utils/rlwe.cpp:234-345): (-(a s + e) + m, a)
+    at the first level, coefficient form for BFV/BGV; decrypts with our Decryptor, the oracle and the reference's own Decryptor"""
+    from troy_amd import capi
+    N = 128
+    primes = ta.CoeffModulus.Create(N, bits)
+    t = ta.PlainModulus.Batching(N, tbits)
+    ctx = ta.SEALContext(scheme, N, primes, t, host_only=True)
+    kg = ta.KeyGenerator(ctx, seed=(11, 12))
+    sk = kg.secretKey()
+    enc, dec = ta.Encryptor(ctx, None), ta.Decryptor(ctx, sk)
+    with pytest.raises(RuntimeError):
+        enc.encryptSymmetric(np.zeros(N, dtype=np.uint64))          # secret key is not set
+    with pytest.raises(RuntimeError):
+        enc.encrypt(np.zeros(N, dtype=np.uint64))                   # public key is not set
+    enc.setSecretKey(sk)
+    m = np.random.default_rng(8).integers(0, t, N, dtype=np.uint64)
+    c1, c2 = enc.encryptSymmetric(m), enc.encryptSymmetric(m)
+    assert c1.shape == (2, ctx.first_limbs, N) and not np.array_equal(c1, c2)
+    assert np.array_equal(dec.decrypt(c1), m) and np.array_equal(dec.decrypt(c2), m)
+    O = oracle.Oracle(scheme, N, primes, t)
+    assert np.array_equal(O.decrypt(ref.Ct(c1), sk), m)
+    if ref.available():
+        R = ref.Ref(scheme, N, primes, t)
+        R.set_secret_key(sk)
+        assert np.array_equal(R.decrypt(ref.Ct(c1))[0], m)
+    with pytest.raises(capi.InvalidArgument):
+        enc.encryptSymmetric(np.zeros(N + 1, dtype=np.uint64))
+
+
+def test_encrypt_symmetric_ckks_every_level(ta):
+    N, bits = 128, [40, 30, 30, 40]
+    primes = ta.CoeffModulus.Create(N, bits)
+    ctx = ta.SEALContext(ta.CKKS, N, primes, 0, host_only=True)
+    kg = ta.KeyGenerator(ctx, seed=(7, 8))
+    enc, dec = ta.Encryptor(ctx, None), ta.Decryptor(ctx, kg.secretKey())
+    enc.setSecretKey(kg.secretKey())
+    coeffs = np.random.default_rng(6).integers(-(1 << 25), 1 << 25, N)
+    for limbs in (3, 2, 1):                                         # the ciphertext is sampled at the plaintext's own level
+        plain = np.stack([oracle.ntt_standalone(N, p, np.array([int(c) % p for c in coeffs], dtype=np.uint64), 1) for p in primes[:limbs]])
+        ct = enc.encryptSymmetric(plain)
+        assert ct.shape == (2, limbs, N)
+        back = dec.decrypt(ct)
+        for l in range(limbs):
+            p = primes[l]
+            got = oracle.ntt_standalone(N, p, back[l], 3).astype(object)
+            centred = np.array([int(v) - p if int(v) > p // 2 else int(v) for v in got])
+            assert np.max(np.abs(centred - coeffs)) < 64           # one fresh error term (|e| <= 21 for the centred binomial)

@@ -808,12 +808,14 @@ class Encryptor:
         """seed=None: every encrypt() draws a fresh 128-bit seed for (u, e0, e1) from os.urandom; an explicit (lo, hi) pair
         gives the deterministic stream (seed, call counter) for tests ONLY."""
         self.context, self.lib = context, context.lib
-        self.pk = np.ascontiguousarray(public_key, dtype=np.uint64)
+        self.pk = None if public_key is None else np.ascontiguousarray(public_key, dtype=np.uint64)
+        self.sk = None
         self.seed, self.counter = (None if seed is None else (int(seed[0]), int(seed[1]))), 0
 
-    def encrypt(self, plain, limbs=None):
-        """BFV/BGV: plain = coefficients mod t (<= N of them) -> uint64 [2][first_limbs][N];
-        CKKS: plain = [limbs][N] NTT-form RNS polynomial -> [2][limbs][N]"""
+    def setSecretKey(self, secret_key):  # src/encryptor_cuda.cuh:98
+        self.sk = np.ascontiguousarray(secret_key, dtype=np.uint64)
+
+    def _run(self, fn, key, plain):
         ctx = self.context
         plain = np.ascontiguousarray(plain, dtype=np.uint64)
         if ctx.scheme == CKKS:
@@ -825,9 +827,21 @@ class Encryptor:
         out = np.zeros((2, limbs, ctx.N), dtype=np.uint64)
         self.counter += 1
         lo, hi = struct.unpack("<QQ", os.urandom(16)) if self.seed is None else ((self.seed[0] + self.counter) & (2**64 - 1), self.seed[1])
-        capi.check(self.lib, self.lib.troyhip_host_encrypt(ctx.h, C.c_uint64(lo), C.c_uint64(hi), _u64p(self.pk), _u64p(plain),
-                                                           C.c_uint64(n), limbs, _u64p(out)))
+        capi.check(self.lib, fn(ctx.h, C.c_uint64(lo), C.c_uint64(hi), _u64p(key), _u64p(plain), C.c_uint64(n), limbs, _u64p(out)))
         return out
+
+    def encrypt(self, plain, limbs=None):
+        """BFV/BGV: plain = coefficients mod t (<= N of them) -> uint64 [2][first_limbs][N];
+        CKKS: plain = [limbs][N] NTT-form RNS polynomial -> [2][limbs][N]"""
+        if self.pk is None:
+            raise RuntimeError("public key is not set")  # encryptor.cpp:157-160 (std::logic_error)
+        return self._run(self.lib.troyhip_host_encrypt, self.pk, plain)
+
+    def encryptSymmetric(self, plain):
+        """Encryptor::encryptSymmetric (src/encryptor_cuda.cuh:259-290): (-(a s + e) + m, a) at the plaintext's level; same layouts as encrypt"""
+        if getattr(self, "sk", None) is None:
+            raise RuntimeError("secret key is not set")  # encryptor.cpp:164-167
+        return self._run(self.lib.troyhip_host_encrypt_symmetric, self.sk, plain)
 
 
 class Decryptor:

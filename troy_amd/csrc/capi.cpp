@@ -371,6 +371,13 @@ int troyhip_host_encrypt(const troyhip_context *ctx, uint64_t seed_lo, uint64_t 
         hostcrypto::encrypt(ctx->ctx, rng, public_key, plain, n_coeffs, limbs, ct_out);
     }, false);
 }
+int troyhip_host_encrypt_symmetric(const troyhip_context *ctx, uint64_t seed_lo, uint64_t seed_hi, const uint64_t *secret_key, const uint64_t *plain,
+                                   uint64_t n_coeffs, int limbs, uint64_t *ct_out) {
+    return guard([&] {
+        hostcrypto::Rng rng(seed_lo, seed_hi, (u64)4 << 32);
+        hostcrypto::encrypt_symmetric(ctx->ctx, rng, secret_key, plain, n_coeffs, limbs, ct_out);
+    }, false);
+}
 int troyhip_host_decrypt(const troyhip_context *ctx, const uint64_t *secret_key, const uint64_t *ct, int size, int limbs, int is_ntt_form,
                          uint64_t correction_factor, uint64_t *plain_out) {
     return guard([&] { hostcrypto::decrypt(ctx->ctx, secret_key, ct, size, limbs, is_ntt_form != 0, correction_factor, plain_out); }, false);

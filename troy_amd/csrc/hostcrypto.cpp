@@ -205,6 +205,36 @@ static void host_mod_switch(const Context &c, int limbs, u64 *x, bool ntt_form) 
     }
 }
 
+// the message lands in c0: BFV round(q*m/t) (scalingvariant.cpp:53-93), BGV m (scalingvariant.cpp:21-36), CKKS the RNS plaintext
+// (encryptor.cpp:232-236)
+static void add_message(const Context &c, const Polys &P, const u64 *plain, size_t n_coeffs, int limbs, u64 *ct) {
+    const size_t N = c.N;
+    if (c.scheme == SCHEME_BFV) { // scalingvariant.cpp:53-93: c0 += round(q * m / t)
+        std::vector<u64> q(c.primes.begin(), c.primes.begin() + limbs);
+        const u64 t = c.t, q_mod_t = host::product_mod(q, t), thr = (t + 1) >> 1;
+        std::vector<u64> deltas(limbs); // floor(q/t) mod q_l = (q - q mod t) / t mod q_l = (-(q mod t)) * t^-1 mod q_l
+        for (int l = 0; l < limbs; l++) {
+            const Mod m = P.mod(l);
+            deltas[l] = mulmod(negmod(q_mod_t % m.p, m.p), host::inv_mod_checked(t % m.p, m.p), m);
+        }
+        for (size_t i = 0; i < n_coeffs; i++) {
+            const u128 num = (u128)plain[i] * q_mod_t + thr;
+            const u64 fix = (u64)(num / t);
+            for (int l = 0; l < limbs; l++) {
+                const Mod m = P.mod(l);
+                const u64 v = addmod(mulmod(plain[i] % m.p, deltas[l], m), fix % m.p, m.p);
+                ct[l * N + i] = addmod(ct[l * N + i], v, m.p);
+            }
+        }
+    } else if (c.scheme == SCHEME_BGV) { // scalingvariant.cpp:21-36
+        for (int l = 0; l < limbs; l++)
+            for (size_t i = 0; i < n_coeffs; i++) ct[l * N + i] = addmod(ct[l * N + i], plain[i] % c.primes[l], c.primes[l]);
+    } else {
+        for (int l = 0; l < limbs; l++)
+            for (size_t i = 0; i < N; i++) ct[l * N + i] = addmod(ct[l * N + i], plain[l * N + i], c.primes[l]);
+    }
+}
+
 // encryptor.cpp:88-260 (asymmetric).  BFV/BGV: plain = n_coeffs coefficients mod t, output [2][first_limbs][N]
 // coefficient form.  CKKS: plain = [limbs][N] RNS polynomial in NTT form, output [2][limbs][N] NTT form.
 void encrypt(const Context &c, Rng &rng, const u64 *pk, const u64 *plain, size_t n_coeffs, int limbs, u64 *ct) {
@@ -238,31 +268,26 @@ void encrypt(const Context &c, Rng &rng, const u64 *pk, const u64 *plain, size_t
         if (has_prev) host_mod_switch(c, el, src, ntt_out);
         std::memcpy(ct + (size_t)j * limbs * N, src, sizeof(u64) * limbs * N);
     }
-    // add the message
-    if (c.scheme == SCHEME_BFV) { // scalingvariant.cpp:53-93: c0 += round(q * m / t)
-        std::vector<u64> q(c.primes.begin(), c.primes.begin() + limbs);
-        const u64 t = c.t, q_mod_t = host::product_mod(q, t), thr = (t + 1) >> 1;
-        std::vector<u64> deltas(limbs); // floor(q/t) mod q_l = (q - q mod t) / t mod q_l = (-(q mod t)) * t^-1 mod q_l
+    add_message(c, P, plain, n_coeffs, limbs, ct);
+}
+
+// encryptor.cpp:88-148 with is_asymmetric == false + rlwe.cpp:234-345: (c0, c1) = (-(a*s + e) + message, a) sampled directly at
+// the level of the plaintext (no switch from the level above); BFV/BGV leave coefficient form, CKKS stays in NTT form
+void encrypt_symmetric(const Context &c, Rng &rng, const u64 *sk, const u64 *plain, size_t n_coeffs, int limbs, u64 *ct) {
+    Polys P(c);
+    const size_t N = c.N;
+    const bool ntt_out = c.scheme == SCHEME_CKKS;
+    if (!ntt_out) limbs = c.first_limbs;
+    if (!c.is_data_level(limbs)) throw Error(ST_INVALID_ARGUMENT, "plain is not valid for encryption parameters");
+    if (!ntt_out && n_coeffs > N) throw Error(ST_INVALID_ARGUMENT, "plain is not valid for encryption parameters");
+    u64 *c0 = ct, *c1 = ct + (size_t)limbs * N;
+    encrypt_zero_symmetric_ntt(P, rng, sk, limbs, c0, c1, c.scheme == SCHEME_BGV ? c.t : 1);
+    if (!ntt_out)
         for (int l = 0; l < limbs; l++) {
-            const Mod m = P.mod(l);
-            deltas[l] = mulmod(negmod(q_mod_t % m.p, m.p), host::inv_mod_checked(t % m.p, m.p), m);
+            ntt_inverse(c0 + (size_t)l * N, c.tables[l]);
+            ntt_inverse(c1 + (size_t)l * N, c.tables[l]);
         }
-        for (size_t i = 0; i < n_coeffs; i++) {
-            const u128 num = (u128)plain[i] * q_mod_t + thr;
-            const u64 fix = (u64)(num / t);
-            for (int l = 0; l < limbs; l++) {
-                const Mod m = P.mod(l);
-                const u64 v = addmod(mulmod(plain[i] % m.p, deltas[l], m), fix % m.p, m.p);
-                ct[l * N + i] = addmod(ct[l * N + i], v, m.p);
-            }
-        }
-    } else if (c.scheme == SCHEME_BGV) { // scalingvariant.cpp:21-36
-        for (int l = 0; l < limbs; l++)
-            for (size_t i = 0; i < n_coeffs; i++) ct[l * N + i] = addmod(ct[l * N + i], plain[i] % c.primes[l], c.primes[l]);
-    } else {
-        for (int l = 0; l < limbs; l++)
-            for (size_t i = 0; i < N; i++) ct[l * N + i] = addmod(ct[l * N + i], plain[l * N + i], c.primes[l]);
-    }
+    add_message(c, P, plain, n_coeffs, limbs, ct);
 }
 
 // decryptor.cpp:115-371.  ct [size][limbs][N]; BFV/BGV: N plaintext coefficients; CKKS: [limbs][N] RNS plaintext (NTT form)

@@ -25,6 +25,7 @@ void keygen_kswitch(const Context &c, Rng &rng, const u64 *sk, const u64 *new_ke
 void relin_source(const Context &c, const u64 *sk, u64 *out);
 void galois_source(const Context &c, const u64 *sk, uint32_t elt, u64 *out);
 void encrypt(const Context &c, Rng &rng, const u64 *pk, const u64 *plain, size_t n_coeffs, int limbs, u64 *ct);
+void encrypt_symmetric(const Context &c, Rng &rng, const u64 *sk, const u64 *plain, size_t n_coeffs, int limbs, u64 *ct);
 void decrypt(const Context &c, const u64 *sk, const u64 *ct, int size, int limbs, bool is_ntt, u64 correction_factor, u64 *out);
 
 } // namespace hostcrypto
