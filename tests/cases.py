@@ -553,18 +553,22 @@ def check_ckks_conv2d_helper(N=4096, bits=(40, 30, 30, 40), batch=2, image=(12, 
     return h
 
 
-def check_bfv_multiply_limb_count(K, N=256, batch=2, seed=900):
+def check_bfv_multiply_limb_count(K, N=256, batch=2, seed=900, big=False):
     """BFV multiply (both BEHZ kernels) at L = K - 1 limbs against the oracle: L runs over every k-block count of the matrix-core
-    kernels and over the three forms of their epilogue (correction term folded into the product when L mod 4 is 1 or 2, else
-    added afterwards), and past 16 limbs over the VALU kernels"""
+    kernels and, past 15 limbs, over the VALU kernels.  big=False: 40/45-bit primes (the q side of Shenoy-Kumaresan takes the two-word
+    reduction), big=True: 55/60-bit primes (one-step quotient estimate everywhere, the headline's case).  The last batch items are
+    extreme inputs: every residue p - 1, and a 0 / 1 pattern."""
     from troy_amd import api, synth
-    cfg = dict(scheme=BFV, N=N, bits=[45] + [40] * (K - 2) + [45], tbits=14)
+    cfg = dict(scheme=BFV, N=N, bits=([60] + [55] * (K - 2) + [60]) if big else ([45] + [40] * (K - 2) + [45]), tbits=14)
     be, ob = GpuBackend(cfg), oracle_backend(cfg)
     L = K - 1
-    xa, xb = synth.uniform_ct(seed + K, be.primes[:L], 2, N, batch), synth.uniform_ct(seed + 50 + K, be.primes[:L], 2, N, batch)
+    xa, xb = synth.uniform_ct(seed + K, be.primes[:L], 2, N, batch + 2), synth.uniform_ct(seed + 50 + K, be.primes[:L], 2, N, batch + 2)
+    top = np.array(be.primes[:L], dtype=np.uint64)[None, :, None] - np.uint64(1)
+    xa[batch], xb[batch] = top, top
+    xa[batch + 1], xb[batch + 1] = (np.arange(N, dtype=np.uint64) & np.uint64(1))[None, None, :], top
     r = be.ev.multiply(api.Ciphertext.from_numpy(be.ctx, xa, False), api.Ciphertext.from_numpy(be.ctx, xb, False))
     got = r.cpu()
-    for i in range(batch):
+    for i in range(batch + 2):
         e = ob.multiply(ob.ct(xa[i], False), ob.ct(xb[i], False))
         assert np.array_equal(got[i], ob.export(e).data), (K, i)
     return sha(got)

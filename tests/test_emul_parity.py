@@ -93,6 +93,13 @@ def test_emulated_general_sizes(name, emul_api):
     cases.check_general_sizes(name, batch=2)
 
 
+@pytest.mark.parametrize("K,big", [(2, True), (5, False), (6, True), (12, True), (15, False), (16, True), (17, True)])
+def test_emulated_bfv_multiply_limb_counts(K, big, emul_api, oracle_lib):
+    """both BEHZ kernels against the oracle at limb counts that cover the k-block counts of the 8-shift matrix-core form
+    (behz2.hip; L = 1, 4, 5, 11, 14, 15), its two q-side reductions, extreme residues, and the VALU kernels at L = 16"""
+    cases.check_bfv_multiply_limb_count(K, N=128, batch=1, big=big)
+
+
 def test_emulated_size_limits(emul_api):
     cases.check_size_limits("bfv_n64_k3")
     cases.check_size_limits("ckks_n128_k6")

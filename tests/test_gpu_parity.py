@@ -430,24 +430,27 @@ def test_conv2d_helper(gpu):
     assert h.blocked
 
 
+@pytest.mark.parametrize("big", [False, True])
 @pytest.mark.parametrize("K", list(range(2, 19)))
-def test_bfv_multiply_every_limb_count(K, gpu, oracle_lib):
-    """BEHZ kernels at L = 1 .. 17: every k-block count, folded / unfolded correction term, VALU kernels past 16 limbs"""
-    cases.check_bfv_multiply_limb_count(K)
+def test_bfv_multiply_every_limb_count(K, big, gpu, oracle_lib):
+    """BEHZ kernels at L = 1 .. 17: every k-block count of the matrix-core form, both reductions of its q-side outputs (primes below and
+    above 2^50), extreme residues, VALU kernels past 15 limbs"""
+    cases.check_bfv_multiply_limb_count(K, big=big)
 
 
-@pytest.mark.parametrize("env", [{"TROYHIP_BEHZ": "valu"}, {"TROYHIP_BEHZ_FOLD": "0"}])
+@pytest.mark.parametrize("env", [{"TROYHIP_BEHZ": "valu"}, {"TROYHIP_BEHZ": "mfma1"}, {"TROYHIP_BEHZ": "mfma1", "TROYHIP_BEHZ_FOLD": "0"}])
 def test_behz_kernel_forms_agree(env, gpu, oracle_lib):
-    """the VALU kernels and the unfolded matrix-core epilogue are selected by environment switches that are read once per process:
-    a child process runs the same oracle comparison under each switch and must reproduce this process's result hashes"""
+    """the VALU kernels and the first matrix-core form (16-shift rows, folded / unfolded correction term) are selected by environment
+    switches that are read once per process: a child process runs the same oracle comparison under each switch and must reproduce
+    this process's result hashes (default: the 8-shift form of behz2.hip)"""
     import subprocess
     import sys
     Ks = [3, 6, 8, 15]
-    here = [cases.check_bfv_multiply_limb_count(K) for K in Ks]
+    here = [cases.check_bfv_multiply_limb_count(K, big=K % 2 == 0) for K in Ks]
     code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
             "import troy_amd as ta, cases\n"
             "ta.KernelProvider.initialize(0)\n"
-            "print(' '.join(cases.check_bfv_multiply_limb_count(K) for K in %r))\n") % (os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__))), Ks)
+            "print(' '.join(cases.check_bfv_multiply_limb_count(K, big=K %% 2 == 0) for K in %r))\n") % (os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__))), Ks)
     out = subprocess.run([sys.executable, "-c", code], env={**os.environ, **env}, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     assert out.stdout.split()[-len(Ks):] == here

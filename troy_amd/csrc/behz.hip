@@ -635,6 +635,7 @@ static bool behz_use_mfma() {
 }
 void launch_behz_extend(const u64 *in, u64 in_pstride, u64 *out, u64 out_pstride, const PrimeDesc *primes, const BehzDev &c, u64 N, u64 polys, hipStream_t s) {
     if (!polys) return;
+    if (c.v2 && behz_use_mfma()) return launch_behz2_extend(in, in_pstride, out, out_pstride, primes, c, N, polys, s);
     const bool mfma = c.ext_frag && behz_use_mfma();
     const u64 tiles = ceil_div(N, (u64)BEHZ_TILE);
     const unsigned tpw = tiles >= 64 ? BEHZ_TPW : 1; // amortise the A-fragment loads over several tiles when there are enough workgroups
@@ -670,6 +671,7 @@ void launch_behz_extend(const u64 *in, u64 in_pstride, u64 *out, u64 out_pstride
 void launch_behz_floor_sk(const u64 *dq, u64 dq_pstride, const u64 *db, u64 db_pstride, u64 *out, u64 out_pstride, const PrimeDesc *primes, const BehzDev &c, u64 N,
                           u64 polys, hipStream_t s) {
     if (!polys) return;
+    if (c.v2 && behz_use_mfma()) return launch_behz2_floor_sk(dq, dq_pstride, db, db_pstride, out, out_pstride, primes, c, N, polys, s);
     const bool mfma = c.floor_frag1 && behz_use_mfma();
     const u64 tiles = ceil_div(N, (u64)BEHZ_TILE);
     const unsigned tpw = tiles >= 64 ? BEHZ_TPW : 1;

@@ -1,0 +1,421 @@
+// behz2.hip -- BEHZ base conversion on the matrix cores, second form: rows reduced modulo the OUTPUT prime on the host.
+//
+// Same contracts as behz_extend_kernel / behz_floor_sk_kernel (behz.hip; reference: src/utils/rns_cuda.cu:96-145, 365-508,
+// CPU twins src/utils/rns.cpp:415-459, 879-1037) and the same canonical residues.
+//
+// A conversion output is  out_o = (sum_l y_l M[o][l]) mod p_o  with y_l < 2^61 written in eight balanced base-256 digits
+// d_{l,k}.  Instead of multiplying digit strings (16 byte-shifts per output, a 126-bit sum, a 128-bit reduction: behz.hip's
+// first MFMA form), the host reduces every column of the digit expansion:
+//     out_o = ( sum_{l,k} d_{l,k} * W[o][l][k] ) mod p_o,      W[o][l][k] = M[o][l] 2^(8k) mod p_o  (< 2^61, eight digits)
+// so row (o, s) of the int8 matrix is digit s of W -- EIGHT shifts per output.  That halves the v_mfma_i32_32x32x32_i8 count
+// (a 32-row block is 4 outputs, not 2) and bounds the recombined sum by 2^77.4: with a bias (a multiple of p_o) it is a
+// non-negative V < 2^79.1 and ONE 32-bit quotient estimate reduces it:
+//     q^ = mulhi32(V >> 48, floor(2^80 / p)),   r = (V - q^ p) mod 2^64 in [0, 2p),   one conditional subtraction
+// (error of q^ below 2^48/p + 0.51 < 0.76 for p >= 2^50).  Recombine + reduce is ~20 VALU instructions per output instead
+// of ~85; the kernels are VALU-issue bound (profiles/r01_behz_probe.txt), so that is where the time goes.
+// The per-coefficient correction terms are extra INPUT columns of the product: the centred m_tilde residue r against
+// q m_tilde^-1 (extension), the centred alpha against -(B mod q_l) (Shenoy-Kumaresan), at limb position L (nB) of the digit
+// matrix -- patched into the B fragment in registers, whatever L mod 4 is.  B^-1 mod m_sk is folded into the m_sk rows of both
+// stages, so alpha is one modular subtraction.
+#include "kernels.h"
+#include <cstdlib>
+
+namespace troyhip {
+
+#define B2_THREADS 256
+#define B2_TILE 64
+#ifndef B2_TPW
+#define B2_TPW 8 // tiles of 64 coefficients per workgroup
+#endif
+// probe hooks for throw-away builds (tools/behz_probe.sh): bit0 no HBM loads, bit1 no MFMA, bit2 no recombine/reduce, bit4 no stores
+#ifndef B2_EXP
+#define B2_EXP 0
+#endif
+
+#ifdef TROYHIP_CPU_EMUL
+#define B2_UNIFORM(x) (x)
+typedef const u64 *b2_cu64;
+#else
+#define B2_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
+typedef const __attribute__((address_space(4))) u64 *b2_cu64; // wave-uniform addresses: scalar loads
+#endif
+
+__device__ __forceinline__ long long b2_mad(int a, int b, long long c) { // c + sext(a) * b in one instruction
+#ifdef TROYHIP_CPU_EMUL
+    return (long long)a * b + c;
+#else
+    long long d;
+    u64 sink;
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(sink) : "v"(a), "s"(b), "v"(c));
+    return d;
+#endif
+}
+__device__ __forceinline__ MfmaFrag b2_frag(const void *base, size_t idx) { return reinterpret_cast<const MfmaFrag *>(base)[idx]; }
+__device__ __forceinline__ void b2_zero(MfmaAcc &a) {
+#pragma unroll
+    for (int r = 0; r < 16; r++) a.v[r] = 0;
+}
+#define B2_MFMA(fa, fb, fc)                                                                                               \
+    do {                                                                                                                 \
+        if (B2_EXP & 2) (fc).v[0] += (fb).bytes[0] + (fa).bytes[0];                                                      \
+        else TROY_MFMA_I8(fa, fb, fc);                                                                                   \
+    } while (0)
+#define B2_LOAD(expr, fake) ((B2_EXP & 1) ? (u64)(fake) : (expr))
+
+// V = lo + top 2^64 (top < 2^16): the biased sum of one output
+struct B2Sum { u64 lo; u32 top; };
+// sum_s C_s 2^(8s) over accumulator registers BASE .. BASE + 7 (|C_s| < 2^21.4), plus `addend` (>= 2^46, < 2^63) into the low
+// half and 2^46 into the high half: both halves stay positive, so the words combine without sign handling
+template <int BASE> __device__ __forceinline__ B2Sum b2_recombine(const MfmaAcc &a, u64 addend) {
+    const int p01 = a.v[BASE] + (a.v[BASE + 1] << 8), p23 = a.v[BASE + 2] + (a.v[BASE + 3] << 8);
+    const int p45 = a.v[BASE + 4] + (a.v[BASE + 5] << 8), p67 = a.v[BASE + 6] + (a.v[BASE + 7] << 8);
+    const u64 w0 = (u64)b2_mad(p01, 1, b2_mad(p23, 1 << 16, (long long)addend));
+    const u64 w1 = (u64)b2_mad(p45, 1, b2_mad(p67, 1 << 16, (long long)(u64(1) << 46)));
+    const u32 w0h = (u32)(w0 >> 32), v1 = w0h + (u32)w1;
+    const u32 v2 = (u32)(w1 >> 32) + (v1 < w0h);
+    return B2Sum{(u64)(u32)w0 | ((u64)v1 << 32), v2};
+}
+__device__ __forceinline__ u64 b2_reduce(const B2Sum v, const BehzK2 &k) {
+    const u32 vt = (v.top << 16) | (u32)(v.lo >> 48);
+    const u32 qh = (u32)(((u64)vt * k.mu) >> 32);
+    const u64 r = v.lo + (u64)qh * k.negp; // V - qh p modulo 2^64: the true value is in [0, 2p)
+    return r >= k.p ? r - k.p : r;
+}
+// any output prime (the q side may hold primes below 2^50): the same sum through the two-word reduction of behz.hip
+struct B2Slow { u64 p, cr1, two_p, r64_op, r64_quo; };
+__device__ __forceinline__ u64 b2_reduce_slow(const B2Sum v, const B2Slow &k) {
+    const u64 a = mul_lazy((u64)v.top, k.r64_op, k.r64_quo, k.p);
+    const u64 b = v.lo - mulhi64(v.lo, k.cr1) * k.p;
+    u64 s = a + b;
+    s = s >= k.two_p ? s - k.two_p : s;
+    return s >= k.p ? s - k.p : s;
+}
+template <int BASE> __device__ __forceinline__ u64 b2_finish(const MfmaAcc &acc, u64 addend, const BehzK2 &k) {
+    if (B2_EXP & 4) return (u64)(u32)acc.v[BASE] ^ addend ^ ((u64)(u32)acc.v[BASE + 7] << 32);
+    return b2_reduce(b2_recombine<BASE>(acc, addend), k);
+}
+
+// words of a fragment: limb (4 kb + 2 half + pos) of this lane's coefficient
+__device__ __forceinline__ u64 b2_digits(u64 v) {
+    const u64 c80 = 0x8080808080808080ull;
+    return (v + c80) ^ c80;
+}
+// the extra input (limb index `xl`, one past the real limbs) sits in the last k-block, in the lanes of half (xl % 4) / 2, word xl % 2
+struct B2Patch { bool w0, w1; };
+__device__ __forceinline__ B2Patch b2_patch_where(int xl, unsigned half) {
+    const bool mine = half == (unsigned)((xl & 3) >> 1);
+    return B2Patch{mine && !(xl & 1), mine && (xl & 1)};
+}
+__device__ __forceinline__ void b2_patch(MfmaFrag &f, const B2Patch w, u64 digits) {
+    MfmaFrag g = f;
+    frag_set_word(g, 0, digits);
+    if (w.w0) f = g;
+    g = f;
+    frag_set_word(g, 1, digits);
+    if (w.w1) f = g;
+}
+
+// ---------------------------------------------------------------- extension q -> Bsk (fastbconvmTilde + smMrq)
+// in [polys][L][N] -> out [polys][nBsk][N].  A 256-thread workgroup walks `tiles_per_wg` tiles of 64 coefficients of one polynomial;
+// wave w converts limbs w, w+4, .. to digits (LDS, double-buffered: one barrier per tile), evaluates the m_tilde row for its own
+// lanes and owns row-block w = outputs 4w .. 4w+3: a lane finishes outputs 4w + half (accumulators 0-7) and 4w + 2 + half (8-15).
+template <int KB> __global__ __launch_bounds__(B2_THREADS) void behz2_extend_kernel(const u64 *in, u64 in_pstride, u64 *out, u64 out_pstride, const PrimeDesc *primes, BehzDev c,
+                                                                                   u64 N, unsigned tiles_per_wg) {
+    __shared__ __attribute__((aligned(16))) u64 ydig[2][2 * KB * B2_TILE * 2]; // [buffer][limb pair][coefficient] 16-byte units
+    const unsigned lane = threadIdx.x & 63, half = lane >> 5, cl = lane & 31;
+    const int w = B2_UNIFORM((int)(threadIdx.x >> 6));
+    const u64 poly = blockIdx.y;
+    const BufRsrc rin = make_rsrc(in + poly * in_pstride, (u32)((u64)c.L * N * 8));
+    const BufRsrc rout = make_rsrc(out + poly * out_pstride, (u32)((u64)c.nBsk * N * 8));
+    const u32 n32 = (u32)N;
+    const bool owner = w < ((c.nBsk + 3) >> 2);
+    MfmaFrag af[KB], am[KB];
+#pragma unroll
+    for (int kb = 0; kb < KB; kb++) {
+        af[kb] = b2_frag(c.x_frag, ((size_t)(owner ? w : 0) * KB + kb) * 64 + lane);
+        am[kb] = b2_frag(c.x_mt_frag, (size_t)kb * 64 + lane);
+    }
+    BehzK2 k2[2];
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const int o = 4 * w + 2 * j + (int)half;
+        k2[j] = c.x_k[o < c.nBsk ? o : c.nBsk - 1];
+    }
+    const B2Patch where = b2_patch_where(c.L, half);
+    u64 qp[KB];
+    Shoup qpre[KB];
+#pragma unroll
+    for (int i = 0; i < KB; i++) {
+        const int l = w + 4 * i;
+        const int lc = l < c.L ? l : 0;
+        const unsigned id = B2_UNIFORM((unsigned)c.q_id[lc]);
+        qp[i] = ((b2_cu64)&primes[id])[0];
+        qpre[i] = Shoup{((b2_cu64)(c.ext_pre + lc))[0], ((b2_cu64)(c.ext_pre + lc))[1]};
+    }
+    u64 xr[KB];
+    auto fetch = [&](unsigned t) { // a tile beyond N, a padding limb: offset out of range, the load returns 0
+        const u32 n = (blockIdx.x * tiles_per_wg + t) * B2_TILE + lane;
+#pragma unroll
+        for (int i = 0; i < KB; i++) {
+            const u32 l = (u32)(w + 4 * i);
+            xr[i] = B2_LOAD(buf_load_u64(rin, (l < (u32)c.L && n < n32) ? (l * n32 + n) * 8u : TROY_BUF_OOB), (lane + n) * 0x9E3779B97F4Aull + l);
+        }
+    };
+    fetch(0);
+    // stand-ins for "the previous tile's stores" so that the loop's waits are counted, not full drains (see behz.hip)
+#pragma unroll
+    for (int i = 0; i < 4; i++) buf_store_u64(rout, TROY_BUF_OOB + 8 * i, 0);
+    for (unsigned t = 0; t < tiles_per_wg; t++) {
+        const u32 n0 = (blockIdx.x * tiles_per_wg + t) * B2_TILE;
+        if (n0 >= n32) break;
+        u64 *yd = ydig[t & 1];
+        // y_l = x_l m_tilde (q/q_l)^-1 mod q_l as balanced digits; limbs L .. 4 KB - 1 (the extra input's slot and padding) are zero
+#pragma unroll
+        for (int i = 0; i < KB; i++) {
+            const int l = w + 4 * i;
+            yd[(((l >> 1) * B2_TILE) + lane) * 2 + (l & 1)] = b2_digits(mul_shoup(xr[i], qpre[i].op, qpre[i].quo, qp[i]));
+        }
+        fetch(t + 1 < tiles_per_wg ? t + 1 : 0x7FFFFFu); // past the last tile: out of range
+        __syncthreads();
+#pragma unroll
+        for (int sub = 0; sub < B2_TILE / 32; sub++) {
+            const unsigned cc = sub * 32 + cl;
+            MfmaFrag bf[KB];
+#pragma unroll
+            for (int kb = 0; kb < KB; kb++) bf[kb] = b2_frag(yd, (size_t)(2 * kb + half) * B2_TILE + cc);
+            // r = -(sum_l y_l (q/q_l)) q^-1 mod 2^32 from the four shift rows of the m_tilde block (both halves hold them)
+            MfmaAcc acc;
+            b2_zero(acc);
+#pragma unroll
+            for (int kb = 0; kb < KB; kb++) B2_MFMA(am[kb], bf[kb], acc);
+            const u32 rsum = (u32)acc.v[0] + ((u32)acc.v[1] << 8) + ((u32)acc.v[2] << 16) + ((u32)acc.v[3] << 24);
+            const u64 r_mt = ((u64)rsum * c.neg_inv_q_mod_mt) & 0xFFFFFFFFull;
+            // centred representative of r (rns.cpp:966-975) as one more input: out = (sum + r q) m_tilde^-1
+            b2_patch(bf[KB - 1], where, b2_digits((u64)((long long)r_mt - (long long)((r_mt >> 31) << 32))));
+            u64 r[2] = {0, 0};
+            if (owner) {
+                b2_zero(acc);
+#pragma unroll
+                for (int kb = 0; kb < KB; kb++) B2_MFMA(af[kb], bf[kb], acc);
+                r[0] = b2_finish<0>(acc, k2[0].biaslo, k2[0]);
+                r[1] = b2_finish<8>(acc, k2[1].biaslo, k2[1]);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; j++) { // the same number of stores on every path keeps the outstanding-store count a constant
+                const u32 o = 4 * (u32)w + 2 * j + half;
+                const bool live = (B2_EXP & 16) ? r[j] == ~0ull : (owner && o < (u32)c.nBsk && n0 + cc < n32);
+                buf_store_u64(rout, live ? (o * n32 + n0 + cc) * 8u : TROY_BUF_OOB, r[j]);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------- floor + Shenoy-Kumaresan (fastFloor + fastbconvSk)
+// dq [polys][L][N], db [polys][nBsk][N] (any representative < 2^64) -> out [polys][L][N].  Two chained products per tile:
+//   (1) rows of f1_frag x digits(y), + db_o T_o  ->  u_b (digits, LDS) for o < nB, and z' = z_sk B^-1 mod m_sk
+//   (2) the m_sk row x digits(u) -> alpha = conv' - z' (every wave, for its own lanes), then rows of f2_frag x [digits(u), alpha] -> out_l
+// All A fragments stay in registers (one row-block per wave and stage); two barriers per tile.
+template <int KB1, int KB2, bool FAST2> __global__ __launch_bounds__(B2_THREADS) void behz2_floor_sk_kernel(const u64 *dq, u64 dq_pstride, const u64 *db, u64 db_pstride,
+                                                                                                           u64 *out, u64 out_pstride, const PrimeDesc *primes, BehzDev c,
+                                                                                                           u64 N, unsigned tiles_per_wg) {
+    __shared__ __attribute__((aligned(16))) u64 ydig[2 * KB1 * B2_TILE * 2];
+    __shared__ __attribute__((aligned(16))) u64 udig[2 * KB2 * B2_TILE * 2];
+    __shared__ u64 zsk[B2_TILE];
+    const unsigned lane = threadIdx.x & 63, half = lane >> 5, cl = lane & 31;
+    const int w = B2_UNIFORM((int)(threadIdx.x >> 6));
+    const u64 poly = blockIdx.y;
+    const BufRsrc rq = make_rsrc(dq + poly * dq_pstride, (u32)((u64)c.L * N * 8));
+    const BufRsrc rb = make_rsrc(db + poly * db_pstride, (u32)((u64)c.nBsk * N * 8));
+    const BufRsrc rout = make_rsrc(out + poly * out_pstride, (u32)((u64)c.L * N * 8));
+    const u32 n32 = (u32)N;
+    const bool owner1 = w < ((c.nBsk + 3) >> 2), owner2 = w < ((c.L + 3) >> 2);
+    for (unsigned i = threadIdx.x; i < 2 * KB2 * B2_TILE * 2; i += B2_THREADS) udig[i] = 0; // limbs nB .. stay zero
+    MfmaFrag af1[KB1], af2[KB2], amsk[KB2];
+#pragma unroll
+    for (int kb = 0; kb < KB1; kb++) af1[kb] = b2_frag(c.f1_frag, ((size_t)(owner1 ? w : 0) * KB1 + kb) * 64 + lane);
+#pragma unroll
+    for (int kb = 0; kb < KB2; kb++) {
+        af2[kb] = b2_frag(c.f2_frag, ((size_t)(owner2 ? w : 0) * KB2 + kb) * 64 + lane);
+        amsk[kb] = b2_frag(c.f2_msk_frag, (size_t)kb * 64 + lane);
+    }
+    BehzK2 k1[2], k2[2];
+    Shoup t1[2];
+    B2Slow s2[2];
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const int o = 4 * w + 2 * j + (int)half;
+        const int oc = o < c.nBsk ? o : c.nBsk - 1, lc = o < c.L ? o : c.L - 1;
+        k1[j] = c.f1_k[oc];
+        t1[j] = c.f1_t[oc];
+        k2[j] = c.f2_k[lc];
+        if (!FAST2) {
+            const PrimeDesc &pd = primes[c.q_id[lc]];
+            s2[j] = B2Slow{pd.p, pd.cr1, pd.two_p, pd.r64.op, pd.r64.quo};
+        }
+    }
+    const BehzK2 msk = c.msk_k; // kernel argument: scalar registers
+    const B2Patch where = b2_patch_where(c.nB, half);
+    u64 qp[KB1];
+    Shoup qpre[KB1];
+#pragma unroll
+    for (int i = 0; i < KB1; i++) {
+        const int l = w + 4 * i;
+        const int lc = l < c.L ? l : 0;
+        const unsigned id = B2_UNIFORM((unsigned)c.q_id[lc]);
+        qp[i] = ((b2_cu64)&primes[id])[0];
+        qpre[i] = Shoup{((b2_cu64)(c.floor_pre + lc))[0], ((b2_cu64)(c.floor_pre + lc))[1]};
+    }
+    // both operands of a tile are fetched while the previous tile is computed: the q residues of this wave's limbs (xr) and the Bsk
+    // residues this lane adds in the stage-1 epilogue, (sub, j) -> db[o = 4w + 2j + half][n0 + 32 sub + cl] (dbn)
+    u64 xr[KB1], dbn[2][2];
+    auto fetch = [&](unsigned t) {
+        const u32 t0 = (blockIdx.x * tiles_per_wg + t) * B2_TILE;
+        const u32 n = t0 + lane;
+#pragma unroll
+        for (int i = 0; i < KB1; i++) {
+            const u32 l = (u32)(w + 4 * i);
+            xr[i] = B2_LOAD(buf_load_u64(rq, (l < (u32)c.L && n < n32) ? (l * n32 + n) * 8u : TROY_BUF_OOB), (lane + n) * 0x9E3779B97F4Aull + l);
+        }
+#pragma unroll
+        for (int sub = 0; sub < 2; sub++)
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const u32 o = 4 * (u32)w + 2 * j + half;
+                const u32 m = t0 + sub * 32 + cl;
+                dbn[sub][j] = B2_LOAD(buf_load_u64(rb, (o < (u32)c.nBsk && m < n32) ? (o * n32 + m) * 8u : TROY_BUF_OOB), (lane + m) * 0x9E3779B97F4Aull + o);
+            }
+    };
+    fetch(0);
+#pragma unroll
+    for (int i = 0; i < 4; i++) buf_store_u64(rout, TROY_BUF_OOB + 8 * i, 0);
+    for (unsigned t = 0; t < tiles_per_wg; t++) {
+        const u32 n0 = (blockIdx.x * tiles_per_wg + t) * B2_TILE;
+        if (n0 >= n32) break;
+        // y_l = t dq_l (q/q_l)^-1 mod q_l as digits (canonical: the conversion sums the integers)
+#pragma unroll
+        for (int i = 0; i < KB1; i++) {
+            const int l = w + 4 * i;
+            ydig[(((l >> 1) * B2_TILE) + lane) * 2 + (l & 1)] = b2_digits(mul_shoup(xr[i], qpre[i].op, qpre[i].quo, qp[i]));
+        }
+        const u64 dbv[2][2] = {{dbn[0][0], dbn[0][1]}, {dbn[1][0], dbn[1][1]}};
+        fetch(t + 1 < tiles_per_wg ? t + 1 : 0x7FFFFFu);
+        __syncthreads(); // also orders this tile's udig / zsk writes after the previous tile's stage-2 reads
+        // ---- stage 1: u_o = (t db_o - conv(t dq)_o) q^-1 [(B/B_o)^-1 | B^-1 for m_sk] mod Bsk_o
+        if (owner1) {
+#pragma unroll
+            for (int sub = 0; sub < 2; sub++) {
+                const unsigned cc = sub * 32 + cl;
+                MfmaAcc acc;
+                b2_zero(acc);
+#pragma unroll
+                for (int kb = 0; kb < KB1; kb++) B2_MFMA(af1[kb], b2_frag(ydig, (size_t)(2 * kb + half) * B2_TILE + cc), acc);
+                const u64 r0 = b2_finish<0>(acc, k1[0].biaslo + mul_lazy(dbv[sub][0], t1[0].op, t1[0].quo, k1[0].p), k1[0]);
+                const u64 r1 = b2_finish<8>(acc, k1[1].biaslo + mul_lazy(dbv[sub][1], t1[1].op, t1[1].quo, k1[1].p), k1[1]);
+#pragma unroll
+                for (int j = 0; j < 2; j++) {
+                    const int o = 4 * w + 2 * j + (int)half;
+                    const u64 r = j ? r1 : r0;
+                    if (o < c.nB) udig[(((o >> 1) * B2_TILE) + cc) * 2 + (o & 1)] = b2_digits(r);
+                    else if (o == c.nB) zsk[cc] = r;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- stage 2: Shenoy-Kumaresan
+#pragma unroll
+        for (int sub = 0; sub < 2; sub++) {
+            const unsigned cc = sub * 32 + cl;
+            MfmaFrag bf[KB2];
+#pragma unroll
+            for (int kb = 0; kb < KB2; kb++) bf[kb] = b2_frag(udig, (size_t)(2 * kb + half) * B2_TILE + cc);
+            MfmaAcc acc;
+            b2_zero(acc);
+#pragma unroll
+            for (int kb = 0; kb < KB2; kb++) B2_MFMA(amsk[kb], bf[kb], acc);
+            // alpha = (conv_{B->m_sk}(z) - z_sk) B^-1 mod m_sk; above m_sk / 2 it stands for a negative value (rns.cpp:905-930)
+            const u64 conv = b2_finish<0>(acc, msk.biaslo, msk);
+            const u64 z = zsk[cc];
+            const u64 alpha = conv >= z ? conv - z : conv + msk.p - z;
+            const bool neg = alpha > (msk.p >> 1);
+            b2_patch(bf[KB2 - 1], where, b2_digits(neg ? alpha - msk.p : alpha)); // out_l = sum - alpha (B mod q_l)
+            u64 r[2] = {0, 0};
+            if (owner2) {
+                b2_zero(acc);
+#pragma unroll
+                for (int kb = 0; kb < KB2; kb++) B2_MFMA(af2[kb], bf[kb], acc);
+                if (FAST2) {
+                    r[0] = b2_finish<0>(acc, k2[0].biaslo, k2[0]);
+                    r[1] = b2_finish<8>(acc, k2[1].biaslo, k2[1]);
+                } else {
+                    r[0] = b2_reduce_slow(b2_recombine<0>(acc, k2[0].biaslo), s2[0]);
+                    r[1] = b2_reduce_slow(b2_recombine<8>(acc, k2[1].biaslo), s2[1]);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const u32 l = 4 * (u32)w + 2 * j + half;
+                const bool live = (B2_EXP & 16) ? r[j] == ~0ull : (owner2 && l < (u32)c.L && n0 + cc < n32);
+                buf_store_u64(rout, live ? (l * n32 + n0 + cc) * 8u : TROY_BUF_OOB, r[j]);
+            }
+        }
+    }
+}
+
+static unsigned b2_tiles_per_wg(u64 tiles) { return tiles >= 64 ? B2_TPW : 1; }
+
+void launch_behz2_extend(const u64 *in, u64 in_pstride, u64 *out, u64 out_pstride, const PrimeDesc *primes, const BehzDev &c, u64 N, u64 polys, hipStream_t s) {
+    const u64 tiles = ceil_div(N, (u64)B2_TILE);
+    const unsigned tpw = b2_tiles_per_wg(tiles);
+    const int kb = (c.L + 1 + 3) / 4;
+    for (u64 p0 = 0; p0 < polys; p0 += 65535) { // gridDim.y limit
+        const u64 np = polys - p0 < 65535 ? polys - p0 : 65535;
+        const dim3 grid((unsigned)ceil_div(tiles, (u64)tpw), (unsigned)np);
+        const u64 *pi = in + p0 * in_pstride;
+        u64 *po = out + p0 * out_pstride;
+#define B2_EXT(KB_) TROY_LAUNCH(HIP_KERNEL_NAME(behz2_extend_kernel<KB_>), grid, dim3(B2_THREADS), 0, s, pi, in_pstride, po, out_pstride, primes, c, N, tpw)
+        switch (kb) {
+        case 1: B2_EXT(1); break;
+        case 2: B2_EXT(2); break;
+        case 3: B2_EXT(3); break;
+        case 4: B2_EXT(4); break;
+        default: throw Error(ST_LOGIC_ERROR, "BEHZ base sizes outside the matrix-core form");
+        }
+#undef B2_EXT
+    }
+    launch_check("behz2_extend_kernel");
+}
+
+void launch_behz2_floor_sk(const u64 *dq, u64 dq_pstride, const u64 *db, u64 db_pstride, u64 *out, u64 out_pstride, const PrimeDesc *primes, const BehzDev &c, u64 N,
+                           u64 polys, hipStream_t s) {
+    const u64 tiles = ceil_div(N, (u64)B2_TILE);
+    const unsigned tpw = b2_tiles_per_wg(tiles);
+    const int kb1 = (c.L + 3) / 4, kb2 = (c.nB + 1 + 3) / 4; // kb2 is kb1 or kb1 + 1 (nB is L or L + 1)
+    for (u64 p0 = 0; p0 < polys; p0 += 65535) {
+        const u64 np = polys - p0 < 65535 ? polys - p0 : 65535;
+        const dim3 grid((unsigned)ceil_div(tiles, (u64)tpw), (unsigned)np);
+        const u64 *pq = dq + p0 * dq_pstride, *pb = db + p0 * db_pstride;
+        u64 *po = out + p0 * out_pstride;
+#define B2_FLOOR(K1_, K2_, F_)                                                                                            \
+    TROY_LAUNCH(HIP_KERNEL_NAME(behz2_floor_sk_kernel<K1_, K2_, F_>), grid, dim3(B2_THREADS), 0, s, pq, dq_pstride, pb, db_pstride, po, out_pstride, primes, c, N, tpw)
+#define B2_FLOOR_F(K1_, K2_)                                                                                              \
+    do {                                                                                                                 \
+        if (c.f2_fast) B2_FLOOR(K1_, K2_, true);                                                                         \
+        else B2_FLOOR(K1_, K2_, false);                                                                                  \
+    } while (0)
+        switch (kb1 * 8 + kb2) {
+        case 1 * 8 + 1: B2_FLOOR_F(1, 1); break;
+        case 1 * 8 + 2: B2_FLOOR_F(1, 2); break;
+        case 2 * 8 + 2: B2_FLOOR_F(2, 2); break;
+        case 2 * 8 + 3: B2_FLOOR_F(2, 3); break;
+        case 3 * 8 + 3: B2_FLOOR_F(3, 3); break;
+        case 3 * 8 + 4: B2_FLOOR_F(3, 4); break;
+        case 4 * 8 + 4: B2_FLOOR_F(4, 4); break;
+        default: throw Error(ST_LOGIC_ERROR, "BEHZ base sizes outside the matrix-core form");
+        }
+#undef B2_FLOOR_F
+#undef B2_FLOOR
+    }
+    launch_check("behz2_floor_sk_kernel");
+}
+
+} // namespace troyhip

@@ -106,6 +106,47 @@ static std::vector<uint8_t> pack_mfma_mt(const std::vector<u64> &row) {
     return f;
 }
 
+// ---- second matrix-core form (behz2.hip).  W[o][limb] are the conversion-matrix entries of output o (already holding every folded
+// row factor); A-matrix row (o, s) holds at k = (limb, i) the balanced digit s of W[o][limb] 2^(8 i) mod p[o].  Tile row m of
+// row-block rb -> output 4 rb + 2 (m / 16) + (m / 4) % 2, shift m % 4 + 4 ((m / 8) % 2): lane l's accumulator registers 0-7 are the
+// shifts of output 4 rb + l / 32, registers 8-15 those of output 4 rb + 2 + l / 32 (D layout of v_mfma_i32_32x32x32_i8).
+// mod32: the modulus is 2^32 (m_tilde) and only shifts 0-3 exist.
+static std::vector<uint8_t> pack_rows8(const std::vector<std::vector<u64>> &W, const std::vector<u64> &p, int KB, bool mod32 = false) {
+    const int n_out = (int)W.size(), RB = (n_out + 3) / 4;
+    std::vector<uint8_t> f((size_t)RB * KB * 64 * 16, 0);
+    for (int rb = 0; rb < RB; rb++)
+        for (int kb = 0; kb < KB; kb++)
+            for (int lane = 0; lane < 64; lane++) {
+                const int m = lane % 32, mm = m % 16, o = 4 * rb + 2 * (m / 16) + (mm / 4) % 2, s = mm % 4 + 4 * (mm / 8);
+                if (o >= n_out || (mod32 && s >= 4)) continue;
+                for (int t = 0; t < 16; t++) {
+                    const int k = 32 * kb + 16 * (lane / 32) + t, limb = k / 8, i = k % 8;
+                    if (limb >= (int)W[o].size()) continue;
+                    u64 w;
+                    if (mod32) w = i < 4 ? (W[o][limb] << (8 * i)) & 0xFFFFFFFFull : 0;
+                    else w = host::mul_mod(W[o][limb] % p[o], host::pow_mod(2, (u64)(8 * i), p[o]), p[o]);
+                    f[(((size_t)rb * KB + kb) * 64 + lane) * 16 + t] = (uint8_t)balanced_digit(w, s);
+                }
+            }
+    return f;
+}
+static BehzK2 make_k2(u64 p) {
+    const u128 base = (u128)1 << 78, target = base + ((u128)1 << 46);
+    const u128 m = (target + p - 1) / p;
+    BehzK2 k;
+    k.p = p;
+    k.negp = 0 - p;
+    k.biaslo = (u64)(m * p - base); // in [2^46, 2^46 + p)
+    k.mu = (u32)std::min<u128>(((u128)1 << 80) / p, 0xFFFFFFFFu);
+    k.pad = 0;
+    return k;
+}
+// TROYHIP_BEHZ selects the base-conversion kernels: "valu", "mfma1" (16-shift Toeplitz rows) or, by default, the 8-shift form
+static bool behz_v2_enabled() {
+    const char *e = getenv("TROYHIP_BEHZ");
+    return !(e && (e[0] == 'v' || strcmp(e, "mfma1") == 0));
+}
+
 template <class T> T *Context::upload(const std::vector<T> &v, std::vector<void *> &owner) {
     if (v.empty()) return nullptr;
     T *d = nullptr;
@@ -317,6 +358,52 @@ void Context::upload_tables() {
             } else
                 c->floor_frag2 = upload(pack_mfma_rows(f2, L), lv.dev_blocks);
             c->floor_msk_frag = upload(pack_mfma_rows(fm, 2), lv.dev_blocks);
+        }
+        bool big_bsk = true;
+        for (u64 p : r.Bsk) big_bsk = big_bsk && p >= (u64(1) << 50);
+        if (L <= 15 && nBsk <= 16 && big_bsk && behz_v2_enabled()) { // second matrix-core form: behz2.hip
+            const int KBx = (L + 1 + 3) / 4, KB1 = (L + 3) / 4, KB2 = (nB + 1 + 3) / 4;
+            std::vector<std::vector<u64>> xw(nBsk), f1w(nBsk), f2w(L), mtw(2), mskw(2);
+            std::vector<u64> bskp(r.Bsk.begin(), r.Bsk.end()), qp(r.q.begin(), r.q.begin() + L), two32(2, 0), mskp(2, r.m_sk);
+            std::vector<BehzK2> xk(nBsk), f1k(nBsk), f2k(L);
+            std::vector<Shoup> f1t(nBsk);
+            for (int o = 0; o < nBsk; o++) {
+                const u64 p = r.Bsk[o];
+                u64 fscale = r.inv_prod_q_mod_Bsk[o];                                               // q^-1
+                if (o < nB) fscale = host::mul_mod(fscale, r.B_to_q.inv_punct[o], p);              // (B/B_o)^-1: u_o is pre-scaled for stage 2
+                else fscale = host::mul_mod(fscale, r.inv_prod_B_mod_msk % p, p);                  // m_sk: z' = z_sk B^-1
+                for (int l = 0; l < L; l++) {
+                    xw[o].push_back(host::mul_mod(r.q_to_Bsk.mat[o][l], r.inv_mtilde_mod_Bsk[o], p));
+                    const u64 f = host::mul_mod(r.q_to_Bsk.mat[o][l], fscale, p);
+                    f1w[o].push_back(f ? p - f : 0);
+                }
+                xw[o].push_back(ext_q[o]);                                                          // the centred r against q m_tilde^-1
+                xk[o] = f1k[o] = make_k2(p);
+                f1t[o] = make_shoup(host::mul_mod(t % p, fscale, p), p);
+            }
+            for (int l = 0; l < L; l++) {
+                for (int b = 0; b < nB; b++) f2w[l].push_back(r.B_to_q.mat[l][b]);
+                const u64 pb = r.prod_B_mod_q[l] % r.q[l];
+                f2w[l].push_back(pb ? r.q[l] - pb : 0);                                             // the centred alpha against -(B mod q_l)
+                f2k[l] = make_k2(r.q[l]);
+            }
+            for (int h = 0; h < 2; h++) {
+                for (int l = 0; l < L; l++) mtw[h].push_back(mt_row[l]);
+                for (int b = 0; b < nB; b++) mskw[h].push_back(host::mul_mod(r.B_to_msk.mat[0][b], r.inv_prod_B_mod_msk, r.m_sk));
+            }
+            c->x_frag = upload(pack_rows8(xw, bskp, KBx), lv.dev_blocks);
+            c->x_mt_frag = upload(pack_rows8(mtw, two32, KBx, true), lv.dev_blocks);
+            c->x_k = upload(xk, lv.dev_blocks);
+            c->f1_frag = upload(pack_rows8(f1w, bskp, KB1), lv.dev_blocks);
+            c->f1_k = upload(f1k, lv.dev_blocks);
+            c->f1_t = upload(f1t, lv.dev_blocks);
+            c->f2_frag = upload(pack_rows8(f2w, qp, KB2), lv.dev_blocks);
+            c->f2_msk_frag = upload(pack_rows8(mskw, mskp, KB2), lv.dev_blocks);
+            c->f2_k = upload(f2k, lv.dev_blocks);
+            c->msk_k = make_k2(r.m_sk);
+            c->f2_fast = 1;
+            for (int l = 0; l < L; l++) c->f2_fast = c->f2_fast && r.q[l] >= (u64(1) << 50);
+            c->v2 = 1;
         }
         c->B2q3 = upload(B2q, lv.dev_blocks);
         c->B2msk3 = upload(B2msk, lv.dev_blocks);

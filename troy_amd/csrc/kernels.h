@@ -119,6 +119,10 @@ void launch_modarith_probe(int op, const u64 *a, const u64 *b, const u64 *c, u64
 // base-change matrix entry split into 21-bit limbs (m = m0 + m1 2^21 + m2 2^42): see behz.hip
 struct Mat3 { u32 m0, m1, m2, pad; };
 
+// epilogue constants of one output prime in the second matrix-core form (behz2.hip): bias = biaslo + 2^78 is a multiple of p,
+// mu = floor(2^80 / p), negp = 2^64 - p
+struct BehzK2 { u64 p, negp, biaslo; u32 mu, pad; };
+
 // device-resident constants of one level (built by Context, see context.cpp)
 struct BehzDev {
     int L, nB, nBsk;
@@ -150,7 +154,23 @@ struct BehzDev {
     const void *floor_msk_frag;       // [4][64]                the B -> m_sk row, in both halves of the tile
     Shoup inv_B_mod_msk;
     const u64 *prod_B_mod_q;          // [L]
+    // --- second matrix-core form (behz2.hip): rows reduced modulo the output prime, 8 byte-shifts per output, a row-block = 4 outputs;
+    // fragments [row-block][k-block][lane] x 16 bytes with k-blocks of 4 limbs x 8 digits.  v2 != 0 when built (L <= 15, |Bsk| <= 16)
+    int v2, f2_fast;                  // f2_fast: every q prime >= 2^50 (one-step quotient estimate), else the two-word reduction
+    const void *x_frag;               // extension: [ceil(nBsk/4)][KBx][64], KBx = ceil((L+1)/4): limbs 0..L-1 and the r column at limb L
+    const void *x_mt_frag;            // [KBx][64]  the m_tilde row (modulo 2^32, 4 shifts) in both halves of the tile
+    const BehzK2 *x_k;                // [nBsk]
+    const void *f1_frag;              // floor stage 1: [ceil(nBsk/4)][KB1][64], KB1 = ceil(L/4); the m_sk row carries B^-1 too
+    const BehzK2 *f1_k;               // [nBsk]
+    const Shoup *f1_t;                // [nBsk]  t q^-1 [(B/B_o)^-1 | B^-1] mod Bsk_o: the db_o term
+    const void *f2_frag;              // stage 2: [ceil(L/4)][KB2][64], KB2 = ceil((nB+1)/4): the B limbs and the alpha column at limb nB
+    const void *f2_msk_frag;          // [KB2][64]  (B/B_b) B^-1 mod m_sk in both halves of the tile
+    const BehzK2 *f2_k;               // [L]
+    BehzK2 msk_k;
 };
+void launch_behz2_extend(const u64 *in, u64 in_pstride, u64 *out, u64 out_pstride, const PrimeDesc *primes, const BehzDev &c, u64 N, u64 polys, hipStream_t s);
+void launch_behz2_floor_sk(const u64 *dq, u64 dq_pstride, const u64 *db, u64 db_pstride, u64 *out, u64 out_pstride, const PrimeDesc *primes, const BehzDev &c, u64 N,
+                           u64 polys, hipStream_t s);
 void launch_behz_extend(const u64 *in, u64 in_pstride, u64 *out, u64 out_pstride, const PrimeDesc *primes, const BehzDev &c, u64 N, u64 polys, hipStream_t s);
 void launch_behz_floor_sk(const u64 *dq, u64 dq_pstride, const u64 *db, u64 db_pstride, u64 *out, u64 out_pstride, const PrimeDesc *primes, const BehzDev &c, u64 N,
                           u64 polys, hipStream_t s);
