@@ -376,7 +376,8 @@ def algorithmic_bytes(w, B):
     k1 = logn - 9 if logn - 9 <= 7 else 7
     logc = 11 - k1
     # multiply: extension of 4 polynomials, forward first passes (q: consumed in place, Bsk), tensor passes, inverse, floor/SK
-    add("behz_extend_mfma_kernel<4, 2>", 2 * 2 * B * (L + nb) * P)
+    fast = "true" if all(int(p) >= 1 << 50 for p in w.ctx.coeff_modulus[:L]) else "false"
+    add(f"behz2_extend_kernel<{(L + 4) // 4}>", 2 * 2 * B * (L + nb) * P)
     add(f"ntt2_kernel<0, 1, {k1}, {logc}, 0, 0, 0>", 2 * (2 * B * L) * 2 * P + 2 * (2 * B * nb) * 2 * P)
     add("ntt2_kernel<0, 0, 9, 0, 1, 0, 2>", 7 * B * (L + nb) * P)
     inv_rows = 3 * B * (L + nb) + 2 * B * (L + 1)
@@ -385,7 +386,7 @@ def algorithmic_bytes(w, B):
         add(f"ntt2_kernel<1, 1, {k1}, {logc}, 2, 0, 0>", inv_rows * 2 * P)
     else:
         add("ntt1_inv_kernel", inv_rows * 2 * P)
-    add("behz_floor_sk_mfma_kernel<4, 2>", 3 * B * (2 * L + nb) * P)
+    add(f"behz2_floor_sk_kernel<{(L + 3) // 4}, {(nb + 3) // 4}, {fast}>", 3 * B * (2 * L + nb) * P)
     # relinearize: digit decomposition + first pass, second pass with the inner product against the key, inverse, mod-down
     add(f"ntt2_kernel<0, 1, {k1}, {logc}, 0, 1, 0>", B * L * P + B * (L + 1) * L * P)
     add("ntt2_kernel<0, 0, 9, 0, 1, 0, 1>", B * (L + 1) * L * P + 2 * (L + 1) * L * P + 2 * B * (L + 1) * P)

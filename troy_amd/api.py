@@ -4,7 +4,7 @@ Names and argument meaning follow src/troy_cuda.cuh / src/evaluator_cuda.cuh (Ke
 SEALContext, Ciphertext, RelinKeys/GaloisKeys, Evaluator::multiply / relinearizeInplace /
 rotateRowsInplace / rescaleToNextInplace ...), with one extension: a `Ciphertext` here is a *batch* of B
 independent ciphertexts of identical shape (B = 1 is the reference's object).  The C++ form of the same
-mirror is include/troy_cuda.cuh.  Everything runs through libtroyhip.so; there is no CPU path.
+mirror is include/troyn.hpp (+ include/troyn_app.hpp for the app helpers).  Everything runs through libtroyhip.so; there is no CPU path.
 """
 import ctypes as C
 import os

@@ -49,7 +49,7 @@ class ContextInfo(C.Structure):
                 ("first_limbs", C.c_int32), ("last_limbs", C.c_int32), ("plain_modulus", C.c_uint64)]
 
 
-# every symbol include/troyhip.h declares (tests/test_cabi_symbols.py checks the header against this list)
+# every symbol include/troyhip.h declares (tests/test_cabi.py checks the header against this list)
 SYMBOLS = [
     "troyhip_initialize", "troyhip_is_initialized", "troyhip_last_error", "troyhip_build_info", "troyhip_malloc",
     "troyhip_free", "troyhip_pool_release", "troyhip_copy_h2d", "troyhip_copy_d2h", "troyhip_copy_d2d", "troyhip_memset_zero",
