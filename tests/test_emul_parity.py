@@ -168,6 +168,20 @@ def test_emulated_single_pass_ntt_row_loop_and_prime_classes(oracle_lib, tmp_pat
         "    assert np.array_equal(y[r], oracle.ntt_standalone(N, primes[(r // 2) %% len(primes)], x[r], 1)), r\n"
         "ctx.ntt(buf, rows, primes, inner=2, inverse=True)\n"
         "assert np.array_equal(buf.to_numpy().reshape(rows, N), x)\n"
+        # extreme inputs of the guard-free inverse rounds (value bounds double per stage): all p - 1, and p - 1 / 0 alternating
+        "rows2 = 2 * len(primes)\n"
+        "e = np.zeros((rows2, N), dtype=np.uint64)\n"
+        "for r in range(rows2):\n"
+        "    p = primes[(r // 2) %% len(primes)]\n"
+        "    e[r] = p - 1\n"
+        "    if r %% 2: e[r, 1::2] = 0\n"
+        "buf2 = api.DeviceBuffer.from_numpy(e)\n"
+        "ctx.ntt(buf2, rows2, primes, inner=2, inverse=True)\n"
+        "z = buf2.to_numpy().reshape(rows2, N)\n"
+        "for r in range(rows2):\n"
+        "    assert np.array_equal(z[r], oracle.ntt_standalone(N, primes[(r // 2) %% len(primes)], e[r], 3)), r\n"
+        "ctx.ntt(buf2, rows2, primes, inner=2)\n"
+        "assert np.array_equal(buf2.to_numpy().reshape(rows2, N), e)\n"
         "print('ok')\n" % (ROOT, os.path.join(ROOT, 'tests'), EMUL))
     for rpw in ("3", "1"):
         env = dict(os.environ, TROYHIP_NTT1_RPW=rpw)

@@ -147,6 +147,29 @@ def test_ntt_properties_at_full_size(gpu):
     assert (delta.to_numpy() == 1).all()                               # NTT(1) = (1, ..., 1)
 
 
+def test_single_pass_ntt_vs_oracle_incl_extremes(gpu, oracle_lib):
+    """ntt1.hip (N = 2^15) against the oracle, row by row: uniform rows, every residue p - 1, and p - 1 / 0 alternating -- the inputs
+    that drive the guard-free rounds (forward: +3p per stage; inverse: the bound doubles per stage between lite reductions) to their
+    largest values -- for primes of both butterfly classes (40 / 50 / 58 bits guard-free, 60 / 61 bits guarded)"""
+    from troy_amd import synth
+    N = 32768
+    kp = gpu.CoeffModulus.Create(N, [60, 50, 58, 40, 60])
+    ctx = gpu.SEALContext(gpu.BFV, N, kp, gpu.PlainModulus.Batching(N, 20))
+    primes = kp[:4] + [int(ctx.behz_bases(4)[0][0])]
+    rows = 3 * len(primes)
+    x = synth.uniform_rows(77, primes, rows, N)
+    for r in range(len(primes), rows):
+        x[r] = primes[r % len(primes)] - 1
+        if r >= 2 * len(primes):
+            x[r, 1::2] = 0
+    for mode, inverse in ((1, False), (3, True)):
+        buf = gpu.DeviceBuffer.from_numpy(x)
+        ctx.ntt(buf, rows, primes, inverse=inverse)
+        y = buf.to_numpy().reshape(rows, N)
+        for r in range(rows):
+            assert np.array_equal(y[r], oracle_lib.ntt_standalone(N, primes[r % len(primes)], x[r], mode)), (mode, r)
+
+
 def test_cfgA_add_on_device(gpu):
     f = np.load(os.path.join(GOLDEN, "cfgA_bfv_n4096_k3.npz"))
     cfg = cases.CONFIGS["cfgA_bfv_n4096_k3"]

@@ -216,6 +216,30 @@ template <bool UNI = false> __device__ __forceinline__ void gs_bfly4_ng(u64 (&X)
 #pragma unroll
     for (int i = 0; i < 4; i++) Y[i] = UNI ? mul_acc_u(0, d[i], w[i].op, q[i], c.negp) : mul_acc(0, d[i], w[i].op, q[i], c.negp);
 }
+// last inverse stage, guard-free: bound(X), bound(Y) <= kp / p and bound(X) + bound(Y) < 2^64 / p; both outputs come out of a
+// multiplication (by N^-1, by the pre-scaled twiddle), i.e. in [0,3p) whatever the inputs were
+template <bool UNI = false> __device__ __forceinline__ void gs_bfly4_last_ng(u64 (&X)[4], u64 (&Y)[4], const Shoup (&w_scaled)[4], const Shoup inv_n, u64 kp, const PrimeConst &c) {
+    u64 s[4], t[4], d[4], q[4];
+    const Shoup wn[4] = {inv_n, inv_n, inv_n, inv_n};
+#pragma unroll
+    for (int i = 0; i < 4; i++) { s[i] = X[i] + Y[i]; t[i] = X[i] + kp; }
+    sub4(d, t, Y);
+    if (UNI) mulhi_approx4_u(q, s, wn); else mulhi_approx4(q, s, wn);
+#pragma unroll
+    for (int i = 0; i < 4; i++) X[i] = UNI ? mul_acc_u(0, s[i], inv_n.op, q[i], c.negp) : mul_acc(0, s[i], inv_n.op, q[i], c.negp);
+    if (UNI) mulhi_approx4_u(q, d, w_scaled); else mulhi_approx4(q, d, w_scaled);
+#pragma unroll
+    for (int i = 0; i < 4; i++) Y[i] = UNI ? mul_acc_u(0, d[i], w_scaled[i].op, q[i], c.negp) : mul_acc(0, d[i], w_scaled[i].op, q[i], c.negp);
+}
+// any x < 2^64 -> the same residue in [0, 4p), for p >= 2^33: q = floor(hi32(x) * floor(2^64/p) / 2^32) is at most 2.5 below x / p
+// (never above).  4 instructions per value -- the price of dropping the range guard from several inverse stages in a row.
+__device__ __forceinline__ void lite_reduce4(u64 (&x)[4], u32 mu, const PrimeConst &c) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const u32 q = (u32)(((u64)hi32(x[i]) * mu) >> 32);
+        x[i] += (u64)q * c.negp;
+    }
+}
 // final normalisations to the canonical residue, four values at a time
 __device__ __forceinline__ void reduce4_from_8p(u64 (&x)[4], const PrimeConst &c) { csub4(x, c.four_p); csub4(x, c.two_p); csub4(x, c.p); }
 __device__ __forceinline__ void reduce4_from_4p(u64 (&x)[4], const PrimeConst &c) { csub4(x, c.two_p); csub4(x, c.p); }

@@ -156,10 +156,16 @@ template <int G, int R, bool LEAN, bool UNI, class TW> __device__ __forceinline_
     }
 }
 // ---- R inverse stages (gaps grow: 1, 2, ..); LAST: the final stage of the transform (N^-1 folded in, tw gives the scaled twiddle)
-template <int G, int R, bool LAST, bool UNI, class TW> __device__ __forceinline__ void inv_stages(u64 (&y)[G << R], const TW &tw, const Shoup inv_n, const PrimeConst &pc) {
+// B0 = 0: guarded butterflies, values in [0,4p) throughout.  B0 > 0 ("lean", primes in [2^33, 2^58)): the inputs are below B0 p and
+// nothing is subtracted conditionally: a sum output doubles the bound per stage, a difference output leaves its multiplication in
+// [0,3p); a stage accepts inputs up to 32p (X + kp - Y with kp = the bound must stay below 64p < 2^64), so the bound may reach 64p at
+// the END of a round, where the caller brings it back with lite_reduce4 -- or, in the last round, where the N^-1 multiplication does.
+template <int G, int R, bool LAST, bool UNI, int B0 = 0, class TW> __device__ __forceinline__ void inv_stages(u64 (&y)[G << R], const TW &tw, const Shoup inv_n, const PrimeConst &pc) {
+    int bound = B0;
 #pragma unroll
     for (int st = 0; st < R; st++) {
         const int dist = 1 << st;
+        const bool halve = B0 && 2 * bound > 32 && st != R - 1; // the next stage could not take 2 * bound
 #pragma unroll
         for (int c = 0; c < (G << (R - 1)) / 4; c++) {
             u64 X[4], Y[4];
@@ -174,11 +180,18 @@ template <int G, int R, bool LAST, bool UNI, class TW> __device__ __forceinline_
                 Y[i] = y[ix[i] + dist];
                 w[i] = tw(st, g, blk);
             }
-            if (LAST && st == R - 1) gs_bfly4_last<UNI>(X, Y, w, inv_n, pc); else gs_bfly4<UNI>(X, Y, w, pc);
+            if (B0) {
+                const u64 kp = pc.p * (u64)bound;
+                if (LAST && st == R - 1) gs_bfly4_last_ng<UNI>(X, Y, w, inv_n, kp, pc);
+                else gs_bfly4_ng<UNI>(X, Y, w, kp, pc);
+                if (halve) csub4(X, kp);
+            } else if (LAST && st == R - 1) gs_bfly4_last<UNI>(X, Y, w, inv_n, pc);
+            else gs_bfly4<UNI>(X, Y, w, pc);
 #pragma unroll
             for (int i = 0; i < 4; i++) { y[ix[i]] = X[i]; y[ix[i] + dist] = Y[i]; }
             N1_SCHED_FENCE();
         }
+        if (!halve) bound = 2 * bound > 3 ? 2 * bound : 3; // a difference output is below 3p whatever came in
     }
 }
 
@@ -356,7 +369,7 @@ template <bool LEAN> __global__ __launch_bounds__(N1_THREADS) void ntt1_fwd_kern
 
 // the first 10 inverse stages (14..5) of sub-block sb: input y (this lane's coefficients 8 u + r, u = lane + 64 i, in y[8 i + r]),
 // result left in the wave's region (position sw1(j))
-__device__ __forceinline__ void inv_subblock(u64 (&yin)[16], u64 *R, const unsigned sb, const unsigned lane_in, const PrimeDesc &pd, const PrimeConst &pc) {
+template <bool LEAN> __device__ __forceinline__ void inv_subblock(u64 (&yin)[16], u64 *R, const unsigned sb, const unsigned lane_in, const PrimeDesc &pd, const PrimeConst &pc) {
     const Shoup none{0, 0};
     const unsigned lane = opaque(lane_in);
     // round D': stages 14, 13, 12 on 8 consecutive coefficients
@@ -373,7 +386,7 @@ __device__ __forceinline__ void inv_subblock(u64 (&yin)[16], u64 *R, const unsig
 #pragma unroll
         for (int i = 0; i < 2; i++) t13[i] = ld_tw(pd.iroot, 16385 + 2 * b12 + i);
         const Shoup t12 = ld_tw(pd.iroot, 24577 + b12);
-        inv_stages<1, 3, false, false>(y, [&](int st, int, int blk) { return st == 0 ? t14[blk] : (st == 1 ? t13[blk] : t12); }, none, pc);
+        inv_stages<1, 3, false, false, LEAN ? 2 : 0>(y, [&](int st, int, int blk) { return st == 0 ? t14[blk] : (st == 1 ? t13[blk] : t12); }, none, pc); // inputs below 2p (stored limbs are canonical) -> 16p
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             ulonglong2 v;
@@ -398,7 +411,7 @@ __device__ __forceinline__ void inv_subblock(u64 (&yin)[16], u64 *R, const unsig
             u64 y[8];
 #pragma unroll
             for (int r = 0; r < 8; r++) y[r] = R[sw1(64 * h + 8 * r + 4 * it + low)];
-            inv_stages<1, 3, false, false>(y, [&](int st, int, int blk) { return st == 0 ? t11[blk] : (st == 1 ? t10[blk] : t9); }, none, pc);
+            inv_stages<1, 3, false, false, LEAN ? 16 : 0>(y, [&](int st, int, int blk) { return st == 0 ? t11[blk] : (st == 1 ? t10[blk] : t9); }, none, pc); // 16p -> 32p -> (halved) 32p -> 64p
 #pragma unroll
             for (int r = 0; r < 8; r++) R[sw1(64 * h + 8 * r + 4 * it + low)] = y[r];
         }
@@ -408,13 +421,22 @@ __device__ __forceinline__ void inv_subblock(u64 (&yin)[16], u64 *R, const unsig
         u64 y[16];
 #pragma unroll
         for (int r = 0; r < 16; r++) y[r] = R[sw1(64 * r + lane)];
-        inv_stages<1, 4, false, true>(y, [&](int st, int, int blk) { return ld_tw_uniform(pd.iroot + (N1_N - (512u >> st) + 1) + ((8 * sb) >> st) + blk); }, none, pc);
+        if (LEAN) { // 64p -> 4p, then four stages -> 64p
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                u64 v[4] = {y[4 * q], y[4 * q + 1], y[4 * q + 2], y[4 * q + 3]};
+                lite_reduce4(v, (u32)pd.cr1, pc);
+#pragma unroll
+                for (int i = 0; i < 4; i++) y[4 * q + i] = v[i];
+            }
+        }
+        inv_stages<1, 4, false, true, LEAN ? 4 : 0>(y, [&](int st, int, int blk) { return ld_tw_uniform(pd.iroot + (N1_N - (512u >> st) + 1) + ((8 * sb) >> st) + blk); }, none, pc);
 #pragma unroll
         for (int r = 0; r < 16; r++) R[sw1(64 * r + lane)] = y[r];
     }
 }
 
-__global__ __launch_bounds__(N1_THREADS) void ntt1_inv_kernel(Ntt1Args a) {
+template <bool LEAN> __global__ __launch_bounds__(N1_THREADS) void ntt1_inv_kernel(Ntt1Args a) {
     __shared__ __attribute__((aligned(16))) u64 lds[16 * 1024];
     const unsigned tid = threadIdx.x, lane = tid & 63;
 #ifdef TROYHIP_CPU_EMUL
@@ -459,18 +481,19 @@ __global__ __launch_bounds__(N1_THREADS) void ntt1_inv_kernel(Ntt1Args a) {
         u64 y[16], y1[16];
         load16(y1, row + 1024 * (16 + wv)); // second half's input: in flight while the first half is transformed
         TROY_WAIT_VMEM();                   // the staged first half has landed (vmcnt counts in order: this also waits for y1 -- see below)
+        const unsigned ol = opaque(lane);   // recomputed per row: hoisted out of the loop these eight addresses are spilled
 #pragma unroll
         for (int i = 0; i < 2; i++)
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(region + sw1(8 * (lane + 64 * i) + 2 * q));
+                const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(region + sw1(8 * (ol + 64 * i) + 2 * q));
                 y[8 * i + 2 * q] = v.x;
                 y[8 * i + 2 * q + 1] = v.y;
             }
         TROY_WAVE_SYNC();
 #pragma unroll
         for (int hf = 0; hf < 2; hf++) {
-            inv_subblock(hf ? y1 : y, region, 16 * hf + wv, lane, pd, pc);
+            inv_subblock<LEAN>(hf ? y1 : y, region, 16 * hf + wv, lane, pd, pc);
             __syncthreads();
 #pragma unroll
             for (int r = 0; r < 8; r++) { x[16 * hf + r] = rlo[1024 * r]; x[16 * hf + 8 + r] = rhi[1024 * r]; }
@@ -478,7 +501,16 @@ __global__ __launch_bounds__(N1_THREADS) void ntt1_inv_kernel(Ntt1Args a) {
         }
         if (mm + 1 < m_end) stage_issue(a.data + row_of(mm + 1) + 1024 * wv); // the regions are free during round A'
         // round A': stages 4..0 across the 32 sub-blocks, N^-1 folded into the last one
-        inv_stages<1, 5, true, true>(x, [&](int st, int, int blk) { return st == 4 ? pd.iroot_last_scaled : ld_tw_uniform((pd.iroot + (N1_N - (32u >> st) + 1) + blk)); }, pd.inv_n, pc);
+        if (LEAN) { // 64p -> 4p; the five stages reach 32p after three, the fourth halves its sums, the last one multiplies everything by N^-1
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                u64 v[4] = {x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]};
+                lite_reduce4(v, (u32)pd.cr1, pc);
+#pragma unroll
+                for (int i = 0; i < 4; i++) x[4 * q + i] = v[i];
+            }
+        }
+        inv_stages<1, 5, true, true, LEAN ? 4 : 0>(x, [&](int st, int, int blk) { return st == 4 ? pd.iroot_last_scaled : ld_tw_uniform((pd.iroot + (N1_N - (32u >> st) + 1) + blk)); }, pd.inv_n, pc);
 #pragma unroll
         for (int q = 0; q < 8; q++) {
             u64 v[4] = {x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]};
@@ -523,10 +555,15 @@ void launch_ntt1(u64 *data, const u64 *src, const PrimeDesc *primes, const LimbM
     if (forced_rpw) rpw = forced_rpw;
     a.rows_per_wg = rpw;
     a.chunks = (a.m_total + rpw - 1) / rpw;
-    if (inverse) {
-        a.nslots = map.period;
-        for (unsigned i = 0; i < map.period; i++) a.slots[i] = (uint8_t)i;
-        TROY_LAUNCH(HIP_KERNEL_NAME(ntt1_inv_kernel), dim3(a.nslots * a.chunks), dim3(N1_THREADS), 0, stream, a);
+    if (inverse) { // same split by prime class as the forward transform below; the lean form takes canonical inputs (every stored limb is)
+        for (int lean = 1; lean >= 0; lean--) {
+            a.nslots = 0;
+            for (unsigned i = 0; i < map.period; i++)
+                if ((int)((map.lean >> i) & 1) == lean) a.slots[a.nslots++] = (uint8_t)i;
+            if (!a.nslots) continue;
+            if (lean) TROY_LAUNCH(HIP_KERNEL_NAME(ntt1_inv_kernel<true>), dim3(a.nslots * a.chunks), dim3(N1_THREADS), 0, stream, a);
+            else TROY_LAUNCH(HIP_KERNEL_NAME(ntt1_inv_kernel<false>), dim3(a.nslots * a.chunks), dim3(N1_THREADS), 0, stream, a);
+        }
         launch_check("ntt1_inv_kernel");
         return;
     }
