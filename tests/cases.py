@@ -555,11 +555,12 @@ def check_ckks_conv2d_helper(N=4096, bits=(40, 30, 30, 40), batch=2, image=(12, 
 
 def check_bfv_multiply_limb_count(K, N=256, batch=2, seed=900, big=False):
     """BFV multiply (both BEHZ kernels) at L = K - 1 limbs against the oracle: L runs over every k-block count of the matrix-core
-    kernels and, past 15 limbs, over the VALU kernels.  big=False: 40/45-bit primes (the q side of Shenoy-Kumaresan takes the two-word
-    reduction), big=True: 55/60-bit primes (one-step quotient estimate everywhere, the headline's case).  The last batch items are
-    extreme inputs: every residue p - 1, and a 0 / 1 pattern."""
+    kernels and, past 15 limbs, over the VALU kernels.  big=False: 40/45-bit primes (6 digit rows per q-side output), big=True:
+    55/60-bit primes (the headline's case), big="small": 30/32-bit primes (below 2^33 the q side of Shenoy-Kumaresan takes the
+    two-word reduction).  The last batch items are extreme inputs: every residue p - 1, and a 0 / 1 pattern."""
     from troy_amd import api, synth
-    cfg = dict(scheme=BFV, N=N, bits=([60] + [55] * (K - 2) + [60]) if big else ([45] + [40] * (K - 2) + [45]), tbits=14)
+    bits = {True: [60] + [55] * (K - 2) + [60], False: [45] + [40] * (K - 2) + [45], "small": [32] + [30] * (K - 2) + [32]}[big]
+    cfg = dict(scheme=BFV, N=N, bits=bits, tbits=14)
     be, ob = GpuBackend(cfg), oracle_backend(cfg)
     L = K - 1
     xa, xb = synth.uniform_ct(seed + K, be.primes[:L], 2, N, batch + 2), synth.uniform_ct(seed + 50 + K, be.primes[:L], 2, N, batch + 2)

@@ -93,7 +93,7 @@ def test_emulated_general_sizes(name, emul_api):
     cases.check_general_sizes(name, batch=2)
 
 
-@pytest.mark.parametrize("K,big", [(2, True), (5, False), (6, True), (12, True), (15, False), (16, True), (17, True)])
+@pytest.mark.parametrize("K,big", [(2, True), (5, False), (6, True), (9, "small"), (12, True), (15, False), (16, True), (17, True)])
 def test_emulated_bfv_multiply_limb_counts(K, big, emul_api, oracle_lib):
     """both BEHZ kernels against the oracle at limb counts that cover the k-block counts of the 8-shift matrix-core form
     (behz2.hip; L = 1, 4, 5, 11, 14, 15), its two q-side reductions, extreme residues, and the VALU kernels at L = 16"""

@@ -453,11 +453,11 @@ def test_conv2d_helper(gpu):
     assert h.blocked
 
 
-@pytest.mark.parametrize("big", [False, True])
+@pytest.mark.parametrize("big", [False, True, "small"])
 @pytest.mark.parametrize("K", list(range(2, 19)))
 def test_bfv_multiply_every_limb_count(K, big, gpu, oracle_lib):
-    """BEHZ kernels at L = 1 .. 17: every k-block count of the matrix-core form, both reductions of its q-side outputs (primes below and
-    above 2^50), extreme residues, VALU kernels past 15 limbs"""
+    """BEHZ kernels at L = 1 .. 17: every k-block count of the matrix-core form, 30/32-, 40/45- and 55/60-bit primes (4 to 8 digit rows
+    per output, the two-word reduction below 2^33), extreme residues, VALU kernels past 15 limbs"""
     cases.check_bfv_multiply_limb_count(K, big=big)
 
 

@@ -8,11 +8,11 @@
 // first MFMA form), the host reduces every column of the digit expansion:
 //     out_o = ( sum_{l,k} d_{l,k} * W[o][l][k] ) mod p_o,      W[o][l][k] = M[o][l] 2^(8k) mod p_o  (< 2^61, eight digits)
 // so row (o, s) of the int8 matrix is digit s of W -- EIGHT shifts per output.  That halves the v_mfma_i32_32x32x32_i8 count
-// (a 32-row block is 4 outputs, not 2) and bounds the recombined sum by 2^77.4: with a bias (a multiple of p_o) it is a
-// non-negative V < 2^79.1 and ONE 32-bit quotient estimate reduces it:
-//     q^ = mulhi32(V >> 48, floor(2^80 / p)),   r = (V - q^ p) mod 2^64 in [0, 2p),   one conditional subtraction
-// (error of q^ below 2^48/p + 0.51 < 0.76 for p >= 2^50).  Recombine + reduce is ~20 VALU instructions per output instead
-// of ~85; the kernels are VALU-issue bound (profiles/r01_behz_probe.txt), so that is where the time goes.
+// (a 32-row block is 4 outputs, not 2) and bounds the recombined sum by 2^(8 nd + 13.4), nd <= 8 the digit count of a residue of
+// p_o: with a bias (a multiple of p_o) it is a non-negative V < 2^(8 nd + 15.1) and ONE 32-bit quotient estimate reduces it:
+//     q^ = mulhi32(V >> sh, floor(2^(sh+32) / p)),  sh = bitlen(p) - 2,   r = (V - q^ p) mod 2^64 in [0, 2p),   one conditional subtraction
+// (V >> sh < 2^25.1; error of q^ below 2^sh/p + 2^-6.9 < 0.51, for every prime >= 2^33).  Recombine + reduce is ~20 VALU instructions
+// per output instead of ~85; the kernels are VALU-issue bound (profiles/r01_behz_probe.txt), so that is where the time goes.
 // The per-coefficient correction terms are extra INPUT columns of the product: the centred m_tilde residue r against
 // q m_tilde^-1 (extension), the centred alpha against -(B mod q_l) (Shenoy-Kumaresan), at limb position L (nB) of the digit
 // matrix -- patched into the B fragment in registers, whatever L mod 4 is.  B^-1 mod m_sk is folded into the m_sk rows of both
@@ -65,23 +65,24 @@ __device__ __forceinline__ void b2_zero(MfmaAcc &a) {
 // V = lo + top 2^64 (top < 2^16): the biased sum of one output
 struct B2Sum { u64 lo; u32 top; };
 // sum_s C_s 2^(8s) over accumulator registers BASE .. BASE + 7 (|C_s| < 2^21.4), plus `addend` (>= 2^46, < 2^63) into the low
-// half and 2^46 into the high half: both halves stay positive, so the words combine without sign handling
-template <int BASE> __device__ __forceinline__ B2Sum b2_recombine(const MfmaAcc &a, u64 addend) {
+// half and `bias1` (at least the magnitude of the high half) into the high half: both halves stay positive, so the words combine
+// without sign handling
+template <int BASE> __device__ __forceinline__ B2Sum b2_recombine(const MfmaAcc &a, u64 addend, u64 bias1) {
     const int p01 = a.v[BASE] + (a.v[BASE + 1] << 8), p23 = a.v[BASE + 2] + (a.v[BASE + 3] << 8);
     const int p45 = a.v[BASE + 4] + (a.v[BASE + 5] << 8), p67 = a.v[BASE + 6] + (a.v[BASE + 7] << 8);
     const u64 w0 = (u64)b2_mad(p01, 1, b2_mad(p23, 1 << 16, (long long)addend));
-    const u64 w1 = (u64)b2_mad(p45, 1, b2_mad(p67, 1 << 16, (long long)(u64(1) << 46)));
+    const u64 w1 = (u64)b2_mad(p45, 1, b2_mad(p67, 1 << 16, (long long)bias1));
     const u32 w0h = (u32)(w0 >> 32), v1 = w0h + (u32)w1;
     const u32 v2 = (u32)(w1 >> 32) + (v1 < w0h);
     return B2Sum{(u64)(u32)w0 | ((u64)v1 << 32), v2};
 }
 __device__ __forceinline__ u64 b2_reduce(const B2Sum v, const BehzK2 &k) {
-    const u32 vt = (v.top << 16) | (u32)(v.lo >> 48);
+    const u32 vt = (u32)((((u64)v.top << 32) | (v.lo >> 32)) >> k.sh32); // bits sh .. sh + 31 of V (sh >= 32; everything above is zero)
     const u32 qh = (u32)(((u64)vt * k.mu) >> 32);
     const u64 r = v.lo + (u64)qh * k.negp; // V - qh p modulo 2^64: the true value is in [0, 2p)
     return r >= k.p ? r - k.p : r;
 }
-// any output prime (the q side may hold primes below 2^50): the same sum through the two-word reduction of behz.hip
+// output primes below 2^33 (q side only): the same sum through the two-word reduction of behz.hip
 struct B2Slow { u64 p, cr1, two_p, r64_op, r64_quo; };
 __device__ __forceinline__ u64 b2_reduce_slow(const B2Sum v, const B2Slow &k) {
     const u64 a = mul_lazy((u64)v.top, k.r64_op, k.r64_quo, k.p);
@@ -92,7 +93,7 @@ __device__ __forceinline__ u64 b2_reduce_slow(const B2Sum v, const B2Slow &k) {
 }
 template <int BASE> __device__ __forceinline__ u64 b2_finish(const MfmaAcc &acc, u64 addend, const BehzK2 &k) {
     if (B2_EXP & 4) return (u64)(u32)acc.v[BASE] ^ addend ^ ((u64)(u32)acc.v[BASE + 7] << 32);
-    return b2_reduce(b2_recombine<BASE>(acc, addend), k);
+    return b2_reduce(b2_recombine<BASE>(acc, addend, k.bias1), k);
 }
 
 // words of a fragment: limb (4 kb + 2 half + pos) of this lane's coefficient
@@ -347,8 +348,8 @@ template <int KB1, int KB2, bool FAST2> __global__ __launch_bounds__(B2_THREADS)
                     r[0] = b2_finish<0>(acc, k2[0].biaslo, k2[0]);
                     r[1] = b2_finish<8>(acc, k2[1].biaslo, k2[1]);
                 } else {
-                    r[0] = b2_reduce_slow(b2_recombine<0>(acc, k2[0].biaslo), s2[0]);
-                    r[1] = b2_reduce_slow(b2_recombine<8>(acc, k2[1].biaslo), s2[1]);
+                    r[0] = b2_reduce_slow(b2_recombine<0>(acc, k2[0].biaslo, k2[0].bias1), s2[0]);
+                    r[1] = b2_reduce_slow(b2_recombine<8>(acc, k2[1].biaslo, k2[1].bias1), s2[1]);
                 }
             }
 #pragma unroll

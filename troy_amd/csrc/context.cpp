@@ -131,14 +131,18 @@ static std::vector<uint8_t> pack_rows8(const std::vector<std::vector<u64>> &W, c
     return f;
 }
 static BehzK2 make_k2(u64 p) {
-    const u128 base = (u128)1 << 78, target = base + ((u128)1 << 46);
-    const u128 m = (target + p - 1) / p;
+    const int b = 64 - __builtin_clzll(p), nd = std::min(8, b / 8 + 1); // balanced digits 0 .. nd-1 of a residue can be non-zero
     BehzK2 k;
     k.p = p;
     k.negp = 0 - p;
-    k.biaslo = (u64)(m * p - base); // in [2^46, 2^46 + p)
-    k.mu = (u32)std::min<u128>(((u128)1 << 80) / p, 0xFFFFFFFFu);
-    k.pad = 0;
+    // the high half sum_{s>=4} C_s 2^(8(s-4)) is below 2^(21.4 + 8 (nd - 5)) in magnitude, the low half below 2^45.5
+    k.bias1 = u64(1) << (nd >= 5 ? 8 * (nd - 5) + 22 : 22);
+    const u128 hi = (u128)k.bias1 << 32, target = hi + ((u128)1 << 46);
+    const u128 m = (target + p - 1) / p;
+    k.biaslo = (u64)(m * p - hi); // in [2^46, 2^46 + p)
+    const int sh = b - 2;         // 2^sh / p < 1/2: the estimate is at most one below the quotient
+    k.sh32 = sh >= 32 ? (u32)(sh - 32) : 0;
+    k.mu = (u32)std::min<u128>(((u128)1 << (sh + 32)) / p, 0xFFFFFFFFu);
     return k;
 }
 // TROYHIP_BEHZ selects the base-conversion kernels: "valu", "mfma1" (16-shift Toeplitz rows) or, by default, the 8-shift form
@@ -402,7 +406,7 @@ void Context::upload_tables() {
             c->f2_k = upload(f2k, lv.dev_blocks);
             c->msk_k = make_k2(r.m_sk);
             c->f2_fast = 1;
-            for (int l = 0; l < L; l++) c->f2_fast = c->f2_fast && r.q[l] >= (u64(1) << 50);
+            for (int l = 0; l < L; l++) c->f2_fast = c->f2_fast && r.q[l] >= (u64(1) << 33);
             c->v2 = 1;
         }
         c->B2q3 = upload(B2q, lv.dev_blocks);

@@ -119,9 +119,10 @@ void launch_modarith_probe(int op, const u64 *a, const u64 *b, const u64 *c, u64
 // base-change matrix entry split into 21-bit limbs (m = m0 + m1 2^21 + m2 2^42): see behz.hip
 struct Mat3 { u32 m0, m1, m2, pad; };
 
-// epilogue constants of one output prime in the second matrix-core form (behz2.hip): bias = biaslo + 2^78 is a multiple of p,
-// mu = floor(2^80 / p), negp = 2^64 - p
-struct BehzK2 { u64 p, negp, biaslo; u32 mu, pad; };
+// epilogue constants of one output prime in the second matrix-core form (behz2.hip): the bias biaslo + bias1 2^32 is a multiple of
+// p that keeps both halves of the recombined sum positive (bias1 = 2^(8 nd - 18), nd = digit rows of a residue of this prime), the
+// quotient estimate reads 32 bits of the sum from bit sh = bitlen(p) - 2 (sh32 = sh - 32) against mu = floor(2^(sh+32) / p); negp = 2^64 - p
+struct BehzK2 { u64 p, negp, biaslo, bias1; u32 mu, sh32; };
 
 // device-resident constants of one level (built by Context, see context.cpp)
 struct BehzDev {
@@ -156,7 +157,7 @@ struct BehzDev {
     const u64 *prod_B_mod_q;          // [L]
     // --- second matrix-core form (behz2.hip): rows reduced modulo the output prime, 8 byte-shifts per output, a row-block = 4 outputs;
     // fragments [row-block][k-block][lane] x 16 bytes with k-blocks of 4 limbs x 8 digits.  v2 != 0 when built (L <= 15, |Bsk| <= 16)
-    int v2, f2_fast;                  // f2_fast: every q prime >= 2^50 (one-step quotient estimate), else the two-word reduction
+    int v2, f2_fast;                  // f2_fast: every q prime >= 2^33 (one-step quotient estimate), else the two-word reduction
     const void *x_frag;               // extension: [ceil(nBsk/4)][KBx][64], KBx = ceil((L+1)/4): limbs 0..L-1 and the r column at limb L
     const void *x_mt_frag;            // [KBx][64]  the m_tilde row (modulo 2^32, 4 shifts) in both halves of the tile
     const BehzK2 *x_k;                // [nBsk]
