@@ -385,7 +385,13 @@ def algorithmic_bytes(w, B):
         add("ntt2_kernel<1, 0, 9, 0, 0, 0, 0>", inv_rows * 2 * P)
         add(f"ntt2_kernel<1, 1, {k1}, {logc}, 2, 0, 0>", inv_rows * 2 * P)
     else:
-        add("ntt1_inv_kernel", inv_rows * 2 * P)
+        # the single-pass inverse runs as two launches by prime class: guard-free rounds below 2^58, guarded butterflies for the rest
+        qs = [int(p) for p in w.ctx.coeff_modulus]
+        lean_q = sum(1 for p in qs[:L] if (1 << 33) <= p < (1 << 58))          # Bsk primes are 61 bits: guarded
+        lean_k = sum(1 for p in qs[:L + 1] if (1 << 33) <= p < (1 << 58))
+        lean_rows = 3 * B * lean_q + 2 * B * lean_k
+        add("ntt1_inv_kernel<true>", lean_rows * 2 * P)
+        add("ntt1_inv_kernel<false>", (inv_rows - lean_rows) * 2 * P)
     add(f"behz2_floor_sk_kernel<{(L + 3) // 4}, {(nb + 3) // 4}, {fast}>", 3 * B * (2 * L + nb) * P)
     # relinearize: digit decomposition + first pass, second pass with the inner product against the key, inverse, mod-down
     add(f"ntt2_kernel<0, 1, {k1}, {logc}, 0, 1, 0>", B * L * P + B * (L + 1) * L * P)

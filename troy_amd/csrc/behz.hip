@@ -633,6 +633,7 @@ static bool behz_use_mfma() {
     static const bool v = [] { const char *e = getenv("TROYHIP_BEHZ"); return !(e && e[0] == 'v'); }();
     return v;
 }
+bool behz_floor_prescaled(const BehzDev &c) { return c.v2 && c.floor_desc && behz_use_mfma(); }
 void launch_behz_extend(const u64 *in, u64 in_pstride, u64 *out, u64 out_pstride, const PrimeDesc *primes, const BehzDev &c, u64 N, u64 polys, hipStream_t s) {
     if (!polys) return;
     if (c.v2 && behz_use_mfma()) return launch_behz2_extend(in, in_pstride, out, out_pstride, primes, c, N, polys, s);

@@ -212,8 +212,9 @@ template <int KB> __global__ __launch_bounds__(B2_THREADS) void behz2_extend_ker
 }
 
 // ---------------------------------------------------------------- floor + Shenoy-Kumaresan (fastFloor + fastbconvSk)
-// dq [polys][L][N], db [polys][nBsk][N] (any representative < 2^64) -> out [polys][L][N].  Two chained products per tile:
-//   (1) rows of f1_frag x digits(y), + db_o T_o  ->  u_b (digits, LDS) for o < nB, and z' = z_sk B^-1 mod m_sk
+// y [polys][L][N], dbt [polys][nBsk][N] -> out [polys][L][N], inputs PRE-SCALED and canonical: y_l = t dq_l (q/q_l)^-1 mod q_l and
+// dbt_o = db_o T_o mod Bsk_o, which the inverse transforms in front deliver for free (BehzDev::floor_desc).  Two chained products per tile:
+//   (1) rows of f1_frag x digits(y), + dbt_o  ->  u_b (digits, LDS) for o < nB, and z' = z_sk B^-1 mod m_sk
 //   (2) the m_sk row x digits(u) -> alpha = conv' - z' (every wave, for its own lanes), then rows of f2_frag x [digits(u), alpha] -> out_l
 // All A fragments stay in registers (one row-block per wave and stage); two barriers per tile.
 template <int KB1, int KB2, bool FAST2> __global__ __launch_bounds__(B2_THREADS) void behz2_floor_sk_kernel(const u64 *dq, u64 dq_pstride, const u64 *db, u64 db_pstride,
@@ -240,14 +241,12 @@ template <int KB1, int KB2, bool FAST2> __global__ __launch_bounds__(B2_THREADS)
         amsk[kb] = b2_frag(c.f2_msk_frag, (size_t)kb * 64 + lane);
     }
     BehzK2 k1[2], k2[2];
-    Shoup t1[2];
     B2Slow s2[2];
 #pragma unroll
     for (int j = 0; j < 2; j++) {
         const int o = 4 * w + 2 * j + (int)half;
         const int oc = o < c.nBsk ? o : c.nBsk - 1, lc = o < c.L ? o : c.L - 1;
         k1[j] = c.f1_k[oc];
-        t1[j] = c.f1_t[oc];
         k2[j] = c.f2_k[lc];
         if (!FAST2) {
             const PrimeDesc &pd = primes[c.q_id[lc]];
@@ -256,16 +255,6 @@ template <int KB1, int KB2, bool FAST2> __global__ __launch_bounds__(B2_THREADS)
     }
     const BehzK2 msk = c.msk_k; // kernel argument: scalar registers
     const B2Patch where = b2_patch_where(c.nB, half);
-    u64 qp[KB1];
-    Shoup qpre[KB1];
-#pragma unroll
-    for (int i = 0; i < KB1; i++) {
-        const int l = w + 4 * i;
-        const int lc = l < c.L ? l : 0;
-        const unsigned id = B2_UNIFORM((unsigned)c.q_id[lc]);
-        qp[i] = ((b2_cu64)&primes[id])[0];
-        qpre[i] = Shoup{((b2_cu64)(c.floor_pre + lc))[0], ((b2_cu64)(c.floor_pre + lc))[1]};
-    }
     // both operands of a tile are fetched while the previous tile is computed: the q residues of this wave's limbs (xr) and the Bsk
     // residues this lane adds in the stage-1 epilogue, (sub, j) -> db[o = 4w + 2j + half][n0 + 32 sub + cl] (dbn)
     u64 xr[KB1], dbn[2][2];
@@ -292,11 +281,11 @@ template <int KB1, int KB2, bool FAST2> __global__ __launch_bounds__(B2_THREADS)
     for (unsigned t = 0; t < tiles_per_wg; t++) {
         const u32 n0 = (blockIdx.x * tiles_per_wg + t) * B2_TILE;
         if (n0 >= n32) break;
-        // y_l = t dq_l (q/q_l)^-1 mod q_l as digits (canonical: the conversion sums the integers)
+        // the digits of y_l (canonical: the conversion sums the integers); a padding limb was loaded as 0
 #pragma unroll
         for (int i = 0; i < KB1; i++) {
             const int l = w + 4 * i;
-            ydig[(((l >> 1) * B2_TILE) + lane) * 2 + (l & 1)] = b2_digits(mul_shoup(xr[i], qpre[i].op, qpre[i].quo, qp[i]));
+            ydig[(((l >> 1) * B2_TILE) + lane) * 2 + (l & 1)] = b2_digits(xr[i]);
         }
         const u64 dbv[2][2] = {{dbn[0][0], dbn[0][1]}, {dbn[1][0], dbn[1][1]}};
         fetch(t + 1 < tiles_per_wg ? t + 1 : 0x7FFFFFu);
@@ -310,8 +299,8 @@ template <int KB1, int KB2, bool FAST2> __global__ __launch_bounds__(B2_THREADS)
                 b2_zero(acc);
 #pragma unroll
                 for (int kb = 0; kb < KB1; kb++) B2_MFMA(af1[kb], b2_frag(ydig, (size_t)(2 * kb + half) * B2_TILE + cc), acc);
-                const u64 r0 = b2_finish<0>(acc, k1[0].biaslo + mul_lazy(dbv[sub][0], t1[0].op, t1[0].quo, k1[0].p), k1[0]);
-                const u64 r1 = b2_finish<8>(acc, k1[1].biaslo + mul_lazy(dbv[sub][1], t1[1].op, t1[1].quo, k1[1].p), k1[1]);
+                const u64 r0 = b2_finish<0>(acc, k1[0].biaslo + dbv[sub][0], k1[0]);
+                const u64 r1 = b2_finish<8>(acc, k1[1].biaslo + dbv[sub][1], k1[1]);
 #pragma unroll
                 for (int j = 0; j < 2; j++) {
                     const int o = 4 * w + 2 * j + (int)half;

@@ -405,6 +405,17 @@ void Context::upload_tables() {
             c->f2_msk_frag = upload(pack_rows8(mskw, mskp, KB2), lv.dev_blocks);
             c->f2_k = upload(f2k, lv.dev_blocks);
             c->msk_k = make_k2(r.m_sk);
+            {   // prime table for the inverse transforms in front of the floor kernel: N^-1 (and the last twiddle, pre-scaled by N^-1) times the
+                // factor the floor step multiplies every input residue by
+                std::vector<PrimeDesc> fd = h_desc;
+                auto scale = [&](PrimeDesc &d, u64 f) {
+                    d.inv_n = make_shoup(host::mul_mod(d.inv_n.op, f % d.p, d.p), d.p);
+                    d.iroot_last_scaled = make_shoup(host::mul_mod(d.iroot_last_scaled.op, f % d.p, d.p), d.p);
+                };
+                for (int l = 0; l < L; l++) scale(fd[l], floor_pre[l].op);
+                for (int o = 0; o < nBsk; o++) scale(fd[lv.bsk_ids[o]], f1t[o].op);
+                c->floor_desc = upload(fd, lv.dev_blocks);
+            }
             c->f2_fast = 1;
             for (int l = 0; l < L; l++) c->f2_fast = c->f2_fast && r.q[l] >= (u64(1) << 33);
             c->v2 = 1;

@@ -195,9 +195,10 @@ void Evaluator::multiply(const CtBatch &a, const CtBatch &b, CtBatch &out, u64 b
             launch_tensor(sa, sb, xq, xq + sa * pw, dq, sp * pw, sp * pw, c.d_desc, qmap, c.logn, L, batch, s);
             launch_tensor(sa, sb, xb, xb + sa * bw, db, sp * bw, sp * bw, c.d_desc, bmap, c.logn, nb, batch, s);
         }
-        // (5) inverse NTT
-        launch_ntt(dq, c.d_desc, qmap, batch * ds * L, c.logn, true, s);
-        launch_ntt(db, c.d_desc, c.ids_map(lv.bsk_ids), batch * ds * nb, c.logn, true, s);
+        // (5) inverse NTT; when the floor kernel takes pre-scaled inputs, the factors of step (6) ride on the N^-1 constants
+        const PrimeDesc *idesc = behz_floor_prescaled(*lv.behz) ? lv.behz->floor_desc : c.d_desc;
+        launch_ntt(dq, idesc, qmap, batch * ds * L, c.logn, true, s);
+        launch_ntt(db, idesc, c.ids_map(lv.bsk_ids), batch * ds * nb, c.logn, true, s);
         // (6)-(8) multiply by t, floor, Shenoy-Kumaresan back to base q
         if (out.bstride == (u64)ds * pw) {
             launch_behz_floor_sk(dq, pw, db, bw, out.data, pw, c.d_desc, *lv.behz, N, batch * ds, s);

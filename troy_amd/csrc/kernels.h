@@ -168,7 +168,12 @@ struct BehzDev {
     const void *f2_msk_frag;          // [KB2][64]  (B/B_b) B^-1 mod m_sk in both halves of the tile
     const BehzK2 *f2_k;               // [L]
     BehzK2 msk_k;
+    // the floor kernel of this form takes its inputs PRE-SCALED: the inverse transforms that produce dq / db run with this copy of the
+    // prime table, whose N^-1 constants carry t (q/q_l)^-1 mod q_l (q limbs) resp. t q^-1 [(B/B_o)^-1 | B^-1] mod Bsk_o (Bsk limbs),
+    // so the per-coefficient multiplications by those factors cost nothing (behz_floor_prescaled() tells the evaluator)
+    const PrimeDesc *floor_desc;
 };
+bool behz_floor_prescaled(const BehzDev &c);
 void launch_behz2_extend(const u64 *in, u64 in_pstride, u64 *out, u64 out_pstride, const PrimeDesc *primes, const BehzDev &c, u64 N, u64 polys, hipStream_t s);
 void launch_behz2_floor_sk(const u64 *dq, u64 dq_pstride, const u64 *db, u64 db_pstride, u64 *out, u64 out_pstride, const PrimeDesc *primes, const BehzDev &c, u64 N,
                            u64 polys, hipStream_t s);
