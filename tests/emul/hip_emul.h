@@ -191,6 +191,9 @@ inline const char *hipGetErrorString(hipError_t) { return "emulated"; }
 inline hipError_t hipGetLastError() { return hipSuccess; }
 inline hipError_t hipSetDevice(int) { return hipSuccess; }
 inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
+inline hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
+enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount = 1 };
+inline hipError_t hipDeviceGetAttribute(int *v, hipDeviceAttribute_t, int) { *v = 4; return hipSuccess; } // a small "chip": the launch planner sees several rounds
 inline hipError_t hipMalloc(void **p, size_t n) { *p = aligned_alloc(256, (n + 255) / 256 * 256); return *p ? hipSuccess : hipErrorInvalidValue; }
 inline hipError_t hipFree(void *p) { free(p); return hipSuccess; }
 inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }

@@ -548,19 +548,34 @@ void launch_ntt1(u64 *data, const u64 *src, const PrimeDesc *primes, const LimbM
     a.primes = primes;
     a.map = map;
     a.m_total = (unsigned)(rows / per_outer * map.inner);
-    // about three workgroups per CU and launch, at most 8 limbs per workgroup (they share the prime: twiddles stay in L1/L2)
-    unsigned rpw = (unsigned)((size_t)a.m_total * map.period / 768);
-    rpw = rpw < 1 ? 1 : (rpw > 8 ? 8 : rpw);
+    // One workgroup fills a CU, so a launch runs in rounds of `cus` workgroups and a round lasts as long as a workgroup's rows (plus
+    // the un-overlapped first load and last store, about a third of a row): pick the rows per workgroup (they share the prime) that
+    // minimises rounds x (rows + 1/3).  A fixed "three workgroups per CU" left mid-size launches with a mostly idle last round.
+    static const unsigned cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        return (unsigned)n;
+    }();
     static const unsigned forced_rpw = [] { const char *e = std::getenv("TROYHIP_NTT1_RPW"); return e ? (unsigned)std::atoi(e) : 0u; }(); // tests: row loop at small batches
-    if (forced_rpw) rpw = forced_rpw;
-    a.rows_per_wg = rpw;
-    a.chunks = (a.m_total + rpw - 1) / rpw;
+    auto plan = [&](unsigned nslots) { // -> rows per workgroup for a launch over `nslots` primes
+        if (forced_rpw) return forced_rpw;
+        unsigned best = 1;
+        double best_cost = 1e30;
+        for (unsigned r = 1; r <= 32 && r <= a.m_total; r++) {
+            const unsigned wgs = nslots * ((a.m_total + r - 1) / r);
+            const double cost = (double)((wgs + cus - 1) / cus) * (r + 0.34);
+            if (cost < best_cost - 1e-9) { best_cost = cost; best = r; }
+        }
+        return best;
+    };
     if (inverse) { // same split by prime class as the forward transform below; the lean form takes canonical inputs (every stored limb is)
         for (int lean = 1; lean >= 0; lean--) {
             a.nslots = 0;
             for (unsigned i = 0; i < map.period; i++)
                 if ((int)((map.lean >> i) & 1) == lean) a.slots[a.nslots++] = (uint8_t)i;
             if (!a.nslots) continue;
+            a.rows_per_wg = plan(a.nslots);
+            a.chunks = (a.m_total + a.rows_per_wg - 1) / a.rows_per_wg;
             if (lean) TROY_LAUNCH(HIP_KERNEL_NAME(ntt1_inv_kernel<true>), dim3(a.nslots * a.chunks), dim3(N1_THREADS), 0, stream, a);
             else TROY_LAUNCH(HIP_KERNEL_NAME(ntt1_inv_kernel<false>), dim3(a.nslots * a.chunks), dim3(N1_THREADS), 0, stream, a);
         }
@@ -579,6 +594,8 @@ void launch_ntt1(u64 *data, const u64 *src, const PrimeDesc *primes, const LimbM
         for (unsigned i = 0; i < map.period; i++)
             if ((int)(!no_lean && ((map.lean >> i) & 1)) == lean) a.slots[a.nslots++] = (uint8_t)i;
         if (!a.nslots) continue;
+        a.rows_per_wg = plan(a.nslots);
+        a.chunks = (a.m_total + a.rows_per_wg - 1) / a.rows_per_wg;
         if (lean) TROY_LAUNCH(HIP_KERNEL_NAME(ntt1_fwd_kernel<true>), dim3(a.nslots * a.chunks), dim3(N1_THREADS), 0, stream, a);
         else TROY_LAUNCH(HIP_KERNEL_NAME(ntt1_fwd_kernel<false>), dim3(a.nslots * a.chunks), dim3(N1_THREADS), 0, stream, a);
         launch_check("ntt1_fwd_kernel");
