@@ -240,6 +240,32 @@ __device__ __forceinline__ void lite_reduce4(u64 (&x)[4], u32 mu, const PrimeCon
         x[i] += (u64)q * c.negp;
     }
 }
+// end of a guard-free forward transform: x < 64p (46p after 15 stages, 59p in the two-pass form), p in [2^33, 2^58) -> canonical.
+// q = floor((x >> sh) * mu / 2^32) with sh = bitlen(p) - 26, mu = floor(2^(sh+32) / p) = floor(2^64 / p) >> (58 - bitlen(p)) is at most
+// one below floor(x / p) (x >> sh < 2^32, so the truncation of mu costs less than 1), never above: one multiply-high, one 64-bit
+// multiply-subtract and one conditional subtraction -- half the instructions of the two-word Barrett step (barrett64)
+struct LeanFinal { unsigned sh; u32 mu; };
+__device__ __forceinline__ LeanFinal make_lean_final(u64 p, u64 cr1) {
+    const int b = 64 - __builtin_clzll(p);
+    return LeanFinal{(unsigned)(b - 26), (u32)(cr1 >> (58 - b))};
+}
+__device__ __forceinline__ void lean_final4(u64 (&x)[4], const LeanFinal f, const PrimeConst &c) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const u32 q = (u32)(((u64)(u32)(x[i] >> f.sh) * f.mu) >> 32);
+        x[i] += (u64)q * c.negp;
+    }
+    csub4(x, c.p);
+}
+template <int NV> __device__ __forceinline__ void lean_final(u64 (&x)[NV], const LeanFinal f, const PrimeConst &c) {
+#pragma unroll
+    for (int h = 0; h < NV / 4; h++) {
+        u64 v[4] = {x[4 * h], x[4 * h + 1], x[4 * h + 2], x[4 * h + 3]};
+        lean_final4(v, f, c);
+#pragma unroll
+        for (int i = 0; i < 4; i++) x[4 * h + i] = v[i];
+    }
+}
 // final normalisations to the canonical residue, four values at a time
 __device__ __forceinline__ void reduce4_from_8p(u64 (&x)[4], const PrimeConst &c) { csub4(x, c.four_p); csub4(x, c.two_p); csub4(x, c.p); }
 __device__ __forceinline__ void reduce4_from_4p(u64 (&x)[4], const PrimeConst &c) { csub4(x, c.two_p); csub4(x, c.p); }

@@ -258,8 +258,7 @@ template <bool LEAN> __device__ __forceinline__ void fwd_subblock(u64 *R, const 
         }
         fwd_stages<1, 3, LEAN, false>(y, [&](int st, int, int blk) { return st == 0 ? t12 : (st == 1 ? t13[blk] : t14[blk]); }, pc);
         if (LEAN) {
-#pragma unroll
-            for (int i = 0; i < 8; i++) y[i] = barrett64(y[i], m);
+            lean_final<8>(y, make_lean_final(m.p, m.cr1), pc);
         } else {
 #pragma unroll
             for (int q = 0; q < 2; q++) {

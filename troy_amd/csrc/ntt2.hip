@@ -289,8 +289,7 @@ template <int INV, int STRIDED, int NS, int LOGC, int LS, int R, bool HOISTP = t
                                                            const Mod &m, u64 *xchg, const bool lean) {
         const PrimeConst pc = make_prime_const(m.p);
         if (lean) { // guard-free transform: values below 59p
-#pragma unroll
-            for (int e = 0; e < 8; e++) x[e] = barrett64(x[e], m);
+            lean_final<8>(x, make_lean_final(m.p, m.cr1), pc);
         } else {
 #pragma unroll
             for (int h = 0; h < 2; h++) {
@@ -375,8 +374,7 @@ template <int INV, int STRIDED, int NS, int LOGC, int LS, int R, bool HOISTP = t
             return;
         }
         if (FINAL == 1 && lean) { // guard-free forward transform: values below 59p
-#pragma unroll
-            for (int e = 0; e < 8; e++) x[e] = barrett64(x[e], m);
+            lean_final<8>(x, make_lean_final(m.p, m.cr1), make_prime_const(p));
         } else if (FINAL) {
             const PrimeConst pc = make_prime_const(p);
 #pragma unroll
