@@ -445,6 +445,7 @@ def check_ckks_matmul_helper(N=4096, bits=(40, 30, 30, 40), batch=3, dims=(128, 
     ctx = api.SEALContext(capi.CKKS, N, primes, 0)
     kg = api.KeyGenerator(ctx, seed=(31, 32))
     enc = api.Encryptor(ctx, kg.createPublicKey())
+    enc.setSecretKey(kg.secretKey())  # the helpers encrypt symmetrically, as the reference's (test/app/linear_ckks.cu:138)
     ev = api.Evaluator(ctx)
     encoder = app.CKKSPolyEncoder(ctx)
     L = len(primes) - 1

@@ -85,6 +85,12 @@ class CKKSPolyEncoder:
         return out
 
 
+def _encrypt(encryptor, plain):
+    """the reference's helpers encrypt with the SECRET key (encryptSymmetric, LinearHelperCKKS.cuh:213-222); an Encryptor that only holds a
+    public key falls back to it"""
+    return encryptor.encryptSymmetric(plain) if getattr(encryptor, "sk", None) is not None else encryptor.encrypt(plain)
+
+
 def _ceil_div(a, b):
     return (a + b - 1) // b
 
@@ -162,7 +168,7 @@ class MatmulHelper:
         out = []
         for lj in range(0, self.inputDims, self.blockHeight):
             uj = min(lj + self.blockHeight, self.inputDims)
-            cts = np.stack([encryptor.encrypt(encoder.encodePolynomial(X[b, lj:uj], limbs, scale)) for b in range(self.batchSize)])
+            cts = np.stack([_encrypt(encryptor, encoder.encodePolynomial(X[b, lj:uj], limbs, scale)) for b in range(self.batchSize)])
             out.append(api.Ciphertext.from_numpy(ctx, cts, True, scale, 1))
         return out
 
@@ -277,7 +283,7 @@ class Conv2dHelper:
         out = []
         for c0 in range(0, self.inputChannels, cs):
             c1 = min(c0 + cs, self.inputChannels)
-            cts = np.stack([encryptor.encrypt(encoder.encodePolynomial(X[b, c0:c1].reshape(-1), limbs, scale)) for b in range(total)])
+            cts = np.stack([_encrypt(encryptor, encoder.encodePolynomial(X[b, c0:c1].reshape(-1), limbs, scale)) for b in range(total)])
             out.append(api.Ciphertext.from_numpy(ctx, cts, True, scale, 1))
         return out
 
