@@ -376,8 +376,10 @@ def algorithmic_bytes(w, B):
     k1 = logn - 9 if logn - 9 <= 7 else 7
     logc = 11 - k1
     # multiply: extension of 4 polynomials, forward first passes (q: consumed in place, Bsk), tensor passes, inverse, floor/SK
-    fast = "true" if all(int(p) >= 1 << 50 for p in w.ctx.coeff_modulus[:L]) else "false"
-    add(f"behz2_extend_kernel<{(L + 4) // 4}>", 2 * 2 * B * (L + nb) * P)
+    fast = "true" if all(int(p) >= 1 << 33 for p in w.ctx.coeff_modulus[:L]) else "false"
+    kbx, kb1, kb2 = (L + 4) // 4, (L + 3) // 4, (nb + 3) // 4  # k-blocks: extension (L limbs + r), floor stage 1, stage 2 (|B| limbs + alpha)
+    small_x, small_f = kbx <= 2 and nb <= 8, kb2 <= 2           # the everything-in-registers kernels of behz2.hip
+    add(f"behz2s_extend_kernel<{kbx}, {(nb + 3) // 4}>" if small_x else f"behz2_extend_kernel<{kbx}>", 2 * 2 * B * (L + nb) * P)
     add(f"ntt2_kernel<0, 1, {k1}, {logc}, 0, 0, 0>", 2 * (2 * B * L) * 2 * P + 2 * (2 * B * nb) * 2 * P)
     add("ntt2_kernel<0, 0, 9, 0, 1, 0, 2>", 7 * B * (L + nb) * P)
     inv_rows = 3 * B * (L + nb) + 2 * B * (L + 1)
@@ -392,7 +394,7 @@ def algorithmic_bytes(w, B):
         lean_rows = 3 * B * lean_q + 2 * B * lean_k
         add("ntt1_inv_kernel<true>", lean_rows * 2 * P)
         add("ntt1_inv_kernel<false>", (inv_rows - lean_rows) * 2 * P)
-    add(f"behz2_floor_sk_kernel<{(L + 3) // 4}, {(nb + 3) // 4}, {fast}>", 3 * B * (2 * L + nb) * P)
+    add(f"behz2{'s' if small_f else ''}_floor_sk_kernel<{kb1}, {kb2}, {fast}>", 3 * B * (2 * L + nb) * P)
     # relinearize: digit decomposition + first pass, second pass with the inner product against the key, inverse, mod-down
     add(f"ntt2_kernel<0, 1, {k1}, {logc}, 0, 1, 0>", B * L * P + B * (L + 1) * L * P)
     add("ntt2_kernel<0, 0, 9, 0, 1, 0, 1>", B * (L + 1) * L * P + 2 * (L + 1) * L * P + 2 * B * (L + 1) * P)

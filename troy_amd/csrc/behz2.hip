@@ -351,17 +351,247 @@ template <int KB1, int KB2, bool FAST2> __global__ __launch_bounds__(B2_THREADS)
     }
 }
 
+// ================================================================ small bases: everything in registers
+// With at most 8 output primes (L <= 7: the default parameter sets up to N = 8192) the row-block partition above leaves waves idle --
+// two row-blocks, four waves.  Here a wave owns 32 COLUMNS of the tile and all row-blocks: each lane loads the residues of its own
+// four limbs (k-block kb, half h: limbs 4kb + 2h, 4kb + 2h + 1) of its own coefficient and builds the B fragments in registers, so
+// there is no LDS, no barrier, and every wave does the same work.  In floor + Shenoy-Kumaresan the stage-1 rows are packed in the
+// order (row-block, half, j) -> output 4 rb + 2 h + j (BehzDev::f1s_frag), so a lane's two finished outputs of row-block rb ARE the
+// two limbs of k-block rb it must feed to stage 2: the second product needs no exchange either (only z' = z_sk B^-1 crosses the
+// halves of the wave, one shuffle).
+#define B2S_TILE 128 // coefficients per workgroup and step: 32 per wave
+
+__device__ __forceinline__ u64 b2_other_half(u64 v) { return __shfl_xor(v, 32); }
+
+// per-lane conversion constants of this lane's limbs (l = 4 kb + 2 half + pos), or a zero factor for padding limbs
+template <int KB> struct B2Limbs { u64 p[KB][2]; Shoup pre[KB][2]; u32 row[KB][2]; };
+
+template <int KB, int RB> __global__ __launch_bounds__(B2_THREADS) void behz2s_extend_kernel(const u64 *in, u64 in_pstride, u64 *out, u64 out_pstride, const PrimeDesc *primes,
+                                                                                            BehzDev c, u64 N, unsigned tiles_per_wg) {
+    const unsigned lane = threadIdx.x & 63, half = lane >> 5, cl = lane & 31;
+    const unsigned w = threadIdx.x >> 6;
+    const u64 poly = blockIdx.y;
+    const BufRsrc rin = make_rsrc(in + poly * in_pstride, (u32)((u64)c.L * N * 8));
+    const BufRsrc rout = make_rsrc(out + poly * out_pstride, (u32)((u64)c.nBsk * N * 8));
+    const u32 n32 = (u32)N;
+    MfmaFrag af[RB][KB], am[KB];
+    BehzK2 k2[RB][2];
+#pragma unroll
+    for (int kb = 0; kb < KB; kb++) {
+        am[kb] = b2_frag(c.x_mt_frag, (size_t)kb * 64 + lane);
+#pragma unroll
+        for (int rb = 0; rb < RB; rb++) af[rb][kb] = b2_frag(c.x_frag, ((size_t)rb * KB + kb) * 64 + lane);
+    }
+#pragma unroll
+    for (int rb = 0; rb < RB; rb++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int o = 4 * rb + 2 * j + (int)half;
+            k2[rb][j] = c.x_k[o < c.nBsk ? o : c.nBsk - 1];
+        }
+    B2Limbs<KB> lm;
+#pragma unroll
+    for (int kb = 0; kb < KB; kb++)
+#pragma unroll
+        for (int pos = 0; pos < 2; pos++) {
+            const int l = 4 * kb + 2 * (int)half + pos;
+            const bool real = l < c.L;
+            lm.p[kb][pos] = primes[c.q_id[real ? l : 0]].p;
+            lm.pre[kb][pos] = real ? c.ext_pre[l] : Shoup{0, 0};
+            lm.row[kb][pos] = real ? (u32)l : 0xFFFFFFFFu;
+        }
+    const B2Patch where = b2_patch_where(c.L, half);
+    u64 xr[KB][2];
+    auto fetch = [&](unsigned t) {
+        const u32 n = (blockIdx.x * tiles_per_wg + t) * B2S_TILE + 32 * w + cl;
+#pragma unroll
+        for (int kb = 0; kb < KB; kb++)
+#pragma unroll
+            for (int pos = 0; pos < 2; pos++)
+                xr[kb][pos] = buf_load_u64(rin, (lm.row[kb][pos] != 0xFFFFFFFFu && n < n32) ? (lm.row[kb][pos] * n32 + n) * 8u : TROY_BUF_OOB);
+    };
+    fetch(0);
+    for (unsigned t = 0; t < tiles_per_wg; t++) {
+        const u32 n = (blockIdx.x * tiles_per_wg + t) * B2S_TILE + 32 * w + cl;
+        if ((blockIdx.x * tiles_per_wg + t) * B2S_TILE >= n32) break;
+        MfmaFrag bf[KB];
+#pragma unroll
+        for (int kb = 0; kb < KB; kb++)
+#pragma unroll
+            for (int pos = 0; pos < 2; pos++)
+                frag_set_word(bf[kb], pos, b2_digits(mul_shoup(xr[kb][pos], lm.pre[kb][pos].op, lm.pre[kb][pos].quo, lm.p[kb][pos]))); // padding limb: 0 * 0
+        fetch(t + 1 < tiles_per_wg ? t + 1 : 0x3FFFFFu);
+        MfmaAcc acc;
+        b2_zero(acc);
+#pragma unroll
+        for (int kb = 0; kb < KB; kb++) B2_MFMA(am[kb], bf[kb], acc);
+        const u32 rsum = (u32)acc.v[0] + ((u32)acc.v[1] << 8) + ((u32)acc.v[2] << 16) + ((u32)acc.v[3] << 24);
+        const u64 r_mt = ((u64)rsum * c.neg_inv_q_mod_mt) & 0xFFFFFFFFull;
+        b2_patch(bf[KB - 1], where, b2_digits((u64)((long long)r_mt - (long long)((r_mt >> 31) << 32))));
+#pragma unroll
+        for (int rb = 0; rb < RB; rb++) {
+            b2_zero(acc);
+#pragma unroll
+            for (int kb = 0; kb < KB; kb++) B2_MFMA(af[rb][kb], bf[kb], acc);
+            const u64 r0 = b2_finish<0>(acc, k2[rb][0].biaslo, k2[rb][0]), r1 = b2_finish<8>(acc, k2[rb][1].biaslo, k2[rb][1]);
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const u32 o = 4 * (u32)rb + 2 * j + half;
+                buf_store_u64(rout, (o < (u32)c.nBsk && n < n32) ? (o * n32 + n) * 8u : TROY_BUF_OOB, j ? r1 : r0);
+            }
+        }
+    }
+}
+
+// KB1 = k-blocks of the q side (= row-blocks of stage 2), KB2 = k-blocks of the B side + alpha (= row-blocks of stage 1)
+template <int KB1, int KB2, bool FAST2> __global__ __launch_bounds__(B2_THREADS) void behz2s_floor_sk_kernel(const u64 *dq, u64 dq_pstride, const u64 *db, u64 db_pstride,
+                                                                                                            u64 *out, u64 out_pstride, const PrimeDesc *primes, BehzDev c,
+                                                                                                            u64 N, unsigned tiles_per_wg) {
+    const unsigned lane = threadIdx.x & 63, half = lane >> 5, cl = lane & 31;
+    const unsigned w = threadIdx.x >> 6;
+    const u64 poly = blockIdx.y;
+    const BufRsrc rq = make_rsrc(dq + poly * dq_pstride, (u32)((u64)c.L * N * 8));
+    const BufRsrc rb_ = make_rsrc(db + poly * db_pstride, (u32)((u64)c.nBsk * N * 8));
+    const BufRsrc rout = make_rsrc(out + poly * out_pstride, (u32)((u64)c.L * N * 8));
+    const u32 n32 = (u32)N;
+    MfmaFrag af1[KB2][KB1], af2[KB1][KB2], amsk[KB2];
+    BehzK2 k1[KB2][2], k2[KB1][2];
+    B2Slow s2[KB1][2];
+#pragma unroll
+    for (int kb = 0; kb < KB2; kb++) amsk[kb] = b2_frag(c.f2_msk_frag, (size_t)kb * 64 + lane);
+#pragma unroll
+    for (int rb = 0; rb < KB2; rb++) {
+#pragma unroll
+        for (int kb = 0; kb < KB1; kb++) af1[rb][kb] = b2_frag(c.f1s_frag, ((size_t)rb * KB1 + kb) * 64 + lane);
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int o = 4 * rb + 2 * (int)half + j; // the permuted stage-1 order
+            k1[rb][j] = c.f1_k[o < c.nBsk ? o : c.nBsk - 1];
+        }
+    }
+#pragma unroll
+    for (int rb = 0; rb < KB1; rb++) {
+#pragma unroll
+        for (int kb = 0; kb < KB2; kb++) af2[rb][kb] = b2_frag(c.f2_frag, ((size_t)rb * KB2 + kb) * 64 + lane);
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+            const int l = 4 * rb + 2 * j + (int)half, lc = l < c.L ? l : c.L - 1;
+            k2[rb][j] = c.f2_k[lc];
+            if (!FAST2) {
+                const PrimeDesc &pd = primes[c.q_id[lc]];
+                s2[rb][j] = B2Slow{pd.p, pd.cr1, pd.two_p, pd.r64.op, pd.r64.quo};
+            }
+        }
+    }
+    const BehzK2 msk = c.msk_k;
+    const B2Patch where = b2_patch_where(c.nB, half);
+    u64 xr[KB1][2], dbn[KB2][2];
+    auto fetch = [&](unsigned t) {
+        const u32 n = (blockIdx.x * tiles_per_wg + t) * B2S_TILE + 32 * w + cl;
+#pragma unroll
+        for (int kb = 0; kb < KB1; kb++)
+#pragma unroll
+            for (int pos = 0; pos < 2; pos++) {
+                const u32 l = 4 * (u32)kb + 2 * half + pos;
+                xr[kb][pos] = buf_load_u64(rq, (l < (u32)c.L && n < n32) ? (l * n32 + n) * 8u : TROY_BUF_OOB);
+            }
+#pragma unroll
+        for (int rb = 0; rb < KB2; rb++)
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const u32 o = 4 * (u32)rb + 2 * half + j;
+                dbn[rb][j] = buf_load_u64(rb_, (o < (u32)c.nBsk && n < n32) ? (o * n32 + n) * 8u : TROY_BUF_OOB);
+            }
+    };
+    fetch(0);
+    for (unsigned t = 0; t < tiles_per_wg; t++) {
+        const u32 n = (blockIdx.x * tiles_per_wg + t) * B2S_TILE + 32 * w + cl;
+        if ((blockIdx.x * tiles_per_wg + t) * B2S_TILE >= n32) break;
+        MfmaFrag bf1[KB1], bf2[KB2];
+#pragma unroll
+        for (int kb = 0; kb < KB1; kb++)
+#pragma unroll
+            for (int pos = 0; pos < 2; pos++) frag_set_word(bf1[kb], pos, b2_digits(xr[kb][pos])); // pre-scaled, canonical; padding limbs loaded as 0
+        u64 dbv[KB2][2];
+#pragma unroll
+        for (int rb = 0; rb < KB2; rb++) { dbv[rb][0] = dbn[rb][0]; dbv[rb][1] = dbn[rb][1]; }
+        fetch(t + 1 < tiles_per_wg ? t + 1 : 0x3FFFFFu);
+        // ---- stage 1: this lane's outputs 4 rb + 2 half + j become limbs 4 rb + 2 half + j of its stage-2 operand
+        u64 z = 0;
+        MfmaAcc acc;
+#pragma unroll
+        for (int rb = 0; rb < KB2; rb++) {
+            b2_zero(acc);
+#pragma unroll
+            for (int kb = 0; kb < KB1; kb++) B2_MFMA(af1[rb][kb], bf1[kb], acc);
+            const u64 r0 = b2_finish<0>(acc, k1[rb][0].biaslo + dbv[rb][0], k1[rb][0]), r1 = b2_finish<8>(acc, k1[rb][1].biaslo + dbv[rb][1], k1[rb][1]);
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const int o = 4 * rb + 2 * (int)half + j;
+                const u64 r = j ? r1 : r0;
+                frag_set_word(bf2[rb], j, o < c.nB ? b2_digits(r) : 0);
+                if (o == c.nB) z = r;
+            }
+        }
+        // z' sits in the lanes of one half (the one that owns output nB): the other half of the wave fetches it
+        {
+            const bool mine = half == (unsigned)((c.nB & 3) >> 1);
+            const u64 other = b2_other_half(z);
+            z = mine ? z : other;
+        }
+        // ---- stage 2
+        b2_zero(acc);
+#pragma unroll
+        for (int kb = 0; kb < KB2; kb++) B2_MFMA(amsk[kb], bf2[kb], acc);
+        const u64 conv = b2_finish<0>(acc, msk.biaslo, msk);
+        const u64 alpha = conv >= z ? conv - z : conv + msk.p - z;
+        const bool neg = alpha > (msk.p >> 1);
+        b2_patch(bf2[KB2 - 1], where, b2_digits(neg ? alpha - msk.p : alpha));
+#pragma unroll
+        for (int rb = 0; rb < KB1; rb++) {
+            b2_zero(acc);
+#pragma unroll
+            for (int kb = 0; kb < KB2; kb++) B2_MFMA(af2[rb][kb], bf2[kb], acc);
+            u64 r0, r1;
+            if (FAST2) {
+                r0 = b2_finish<0>(acc, k2[rb][0].biaslo, k2[rb][0]);
+                r1 = b2_finish<8>(acc, k2[rb][1].biaslo, k2[rb][1]);
+            } else {
+                r0 = b2_reduce_slow(b2_recombine<0>(acc, k2[rb][0].biaslo, k2[rb][0].bias1), s2[rb][0]);
+                r1 = b2_reduce_slow(b2_recombine<8>(acc, k2[rb][1].biaslo, k2[rb][1].bias1), s2[rb][1]);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const u32 l = 4 * (u32)rb + 2 * j + half;
+                buf_store_u64(rout, (l < (u32)c.L && n < n32) ? (l * n32 + n) * 8u : TROY_BUF_OOB, j ? r1 : r0);
+            }
+        }
+    }
+}
+
 static unsigned b2_tiles_per_wg(u64 tiles) { return tiles >= 64 ? B2_TPW : 1; }
+// small-base kernels: a wave takes 32 columns per step, so the per-workgroup setup (fragments, per-lane constants) wants more steps
+static unsigned b2s_tiles_per_wg(u64 tiles) { return tiles >= 64 ? 16u : (tiles >= 16 ? (unsigned)(tiles / 4) : 1u); } // 8 / 16 / 32 / 64 at N = 8192: 389 / 352 / 347 / 390 us
 
 void launch_behz2_extend(const u64 *in, u64 in_pstride, u64 *out, u64 out_pstride, const PrimeDesc *primes, const BehzDev &c, u64 N, u64 polys, hipStream_t s) {
-    const u64 tiles = ceil_div(N, (u64)B2_TILE);
-    const unsigned tpw = b2_tiles_per_wg(tiles);
     const int kb = (c.L + 1 + 3) / 4;
+    const bool small = c.f1s_frag && kb <= 2 && c.nBsk <= 8; // everything-in-registers form
+    const u64 tiles = ceil_div(N, (u64)(small ? B2S_TILE : B2_TILE));
+    const unsigned tpw = small ? b2s_tiles_per_wg(tiles) : b2_tiles_per_wg(tiles);
     for (u64 p0 = 0; p0 < polys; p0 += 65535) { // gridDim.y limit
         const u64 np = polys - p0 < 65535 ? polys - p0 : 65535;
         const dim3 grid((unsigned)ceil_div(tiles, (u64)tpw), (unsigned)np);
         const u64 *pi = in + p0 * in_pstride;
         u64 *po = out + p0 * out_pstride;
+#define B2S_EXT(KB_, RB_) TROY_LAUNCH(HIP_KERNEL_NAME(behz2s_extend_kernel<KB_, RB_>), grid, dim3(B2_THREADS), 0, s, pi, in_pstride, po, out_pstride, primes, c, N, tpw)
+        if (small) {
+            const int rb = (c.nBsk + 3) / 4;
+            if (kb == 1 && rb == 1) B2S_EXT(1, 1);
+            else if (kb == 1) B2S_EXT(1, 2);
+            else B2S_EXT(2, 2);
+            continue;
+        }
+#undef B2S_EXT
 #define B2_EXT(KB_) TROY_LAUNCH(HIP_KERNEL_NAME(behz2_extend_kernel<KB_>), grid, dim3(B2_THREADS), 0, s, pi, in_pstride, po, out_pstride, primes, c, N, tpw)
         switch (kb) {
         case 1: B2_EXT(1); break;
@@ -377,14 +607,27 @@ void launch_behz2_extend(const u64 *in, u64 in_pstride, u64 *out, u64 out_pstrid
 
 void launch_behz2_floor_sk(const u64 *dq, u64 dq_pstride, const u64 *db, u64 db_pstride, u64 *out, u64 out_pstride, const PrimeDesc *primes, const BehzDev &c, u64 N,
                            u64 polys, hipStream_t s) {
-    const u64 tiles = ceil_div(N, (u64)B2_TILE);
-    const unsigned tpw = b2_tiles_per_wg(tiles);
     const int kb1 = (c.L + 3) / 4, kb2 = (c.nB + 1 + 3) / 4; // kb2 is kb1 or kb1 + 1 (nB is L or L + 1)
+    const bool small = c.f1s_frag && kb2 <= 2;
+    const u64 tiles = ceil_div(N, (u64)(small ? B2S_TILE : B2_TILE));
+    const unsigned tpw = small ? b2s_tiles_per_wg(tiles) : b2_tiles_per_wg(tiles);
     for (u64 p0 = 0; p0 < polys; p0 += 65535) {
         const u64 np = polys - p0 < 65535 ? polys - p0 : 65535;
         const dim3 grid((unsigned)ceil_div(tiles, (u64)tpw), (unsigned)np);
         const u64 *pq = dq + p0 * dq_pstride, *pb = db + p0 * db_pstride;
         u64 *po = out + p0 * out_pstride;
+#define B2S_FLOOR(K1_, K2_)                                                                                               \
+    do {                                                                                                                 \
+        if (c.f2_fast) TROY_LAUNCH(HIP_KERNEL_NAME(behz2s_floor_sk_kernel<K1_, K2_, true>), grid, dim3(B2_THREADS), 0, s, pq, dq_pstride, pb, db_pstride, po, out_pstride, primes, c, N, tpw); \
+        else TROY_LAUNCH(HIP_KERNEL_NAME(behz2s_floor_sk_kernel<K1_, K2_, false>), grid, dim3(B2_THREADS), 0, s, pq, dq_pstride, pb, db_pstride, po, out_pstride, primes, c, N, tpw); \
+    } while (0)
+        if (small) {
+            if (kb1 == 1 && kb2 == 1) B2S_FLOOR(1, 1);
+            else if (kb1 == 1) B2S_FLOOR(1, 2);
+            else B2S_FLOOR(2, 2);
+            continue;
+        }
+#undef B2S_FLOOR
 #define B2_FLOOR(K1_, K2_, F_)                                                                                            \
     TROY_LAUNCH(HIP_KERNEL_NAME(behz2_floor_sk_kernel<K1_, K2_, F_>), grid, dim3(B2_THREADS), 0, s, pq, dq_pstride, pb, db_pstride, po, out_pstride, primes, c, N, tpw)
 #define B2_FLOOR_F(K1_, K2_)                                                                                              \

@@ -111,13 +111,15 @@ static std::vector<uint8_t> pack_mfma_mt(const std::vector<u64> &row) {
 // row-block rb -> output 4 rb + 2 (m / 16) + (m / 4) % 2, shift m % 4 + 4 ((m / 8) % 2): lane l's accumulator registers 0-7 are the
 // shifts of output 4 rb + l / 32, registers 8-15 those of output 4 rb + 2 + l / 32 (D layout of v_mfma_i32_32x32x32_i8).
 // mod32: the modulus is 2^32 (m_tilde) and only shifts 0-3 exist.
-static std::vector<uint8_t> pack_rows8(const std::vector<std::vector<u64>> &W, const std::vector<u64> &p, int KB, bool mod32 = false) {
+static std::vector<uint8_t> pack_rows8(const std::vector<std::vector<u64>> &W, const std::vector<u64> &p, int KB, bool mod32 = false, bool half_major = false) {
     const int n_out = (int)W.size(), RB = (n_out + 3) / 4;
     std::vector<uint8_t> f((size_t)RB * KB * 64 * 16, 0);
     for (int rb = 0; rb < RB; rb++)
         for (int kb = 0; kb < KB; kb++)
             for (int lane = 0; lane < 64; lane++) {
-                const int m = lane % 32, mm = m % 16, o = 4 * rb + 2 * (m / 16) + (mm / 4) % 2, s = mm % 4 + 4 * (mm / 8);
+                // half_major: output 4 rb + 2 (half) + (register group) -- the order in which a lane's results are the limbs of its next operand
+                const int m = lane % 32, mm = m % 16, s = mm % 4 + 4 * (mm / 8);
+                const int o = half_major ? 4 * rb + 2 * ((mm / 4) % 2) + m / 16 : 4 * rb + 2 * (m / 16) + (mm / 4) % 2;
                 if (o >= n_out || (mod32 && s >= 4)) continue;
                 for (int t = 0; t < 16; t++) {
                     const int k = 32 * kb + 16 * (lane / 32) + t, limb = k / 8, i = k % 8;
@@ -399,6 +401,7 @@ void Context::upload_tables() {
             c->x_mt_frag = upload(pack_rows8(mtw, two32, KBx, true), lv.dev_blocks);
             c->x_k = upload(xk, lv.dev_blocks);
             c->f1_frag = upload(pack_rows8(f1w, bskp, KB1), lv.dev_blocks);
+            if (KB2 <= 2) c->f1s_frag = upload(pack_rows8(f1w, bskp, KB1, false, true), lv.dev_blocks);
             c->f1_k = upload(f1k, lv.dev_blocks);
             c->f1_t = upload(f1t, lv.dev_blocks);
             c->f2_frag = upload(pack_rows8(f2w, qp, KB2), lv.dev_blocks);
