@@ -372,7 +372,7 @@ void Context::upload_tables() {
             std::vector<std::vector<u64>> xw(nBsk), f1w(nBsk), f2w(L), mtw(2), mskw(2);
             std::vector<u64> bskp(r.Bsk.begin(), r.Bsk.end()), qp(r.q.begin(), r.q.begin() + L), two32(2, 0), mskp(2, r.m_sk);
             std::vector<BehzK2> xk(nBsk), f1k(nBsk), f2k(L);
-            std::vector<Shoup> f1t(nBsk);
+            std::vector<Shoup> f1t(nBsk); // t q^-1 [(B/B_o)^-1 | B^-1] mod Bsk_o, the factor of the db_o term: rides on the inverse transform (floor_desc below)
             for (int o = 0; o < nBsk; o++) {
                 const u64 p = r.Bsk[o];
                 u64 fscale = r.inv_prod_q_mod_Bsk[o];                                               // q^-1
@@ -403,7 +403,6 @@ void Context::upload_tables() {
             c->f1_frag = upload(pack_rows8(f1w, bskp, KB1), lv.dev_blocks);
             if (KB2 <= 2) c->f1s_frag = upload(pack_rows8(f1w, bskp, KB1, false, true), lv.dev_blocks);
             c->f1_k = upload(f1k, lv.dev_blocks);
-            c->f1_t = upload(f1t, lv.dev_blocks);
             c->f2_frag = upload(pack_rows8(f2w, qp, KB2), lv.dev_blocks);
             c->f2_msk_frag = upload(pack_rows8(mskw, mskp, KB2), lv.dev_blocks);
             c->f2_k = upload(f2k, lv.dev_blocks);

@@ -164,7 +164,6 @@ struct BehzDev {
     const void *f1_frag;              // floor stage 1: [ceil(nBsk/4)][KB1][64], KB1 = ceil(L/4); the m_sk row carries B^-1 too
     const void *f1s_frag;             // the same rows in the order (row-block, half, j) -> output 4 rb + 2 half + j, for the small-base kernels (nullptr: not built)
     const BehzK2 *f1_k;               // [nBsk]
-    const Shoup *f1_t;                // [nBsk]  t q^-1 [(B/B_o)^-1 | B^-1] mod Bsk_o: the db_o term
     const void *f2_frag;              // stage 2: [ceil(L/4)][KB2][64], KB2 = ceil((nB+1)/4): the B limbs and the alpha column at limb nB
     const void *f2_msk_frag;          // [KB2][64]  (B/B_b) B^-1 mod m_sk in both halves of the tile
     const BehzK2 *f2_k;               // [L]
