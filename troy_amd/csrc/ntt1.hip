@@ -526,6 +526,7 @@ template <bool LEAN> __global__ __launch_bounds__(N1_THREADS) void ntt1_inv_kern
 }
 
 // ---- host side ----
+
 static bool ntt1_enabled() {
     static const bool on = [] { const char *e = std::getenv("TROYHIP_NTT"); return !(e && std::strcmp(e, "twopass") == 0); }();
     return on;
@@ -571,51 +572,54 @@ void launch_ntt1(u64 *data, const u64 *src, const PrimeDesc *primes, const LimbM
         }
         return best;
     };
-    if (inverse) { // same split by prime class as the forward transform below; the lean form takes canonical inputs (every stored limb is)
-        for (int lean = 1; lean >= 0; lean--) {
-            a.nslots = 0;
-            for (unsigned i = 0; i < map.period; i++)
-                if ((int)((map.lean >> i) & 1) == lean) a.slots[a.nslots++] = (uint8_t)i;
-            if (!a.nslots) continue;
-            a.rows_per_wg = plan(a.nslots);
-            a.chunks = (a.m_total + a.rows_per_wg - 1) / a.rows_per_wg;
-            if (lean) TROY_LAUNCH(HIP_KERNEL_NAME(ntt1_inv_kernel<true>), dim3(a.nslots * a.chunks), dim3(N1_THREADS), 0, stream, a);
-            else TROY_LAUNCH(HIP_KERNEL_NAME(ntt1_inv_kernel<false>), dim3(a.nslots * a.chunks), dim3(N1_THREADS), 0, stream, a);
-        }
-        launch_check("ntt1_inv_kernel");
-        return;
-    }
-#ifdef N1_TIMING
-    static u64 *dbg = nullptr;
-    if (!dbg) HIP_CHECK(hipMalloc((void **)&dbg, 16 * 8 * 8));
-    a.dbg = dbg;
-    a.dbg_block = (map.period * a.chunks) / 2 + 3;
-#endif
-    const bool no_lean = false; // TROYHIP_BFLY=guarded already clears map.lean (context.cpp)
+    // split by prime class (guard-free / guarded butterflies), back to back on the caller's stream; the lean inverse takes canonical
+    // inputs (every stored limb is).  Tried and rejected: both classes in one kernel behind a workgroup-uniform branch (the merged
+    // function spills 40-120 registers), the smaller class forked onto a companion stream (concurrent kernels interleave their
+    // workgroups and lose the per-prime locality: 0.34 -> 0.28 at B=64).
+    struct Cls { Ntt1Args a; bool lean; } cls[2];
+    int ncls = 0;
     for (int lean = 1; lean >= 0; lean--) {
         a.nslots = 0;
         for (unsigned i = 0; i < map.period; i++)
-            if ((int)(!no_lean && ((map.lean >> i) & 1)) == lean) a.slots[a.nslots++] = (uint8_t)i;
+            if ((int)((map.lean >> i) & 1) == lean) a.slots[a.nslots++] = (uint8_t)i;
         if (!a.nslots) continue;
         a.rows_per_wg = plan(a.nslots);
         a.chunks = (a.m_total + a.rows_per_wg - 1) / a.rows_per_wg;
-        if (lean) TROY_LAUNCH(HIP_KERNEL_NAME(ntt1_fwd_kernel<true>), dim3(a.nslots * a.chunks), dim3(N1_THREADS), 0, stream, a);
-        else TROY_LAUNCH(HIP_KERNEL_NAME(ntt1_fwd_kernel<false>), dim3(a.nslots * a.chunks), dim3(N1_THREADS), 0, stream, a);
-        launch_check("ntt1_fwd_kernel");
-#ifdef N1_TIMING
-        if (lean) {
-            u64 h[16 * 8];
-            HIP_CHECK(hipStreamSynchronize(stream));
-            HIP_CHECK(hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost));
-            for (unsigned r = 0; r < a.rows_per_wg && r < 8; r++) {
-                fprintf(stderr, "n1 fwd row %u:", r);
-                for (int i = 1; i < 14; i++) fprintf(stderr, " %lld", (long long)(h[16 * r + i] - h[16 * r + i - 1]));
-                if (r + 1 < a.rows_per_wg && r + 1 < 8) fprintf(stderr, " | next %lld", (long long)(h[16 * (r + 1)] - h[16 * r + 13]));
-                fprintf(stderr, "\n");
-            }
-        }
-#endif
+        cls[ncls].a = a;
+        cls[ncls++].lean = lean != 0;
     }
+    auto launch = [&](const Cls &k, hipStream_t st) {
+        const Ntt1Args &x = k.a;
+        const dim3 grid(x.nslots * x.chunks);
+        if (inverse) {
+            if (k.lean) TROY_LAUNCH(HIP_KERNEL_NAME(ntt1_inv_kernel<true>), grid, dim3(N1_THREADS), 0, st, x);
+            else TROY_LAUNCH(HIP_KERNEL_NAME(ntt1_inv_kernel<false>), grid, dim3(N1_THREADS), 0, st, x);
+        } else {
+            if (k.lean) TROY_LAUNCH(HIP_KERNEL_NAME(ntt1_fwd_kernel<true>), grid, dim3(N1_THREADS), 0, st, x);
+            else TROY_LAUNCH(HIP_KERNEL_NAME(ntt1_fwd_kernel<false>), grid, dim3(N1_THREADS), 0, st, x);
+        }
+    };
+#ifdef N1_TIMING // development build: phase stamps of one workgroup of the guard-free forward kernel
+    static u64 *dbg = nullptr;
+    if (!dbg) HIP_CHECK(hipMalloc((void **)&dbg, 16 * 8 * 8));
+    for (int i = 0; i < ncls; i++)
+        if (cls[i].lean && !inverse) { cls[i].a.dbg = dbg; cls[i].a.dbg_block = (cls[i].a.nslots * cls[i].a.chunks) / 2 + 3; }
+#endif
+    for (int i = 0; i < ncls; i++) launch(cls[i], stream);
+    launch_check("ntt1 kernels");
+#ifdef N1_TIMING
+    if (!inverse && ncls && cls[0].lean) {
+        u64 h[16 * 8];
+        HIP_CHECK(hipStreamSynchronize(stream));
+        HIP_CHECK(hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost));
+        for (unsigned r = 0; r < cls[0].a.rows_per_wg && r < 8; r++) {
+            fprintf(stderr, "n1 fwd row %u:", r);
+            for (int i = 1; i < 14; i++) fprintf(stderr, " %lld", (long long)(h[16 * r + i] - h[16 * r + i - 1]));
+            if (r + 1 < cls[0].a.rows_per_wg && r + 1 < 8) fprintf(stderr, " | next %lld", (long long)(h[16 * (r + 1)] - h[16 * r + 13]));
+            fprintf(stderr, "\n");
+        }
+    }
+#endif
 }
 
 } // namespace troyhip
