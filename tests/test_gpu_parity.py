@@ -497,6 +497,26 @@ def test_unfused_kernel_paths_agree(env, gpu):
     assert out.stdout.split()[-len(names):] == here
 
 
+@pytest.mark.parametrize("env", [{"TROYHIP_NTT": "twopass"}, {"TROYHIP_BFLY": "guarded"}, {"TROYHIP_NTT": "twopass", "TROYHIP_BFLY": "guarded"}])
+def test_ntt_forms_agree_at_headline_size(env, gpu):
+    """N = 2^15: the two-pass transform instead of the single-pass one, and guarded butterflies instead of the guard-free ones (both
+    environment switches, read once per process), give the same limbs through multiply + relinearize as the default path, which the
+    golden files pin on the reference"""
+    import subprocess
+    import sys
+    names = ["cfgNS_bfv_n32768_k15", "cfgC_ckks_n32768_k15"]
+    names = [n for n in names if n in cases.CONFIGS]
+    here = [cases.mul_relin_hash(n) for n in names]
+    tests_dir = os.path.dirname(os.path.abspath(__file__))
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import troy_amd as ta, cases\n"
+            "ta.KernelProvider.initialize(0)\n"
+            "print(' '.join(cases.mul_relin_hash(n) for n in %r))\n") % (tests_dir, os.path.dirname(tests_dir), names)
+    out = subprocess.run([sys.executable, "-c", code], env={**os.environ, **env}, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.split()[-len(names):] == here and names
+
+
 def _run_bench(args, timeout=900):
     import json
     import subprocess
