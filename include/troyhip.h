@@ -144,7 +144,8 @@ int troyhip_host_decrypt(const troyhip_context *ctx, const uint64_t *secret_key,
 
 /* ---- kernel_util (src/kernelutils.cuh:562-672) ----
  * rows limb-polynomials of N coefficients at `data`; row r is reduced modulo row_primes[(r / inner) % period].
- * kNttNegacyclicHarvey / kInverseNttNegacyclicHarvey: outputs canonical in [0,p). */
+ * kNttNegacyclicHarvey / kInverseNttNegacyclicHarvey: inputs are residues in [0,p) (what every operation of this library stores; the
+ * kernels tolerate lazy values below 2p), outputs canonical in [0,p). */
 int troyhip_ntt(troyhip_context *ctx, uint64_t *data, uint64_t rows, const uint64_t *row_primes, int period, int inner, int inverse, void *stream);
 /* synthetic uniform residues (bench / tests): value(row, n) = splitmix64(seed ^ (row0+row)*C, n) mod p_row */
 int troyhip_fill_uniform(troyhip_context *ctx, uint64_t *data, uint64_t rows, const uint64_t *row_primes, int period, int inner,
