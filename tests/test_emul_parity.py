@@ -184,6 +184,6 @@ def test_emulated_single_pass_ntt_row_loop_and_prime_classes(oracle_lib, tmp_pat
         "assert np.array_equal(buf2.to_numpy().reshape(rows2, N), e)\n"
         "print('ok')\n" % (ROOT, os.path.join(ROOT, 'tests'), EMUL))
     for rpw in ("3", "1"):
-        env = dict(os.environ, TROYHIP_NTT1_RPW=rpw)
+        env = dict(os.environ, TROYHIP_NTT1_RPW=rpw, TROYHIP_NTT="single")  # small launches go to the two-pass kernels by default
         out = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=900)
         assert out.returncode == 0 and "ok" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]

@@ -156,11 +156,11 @@ def test_single_pass_ntt_vs_oracle_incl_extremes(gpu, oracle_lib):
     kp = gpu.CoeffModulus.Create(N, [60, 50, 58, 40, 60])
     ctx = gpu.SEALContext(gpu.BFV, N, kp, gpu.PlainModulus.Batching(N, 20))
     primes = kp[:4] + [int(ctx.behz_bases(4)[0][0])]
-    rows = 3 * len(primes)
+    rows = 206 * len(primes)  # 1030 rows: at least four per CU, the size from which the single-pass kernel is used
     x = synth.uniform_rows(77, primes, rows, N)
-    for r in range(len(primes), rows):
+    for r in range(rows - 2 * len(primes), rows):
         x[r] = primes[r % len(primes)] - 1
-        if r >= 2 * len(primes):
+        if r >= rows - len(primes):
             x[r, 1::2] = 0
     for mode, inverse in ((1, False), (3, True)):
         buf = gpu.DeviceBuffer.from_numpy(x)
@@ -497,11 +497,11 @@ def test_unfused_kernel_paths_agree(env, gpu):
     assert out.stdout.split()[-len(names):] == here
 
 
-@pytest.mark.parametrize("env", [{"TROYHIP_NTT": "twopass"}, {"TROYHIP_BFLY": "guarded"}, {"TROYHIP_NTT": "twopass", "TROYHIP_BFLY": "guarded"}])
+@pytest.mark.parametrize("env", [{"TROYHIP_NTT": "single"}, {"TROYHIP_NTT": "twopass"}, {"TROYHIP_BFLY": "guarded"}, {"TROYHIP_NTT": "single", "TROYHIP_BFLY": "guarded"}])
 def test_ntt_forms_agree_at_headline_size(env, gpu):
-    """N = 2^15: the two-pass transform instead of the single-pass one, and guarded butterflies instead of the guard-free ones (both
-    environment switches, read once per process), give the same limbs through multiply + relinearize as the default path, which the
-    golden files pin on the reference"""
+    """N = 2^15: the single-pass transform forced at a small batch (by default it takes launches of four rows per CU and more), the
+    two-pass transform forced, and guarded butterflies instead of the guard-free ones (environment switches, read once per process)
+    give the same limbs through multiply + relinearize as the default path, which the golden files pin on the reference"""
     import subprocess
     import sys
     names = ["cfgNS_bfv_n32768_k15", "cfgC_ckks_n32768_k15"]

@@ -527,12 +527,28 @@ template <bool LEAN> __global__ __launch_bounds__(N1_THREADS) void ntt1_inv_kern
 
 // ---- host side ----
 
-static bool ntt1_enabled() {
-    static const bool on = [] { const char *e = std::getenv("TROYHIP_NTT"); return !(e && std::strcmp(e, "twopass") == 0); }();
-    return on;
+static unsigned ntt1_cus() {
+    static const unsigned cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        return (unsigned)n;
+    }();
+    return cus;
+}
+// TROYHIP_NTT = twopass | single forces one form (tests, A/B runs); by default the single-pass kernel takes the launches that give
+// every CU at least four rows.  Below that a whole-limb workgroup per CU is the wrong grain -- a lone row costs ~45 us however few rows
+// there are, while the two-pass kernels spread a row over 32 small workgroups: BFV multiply+relinearize at B = 1 takes 0.29 ms with
+// two passes and 0.45 ms with one, the two meet at B = 32 (1000-1400 rows per launch), and from there the single pass wins.
+static int ntt1_mode() {
+    static const int mode = [] {
+        const char *e = std::getenv("TROYHIP_NTT");
+        return !e ? 0 : (std::strcmp(e, "twopass") == 0 ? 1 : (std::strcmp(e, "single") == 0 ? 2 : 0));
+    }();
+    return mode;
 }
 bool ntt1_supported(int logn, const LimbMap &map, size_t rows) {
-    return ntt1_enabled() && logn == N1_LOGN && rows && rows % ((size_t)map.period * map.inner) == 0;
+    if (ntt1_mode() == 1 || logn != N1_LOGN || !rows || rows % ((size_t)map.period * map.inner)) return false;
+    return ntt1_mode() == 2 || rows >= 4 * (size_t)ntt1_cus();
 }
 // rows laid out r = (o * period + i) * inner + k, prime map.id[i].  The forward transform is launched once per prime class:
 // guard-free butterflies for the slots in map.lean, guarded ones for the rest.
@@ -552,11 +568,7 @@ void launch_ntt1(u64 *data, const u64 *src, const PrimeDesc *primes, const LimbM
     // the un-overlapped first load and last store, about a third of a row): pick the rows per workgroup (they share the prime) that
     // minimises rounds x (rows + 1/3), with a small penalty for spreading the CUs over many primes at once.  A fixed "three workgroups
     // per CU" left mid-size launches with a mostly idle last round.
-    static const unsigned cus = [] {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-        return (unsigned)n;
-    }();
+    const unsigned cus = ntt1_cus();
     static const unsigned forced_rpw = [] { const char *e = std::getenv("TROYHIP_NTT1_RPW"); return e ? (unsigned)std::atoi(e) : 0u; }(); // tests: row loop at small batches
     auto plan = [&](unsigned nslots) { // -> rows per workgroup for a launch over `nslots` primes
         if (forced_rpw) return forced_rpw;
