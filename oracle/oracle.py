@@ -126,7 +126,10 @@ def coeff_modulus_create(N, bits):
 
 
 def plain_batching(N, bits):
-    return int(lib().orc_plain_batching(U(N), bits))
+    v = int(lib().orc_plain_batching(U(N), bits))
+    if v == 0:
+        raise ValueError("failed to find enough qualifying primes")
+    return v
 
 
 def ntt_standalone(N, p, data, mode):

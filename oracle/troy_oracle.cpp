@@ -1308,7 +1308,9 @@ int orc_get_primes(uint64_t factor, int bits, int count, uint64_t *out) {
 int orc_coeff_modulus_create(uint64_t N, const int *bits, int n, uint64_t *out) {
     try { auto v = coeff_modulus_create(N, std::vector<int>(bits, bits + n)); std::copy(v.begin(), v.end(), out); return 0; } catch (...) { return -1; }
 }
-uint64_t orc_plain_batching(uint64_t N, int bits) { return coeff_modulus_create(N, {bits})[0]; } // modulus.h:528-531
+uint64_t orc_plain_batching(uint64_t N, int bits) { // modulus.h:528-531; 0 = no such prime (the reference throws logic_error)
+    try { return coeff_modulus_create(N, {bits})[0]; } catch (...) { return 0; }
+}
 
 void *orc_create(int scheme, uint64_t N, const uint64_t *primes, int K, uint64_t t) {
     auto *o = new Orc();

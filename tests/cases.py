@@ -576,6 +576,54 @@ def check_bfv_multiply_limb_count(K, N=256, batch=2, seed=900, big=False):
     return sha(got)
 
 
+def random_config(seed, sizes=(256, 1024, 4096)):
+    """a seeded random parameter set: scheme, N, 2..6 primes whose sizes sit on the thresholds the kernels branch on (2^33: BEHZ one-step
+    reduction and guard-free butterflies start; 2^50: Bsk-sized; 2^58: guard-free butterflies end; 60 bits: largest allowed)"""
+    rng = np.random.default_rng(seed)
+    scheme = (BFV, CKKS, BGV)[seed % 3]  # balanced over consecutive seeds
+    N = int(rng.choice(sizes))
+    K = int(rng.integers(2, 7))
+    pool = [33, 34, 36, 40, 45, 49, 50, 51, 55, 57, 58, 59, 60]
+    bits = [int(rng.choice(pool)) for _ in range(K)]
+    if scheme == CKKS:  # rescaling divides by the last data prime: keep the primes at least as large as a sensible scale
+        bits = [max(b, 36) for b in bits]
+    return dict(scheme=scheme, N=N, bits=bits, tbits=int(rng.integers(14, 21)))
+
+
+def check_random_config(seed, sizes=(256, 1024, 4096), batch=2):
+    """the whole op list of `scenario` (every level, every op) on a random parameter set: product vs CPU oracle, limb for limb"""
+    from oracle import oracle
+    from troy_amd import api
+    cfg = random_config(seed, sizes)
+    if cfg["scheme"] != CKKS:  # not every size has a batching prime (N = 4096: none of 14 or 15 bits): both sides must say so, then move up
+        while True:
+            ours = theirs = None
+            try:
+                ours = api.PlainModulus.Batching(cfg["N"], cfg["tbits"])
+            except Exception:
+                pass
+            try:
+                theirs = oracle.plain_batching(cfg["N"], cfg["tbits"])
+            except Exception:
+                pass
+            assert ours == theirs, (cfg, ours, theirs)
+            if ours is not None:
+                break
+            cfg["tbits"] += 1
+    try:
+        be = GpuBackend(cfg, batch=batch)
+    except Exception as e:  # a parameter set the context rejects (plain modulus not below the coefficient modulus, ...): both sides must agree
+        try:
+            oracle_backend(cfg)
+        except Exception:
+            return cfg, None
+        raise e
+    got, exp = scenario(be, cfg), scenario(oracle_backend(cfg), cfg)
+    bad = compare(got, exp)
+    assert not bad, (cfg, bad[:8])
+    return cfg, len(got)
+
+
 def mul_relin_hash(name, batch=2, seed=4242):
     """SHA-256 of multiply + relinearize on seeded inputs of config `name` (GPU backend): used to compare kernel variants that are
     selected by environment switches in child processes"""

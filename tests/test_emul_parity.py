@@ -100,6 +100,14 @@ def test_emulated_bfv_multiply_limb_counts(K, big, emul_api, oracle_lib):
     cases.check_bfv_multiply_limb_count(K, N=128, batch=1, big=big)
 
 
+@pytest.mark.parametrize("seed", [3, 4, 5, 6, 9, 12, 15, 21])
+def test_emulated_random_parameter_sets(seed, emul_api, oracle_lib):
+    """the whole op list at every level on seeded random parameter sets (scheme, N, 2..6 primes of 33..60 bits -- the sizes the kernels
+    branch on), product vs CPU oracle"""
+    cfg, n = cases.check_random_config(seed, sizes=(64, 128, 256), batch=1)
+    assert n is None or n > 10, cfg
+
+
 def test_emulated_size_limits(emul_api):
     cases.check_size_limits("bfv_n64_k3")
     cases.check_size_limits("ckks_n128_k6")

@@ -453,6 +453,15 @@ def test_conv2d_helper(gpu):
     assert h.blocked
 
 
+@pytest.mark.parametrize("seed", list(range(1, 25)))
+def test_random_parameter_sets(seed, gpu, oracle_lib):
+    """the whole op list at every level on seeded random parameter sets (scheme, N = 256..4096, 2..6 primes of 33..60 bits -- the sizes
+    the kernels branch on: one-step BEHZ reduction and guard-free butterflies from 2^33, guarded butterflies from 2^58), product vs
+    CPU oracle, limb for limb"""
+    cfg, n = cases.check_random_config(seed)
+    assert n is None or n > 10, cfg
+
+
 @pytest.mark.parametrize("big", [False, True, "small"])
 @pytest.mark.parametrize("K", list(range(2, 19)))
 def test_bfv_multiply_every_limb_count(K, big, gpu, oracle_lib):
