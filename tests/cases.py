@@ -590,7 +590,7 @@ def random_config(seed, sizes=(256, 1024, 4096)):
     return dict(scheme=scheme, N=N, bits=bits, tbits=int(rng.integers(14, 21)))
 
 
-def check_random_config(seed, sizes=(256, 1024, 4096), batch=2):
+def check_random_config(seed, sizes=(256, 1024, 4096), batch=2, light=False):
     """the whole op list of `scenario` (every level, every op) on a random parameter set: product vs CPU oracle, limb for limb"""
     from oracle import oracle
     from troy_amd import api
@@ -618,7 +618,7 @@ def check_random_config(seed, sizes=(256, 1024, 4096), batch=2):
         except Exception:
             return cfg, None
         raise e
-    got, exp = scenario(be, cfg), scenario(oracle_backend(cfg), cfg)
+    got, exp = scenario(be, cfg, light=light), scenario(oracle_backend(cfg), cfg, light=light)
     bad = compare(got, exp)
     assert not bad, (cfg, bad[:8])
     return cfg, len(got)

@@ -462,6 +462,14 @@ def test_random_parameter_sets(seed, gpu, oracle_lib):
     assert n is None or n > 10, cfg
 
 
+@pytest.mark.parametrize("seed", list(range(101, 109)))
+def test_random_parameter_sets_large(seed, gpu, oracle_lib):
+    """the same at N = 8192 .. 32768 (multiply, relinearize, rotate / rescale at the first level): the two-pass transform with its fused
+    key-switch and tensor passes, and the small-base BEHZ kernels, on prime sizes no fixed configuration has"""
+    cfg, n = cases.check_random_config(seed, sizes=(8192, 16384, 32768), batch=1, light=True)
+    assert n is None or n >= 3, cfg
+
+
 @pytest.mark.parametrize("big", [False, True, "small"])
 @pytest.mark.parametrize("K", list(range(2, 19)))
 def test_bfv_multiply_every_limb_count(K, big, gpu, oracle_lib):
