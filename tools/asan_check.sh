@@ -1,0 +1,15 @@
+#!/bin/bash
+# AddressSanitizer over the kernel sources, on the CPU: the emulator build of libtroyhip (tests/emul/hip_emul.h) compiled with
+# -fsanitize=address, driven through the BEHZ kernels at every limb count, random parameter sets, the single-pass NTT, and the two C++
+# shim tests.  LDS arrays are globals and device allocations are heap blocks there, so out-of-range indexing shows up.  (GPU sanitizers are
+# not available on the pool.)  usage: tools/asan_check.sh
+set -e
+cd "$(dirname "$0")/.."
+make -s -j8 -C troy_amd/csrc emul OBJDIR=$PWD/troy_amd/csrc/build/asan EMUL_OUT=/tmp/libtroyhip_emul_asan.so \
+     EMUL_FLAGS="-O1 -g -fsanitize=address -fno-omit-frame-pointer" EMUL_LDFLAGS="-fsanitize=address"
+export ASAN_OPTIONS=detect_leaks=0:detect_stack_use_after_return=0   # ucontext fibers: no fake stacks
+LD_PRELOAD=$(gcc -print-file-name=libasan.so) TROYHIP_NTT=single python tools/asan_run.py
+for t in test_troyn test_troyn_app; do
+    g++ -std=c++17 -O1 -g -fsanitize=address -fno-omit-frame-pointer -Iinclude tests/cpp/$t.cpp -o /tmp/${t}_asan /tmp/libtroyhip_emul_asan.so -Wl,-rpath,/tmp
+    /tmp/${t}_asan | grep -E "FAIL|ALL OK"
+done
