@@ -1,7 +1,7 @@
 import sys, os, time
 sys.path.insert(0,'/root/repo/tests'); sys.path.insert(0,'/root/repo')
 from troy_amd import api, capi
-lib = capi.load('/tmp/libtroyhip_emul_asan.so')
+lib = capi.load(os.environ.get('TROY_EMUL_LIB', '/tmp/libtroyhip_emul_asan.so'))  # the sanitizer build made by tools/asan_check.sh
 api.KernelProvider.initialize(0, _lib=lib)
 import cases
 t=time.time()

@@ -299,7 +299,7 @@ __device__ __forceinline__ U128 mfma_recombine(const MfmaAcc &a) {
     long long w[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-        const int p01 = a.v[4 * j] + (a.v[4 * j + 1] << 8), p23 = a.v[4 * j + 2] + (a.v[4 * j + 3] << 8);
+        const int p01 = (int)((u32)a.v[4 * j] + ((u32)a.v[4 * j + 1] << 8)), p23 = (int)((u32)a.v[4 * j + 2] + ((u32)a.v[4 * j + 3] << 8));
         w[j] = mad_i64_i32(p23, 1 << 16, (long long)p01);
     }
     // lo = W0 + (W1 << 32) ; hi = sext(W0) + (W1 >> 32) + W2 + (W3 << 32) + carry   (all modulo 2^64: the result fits 128 bits)

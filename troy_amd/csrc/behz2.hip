@@ -68,8 +68,10 @@ struct B2Sum { u64 lo; u32 top; };
 // half and `bias1` (at least the magnitude of the high half) into the high half: both halves stay positive, so the words combine
 // without sign handling
 template <int BASE> __device__ __forceinline__ B2Sum b2_recombine(const MfmaAcc &a, u64 addend, u64 bias1) {
-    const int p01 = a.v[BASE] + (a.v[BASE + 1] << 8), p23 = a.v[BASE + 2] + (a.v[BASE + 3] << 8);
-    const int p45 = a.v[BASE + 4] + (a.v[BASE + 5] << 8), p67 = a.v[BASE + 6] + (a.v[BASE + 7] << 8);
+    // two's-complement arithmetic on the 32-bit words (a left shift of a negative int is undefined in C++17: shift the unsigned image)
+    auto sh8 = [](int lo, int hi) { return (int)((u32)lo + ((u32)hi << 8)); };
+    const int p01 = sh8(a.v[BASE], a.v[BASE + 1]), p23 = sh8(a.v[BASE + 2], a.v[BASE + 3]);
+    const int p45 = sh8(a.v[BASE + 4], a.v[BASE + 5]), p67 = sh8(a.v[BASE + 6], a.v[BASE + 7]);
     const u64 w0 = (u64)b2_mad(p01, 1, b2_mad(p23, 1 << 16, (long long)addend));
     const u64 w1 = (u64)b2_mad(p45, 1, b2_mad(p67, 1 << 16, (long long)bias1));
     const u32 w0h = (u32)(w0 >> 32), v1 = w0h + (u32)w1;
