@@ -391,14 +391,22 @@ def algorithmic_bytes(w, B):
         qs = [int(p) for p in w.ctx.coeff_modulus]
         lean_q = sum(1 for p in qs[:L] if (1 << 33) <= p < (1 << 58))          # Bsk primes are 61 bits: guarded
         lean_k = sum(1 for p in qs[:L + 1] if (1 << 33) <= p < (1 << 58))
-        lean_rows = 3 * B * lean_q + 2 * B * lean_k
-        add("ntt1_inv_kernel<true>", lean_rows * 2 * P)
-        add("ntt1_inv_kernel<false>", (inv_rows - lean_rows) * 2 * P)
+        fused_md = os.environ.get("TROYHIP_MODDOWN", "") [:1] != "s" and all(p >= 1 << 33 for p in qs[:L])
+        # multiply: 3 polynomials in both bases; key switch: 2 accumulators over the L + 1 key primes.  With the mod-down fused (the
+        # default) the special limb is transformed on its own and the L data limbs leave through the epilogue: read acc and ct, write ct,
+        # plus the special limb once per (ciphertext, accumulator)
+        add("ntt1_inv_kernel<true, false>", 3 * B * lean_q * 2 * P + (0 if fused_md else 2 * B * lean_k * 2 * P))
+        add("ntt1_inv_kernel<false, false>", 3 * B * ((L - lean_q) + nb) * 2 * P + (2 * B * 2 * P if fused_md else 2 * B * (L + 1 - lean_k) * 2 * P))
+        if fused_md:
+            add("ntt1_inv_kernel<true, true>", 2 * B * lean_q * 3 * P + (2 * B * P if lean_q else 0))
+            if L - lean_q:
+                add("ntt1_inv_kernel<false, true>", 2 * B * (L - lean_q) * 3 * P + (0 if lean_q else 2 * B * P))
     add(f"behz2{'s' if small_f else ''}_floor_sk_kernel<{kb1}, {kb2}, {fast}>", 3 * B * (2 * L + nb) * P)
     # relinearize: digit decomposition + first pass, second pass with the inner product against the key, inverse, mod-down
     add(f"ntt2_kernel<0, 1, {k1}, {logc}, 0, 1, 0>", B * L * P + B * (L + 1) * L * P)
     add("ntt2_kernel<0, 0, 9, 0, 1, 0, 1>", B * (L + 1) * L * P + 2 * (L + 1) * L * P + 2 * B * (L + 1) * P)
-    add("ks_moddown_kernel<0>", B * (2 * (L + 1) + 4 * L) * P)
+    if two_pass or not (os.environ.get("TROYHIP_MODDOWN", "")[:1] != "s" and all(int(p) >= 1 << 33 for p in w.ctx.coeff_modulus[:L])):
+        add("ks_moddown_kernel<0>", B * (2 * (L + 1) + 4 * L) * P)
     return t
 
 

@@ -46,7 +46,7 @@ def per_row(d, names, launches_each):
         tot += f + w
     return tot / rows
 sp = load("r02sp")
-n1 = per_row(sp, ["ntt1_inv_kernel<true>", "ntt1_inv_kernel<false>"], 3)
+n1 = per_row(sp, ["ntt1_inv_kernel<true, false>", "ntt1_inv_kernel<false, false>"], 3)
 n1f = None
 if "ntt1_fwd_kernel<true>" in sp and "ntt1_fwd_kernel<false>" in sp:
     n1f = per_row(sp, ["ntt1_fwd_kernel<true>", "ntt1_fwd_kernel<false>"], 3)

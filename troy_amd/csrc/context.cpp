@@ -267,8 +267,21 @@ void Context::upload_tables() {
         d.iroot_last_scaled = tb.iroot_last_scaled;
         d.root = upload(tb.root, dev_allocs_);
         d.iroot = upload(tb.iroot, dev_allocs_);
+        d.aux = Shoup{0, 0};
     }
     d_desc = upload(h_desc, dev_allocs_);
+    if (scheme == SCHEME_BFV && K >= 2) {
+        std::vector<PrimeDesc> md = h_desc;
+        const host::RnsLevel &kr = level(K).rns;
+        for (int j = 0; j + 1 < K; j++) {
+            PrimeDesc &d = md[j];
+            const u64 f = kr.inv_q_last_mod_q[j] % d.p;
+            d.inv_n = make_shoup(host::mul_mod(d.inv_n.op, f, d.p), d.p);
+            d.iroot_last_scaled = make_shoup(host::mul_mod(d.iroot_last_scaled.op, f, d.p), d.p);
+            d.aux = make_shoup(f, d.p);
+        }
+        d_desc_md = upload(md, dev_allocs_);
+    }
 
     if (scheme != SCHEME_BFV) return;
     // BEHZ constants, per data level

@@ -71,6 +71,9 @@ public:
     std::vector<host::NttTable> tables;
     std::vector<PrimeDesc> h_desc;
     PrimeDesc *d_desc = nullptr;
+    // d_desc with q_special^-1 mod q_j folded into the N^-1 constants of the data primes (and in `aux`): the inverse transform of the
+    // key-switch accumulators then delivers acc qk^-1, half of the mod-down (Ntt1ModDown, kernels.h).  BFV contexts with a special prime.
+    PrimeDesc *d_desc_md = nullptr;
     std::map<int, Level> levels; // by limb count, K .. last_limbs
     Arena arena;
 

@@ -12,6 +12,7 @@ struct PrimeDesc {
     Shoup r64;               // 2^64 mod p (folds the high word of a 128-bit sum: reduce128 in behz.hip)
     const Shoup *root;       // [N] forward twiddles, bit-reversed order (src/utils/ntt.cpp:38-43)
     const Shoup *iroot;      // [N] inverse twiddles, scrambled order   (src/utils/ntt.cpp:49-54)
+    Shoup aux;               // free for derived tables (Context::d_desc_md: q_special^-1 mod p); appended last -- behz.hip indexes the words above
 };
 __host__ __device__ inline Mod mod_of(const PrimeDesc &d) { return Mod{d.p, d.cr0, d.cr1}; }
 

@@ -19,6 +19,12 @@ static bool ks_fused() {
     return v;
 }
 
+// TROYHIP_MODDOWN=split keeps the BFV mod-down in its own kernel behind the inverse transform (tests, measurements); read once
+static bool ks_moddown_fused() {
+    static const bool v = [] { const char *e = getenv("TROYHIP_MODDOWN"); return !(e && e[0] == 's'); }();
+    return v;
+}
+
 static inline u64 poly_words(const Context &c, int limbs) { return (u64)limbs * c.N; }
 
 void Evaluator::check_ct(const CtBatch &a) const {
@@ -334,8 +340,19 @@ void Evaluator::switch_key(CtBatch &ct, const u64 *target, u64 t_bstride, const 
         launch_ntt(corr, c.d_desc, c.ct_map((int)dl), batch * 2 * dl, c.logn, false, s);
         launch_ks_ckks_combine(acc, corr, ct.data, ct.bstride, a, s);
     } else {
-        launch_ntt(acc, c.d_desc, c.ids_map(out_ids), batch * 2 * rl, c.logn, true, s);
-        launch_ks_moddown(c.scheme == SCHEME_BFV ? 0 : 2, acc, ct.data, ct.bstride, a, s);
+        const LimbMap amap = c.ids_map(out_ids);
+        bool md_primes = true; // the epilogue's lazy reduction (lite_reduce4) wants primes of at least 33 bits
+        for (u64 j = 0; j < dl; j++) md_primes = md_primes && c.primes[j] >= (u64(1) << 33);
+        if (c.scheme == SCHEME_BFV && c.d_desc_md && md_primes && ntt1_supported(c.logn, amap, batch * 2 * rl) && ks_moddown_fused()) {
+            // single-pass inverse: the special limb first, then the data limbs with the mod-down as their store epilogue (no acc round trip,
+            // no separate memory-bound kernel)
+            launch_ntt1(acc, nullptr, c.d_desc, amap, batch * 2 * rl, true, s, u64(1) << dl, nullptr);
+            const Ntt1ModDown md{ct.data, ct.bstride, dl, qk, a.half};
+            launch_ntt1(acc, nullptr, c.d_desc_md, amap, batch * 2 * rl, true, s, (u64(1) << dl) - 1, &md);
+        } else {
+            launch_ntt(acc, c.d_desc, amap, batch * 2 * rl, c.logn, true, s);
+            launch_ks_moddown(c.scheme == SCHEME_BFV ? 0 : 2, acc, ct.data, ct.bstride, a, s);
+        }
     }
 }
 

@@ -24,7 +24,14 @@ void launch_ntt2(u64 *data, const u64 *src, u64 src_ostride, bool src_reduce, co
 
 // ---- ntt1.hip (N = 2^15: one HBM round trip per limb-transform) ----
 bool ntt1_supported(int logn, const LimbMap &map, size_t rows);
-void launch_ntt1(u64 *data, const u64 *src, const PrimeDesc *primes, const LimbMap &map, size_t rows, bool inverse, hipStream_t stream);
+// BFV mod-down by the special prime (ks_moddown_kernel<0>, evaluator.cpp:2528-2648) fused into the inverse transform of the key-switch
+// accumulators acc[o = 2 b + cpt][slot][N]: the slots below `dl` leave the kernel as  ct[b][cpt][slot] += (acc - [t']_q + [half]_q) qk^-1
+// instead of being stored; slot `dl` (the special limb) must already be in coefficient form.  `primes` is then Context::d_desc_md,
+// whose N^-1 constants carry qk^-1 and whose `aux` is qk^-1 itself.
+struct Ntt1ModDown { u64 *ct; u64 ct_bstride; u64 dl, qk, half; };
+// slot_mask: only these prime slots of the row pattern are transformed
+void launch_ntt1(u64 *data, const u64 *src, const PrimeDesc *primes, const LimbMap &map, size_t rows, bool inverse, hipStream_t stream, u64 slot_mask = ~0ull,
+                 const Ntt1ModDown *md = nullptr);
 
 // ---- poly.hip ----
 void launch_ew(int op, const u64 *a, const u64 *b, u64 *out, const PrimeDesc *primes, const LimbMap &map, int logn, u64 rows, hipStream_t s);

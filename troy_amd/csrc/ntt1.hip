@@ -44,6 +44,10 @@ struct Ntt1Args {
     unsigned chunks;      // ceil(m_total / rows_per_wg)
     unsigned nslots;      // a launch covers the prime slots slots[0 .. nslots) of the pattern (one launch per prime class)
     uint8_t slots[64];
+    // inverse only: mod-down epilogue (Ntt1ModDown); md_ct == nullptr: plain stores
+    u64 *md_ct;
+    u64 md_ct_bstride, md_qk, md_half;
+    unsigned md_dl;
     u64 *dbg;             // development builds (-DN1_TIMING): s_memtime stamps of wave 0 of workgroup dbg_block
     unsigned dbg_block;
 };
@@ -435,7 +439,7 @@ template <bool LEAN> __device__ __forceinline__ void inv_subblock(u64 (&yin)[16]
     }
 }
 
-template <bool LEAN> __global__ __launch_bounds__(N1_THREADS) void ntt1_inv_kernel(Ntt1Args a) {
+template <bool LEAN, bool MD> __global__ __launch_bounds__(N1_THREADS) void ntt1_inv_kernel(Ntt1Args a) {
     __shared__ __attribute__((aligned(16))) u64 lds[16 * 1024];
     const unsigned tid = threadIdx.x, lane = tid & 63;
 #ifdef TROYHIP_CPU_EMUL
@@ -517,7 +521,36 @@ template <bool LEAN> __global__ __launch_bounds__(N1_THREADS) void ntt1_inv_kern
 #pragma unroll
             for (int i = 0; i < 4; i++) x[4 * q + i] = v[i];
         }
-        {
+        if (MD) { // x = acc qk^-1 mod p (canonical): add the special limb's share and accumulate into the ciphertext (inner == 1 here)
+            const unsigned t = opaque(tid);
+            const Mod m = mod_of(pd);
+            const u64 bias = pd.p * 4 + barrett64(a.md_half, m);         // [half]_p + 4p: keeps the difference below positive
+            const u64 *special = a.data + (((u64)mm * period + a.md_dl) << N1_LOGN);
+            u64 *dst = a.md_ct + (u64)(mm >> 1) * a.md_ct_bstride + (((u64)(mm & 1) * a.md_dl + slot) << N1_LOGN);
+            const Shoup iq[4] = {pd.aux, pd.aux, pd.aux, pd.aux};
+#pragma unroll
+            for (int g = 0; g < 8; g++) { // four coefficients at a time through the butterfly building blocks (bfly.h); x[] stays in registers
+                u64 tl[4], c[4], q[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const unsigned n = t + 1024 * (4 * g + i);
+                    tl[i] = ld_g(special, n) + a.md_half;                 // t' = (acc_last + half) mod qk
+                    c[i] = ld_g(dst, n);
+                }
+                csub4(tl, a.md_qk);
+                lite_reduce4(tl, (u32)pd.cr1, pc);                        // [t']_p lazily, below 4p
+#pragma unroll
+                for (int i = 0; i < 4; i++) tl[i] = bias - tl[i];         // [half]_p - [t']_p + 4p, in (0, 5p)
+                mulhi_approx4_u(q, tl, iq);
+#pragma unroll
+                for (int i = 0; i < 4; i++) c[i] += mul_acc_u(x[4 * g + i], tl[i], pd.aux.op, q[i], pc.negp); // + acc qk^-1 + (..) qk^-1: below 5p
+                csub4(c, pc.four_p);
+                csub4(c, pc.two_p);
+                csub4(c, pc.p);
+#pragma unroll
+                for (int i = 0; i < 4; i++) st_g(dst, t + 1024 * (4 * g + i), c[i]);
+            }
+        } else {
             const unsigned t = opaque(tid);
 #pragma unroll
             for (int r = 0; r < 32; r++) st_g(row, t + 1024 * r, x[r]);
@@ -552,11 +585,13 @@ bool ntt1_supported(int logn, const LimbMap &map, size_t rows) {
 }
 // rows laid out r = (o * period + i) * inner + k, prime map.id[i].  The forward transform is launched once per prime class:
 // guard-free butterflies for the slots in map.lean, guarded ones for the rest.
-void launch_ntt1(u64 *data, const u64 *src, const PrimeDesc *primes, const LimbMap &map, size_t rows, bool inverse, hipStream_t stream) {
+void launch_ntt1(u64 *data, const u64 *src, const PrimeDesc *primes, const LimbMap &map, size_t rows, bool inverse, hipStream_t stream, u64 slot_mask,
+                 const Ntt1ModDown *md) {
     if (rows == 0) return;
     const size_t per_outer = (size_t)map.period * map.inner;
     if (rows % per_outer) throw Error(ST_INVALID_ARGUMENT, "ntt1: row count must be a multiple of the limb pattern");
     if (src && inverse) throw Error(ST_LOGIC_ERROR, "ntt1: out-of-place input is only supported by the forward transform");
+    if (md && (!inverse || map.inner != 1 || md->dl >= map.period)) throw Error(ST_LOGIC_ERROR, "ntt1: the mod-down epilogue belongs to the inverse transform of [..][slot][N] accumulators");
     Ntt1Args a;
     std::memset(&a, 0, sizeof(a));
     a.data = data;
@@ -564,6 +599,7 @@ void launch_ntt1(u64 *data, const u64 *src, const PrimeDesc *primes, const LimbM
     a.primes = primes;
     a.map = map;
     a.m_total = (unsigned)(rows / per_outer * map.inner);
+    if (md) { a.md_ct = md->ct; a.md_ct_bstride = md->ct_bstride; a.md_qk = md->qk; a.md_half = md->half; a.md_dl = (unsigned)md->dl; }
     // One workgroup fills a CU, so a launch runs in rounds of `cus` workgroups and a round lasts as long as a workgroup's rows (plus
     // the un-overlapped first load and last store, about a third of a row): pick the rows per workgroup (they share the prime) that
     // minimises rounds x (rows + 1/3), with a small penalty for spreading the CUs over many primes at once.  A fixed "three workgroups
@@ -593,7 +629,7 @@ void launch_ntt1(u64 *data, const u64 *src, const PrimeDesc *primes, const LimbM
     for (int lean = 1; lean >= 0; lean--) {
         a.nslots = 0;
         for (unsigned i = 0; i < map.period; i++)
-            if ((int)((map.lean >> i) & 1) == lean) a.slots[a.nslots++] = (uint8_t)i;
+            if ((int)((map.lean >> i) & 1) == lean && ((slot_mask >> i) & 1)) a.slots[a.nslots++] = (uint8_t)i;
         if (!a.nslots) continue;
         a.rows_per_wg = plan(a.nslots);
         a.chunks = (a.m_total + a.rows_per_wg - 1) / a.rows_per_wg;
@@ -604,8 +640,11 @@ void launch_ntt1(u64 *data, const u64 *src, const PrimeDesc *primes, const LimbM
         const Ntt1Args &x = k.a;
         const dim3 grid(x.nslots * x.chunks);
         if (inverse) {
-            if (k.lean) TROY_LAUNCH(HIP_KERNEL_NAME(ntt1_inv_kernel<true>), grid, dim3(N1_THREADS), 0, st, x);
-            else TROY_LAUNCH(HIP_KERNEL_NAME(ntt1_inv_kernel<false>), grid, dim3(N1_THREADS), 0, st, x);
+            if (x.md_ct) {
+                if (k.lean) TROY_LAUNCH(HIP_KERNEL_NAME(ntt1_inv_kernel<true, true>), grid, dim3(N1_THREADS), 0, st, x);
+                else TROY_LAUNCH(HIP_KERNEL_NAME(ntt1_inv_kernel<false, true>), grid, dim3(N1_THREADS), 0, st, x);
+            } else if (k.lean) TROY_LAUNCH(HIP_KERNEL_NAME(ntt1_inv_kernel<true, false>), grid, dim3(N1_THREADS), 0, st, x);
+            else TROY_LAUNCH(HIP_KERNEL_NAME(ntt1_inv_kernel<false, false>), grid, dim3(N1_THREADS), 0, st, x);
         } else {
             if (k.lean) TROY_LAUNCH(HIP_KERNEL_NAME(ntt1_fwd_kernel<true>), grid, dim3(N1_THREADS), 0, st, x);
             else TROY_LAUNCH(HIP_KERNEL_NAME(ntt1_fwd_kernel<false>), grid, dim3(N1_THREADS), 0, st, x);
