@@ -5,12 +5,12 @@
 # not available on the pool.)  usage: tools/asan_check.sh
 set -e
 cd "$(dirname "$0")/.."
-make -s -j8 -C troy_amd/csrc emul OBJDIR=$PWD/troy_amd/csrc/build/asan EMUL_OUT=/tmp/libtroyhip_emul_asan.so \
+make -s -j8 -C troy_amd/csrc emul OBJDIR=/tmp/troy_build_asan EMUL_OUT=/tmp/libtroyhip_emul_asan.so \
      EMUL_FLAGS="-O1 -g -fsanitize=address -fno-omit-frame-pointer" EMUL_LDFLAGS="-fsanitize=address"
 export ASAN_OPTIONS=detect_leaks=0:detect_stack_use_after_return=0   # ucontext fibers: no fake stacks
 LD_PRELOAD=$(gcc -print-file-name=libasan.so) TROYHIP_NTT=single python tools/asan_run.py
 # UndefinedBehaviorSanitizer over the same drive (default kernels and the alternative forms)
-make -s -j8 -C troy_amd/csrc emul OBJDIR=$PWD/troy_amd/csrc/build/ubsan EMUL_OUT=/tmp/libtroyhip_emul_ubsan.so \
+make -s -j8 -C troy_amd/csrc emul OBJDIR=/tmp/troy_build_ubsan EMUL_OUT=/tmp/libtroyhip_emul_ubsan.so \
      EMUL_FLAGS="-O1 -g -fsanitize=undefined -fno-sanitize-recover=undefined" EMUL_LDFLAGS="-fsanitize=undefined"
 for e in TROYHIP_NTT=single TROYHIP_BEHZ=mfma1 TROYHIP_BEHZ=valu TROYHIP_NTT=twopass; do
     env $e TROY_EMUL_LIB=/tmp/libtroyhip_emul_ubsan.so LD_PRELOAD=$(gcc -print-file-name=libubsan.so) python tools/asan_run.py
