@@ -39,7 +39,7 @@ WORKLOADS = {
                            metric="ct x ct multiply+relinearize ops/sec, BFV N=2^15 L=14; achieved HBM GB/s vs peak"),
     "bfv_n8192_l4": dict(scheme=BFV, N=8192, bits=[40, 36, 36, 36, 40], tbits=20, kind="mul_relin", batch=1024, streams=2,
                          metric="ct x ct multiply+relinearize ops/sec, BFV N=8192 L=4 (BASELINE configs[1]); achieved HBM GB/s vs peak"),
-    "ckks_n32768_chain": dict(scheme=CKKS, N=32768, bits=[60] + [40] * 13 + [60], tbits=0, kind="ckks_chain", batch=32, streams=1, depth=3,
+    "ckks_n32768_chain": dict(scheme=CKKS, N=32768, bits=[60] + [40] * 13 + [60], tbits=0, kind="ckks_chain", batch=128, streams=1, depth=3,
                               metric="multiply->relinearize->rescale->rotate steps/sec, CKKS N=32768 L=14, chained to depth 3 (BASELINE configs[2])"),
     "bgv_n65536_relin_rot": dict(scheme=BGV, N=65536, bits=[60] + [50] * 13 + [60], tbits=20, kind="relin_rot", batch=32, streams=1,
                                  metric="relinearize+rotateRows ops/sec on size-3 ciphertexts, BGV N=65536 L=14 (BASELINE configs[3])"),

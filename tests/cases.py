@@ -636,7 +636,10 @@ def mul_relin_hash(name, batch=2, seed=4242):
     r = be.ev.multiply(api.Ciphertext.from_numpy(be.ctx, xa, ntt), api.Ciphertext.from_numpy(be.ctx, xb, ntt))
     h1 = sha(r.cpu())
     be.ev.relinearizeInplace(r, be.rlk)
-    return h1 + ":" + sha(r.cpu())
+    h = h1 + ":" + sha(r.cpu())
+    if ntt and L - 1 >= be.last_limbs:  # CKKS: the rescale too (its correction transform has a fused and an element-wise form)
+        h += ":" + sha(be.ev.rescaleToNext(r).cpu())
+    return h
 
 
 def check_modswitch_as_first_op(cfg_name, batch=2):

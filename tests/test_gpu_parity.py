@@ -515,11 +515,12 @@ def test_unfused_kernel_paths_agree(env, gpu):
 
 
 @pytest.mark.parametrize("env", [{"TROYHIP_NTT": "single"}, {"TROYHIP_NTT": "twopass"}, {"TROYHIP_BFLY": "guarded"}, {"TROYHIP_NTT": "single", "TROYHIP_BFLY": "guarded"},
-                                 {"TROYHIP_NTT": "single", "TROYHIP_MODDOWN": "split"}])
+                                 {"TROYHIP_NTT": "single", "TROYHIP_MODDOWN": "split"}, {"TROYHIP_NTT": "single", "TROYHIP_CORR": "split"}])
 def test_ntt_forms_agree_at_headline_size(env, gpu):
     """N = 2^15: the single-pass transform forced at a small batch (by default it takes launches of four rows per CU and more), the
-    two-pass transform forced, guarded butterflies instead of the guard-free ones, and the BFV mod-down in its own kernel instead of in the
-    inverse transform's epilogue (environment switches, read once per process) give the same limbs through multiply + relinearize as the default path, which the golden files pin on the reference"""
+    two-pass transform forced, guarded butterflies instead of the guard-free ones, the BFV mod-down in its own kernel instead of in the
+    inverse transform's epilogue, and the CKKS divide-and-round correction as element-wise kernels instead of inside the forward
+    transform (environment switches, read once per process) give the same limbs through multiply + relinearize as the default path, which the golden files pin on the reference"""
     import subprocess
     import sys
     names = ["cfgNS_bfv_n32768_k15", "cfgC_ckks_n32768_k15"]

@@ -270,6 +270,20 @@ void Context::upload_tables() {
         d.aux = Shoup{0, 0};
     }
     d_desc = upload(h_desc, dev_allocs_);
+    if (scheme == SCHEME_CKKS) { // per-slot inverses of the prime a divide-and-round drops, for the fused correction transform (ntt1.hip)
+        if (K >= 2) {
+            std::vector<Shoup> v;
+            for (int j = 0; j + 1 < K; j++) v.push_back(make_shoup(level(K).rns.inv_q_last_mod_q[j], primes[j]));
+            d_inv_qk = upload(v, dev_allocs_);
+        }
+        for (auto &kv : levels) {
+            Level &lv = kv.second;
+            if (lv.limbs < 2) continue;
+            std::vector<Shoup> v;
+            for (int l = 0; l + 1 < lv.limbs; l++) v.push_back(make_shoup(lv.rns.inv_q_last_mod_q[l], primes[l]));
+            lv.d_inv_qlast = upload(v, lv.dev_blocks);
+        }
+    }
     if (scheme == SCHEME_BFV && K >= 2) {
         std::vector<PrimeDesc> md = h_desc;
         const host::RnsLevel &kr = level(K).rns;

@@ -49,6 +49,7 @@ struct Level {
     host::RnsLevel rns;
     std::vector<uint8_t> bsk_ids;
     std::shared_ptr<BehzDev> behz; // BFV only
+    const Shoup *d_inv_qlast = nullptr; // [limbs - 1]  q_last^-1 mod q_l on the device (Ntt1Corr::inv of the CKKS rescale at this level)
     std::vector<void *> dev_blocks;
 };
 
@@ -74,6 +75,7 @@ public:
     // d_desc with q_special^-1 mod q_j folded into the N^-1 constants of the data primes (and in `aux`): the inverse transform of the
     // key-switch accumulators then delivers acc qk^-1, half of the mod-down (Ntt1ModDown, kernels.h).  BFV contexts with a special prime.
     PrimeDesc *d_desc_md = nullptr;
+    const Shoup *d_inv_qk = nullptr; // [K - 1]  q_special^-1 mod q_j on the device (Ntt1Corr::inv of the CKKS key-switch mod-down)
     std::map<int, Level> levels; // by limb count, K .. last_limbs
     Arena arena;
 

@@ -25,6 +25,17 @@ static bool ks_moddown_fused() {
     return v;
 }
 
+// TROYHIP_CORR=split keeps the CKKS divide-and-round correction as element-wise kernels around a plain transform (tests, measurements)
+static bool corr_fused() {
+    static const bool v = [] { const char *e = getenv("TROYHIP_CORR"); return !(e && e[0] == 's'); }();
+    return v;
+}
+static bool primes_at_least_33_bits(const Context &c, int limbs) { // what the lazy reductions of the fused epilogues (lite_reduce4) take
+    for (int l = 0; l < limbs; l++)
+        if (c.primes[l] < (u64(1) << 33)) return false;
+    return true;
+}
+
 static inline u64 poly_words(const Context &c, int limbs) { return (u64)limbs * c.N; }
 
 void Evaluator::check_ct(const CtBatch &a) const {
@@ -336,9 +347,16 @@ void Evaluator::switch_key(CtBatch &ct, const u64 *target, u64 t_bstride, const 
         u64 *last = c.arena.take(batch * 2 * N), *corr = c.arena.take(batch * 2 * dl * N);
         launch_gather_limb(acc, last, c.logn, rl * N, dl, batch * 2, s);
         launch_ntt(last, c.d_desc, c.single_map((int)K - 1), batch * 2, c.logn, true, s);
-        launch_ks_ckks_corr(last, corr, a, s);
-        launch_ntt(corr, c.d_desc, c.ct_map((int)dl), batch * 2 * dl, c.logn, false, s);
-        launch_ks_ckks_combine(acc, corr, ct.data, ct.bstride, a, s);
+        const LimbMap cmap = c.ct_map((int)dl);
+        if (c.d_inv_qk && corr_fused() && primes_at_least_33_bits(c, (int)dl) && ntt1_supported(c.logn, cmap, batch * 2 * dl)) {
+            // the correction is built, transformed and combined by ONE single-pass transform (Ntt1Corr): no corr buffer, no element-wise kernels
+            const Ntt1Corr cr{last, acc, rl * N, ct.data, ct.bstride, dl * N, 2, c.d_inv_qk, qk, a.half, true};
+            launch_ntt1(nullptr, nullptr, c.d_desc, cmap, batch * 2 * dl, false, s, ~0ull, nullptr, &cr);
+        } else {
+            launch_ks_ckks_corr(last, corr, a, s);
+            launch_ntt(corr, c.d_desc, cmap, batch * 2 * dl, c.logn, false, s);
+            launch_ks_ckks_combine(acc, corr, ct.data, ct.bstride, a, s);
+        }
     } else {
         const LimbMap amap = c.ids_map(out_ids);
         bool md_primes = true; // the epilogue's lazy reduction (lite_reduce4) wants primes of at least 33 bits
@@ -420,9 +438,16 @@ void Evaluator::mod_switch_scale(const CtBatch &in, CtBatch &out, u64 batch, hip
         u64 *last = c.arena.take(batch * in.size * N), *corr = c.arena.take(batch * in.size * npw);
         launch_gather_limb(src, last, c.logn, pw, (u64)nl, batch * in.size, s);
         launch_ntt(last, c.d_desc, c.single_map(L - 1), batch * in.size, c.logn, true, s);
-        launch_rescale_stepA(last, N, corr, a, s);
-        launch_ntt(corr, c.d_desc, c.ct_map(nl), batch * in.size * nl, c.logn, false, s);
-        launch_rescale_stepB(src, corr, dst, a, s);
+        const LimbMap cmap = c.ct_map(nl);
+        const Level &lvl = c.level(L);
+        if (lvl.d_inv_qlast && corr_fused() && primes_at_least_33_bits(c, nl) && ntt1_supported(c.logn, cmap, batch * in.size * nl)) {
+            const Ntt1Corr cr{last, src, (u64)pw, dst, 0, (u64)npw, 0x7FFFFFFFu, lvl.d_inv_qlast, c.primes[L - 1], a.half, false};
+            launch_ntt1(nullptr, nullptr, c.d_desc, cmap, batch * in.size * nl, false, s, ~0ull, nullptr, &cr);
+        } else {
+            launch_rescale_stepA(last, N, corr, a, s);
+            launch_ntt(corr, c.d_desc, cmap, batch * in.size * nl, c.logn, false, s);
+            launch_rescale_stepB(src, corr, dst, a, s);
+        }
     } else {
         launch_modswitch(c.scheme == SCHEME_BFV ? 0 : 2, src, dst, a, s);
     }

@@ -29,9 +29,25 @@ bool ntt1_supported(int logn, const LimbMap &map, size_t rows);
 // instead of being stored; slot `dl` (the special limb) must already be in coefficient form.  `primes` is then Context::d_desc_md,
 // whose N^-1 constants carry qk^-1 and whose `aux` is qk^-1 itself.
 struct Ntt1ModDown { u64 *ct; u64 ct_bstride; u64 dl, qk, half; };
+// CKKS divide-and-round by a prime qx in NTT form (divideAndRoundqLastNttInplace, rns.cpp:832-877; the mod-down of the CKKS key switch,
+// evaluator.cpp:2600-2648): the correction polynomial corr_slot = [(last + half) mod qx]_p + (p - [half]_p) is BUILT on load from the
+// coefficient-form residues `last` of qx (one row per outer index), transformed, and COMBINED on store:
+//   out = (in + p - NTT(corr)) * qx^-1 mod p,   stored, or added to what out holds (accumulate)
+// so the correction never exists in memory and the two element-wise kernels around the transform disappear.  Row (o, slot):
+// in[o * in_ostride + slot * N ..], out[(o / group) * out_gstride + (o % group) * out_ostride + slot * N ..], inv[slot] = qx^-1 mod p_slot.
+struct Ntt1Corr {
+    const u64 *last, *in;
+    u64 in_ostride;
+    u64 *out;
+    u64 out_gstride, out_ostride;
+    unsigned group;
+    const Shoup *inv;
+    u64 qx, half;
+    bool accumulate;
+};
 // slot_mask: only these prime slots of the row pattern are transformed
 void launch_ntt1(u64 *data, const u64 *src, const PrimeDesc *primes, const LimbMap &map, size_t rows, bool inverse, hipStream_t stream, u64 slot_mask = ~0ull,
-                 const Ntt1ModDown *md = nullptr);
+                 const Ntt1ModDown *md = nullptr, const Ntt1Corr *cr = nullptr);
 
 // ---- poly.hip ----
 void launch_ew(int op, const u64 *a, const u64 *b, u64 *out, const PrimeDesc *primes, const LimbMap &map, int logn, u64 rows, hipStream_t s);

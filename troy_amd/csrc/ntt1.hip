@@ -44,6 +44,12 @@ struct Ntt1Args {
     unsigned chunks;      // ceil(m_total / rows_per_wg)
     unsigned nslots;      // a launch covers the prime slots slots[0 .. nslots) of the pattern (one launch per prime class)
     uint8_t slots[64];
+    // forward only: divide-and-round correction (Ntt1Corr): rows are BUILT from cr_last on load and COMBINED with cr_in on store
+    const u64 *cr_last, *cr_in;
+    u64 *cr_out;
+    const Shoup *cr_inv;
+    u64 cr_in_ostride, cr_out_gstride, cr_out_ostride, cr_qx, cr_half;
+    unsigned cr_group, cr_accumulate;
     // inverse only: mod-down epilogue (Ntt1ModDown); md_ct == nullptr: plain stores
     u64 *md_ct;
     u64 md_ct_bstride, md_qk, md_half;
@@ -201,8 +207,9 @@ template <int G, int R, bool LAST, bool UNI, int B0 = 0, class TW> __device__ __
 
 // the last 10 forward stages (5..14) of sub-block sb (coefficients 1024 sb .. 1024 sb + 1023), in place in the wave's region,
 // result canonical to `out` (the sub-block's 1024 coefficients in HBM)
-template <bool LEAN> __device__ __forceinline__ void fwd_subblock(u64 *R, const unsigned sb, const unsigned lane_in, const PrimeDesc &pd, const PrimeConst &pc, const Mod &m,
-                                                                  u64 *out, const Ntt1Args &a, const unsigned mm, const unsigned m_begin, const int stamp0, const bool hf_last) {
+template <bool LEAN, bool CR> __device__ __forceinline__ void fwd_subblock(u64 *R, const unsigned sb, const unsigned lane_in, const PrimeDesc &pd, const PrimeConst &pc, const Mod &m,
+                                                                  u64 *out, const Ntt1Args &a, const unsigned mm, const unsigned m_begin, const int stamp0, const bool hf_last,
+                                                                  const u64 *cr_in = nullptr, const Shoup cr_inv = Shoup{0, 0}) {
     (void)a; (void)mm; (void)m_begin; (void)stamp0; (void)hf_last;
     const unsigned lane = opaque(lane_in);
     N1_PRIO(3);
@@ -272,6 +279,34 @@ template <bool LEAN> __device__ __forceinline__ void fwd_subblock(u64 *R, const 
                 for (int i = 0; i < 4; i++) y[4 * q + i] = v[i];
             }
         }
+        if (CR) { // y = NTT(corr), canonical: out = (in + p - y) * inv mod p, stored or added to what is there (Ntt1Corr)
+            const Shoup iq[4] = {cr_inv, cr_inv, cr_inv, cr_inv};
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                u64 w[4], q[4], r[4];
+#pragma unroll
+                for (int e = 0; e < 2; e++) {
+                    const ulonglong2 v = ld_g2(cr_in, 8 * u + 4 * h + 2 * e);
+                    w[2 * e] = v.x + pc.p - y[4 * h + 2 * e];
+                    w[2 * e + 1] = v.y + pc.p - y[4 * h + 2 * e + 1];
+                }
+                mulhi_approx4_u(q, w, iq);
+#pragma unroll
+                for (int i = 0; i < 4; i++) r[i] = mul_acc_u(0, w[i], cr_inv.op, q[i], pc.negp); // [0, 3p)
+                if (a.cr_accumulate) {
+#pragma unroll
+                    for (int e = 0; e < 2; e++) {
+                        const ulonglong2 v = ld_g2(out, 8 * u + 4 * h + 2 * e);
+                        r[2 * e] += v.x;
+                        r[2 * e + 1] += v.y;
+                    }
+                }
+                csub4(r, pc.two_p);
+                csub4(r, pc.p);
+#pragma unroll
+                for (int i = 0; i < 4; i++) y[4 * h + i] = r[i];
+            }
+        }
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             ulonglong2 v;
@@ -282,7 +317,7 @@ template <bool LEAN> __device__ __forceinline__ void fwd_subblock(u64 *R, const 
     }
 }
 
-template <bool LEAN> __global__ __launch_bounds__(N1_THREADS) void ntt1_fwd_kernel(Ntt1Args a) {
+template <bool LEAN, bool CR> __global__ __launch_bounds__(N1_THREADS) void ntt1_fwd_kernel(Ntt1Args a) {
     // 16 regions of 8 KiB + 32 KiB in which four of the sixteen registers of the waiting half are parked (the other twelve stay in
     // VGPRs): all 160 KiB of the CU
     __shared__ __attribute__((aligned(16))) u64 lds[20 * 1024];
@@ -305,6 +340,10 @@ template <bool LEAN> __global__ __launch_bounds__(N1_THREADS) void ntt1_fwd_kern
         return (((u64)o * period + slot) * inner + k) << N1_LOGN;
     };
     const u64 *in_base = a.src ? a.src : a.data;
+    // CR (inner == 1): row mm of this slot is built from the single source row cr_last[mm] and leaves through the epilogue
+    auto in_row = [&](unsigned mm) -> const u64 * { return CR ? a.cr_last + ((u64)mm << N1_LOGN) : in_base + row_of(mm); };
+    const Shoup cr_inv = CR ? Shoup{((const u64 *)(a.cr_inv + slot))[0], ((const u64 *)(a.cr_inv + slot))[1]} : Shoup{0, 0};
+    const u64 cr_add = CR ? pd.p - barrett64(a.cr_half, m) : 0; // p - [half]_p
     u64 *const region = lds + 1024 * wv;
     // registers of round A: xe[r'] = coefficient 1024 (2 r') + tid, xo[r'] = coefficient 1024 (2 r' + 1) + tid
     u64 xe[16], xo[16];
@@ -315,12 +354,24 @@ template <bool LEAN> __global__ __launch_bounds__(N1_THREADS) void ntt1_fwd_kern
 #pragma unroll
         for (int r = 0; r < 16; r++) x[r] = ld_g(rowp, t + 2048 * r + 1024 * odd);
     };
-    load_half(xe, in_base + row_of(m_begin), 0);
-    load_half(xo, in_base + row_of(m_begin), 1);
+    load_half(xe, in_row(m_begin), 0);
+    load_half(xo, in_row(m_begin), 1);
     u64 *const wlo = lds + sw1(tid), *const whi = wlo + 8 * 1024; // LDS addresses of this thread's element in regions 0..7 / 8..15
     u64 *const park = lds + 16 * 1024 + tid;
     for (unsigned mm = m_begin; mm < m_end; mm++) {
-        u64 *const out = a.data + row_of(mm);
+        u64 *const out = CR ? a.cr_out + (u64)(mm / a.cr_group) * a.cr_out_gstride + (u64)(mm % a.cr_group) * a.cr_out_ostride + ((u64)slot << N1_LOGN) : a.data + row_of(mm);
+        const u64 *const cin = CR ? a.cr_in + (u64)mm * a.cr_in_ostride + ((u64)slot << N1_LOGN) : nullptr;
+        if (CR) { // corr = [(last + half) mod qx]_p + (p - [half]_p), the residue lazily below 4p: below 5p, inside what the butterflies take
+#pragma unroll
+            for (int g = 0; g < 8; g++) {
+                u64 (&xx)[16] = g < 4 ? xe : xo;
+                u64 v[4] = {xx[4 * (g & 3)] + a.cr_half, xx[4 * (g & 3) + 1] + a.cr_half, xx[4 * (g & 3) + 2] + a.cr_half, xx[4 * (g & 3) + 3] + a.cr_half};
+                csub4(v, a.cr_qx);
+                lite_reduce4(v, (u32)pd.cr1, pc);
+#pragma unroll
+                for (int i = 0; i < 4; i++) xx[4 * (g & 3) + i] = v[i] + cr_add;
+            }
+        }
         N1_STAMP(0);
         // round A: stages 0..3 on the even and on the odd registers (the odd ones were requested last), then stage 4 across
         auto twA = [&](int st, int, int blk) { return ld_tw_uniform((pd.root + (1u << st) + blk)); };
@@ -362,11 +413,11 @@ template <bool LEAN> __global__ __launch_bounds__(N1_THREADS) void ntt1_fwd_kern
             }
             __syncthreads();
             N1_STAMP(3 + 6 * hf);
-            if (hf == 1 && mm + 1 < m_end) load_half(xe, in_base + row_of(mm + 1), 0); // all 32 registers are free now: request the next limb's even half
-            fwd_subblock<LEAN>(region, 16 * hf + wv, lane, pd, pc, m, out + 1024 * (16 * hf + wv), a, mm, m_begin, 4 + 6 * hf, hf == 1);
+            if (hf == 1 && mm + 1 < m_end) load_half(xe, in_row(mm + 1), 0); // all 32 registers are free now: request the next limb's even half
+            fwd_subblock<LEAN, CR>(region, 16 * hf + wv, lane, pd, pc, m, out + 1024 * (16 * hf + wv), a, mm, m_begin, 4 + 6 * hf, hf == 1, CR ? cin + 1024 * (16 * hf + wv) : nullptr, cr_inv);
             N1_STAMP(7 + 6 * hf);
         }
-        if (mm + 1 < m_end) load_half(xo, in_base + row_of(mm + 1), 1);
+        if (mm + 1 < m_end) load_half(xo, in_row(mm + 1), 1);
     }
 }
 
@@ -586,7 +637,7 @@ bool ntt1_supported(int logn, const LimbMap &map, size_t rows) {
 // rows laid out r = (o * period + i) * inner + k, prime map.id[i].  The forward transform is launched once per prime class:
 // guard-free butterflies for the slots in map.lean, guarded ones for the rest.
 void launch_ntt1(u64 *data, const u64 *src, const PrimeDesc *primes, const LimbMap &map, size_t rows, bool inverse, hipStream_t stream, u64 slot_mask,
-                 const Ntt1ModDown *md) {
+                 const Ntt1ModDown *md, const Ntt1Corr *cr) {
     if (rows == 0) return;
     const size_t per_outer = (size_t)map.period * map.inner;
     if (rows % per_outer) throw Error(ST_INVALID_ARGUMENT, "ntt1: row count must be a multiple of the limb pattern");
@@ -599,6 +650,12 @@ void launch_ntt1(u64 *data, const u64 *src, const PrimeDesc *primes, const LimbM
     a.primes = primes;
     a.map = map;
     a.m_total = (unsigned)(rows / per_outer * map.inner);
+    if (cr) {
+        if (inverse || map.inner != 1 || src) throw Error(ST_LOGIC_ERROR, "ntt1: the correction form belongs to the forward transform of [outer][slot][N] rows");
+        a.cr_last = cr->last; a.cr_in = cr->in; a.cr_out = cr->out; a.cr_inv = cr->inv;
+        a.cr_in_ostride = cr->in_ostride; a.cr_out_gstride = cr->out_gstride; a.cr_out_ostride = cr->out_ostride;
+        a.cr_qx = cr->qx; a.cr_half = cr->half; a.cr_group = cr->group ? cr->group : 1; a.cr_accumulate = cr->accumulate ? 1 : 0;
+    }
     if (md) { a.md_ct = md->ct; a.md_ct_bstride = md->ct_bstride; a.md_qk = md->qk; a.md_half = md->half; a.md_dl = (unsigned)md->dl; }
     // One workgroup fills a CU, so a launch runs in rounds of `cus` workgroups and a round lasts as long as a workgroup's rows (plus
     // the un-overlapped first load and last store, about a third of a row): pick the rows per workgroup (they share the prime) that
@@ -646,8 +703,11 @@ void launch_ntt1(u64 *data, const u64 *src, const PrimeDesc *primes, const LimbM
             } else if (k.lean) TROY_LAUNCH(HIP_KERNEL_NAME(ntt1_inv_kernel<true, false>), grid, dim3(N1_THREADS), 0, st, x);
             else TROY_LAUNCH(HIP_KERNEL_NAME(ntt1_inv_kernel<false, false>), grid, dim3(N1_THREADS), 0, st, x);
         } else {
-            if (k.lean) TROY_LAUNCH(HIP_KERNEL_NAME(ntt1_fwd_kernel<true>), grid, dim3(N1_THREADS), 0, st, x);
-            else TROY_LAUNCH(HIP_KERNEL_NAME(ntt1_fwd_kernel<false>), grid, dim3(N1_THREADS), 0, st, x);
+            if (x.cr_last) {
+                if (k.lean) TROY_LAUNCH(HIP_KERNEL_NAME(ntt1_fwd_kernel<true, true>), grid, dim3(N1_THREADS), 0, st, x);
+                else TROY_LAUNCH(HIP_KERNEL_NAME(ntt1_fwd_kernel<false, true>), grid, dim3(N1_THREADS), 0, st, x);
+            } else if (k.lean) TROY_LAUNCH(HIP_KERNEL_NAME(ntt1_fwd_kernel<true, false>), grid, dim3(N1_THREADS), 0, st, x);
+            else TROY_LAUNCH(HIP_KERNEL_NAME(ntt1_fwd_kernel<false, false>), grid, dim3(N1_THREADS), 0, st, x);
         }
     };
 #ifdef N1_TIMING // development build: phase stamps of one workgroup of the guard-free forward kernel
