@@ -307,8 +307,13 @@ void Evaluator::switch_key(CtBatch &ct, const u64 *target, u64 t_bstride, const 
     u64 ct_tb = t_bstride;
     if (c.scheme == SCHEME_CKKS) { // bring the target to coefficient form (evaluator_cuda.cu:1215-1216)
         u64 *tt = c.arena.take(batch * dl * N);
-        launch_copy_strided(target, t_bstride, tt, dl * N, dl * N, batch, s);
-        launch_ntt(tt, c.d_desc, c.ct_map((int)dl), batch * dl, c.logn, true, s);
+        const LimbMap tmap = c.ct_map((int)dl);
+        if (ntt1_supported(c.logn, tmap, batch * dl)) { // out of place: the single-pass inverse reads the strided target itself
+            launch_ntt1(tt, target, c.d_desc, tmap, batch * dl, true, s, ~0ull, nullptr, nullptr, t_bstride);
+        } else {
+            launch_copy_strided(target, t_bstride, tt, dl * N, dl * N, batch, s);
+            launch_ntt(tt, c.d_desc, tmap, batch * dl, c.logn, true, s);
+        }
         coeff_target = tt;
         ct_tb = dl * N;
     }

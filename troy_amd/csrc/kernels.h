@@ -47,7 +47,7 @@ struct Ntt1Corr {
 };
 // slot_mask: only these prime slots of the row pattern are transformed
 void launch_ntt1(u64 *data, const u64 *src, const PrimeDesc *primes, const LimbMap &map, size_t rows, bool inverse, hipStream_t stream, u64 slot_mask = ~0ull,
-                 const Ntt1ModDown *md = nullptr, const Ntt1Corr *cr = nullptr);
+                 const Ntt1ModDown *md = nullptr, const Ntt1Corr *cr = nullptr, u64 src_ostride = 0);
 
 // ---- poly.hip ----
 void launch_ew(int op, const u64 *a, const u64 *b, u64 *out, const PrimeDesc *primes, const LimbMap &map, int logn, u64 rows, hipStream_t s);

@@ -36,7 +36,8 @@ namespace troyhip {
 
 struct Ntt1Args {
     u64 *data;            // rows of N coefficients, transformed in place ...
-    const u64 *src;       // ... or read from here (same row layout) when not null
+    const u64 *src;       // ... or read from here when not null: same row layout, or (inverse, src_ostride != 0) outer index o at
+    u64 src_ostride;      //     src + o * src_ostride with its limbs packed behind each other (a strided batch of ciphertext polynomials)
     const PrimeDesc *primes;
     LimbMap map;          // row r = (o * period + i) * inner + k  has prime map.id[i]
     unsigned m_total;     // outer * inner rows per prime slot
@@ -527,13 +528,19 @@ template <bool LEAN, bool MD> __global__ __launch_bounds__(N1_THREADS) void ntt1
                 y[8 * i + 2 * q + 1] = v.y;
             }
     };
-    stage_issue(a.data + row_of(m_begin) + 1024 * wv);
+    // out of place: the first touch of a row reads it from the source (strided batch: a.src_ostride words between outer indices)
+    auto in_of = [&](unsigned mm) -> const u64 * {
+        if (!a.src) return a.data + row_of(mm);
+        const unsigned o = mm / inner, k = mm - o * inner;
+        return a.src + (u64)o * a.src_ostride + ((u64)(slot * inner + k) << N1_LOGN);
+    };
+    stage_issue(in_of(m_begin) + 1024 * wv);
     const u64 *const rlo = lds + sw1(tid), *const rhi = rlo + 8 * 1024;
     for (unsigned mm = m_begin; mm < m_end; mm++) {
         u64 *const row = a.data + row_of(mm);
         u64 x[32]; // x[r] = coefficient tid of sub-block r after its 10 stages
         u64 y[16], y1[16];
-        load16(y1, row + 1024 * (16 + wv)); // second half's input: in flight while the first half is transformed
+        load16(y1, in_of(mm) + 1024 * (16 + wv)); // second half's input: in flight while the first half is transformed
         TROY_WAIT_VMEM();                   // the staged first half has landed (vmcnt counts in order: this also waits for y1 -- see below)
         const unsigned ol = opaque(lane);   // recomputed per row: hoisted out of the loop these eight addresses are spilled
 #pragma unroll
@@ -553,7 +560,7 @@ template <bool LEAN, bool MD> __global__ __launch_bounds__(N1_THREADS) void ntt1
             for (int r = 0; r < 8; r++) { x[16 * hf + r] = rlo[1024 * r]; x[16 * hf + 8 + r] = rhi[1024 * r]; }
             __syncthreads();
         }
-        if (mm + 1 < m_end) stage_issue(a.data + row_of(mm + 1) + 1024 * wv); // the regions are free during round A'
+        if (mm + 1 < m_end) stage_issue(in_of(mm + 1) + 1024 * wv); // the regions are free during round A'
         // round A': stages 4..0 across the 32 sub-blocks, N^-1 folded into the last one
         if (LEAN) { // 64p -> 4p; the five stages reach 32p after three, the fourth halves its sums, the last one multiplies everything by N^-1
 #pragma unroll
@@ -637,16 +644,17 @@ bool ntt1_supported(int logn, const LimbMap &map, size_t rows) {
 // rows laid out r = (o * period + i) * inner + k, prime map.id[i].  The forward transform is launched once per prime class:
 // guard-free butterflies for the slots in map.lean, guarded ones for the rest.
 void launch_ntt1(u64 *data, const u64 *src, const PrimeDesc *primes, const LimbMap &map, size_t rows, bool inverse, hipStream_t stream, u64 slot_mask,
-                 const Ntt1ModDown *md, const Ntt1Corr *cr) {
+                 const Ntt1ModDown *md, const Ntt1Corr *cr, u64 src_ostride) {
     if (rows == 0) return;
     const size_t per_outer = (size_t)map.period * map.inner;
     if (rows % per_outer) throw Error(ST_INVALID_ARGUMENT, "ntt1: row count must be a multiple of the limb pattern");
-    if (src && inverse) throw Error(ST_LOGIC_ERROR, "ntt1: out-of-place input is only supported by the forward transform");
     if (md && (!inverse || map.inner != 1 || md->dl >= map.period)) throw Error(ST_LOGIC_ERROR, "ntt1: the mod-down epilogue belongs to the inverse transform of [..][slot][N] accumulators");
     Ntt1Args a;
     std::memset(&a, 0, sizeof(a));
     a.data = data;
     a.src = src;
+    a.src_ostride = src_ostride;
+    if (src && inverse && !src_ostride) throw Error(ST_LOGIC_ERROR, "ntt1: the out-of-place inverse takes a strided source");
     a.primes = primes;
     a.map = map;
     a.m_total = (unsigned)(rows / per_outer * map.inner);
