@@ -411,8 +411,9 @@ def algorithmic_bytes(w, B):
 
 
 def matmul_roofline(ta, capi, lib, w):
-    """configs[4]: the dominant kernel is the plaintext multiply (mul_plain_kernel: reads the ciphertext and the plaintext, writes
-    the ciphertext = (2 + 2) B + 1 limb-polynomials per product); timed live by the library's per-launch events over one step"""
+    """configs[4]: the dominant kernel is the fused sum of plaintext products of one output block (mul_plain_acc_kernel: reads `count`
+    ciphertext columns and plaintexts, writes one column = (2 count + 2) B + count limb-polynomials), or, with more than 16 input
+    blocks, the plain multiply (mul_plain_kernel: (2 + 2) B + 1); timed live by the library's per-launch events over one step"""
     w.sync_all()
     capi.check(lib, lib.troyhip_ktime_enable(1))
     w.step()
@@ -421,7 +422,8 @@ def matmul_roofline(ta, capi, lib, w):
     capi.check(lib, lib.troyhip_ktime_enable(0))
     k = max(ks, key=lambda e: e["total_us"])
     P = 8.0 * w.N * w.L
-    per_call = (4 * w.B + 1) * P if "mul_plain" in k["name"] else None
+    count = len(w.helper.encodedWeights)  # input blocks summed per output block
+    per_call = ((2 * count + 2) * w.B + count) * P if "mul_plain_acc" in k["name"] else ((4 * w.B + 1) * P if "mul_plain" in k["name"] else None)
     us = k["total_us"] / k["calls"]
     roof = {"bound": "hbm", "kernel": k["name"], "peak": HBM_PEAK_GBPS, "unit": "GB/s", "traffic": None, "launch_us": round(us, 2), "calls_per_step": k["calls"]}
     if per_call:

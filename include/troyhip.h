@@ -175,6 +175,11 @@ int troyhip_rotate(troyhip_context *ctx, troyhip_ct *ct, int steps, int conjugat
 int troyhip_transform_to_ntt(troyhip_context *ctx, troyhip_ct *ct, uint64_t batch, void *stream);            /* transformToNttInplace(Ciphertext) */
 int troyhip_transform_from_ntt(troyhip_context *ctx, troyhip_ct *ct, uint64_t batch, void *stream);          /* transformFromNttInplace */
 int troyhip_multiply_plain_ntt(troyhip_context *ctx, troyhip_ct *ct, const uint64_t *plain, double plain_scale, uint64_t batch, void *stream); /* multiplyPlainInplace, NTT-form operands */
+/* out = sum_i cts[i] (x) plains[i], 1 <= count <= 16, NTT-form operands of one level and one scale; `out` is a caller-allocated batch
+ * (data, batch_stride) that is none of the operands.  One pass instead of the multiplyPlain + addInplace loop of a linear layer
+ * (app/LinearHelperCKKS.cuh:227-248 MatmulHelper::matmul, :536-556 Conv2dHelper::conv2d): same residues, every operand read once. */
+int troyhip_multiply_plain_accumulate(troyhip_context *ctx, const troyhip_ct *const *cts, const uint64_t *const *plains, int count, double plain_scale, troyhip_ct *out,
+                                      uint64_t batch, void *stream);
 /* ---- plaintext operands in coefficient form.  BFV/BGV: plain = plain_coeff_count coefficients mod t per item
  * (device memory); plain_batch_stride = words between the plaintexts of consecutive batch items, 0 = one plaintext for all. ---- */
 /* addPlainInplace / subPlainInplace (src/evaluator_cuda.cu:1654-1720, src/utils/scalingvariant_cuda.cu:21-176).

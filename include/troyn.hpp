@@ -822,6 +822,30 @@ public:
         for (auto &c : out) c.copyMeta(t);
         return out;
     }
+    // sum_i column_i (x) plain_i for whole slab columns in ONE pass (troyhip_multiply_plain_accumulate): what a linear layer's
+    // multiplyPlain + addInplace loop computes per output block, same residues, every operand read once.  Up to 16 products.
+    std::vector<Ciphertext> multiplyPlainAccumulateBatch(const std::vector<std::vector<const Ciphertext *>> &columns, const std::vector<const Plaintext *> &plains) const {
+        if (columns.empty() || columns.size() != plains.size() || columns.size() > 16) throw std::invalid_argument("multiplyPlainAccumulateBatch: 1 to 16 (column, plaintext) pairs");
+        const size_t count = columns.size(), batch = columns[0].size();
+        std::vector<troyhip_ct> views(count);
+        std::vector<const troyhip_ct *> ct_ptrs(count);
+        std::vector<const uint64_t *> pl_ptrs(count);
+        for (size_t i = 0; i < count; i++) {
+            if (columns[i].size() != batch || !Ciphertext::isBatch(columns[i])) throw std::invalid_argument("multiplyPlainAccumulateBatch: the ciphertexts are not dense runs of slabs");
+            const Ciphertext &head = *columns[i][0];
+            if (!head.isNttForm() || !plains[i]->isNttForm()) throw std::invalid_argument("NTT form mismatch");
+            if (head.parmsID() != plains[i]->parmsID()) throw std::invalid_argument("encrypted_ntt and plain_ntt parameter mismatch");
+            if (plains[i]->scale() != plains[0]->scale()) throw std::invalid_argument("scale mismatch");
+            views[i] = *head.raw();
+            ct_ptrs[i] = &views[i];
+            pl_ptrs[i] = plains[i]->device();
+        }
+        std::vector<Ciphertext> out = Ciphertext::allocateBatch(batch, *columns[0][0]);
+        troyhip_ct t = *out[0].raw();
+        check(troyhip_multiply_plain_accumulate(h(), ct_ptrs.data(), pl_ptrs.data(), (int)count, plains[0]->scale(), &t, batch, nullptr));
+        for (auto &c : out) c.copyMeta(t);
+        return out;
+    }
     void addInplaceBatch(std::vector<Ciphertext> &acc, const std::vector<Ciphertext> &x) const {
         if (acc.size() != x.size()) throw std::invalid_argument("Size incorrect.");
         std::vector<const Ciphertext *> pa, px;

@@ -8,8 +8,9 @@
 //
 // What is MI355X-specific: the ciphertexts of one Cipher2d column live in ONE device slab (troyn::Ciphertext::allocateBatch), and
 // the helpers hand a whole column to the library as a single batched launch (Evaluator::multiplyPlainBatch / addInplaceBatch) when
-// they find that layout -- 3 launches for a 128x128 layer at any batch size instead of 3 per input row.  Inputs that were
-// assembled ciphertext by ciphertext take the reference's per-element loop.
+// they find that layout -- ONE launch per output block (the sum over the input blocks inside it: troyhip_multiply_plain_accumulate) for
+// a 128x128 layer at any batch size instead of 3 kernels per input row.  Inputs that were assembled ciphertext by ciphertext take the
+// reference's per-element loop.
 #pragma once
 #include "troyn.hpp"
 #include <cassert>
@@ -131,11 +132,21 @@ template <class W> inline Cipher2d multiplyAccumulate(const troyn::Evaluator &ev
     }
     for (size_t o = 0; o < outputs; o++) {
         std::vector<troyn::Ciphertext> acc;
-        for (size_t i = 0; i < inputs; i++) {
-            for (size_t b = 0; b < rows; b++) column[b] = &a[b][i];
-            std::vector<troyn::Ciphertext> prod = evaluator.multiplyPlainBatch(column, weight(o, i));
-            if (i == 0) acc = std::move(prod);
-            else evaluator.addInplaceBatch(acc, prod);
+        if (inputs <= 16) { // the whole sum over the input blocks in one pass
+            std::vector<std::vector<const troyn::Ciphertext *>> columns(inputs, std::vector<const troyn::Ciphertext *>(rows));
+            std::vector<const troyn::Plaintext *> plains(inputs);
+            for (size_t i = 0; i < inputs; i++) {
+                for (size_t b = 0; b < rows; b++) columns[i][b] = &a[b][i];
+                plains[i] = &weight(o, i);
+            }
+            acc = evaluator.multiplyPlainAccumulateBatch(columns, plains);
+        } else {
+            for (size_t i = 0; i < inputs; i++) {
+                for (size_t b = 0; b < rows; b++) column[b] = &a[b][i];
+                std::vector<troyn::Ciphertext> prod = evaluator.multiplyPlainBatch(column, weight(o, i));
+                if (i == 0) acc = std::move(prod);
+                else evaluator.addInplaceBatch(acc, prod);
+            }
         }
         for (size_t b = 0; b < rows; b++) ret[b][o] = std::move(acc[b]);
     }

@@ -576,6 +576,41 @@ def check_bfv_multiply_limb_count(K, N=256, batch=2, seed=900, big=False):
     return sha(got)
 
 
+def check_multiply_plain_accumulate(N=256, batch=3):
+    """troyhip_multiply_plain_accumulate (one pass) == the multiplyPlain + addInplace loop of the reference's linear helpers, limb for limb:
+    CKKS and BFV (NTT-form operands), sizes 2 and 3, 1 / 3 / 16 products, a strided operand; the argument errors"""
+    from troy_amd import api, capi, synth
+    for scheme, bits, tbits in ((CKKS, [50, 40, 40, 50], 0), (BFV, [58, 57, 60], 20)):
+        primes = api.CoeffModulus.Create(N, bits)
+        ctx = api.SEALContext(scheme, N, primes, api.PlainModulus.Batching(N, tbits) if tbits else 0)
+        ev = api.Evaluator(ctx)
+        L = len(primes) - 1
+        q = primes[:L]
+        for size, count in ((2, 1), (2, 3), (3, 16)):
+            cts = [api.Ciphertext.from_numpy(ctx, synth.uniform_ct(70 + i, q, size, N, batch), True, scale=2.0 ** 20, capacity=3 if i == 1 else None) for i in range(count)]
+            pls = [api.DeviceBuffer.from_numpy(synth.uniform_rows(90 + i, q, L, N)) for i in range(count)]
+            got = ev.multiplyPlainAccumulate(cts, pls, 2.0 ** 10)
+            acc = None
+            for ct, pl in zip(cts, pls):
+                prod = ct.copy()
+                ev.multiplyPlainInplace(prod, pl, 2.0 ** 10)
+                if acc is None:
+                    acc = prod
+                else:
+                    ev.addInplace(acc, prod)
+            assert np.array_equal(got.cpu(), acc.cpu()) and got.scale == acc.scale and got.is_ntt_form and got.size() == size, (scheme, size, count)
+        a = api.Ciphertext.from_numpy(ctx, synth.uniform_ct(1, q, 2, N, batch), True)
+        pl = api.DeviceBuffer.from_numpy(synth.uniform_rows(2, q, L, N))
+        for bad in (lambda: ev.multiplyPlainAccumulate([], [], 1.0), lambda: ev.multiplyPlainAccumulate([a] * 17, [pl] * 17, 1.0),
+                    lambda: ev.multiplyPlainAccumulate([a, api.Ciphertext.from_numpy(ctx, synth.uniform_ct(3, q[:L - 1], 2, N, batch), True)], [pl, pl], 1.0) if L > 1 else (_ for _ in ()).throw(capi.InvalidArgument(0, "")),
+                    lambda: ev.multiplyPlainAccumulate([api.Ciphertext.from_numpy(ctx, synth.uniform_ct(4, q, 2, N, batch), False)], [pl], 1.0)):
+            try:
+                bad()
+            except capi.InvalidArgument:
+                continue
+            raise AssertionError("multiplyPlainAccumulate accepted a bad argument")
+
+
 def random_config(seed, sizes=(256, 1024, 4096)):
     """a seeded random parameter set: scheme, N, 2..6 primes whose sizes sit on the thresholds the kernels branch on (2^33: BEHZ one-step
     reduction and guard-free butterflies start; 2^50: Bsk-sized; 2^58: guard-free butterflies end; 60 bits: largest allowed)"""

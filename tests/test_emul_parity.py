@@ -108,6 +108,10 @@ def test_emulated_random_parameter_sets(seed, emul_api, oracle_lib):
     assert n is None or n > 10, cfg
 
 
+def test_emulated_multiply_plain_accumulate(emul_api):
+    cases.check_multiply_plain_accumulate(N=128, batch=2)
+
+
 def test_emulated_size_limits(emul_api):
     cases.check_size_limits("bfv_n64_k3")
     cases.check_size_limits("ckks_n128_k6")

@@ -462,6 +462,12 @@ def test_random_parameter_sets(seed, gpu, oracle_lib):
     assert n is None or n > 10, cfg
 
 
+def test_multiply_plain_accumulate(gpu):
+    """the fused sum of ciphertext x plaintext products == the multiplyPlain + addInplace loop, limb for limb"""
+    cases.check_multiply_plain_accumulate()
+    cases.check_multiply_plain_accumulate(N=8192, batch=5)
+
+
 @pytest.mark.parametrize("seed", list(range(101, 109)))
 def test_random_parameter_sets_large(seed, gpu, oracle_lib):
     """the same at N = 8192 .. 32768 (multiply, relinearize, rotate / rescale at the first level): the two-pass transform with its fused

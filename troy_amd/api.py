@@ -715,6 +715,22 @@ class Evaluator:
         self._chk(self.lib.troyhip_multiply_plain_ntt(self.context.h, C.byref(st), C.c_void_p(plain_ntt.ptr), C.c_double(plain_scale), C.c_uint64(a.batch), self.stream))
         a._absorb(st)
 
+    def multiplyPlainAccumulate(self, cts, plains, plain_scale=1.0):
+        """sum_i cts[i] (x) plains[i] as ONE pass (troyhip_multiply_plain_accumulate): what the multiplyPlain + addInplace loop of
+        MatmulHelper::matmul / Conv2dHelper::conv2d computes per output block (app/LinearHelperCKKS.cuh:227-248, 536-556), same residues.
+        cts: batched NTT-form ciphertexts of one shape and scale; plains: DeviceBuffer [limbs][N] each; 1..16 products."""
+        if not 1 <= len(cts) <= 16 or len(cts) != len(plains):
+            raise capi.InvalidArgument(capi.INVALID_ARGUMENT, "multiplyPlainAccumulate takes 1 to 16 (ciphertext, plaintext) pairs")
+        a0 = cts[0]
+        out = Ciphertext(self.context, a0.batch, a0.size(), a0.limbs, True, a0.scale, a0.correction_factor, capacity=a0.size())
+        structs = [c.struct() for c in cts]
+        ct_ptrs = (C.POINTER(CtStruct) * len(cts))(*[C.pointer(st) for st in structs])
+        pl_ptrs = (C.c_void_p * len(plains))(*[p.ptr for p in plains])
+        st = out.struct()
+        self._chk(self.lib.troyhip_multiply_plain_accumulate(self.context.h, ct_ptrs, pl_ptrs, len(cts), C.c_double(plain_scale), C.byref(st), C.c_uint64(a0.batch), self.stream))
+        out._absorb(st)
+        return out
+
     # ---- plaintext operands in coefficient form (evaluator_cuda.cu:1654-1948).  plain: DeviceBuffer holding either ONE
     # plaintext (n_coeffs coefficients mod t; CKKS: [limbs][N] NTT rows) or one per batch item (per_item=True, back to back)
     def _plain_stride(self, a, n_coeffs, per_item):

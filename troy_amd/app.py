@@ -177,7 +177,10 @@ class MatmulHelper:
         reference: block row i = 0 initialises, the others are added in order)"""
         if len(a) != len(self.encodedWeights):
             raise capi.InvalidArgument(capi.INVALID_ARGUMENT, "Input size incorrect.")
-        outs = [None] * len(self.encodedWeights[0])
+        rows, cols = len(self.encodedWeights), len(self.encodedWeights[0])
+        if rows <= 16:  # one pass per output block: sum_i a[i] (x) W[i][j], every operand read once (same residues as the loop below)
+            return [evaluator.multiplyPlainAccumulate([a[i] for i in range(rows)], [self.encodedWeights[i][j] for i in range(rows)], self.weightScale) for j in range(cols)]
+        outs = [None] * cols
         for i, wrow in enumerate(self.encodedWeights):
             for j, wp in enumerate(wrow):
                 prod = a[i].copy()
@@ -289,6 +292,8 @@ class Conv2dHelper:
 
     def conv2d(self, evaluator, a):
         """-> list over output channels of one batched ciphertext (sum over input-channel groups in order)"""
+        if len(a) <= 16:  # one pass per output channel (troyhip_multiply_plain_accumulate), as in MatmulHelper.matmul
+            return [evaluator.multiplyPlainAccumulate(list(a), [self.encodedWeights[oc][i] for i in range(len(a))], self.weightScale) for oc in range(self.outputChannels)]
         outs = []
         for oc in range(self.outputChannels):
             acc = None

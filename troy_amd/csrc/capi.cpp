@@ -476,6 +476,17 @@ int troyhip_transform_from_ntt(troyhip_context *ctx, troyhip_ct *ct, uint64_t ba
 int troyhip_multiply_plain_ntt(troyhip_context *ctx, troyhip_ct *ct, const uint64_t *plain, double plain_scale, uint64_t batch, void *stream) {
     return guard([&] { CtBatch x = view(ct); ctx->ev.multiply_plain_ntt(x, plain, plain_scale, batch, (hipStream_t)stream); store(x, ct); });
 }
+int troyhip_multiply_plain_accumulate(troyhip_context *ctx, const troyhip_ct *const *cts, const uint64_t *const *plains, int count, double plain_scale, troyhip_ct *out,
+                                      uint64_t batch, void *stream) {
+    return guard([&] {
+        if (!cts || !plains || count < 1 || count > 16) throw Error(ST_INVALID_ARGUMENT, "multiply_plain_accumulate takes 1 to 16 products");
+        CtBatch v[16];
+        for (int i = 0; i < count; i++) v[i] = view(cts[i]);
+        CtBatch o = view(out);
+        ctx->ev.multiply_plain_accumulate(v, plains, count, plain_scale, o, batch, (hipStream_t)stream);
+        store(o, out);
+    });
+}
 int troyhip_add_plain(troyhip_context *ctx, troyhip_ct *ct, const uint64_t *plain, uint64_t plain_coeff_count, uint64_t plain_batch_stride, double plain_scale,
                       int subtract, uint64_t batch, void *stream) {
     return guard([&] {

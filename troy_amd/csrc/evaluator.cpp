@@ -544,6 +544,31 @@ void Evaluator::multiply_plain_ntt(CtBatch &ct, const u64 *plain, double plain_s
     ct.scale = new_scale;
 }
 
+void Evaluator::multiply_plain_accumulate(const CtBatch *cts, const u64 *const *plains, int count, double plain_scale, CtBatch &out, u64 batch, hipStream_t s) {
+    if (count < 1 || count > 16) throw Error(ST_INVALID_ARGUMENT, "multiply_plain_accumulate takes 1 to 16 products");
+    const CtBatch &a0 = cts[0];
+    check_ct(a0);
+    const u64 words = (u64)a0.size * poly_words(c, a0.limbs);
+    MulPlainAccArgs x;
+    std::memset(&x, 0, sizeof(x));
+    x.count = count;
+    for (int i = 0; i < count; i++) {
+        const CtBatch &a = cts[i];
+        check_ct(a);
+        if (!a.ntt) throw Error(ST_INVALID_ARGUMENT, "encrypted_ntt is not in NTT form");
+        if (!plains[i]) throw Error(ST_INVALID_ARGUMENT, "plain_ntt is not valid for encryption parameters");
+        if (a.size != a0.size || a.limbs != a0.limbs) throw Error(ST_INVALID_ARGUMENT, "encrypted1 and encrypted2 parameter mismatch"); // what addInplace would say
+        if (a.scale != a0.scale) throw Error(ST_INVALID_ARGUMENT, "scale mismatch");
+        if (a.data == out.data) throw Error(ST_INVALID_ARGUMENT, "the destination cannot be one of the operands");
+        x.ct[i] = a.data; x.ct_bstride[i] = a.bstride; x.plain[i] = plains[i];
+    }
+    const double new_scale = a0.scale * plain_scale;
+    if (c.scheme == SCHEME_CKKS && !scale_ok(new_scale, a0.limbs)) throw Error(ST_INVALID_ARGUMENT, "scale out of bounds");
+    if (!out.data || out.bstride < words) throw Error(ST_INVALID_ARGUMENT, "destination batch stride too small for the result size");
+    launch_mul_plain_acc(x, out.data, out.bstride, c.d_desc, c.ct_map(a0.limbs), c.logn, a0.limbs, a0.size, batch, s);
+    out.size = a0.size; out.limbs = a0.limbs; out.ntt = true; out.scale = new_scale; out.cf = a0.cf;
+}
+
 // ---- plaintext operands ----
 static PlainArgs plain_args(Context &c, int limbs, u64 n_coeffs, u64 plain_bstride, u64 items, u64 cf) {
     if (limbs < 1 || limbs > c.K) throw Error(ST_INVALID_ARGUMENT, "parms_id is not valid for the current context");

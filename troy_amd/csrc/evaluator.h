@@ -55,6 +55,8 @@ public:
     void transform_to_ntt(CtBatch &ct, u64 batch, hipStream_t s);
     void transform_from_ntt(CtBatch &ct, u64 batch, hipStream_t s);
     void multiply_plain_ntt(CtBatch &ct, const u64 *plain, double plain_scale, u64 batch, hipStream_t s);
+    // out = sum_i cts[i] (x) plains[i]: the multiplyPlain + addInplace loop of a linear layer as one pass (NTT-form operands of one level)
+    void multiply_plain_accumulate(const CtBatch *cts, const u64 *const *plains, int count, double plain_scale, CtBatch &out, u64 batch, hipStream_t s);
 
     // scratch words needed by the ops (so callers can pre-reserve outside timed regions)
     size_t scratch_multiply(int sa, int sb, int limbs, u64 batch) const;

@@ -138,6 +138,11 @@ void launch_fill_uniform(u64 *out, const PrimeDesc *primes, const LimbMap &map, 
 // ---- selftest.hip (test support) ----
 void launch_modarith_probe(int op, const u64 *a, const u64 *b, const u64 *c, u64 p, u64 aux_value, u64 *out, u64 n, hipStream_t s);
 
+// sum of up to 16 ciphertext (x) plaintext products in NTT form (poly.hip)
+struct MulPlainAccArgs { const u64 *ct[16]; u64 ct_bstride[16]; const u64 *plain[16]; int count; };
+void launch_mul_plain_acc(const MulPlainAccArgs &x, u64 *out, u64 out_bstride, const PrimeDesc *primes, const LimbMap &map, int logn, u64 limbs, u64 size, u64 batch,
+                          hipStream_t s);
+
 // ---- behz.hip ----
 // base-change matrix entry split into 21-bit limbs (m = m0 + m1 2^21 + m2 2^42): see behz.hip
 struct Mat3 { u32 m0, m1, m2, pad; };

@@ -95,6 +95,36 @@ void launch_mul_plain(u64 *a, const u64 *plain, const PrimeDesc *primes, const L
     launch_check("mul_plain_kernel");
 }
 
+// sum_i ct_i (x) plain_i in NTT form, one pass: out[b][k][l][n] = sum_i ct_i[b][k][l][n] * plain_i[l][n] mod p.  The loop of multiplyPlain +
+// addInplace a linear layer runs per output block (app/LinearHelperCKKS.cuh:227-248, 536-556) costs 2 count + (count - 1) kernels and moves
+// every partial product through HBM; here every operand is read once, the products accumulate in 128 bits (count * p^2 < 2^128) and
+// one Barrett step gives the same canonical residue (sums and products of residues are exact whatever the order of reductions).
+__global__ __launch_bounds__(EW_THREADS) void mul_plain_acc_kernel(MulPlainAccArgs x, u64 *out, u64 out_bstride, const PrimeDesc *primes, LimbMap map, int logn, u64 limbs,
+                                                                   u64 item_words, u64 total) {
+    const u64 i = ((u64)blockIdx.x * EW_THREADS + threadIdx.x) * 2; // two coefficients per thread, over batch * size * limbs * N
+    if (i >= total) return;
+    const u64 b = i / item_words, r = i - b * item_words, row = r >> logn, l = row % limbs, n = r & ((u64(1) << logn) - 1);
+    const Mod m = mod_of(prime_of(primes, map, l));
+    U128 s0{0, 0}, s1{0, 0};
+    for (int t = 0; t < x.count; t++) {
+        const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(x.ct[t] + b * x.ct_bstride[t] + r);
+        const ulonglong2 w = *reinterpret_cast<const ulonglong2 *>(x.plain[t] + (l << logn) + n);
+        mac128(s0, v.x, w.x);
+        mac128(s1, v.y, w.y);
+    }
+    ulonglong2 o;
+    o.x = barrett128(s0.lo, s0.hi, m);
+    o.y = barrett128(s1.lo, s1.hi, m);
+    *reinterpret_cast<ulonglong2 *>(out + b * out_bstride + r) = o;
+}
+void launch_mul_plain_acc(const MulPlainAccArgs &x, u64 *out, u64 out_bstride, const PrimeDesc *primes, const LimbMap &map, int logn, u64 limbs, u64 size, u64 batch,
+                          hipStream_t s) {
+    const u64 item_words = (size * limbs) << logn, total = batch * item_words;
+    if (!total) return;
+    TROY_LAUNCH(mul_plain_acc_kernel, dim3(ceil_div(total / 2, EW_THREADS)), dim3(EW_THREADS), 0, s, x, out, out_bstride, primes, map, logn, limbs, item_words, total);
+    launch_check("mul_plain_acc_kernel");
+}
+
 // ---------------------------------------------------------------- plaintext operands
 // addPlain / subPlain on c0 (evaluator_cuda.cu:1654-1720):
 //   BFV  (scalingvariant_cuda.cu:21-176 multiplyAdd/SubPlainWithScalingVariant): c0_l[j] +-= m_j * Delta_l + floor((m_j (q mod t) + (t+1)/2) / t)
