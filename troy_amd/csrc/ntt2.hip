@@ -84,6 +84,12 @@ struct Ntt2Args {
     uint8_t mac_key_limb[65];
 };
 
+__device__ __forceinline__ unsigned n2_opaque(unsigned v) {
+#ifndef TROYHIP_CPU_EMUL
+    asm volatile("" : "+v"(v));
+#endif
+    return v;
+}
 __device__ __forceinline__ unsigned swz(unsigned f) { return f ^ ((f >> 3) & 7u) ^ (((f >> 6) & 3u) << 3); }
 
 // global coefficient index of flattened tile index f
@@ -215,19 +221,21 @@ template <int INV, int STRIDED, int NS, int LOGC, int LS, int R, bool HOISTP = t
             for (int i = 0; i < 4; i++) { x[ix[i]] = X[i]; x[iy[i]] = Y[i]; }
         }
     }
-    __device__ static __forceinline__ void lds_read(u64 (&x)[8], const u64 *lds) {
+    // t = threadIdx.x, or an opaque copy of it made inside the row loop: the addresses are then formed next to the access instead of
+    // being hoisted out of the loop, where eight of them per exchange would live (or be spilled) across the whole kernel
+    __device__ static __forceinline__ void lds_read(u64 (&x)[8], const u64 *lds, const unsigned t) {
         if (N2_EXP & 2) return;
 #pragma unroll
         for (int u = 0; u < G; u++)
 #pragma unroll
-            for (int e = 0; e < (1 << R); e++) x[(u << R) + e] = lds[swz(elem(threadIdx.x + N2_THREADS * u, e))];
+            for (int e = 0; e < (1 << R); e++) x[(u << R) + e] = lds[swz(elem(t + N2_THREADS * u, e))];
     }
-    __device__ static __forceinline__ void lds_write(const u64 (&x)[8], u64 *lds) {
+    __device__ static __forceinline__ void lds_write(const u64 (&x)[8], u64 *lds, const unsigned t) {
         if (N2_EXP & 2) return;
 #pragma unroll
         for (int u = 0; u < G; u++)
 #pragma unroll
-            for (int e = 0; e < (1 << R); e++) lds[swz(elem(threadIdx.x + N2_THREADS * u, e))] = x[(u << R) + e];
+            for (int e = 0; e < (1 << R); e++) lds[swz(elem(t + N2_THREADS * u, e))] = x[(u << R) + e];
     }
     // ---- LDS-DMA staging of the first round's input (contiguous passes): the next row streams into a wave-private
     // 4 KiB staging area while the current row is being transformed, without holding VGPRs for it.  Every DMA
@@ -417,7 +425,7 @@ template <> struct Plan<3> { static constexpr int r[4] = {3, 0, 0, 0}; };
 template <> struct Plan<4> { static constexpr int r[4] = {3, 1, 0, 0}; };
 template <> struct Plan<5> { static constexpr int r[4] = {3, 2, 0, 0}; };
 template <> struct Plan<6> { static constexpr int r[4] = {3, 3, 0, 0}; };
-template <> struct Plan<7> { static constexpr int r[4] = {3, 3, 1, 0}; };
+template <> struct Plan<7> { static constexpr int r[4] = {3, 1, 3, 0}; }; // the single stage in the MIDDLE: wave-uniform twiddles (SGPRs) in both directions; {3, 3, 1} spilled
 template <> struct Plan<9> { static constexpr int r[4] = {3, 3, 3, 0}; };
 template <> struct Plan<10> { static constexpr int r[4] = {3, 3, 3, 1}; };
 template <> struct Plan<11> { static constexpr int r[4] = {3, 3, 3, 2}; };
@@ -430,6 +438,12 @@ __global__ __launch_bounds__(N2_THREADS, MAC ? N2_MAC_WAVES : N2_MIN_WAVES) void
     // leave [512*(t/64), 512*(t/64)+512), and the XOR swizzle only permutes address bits 0..4), so the LDS exchange
     // needs no workgroup barrier at all: the four waves run fully decoupled and overlap each other's HBM phases.
     constexpr bool WAVE_PRIVATE = !STRIDED && NS == 9;
+    // Which LDS exchanges form their addresses per row instead of once per workgroup (bit 0: round 0 write, 1: round 1 read, 2: round 1
+    // write, 3: round 2 read, 4: round 2 write, 5: round 3 read).  Hoisted, the eight swizzled addresses of an exchange live across the
+    // whole row loop; in the instances at the 128-register limit the compiler spilled them, and a spill reload waits with vmcnt(0) --
+    // i.e. for the NEXT row's loads, which were issued before it: the HBM latency landed in the middle of every row (forward
+    // contiguous pass 2038 -> 1525 us per 6720 rows of N = 2^16; three XORs per address are nothing next to that).
+    constexpr int FRESH = (!STRIDED && !INV && NS == 9 && MAC == 0) ? (FINAL ? 15 : 1) : (STRIDED && !INV && NS == 7) ? 1 : (!STRIDED && NS == 10) ? 63 : 0;
     auto round_sync = [&]() {
         if (N2_EXP & 2) return;
         if (WAVE_PRIVATE) TROY_WAVE_SYNC(); else __syncthreads();
@@ -538,18 +552,18 @@ __global__ __launch_bounds__(N2_THREADS, MAC ? N2_MAC_WAVES : N2_MIN_WAVES) void
         if constexpr (NR == 1) {
             Rd0::template g_write<FINAL>(x, row, tile, logn, m, lean);
         } else {
-            Rd0::lds_write(x, buf);
+            Rd0::lds_write(x, buf, (FRESH & 1) ? n2_opaque(threadIdx.x) : threadIdx.x);
             round_sync();
             if constexpr (!Rd1::HOIST) Rd1::load_tw(tw1, pd, tile, logn, s_first);
-            Rd1::lds_read(x, buf);
+            Rd1::lds_read(x, buf, (FRESH & 2) ? n2_opaque(threadIdx.x) : threadIdx.x);
             Rd1::compute(x, tw1, pd, lean);
             if constexpr (NR == 2) {
                 Rd1::template g_write<FINAL>(x, row, tile, logn, m, lean);
             } else {
-                Rd1::lds_write(x, buf);
+                Rd1::lds_write(x, buf, (FRESH & 4) ? n2_opaque(threadIdx.x) : threadIdx.x);
                 round_sync();
                 if constexpr (!Rd2::HOIST) Rd2::load_tw(tw2, pd, tile, logn, s_first);
-                Rd2::lds_read(x, buf);
+                Rd2::lds_read(x, buf, (FRESH & 8) ? n2_opaque(threadIdx.x) : threadIdx.x);
                 Rd2::compute(x, tw2, pd, lean);
                 if constexpr (NR == 3 && MAC == 2) {
                     Rd2::tensor_epilogue(x, tx, mm, a.tensor_out, period, slot, tile, logn, m, WAVE_PRIVATE ? buf : nullptr, lean);
@@ -589,10 +603,10 @@ __global__ __launch_bounds__(N2_THREADS, MAC ? N2_MAC_WAVES : N2_MIN_WAVES) void
                 } else if constexpr (NR == 3) {
                     Rd2::template g_write<FINAL>(x, row, tile, logn, m, lean, WAVE_PRIVATE ? buf : nullptr);
                 } else {
-                    Rd2::lds_write(x, buf);
+                    Rd2::lds_write(x, buf, (FRESH & 16) ? n2_opaque(threadIdx.x) : threadIdx.x);
                     round_sync();
                     if constexpr (!Rd3::HOIST) Rd3::load_tw(tw3, pd, tile, logn, s_first);
-                    Rd3::lds_read(x, buf);
+                    Rd3::lds_read(x, buf, (FRESH & 32) ? n2_opaque(threadIdx.x) : threadIdx.x);
                     Rd3::compute(x, tw3, pd, lean);
                     Rd3::template g_write<FINAL>(x, row, tile, logn, m, lean);
                 }
