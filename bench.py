@@ -383,9 +383,14 @@ def algorithmic_bytes(w, B):
     add(f"ntt2_kernel<0, 1, {k1}, {logc}, 0, 0, 0>", 2 * (2 * B * L) * 2 * P + 2 * (2 * B * nb) * 2 * P)
     add("ntt2_kernel<0, 0, 9, 0, 1, 0, 2>", 7 * B * (L + nb) * P)
     inv_rows = 3 * B * (L + nb) + 2 * B * (L + 1)
+    md_split = os.environ.get("TROYHIP_MODDOWN", "")[:1] == "s"
     if two_pass:
+        # with the mod-down fused (the default) the last pass of the L data limbs of the accumulators reads ct as well and writes ct instead
+        # of acc (+ the special limb once per (ciphertext, accumulator)); the special limb goes through both passes on its own
         add("ntt2_kernel<1, 0, 9, 0, 0, 0, 0>", inv_rows * 2 * P)
-        add(f"ntt2_kernel<1, 1, {k1}, {logc}, 2, 0, 0>", inv_rows * 2 * P)
+        add(f"ntt2_kernel<1, 1, {k1}, {logc}, 2, 0, 0>", (inv_rows if md_split else inv_rows - 2 * B * L) * 2 * P)
+        if not md_split:
+            add(f"ntt2_kernel<1, 1, {k1}, {logc}, 3, 0, 0>", 2 * B * L * 3 * P + 2 * B * P)
     else:
         # the single-pass inverse runs as two launches by prime class: guard-free rounds below 2^58, guarded butterflies for the rest
         qs = [int(p) for p in w.ctx.coeff_modulus]
@@ -405,7 +410,7 @@ def algorithmic_bytes(w, B):
     # relinearize: digit decomposition + first pass, second pass with the inner product against the key, inverse, mod-down
     add(f"ntt2_kernel<0, 1, {k1}, {logc}, 0, 1, 0>", B * L * P + B * (L + 1) * L * P)
     add("ntt2_kernel<0, 0, 9, 0, 1, 0, 1>", B * (L + 1) * L * P + 2 * (L + 1) * L * P + 2 * B * (L + 1) * P)
-    if two_pass or not (os.environ.get("TROYHIP_MODDOWN", "")[:1] != "s" and all(int(p) >= 1 << 33 for p in w.ctx.coeff_modulus[:L])):
+    if md_split or (not two_pass and not all(int(p) >= 1 << 33 for p in w.ctx.coeff_modulus[:L])):
         add("ks_moddown_kernel<0>", B * (2 * (L + 1) + 4 * L) * P)
     return t
 

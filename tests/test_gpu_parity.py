@@ -502,10 +502,11 @@ def test_behz_kernel_forms_agree(env, gpu, oracle_lib):
     assert out.stdout.split()[-len(Ks):] == here
 
 
-@pytest.mark.parametrize("env", [{"TROYHIP_KS": "split"}, {"TROYHIP_TENSOR": "split"}, {"TROYHIP_BEHZ": "valu"}])
+@pytest.mark.parametrize("env", [{"TROYHIP_KS": "split"}, {"TROYHIP_TENSOR": "split"}, {"TROYHIP_BEHZ": "valu"}, {"TROYHIP_MODDOWN": "split"}])
 def test_unfused_kernel_paths_agree(env, gpu):
-    """the unfused key-switch inner product, the unfused tensor and the VALU BEHZ kernels (environment switches, read once per
-    process) give the same limbs as the default path, which the tests above pin against the oracle and the golden files"""
+    """the unfused key-switch inner product, the unfused tensor, the VALU BEHZ kernels and the element-wise BFV / BGV mod-down instead of
+    the inverse transform's epilogue (environment switches, read once per process) give the same limbs as the default path, which the
+    tests above pin against the oracle and the golden files"""
     import subprocess
     import sys
     names = ["cfgA_bfv_n4096_k3", "cfgB_bfv_n8192_k5", "bgv_n4096_k3", "ckks_n4096_k4", "bfv_n16384_k4"]

@@ -284,7 +284,7 @@ void Context::upload_tables() {
             lv.d_inv_qlast = upload(v, lv.dev_blocks);
         }
     }
-    if (scheme == SCHEME_BFV && K >= 2) {
+    if ((scheme == SCHEME_BFV || scheme == SCHEME_BGV) && K >= 2) {
         std::vector<PrimeDesc> md = h_desc;
         const host::RnsLevel &kr = level(K).rns;
         for (int j = 0; j + 1 < K; j++) {

@@ -73,7 +73,7 @@ public:
     std::vector<PrimeDesc> h_desc;
     PrimeDesc *d_desc = nullptr;
     // d_desc with q_special^-1 mod q_j folded into the N^-1 constants of the data primes (and in `aux`): the inverse transform of the
-    // key-switch accumulators then delivers acc qk^-1, half of the mod-down (Ntt1ModDown, kernels.h).  BFV contexts with a special prime.
+    // key-switch accumulators then delivers acc qk^-1, half of the mod-down (Ntt1ModDown / Ntt2ModDown, kernels.h).  BFV and BGV contexts with a special prime.
     PrimeDesc *d_desc_md = nullptr;
     const Shoup *d_inv_qk = nullptr; // [K - 1]  q_special^-1 mod q_j on the device (Ntt1Corr::inv of the CKKS key-switch mod-down)
     std::map<int, Level> levels; // by limb count, K .. last_limbs

@@ -372,6 +372,16 @@ void Evaluator::switch_key(CtBatch &ct, const u64 *target, u64 t_bstride, const 
             launch_ntt1(acc, nullptr, c.d_desc, amap, batch * 2 * rl, true, s, u64(1) << dl, nullptr);
             const Ntt1ModDown md{ct.data, ct.bstride, dl, qk, a.half};
             launch_ntt1(acc, nullptr, c.d_desc_md, amap, batch * 2 * rl, true, s, (u64(1) << dl) - 1, &md);
+        } else if (c.d_desc_md && ntt2_supported(c.logn) && ks_moddown_fused()) {
+            // two-pass inverse, same shape: the special limb first, then the data limbs with the mod-down (BFV or BGV) as the last pass's epilogue
+            launch_ntt2_slots(acc, nullptr, 0, false, c.d_desc, amap, batch * 2 * rl, c.logn, true, s, false, 0, (unsigned)dl, 1, nullptr);
+            u64 *share = nullptr;
+            if (c.scheme == SCHEME_BGV) { // what the special limb takes out of every data limb, once per coefficient (the CKKS part of the reservation is free)
+                share = c.arena.take(batch * 4 * N);
+                launch_ks_bgv_share(acc, share, a, s);
+            }
+            const Ntt2ModDown md{c.scheme == SCHEME_BFV ? 0 : 2, ct.data, ct.bstride, (unsigned)dl, qk, a.half, share};
+            launch_ntt2_slots(acc, nullptr, 0, false, c.d_desc_md, amap, batch * 2 * rl, c.logn, true, s, false, 0, 0, (unsigned)dl, &md);
         } else {
             launch_ntt(acc, c.d_desc, amap, batch * 2 * rl, c.logn, true, s);
             launch_ks_moddown(c.scheme == SCHEME_BFV ? 0 : 2, acc, ct.data, ct.bstride, a, s);

@@ -19,6 +19,14 @@ void launch_ntt_from(u64 *data, const u64 *src, const PrimeDesc *primes, const L
 
 // ---- ntt2.hip (N >= 4096) ----
 bool ntt2_supported(int logn);
+// Mod-down of BFV (kind 0) / BGV (kind 2) key switching as the store epilogue of the two-pass inverse transform (every size the
+// single-pass kernel does not take): `data` = acc[2 batch][dl + 1][N], slot dl already in coefficient form, `primes` = Context::d_desc_md
+// (N^-1 constants carry qk^-1, aux = qk^-1); the data slots are transformed and  ct[b][k][j] += (acc_j - share of the special limb) qk^-1
+// is applied instead of storing them (evaluator.cpp:2528-2648).
+// BGV: `share` = the 128-bit integers al + k_t qk per (item, coefficient) from launch_ks_bgv_share (poly.hip).
+struct Ntt2ModDown { int kind; u64 *ct; u64 ct_bstride; unsigned dl; u64 qk, half; const u64 *share; };
+void launch_ntt2_slots(u64 *data, const u64 *src, u64 src_ostride, bool src_reduce, const PrimeDesc *primes, const LimbMap &map, size_t rows, int logn,
+                       bool inverse, hipStream_t stream, bool src_same_layout, u64 src_bound, unsigned slot_begin, unsigned slot_count, const Ntt2ModDown *md);
 void launch_ntt2(u64 *data, const u64 *src, u64 src_ostride, bool src_reduce, const PrimeDesc *primes, const LimbMap &map, size_t rows, int logn,
                  bool inverse, hipStream_t stream, bool src_same_layout = false, u64 src_bound = 0);
 
@@ -107,6 +115,7 @@ struct KsArgs {
 void launch_ks_expand(const u64 *target, u64 t_bstride, u64 *D, const KsArgs &a, hipStream_t s);
 void launch_ks_mac(const u64 *D, const u64 *key, const u64 *ckks_target, u64 t_bstride, u64 *acc, const KsArgs &a, hipStream_t s);
 void launch_ks_moddown(int kind, const u64 *acc, u64 *ct, u64 ct_bstride, const KsArgs &a, hipStream_t s);
+void launch_ks_bgv_share(const u64 *acc, u64 *share /* [2 batch][N][2] */, const KsArgs &a, hipStream_t s);
 void launch_ks_ckks_corr(const u64 *last, u64 *corr, const KsArgs &a, hipStream_t s);
 void launch_ks_ckks_combine(const u64 *acc, const u64 *corr, u64 *ct, u64 ct_bstride, const KsArgs &a, hipStream_t s);
 // ---- decryption (decryptor_cuda.cu:61-330, rns_cuda.cu:510-621) ----

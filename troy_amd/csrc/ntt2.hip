@@ -50,6 +50,9 @@ namespace troyhip {
 #ifndef N2_COALESCED_STORE
 #define N2_COALESCED_STORE 1 // forward contiguous pass: transpose the last round through LDS, store 1 KiB per instruction
 #endif
+#ifndef N2_FRESH_MD
+#define N2_FRESH_MD 15
+#endif
 #define N2_THREADS 256
 #define N2_LOGT 11
 #define N2_T 2048
@@ -82,6 +85,13 @@ struct Ntt2Args {
     unsigned mac_K;
     int mac_lazy;           // every output prime p satisfies dl * 8p * p < 2^128: the transforms are accumulated unreduced
     uint8_t mac_key_limb[65];
+    // inverse transforms of a range of prime slots only, and the key-switch mod-down as the store epilogue of the last pass
+    // (Ntt2ModDown, kernels.h; FINAL = 3 BFV / 4 BGV): rows are acc[o][slot][N] with inner == 1, o = 2 b + k
+    unsigned slot_begin = 0;
+    u64 *md_ct = nullptr;
+    u64 md_ct_bstride = 0, md_qk = 0, md_half = 0;
+    const u64 *md_share = nullptr; // BGV: [o][N] 128-bit integers al + k_t qk (ks_bgv_share_kernel, poly.hip)
+    unsigned md_dl = 0;
 };
 
 __device__ __forceinline__ unsigned n2_opaque(unsigned v) {
@@ -348,15 +358,15 @@ template <int INV, int STRIDED, int NS, int LOGC, int LS, int R, bool HOISTP = t
         }
     }
     // global access; consecutive-element runs are moved 16 bytes at a time
-    template <int REDUCE> __device__ static __forceinline__ void g_read(u64 (&x)[8], const u64 *row, unsigned tile, int logn, const Mod &m) {
+    template <int REDUCE> __device__ static __forceinline__ void g_read(u64 (&x)[8], const u64 *row, unsigned tile, int logn, const Mod &m, const unsigned t = threadIdx.x) {
         if (N2_EXP & 1) {
 #pragma unroll
-            for (int e = 0; e < 8; e++) x[e] = (u64)(uintptr_t)row + threadIdx.x * 8 + e;
+            for (int e = 0; e < 8; e++) x[e] = (u64)(uintptr_t)row + t * 8 + e;
             return;
         }
 #pragma unroll
         for (int u = 0; u < G; u++) {
-            const unsigned q = threadIdx.x + N2_THREADS * u;
+            const unsigned q = t + N2_THREADS * u;
             if (LOGD == 0) {
 #pragma unroll
                 for (int e = 0; e < (1 << R); e += 2) {
@@ -417,6 +427,50 @@ template <int INV, int STRIDED, int NS, int LOGC, int LS, int R, bool HOISTP = t
             }
         }
     }
+    // FINAL = 3 / 4: the mod-down of BFV / BGV key switching (evaluator.cpp:2528-2648, the element-wise ks_moddown_kernel of poly.hip) instead
+    // of the store.  The row is acc[o][slot] transformed with a prime table whose N^-1 constants carry qk^-1 (Context::d_desc_md), so x is
+    // acc_j qk^-1, lazily below 4p; the special limb acc[o][dl] is already in coefficient form.  With al = acc[o][dl][n]:
+    //   BFV: ct[b][k][slot][n] += x + ([half]_p - [(al + half) mod qk]_p) qk^-1
+    //   BGV: ct[b][k][slot][n] += x - [al + k_t qk]_p qk^-1,   k_t = -al qk^-1 mod t; the integer al + k_t qk comes from md_share
+    // every term canonical before the final addition, as in the element-wise kernel: same residues, same stored values.
+    template <int FINAL> __device__ static __forceinline__ void md_write(u64 (&x)[8], const Ntt2Args &a, unsigned o, unsigned slot, unsigned tile, int logn, const Mod &m,
+                                                                         const PrimeDesc &pd) {
+        static_assert(INV && STRIDED && G == 1, "the mod-down epilogue belongs to the last inverse pass");
+        const u64 p = m.p;
+        const PrimeConst pc = make_prime_const(p);
+        const u64 *sp = a.data + (((u64)o * a.map.period + a.md_dl) << logn);
+        u64 *ct = a.md_ct + (u64)(o >> 1) * a.md_ct_bstride + (((u64)(o & 1) * a.md_dl + slot) << logn);
+        const ulonglong2 *sh = reinterpret_cast<const ulonglong2 *>(a.md_share) + ((u64)o << logn);
+        const u64 c_p = FINAL == 3 ? barrett64(a.md_half, m) : 0; // [half]_p
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            u64 v[4] = {x[4 * h], x[4 * h + 1], x[4 * h + 2], x[4 * h + 3]};
+            reduce4_from_4p(v, pc);
+            u64 al[4], ah[4], c[4];
+            unsigned n[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                n[i] = g_index<STRIDED, NS, LOGC>(tile, elem(threadIdx.x, 4 * h + i), logn);
+                if (FINAL == 3) { al[i] = sp[n[i]]; ah[i] = 0; }
+                else { const ulonglong2 t = sh[n[i]]; al[i] = t.x; ah[i] = t.y; }
+                c[i] = ct[n[i]];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                u64 w; // minus the special limb's share before the multiplication by qk^-1, in (0, 2p]
+                if (FINAL == 3) {
+                    u64 tl = al[i] + a.md_half;
+                    tl = tl >= a.md_qk ? tl - a.md_qk : tl;
+                    w = p + c_p - barrett64(tl, m);
+                } else {
+                    w = p - barrett128(al[i], ah[i], m);
+                }
+                u64 r = v[i] + mul_shoup(w, pd.aux, p);
+                r = r >= p ? r - p : r;
+                ct[n[i]] = addmod(c[i], r, p);
+            }
+        }
+    }
 };
 
 // stage split of a pass into rounds: up to four rounds R0..R3 (0 = unused)
@@ -443,7 +497,7 @@ __global__ __launch_bounds__(N2_THREADS, MAC ? N2_MAC_WAVES : N2_MIN_WAVES) void
     // whole row loop; in the instances at the 128-register limit the compiler spilled them, and a spill reload waits with vmcnt(0) --
     // i.e. for the NEXT row's loads, which were issued before it: the HBM latency landed in the middle of every row (forward
     // contiguous pass 2038 -> 1525 us per 6720 rows of N = 2^16; three XORs per address are nothing next to that).
-    constexpr int FRESH = (!STRIDED && !INV && NS == 9 && MAC == 0) ? (FINAL ? 15 : 1) : (STRIDED && !INV && NS == 7) ? 1 : (!STRIDED && NS == 10) ? 63 : 0;
+    constexpr int FRESH = (!STRIDED && !INV && NS == 9 && MAC == 0) ? (FINAL ? 15 : 1) : (STRIDED && !INV && NS == 7) ? 1 : (!STRIDED && NS == 10) ? 63 : (FINAL >= 3 && NS >= 6) ? N2_FRESH_MD : 0;
     auto round_sync = [&]() {
         if (N2_EXP & 2) return;
         if (WAVE_PRIVATE) TROY_WAVE_SYNC(); else __syncthreads();
@@ -466,7 +520,7 @@ __global__ __launch_bounds__(N2_THREADS, MAC ? N2_MAC_WAVES : N2_MIN_WAVES) void
     const unsigned grp = blockIdx.x >> a.tiles_per_row_log;
     // group order: prime slot major (workgroups in flight share the twiddles, and in the fused key-switch pass the key window),
     // or slot FASTEST (the first key-switch pass: the L+1 readers of one source digit run together and hit in L2)
-    const unsigned slot = a.slot_fastest ? grp % a.map.period : grp / a.chunks, chunk = a.slot_fastest ? grp / a.map.period : grp % a.chunks;
+    const unsigned slot = a.slot_fastest ? grp % a.map.period : a.slot_begin + grp / a.chunks, chunk = a.slot_fastest ? grp / a.map.period : grp % a.chunks;
     const PrimeDesc pd = a.primes[a.map.id[slot]];
     const Mod m = mod_of(pd);
     const bool need_reduce = REDUCE && (a.src_bound == 0 || (pd.p >> 61) != 0 || a.src_bound > 8 * pd.p);
@@ -550,7 +604,8 @@ __global__ __launch_bounds__(N2_THREADS, MAC ? N2_MAC_WAVES : N2_MIN_WAVES) void
         if constexpr (!Rd0::HOIST) Rd0::load_tw(tw0, pd, tile, logn, s_first);
         Rd0::compute(x, tw0, pd, lean);
         if constexpr (NR == 1) {
-            Rd0::template g_write<FINAL>(x, row, tile, logn, m, lean);
+            if constexpr (FINAL >= 3) Rd0::template md_write<FINAL>(x, a, mm, slot, tile, logn, m, pd);
+            else Rd0::template g_write<FINAL>(x, row, tile, logn, m, lean);
         } else {
             Rd0::lds_write(x, buf, (FRESH & 1) ? n2_opaque(threadIdx.x) : threadIdx.x);
             round_sync();
@@ -558,7 +613,8 @@ __global__ __launch_bounds__(N2_THREADS, MAC ? N2_MAC_WAVES : N2_MIN_WAVES) void
             Rd1::lds_read(x, buf, (FRESH & 2) ? n2_opaque(threadIdx.x) : threadIdx.x);
             Rd1::compute(x, tw1, pd, lean);
             if constexpr (NR == 2) {
-                Rd1::template g_write<FINAL>(x, row, tile, logn, m, lean);
+                if constexpr (FINAL >= 3) Rd1::template md_write<FINAL>(x, a, mm, slot, tile, logn, m, pd);
+                else Rd1::template g_write<FINAL>(x, row, tile, logn, m, lean);
             } else {
                 Rd1::lds_write(x, buf, (FRESH & 4) ? n2_opaque(threadIdx.x) : threadIdx.x);
                 round_sync();
@@ -601,7 +657,8 @@ __global__ __launch_bounds__(N2_THREADS, MAC ? N2_MAC_WAVES : N2_MIN_WAVES) void
                         }
                     }
                 } else if constexpr (NR == 3) {
-                    Rd2::template g_write<FINAL>(x, row, tile, logn, m, lean, WAVE_PRIVATE ? buf : nullptr);
+                    if constexpr (FINAL >= 3) Rd2::template md_write<FINAL>(x, a, mm, slot, tile, logn, m, pd);
+                    else Rd2::template g_write<FINAL>(x, row, tile, logn, m, lean, WAVE_PRIVATE ? buf : nullptr);
                 } else {
                     Rd2::lds_write(x, buf, (FRESH & 16) ? n2_opaque(threadIdx.x) : threadIdx.x);
                     round_sync();
@@ -616,7 +673,8 @@ __global__ __launch_bounds__(N2_THREADS, MAC ? N2_MAC_WAVES : N2_MIN_WAVES) void
             if (mm + 1 < m_end) {
                 u64 *nrow; const u64 *nin;
                 row_ptrs(mm + 1, nrow, nin);
-                Rd0::template g_read<REDUCE>(x, nin, tile, logn, m);
+                if constexpr (FINAL >= 3) Rd0::template g_read<REDUCE>(x, nin, tile, logn, m, n2_opaque(threadIdx.x)); // offsets formed here, not carried across the epilogue
+                else Rd0::template g_read<REDUCE>(x, nin, tile, logn, m);
             }
         }
     }
@@ -655,10 +713,12 @@ template <int INV, int NS> static void launch_contig(const Ntt2Args &a, unsigned
     if (final_pass) launch_one<INV, 0, NS, 0, INV ? 2 : 1, 0>(a, blocks, s);
     else launch_one<INV, 0, NS, 0, 0, 0>(a, blocks, s);
 }
-template <int INV, int NS> static void launch_strided(const Ntt2Args &a, unsigned blocks, bool final_pass, bool reduce, hipStream_t s) {
+template <int INV, int NS> static void launch_strided(const Ntt2Args &a, unsigned blocks, bool final_pass, bool reduce, hipStream_t s, int md_kind = -1) {
     constexpr int LOGC = N2_LOGT - NS;
     if (INV) { // the strided pass is the last inverse pass
-        launch_one<1, 1, NS, LOGC, 2, 0>(a, blocks, s);
+        if (md_kind == 0) launch_one<1, 1, NS, LOGC, 3, 0>(a, blocks, s);
+        else if (md_kind == 2) launch_one<1, 1, NS, LOGC, 4, 0>(a, blocks, s);
+        else launch_one<1, 1, NS, LOGC, 2, 0>(a, blocks, s);
     } else {
         (void)final_pass;
         if (reduce) launch_one<0, 1, NS, LOGC, 0, 1>(a, blocks, s);
@@ -669,7 +729,17 @@ template <int INV, int NS> static void launch_strided(const Ntt2Args &a, unsigne
 // rows are laid out r = (o * period + i) * inner + k; src (optional, forward only): item o, digit k at src + o*src_ostride + k*N
 void launch_ntt2(u64 *data, const u64 *src, u64 src_ostride, bool src_reduce, const PrimeDesc *primes, const LimbMap &map, size_t rows, int logn,
                  bool inverse, hipStream_t stream, bool src_same_layout, u64 src_bound) {
-    if (rows == 0) return;
+    launch_ntt2_slots(data, src, src_ostride, src_reduce, primes, map, rows, logn, inverse, stream, src_same_layout, src_bound, 0, map.period, nullptr);
+}
+// the general form: only the prime slots [slot_begin, slot_begin + slot_count) of the pattern; md (inverse, inner == 1): the last pass ends in
+// the key-switch mod-down instead of storing (Ntt2ModDown, kernels.h)
+void launch_ntt2_slots(u64 *data, const u64 *src, u64 src_ostride, bool src_reduce, const PrimeDesc *primes, const LimbMap &map, size_t rows, int logn,
+                       bool inverse, hipStream_t stream, bool src_same_layout, u64 src_bound, unsigned slot_begin, unsigned slot_count, const Ntt2ModDown *md) {
+    if (rows == 0 || slot_count == 0) return;
+    if (slot_begin + slot_count > map.period) throw Error(ST_INVALID_ARGUMENT, "ntt2: slot range");
+    const bool partial = slot_begin != 0 || slot_count != map.period;
+    if ((partial || md) && (!inverse || src)) throw Error(ST_LOGIC_ERROR, "ntt2: slot ranges and the mod-down epilogue belong to the in-place inverse transform");
+    if (md && map.inner != 1) throw Error(ST_LOGIC_ERROR, "ntt2: the mod-down epilogue takes one row per (item, prime)");
     if (!ntt2_supported(logn)) throw Error(ST_LOGIC_ERROR, "ntt2: unsupported size");
     const size_t per_outer = (size_t)map.period * map.inner;
     if (rows % per_outer) throw Error(ST_INVALID_ARGUMENT, "ntt2: row count must be a multiple of the limb pattern");
@@ -691,7 +761,13 @@ void launch_ntt2(u64 *data, const u64 *src, u64 src_ostride, bool src_reduce, co
     a.src_reduce = 0;
     a.src_same_layout = 0;
     a.slot_fastest = 0;
-    const unsigned blocks = (unsigned)((map.period * a.chunks) << a.tiles_per_row_log);
+    a.slot_begin = slot_begin;
+    if (md) {
+        a.md_ct = md->ct; a.md_ct_bstride = md->ct_bstride; a.md_dl = md->dl; a.md_qk = md->qk; a.md_half = md->half;
+        a.md_share = md->share;
+        if (md->kind == 2 && !md->share) throw Error(ST_LOGIC_ERROR, "ntt2: the BGV mod-down needs the special limb's shares");
+    }
+    const unsigned blocks = (unsigned)((slot_count * a.chunks) << a.tiles_per_row_log);
     auto contig = [&](auto inv_tag, bool final_pass) {
         constexpr int INV = decltype(inv_tag)::value;
         if (k2 == 9) launch_contig<INV, 9>(a, blocks, final_pass, stream);
@@ -701,11 +777,11 @@ void launch_ntt2(u64 *data, const u64 *src, u64 src_ostride, bool src_reduce, co
     auto strided = [&](auto inv_tag, const Ntt2Args &args, bool reduce) {
         constexpr int INV = decltype(inv_tag)::value;
         switch (k1) {
-        case 3: launch_strided<INV, 3>(args, blocks, false, reduce, stream); break;
-        case 4: launch_strided<INV, 4>(args, blocks, false, reduce, stream); break;
-        case 5: launch_strided<INV, 5>(args, blocks, false, reduce, stream); break;
-        case 6: launch_strided<INV, 6>(args, blocks, false, reduce, stream); break;
-        case 7: launch_strided<INV, 7>(args, blocks, false, reduce, stream); break;
+        case 3: launch_strided<INV, 3>(args, blocks, false, reduce, stream, md ? md->kind : -1); break;
+        case 4: launch_strided<INV, 4>(args, blocks, false, reduce, stream, md ? md->kind : -1); break;
+        case 5: launch_strided<INV, 5>(args, blocks, false, reduce, stream, md ? md->kind : -1); break;
+        case 6: launch_strided<INV, 6>(args, blocks, false, reduce, stream, md ? md->kind : -1); break;
+        case 7: launch_strided<INV, 7>(args, blocks, false, reduce, stream, md ? md->kind : -1); break;
         default: throw Error(ST_LOGIC_ERROR, "ntt2 plan");
         }
     };

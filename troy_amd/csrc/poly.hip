@@ -616,6 +616,25 @@ template <int KIND> __global__ __launch_bounds__(EW_THREADS) void ks_moddown_ker
     u64 *c = ct + b * ct_bstride + (k * a.dl + j) * N + n;
     *c = addmod(*c, v, m.p);
 }
+// BGV mod-down inside the inverse transform (Ntt2ModDown, ntt2.hip): what the special limb contributes to EVERY data limb, once per
+// coefficient instead of once per (limb, coefficient):  S = al + k_t qk  as a 128-bit integer, k_t = -al qk^-1 mod t; the epilogue of
+// limb j subtracts [S]_{q_j} = [al]_{q_j} + [k_t]_{q_j} qk  (mod q_j).  share[o][n] = (lo, hi).
+__global__ __launch_bounds__(EW_THREADS) void ks_bgv_share_kernel(const u64 *acc, u64 *share, KsArgs a) {
+    const u64 idx = (u64)blockIdx.x * EW_THREADS + threadIdx.x; // over batch * 2 * N
+    const u64 N = u64(1) << a.logn, rl = a.dl + 1;
+    if (idx >= a.batch * 2 * N) return;
+    const u64 n = idx & (N - 1), o = idx >> a.logn;
+    const u64 qk = a.primes[a.key_id[a.dl]].p;
+    const u64 al = acc[(o * rl + a.dl) * N + n];
+    const Mod tm{a.t_p, a.t_cr0, a.t_cr1};
+    u64 kt = negmod(barrett64(al, tm), tm.p);
+    if (a.inv_qk_mod_t != 1) kt = mulmod(kt, a.inv_qk_mod_t, tm);
+    const u64 lo = kt * qk, hi = mulhi64(kt, qk);
+    ulonglong2 v;
+    v.x = lo + al;
+    v.y = hi + (v.x < lo ? 1 : 0);
+    reinterpret_cast<ulonglong2 *>(share)[idx] = v;
+}
 // CKKS mod-down, NTT form: step F builds the correction polynomial from the coefficient-form special limb
 //   corr[b][k][j][n] = [t']_{q_j} + (q_j - [half]_{q_j}),  t' = (last + half) mod qk
 // (NTT over corr), step G: ct += (acc_j + q_j - corr_j) * qk^-1 mod q_j
@@ -659,6 +678,11 @@ void launch_ks_moddown(int kind, const u64 *acc, u64 *ct, u64 ct_bstride, const 
     if (kind == 0) TROY_LAUNCH(HIP_KERNEL_NAME(ks_moddown_kernel<0>), grid, blk, 0, s, acc, ct, ct_bstride, a);
     else TROY_LAUNCH(HIP_KERNEL_NAME(ks_moddown_kernel<2>), grid, blk, 0, s, acc, ct, ct_bstride, a);
     launch_check("ks_moddown_kernel");
+}
+void launch_ks_bgv_share(const u64 *acc, u64 *share, const KsArgs &a, hipStream_t s) {
+    const u64 total = a.batch * 2 << a.logn;
+    TROY_LAUNCH(ks_bgv_share_kernel, dim3(ceil_div(total, EW_THREADS)), dim3(EW_THREADS), 0, s, acc, share, a);
+    launch_check("ks_bgv_share_kernel");
 }
 void launch_ks_ckks_corr(const u64 *last, u64 *corr, const KsArgs &a, hipStream_t s) {
     u64 total = a.batch * 2 * a.dl << a.logn;
