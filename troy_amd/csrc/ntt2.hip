@@ -564,6 +564,8 @@ __global__ __launch_bounds__(N2_THREADS, MAC ? N2_MAC_WAVES : N2_MIN_WAVES) void
 #pragma unroll
                 for (int e = 0; e < 4; e++) macc[cpt][g][e] = Acc128{0, 0, 0, 0};
     }
+    // read once: indexing the argument block with `slot` is a memory load, and inside the row loop it sat, with its wait, in front of the key loads
+    const unsigned key_limb = MAC == 1 ? (unsigned)__builtin_amdgcn_readfirstlane((int)a.mac_key_limb[slot]) : 0;
     u64 *const wave_stage = lds[1] + 512 * (threadIdx.x >> 6);
     u64 x[8];
     {
@@ -575,25 +577,26 @@ __global__ __launch_bounds__(N2_THREADS, MAC ? N2_MAC_WAVES : N2_MIN_WAVES) void
     for (unsigned mm = m_begin; mm < m_end; mm++) {
         u64 *row; const u64 *in;
         row_ptrs(mm, row, in);
+        if constexpr (DMA) TROY_WAIT_VMEM(); // this wave's staged row has landed (and its previous stores are out)
+        ulonglong2 kv[2][MAC == 1 ? 4 : 1]; // MAC: this row's key words, requested now -- BEFORE the next row's staging loads, so that the wait for them (vmcnt counts in
+        // order) does not include the staging loads' HBM latency -- and used after the three rounds
+        if constexpr (MAC == 1) {
+            const unsigned ko = mm / inner, kk = mm - ko * inner;
+            const u64 *kp = a.mac_key + ((((u64)kk * 2) * a.mac_K + key_limb) << logn) + ((u64)tile << N2_LOGT) + 8 * threadIdx.x;
+#pragma unroll
+            for (int cpt = 0; cpt < 2; cpt++) {
+                const ulonglong2 *kq = reinterpret_cast<const ulonglong2 *>(kp + ((u64)cpt * a.mac_K << logn));
+#pragma unroll
+                for (int e = 0; e < 4; e++) kv[cpt][MAC == 1 ? e : 0] = kq[e];
+            }
+        }
         if constexpr (DMA) {
-            TROY_WAIT_VMEM();            // this wave's staged row has landed (and its previous stores are out)
             Rd0::stage_read(x, wave_stage);
             TROY_WAIT_LDS();             // ... and has been read before the next row overwrites it
             if (mm + 1 < m_end) {
                 u64 *nrow; const u64 *nin;
                 row_ptrs(mm + 1, nrow, nin);
                 Rd0::stage_issue(nin, tile, wave_stage);
-            }
-        }
-        ulonglong2 kv[2][MAC == 1 ? 4 : 1]; // MAC: this row's key words, requested now, used after the three rounds (L2 latency hidden)
-        if constexpr (MAC == 1) {
-            const unsigned ko = mm / inner, kk = mm - ko * inner;
-            const u64 *kp = a.mac_key + ((((u64)kk * 2) * a.mac_K + a.mac_key_limb[slot]) << logn) + ((u64)tile << N2_LOGT) + 8 * threadIdx.x;
-#pragma unroll
-            for (int cpt = 0; cpt < 2; cpt++) {
-                const ulonglong2 *kq = reinterpret_cast<const ulonglong2 *>(kp + ((u64)cpt * a.mac_K << logn));
-#pragma unroll
-                for (int e = 0; e < 4; e++) kv[cpt][MAC == 1 ? e : 0] = kq[e];
             }
         }
         u64 *buf = DMA ? lds[0] : lds[mm & 1];
