@@ -539,14 +539,14 @@ __global__ __launch_bounds__(N2_THREADS, MAC ? N2_MAC_WAVES : N2_MIN_WAVES) void
     const unsigned m_end = (m_begin + a.rows_per_wg < a.m_total) ? m_begin + a.rows_per_wg : a.m_total;
     const unsigned inner = a.map.inner, period = a.map.period;
     // software pipeline over the rows of this group: the loads of row mm+1 are in flight while row mm is transformed
-    auto row_ptrs = [&](unsigned mm, u64 *&row, const u64 *&in) {
+    // row mm = o * inner + k: (o, k) is carried along the row loop (one division per workgroup, not three per row)
+    auto row_ptrs = [&](unsigned mm, unsigned o, unsigned k, u64 *&row, const u64 *&in) {
         if constexpr (MAC == 2) { // virtual row mm = 4 b + vr: vr 0,1 -> a0, a1 ; 2,3 -> b0, b1
             const unsigned b = mm >> 2, vr = mm & 3;
             row = (vr < 2 ? a.data : a.tensor_b) + ((((u64)b * 2 + (vr & 1)) * period + slot) << logn);
             in = row;
             return;
         }
-        const unsigned o = mm / inner, k = mm - o * inner;
         const u64 r = ((u64)o * period + slot) * inner + k;
         row = a.data + (r << logn);
         in = (REDUCE || a.src) ? (a.src_same_layout ? a.src + (r << logn) : a.src + (u64)o * a.src_ostride + ((u64)k << logn)) : row;
@@ -568,20 +568,22 @@ __global__ __launch_bounds__(N2_THREADS, MAC ? N2_MAC_WAVES : N2_MIN_WAVES) void
     const unsigned key_limb = MAC == 1 ? (unsigned)__builtin_amdgcn_readfirstlane((int)a.mac_key_limb[slot]) : 0;
     u64 *const wave_stage = lds[1] + 512 * (threadIdx.x >> 6);
     u64 x[8];
+    unsigned ro = m_begin / inner, rk = m_begin - ro * inner; // (o, k) of the current row
     {
         u64 *row0; const u64 *in0;
-        row_ptrs(m_begin, row0, in0);
+        row_ptrs(m_begin, ro, rk, row0, in0);
         if constexpr (DMA) Rd0::stage_issue(in0, tile, wave_stage);
         else Rd0::template g_read<REDUCE>(x, in0, tile, logn, m);
     }
     for (unsigned mm = m_begin; mm < m_end; mm++) {
         u64 *row; const u64 *in;
-        row_ptrs(mm, row, in);
+        row_ptrs(mm, ro, rk, row, in);
+        const unsigned no = rk + 1 == inner ? ro + 1 : ro, nk = rk + 1 == inner ? 0 : rk + 1; // (o, k) of row mm + 1
         if constexpr (DMA) TROY_WAIT_VMEM(); // this wave's staged row has landed (and its previous stores are out)
         ulonglong2 kv[2][MAC == 1 ? 4 : 1]; // MAC: this row's key words, requested now -- BEFORE the next row's staging loads, so that the wait for them (vmcnt counts in
         // order) does not include the staging loads' HBM latency -- and used after the three rounds
         if constexpr (MAC == 1) {
-            const unsigned ko = mm / inner, kk = mm - ko * inner;
+            const unsigned kk = rk;
             const u64 *kp = a.mac_key + ((((u64)kk * 2) * a.mac_K + key_limb) << logn) + ((u64)tile << N2_LOGT) + 8 * threadIdx.x;
 #pragma unroll
             for (int cpt = 0; cpt < 2; cpt++) {
@@ -595,7 +597,7 @@ __global__ __launch_bounds__(N2_THREADS, MAC ? N2_MAC_WAVES : N2_MIN_WAVES) void
             TROY_WAIT_LDS();             // ... and has been read before the next row overwrites it
             if (mm + 1 < m_end) {
                 u64 *nrow; const u64 *nin;
-                row_ptrs(mm + 1, nrow, nin);
+                row_ptrs(mm + 1, no, nk, nrow, nin);
                 Rd0::stage_issue(nin, tile, wave_stage);
             }
         }
@@ -642,7 +644,7 @@ __global__ __launch_bounds__(N2_THREADS, MAC ? N2_MAC_WAVES : N2_MIN_WAVES) void
                             for (int i = 0; i < 4; i++) x[4 * h + i] = v[i];
                         }
                     }
-                    const unsigned o = mm / inner, k = mm - o * inner;
+                    const unsigned o = ro, k = rk;
                     const u64 pos = ((u64)tile << N2_LOGT) + 8 * threadIdx.x;
                     if (a.mac_target && k == slot) {
                         const ulonglong2 *tp = reinterpret_cast<const ulonglong2 *>(a.mac_target + (u64)o * a.mac_tstride + ((u64)k << logn) + pos);
@@ -675,11 +677,13 @@ __global__ __launch_bounds__(N2_THREADS, MAC ? N2_MAC_WAVES : N2_MIN_WAVES) void
         if constexpr (!DMA) {
             if (mm + 1 < m_end) {
                 u64 *nrow; const u64 *nin;
-                row_ptrs(mm + 1, nrow, nin);
+                row_ptrs(mm + 1, no, nk, nrow, nin);
                 if constexpr (FINAL >= 3) Rd0::template g_read<REDUCE>(x, nin, tile, logn, m, n2_opaque(threadIdx.x)); // offsets formed here, not carried across the epilogue
                 else Rd0::template g_read<REDUCE>(x, nin, tile, logn, m);
             }
         }
+        ro = no;
+        rk = nk;
     }
     if constexpr (MAC == 1) { // one reduction per output coefficient; acc[o][c][slot][N]
         const unsigned o = m_begin / inner;
