@@ -50,6 +50,12 @@ namespace troyhip {
 #ifndef N2_COALESCED_STORE
 #define N2_COALESCED_STORE 1 // forward contiguous pass: transpose the last round through LDS, store 1 KiB per instruction
 #endif
+#ifndef N2_TENSOR_WAVES
+#define N2_TENSOR_WAVES 3 // waves per SIMD of the tensor fused kernel: with the LDS addresses formed per row (N2_FRESH_TENSOR) it fits 168 VGPRs
+#endif                    // (196 with hoisted addresses = 2 waves): 1183 -> 1044 us per step, headline +3 %
+#ifndef N2_FRESH_TENSOR
+#define N2_FRESH_TENSOR 15
+#endif
 #ifndef N2_FRESH_MD
 #define N2_FRESH_MD 15
 #endif
@@ -485,7 +491,7 @@ template <> struct Plan<10> { static constexpr int r[4] = {3, 3, 3, 1}; };
 template <> struct Plan<11> { static constexpr int r[4] = {3, 3, 3, 2}; };
 
 template <int INV, int STRIDED, int NS, int LOGC, int FINAL, int REDUCE, int MAC = 0>
-__global__ __launch_bounds__(N2_THREADS, MAC ? N2_MAC_WAVES : N2_MIN_WAVES) void ntt2_kernel(Ntt2Args a) {
+__global__ __launch_bounds__(N2_THREADS, MAC == 2 ? N2_TENSOR_WAVES : MAC ? N2_MAC_WAVES : N2_MIN_WAVES) void ntt2_kernel(Ntt2Args a) {
     __shared__ u64 lds[2][N2_T];
     using P = Plan<NS>;
     // NS == 9, contiguous: every 512-point sub-transform is owned by ONE wave in every round (thread t's points never
@@ -497,7 +503,7 @@ __global__ __launch_bounds__(N2_THREADS, MAC ? N2_MAC_WAVES : N2_MIN_WAVES) void
     // whole row loop; in the instances at the 128-register limit the compiler spilled them, and a spill reload waits with vmcnt(0) --
     // i.e. for the NEXT row's loads, which were issued before it: the HBM latency landed in the middle of every row (forward
     // contiguous pass 2038 -> 1525 us per 6720 rows of N = 2^16; three XORs per address are nothing next to that).
-    constexpr int FRESH = (!STRIDED && !INV && NS == 9 && MAC == 0) ? (FINAL ? 15 : 1) : (STRIDED && !INV && NS == 7) ? 1 : (!STRIDED && NS == 10) ? 63 : (FINAL >= 3 && NS >= 6) ? N2_FRESH_MD : 0;
+    constexpr int FRESH = (!STRIDED && !INV && NS == 9 && MAC == 0) ? (FINAL ? 15 : 1) : (STRIDED && !INV && NS == 7) ? 1 : (!STRIDED && NS == 10) ? 63 : (FINAL >= 3 && NS >= 6) ? N2_FRESH_MD : MAC == 2 ? N2_FRESH_TENSOR : 0;
     auto round_sync = [&]() {
         if (N2_EXP & 2) return;
         if (WAVE_PRIVATE) TROY_WAVE_SYNC(); else __syncthreads();
@@ -582,7 +588,7 @@ __global__ __launch_bounds__(N2_THREADS, MAC ? N2_MAC_WAVES : N2_MIN_WAVES) void
         if constexpr (DMA) TROY_WAIT_VMEM(); // this wave's staged row has landed (and its previous stores are out)
         ulonglong2 kv[2][MAC == 1 ? 4 : 1]; // MAC: this row's key words, requested now -- BEFORE the next row's staging loads, so that the wait for them (vmcnt counts in
         // order) does not include the staging loads' HBM latency -- and used after the three rounds
-        if constexpr (MAC == 1) {
+        auto load_keys = [&]() {
             const unsigned kk = rk;
             const u64 *kp = a.mac_key + ((((u64)kk * 2) * a.mac_K + key_limb) << logn) + ((u64)tile << N2_LOGT) + 8 * threadIdx.x;
 #pragma unroll
@@ -591,7 +597,8 @@ __global__ __launch_bounds__(N2_THREADS, MAC ? N2_MAC_WAVES : N2_MIN_WAVES) void
 #pragma unroll
                 for (int e = 0; e < 4; e++) kv[cpt][MAC == 1 ? e : 0] = kq[e];
             }
-        }
+        };
+        if constexpr (MAC == 1) load_keys();
         if constexpr (DMA) {
             Rd0::stage_read(x, wave_stage);
             TROY_WAIT_LDS();             // ... and has been read before the next row overwrites it
