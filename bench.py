@@ -35,7 +35,7 @@ BFV, CKKS, BGV = 1, 2, 3
 
 WORKLOADS = {
     # name: scheme, N, prime bit sizes, plain-modulus bits, kind, default batch per GPU, default streams
-    "bfv_n32768_l14": dict(scheme=BFV, N=32768, bits=[60] + [58] * 13 + [60], tbits=20, kind="mul_relin", batch=128, streams=2,
+    "bfv_n32768_l14": dict(scheme=BFV, N=32768, bits=[60] + [58] * 13 + [60], tbits=20, kind="mul_relin", batch=256, streams=2,
                            metric="ct x ct multiply+relinearize ops/sec, BFV N=2^15 L=14; achieved HBM GB/s vs peak"),
     "bfv_n8192_l4": dict(scheme=BFV, N=8192, bits=[40, 36, 36, 36, 40], tbits=20, kind="mul_relin", batch=1024, streams=2,
                          metric="ct x ct multiply+relinearize ops/sec, BFV N=8192 L=4 (BASELINE configs[1]); achieved HBM GB/s vs peak"),

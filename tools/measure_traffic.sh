@@ -34,7 +34,7 @@ for name, v in op.items():
     w = sum(x[1] for x in v["WRITE_SIZE"]) * 1024
     res["per_kernel"][name] = {"calls": len(v["FETCH_SIZE"]), "fetch_bytes_corrected": f, "write_bytes": w, "hbm_bytes": f + w}
 # the roofline launches: rows = B * (L+1) * L per transform; ntt1 = 1 launch (lean + guarded forward kernels together) per transform
-rows = B * (L + 1) * L
+rows = min(B, 128) * (L + 1) * L  # bench.py:ntt_roofline caps the launch at the rows of 128 ciphertexts
 def per_row(d, names, launches_each):
     tot = 0.0
     for n in names:
@@ -48,8 +48,8 @@ def per_row(d, names, launches_each):
 sp = load("r02sp")
 n1 = per_row(sp, ["ntt1_inv_kernel<true, false>", "ntt1_inv_kernel<false, false>"], 3)
 n1f = None
-if "ntt1_fwd_kernel<true>" in sp and "ntt1_fwd_kernel<false>" in sp:
-    n1f = per_row(sp, ["ntt1_fwd_kernel<true>", "ntt1_fwd_kernel<false>"], 3)
+if "ntt1_fwd_kernel<true, false>" in sp and "ntt1_fwd_kernel<false, false>" in sp:
+    n1f = per_row(sp, ["ntt1_fwd_kernel<true, false>", "ntt1_fwd_kernel<false, false>"], 3)
 if n1 and n1f:
     res["hbm_bytes_per_limb_transform"]["ntt1"] = (n1 + n1f) / 2
     res["hbm_bytes_per_limb_transform"]["ntt1_forward"] = n1f

@@ -74,7 +74,9 @@ def load(path=None):
     global _lib
     if _lib is not None and path is None:
         return _lib
-    p = path or LIB_PATH
+    # TROYHIP_LIB: development switch for same-box A/B runs of two builds of the library (tools/ntt_probe.sh variants); it must still be
+    # a gfx950 build of this library -- the check below applies to it as to the in-tree file
+    p = path or os.environ.get("TROYHIP_LIB") or LIB_PATH
     if not os.path.exists(p):
         raise ImportError(
             f"{p} is missing: the HIP extension has not been built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
