@@ -503,7 +503,7 @@ __global__ __launch_bounds__(N2_THREADS, MAC == 2 ? N2_TENSOR_WAVES : MAC ? N2_M
     // whole row loop; in the instances at the 128-register limit the compiler spilled them, and a spill reload waits with vmcnt(0) --
     // i.e. for the NEXT row's loads, which were issued before it: the HBM latency landed in the middle of every row (forward
     // contiguous pass 2038 -> 1525 us per 6720 rows of N = 2^16; three XORs per address are nothing next to that).
-    constexpr int FRESH = (!STRIDED && !INV && NS == 9 && MAC == 0) ? (FINAL ? 15 : 1) : (STRIDED && !INV && NS == 7) ? 1 : (!STRIDED && NS == 10) ? 63 : (FINAL >= 3 && NS >= 6) ? N2_FRESH_MD : MAC == 2 ? N2_FRESH_TENSOR : 0;
+    constexpr int FRESH = (!STRIDED && !INV && NS == 9 && MAC == 0) ? (FINAL ? 15 : 1) : (STRIDED && !INV && NS == 7) ? 1 : (!STRIDED && NS == 10) ? 63 : (FINAL >= 3 && NS >= 6) ? N2_FRESH_MD : MAC == 2 ? N2_FRESH_TENSOR : (STRIDED && !INV && !REDUCE && NS >= 4 && NS <= 6) ? 15 : 0;
     auto round_sync = [&]() {
         if (N2_EXP & 2) return;
         if (WAVE_PRIVATE) TROY_WAVE_SYNC(); else __syncthreads();
@@ -559,6 +559,11 @@ __global__ __launch_bounds__(N2_THREADS, MAC == 2 ? N2_TENSOR_WAVES : MAC ? N2_M
         if ((N2_EXP & 8) && !STRIDED) in = a.data + ((r & 63) << logn); // probe: the contiguous pass reads a 16 MB window (L2-resident input)
     };
     constexpr bool DMA = N2_DMA && WAVE_PRIVATE && !(N2_EXP & 1);
+    // plain strided forward passes of two rounds: the next row is requested into a second register set before the last round's butterflies
+    // (the registers come from forming the LDS addresses per row, FRESH, so the kernel stays at four waves per SIMD): -2 % on that pass.
+    // Not the digit-reducing first pass of key switching, whose L2-resident sources arrive fast enough anyway: +6 % there.
+    constexpr bool PF = STRIDED && !INV && NR == 2 && !REDUCE && !(N2_EXP & 1);
+    u64 xn[PF ? 8 : 1];
     static_assert(!MAC || (!INV && !STRIDED && NS == 9), "the inner product is fused into the forward contiguous pass");
     u64 tx[MAC == 2 ? 3 : 1][8]; // MAC = 2: the transforms of a0, a1, b0 while b1 is being computed
     Acc128 macc[2][2][4]; // [key component][group of four coefficients][coefficient]
@@ -623,6 +628,13 @@ __global__ __launch_bounds__(N2_THREADS, MAC == 2 ? N2_TENSOR_WAVES : MAC ? N2_M
             round_sync();
             if constexpr (!Rd1::HOIST) Rd1::load_tw(tw1, pd, tile, logn, s_first);
             Rd1::lds_read(x, buf, (FRESH & 2) ? n2_opaque(threadIdx.x) : threadIdx.x);
+            if constexpr (PF) {
+                if (mm + 1 < m_end) {
+                    u64 *nrow; const u64 *nin;
+                    row_ptrs(mm + 1, no, nk, nrow, nin);
+                    Rd0::template g_read<REDUCE>(xn, nin, tile, logn, m, n2_opaque(threadIdx.x));
+                }
+            }
             Rd1::compute(x, tw1, pd, lean);
             if constexpr (NR == 2) {
                 if constexpr (FINAL >= 3) Rd1::template md_write<FINAL>(x, a, mm, slot, tile, logn, m, pd);
@@ -681,7 +693,10 @@ __global__ __launch_bounds__(N2_THREADS, MAC == 2 ? N2_TENSOR_WAVES : MAC ? N2_M
                 }
             }
         }
-        if constexpr (!DMA) {
+        if constexpr (PF) {
+#pragma unroll
+            for (int e = 0; e < 8; e++) x[e] = xn[PF ? e : 0];
+        } else if constexpr (!DMA) {
             if (mm + 1 < m_end) {
                 u64 *nrow; const u64 *nin;
                 row_ptrs(mm + 1, no, nk, nrow, nin);
