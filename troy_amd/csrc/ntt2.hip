@@ -183,6 +183,23 @@ template <int INV, int STRIDED, int NS, int LOGC, int LS, int R, bool HOISTP = t
             }
         }
     }
+    // Twiddles that were loaded once per workgroup are CONSUMED here, ahead of the row loop: otherwise the compiler places the wait for them at
+    // their first use inside the loop body -- an s_waitcnt vmcnt(0) that every iteration executes, and that then also waits for whatever the
+    // iteration has in flight at that point (the next row's staging loads, the key words).  Measured neutral on the headline (8992 / 8965
+    // vs 8982 / 8979 ops/s on one box: the staged row has usually landed by then); kept so that the loop body waits where the source says.
+    // Hand-written vmcnt(4) for the key words (asm loads) and asm staging loads were tried on top: neutral to -0.4 %, not kept.
+    __device__ static __forceinline__ void settle_tw(const Shoup (&tw)[G][NTW]) {
+#ifndef TROYHIP_CPU_EMUL
+        if (!UNIFORM) {
+#pragma unroll
+            for (int u = 0; u < G; u++)
+#pragma unroll
+                for (int i = 0; i < NTW; i++) asm volatile("" ::"v"(tw[u][i].op), "v"(tw[u][i].quo));
+        }
+#else
+        (void)tw;
+#endif
+    }
     // every stage = exactly four independent butterflies per thread -> one ct_bfly4 / gs_bfly4 call
     // lean (forward only, wave-uniform): the prime is below 2^58 -- guard-free butterflies, every stage adds at most 3p to the
     // value bound (8p at the input of the first pass + 3p * 17 stages at most = 59p < 2^64); the caller reduces with barrett64
@@ -540,6 +557,10 @@ __global__ __launch_bounds__(N2_THREADS, MAC == 2 ? N2_TENSOR_WAVES : MAC ? N2_M
     if constexpr (NR > 1 && Rd1::HOIST) Rd1::load_tw(tw1, pd, tile, logn, s_first);
     if constexpr (NR > 2 && Rd2::HOIST) Rd2::load_tw(tw2, pd, tile, logn, s_first);
     if constexpr (NR > 3 && Rd3::HOIST) Rd3::load_tw(tw3, pd, tile, logn, s_first);
+    if constexpr (Rd0::HOIST) Rd0::settle_tw(tw0);
+    if constexpr (NR > 1 && Rd1::HOIST) Rd1::settle_tw(tw1);
+    if constexpr (NR > 2 && Rd2::HOIST) Rd2::settle_tw(tw2);
+    if constexpr (NR > 3 && Rd3::HOIST) Rd3::settle_tw(tw3);
 
     const unsigned m_begin = chunk * a.rows_per_wg;
     const unsigned m_end = (m_begin + a.rows_per_wg < a.m_total) ? m_begin + a.rows_per_wg : a.m_total;
