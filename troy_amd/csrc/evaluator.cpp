@@ -442,7 +442,10 @@ void Evaluator::mod_switch_scale(const CtBatch &in, CtBatch &out, u64 batch, hip
         c.arena.reserve(need);
     }
     const u64 *src = in.data;
-    if (!dense_in) {
+    // CKKS through the fused correction transform reads a strided batch (a relinearized ciphertext keeps its three-polynomial stride) as it lies
+    const bool ckks_fused = c.scheme == SCHEME_CKKS && c.level(L).d_inv_qlast && corr_fused() && primes_at_least_33_bits(c, nl) &&
+                            ntt1_supported(c.logn, c.ct_map(nl), batch * in.size * nl);
+    if (!dense_in && !ckks_fused) {
         u64 *tmp = c.arena.take(batch * in.size * pw);
         launch_copy_strided(in.data, in.bstride, tmp, in.size * pw, in.size * pw, batch, s);
         src = tmp;
@@ -451,12 +454,14 @@ void Evaluator::mod_switch_scale(const CtBatch &in, CtBatch &out, u64 batch, hip
     if (dst == src) throw Error(ST_INVALID_ARGUMENT, "mod switch cannot run in place");
     if (c.scheme == SCHEME_CKKS) {
         u64 *last = c.arena.take(batch * in.size * N), *corr = c.arena.take(batch * in.size * npw);
-        launch_gather_limb(src, last, c.logn, pw, (u64)nl, batch * in.size, s);
+        if (ckks_fused && !dense_in) launch_gather_limb(src, last, c.logn, pw, (u64)nl, batch * in.size, s, (u64)in.size, in.bstride);
+        else launch_gather_limb(src, last, c.logn, pw, (u64)nl, batch * in.size, s);
         launch_ntt(last, c.d_desc, c.single_map(L - 1), batch * in.size, c.logn, true, s);
         const LimbMap cmap = c.ct_map(nl);
         const Level &lvl = c.level(L);
-        if (lvl.d_inv_qlast && corr_fused() && primes_at_least_33_bits(c, nl) && ntt1_supported(c.logn, cmap, batch * in.size * nl)) {
-            const Ntt1Corr cr{last, src, (u64)pw, dst, 0, (u64)npw, 0x7FFFFFFFu, lvl.d_inv_qlast, c.primes[L - 1], a.half, false};
+        if (ckks_fused) {
+            Ntt1Corr cr{last, src, (u64)pw, dst, (u64)in.size * npw, (u64)npw, (unsigned)in.size, lvl.d_inv_qlast, c.primes[L - 1], a.half, false};
+            if (!dense_in) cr.in_gstride = in.bstride;
             launch_ntt1(nullptr, nullptr, c.d_desc, cmap, batch * in.size * nl, false, s, ~0ull, nullptr, &cr);
         } else {
             launch_rescale_stepA(last, N, corr, a, s);

@@ -42,7 +42,8 @@ struct Ntt1ModDown { u64 *ct; u64 ct_bstride; u64 dl, qk, half; };
 // coefficient-form residues `last` of qx (one row per outer index), transformed, and COMBINED on store:
 //   out = (in + p - NTT(corr)) * qx^-1 mod p,   stored, or added to what out holds (accumulate)
 // so the correction never exists in memory and the two element-wise kernels around the transform disappear.  Row (o, slot):
-// in[o * in_ostride + slot * N ..], out[(o / group) * out_gstride + (o % group) * out_ostride + slot * N ..], inv[slot] = qx^-1 mod p_slot.
+// in[(o / group) * in_gstride + (o % group) * in_ostride + slot * N ..] (in_gstride == 0: o * in_ostride),
+// out[(o / group) * out_gstride + (o % group) * out_ostride + slot * N ..], inv[slot] = qx^-1 mod p_slot.
 struct Ntt1Corr {
     const u64 *last, *in;
     u64 in_ostride;
@@ -52,6 +53,7 @@ struct Ntt1Corr {
     const Shoup *inv;
     u64 qx, half;
     bool accumulate;
+    u64 in_gstride = 0;
 };
 // slot_mask: only these prime slots of the row pattern are transformed
 void launch_ntt1(u64 *data, const u64 *src, const PrimeDesc *primes, const LimbMap &map, size_t rows, bool inverse, hipStream_t stream, u64 slot_mask = ~0ull,
@@ -98,7 +100,8 @@ void launch_modswitch(int kind, const u64 *in, u64 *out, const ModSwitchArgs &a,
 void launch_rescale_stepA(const u64 *last, u64 last_pstride, u64 *corr, const ModSwitchArgs &a, hipStream_t s);
 void launch_rescale_stepB(const u64 *in, const u64 *corr, u64 *out, const ModSwitchArgs &a, hipStream_t s);
 void launch_drop_last(const u64 *in, u64 *out, int logn, u64 limbs, u64 polys, hipStream_t s);
-void launch_gather_limb(const u64 *in, u64 *out, int logn, u64 pstride, u64 limb, u64 polys, hipStream_t s);
+// group != 0: poly i sits at (i / group) * gstride + (i % group) * pstride (a strided batch of ciphertexts)
+void launch_gather_limb(const u64 *in, u64 *out, int logn, u64 pstride, u64 limb, u64 polys, hipStream_t s, u64 group = 0, u64 gstride = 0);
 
 struct KsArgs {
     const PrimeDesc *primes;

@@ -49,7 +49,7 @@ struct Ntt1Args {
     const u64 *cr_last, *cr_in;
     u64 *cr_out;
     const Shoup *cr_inv;
-    u64 cr_in_ostride, cr_out_gstride, cr_out_ostride, cr_qx, cr_half;
+    u64 cr_in_ostride, cr_in_gstride, cr_out_gstride, cr_out_ostride, cr_qx, cr_half;
     unsigned cr_group, cr_accumulate;
     // inverse only: mod-down epilogue (Ntt1ModDown); md_ct == nullptr: plain stores
     u64 *md_ct;
@@ -361,7 +361,7 @@ template <bool LEAN, bool CR> __global__ __launch_bounds__(N1_THREADS) void ntt1
     u64 *const park = lds + 16 * 1024 + tid;
     for (unsigned mm = m_begin; mm < m_end; mm++) {
         u64 *const out = CR ? a.cr_out + (u64)(mm / a.cr_group) * a.cr_out_gstride + (u64)(mm % a.cr_group) * a.cr_out_ostride + ((u64)slot << N1_LOGN) : a.data + row_of(mm);
-        const u64 *const cin = CR ? a.cr_in + (u64)mm * a.cr_in_ostride + ((u64)slot << N1_LOGN) : nullptr;
+        const u64 *const cin = CR ? a.cr_in + (a.cr_in_gstride ? (u64)(mm / a.cr_group) * a.cr_in_gstride + (u64)(mm % a.cr_group) * a.cr_in_ostride : (u64)mm * a.cr_in_ostride) + ((u64)slot << N1_LOGN) : nullptr;
         if (CR) { // corr = [(last + half) mod qx]_p + (p - [half]_p), the residue lazily below 4p: below 5p, inside what the butterflies take
 #pragma unroll
             for (int g = 0; g < 8; g++) {
@@ -661,7 +661,7 @@ void launch_ntt1(u64 *data, const u64 *src, const PrimeDesc *primes, const LimbM
     if (cr) {
         if (inverse || map.inner != 1 || src) throw Error(ST_LOGIC_ERROR, "ntt1: the correction form belongs to the forward transform of [outer][slot][N] rows");
         a.cr_last = cr->last; a.cr_in = cr->in; a.cr_out = cr->out; a.cr_inv = cr->inv;
-        a.cr_in_ostride = cr->in_ostride; a.cr_out_gstride = cr->out_gstride; a.cr_out_ostride = cr->out_ostride;
+        a.cr_in_ostride = cr->in_ostride; a.cr_in_gstride = cr->in_gstride; a.cr_out_gstride = cr->out_gstride; a.cr_out_ostride = cr->out_ostride;
         a.cr_qx = cr->qx; a.cr_half = cr->half; a.cr_group = cr->group ? cr->group : 1; a.cr_accumulate = cr->accumulate ? 1 : 0;
     }
     if (md) { a.md_ct = md->ct; a.md_ct_bstride = md->ct_bstride; a.md_qk = md->qk; a.md_half = md->half; a.md_dl = (unsigned)md->dl; }

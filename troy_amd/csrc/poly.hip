@@ -425,16 +425,17 @@ void launch_drop_last(const u64 *in, u64 *out, int logn, u64 limbs, u64 polys, h
     launch_check("drop_last_kernel");
 }
 // gather one limb out of every poly: out[poly][n] = in[poly*pstride + limb*N + n]
-__global__ __launch_bounds__(EW_THREADS) void gather_limb_kernel(const u64 *in, u64 *out, int logn, u64 pstride, u64 limb, u64 total) {
+__global__ __launch_bounds__(EW_THREADS) void gather_limb_kernel(const u64 *in, u64 *out, int logn, u64 pstride, u64 limb, u64 total, u64 group, u64 gstride) {
     u64 i = (u64)blockIdx.x * EW_THREADS + threadIdx.x;
     if (i >= total) return;
     u64 n = i & ((u64(1) << logn) - 1), poly = i >> logn;
-    out[i] = in[poly * pstride + (limb << logn) + n];
+    const u64 base = group ? (poly / group) * gstride + (poly % group) * pstride : poly * pstride;
+    out[i] = in[base + (limb << logn) + n];
 }
-void launch_gather_limb(const u64 *in, u64 *out, int logn, u64 pstride, u64 limb, u64 polys, hipStream_t s) {
+void launch_gather_limb(const u64 *in, u64 *out, int logn, u64 pstride, u64 limb, u64 polys, hipStream_t s, u64 group, u64 gstride) {
     u64 total = polys << logn;
     if (!total) return;
-    TROY_LAUNCH(gather_limb_kernel, dim3(ceil_div(total, EW_THREADS)), dim3(EW_THREADS), 0, s, in, out, logn, pstride, limb, total);
+    TROY_LAUNCH(gather_limb_kernel, dim3(ceil_div(total, EW_THREADS)), dim3(EW_THREADS), 0, s, in, out, logn, pstride, limb, total, group, gstride);
     launch_check("gather_limb_kernel");
 }
 
