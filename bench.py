@@ -360,7 +360,12 @@ def per_kernel(ta, capi, lib, w):
 
 def algorithmic_bytes(w, B):
     """compulsory HBM bytes per kernel NAME over one step of B units (each stage reads its inputs and writes its outputs once;
-    the key is read once per launch).  Only the BFV multiply+relinearize path is tabulated: SURVEY.md 8d's 545 MB per op at cfgNS."""
+    the key is read once per launch): the BFV multiply+relinearize path (SURVEY.md 8d's 545 MB per op at cfgNS) here, configs[2] and configs[3] in
+    the two functions below."""
+    if w.wl["kind"] == "relin_rot":
+        return algorithmic_bytes_relin_rot(w, w.B)
+    if w.wl["kind"] == "ckks_chain":
+        return algorithmic_bytes_ckks_chain(w, w.B)
     if w.wl["kind"] != "mul_relin":
         return {}
     N, L = w.N, w.L
@@ -412,6 +417,83 @@ def algorithmic_bytes(w, B):
     add("ntt2_kernel<0, 0, 9, 0, 1, 0, 1>", B * (L + 1) * L * P + 2 * (L + 1) * L * P + 2 * B * (L + 1) * P)
     if md_split or (not two_pass and not all(int(p) >= 1 << 33 for p in w.ctx.coeff_modulus[:L])):
         add("ks_moddown_kernel<0>", B * (2 * (L + 1) + 4 * L) * P)
+    return t
+
+
+def _ks_two_pass(add, B, L, P, logn, kind):
+    """one key switch of B targets with L limbs through the two-pass kernels (BFV kind 3 / BGV kind 4 mod-down epilogue)"""
+    k1 = logn - 9 if logn - 9 <= 7 else 7
+    logc = 11 - k1
+    add(f"ntt2_kernel<0, 1, {k1}, {logc}, 0, 1, 0>", B * L * P + B * (L + 1) * L * P)                          # digits read once, (L+1) L expanded limbs written
+    add("ntt2_kernel<0, 0, 9, 0, 1, 0, 1>", B * (L + 1) * L * P + 2 * (L + 1) * L * P + 2 * B * (L + 1) * P)   # + the key once, 2 (L+1) accumulator limbs written
+    add("ntt2_kernel<1, 0, 9, 0, 0, 0, 0>", 2 * B * (L + 1) * 2 * P)                                            # first inverse pass of every accumulator limb
+    add(f"ntt2_kernel<1, 1, {k1}, {logc}, 2, 0, 0>", 2 * B * 2 * P)                                             # the special limb's last pass
+    if kind == 4:
+        add("ks_bgv_share_kernel", 2 * B * 3 * P)                                                               # special limb read, 128-bit shares written
+    add(f"ntt2_kernel<1, 1, {k1}, {logc}, {kind}, 0, 0>", 2 * B * L * 3 * P + 2 * B * (2 if kind == 4 else 1) * P)  # acc + ct read, ct written, shares / special limb once
+
+
+def algorithmic_bytes_relin_rot(w, B):
+    """configs[3] (BGV, two-pass sizes): relinearize of a size-3 batch + rotateRows = two key switches, two Galois permutations"""
+    if os.environ.get("TROYHIP_MODDOWN", "")[:1] == "s" or os.environ.get("TROYHIP_KS", "")[:1] == "s":
+        return {}
+    N, L, P = w.N, w.L, 8.0 * w.N
+    t = {}
+
+    def add(name, b):
+        t[name] = t.get(name, 0) + b
+
+    for _ in range(2):
+        _ks_two_pass(add, B, L, P, N.bit_length() - 1, 4)
+    add("galois_coeff_kernel", 2 * B * L * 2 * P)
+    add("copy_strided_kernel", B * L * 2 * P)
+    add("zero_strided_kernel", B * L * P)
+    return t
+
+
+def algorithmic_bytes_ckks_chain(w, B):
+    """configs[2] at N = 2^15 (single-pass transforms, fused correction): per level l = L .. L - depth + 1 a tensor, a key switch at l, the rescale
+    to l - 1, two Galois permutations and a key switch at l - 1"""
+    if w.N != 32768 or os.environ.get("TROYHIP_NTT") or os.environ.get("TROYHIP_CORR") or os.environ.get("TROYHIP_KS"):
+        return {}
+    P = 8.0 * w.N
+    qs = [int(p) for p in w.ctx.coeff_modulus]
+    lean = [(1 << 33) <= p < (1 << 58) for p in qs]
+    t = {}
+
+    def add(name, b):
+        t[name] = t.get(name, 0) + b
+
+    def by_class(kernel, tail, slots, per_slot):  # rows of the prime slots split into the guard-free and the guarded launch
+        nl = sum(1 for i in slots if lean[i])
+        if nl:
+            add(f"{kernel}<true, {tail}>", nl * per_slot)
+        if len(slots) - nl:
+            add(f"{kernel}<false, {tail}>", (len(slots) - nl) * per_slot)
+
+    def ks(l):
+        by_class("ntt1_inv_kernel", "false", range(l), B * 2 * P)                                   # the target to coefficient form, out of place
+        add("ntt2_kernel<0, 1, 6, 5, 0, 1, 0>", B * l * P + B * (l + 1) * l * P)
+        add("ntt2_kernel<0, 0, 9, 0, 1, 0, 1>", B * (l + 1) * l * P + 2 * (l + 1) * l * P + B * l * P + 2 * B * (l + 1) * P)  # + the NTT-form target (k == slot)
+        add("gather_limb_kernel", 2 * B * 2 * P)
+        add("ntt2_kernel<1, 0, 9, 0, 0, 0, 0>", 2 * B * 2 * P)                                       # the special limb of the accumulators (2 B rows: two-pass)
+        add("ntt2_kernel<1, 1, 6, 5, 2, 0, 0>", 2 * B * 2 * P)
+        by_class("ntt1_fwd_kernel", "true", range(l), 2 * B * 3 * P)                                # per row: accumulator + ciphertext read, ciphertext written
+        add("ntt1_fwd_kernel<true, true>", 2 * B * P)                                                # the coefficient-form special limb, once per item
+
+    for d in range(w.wl["depth"]):
+        l = w.L - d
+        add("tensor_kernel<2, 2>", B * l * 7 * P)
+        ks(l)
+        add("gather_limb_kernel", 2 * B * 2 * P)                                                     # rescale: dropped limb out, inverse, correction transform
+        add("ntt2_kernel<1, 0, 9, 0, 0, 0, 0>", 2 * B * 2 * P)
+        add("ntt2_kernel<1, 1, 6, 5, 2, 0, 0>", 2 * B * 2 * P)
+        by_class("ntt1_fwd_kernel", "true", range(l - 1), 2 * B * 2 * P)
+        add("ntt1_fwd_kernel<true, true>", 2 * B * P)
+        add("galois_ntt_kernel", 2 * B * (l - 1) * 2 * P)
+        add("copy_strided_kernel", B * (l - 1) * 2 * P)
+        add("zero_strided_kernel", B * (l - 1) * P)
+        ks(l - 1)
     return t
 
 
