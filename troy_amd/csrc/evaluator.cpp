@@ -270,7 +270,7 @@ size_t Evaluator::scratch_switch_key(int limbs, u64 batch) const {
 }
 
 // switchKeyInplace (evaluator_cuda.cu:1163-1362; CPU src/evaluator.cpp:2310-2653)
-void Evaluator::switch_key(CtBatch &ct, const u64 *target, u64 t_bstride, const KsKey &key, u64 batch, hipStream_t s) {
+void Evaluator::switch_key(CtBatch &ct, const u64 *target, u64 t_bstride, const KsKey &key, u64 batch, hipStream_t s, const u64 *base, u64 base_bstride) {
     check_ct(ct);
     if (!target) throw Error(ST_INVALID_ARGUMENT, "target_iter");
     if (c.K < 2) throw Error(ST_LOGIC_ERROR, "keyswitching is not supported by the context");
@@ -347,6 +347,16 @@ void Evaluator::switch_key(CtBatch &ct, const u64 *target, u64 t_bstride, const 
         launch_ks_mac(D, key.data, mac_target, t_bstride, acc, a, s);
     }
 
+    const LimbMap amap_md = c.ids_map(out_ids);
+    bool md_primes33 = true; // the single-pass epilogue's lazy reduction (lite_reduce4) wants primes of at least 33 bits
+    for (u64 j = 0; j < dl; j++) md_primes33 = md_primes33 && c.primes[j] >= (u64(1) << 33);
+    const bool md_single = c.scheme == SCHEME_BFV && c.d_desc_md && md_primes33 && ntt1_supported(c.logn, amap_md, batch * 2 * rl) && ks_moddown_fused();
+    const bool md_two_pass = c.scheme != SCHEME_CKKS && !md_single && c.d_desc_md && ntt2_supported(c.logn) && ks_moddown_fused();
+    if (base && !md_two_pass) { // only the two-pass epilogue takes (base, 0) directly: every other form accumulates onto what ct holds
+        launch_copy_strided(base, base_bstride, ct.data, ct.bstride, dl * N, batch, s);
+        launch_zero_strided(ct.data + dl * N, ct.bstride, dl * N, batch, s);
+        base = nullptr;
+    }
     if (c.scheme == SCHEME_CKKS) {
         // special-prime limb -> coefficient form, correction polynomial -> NTT form, combine
         u64 *last = c.arena.take(batch * 2 * N), *corr = c.arena.take(batch * 2 * dl * N);
@@ -363,16 +373,14 @@ void Evaluator::switch_key(CtBatch &ct, const u64 *target, u64 t_bstride, const 
             launch_ks_ckks_combine(acc, corr, ct.data, ct.bstride, a, s);
         }
     } else {
-        const LimbMap amap = c.ids_map(out_ids);
-        bool md_primes = true; // the epilogue's lazy reduction (lite_reduce4) wants primes of at least 33 bits
-        for (u64 j = 0; j < dl; j++) md_primes = md_primes && c.primes[j] >= (u64(1) << 33);
-        if (c.scheme == SCHEME_BFV && c.d_desc_md && md_primes && ntt1_supported(c.logn, amap, batch * 2 * rl) && ks_moddown_fused()) {
+        const LimbMap &amap = amap_md;
+        if (md_single) {
             // single-pass inverse: the special limb first, then the data limbs with the mod-down as their store epilogue (no acc round trip,
             // no separate memory-bound kernel)
             launch_ntt1(acc, nullptr, c.d_desc, amap, batch * 2 * rl, true, s, u64(1) << dl, nullptr);
             const Ntt1ModDown md{ct.data, ct.bstride, dl, qk, a.half};
             launch_ntt1(acc, nullptr, c.d_desc_md, amap, batch * 2 * rl, true, s, (u64(1) << dl) - 1, &md);
-        } else if (c.d_desc_md && ntt2_supported(c.logn) && ks_moddown_fused()) {
+        } else if (md_two_pass) {
             // two-pass inverse, same shape: the special limb first, then the data limbs with the mod-down (BFV or BGV) as the last pass's epilogue
             launch_ntt2_slots(acc, nullptr, 0, false, c.d_desc, amap, batch * 2 * rl, c.logn, true, s, false, 0, (unsigned)dl, 1, nullptr);
             u64 *share = nullptr;
@@ -380,7 +388,9 @@ void Evaluator::switch_key(CtBatch &ct, const u64 *target, u64 t_bstride, const 
                 share = c.arena.take(batch * 4 * N);
                 launch_ks_bgv_share(acc, share, a, s);
             }
-            const Ntt2ModDown md{c.scheme == SCHEME_BFV ? 0 : 2, ct.data, ct.bstride, (unsigned)dl, qk, a.half, share};
+            Ntt2ModDown md{c.scheme == SCHEME_BFV ? 0 : 2, ct.data, ct.bstride, (unsigned)dl, qk, a.half, share};
+            md.base = base;
+            md.base_bstride = base_bstride;
             launch_ntt2_slots(acc, nullptr, 0, false, c.d_desc_md, amap, batch * 2 * rl, c.logn, true, s, false, 0, 0, (unsigned)dl, &md);
         } else {
             launch_ntt(acc, c.d_desc, amap, batch * 2 * rl, c.logn, true, s);
@@ -523,10 +533,8 @@ void Evaluator::apply_galois(CtBatch &ct, uint32_t elt, const KsKey &key, u64 ba
     const bool ntt_form = c.scheme == SCHEME_CKKS;
     launch_galois(ntt_form, ct.data, ct.bstride, t0, pw, c.d_desc, map, c.logn, elt, L, batch, s);
     launch_galois(ntt_form, ct.data + pw, ct.bstride, t1, pw, c.d_desc, map, c.logn, elt, L, batch, s);
-    launch_copy_strided(t0, pw, ct.data, ct.bstride, pw, batch, s);
-    launch_zero_strided(ct.data + pw, ct.bstride, pw, batch, s);
-    // switch_key resets the arena but never grows it now, so t1 (beyond its working set) stays intact
-    switch_key(ct, t1, pw, key, batch, s);
+    // switch_key resets the arena but never grows it now, so t0 and t1 (beyond its working set) stay intact; it takes ct as (t0, 0)
+    switch_key(ct, t1, pw, key, batch, s, t0, pw);
 }
 
 void Evaluator::transform_to_ntt(CtBatch &ct, u64 batch, hipStream_t s) { // evaluator_cuda.cu:1950-1985

@@ -24,7 +24,9 @@ bool ntt2_supported(int logn);
 // (N^-1 constants carry qk^-1, aux = qk^-1); the data slots are transformed and  ct[b][k][j] += (acc_j - share of the special limb) qk^-1
 // is applied instead of storing them (evaluator.cpp:2528-2648).
 // BGV: `share` = the 128-bit integers al + k_t qk per (item, coefficient) from launch_ks_bgv_share (poly.hip).
-struct Ntt2ModDown { int kind; u64 *ct; u64 ct_bstride; unsigned dl; u64 qk, half; const u64 *share; };
+// base != nullptr: the ciphertext being accumulated into is (base, 0), i.e. ct[b][0] = base[b] + ..., ct[b][1] = ... (rotations: base = sigma(c0) in a
+// temporary; spares the copy into ct[b][0] and the zero fill of ct[b][1])
+struct Ntt2ModDown { int kind; u64 *ct; u64 ct_bstride; unsigned dl; u64 qk, half; const u64 *share; const u64 *base = nullptr; u64 base_bstride = 0; };
 void launch_ntt2_slots(u64 *data, const u64 *src, u64 src_ostride, bool src_reduce, const PrimeDesc *primes, const LimbMap &map, size_t rows, int logn,
                        bool inverse, hipStream_t stream, bool src_same_layout, u64 src_bound, unsigned slot_begin, unsigned slot_count, const Ntt2ModDown *md);
 void launch_ntt2(u64 *data, const u64 *src, u64 src_ostride, bool src_reduce, const PrimeDesc *primes, const LimbMap &map, size_t rows, int logn,
