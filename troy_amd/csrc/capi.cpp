@@ -168,6 +168,23 @@ struct DevicePool {
             free_blocks.erase(it);
             return p;
         }
+#ifndef TROYHIP_CPU_EMUL
+        // No block of this size has been passed by every stream yet (the host runs ahead of the device: a loop that allocates a result per
+        // step): rather than allocating again -- hipMalloc of a few hundred MB costs tens of milliseconds, and the cache would grow by one
+        // block per step -- take a pending block and make every stream wait for the point at which it was freed (stream-ordered reuse).
+        for (auto it = free_blocks.lower_bound(bytes); it != free_blocks.end() && it->first <= 2 * bytes; ++it) {
+            Block &b = it->second;
+            for (hipEvent_t e : b.pending) {
+                for (size_t i = 0; i <= streams.size(); i++) HIP_CHECK(hipStreamWaitEvent(i ? streams[i - 1] : (hipStream_t) nullptr, e, 0));
+                spare_events.push_back(e);
+            }
+            b.pending.clear();
+            void *p = b.p;
+            live[p] = it->first;
+            free_blocks.erase(it);
+            return p;
+        }
+#endif
         void *p = nullptr;
         if (hipMalloc(&p, bytes) != hipSuccess) { // release the cache and retry once
             (void)hipGetLastError();
