@@ -352,7 +352,9 @@ void Evaluator::switch_key(CtBatch &ct, const u64 *target, u64 t_bstride, const 
     for (u64 j = 0; j < dl; j++) md_primes33 = md_primes33 && c.primes[j] >= (u64(1) << 33);
     const bool md_single = c.scheme == SCHEME_BFV && c.d_desc_md && md_primes33 && ntt1_supported(c.logn, amap_md, batch * 2 * rl) && ks_moddown_fused();
     const bool md_two_pass = c.scheme != SCHEME_CKKS && !md_single && c.d_desc_md && ntt2_supported(c.logn) && ks_moddown_fused();
-    if (base && !md_two_pass) { // only the two-pass epilogue takes (base, 0) directly: every other form accumulates onto what ct holds
+    const bool ckks_single = c.scheme == SCHEME_CKKS && c.d_inv_qk && corr_fused() && primes_at_least_33_bits(c, (int)dl) &&
+                             ntt1_supported(c.logn, c.ct_map((int)dl), batch * 2 * dl);
+    if (base && !md_two_pass && !ckks_single) { // only the two-pass epilogue and the fused CKKS correction take (base, 0) directly: every other form accumulates onto what ct holds
         launch_copy_strided(base, base_bstride, ct.data, ct.bstride, dl * N, batch, s);
         launch_zero_strided(ct.data + dl * N, ct.bstride, dl * N, batch, s);
         base = nullptr;
@@ -363,9 +365,11 @@ void Evaluator::switch_key(CtBatch &ct, const u64 *target, u64 t_bstride, const 
         launch_gather_limb(acc, last, c.logn, rl * N, dl, batch * 2, s);
         launch_ntt(last, c.d_desc, c.single_map((int)K - 1), batch * 2, c.logn, true, s);
         const LimbMap cmap = c.ct_map((int)dl);
-        if (c.d_inv_qk && corr_fused() && primes_at_least_33_bits(c, (int)dl) && ntt1_supported(c.logn, cmap, batch * 2 * dl)) {
+        if (ckks_single) {
             // the correction is built, transformed and combined by ONE single-pass transform (Ntt1Corr): no corr buffer, no element-wise kernels
-            const Ntt1Corr cr{last, acc, rl * N, ct.data, ct.bstride, dl * N, 2, c.d_inv_qk, qk, a.half, true};
+            Ntt1Corr cr{last, acc, rl * N, ct.data, ct.bstride, dl * N, 2, c.d_inv_qk, qk, a.half, true};
+            cr.base = base;
+            cr.base_gstride = base_bstride;
             launch_ntt1(nullptr, nullptr, c.d_desc, cmap, batch * 2 * dl, false, s, ~0ull, nullptr, &cr);
         } else {
             launch_ks_ckks_corr(last, corr, a, s);

@@ -56,6 +56,10 @@ struct Ntt1Corr {
     u64 qx, half;
     bool accumulate;
     u64 in_gstride = 0;
+    // accumulate with base != nullptr: what is added to is (base, 0, 0, ..) per group instead of what out holds -- member 0 of group g reads
+    // base[g * base_gstride + slot * N ..], the other members start from zero (rotations: base = sigma(c0) in a temporary)
+    const u64 *base = nullptr;
+    u64 base_gstride = 0;
 };
 // slot_mask: only these prime slots of the row pattern are transformed
 void launch_ntt1(u64 *data, const u64 *src, const PrimeDesc *primes, const LimbMap &map, size_t rows, bool inverse, hipStream_t stream, u64 slot_mask = ~0ull,

@@ -51,6 +51,8 @@ struct Ntt1Args {
     const Shoup *cr_inv;
     u64 cr_in_ostride, cr_in_gstride, cr_out_gstride, cr_out_ostride, cr_qx, cr_half;
     unsigned cr_group, cr_accumulate;
+    const u64 *cr_base;   // accumulate onto (base, 0) per group instead of onto out (Ntt1Corr::base)
+    u64 cr_base_gstride;
     // inverse only: mod-down epilogue (Ntt1ModDown); md_ct == nullptr: plain stores
     u64 *md_ct;
     u64 md_ct_bstride, md_qk, md_half;
@@ -210,7 +212,7 @@ template <int G, int R, bool LAST, bool UNI, int B0 = 0, class TW> __device__ __
 // result canonical to `out` (the sub-block's 1024 coefficients in HBM)
 template <bool LEAN, bool CR> __device__ __forceinline__ void fwd_subblock(u64 *R, const unsigned sb, const unsigned lane_in, const PrimeDesc &pd, const PrimeConst &pc, const Mod &m,
                                                                   u64 *out, const Ntt1Args &a, const unsigned mm, const unsigned m_begin, const int stamp0, const bool hf_last,
-                                                                  const u64 *cr_in = nullptr, const Shoup cr_inv = Shoup{0, 0}) {
+                                                                  const u64 *cr_in = nullptr, const Shoup cr_inv = Shoup{0, 0}, const u64 *cr_acc = nullptr) {
     (void)a; (void)mm; (void)m_begin; (void)stamp0; (void)hf_last;
     const unsigned lane = opaque(lane_in);
     N1_PRIO(3);
@@ -294,10 +296,10 @@ template <bool LEAN, bool CR> __device__ __forceinline__ void fwd_subblock(u64 *
                 mulhi_approx4_u(q, w, iq);
 #pragma unroll
                 for (int i = 0; i < 4; i++) r[i] = mul_acc_u(0, w[i], cr_inv.op, q[i], pc.negp); // [0, 3p)
-                if (a.cr_accumulate) {
+                if (cr_acc) { // what the result is added to: the output itself, or the base polynomial of a rotation (null: nothing, start from zero)
 #pragma unroll
                     for (int e = 0; e < 2; e++) {
-                        const ulonglong2 v = ld_g2(out, 8 * u + 4 * h + 2 * e);
+                        const ulonglong2 v = ld_g2(cr_acc, 8 * u + 4 * h + 2 * e);
                         r[2 * e] += v.x;
                         r[2 * e + 1] += v.y;
                     }
@@ -361,6 +363,11 @@ template <bool LEAN, bool CR> __global__ __launch_bounds__(N1_THREADS) void ntt1
     u64 *const park = lds + 16 * 1024 + tid;
     for (unsigned mm = m_begin; mm < m_end; mm++) {
         u64 *const out = CR ? a.cr_out + (u64)(mm / a.cr_group) * a.cr_out_gstride + (u64)(mm % a.cr_group) * a.cr_out_ostride + ((u64)slot << N1_LOGN) : a.data + row_of(mm);
+        // accumulate: onto out, or -- rotations -- onto (base, 0): member 0 of a group reads the base polynomial, the others start from zero
+        const u64 *const cacc = !CR || !a.cr_accumulate ? nullptr
+                                : !a.cr_base            ? out
+                                : (mm % a.cr_group == 0) ? a.cr_base + (u64)(mm / a.cr_group) * a.cr_base_gstride + ((u64)slot << N1_LOGN)
+                                                         : nullptr;
         const u64 *const cin = CR ? a.cr_in + (a.cr_in_gstride ? (u64)(mm / a.cr_group) * a.cr_in_gstride + (u64)(mm % a.cr_group) * a.cr_in_ostride : (u64)mm * a.cr_in_ostride) + ((u64)slot << N1_LOGN) : nullptr;
         if (CR) { // corr = [(last + half) mod qx]_p + (p - [half]_p), the residue lazily below 4p: below 5p, inside what the butterflies take
 #pragma unroll
@@ -415,7 +422,8 @@ template <bool LEAN, bool CR> __global__ __launch_bounds__(N1_THREADS) void ntt1
             __syncthreads();
             N1_STAMP(3 + 6 * hf);
             if (hf == 1 && mm + 1 < m_end) load_half(xe, in_row(mm + 1), 0); // all 32 registers are free now: request the next limb's even half
-            fwd_subblock<LEAN, CR>(region, 16 * hf + wv, lane, pd, pc, m, out + 1024 * (16 * hf + wv), a, mm, m_begin, 4 + 6 * hf, hf == 1, CR ? cin + 1024 * (16 * hf + wv) : nullptr, cr_inv);
+            fwd_subblock<LEAN, CR>(region, 16 * hf + wv, lane, pd, pc, m, out + 1024 * (16 * hf + wv), a, mm, m_begin, 4 + 6 * hf, hf == 1, CR ? cin + 1024 * (16 * hf + wv) : nullptr, cr_inv,
+                                   CR && cacc ? cacc + 1024 * (16 * hf + wv) : nullptr);
             N1_STAMP(7 + 6 * hf);
         }
         if (mm + 1 < m_end) load_half(xo, in_row(mm + 1), 1);
@@ -663,6 +671,7 @@ void launch_ntt1(u64 *data, const u64 *src, const PrimeDesc *primes, const LimbM
         a.cr_last = cr->last; a.cr_in = cr->in; a.cr_out = cr->out; a.cr_inv = cr->inv;
         a.cr_in_ostride = cr->in_ostride; a.cr_in_gstride = cr->in_gstride; a.cr_out_gstride = cr->out_gstride; a.cr_out_ostride = cr->out_ostride;
         a.cr_qx = cr->qx; a.cr_half = cr->half; a.cr_group = cr->group ? cr->group : 1; a.cr_accumulate = cr->accumulate ? 1 : 0;
+        a.cr_base = cr->base; a.cr_base_gstride = cr->base_gstride;
     }
     if (md) { a.md_ct = md->ct; a.md_ct_bstride = md->ct_bstride; a.md_qk = md->qk; a.md_half = md->half; a.md_dl = (unsigned)md->dl; }
     // One workgroup fills a CU, so a launch runs in rounds of `cus` workgroups and a round lasts as long as a workgroup's rows (plus
