@@ -674,6 +674,10 @@ def mul_relin_hash(name, batch=2, seed=4242):
     h = h1 + ":" + sha(r.cpu())
     if ntt and L - 1 >= be.last_limbs:  # CKKS: the rescale too (its correction transform has a fused and an element-wise form)
         h += ":" + sha(be.ev.rescaleToNext(r).cpu())
+    # a rotation: its key switch accumulates onto (sigma(c0), 0) -- directly in the fused epilogues, through a copy + zero fill in the others
+    elt = be.elt_from_step(1)
+    be.set_galois_key(elt, synth.uniform_kswitch_key(seed + 3, be.primes, N))
+    h += ":" + sha(be.rotate(r, 1).cpu())
     return h
 
 

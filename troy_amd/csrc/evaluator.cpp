@@ -354,7 +354,7 @@ void Evaluator::switch_key(CtBatch &ct, const u64 *target, u64 t_bstride, const 
     const bool md_two_pass = c.scheme != SCHEME_CKKS && !md_single && c.d_desc_md && ntt2_supported(c.logn) && ks_moddown_fused();
     const bool ckks_single = c.scheme == SCHEME_CKKS && c.d_inv_qk && corr_fused() && primes_at_least_33_bits(c, (int)dl) &&
                              ntt1_supported(c.logn, c.ct_map((int)dl), batch * 2 * dl);
-    if (base && !md_two_pass && !ckks_single) { // only the two-pass epilogue and the fused CKKS correction take (base, 0) directly: every other form accumulates onto what ct holds
+    if (base && !md_two_pass && !md_single && !ckks_single) { // the fused epilogues take (base, 0) directly; the element-wise forms accumulate onto what ct holds
         launch_copy_strided(base, base_bstride, ct.data, ct.bstride, dl * N, batch, s);
         launch_zero_strided(ct.data + dl * N, ct.bstride, dl * N, batch, s);
         base = nullptr;
@@ -382,7 +382,9 @@ void Evaluator::switch_key(CtBatch &ct, const u64 *target, u64 t_bstride, const 
             // single-pass inverse: the special limb first, then the data limbs with the mod-down as their store epilogue (no acc round trip,
             // no separate memory-bound kernel)
             launch_ntt1(acc, nullptr, c.d_desc, amap, batch * 2 * rl, true, s, u64(1) << dl, nullptr);
-            const Ntt1ModDown md{ct.data, ct.bstride, dl, qk, a.half};
+            Ntt1ModDown md{ct.data, ct.bstride, dl, qk, a.half};
+            md.base = base;
+            md.base_bstride = base_bstride;
             launch_ntt1(acc, nullptr, c.d_desc_md, amap, batch * 2 * rl, true, s, (u64(1) << dl) - 1, &md);
         } else if (md_two_pass) {
             // two-pass inverse, same shape: the special limb first, then the data limbs with the mod-down (BFV or BGV) as the last pass's epilogue

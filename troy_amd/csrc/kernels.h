@@ -38,7 +38,8 @@ bool ntt1_supported(int logn, const LimbMap &map, size_t rows);
 // accumulators acc[o = 2 b + cpt][slot][N]: the slots below `dl` leave the kernel as  ct[b][cpt][slot] += (acc - [t']_q + [half]_q) qk^-1
 // instead of being stored; slot `dl` (the special limb) must already be in coefficient form.  `primes` is then Context::d_desc_md,
 // whose N^-1 constants carry qk^-1 and whose `aux` is qk^-1 itself.
-struct Ntt1ModDown { u64 *ct; u64 ct_bstride; u64 dl, qk, half; };
+// base != nullptr: accumulate onto (base[b], 0) instead of onto what ct holds (rotations)
+struct Ntt1ModDown { u64 *ct; u64 ct_bstride; u64 dl, qk, half; const u64 *base = nullptr; u64 base_bstride = 0; };
 // CKKS divide-and-round by a prime qx in NTT form (divideAndRoundqLastNttInplace, rns.cpp:832-877; the mod-down of the CKKS key switch,
 // evaluator.cpp:2600-2648): the correction polynomial corr_slot = [(last + half) mod qx]_p + (p - [half]_p) is BUILT on load from the
 // coefficient-form residues `last` of qx (one row per outer index), transformed, and COMBINED on store:

@@ -56,6 +56,8 @@ struct Ntt1Args {
     // inverse only: mod-down epilogue (Ntt1ModDown); md_ct == nullptr: plain stores
     u64 *md_ct;
     u64 md_ct_bstride, md_qk, md_half;
+    const u64 *md_base;   // accumulate onto (base[b], 0) instead of onto ct (Ntt1ModDown::base)
+    u64 md_base_bstride;
     unsigned md_dl;
     u64 *dbg;             // development builds (-DN1_TIMING): s_memtime stamps of wave 0 of workgroup dbg_block
     unsigned dbg_block;
@@ -593,6 +595,7 @@ template <bool LEAN, bool MD> __global__ __launch_bounds__(N1_THREADS) void ntt1
             const u64 bias = pd.p * 4 + barrett64(a.md_half, m);         // [half]_p + 4p: keeps the difference below positive
             const u64 *special = a.data + (((u64)mm * period + a.md_dl) << N1_LOGN);
             u64 *dst = a.md_ct + (u64)(mm >> 1) * a.md_ct_bstride + (((u64)(mm & 1) * a.md_dl + slot) << N1_LOGN);
+            const u64 *onto = !a.md_base ? dst : (mm & 1) ? nullptr : a.md_base + (u64)(mm >> 1) * a.md_base_bstride + ((u64)slot << N1_LOGN);
             const Shoup iq[4] = {pd.aux, pd.aux, pd.aux, pd.aux};
 #pragma unroll
             for (int g = 0; g < 8; g++) { // four coefficients at a time through the butterfly building blocks (bfly.h); x[] stays in registers
@@ -601,7 +604,7 @@ template <bool LEAN, bool MD> __global__ __launch_bounds__(N1_THREADS) void ntt1
                 for (int i = 0; i < 4; i++) {
                     const unsigned n = t + 1024 * (4 * g + i);
                     tl[i] = ld_g(special, n) + a.md_half;                 // t' = (acc_last + half) mod qk
-                    c[i] = ld_g(dst, n);
+                    c[i] = onto ? ld_g(onto, n) : 0;
                 }
                 csub4(tl, a.md_qk);
                 lite_reduce4(tl, (u32)pd.cr1, pc);                        // [t']_p lazily, below 4p
@@ -673,7 +676,7 @@ void launch_ntt1(u64 *data, const u64 *src, const PrimeDesc *primes, const LimbM
         a.cr_qx = cr->qx; a.cr_half = cr->half; a.cr_group = cr->group ? cr->group : 1; a.cr_accumulate = cr->accumulate ? 1 : 0;
         a.cr_base = cr->base; a.cr_base_gstride = cr->base_gstride;
     }
-    if (md) { a.md_ct = md->ct; a.md_ct_bstride = md->ct_bstride; a.md_qk = md->qk; a.md_half = md->half; a.md_dl = (unsigned)md->dl; }
+    if (md) { a.md_ct = md->ct; a.md_ct_bstride = md->ct_bstride; a.md_qk = md->qk; a.md_half = md->half; a.md_dl = (unsigned)md->dl; a.md_base = md->base; a.md_base_bstride = md->base_bstride; }
     // One workgroup fills a CU, so a launch runs in rounds of `cus` workgroups and a round lasts as long as a workgroup's rows (plus
     // the un-overlapped first load and last store, about a third of a row): pick the rows per workgroup (they share the prime) that
     // minimises rounds x (rows + 1/3), with a small penalty for spreading the CUs over many primes at once.  A fixed "three workgroups
