@@ -223,8 +223,9 @@ class Workload:
         self.gk.keys[ta.GaloisKeys.getIndex(self.ctx.galois_elt_from_step(1))] = self._key(self.ctx, 0xC0FFEF)
 
         def step():
-            w = self.x3.copy()  # relinearize consumes its operand: every step starts from the same size-3 batch (device copy, part of the step)
-            self.ev.relinearizeInplace(w, self.rlk)
+            # relinearize(encrypted, keys, destination): every step starts from the same size-3 batch.  The reference's form copies the
+            # operand and relinearizes the copy in place; the library reads it where it lies (troyhip_relinearize_to)
+            w = self.ev.relinearize(self.x3, self.rlk)
             self.ev.rotateRowsInplace(w, 1, self.gk)
             self.last = w
 

@@ -162,6 +162,10 @@ int troyhip_relinearize(troyhip_context *ctx, troyhip_ct *ct, const uint64_t *re
 /* relinearizeInplace from any size <= 16 (relinearizeInternal, src/evaluator_cuda.cu:703-744): relin_keys[i] = device key of index i
  * (RelinKeys::getIndex(i + 2)), n_keys >= size - 2; the step sequence is the reference's, see evaluator.cpp */
 int troyhip_relinearize_keys(troyhip_context *ctx, troyhip_ct *ct, const uint64_t *const *relin_keys, int n_keys, uint64_t batch, void *stream);
+/* relinearize(encrypted, relin_keys, destination) (src/evaluator_cuda.cuh: copy + relinearizeInplace): out->data / out->batch_stride are inputs
+ * (a distinct buffer of at least 2 polynomials per item; at least in->size for in->size > 3), the rest of *out is set.  From size 3 the operand is
+ * read where it lies (c2 as the key-switch target, c0 / c1 as what the result is accumulated onto): no copy of the operand is made. */
+int troyhip_relinearize_to(troyhip_context *ctx, const troyhip_ct *in, troyhip_ct *out, const uint64_t *const *relin_keys, int n_keys, uint64_t batch, void *stream);
 int troyhip_switch_key(troyhip_context *ctx, troyhip_ct *ct, const uint64_t *target, uint64_t target_batch_stride,
                        const uint64_t *kswitch_key, uint64_t batch, void *stream);                            /* applyKeySwitchingInplace / switchKeyInplace */
 int troyhip_mod_switch_to_next(troyhip_context *ctx, const troyhip_ct *in, troyhip_ct *out, uint64_t batch, void *stream);   /* modSwitchToNext */

@@ -750,7 +750,17 @@ public:
         }
         check(troyhip_relinearize_keys(h(), a.raw(), keys.data(), (int)need, 1, nullptr));
     }
-    void relinearize(const Ciphertext &a, const RelinKeys &k, Ciphertext &d) const { d = a; relinearizeInplace(d, k); }
+    // the reference copies and relinearizes in place; from size 3 the library reads the operand where it lies (troyhip_relinearize_to): no copy
+    void relinearize(const Ciphertext &a, const RelinKeys &k, Ciphertext &d) const {
+        if (a.size() != 3 || &d == &a) { d = a; relinearizeInplace(d, k); return; }
+        if (!k.hasKey(2)) throw std::invalid_argument("not enough relinearization keys");
+        const uint64_t *key = k.device(RelinKeys::getIndex(2));
+        Ciphertext out;
+        out.resize(a.polyModulusDegree(), a.coeffModulusSize(), 2);
+        check(troyhip_relinearize_to(h(), a.raw(), out.raw(), &key, 1, 1, nullptr));
+        out.bind(a);
+        d = std::move(out);
+    }
     // applyKeySwitchingInplace (evaluator_cuda.cu:1365-1378), negacyclicShiftInplace (:2342-2351)
     void applyKeySwitchingInplace(Ciphertext &a, const KSwitchKeys &k) const {
         if (k.all().size() != 1) throw std::invalid_argument("kswitch_keys.data().size() != 1");

@@ -681,6 +681,25 @@ def mul_relin_hash(name, batch=2, seed=4242):
     return h
 
 
+def check_relinearize_out_of_place(name, batch=3, seed=99):
+    """relinearize(a, keys) -- from size 3 the operand is read where it lies (troyhip_relinearize_to), larger sizes copy -- against the copy +
+    relinearizeInplace it replaces, limb for limb; the operand must come out untouched"""
+    from troy_amd import api, synth
+    cfg = CONFIGS[name]
+    be = GpuBackend(cfg, batch=batch)
+    L, N, ntt = len(be.primes) - 1, cfg["N"], cfg["scheme"] == CKKS
+    be.set_relin_key(synth.uniform_kswitch_key(seed, be.primes, N), 0)
+    be.set_relin_key(synth.uniform_kswitch_key(seed + 1, be.primes, N), 1)
+    for size in (3, 4):
+        x = synth.uniform_ct(seed + size, be.primes[:L], size, N, batch)
+        a = api.Ciphertext.from_numpy(be.ctx, x, ntt, 1.0, 1, capacity=size + (size == 3))  # a strided operand too
+        want = a.copy()
+        be.ev.relinearizeInplace(want, be.rlk)
+        got = be.ev.relinearize(a, be.rlk)
+        assert got.size() == 2 and np.array_equal(got.cpu(), want.cpu()), (name, size)
+        assert np.array_equal(a.cpu(), x), (name, size, "operand modified")
+
+
 def check_modswitch_as_first_op(cfg_name, batch=2):
     """rescaleToNext / modSwitchToNext as the FIRST operation on a fresh context (nothing has sized the scratch arena
     yet), with strided (capacity 3) and dense operands, then again at a larger batch.  Results against the oracle."""

@@ -462,6 +462,15 @@ def test_random_parameter_sets(seed, gpu, oracle_lib):
     assert n is None or n > 10, cfg
 
 
+@pytest.mark.parametrize("name", ["cfgA_bfv_n4096_k3", "cfgB_bfv_n8192_k5", "bgv_n4096_k3", "ckks_n4096_k4", "cfgNS_bfv_n32768_k15", "cfgC_ckks_n32768_k15"])
+def test_relinearize_out_of_place(name, gpu):
+    """the destination form of relinearize (operand read in place from size 3, every mod-down epilogue accumulating onto (c0, c1) of the
+    operand) == copy + relinearizeInplace"""
+    if name not in cases.CONFIGS:
+        pytest.skip("configuration not in this build of the fixtures")
+    cases.check_relinearize_out_of_place(name)
+
+
 def test_multiply_plain_accumulate(gpu):
     """the fused sum of ciphertext x plaintext products == the multiplyPlain + addInplace loop, limb for limb"""
     cases.check_multiply_plain_accumulate()

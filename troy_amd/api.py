@@ -453,10 +453,22 @@ class Evaluator:
         self._chk(self.lib.troyhip_relinearize_keys(self.context.h, C.byref(st), ptrs, need, C.c_uint64(a.batch), self.stream))
         a._absorb(st)
 
-    def relinearize(self, a, relin_keys):
-        r = a.copy()
-        self.relinearizeInplace(r, relin_keys)
-        return r
+    def relinearize(self, a, relin_keys, destination=None):
+        """relinearize(encrypted, relin_keys, destination): the reference copies and relinearizes in place; from size 3 the library reads the
+        operand where it lies and writes the size-2 result to the destination (troyhip_relinearize_to): no copy of the operand"""
+        need = max(a.size() - 2, 0)
+        for idx in range(need):
+            if not relin_keys.hasKey(idx):
+                raise capi.InvalidArgument(capi.INVALID_ARGUMENT, "not enough relinearization keys")
+        cap = 2 if a.size() == 3 else a.size()
+        out = destination or Ciphertext(a.context, a.batch, cap, a.limbs, capacity=cap)
+        if out is a or out.capacity < cap:
+            raise capi.InvalidArgument(capi.INVALID_ARGUMENT, "destination must be a distinct ciphertext of sufficient capacity")
+        si, so = a.struct(), out.struct()
+        ptrs = (C.c_void_p * max(need, 1))(*[relin_keys.keys[i].ptr for i in range(need)])
+        self._chk(self.lib.troyhip_relinearize_to(self.context.h, C.byref(si), C.byref(so), ptrs, need, C.c_uint64(a.batch), self.stream))
+        out._absorb(so)
+        return out
 
     def applyKeySwitchingInplace(self, a, kswitch_keys):
         """applyKeySwitchingInplace (evaluator_cuda.cu:1365-1378): kswitch_keys must hold exactly one key; c1 of a size-2

@@ -59,7 +59,7 @@ SYMBOLS = [
     "troyhip_host_keygen", "troyhip_host_relin_key", "troyhip_host_galois_key", "troyhip_host_encrypt", "troyhip_host_encrypt_symmetric", "troyhip_multiply_plain_accumulate", "troyhip_host_decrypt", "troyhip_context_info",
     "troyhip_context_behz_bases", "troyhip_context_ntt_tables", "troyhip_test_modarith", "troyhip_ktime_enable", "troyhip_ktime_report", "troyhip_blake2b", "troyhip_random_bytes", "troyhip_context_parms_id", "troyhip_context_release_stream", "troyhip_context_reserve_scratch",
     "troyhip_context_scratch_words", "troyhip_galois_elt_from_step", "troyhip_ntt", "troyhip_fill_uniform",
-    "troyhip_negate", "troyhip_add", "troyhip_sub", "troyhip_multiply", "troyhip_relinearize", "troyhip_relinearize_keys", "troyhip_switch_key",
+    "troyhip_negate", "troyhip_add", "troyhip_sub", "troyhip_multiply", "troyhip_relinearize", "troyhip_relinearize_keys", "troyhip_relinearize_to", "troyhip_switch_key",
     "troyhip_mod_switch_to_next", "troyhip_rescale_to_next", "troyhip_apply_galois", "troyhip_rotate",
     "troyhip_transform_to_ntt", "troyhip_transform_from_ntt", "troyhip_multiply_plain_ntt", "troyhip_add_plain", "troyhip_multiply_plain",
     "troyhip_plain_to_ntt", "troyhip_decrypt", "troyhip_apply_key_switching", "troyhip_negacyclic_shift", "troyhip_divide_by_poly_modulus_degree",

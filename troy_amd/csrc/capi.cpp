@@ -444,6 +444,17 @@ int troyhip_relinearize_keys(troyhip_context *ctx, troyhip_ct *ct, const uint64_
         store(x, ct);
     });
 }
+int troyhip_relinearize_to(troyhip_context *ctx, const troyhip_ct *in, troyhip_ct *out, const uint64_t *const *relin_keys, int n_keys, uint64_t batch, void *stream) {
+    return guard([&] {
+        if (n_keys < 0 || n_keys > 14 || (n_keys && !relin_keys)) throw Error(ST_INVALID_ARGUMENT, "not enough relinearization keys");
+        if (!in || !out) throw Error(ST_INVALID_ARGUMENT, "null ciphertext");
+        KsKey keys[14];
+        for (int i = 0; i < n_keys; i++) keys[i] = KsKey{relin_keys[i]};
+        CtBatch o = view(out);
+        ctx->ev.relinearize_to(view(in), o, keys, n_keys, batch, (hipStream_t)stream);
+        store(o, out);
+    });
+}
 int troyhip_switch_key(troyhip_context *ctx, troyhip_ct *ct, const uint64_t *target, uint64_t target_batch_stride, const uint64_t *kswitch_key,
                        uint64_t batch, void *stream) {
     return guard([&] { CtBatch x = view(ct); ctx->ev.switch_key(x, target, target_batch_stride, KsKey{kswitch_key}, batch, (hipStream_t)stream); store(x, ct); });

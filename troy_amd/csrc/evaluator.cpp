@@ -270,7 +270,7 @@ size_t Evaluator::scratch_switch_key(int limbs, u64 batch) const {
 }
 
 // switchKeyInplace (evaluator_cuda.cu:1163-1362; CPU src/evaluator.cpp:2310-2653)
-void Evaluator::switch_key(CtBatch &ct, const u64 *target, u64 t_bstride, const KsKey &key, u64 batch, hipStream_t s, const u64 *base, u64 base_bstride) {
+void Evaluator::switch_key(CtBatch &ct, const u64 *target, u64 t_bstride, const KsKey &key, u64 batch, hipStream_t s, const u64 *base, u64 base_bstride, int base_polys) {
     check_ct(ct);
     if (!target) throw Error(ST_INVALID_ARGUMENT, "target_iter");
     if (c.K < 2) throw Error(ST_LOGIC_ERROR, "keyswitching is not supported by the context");
@@ -355,8 +355,8 @@ void Evaluator::switch_key(CtBatch &ct, const u64 *target, u64 t_bstride, const 
     const bool ckks_single = c.scheme == SCHEME_CKKS && c.d_inv_qk && corr_fused() && primes_at_least_33_bits(c, (int)dl) &&
                              ntt1_supported(c.logn, c.ct_map((int)dl), batch * 2 * dl);
     if (base && !md_two_pass && !md_single && !ckks_single) { // the fused epilogues take (base, 0) directly; the element-wise forms accumulate onto what ct holds
-        launch_copy_strided(base, base_bstride, ct.data, ct.bstride, dl * N, batch, s);
-        launch_zero_strided(ct.data + dl * N, ct.bstride, dl * N, batch, s);
+        launch_copy_strided(base, base_bstride, ct.data, ct.bstride, (u64)base_polys * dl * N, batch, s);
+        if (base_polys < 2) launch_zero_strided(ct.data + dl * N, ct.bstride, dl * N, batch, s);
         base = nullptr;
     }
     if (c.scheme == SCHEME_CKKS) {
@@ -370,6 +370,7 @@ void Evaluator::switch_key(CtBatch &ct, const u64 *target, u64 t_bstride, const 
             Ntt1Corr cr{last, acc, rl * N, ct.data, ct.bstride, dl * N, 2, c.d_inv_qk, qk, a.half, true};
             cr.base = base;
             cr.base_gstride = base_bstride;
+            cr.base_polys = base_polys;
             launch_ntt1(nullptr, nullptr, c.d_desc, cmap, batch * 2 * dl, false, s, ~0ull, nullptr, &cr);
         } else {
             launch_ks_ckks_corr(last, corr, a, s);
@@ -385,6 +386,7 @@ void Evaluator::switch_key(CtBatch &ct, const u64 *target, u64 t_bstride, const 
             Ntt1ModDown md{ct.data, ct.bstride, dl, qk, a.half};
             md.base = base;
             md.base_bstride = base_bstride;
+            md.base_polys = base_polys;
             launch_ntt1(acc, nullptr, c.d_desc_md, amap, batch * 2 * rl, true, s, (u64(1) << dl) - 1, &md);
         } else if (md_two_pass) {
             // two-pass inverse, same shape: the special limb first, then the data limbs with the mod-down (BFV or BGV) as the last pass's epilogue
@@ -397,6 +399,7 @@ void Evaluator::switch_key(CtBatch &ct, const u64 *target, u64 t_bstride, const 
             Ntt2ModDown md{c.scheme == SCHEME_BFV ? 0 : 2, ct.data, ct.bstride, (unsigned)dl, qk, a.half, share};
             md.base = base;
             md.base_bstride = base_bstride;
+            md.base_polys = base_polys;
             launch_ntt2_slots(acc, nullptr, 0, false, c.d_desc_md, amap, batch * 2 * rl, c.logn, true, s, false, 0, 0, (unsigned)dl, &md);
         } else {
             launch_ntt(acc, c.d_desc, amap, batch * 2 * rl, c.logn, true, s);
@@ -420,6 +423,34 @@ void Evaluator::relinearize(CtBatch &ct, const KsKey *keys, int n_keys, u64 batc
     const u64 pw = poly_words(c, ct.limbs);
     for (int i = 0; i < size - 2; i++) switch_key(ct, ct.data + (u64)(size - 1) * pw, ct.bstride, keys[size - 3 - i], batch, s);
     ct.size = 2;
+}
+
+// relinearize(encrypted, relin_keys, destination) (evaluator_cuda.cuh: copy + relinearizeInplace).  From size 3 the key switch reads c2 of
+// the operand as its target and accumulates onto (c0, c1) of the operand -- written to `out` by the mod-down epilogue -- so the copy the
+// reference makes does not happen; other sizes take the reference's route.
+void Evaluator::relinearize_to(const CtBatch &in, CtBatch &out, const KsKey *keys, int n_keys, u64 batch, hipStream_t s) {
+    check_ct(in);
+    const u64 pw = poly_words(c, in.limbs);
+    if (!out.data || out.data == in.data) throw Error(ST_INVALID_ARGUMENT, "relinearize: destination must be a distinct buffer");
+    if (in.size != 3 || out.bstride < 2 * pw) { // general sizes: the reference's copy, then in place (needs room for every polynomial)
+        if (out.bstride < (u64)in.size * pw) throw Error(ST_INVALID_ARGUMENT, "relinearize: destination too small");
+        launch_copy_strided(in.data, in.bstride, out.data, out.bstride, (u64)in.size * pw, batch, s);
+        const u64 *d = out.data;
+        const u64 bs = out.bstride;
+        out = in;
+        out.data = const_cast<u64 *>(d);
+        out.bstride = bs;
+        relinearize(out, keys, n_keys, batch, s);
+        return;
+    }
+    if (n_keys < 1 || !keys[0].data) throw Error(ST_INVALID_ARGUMENT, "not enough relinearization keys");
+    u64 *d = out.data;
+    const u64 bs = out.bstride;
+    out = in;
+    out.data = d;
+    out.bstride = bs;
+    out.size = 2;
+    switch_key(out, in.data + 2 * pw, in.bstride, keys[0], batch, s, in.data, in.bstride, 2);
 }
 void Evaluator::relinearize(CtBatch &ct, const KsKey &key, u64 batch, hipStream_t s) { relinearize(ct, &key, 1, batch, s); }
 

@@ -46,8 +46,11 @@ public:
     void negate(CtBatch &a, u64 batch, hipStream_t s);
     // out may alias a or b; out.size/limbs/... are set; out.data/out.bstride are the caller's
     void multiply(const CtBatch &a, const CtBatch &b, CtBatch &out, u64 batch, hipStream_t s);
-    // base != nullptr: ct is to be taken as (base, 0) -- polynomial 0 from base[b * base_bstride ..], polynomial 1 zero -- whatever it holds
-    void switch_key(CtBatch &ct, const u64 *target, u64 t_bstride, const KsKey &key, u64 batch, hipStream_t s, const u64 *base = nullptr, u64 base_bstride = 0);
+    // base != nullptr: ct is to be taken as (base, 0) -- polynomial 0 from base[b * base_bstride ..], polynomial 1 zero -- whatever it holds;
+    // base_polys == 2: as (base[b][0], base[b][1])
+    void switch_key(CtBatch &ct, const u64 *target, u64 t_bstride, const KsKey &key, u64 batch, hipStream_t s, const u64 *base = nullptr, u64 base_bstride = 0, int base_polys = 1);
+    // relinearize (not in place): size 3 -> 2 reads the operand where it lies and writes out; larger sizes copy and run in place
+    void relinearize_to(const CtBatch &in, CtBatch &out, const KsKey *keys, int n_keys, u64 batch, hipStream_t s);
     void relinearize(CtBatch &ct, const KsKey &key, u64 batch, hipStream_t s);
     void relinearize(CtBatch &ct, const KsKey *keys, int n_keys, u64 batch, hipStream_t s); // keys[i]: relin key of index i (power i + 2)
     void mod_switch_to_next(const CtBatch &in, CtBatch &out, u64 batch, hipStream_t s);

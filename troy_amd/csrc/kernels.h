@@ -26,7 +26,7 @@ bool ntt2_supported(int logn);
 // BGV: `share` = the 128-bit integers al + k_t qk per (item, coefficient) from launch_ks_bgv_share (poly.hip).
 // base != nullptr: the ciphertext being accumulated into is (base, 0), i.e. ct[b][0] = base[b] + ..., ct[b][1] = ... (rotations: base = sigma(c0) in a
 // temporary; spares the copy into ct[b][0] and the zero fill of ct[b][1])
-struct Ntt2ModDown { int kind; u64 *ct; u64 ct_bstride; unsigned dl; u64 qk, half; const u64 *share; const u64 *base = nullptr; u64 base_bstride = 0; };
+struct Ntt2ModDown { int kind; u64 *ct; u64 ct_bstride; unsigned dl; u64 qk, half; const u64 *share; const u64 *base = nullptr; u64 base_bstride = 0; int base_polys = 1; };
 void launch_ntt2_slots(u64 *data, const u64 *src, u64 src_ostride, bool src_reduce, const PrimeDesc *primes, const LimbMap &map, size_t rows, int logn,
                        bool inverse, hipStream_t stream, bool src_same_layout, u64 src_bound, unsigned slot_begin, unsigned slot_count, const Ntt2ModDown *md);
 void launch_ntt2(u64 *data, const u64 *src, u64 src_ostride, bool src_reduce, const PrimeDesc *primes, const LimbMap &map, size_t rows, int logn,
@@ -39,7 +39,7 @@ bool ntt1_supported(int logn, const LimbMap &map, size_t rows);
 // instead of being stored; slot `dl` (the special limb) must already be in coefficient form.  `primes` is then Context::d_desc_md,
 // whose N^-1 constants carry qk^-1 and whose `aux` is qk^-1 itself.
 // base != nullptr: accumulate onto (base[b], 0) instead of onto what ct holds (rotations)
-struct Ntt1ModDown { u64 *ct; u64 ct_bstride; u64 dl, qk, half; const u64 *base = nullptr; u64 base_bstride = 0; };
+struct Ntt1ModDown { u64 *ct; u64 ct_bstride; u64 dl, qk, half; const u64 *base = nullptr; u64 base_bstride = 0; int base_polys = 1; }; // base_polys == 2: onto (base[b][0], base[b][1]) -- relinearize out of place
 // CKKS divide-and-round by a prime qx in NTT form (divideAndRoundqLastNttInplace, rns.cpp:832-877; the mod-down of the CKKS key switch,
 // evaluator.cpp:2600-2648): the correction polynomial corr_slot = [(last + half) mod qx]_p + (p - [half]_p) is BUILT on load from the
 // coefficient-form residues `last` of qx (one row per outer index), transformed, and COMBINED on store:
@@ -61,6 +61,7 @@ struct Ntt1Corr {
     // base[g * base_gstride + slot * N ..], the other members start from zero (rotations: base = sigma(c0) in a temporary)
     const u64 *base = nullptr;
     u64 base_gstride = 0;
+    int base_polys = 1; // 2: members 0 and 1 of a group read base[g * base_gstride + {0, 1} * out_ostride ..] (relinearize out of place)
 };
 // slot_mask: only these prime slots of the row pattern are transformed
 void launch_ntt1(u64 *data, const u64 *src, const PrimeDesc *primes, const LimbMap &map, size_t rows, bool inverse, hipStream_t stream, u64 slot_mask = ~0ull,

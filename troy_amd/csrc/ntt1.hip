@@ -53,6 +53,7 @@ struct Ntt1Args {
     unsigned cr_group, cr_accumulate;
     const u64 *cr_base;   // accumulate onto (base, 0) per group instead of onto out (Ntt1Corr::base)
     u64 cr_base_gstride;
+    int cr_base_polys, md_base_polys; // 2: the second member / component reads its base polynomial too (relinearize out of place)
     // inverse only: mod-down epilogue (Ntt1ModDown); md_ct == nullptr: plain stores
     u64 *md_ct;
     u64 md_ct_bstride, md_qk, md_half;
@@ -368,7 +369,7 @@ template <bool LEAN, bool CR> __global__ __launch_bounds__(N1_THREADS) void ntt1
         // accumulate: onto out, or -- rotations -- onto (base, 0): member 0 of a group reads the base polynomial, the others start from zero
         const u64 *const cacc = !CR || !a.cr_accumulate ? nullptr
                                 : !a.cr_base            ? out
-                                : (mm % a.cr_group == 0) ? a.cr_base + (u64)(mm / a.cr_group) * a.cr_base_gstride + ((u64)slot << N1_LOGN)
+                                : ((int)(mm % a.cr_group) < a.cr_base_polys) ? a.cr_base + (u64)(mm / a.cr_group) * a.cr_base_gstride + (u64)(mm % a.cr_group) * a.cr_out_ostride + ((u64)slot << N1_LOGN)
                                                          : nullptr;
         const u64 *const cin = CR ? a.cr_in + (a.cr_in_gstride ? (u64)(mm / a.cr_group) * a.cr_in_gstride + (u64)(mm % a.cr_group) * a.cr_in_ostride : (u64)mm * a.cr_in_ostride) + ((u64)slot << N1_LOGN) : nullptr;
         if (CR) { // corr = [(last + half) mod qx]_p + (p - [half]_p), the residue lazily below 4p: below 5p, inside what the butterflies take
@@ -595,7 +596,7 @@ template <bool LEAN, bool MD> __global__ __launch_bounds__(N1_THREADS) void ntt1
             const u64 bias = pd.p * 4 + barrett64(a.md_half, m);         // [half]_p + 4p: keeps the difference below positive
             const u64 *special = a.data + (((u64)mm * period + a.md_dl) << N1_LOGN);
             u64 *dst = a.md_ct + (u64)(mm >> 1) * a.md_ct_bstride + (((u64)(mm & 1) * a.md_dl + slot) << N1_LOGN);
-            const u64 *onto = !a.md_base ? dst : (mm & 1) ? nullptr : a.md_base + (u64)(mm >> 1) * a.md_base_bstride + ((u64)slot << N1_LOGN);
+            const u64 *onto = !a.md_base ? dst : ((int)(mm & 1) >= a.md_base_polys) ? nullptr : a.md_base + (u64)(mm >> 1) * a.md_base_bstride + (((u64)(mm & 1) * a.md_dl + slot) << N1_LOGN);
             const Shoup iq[4] = {pd.aux, pd.aux, pd.aux, pd.aux};
 #pragma unroll
             for (int g = 0; g < 8; g++) { // four coefficients at a time through the butterfly building blocks (bfly.h); x[] stays in registers
@@ -674,9 +675,9 @@ void launch_ntt1(u64 *data, const u64 *src, const PrimeDesc *primes, const LimbM
         a.cr_last = cr->last; a.cr_in = cr->in; a.cr_out = cr->out; a.cr_inv = cr->inv;
         a.cr_in_ostride = cr->in_ostride; a.cr_in_gstride = cr->in_gstride; a.cr_out_gstride = cr->out_gstride; a.cr_out_ostride = cr->out_ostride;
         a.cr_qx = cr->qx; a.cr_half = cr->half; a.cr_group = cr->group ? cr->group : 1; a.cr_accumulate = cr->accumulate ? 1 : 0;
-        a.cr_base = cr->base; a.cr_base_gstride = cr->base_gstride;
+        a.cr_base = cr->base; a.cr_base_gstride = cr->base_gstride; a.cr_base_polys = cr->base_polys;
     }
-    if (md) { a.md_ct = md->ct; a.md_ct_bstride = md->ct_bstride; a.md_qk = md->qk; a.md_half = md->half; a.md_dl = (unsigned)md->dl; a.md_base = md->base; a.md_base_bstride = md->base_bstride; }
+    if (md) { a.md_ct = md->ct; a.md_ct_bstride = md->ct_bstride; a.md_qk = md->qk; a.md_half = md->half; a.md_dl = (unsigned)md->dl; a.md_base = md->base; a.md_base_bstride = md->base_bstride; a.md_base_polys = md->base_polys; }
     // One workgroup fills a CU, so a launch runs in rounds of `cus` workgroups and a round lasts as long as a workgroup's rows (plus
     // the un-overlapped first load and last store, about a third of a row): pick the rows per workgroup (they share the prime) that
     // minimises rounds x (rows + 1/3), with a small penalty for spreading the CUs over many primes at once.  A fixed "three workgroups

@@ -99,6 +99,7 @@ struct Ntt2Args {
     const u64 *md_share = nullptr; // BGV: [o][N] 128-bit integers al + k_t qk (ks_bgv_share_kernel, poly.hip)
     const u64 *md_base = nullptr;  // not null: accumulate onto (base[b], 0) instead of onto what ct holds
     u64 md_base_bstride = 0;
+    int md_base_polys = 1;         // 2: component 1 reads base[b] + dl * N too (relinearize out of place)
     unsigned md_dl = 0;
 };
 
@@ -465,8 +466,8 @@ template <int INV, int STRIDED, int NS, int LOGC, int LS, int R, bool HOISTP = t
         const PrimeConst pc = make_prime_const(p);
         const u64 *sp = a.data + (((u64)o * a.map.period + a.md_dl) << logn);
         u64 *ct = a.md_ct + (u64)(o >> 1) * a.md_ct_bstride + (((u64)(o & 1) * a.md_dl + slot) << logn);
-        const u64 *base = a.md_base ? a.md_base + (u64)(o >> 1) * a.md_base_bstride + ((u64)slot << logn) : ct; // component 0 only
-        const bool from_zero = a.md_base && (o & 1);
+        const u64 *base = a.md_base ? a.md_base + (u64)(o >> 1) * a.md_base_bstride + (((u64)(o & 1) * a.md_dl + slot) << logn) : ct;
+        const bool from_zero = a.md_base && (o & 1) && a.md_base_polys < 2;
         const ulonglong2 *sh = reinterpret_cast<const ulonglong2 *>(a.md_share) + ((u64)o << logn);
         const u64 c_p = FINAL == 3 ? barrett64(a.md_half, m) : 0; // [half]_p
 #pragma unroll
@@ -825,7 +826,7 @@ void launch_ntt2_slots(u64 *data, const u64 *src, u64 src_ostride, bool src_redu
     if (md) {
         a.md_ct = md->ct; a.md_ct_bstride = md->ct_bstride; a.md_dl = md->dl; a.md_qk = md->qk; a.md_half = md->half;
         a.md_share = md->share;
-        a.md_base = md->base; a.md_base_bstride = md->base_bstride;
+        a.md_base = md->base; a.md_base_bstride = md->base_bstride; a.md_base_polys = md->base_polys;
         if (md->kind == 2 && !md->share) throw Error(ST_LOGIC_ERROR, "ntt2: the BGV mod-down needs the special limb's shares");
     }
     const unsigned blocks = (unsigned)((slot_count * a.chunks) << a.tiles_per_row_log);
