@@ -523,8 +523,8 @@ def matmul_roofline(ta, capi, lib, w):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=0, help="units (ciphertext pairs / ciphertexts / input rows) per GPU per step; 0 = the workload's default")
     ap.add_argument("--workload", default="bfv_n32768_l14", choices=sorted(WORKLOADS))
     ap.add_argument("--streams", type=int, default=0, help="split the batch over this many HIP streams (one context each); 0 = the workload's default")
