@@ -355,7 +355,7 @@ void Evaluator::switch_key(CtBatch &ct, const u64 *target, u64 t_bstride, const 
     const bool ckks_single = c.scheme == SCHEME_CKKS && c.d_inv_qk && corr_fused() && primes_at_least_33_bits(c, (int)dl) &&
                              ntt1_supported(c.logn, c.ct_map((int)dl), batch * 2 * dl);
     if (base && !md_two_pass && !md_single && !ckks_single) { // the fused epilogues take (base, 0) directly; the element-wise forms accumulate onto what ct holds
-        launch_copy_strided(base, base_bstride, ct.data, ct.bstride, (u64)base_polys * dl * N, batch, s);
+        if (base != ct.data) launch_copy_strided(base, base_bstride, ct.data, ct.bstride, (u64)base_polys * dl * N, batch, s);
         if (base_polys < 2) launch_zero_strided(ct.data + dl * N, ct.bstride, dl * N, batch, s);
         base = nullptr;
     }
@@ -706,14 +706,9 @@ void Evaluator::apply_key_switching(CtBatch &ct, const KsKey &key, u64 batch, hi
     if (!key.data) throw Error(ST_INVALID_ARGUMENT, "kswitch_keys.data().size() != 1");
     if (ct.size != 2) throw Error(ST_INVALID_ARGUMENT, "encrypted.size() != 2");
     const u64 pw = poly_words(c, ct.limbs);
-    c.arena.begin(s);
-    const size_t ks = scratch_switch_key(ct.limbs, batch);
-    c.arena.reserve(ks + batch * pw + 128);
-    (void)c.arena.take(ks);
-    u64 *target = c.arena.take(batch * pw); // beyond switch_key's own working set, like apply_galois
-    launch_copy_strided(ct.data + pw, ct.bstride, target, pw, pw, batch, s);
-    launch_zero_strided(ct.data + pw, ct.bstride, pw, batch, s);
-    switch_key(ct, target, pw, key, batch, s);
+    // c1 is read as the target by the first stages of the key switch and written only by its last one (the mod-down), which takes the
+    // ciphertext as (c0, 0): no copy of c1, no zero fill
+    switch_key(ct, ct.data + pw, ct.bstride, key, batch, s, ct.data, ct.bstride, 1);
 }
 // negacyclicShift (evaluator_cuda.cu:2342-2351): every limb of every polynomial is multiplied by x^shift
 void Evaluator::negacyclic_shift(CtBatch &ct, u64 shift, u64 batch, hipStream_t s) {
