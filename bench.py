@@ -474,8 +474,9 @@ def algorithmic_bytes_ckks_chain(w, B):
 
     def ks(l):
         by_class("ntt1_inv_kernel", "false", range(l), B * 2 * P)                                   # the target to coefficient form, out of place
-        add("ntt2_kernel<0, 1, 6, 5, 0, 1, 0>", B * l * P + B * (l + 1) * l * P)
-        add("ntt2_kernel<0, 0, 9, 0, 1, 0, 1>", B * (l + 1) * l * P + 2 * (l + 1) * l * P + B * l * P + 2 * B * (l + 1) * P)  # + the NTT-form target (k == slot)
+        # CKKS: the l rows (digit k == output slot) are the NTT-form input itself: not expanded by the first pass, read from the target by the second
+        add("ntt2_kernel<0, 1, 6, 5, 0, 2, 0>", B * l * P + B * l * l * P)
+        add("ntt2_kernel<0, 0, 9, 0, 1, 0, 3>", B * l * l * P + 2 * (l + 1) * l * P + B * l * P + 2 * B * (l + 1) * P)
         add("gather_limb_kernel", 2 * B * 2 * P)
         add("ntt2_kernel<1, 0, 9, 0, 0, 0, 0>", 2 * B * 2 * P)                                       # the special limb of the accumulators (2 B rows: two-pass)
         add("ntt2_kernel<1, 1, 6, 5, 2, 0, 0>", 2 * B * 2 * P)

@@ -99,7 +99,8 @@ struct Ntt2Args {
     const u64 *md_share = nullptr; // BGV: [o][N] 128-bit integers al + k_t qk (ks_bgv_share_kernel, poly.hip)
     const u64 *md_base = nullptr;  // not null: accumulate onto (base[b], 0) instead of onto what ct holds
     u64 md_base_bstride = 0;
-    int md_base_polys = 1;         // 2: component 1 reads base[b] + dl * N too (relinearize out of place)
+    int md_base_polys = 1;
+    int skip_diag = 0;             // CKKS key switch: the (digit k == output slot) rows are not expanded -- the second pass takes them from mac_target         // 2: component 1 reads base[b] + dl * N too (relinearize out of place)
     unsigned md_dl = 0;
 };
 
@@ -520,13 +521,16 @@ __global__ __launch_bounds__(N2_THREADS, MAC == 2 ? N2_TENSOR_WAVES : MAC ? N2_M
     // leave [512*(t/64), 512*(t/64)+512), and the XOR swizzle only permutes address bits 0..4), so the LDS exchange
     // needs no workgroup barrier at all: the four waves run fully decoupled and overlap each other's HBM phases.
     constexpr bool WAVE_PRIVATE = !STRIDED && NS == 9;
+    // MAC = 1: key-switch inner product (BFV / BGV); MAC = 3: the same for CKKS, where the row of digit k == output slot is the NTT-form input
+    // itself and is neither staged nor transformed; REDUCE = 2: the digit-reducing first pass of that key switch, which does not expand those rows
+    constexpr bool KS = MAC == 1 || MAC == 3;
     // Which LDS exchanges form their addresses per row instead of once per workgroup (bit 0: round 0 write, 1: round 1 read, 2: round 1
     // write, 3: round 2 read, 4: round 2 write, 5: round 3 read).  Hoisted, the eight swizzled addresses of an exchange live across the
     // whole row loop; in the instances at the 128-register limit the compiler spilled them, and a spill reload waits with vmcnt(0) --
     // i.e. for the NEXT row's loads, which were issued before it: the HBM latency landed in the middle of every row (forward
     // contiguous pass 2038 -> 1525 us per 6720 rows of N = 2^16; three XORs per address are nothing next to that).
     constexpr int FRESH = (!STRIDED && !INV && NS == 9 && MAC == 0) ? (FINAL ? 15 : 1)            // plain forward contiguous pass (it spilled)
-                          : (STRIDED && !INV && NS == 7)                 ? 1                         // 7-stage strided forward pass (it spilled)
+                          : (STRIDED && !INV && NS == 7)                 ? (REDUCE == 2 ? 15 : 1)    // 7-stage strided forward pass (it spilled)
                           : (!STRIDED && NS == 10)                       ? 63                        // N = 2^17
                           : (FINAL >= 3 && NS >= 6)                      ? N2_FRESH_MD               // mod-down epilogues: room for their operands
                           : MAC == 2                                     ? N2_FRESH_TENSOR           // tensor pass: 168 VGPRs = 3 waves per SIMD
@@ -547,7 +551,7 @@ __global__ __launch_bounds__(N2_THREADS, MAC == 2 ? N2_TENSOR_WAVES : MAC ? N2_M
     constexpr int Q3 = NR > 3 ? (INV ? P::r[NR - 4] : R3) : 0;
     using Rd0 = Round<INV, STRIDED, NS, LOGC, 0, Q0>;
     using Rd1 = Round<INV, STRIDED, NS, LOGC, Q0, Q1 ? Q1 : 1>;
-    using Rd2 = Round<INV, STRIDED, NS, LOGC, Q0 + Q1, Q2 ? Q2 : 1, MAC == 0 || N2_MAC_HOIST>;
+    using Rd2 = Round<INV, STRIDED, NS, LOGC, Q0 + Q1, Q2 ? Q2 : 1, (MAC != 1 && MAC != 3) || N2_MAC_HOIST>;
     using Rd3 = Round<INV, STRIDED, NS, LOGC, Q0 + Q1 + Q2, Q3 ? Q3 : 1>;
 
     const unsigned tile = blockIdx.x & ((1u << a.tiles_per_row_log) - 1);
@@ -599,7 +603,7 @@ __global__ __launch_bounds__(N2_THREADS, MAC == 2 ? N2_TENSOR_WAVES : MAC ? N2_M
     static_assert(!MAC || (!INV && !STRIDED && NS == 9), "the inner product is fused into the forward contiguous pass");
     u64 tx[MAC == 2 ? 3 : 1][8]; // MAC = 2: the transforms of a0, a1, b0 while b1 is being computed
     Acc128 macc[2][2][4]; // [key component][group of four coefficients][coefficient]
-    if (MAC == 1) {
+    if (KS) {
 #pragma unroll
         for (int cpt = 0; cpt < 2; cpt++)
 #pragma unroll
@@ -608,22 +612,40 @@ __global__ __launch_bounds__(N2_THREADS, MAC == 2 ? N2_TENSOR_WAVES : MAC ? N2_M
                 for (int e = 0; e < 4; e++) macc[cpt][g][e] = Acc128{0, 0, 0, 0};
     }
     // read once: indexing the argument block with `slot` is a memory load, and inside the row loop it sat, with its wait, in front of the key loads
-    const unsigned key_limb = MAC == 1 ? (unsigned)__builtin_amdgcn_readfirstlane((int)a.mac_key_limb[slot]) : 0;
+    const unsigned key_limb = KS ? (unsigned)__builtin_amdgcn_readfirstlane((int)a.mac_key_limb[slot]) : 0;
     u64 *const wave_stage = lds[1] + 512 * (threadIdx.x >> 6);
     u64 x[8];
     unsigned ro = m_begin / inner, rk = m_begin - ro * inner; // (o, k) of the current row
+    // CKKS key switch: the row whose digit index equals the output slot is the NTT-form input itself (evaluator.cpp:2424-2427): the first
+    // pass does not expand it and the fused second pass neither stages nor transforms it (one row in L + 1 of both passes)
+    auto is_diag = [&](unsigned k) { return (MAC == 3 || REDUCE == 2) && k == slot; };
     {
         u64 *row0; const u64 *in0;
         row_ptrs(m_begin, ro, rk, row0, in0);
-        if constexpr (DMA) Rd0::stage_issue(in0, tile, wave_stage);
-        else Rd0::template g_read<REDUCE>(x, in0, tile, logn, m);
+        if (!is_diag(rk)) {
+            if constexpr (DMA) Rd0::stage_issue(in0, tile, wave_stage);
+            else Rd0::template g_read<REDUCE>(x, in0, tile, logn, m);
+        }
     }
     for (unsigned mm = m_begin; mm < m_end; mm++) {
         u64 *row; const u64 *in;
         row_ptrs(mm, ro, rk, row, in);
         const unsigned no = rk + 1 == inner ? ro + 1 : ro, nk = rk + 1 == inner ? 0 : rk + 1; // (o, k) of row mm + 1
+        const bool next_wanted = mm + 1 < m_end && !is_diag(nk);
+        if constexpr (REDUCE == 2) {
+            if (is_diag(rk)) { // nothing to expand; keep the software pipeline going
+                if (next_wanted) {
+                    u64 *nrow; const u64 *nin;
+                    row_ptrs(mm + 1, no, nk, nrow, nin);
+                    Rd0::template g_read<REDUCE>(x, nin, tile, logn, m);
+                }
+                ro = no;
+                rk = nk;
+                continue;
+            }
+        }
         if constexpr (DMA) TROY_WAIT_VMEM(); // this wave's staged row has landed (and its previous stores are out)
-        ulonglong2 kv[2][MAC == 1 ? 4 : 1]; // MAC: this row's key words, requested now -- BEFORE the next row's staging loads, so that the wait for them (vmcnt counts in
+        ulonglong2 kv[2][KS ? 4 : 1]; // MAC: this row's key words, requested now -- BEFORE the next row's staging loads, so that the wait for them (vmcnt counts in
         // order) does not include the staging loads' HBM latency -- and used after the three rounds
         auto load_keys = [&]() {
             const unsigned kk = rk;
@@ -632,14 +654,69 @@ __global__ __launch_bounds__(N2_THREADS, MAC == 2 ? N2_TENSOR_WAVES : MAC ? N2_M
             for (int cpt = 0; cpt < 2; cpt++) {
                 const ulonglong2 *kq = reinterpret_cast<const ulonglong2 *>(kp + ((u64)cpt * a.mac_K << logn));
 #pragma unroll
-                for (int e = 0; e < 4; e++) kv[cpt][MAC == 1 ? e : 0] = kq[e];
+                for (int e = 0; e < 4; e++) kv[cpt][KS ? e : 0] = kq[e];
             }
         };
-        if constexpr (MAC == 1) load_keys();
+        if constexpr (KS) load_keys();
+        if constexpr (MAC == 3) { // CKKS key switch: one code path for both kinds of rows, so that the accumulate code exists once
+            const bool diag = is_diag(rk);
+            if (!diag) {
+                Rd0::stage_read(x, wave_stage);
+                TROY_WAIT_LDS();
+            }
+            if (next_wanted) {
+                u64 *nrow; const u64 *nin;
+                row_ptrs(mm + 1, no, nk, nrow, nin);
+                Rd0::stage_issue(nin, tile, wave_stage);
+            }
+            if (!diag) {
+                u64 *buf = lds[0];
+                Rd0::compute(x, tw0, pd, lean);
+                Rd0::lds_write(x, buf, threadIdx.x);
+                round_sync();
+                Rd1::lds_read(x, buf, threadIdx.x);
+                Rd1::compute(x, tw1, pd, lean);
+                Rd1::lds_write(x, buf, threadIdx.x);
+                round_sync();
+                if constexpr (!Rd2::HOIST) Rd2::load_tw(tw2, pd, tile, logn, s_first);
+                Rd2::lds_read(x, buf, threadIdx.x);
+                Rd2::compute(x, tw2, pd, lean);
+                if (!a.mac_lazy && lean) {
+#pragma unroll
+                    for (int e = 0; e < 8; e++) x[e] = barrett64(x[e], m);
+                } else if (!a.mac_lazy) {
+                    const PrimeConst pc = make_prime_const(pd.p);
+#pragma unroll
+                    for (int h = 0; h < 2; h++) {
+                        u64 v[4] = {x[4 * h], x[4 * h + 1], x[4 * h + 2], x[4 * h + 3]};
+                        reduce4_from_8p(v, pc);
+#pragma unroll
+                        for (int i = 0; i < 4; i++) x[4 * h + i] = v[i];
+                    }
+                }
+            } else { // the operand is the NTT-form input limb: no staged row, no transform
+                const ulonglong2 *tp = reinterpret_cast<const ulonglong2 *>(a.mac_target + (u64)ro * a.mac_tstride + ((u64)rk << logn) + ((u64)tile << N2_LOGT) + 8 * threadIdx.x);
+#pragma unroll
+                for (int e = 0; e < 4; e++) { const ulonglong2 v = tp[e]; x[2 * e] = v.x; x[2 * e + 1] = v.y; }
+            }
+#pragma unroll
+            for (int cpt = 0; cpt < 2; cpt++) {
+#pragma unroll
+                for (int g = 0; g < 2; g++) {
+                    const ulonglong2 k01 = kv[cpt][2 * g], k23 = kv[cpt][2 * g + 1];
+                    const u64 kk[4] = {k01.x, k01.y, k23.x, k23.y};
+                    const u64 xx[4] = {x[4 * g], x[4 * g + 1], x[4 * g + 2], x[4 * g + 3]};
+                    mac128x4(macc[cpt][g], xx, kk);
+                }
+            }
+            ro = no;
+            rk = nk;
+            continue;
+        }
         if constexpr (DMA) {
             Rd0::stage_read(x, wave_stage);
             TROY_WAIT_LDS();             // ... and has been read before the next row overwrites it
-            if (mm + 1 < m_end) {
+            if (next_wanted) {
                 u64 *nrow; const u64 *nin;
                 row_ptrs(mm + 1, no, nk, nrow, nin);
                 Rd0::stage_issue(nin, tile, wave_stage);
@@ -679,7 +756,7 @@ __global__ __launch_bounds__(N2_THREADS, MAC == 2 ? N2_TENSOR_WAVES : MAC ? N2_M
                 Rd2::compute(x, tw2, pd, lean);
                 if constexpr (NR == 3 && MAC == 2) {
                     Rd2::tensor_epilogue(x, tx, mm, a.tensor_out, period, slot, tile, logn, m, WAVE_PRIVATE ? buf : nullptr, lean);
-                } else if constexpr (NR == 3 && MAC == 1) {
+                } else if constexpr (NR == 3 && KS) {
                     // the transform of digit k of (o, slot) stays in registers: acc_c += x (.) key[k][c][limb(slot)].  x is lazy, in
                     // [0, 8p); it is only normalised when dl * 8p * p could overflow the 128-bit accumulator (mac_lazy == 0)
                     if (!a.mac_lazy && lean) {
@@ -694,13 +771,6 @@ __global__ __launch_bounds__(N2_THREADS, MAC == 2 ? N2_TENSOR_WAVES : MAC ? N2_M
 #pragma unroll
                             for (int i = 0; i < 4; i++) x[4 * h + i] = v[i];
                         }
-                    }
-                    const unsigned o = ro, k = rk;
-                    const u64 pos = ((u64)tile << N2_LOGT) + 8 * threadIdx.x;
-                    if (a.mac_target && k == slot) {
-                        const ulonglong2 *tp = reinterpret_cast<const ulonglong2 *>(a.mac_target + (u64)o * a.mac_tstride + ((u64)k << logn) + pos);
-#pragma unroll
-                        for (int e = 0; e < 4; e++) { const ulonglong2 v = tp[e]; x[2 * e] = v.x; x[2 * e + 1] = v.y; }
                     }
 #pragma unroll
                     for (int cpt = 0; cpt < 2; cpt++) {
@@ -729,7 +799,7 @@ __global__ __launch_bounds__(N2_THREADS, MAC == 2 ? N2_TENSOR_WAVES : MAC ? N2_M
 #pragma unroll
             for (int e = 0; e < 8; e++) x[e] = xn[PF ? e : 0];
         } else if constexpr (!DMA) {
-            if (mm + 1 < m_end) {
+            if (next_wanted) {
                 u64 *nrow; const u64 *nin;
                 row_ptrs(mm + 1, no, nk, nrow, nin);
                 if constexpr (FINAL >= 3) Rd0::template g_read<REDUCE>(x, nin, tile, logn, m, n2_opaque(threadIdx.x)); // offsets formed here, not carried across the epilogue
@@ -739,7 +809,7 @@ __global__ __launch_bounds__(N2_THREADS, MAC == 2 ? N2_TENSOR_WAVES : MAC ? N2_M
         ro = no;
         rk = nk;
     }
-    if constexpr (MAC == 1) { // one reduction per output coefficient; acc[o][c][slot][N]
+    if constexpr (KS) { // one reduction per output coefficient; acc[o][c][slot][N]
         const unsigned o = m_begin / inner;
         const u64 pos = ((u64)tile << N2_LOGT) + 8 * threadIdx.x;
 #pragma unroll
@@ -774,7 +844,7 @@ template <int INV, int NS> static void launch_contig(const Ntt2Args &a, unsigned
     if (final_pass) launch_one<INV, 0, NS, 0, INV ? 2 : 1, 0>(a, blocks, s);
     else launch_one<INV, 0, NS, 0, 0, 0>(a, blocks, s);
 }
-template <int INV, int NS> static void launch_strided(const Ntt2Args &a, unsigned blocks, bool final_pass, bool reduce, hipStream_t s, int md_kind = -1) {
+template <int INV, int NS> static void launch_strided(const Ntt2Args &a, unsigned blocks, bool final_pass, bool reduce, hipStream_t s, int md_kind = -1, bool skip_diag = false) {
     constexpr int LOGC = N2_LOGT - NS;
     if (INV) { // the strided pass is the last inverse pass
         if (md_kind == 0) launch_one<1, 1, NS, LOGC, 3, 0>(a, blocks, s);
@@ -782,7 +852,8 @@ template <int INV, int NS> static void launch_strided(const Ntt2Args &a, unsigne
         else launch_one<1, 1, NS, LOGC, 2, 0>(a, blocks, s);
     } else {
         (void)final_pass;
-        if (reduce) launch_one<0, 1, NS, LOGC, 0, 1>(a, blocks, s);
+        if (reduce && skip_diag) launch_one<0, 1, NS, LOGC, 0, 2>(a, blocks, s);
+        else if (reduce) launch_one<0, 1, NS, LOGC, 0, 1>(a, blocks, s);
         else launch_one<0, 1, NS, LOGC, 0, 0>(a, blocks, s);
     }
 }
@@ -882,18 +953,25 @@ void launch_ntt2_ks_mac(u64 *D, const u64 *src, u64 src_ostride, const PrimeDesc
     Ntt2Args first = a;
     first.src = src; first.src_ostride = src_ostride; first.src_reduce = 1; first.src_bound = src_bound;
     first.slot_fastest = 1;
+    const bool skip_diag = ckks_target != nullptr; // CKKS: rows (digit k == output slot) are the NTT-form input, not expanded
+    first.skip_diag = skip_diag;
     switch (k1) {
-    case 3: launch_strided<0, 3>(first, blocks, false, true, stream); break;
-    case 4: launch_strided<0, 4>(first, blocks, false, true, stream); break;
-    case 5: launch_strided<0, 5>(first, blocks, false, true, stream); break;
-    case 6: launch_strided<0, 6>(first, blocks, false, true, stream); break;
-    default: launch_strided<0, 7>(first, blocks, false, true, stream); break;
+    case 3: launch_strided<0, 3>(first, blocks, false, true, stream, -1, skip_diag); break;
+    case 4: launch_strided<0, 4>(first, blocks, false, true, stream, -1, skip_diag); break;
+    case 5: launch_strided<0, 5>(first, blocks, false, true, stream, -1, skip_diag); break;
+    case 6: launch_strided<0, 6>(first, blocks, false, true, stream, -1, skip_diag); break;
+    default: launch_strided<0, 7>(first, blocks, false, true, stream, -1, skip_diag); break;
     }
     a.mac_key = key; a.mac_acc = acc; a.mac_target = ckks_target; a.mac_tstride = t_bstride; a.mac_K = K;
     a.mac_lazy = lazy;
     std::memcpy(a.mac_key_limb, key_limb, map.period);
-    N2_KTAG("ntt2_kernel<0, 0, 9, 0, 1, 0, 1>");
-    TROY_LAUNCH(HIP_KERNEL_NAME(ntt2_kernel<0, 0, 9, 0, 1, 0, 1>), dim3(blocks), dim3(N2_THREADS), 0, stream, a);
+    if (skip_diag) {
+        N2_KTAG("ntt2_kernel<0, 0, 9, 0, 1, 0, 3>");
+        TROY_LAUNCH(HIP_KERNEL_NAME(ntt2_kernel<0, 0, 9, 0, 1, 0, 3>), dim3(blocks), dim3(N2_THREADS), 0, stream, a);
+    } else {
+        N2_KTAG("ntt2_kernel<0, 0, 9, 0, 1, 0, 1>");
+        TROY_LAUNCH(HIP_KERNEL_NAME(ntt2_kernel<0, 0, 9, 0, 1, 0, 1>), dim3(blocks), dim3(N2_THREADS), 0, stream, a);
+    }
     launch_check("ntt2_kernel(ks_mac)");
 }
 
