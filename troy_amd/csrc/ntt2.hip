@@ -616,6 +616,7 @@ __global__ __launch_bounds__(N2_THREADS, MAC == 2 ? N2_TENSOR_WAVES : MAC ? N2_M
     u64 *const wave_stage = lds[1] + 512 * (threadIdx.x >> 6);
     u64 x[8];
     unsigned ro = m_begin / inner, rk = m_begin - ro * inner; // (o, k) of the current row
+    unsigned parity = 0;
     // CKKS key switch: the row whose digit index equals the output slot is the NTT-form input itself (evaluator.cpp:2424-2427): the first
     // pass does not expand it and the fused second pass neither stages nor transforms it (one row in L + 1 of both passes)
     auto is_diag = [&](unsigned k) { return (MAC == 3 || REDUCE == 2) && k == slot; };
@@ -722,7 +723,7 @@ __global__ __launch_bounds__(N2_THREADS, MAC == 2 ? N2_TENSOR_WAVES : MAC ? N2_M
                 Rd0::stage_issue(nin, tile, wave_stage);
             }
         }
-        u64 *buf = DMA ? lds[0] : lds[mm & 1];
+        u64 *buf = DMA ? lds[0] : lds[parity]; // the exchange buffers alternate over the rows that are actually processed (skipped rows have no barriers)
         if (REDUCE && need_reduce) { // wave-uniform: the butterflies take any input below 8p (ct_bfly4), most prime sets never need this
 #pragma unroll
             for (int e = 0; e < 8; e++) x[e] = barrett64(x[e], m);
@@ -808,6 +809,7 @@ __global__ __launch_bounds__(N2_THREADS, MAC == 2 ? N2_TENSOR_WAVES : MAC ? N2_M
         }
         ro = no;
         rk = nk;
+        parity ^= 1u;
     }
     if constexpr (KS) { // one reduction per output coefficient; acc[o][c][slot][N]
         const unsigned o = m_begin / inner;
