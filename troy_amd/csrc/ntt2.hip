@@ -633,18 +633,7 @@ __global__ __launch_bounds__(N2_THREADS, MAC == 2 ? N2_TENSOR_WAVES : MAC ? N2_M
         row_ptrs(mm, ro, rk, row, in);
         const unsigned no = rk + 1 == inner ? ro + 1 : ro, nk = rk + 1 == inner ? 0 : rk + 1; // (o, k) of row mm + 1
         const bool next_wanted = mm + 1 < m_end && !is_diag(nk);
-        if constexpr (REDUCE == 2) {
-            if (is_diag(rk)) { // nothing to expand; keep the software pipeline going
-                if (next_wanted) {
-                    u64 *nrow; const u64 *nin;
-                    row_ptrs(mm + 1, no, nk, nrow, nin);
-                    Rd0::template g_read<REDUCE>(x, nin, tile, logn, m);
-                }
-                ro = no;
-                rk = nk;
-                continue;
-            }
-        }
+        const bool skip_row = REDUCE == 2 && is_diag(rk); // nothing to expand: the body below is skipped as a whole, the software pipeline goes on
         if constexpr (DMA) TROY_WAIT_VMEM(); // this wave's staged row has landed (and its previous stores are out)
         ulonglong2 kv[2][KS ? 4 : 1]; // MAC: this row's key words, requested now -- BEFORE the next row's staging loads, so that the wait for them (vmcnt counts in
         // order) does not include the staging loads' HBM latency -- and used after the three rounds
@@ -723,6 +712,7 @@ __global__ __launch_bounds__(N2_THREADS, MAC == 2 ? N2_TENSOR_WAVES : MAC ? N2_M
                 Rd0::stage_issue(nin, tile, wave_stage);
             }
         }
+        if (!skip_row) {
         u64 *buf = DMA ? lds[0] : lds[parity]; // the exchange buffers alternate over the rows that are actually processed (skipped rows have no barriers)
         if (REDUCE && need_reduce) { // wave-uniform: the butterflies take any input below 8p (ct_bfly4), most prime sets never need this
 #pragma unroll
@@ -796,6 +786,7 @@ __global__ __launch_bounds__(N2_THREADS, MAC == 2 ? N2_TENSOR_WAVES : MAC ? N2_M
                 }
             }
         }
+        } // !skip_row
         if constexpr (PF) {
 #pragma unroll
             for (int e = 0; e < 8; e++) x[e] = xn[PF ? e : 0];
@@ -809,7 +800,7 @@ __global__ __launch_bounds__(N2_THREADS, MAC == 2 ? N2_TENSOR_WAVES : MAC ? N2_M
         }
         ro = no;
         rk = nk;
-        parity ^= 1u;
+        if (!skip_row) parity ^= 1u;
     }
     if constexpr (KS) { // one reduction per output coefficient; acc[o][c][slot][N]
         const unsigned o = m_begin / inner;
