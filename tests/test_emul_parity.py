@@ -117,6 +117,17 @@ def test_emulated_relinearize_out_of_place(name, emul_api):
     cases.check_relinearize_out_of_place(name, batch=2)
 
 
+@pytest.mark.parametrize("N,bits", [(8192, [60, 40, 40, 60]), (16384, [50, 45, 55])])
+def test_emulated_ckks_two_round_strided_plans(N, bits, emul_api, oracle_lib):
+    """CKKS key switch at the sizes whose strided pass has two rounds (N = 8192, 16384): the rows (digit k == output prime) are skipped by the
+    first pass, which must not advance its LDS buffer alternation there -- on the emulator a violation is deterministic (on the GPU it is a race
+    that the suite did not hit).  Light scenario against the oracle, limb for limb."""
+    cfg = dict(scheme=cases.CKKS, N=N, bits=bits, tbits=0)
+    got = cases.scenario(cases.GpuBackend(cfg, batch=1), cfg, light=True)
+    exp = cases.scenario(cases.oracle_backend(cfg), cfg, light=True)
+    assert not cases.compare(got, exp)
+
+
 def test_emulated_size_limits(emul_api):
     cases.check_size_limits("bfv_n64_k3")
     cases.check_size_limits("ckks_n128_k6")
