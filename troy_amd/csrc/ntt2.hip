@@ -530,7 +530,7 @@ __global__ __launch_bounds__(N2_THREADS, MAC == 2 ? N2_TENSOR_WAVES : MAC ? N2_M
     // i.e. for the NEXT row's loads, which were issued before it: the HBM latency landed in the middle of every row (forward
     // contiguous pass 2038 -> 1525 us per 6720 rows of N = 2^16; three XORs per address are nothing next to that).
     constexpr int FRESH = (!STRIDED && !INV && NS == 9 && MAC == 0) ? (FINAL ? 15 : 1)            // plain forward contiguous pass (it spilled)
-                          : (STRIDED && !INV && NS == 7)                 ? (REDUCE == 2 ? 15 : 1)    // 7-stage strided forward pass (it spilled)
+                          : (STRIDED && !INV && NS == 7)                 ? 1                         // 7-stage strided forward pass (it spilled; more than the first exchange costs 2-6 % there)
                           : (!STRIDED && NS == 10)                       ? 63                        // N = 2^17
                           : (FINAL >= 3 && NS >= 6)                      ? N2_FRESH_MD               // mod-down epilogues: room for their operands
                           : MAC == 2                                     ? N2_FRESH_TENSOR           // tensor pass: 168 VGPRs = 3 waves per SIMD
