@@ -80,6 +80,13 @@ int troyhip_mem_info(size_t *free_bytes, size_t *total_bytes);
 int troyhip_test_modarith(int op, const uint64_t *a, const uint64_t *b, const uint64_t *c, uint64_t p, uint64_t aux, uint64_t *out, uint64_t n, void *stream);
 /* per-kernel timing: while enabled every kernel launch is bracketed by HIP events on its own stream; the report is JSON text
  * [{"name", "calls", "total_us"}, ...] in first-launch order and clears the log (bench.py: roofline.per_kernel) */
+/* path counters ("ks_fp_launches", "ks_int_launches", "ntt1_fp_launches", "ntt1_int_launches"): which kernel class the launchers chose so far in
+ * this process -- the parity tests read them so that a test of the FP64 instances cannot pass on the integer kernels unnoticed.  No
+ * reference counterpart (test / diagnostics support, like troyhip_ktime_*). */
+int troyhip_stat(const char *name, uint64_t *value);
+/* first 16 hex digits of the SHA-256 over the library's sources (troy_amd/csrc/Makefile): ties a measurement file (profiles/ *_traffic.json) to the
+ * build it was taken on; bench.py reports `traffic: null` when the two differ */
+const char *troyhip_build_id(void);
 int troyhip_ktime_enable(int on);
 int troyhip_ktime_report(char *out, size_t capacity);
 int troyhip_timer_create(void **timer);

@@ -53,6 +53,7 @@ public:
     Modulus(uint64_t v = 0) : value_(v) {}
     uint64_t value() const { return value_; }
     bool isZero() const { return value_ == 0; }
+    int bitCount() const { return value_ ? 64 - __builtin_clzll(value_) : 0; } // src/modulus.h: bit_count_
 private:
     uint64_t value_;
 };
@@ -766,6 +767,7 @@ public:
         if (k.all().size() != 1) throw std::invalid_argument("kswitch_keys.data().size() != 1");
         check(troyhip_apply_key_switching(h(), a.raw(), k.all().begin()->second->get(), 1, nullptr));
     }
+    void applyKeySwitching(const Ciphertext &a, const KSwitchKeys &k, Ciphertext &d) const { d = a; applyKeySwitchingInplace(d, k); } // src/evaluator_cuda.cuh:104-110
     void negacyclicShiftInplace(Ciphertext &a, size_t shift) const { check(troyhip_negacyclic_shift(h(), a.raw(), shift, 1, nullptr)); }
     // multiplyMany / exponentiate (src/evaluator.cpp:1502-1601): pairwise products appended to the work list, each relinearized
     void multiplyMany(const std::vector<Ciphertext> &v, const RelinKeys &rk, Ciphertext &d) const {
@@ -784,6 +786,7 @@ public:
         std::vector<Ciphertext> v((size_t)exponent, a);
         multiplyMany(v, rk, a);
     }
+    void exponentiate(const Ciphertext &a, uint64_t exponent, const RelinKeys &rk, Ciphertext &d) const { d = a; exponentiateInplace(d, exponent, rk); } // :206-211
     void modSwitchToNextInplace(Ciphertext &a) const { next(a, troyhip_mod_switch_to_next); }
     void modSwitchToNext(const Ciphertext &a, Ciphertext &d) const { d = a; modSwitchToNextInplace(d); }
     void modSwitchToInplace(Ciphertext &a, const ParmsID &parms_id) const {
@@ -791,6 +794,29 @@ public:
         if (parms_id.limbs > a.parmsID().limbs) throw std::invalid_argument("cannot switch to higher level modulus");
         while (a.parmsID() != parms_id) modSwitchToNextInplace(a);
     }
+    void modSwitchTo(const Ciphertext &a, const ParmsID &parms_id, Ciphertext &d) const { d = a; modSwitchToInplace(d, parms_id); } // :162-167
+    // Plaintext forms (src/evaluator_cuda.cuh:140-151,170-177; modSwitchDropToNext(PlaintextCuda&) src/evaluator_cuda.cu:891-925): an NTT-form
+    // plaintext [limbs][N] loses its last limb; same checks, same messages
+    void modSwitchToNextInplace(Plaintext &plain) const {
+        if (!plain.isNttForm()) throw std::invalid_argument("plain is not in NTT form");
+        auto cd = c_.getContextData(plain.parmsID());
+        if (!cd) throw std::invalid_argument("plain is not valid for encryption parameters");
+        auto nx = cd->nextContextData();
+        if (!nx) throw std::invalid_argument("end of modulus switching chain reached");
+        if (!scaleWithinBounds(plain.scale(), *nx)) throw std::invalid_argument("scale out of bounds");
+        plain.resize(nx->parms().coeffModulus().size() * c_.polyModulusDegree());
+        plain.setNttForm(nx->parmsID());
+    }
+    void modSwitchToNext(const Plaintext &plain, Plaintext &d) const { d = plain; modSwitchToNextInplace(d); }
+    void modSwitchToInplace(Plaintext &plain, const ParmsID &parms_id) const { // src/evaluator_cuda.cu:982-1008
+        auto cd = c_.getContextData(plain.parmsID()), target = c_.getContextData(parms_id);
+        if (!cd) throw std::invalid_argument("plain is not valid for encryption parameters");
+        if (!target) throw std::invalid_argument("parms_id is not valid for encryption parameters");
+        if (!plain.isNttForm()) throw std::invalid_argument("plain is not in NTT form");
+        if (cd->chainIndex() < target->chainIndex()) throw std::invalid_argument("cannot switch to higher level modulus");
+        while (plain.parmsID() != parms_id) modSwitchToNextInplace(plain);
+    }
+    void modSwitchTo(const Plaintext &plain, const ParmsID &parms_id, Plaintext &d) const { d = plain; modSwitchToInplace(d, parms_id); }
     void rescaleToNextInplace(Ciphertext &a) const { next(a, troyhip_rescale_to_next); }
     void rescaleToNext(const Ciphertext &a, Ciphertext &d) const { d = a; rescaleToNextInplace(d); }
     void rescaleToInplace(Ciphertext &a, const ParmsID &parms_id) const {
@@ -798,6 +824,7 @@ public:
         if (parms_id.limbs > a.parmsID().limbs) throw std::invalid_argument("cannot switch to higher level modulus");
         while (a.parmsID() != parms_id) rescaleToNextInplace(a);
     }
+    void rescaleTo(const Ciphertext &a, const ParmsID &parms_id, Ciphertext &d) const { d = a; rescaleToInplace(d, parms_id); } // :193-198
     void applyGaloisInplace(Ciphertext &a, uint32_t galois_elt, const GaloisKeys &gk) const {
         if (!gk.hasKey(galois_elt)) throw std::invalid_argument("Galois key not present");
         check(troyhip_apply_galois(h(), a.raw(), galois_elt, gk.device(GaloisKeys::getIndex(galois_elt)), 1, nullptr));
@@ -806,8 +833,16 @@ public:
     void rotateColumnsInplace(Ciphertext &a, const GaloisKeys &gk) const { need(SchemeType::ckks, false); rotate(a, 0, 1, gk); }
     void rotateVectorInplace(Ciphertext &a, int steps, const GaloisKeys &gk) const { need(SchemeType::ckks, true); rotate(a, steps, 0, gk); }
     void complexConjugateInplace(Ciphertext &a, const GaloisKeys &gk) const { need(SchemeType::ckks, true); rotate(a, 0, 1, gk); }
+    // the out-of-place forms of src/evaluator_cuda.cuh:273-349: destination = encrypted; ...Inplace(destination)
+    void applyGalois(const Ciphertext &a, uint32_t galois_elt, const GaloisKeys &gk, Ciphertext &d) const { d = a; applyGaloisInplace(d, galois_elt, gk); }
+    void rotateRows(const Ciphertext &a, int steps, const GaloisKeys &gk, Ciphertext &d) const { d = a; rotateRowsInplace(d, steps, gk); }
+    void rotateColumns(const Ciphertext &a, const GaloisKeys &gk, Ciphertext &d) const { d = a; rotateColumnsInplace(d, gk); }
+    void rotateVector(const Ciphertext &a, int steps, const GaloisKeys &gk, Ciphertext &d) const { d = a; rotateVectorInplace(d, steps, gk); }
+    void complexConjugate(const Ciphertext &a, const GaloisKeys &gk, Ciphertext &d) const { d = a; complexConjugateInplace(d, gk); }
     void transformToNttInplace(Ciphertext &a) const { check(troyhip_transform_to_ntt(h(), a.raw(), 1, nullptr)); }
     void transformFromNttInplace(Ciphertext &a) const { check(troyhip_transform_from_ntt(h(), a.raw(), 1, nullptr)); }
+    void transformToNtt(const Ciphertext &a, Ciphertext &d) const { d = a; transformToNttInplace(d); }     // :246-250
+    void transformFromNtt(const Ciphertext &a, Ciphertext &d) const { d = a; transformFromNttInplace(d); } // :254-258
     // multiplyPlainInplace (evaluator_cuda.cu:1722-1755): NTT-form pair -> multiplyPlainNtt, coefficient-form pair -> multiplyPlainNormal
     void multiplyPlainInplace(Ciphertext &a, const Plaintext &plain) const {
         if (a.isNttForm() != plain.isNttForm() && c_.parms().scheme() != SchemeType::ckks) throw std::invalid_argument("NTT form mismatch");
@@ -886,6 +921,7 @@ public:
         check(troyhip_copy_d2h(plain.data(), out.get(), limbs * n * 8, nullptr));
         plain.setNttForm(parms_id);
     }
+    void transformToNtt(const Plaintext &plain, const ParmsID &parms_id, Plaintext &d) const { d = plain; transformToNttInplace(d, parms_id); } // :237-242
 
     void negacyclicShift(const Ciphertext &a, size_t shift, Ciphertext &d) const { d = a; negacyclicShiftInplace(d, shift); }
     // divideByPolyModulusDegreeInplace (src/evaluator_cuda.cu:2262-2276): every limb times N^-1 (times `mul`)
@@ -976,6 +1012,11 @@ public:
 
 private:
     troyhip_context *h() const { return c_.handle(); }
+    // isScaleWithinBounds (src/evaluator_cuda.cu:32-51)
+    static bool scaleWithinBounds(double scale, const ContextData &cd) {
+        const int bound = cd.parms().scheme() == SchemeType::ckks ? cd.totalCoeffModulusBitCount() : cd.parms().plainModulus().bitCount();
+        return !(scale <= 0 || (int)std::log2(scale) >= bound);
+    }
     void plain_addsub(Ciphertext &a, const Plaintext &plain, int sub) const {
         check(troyhip_add_plain(h(), a.raw(), plain.device(), plain.coeffCount(), 0, plain.scale(), sub, 1, nullptr));
     }

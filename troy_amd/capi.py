@@ -62,7 +62,7 @@ SYMBOLS = [
     "troyhip_negate", "troyhip_add", "troyhip_sub", "troyhip_multiply", "troyhip_relinearize", "troyhip_relinearize_keys", "troyhip_relinearize_to", "troyhip_switch_key",
     "troyhip_mod_switch_to_next", "troyhip_rescale_to_next", "troyhip_apply_galois", "troyhip_rotate",
     "troyhip_transform_to_ntt", "troyhip_transform_from_ntt", "troyhip_multiply_plain_ntt", "troyhip_add_plain", "troyhip_multiply_plain",
-    "troyhip_plain_to_ntt", "troyhip_decrypt", "troyhip_apply_key_switching", "troyhip_negacyclic_shift", "troyhip_divide_by_poly_modulus_degree",
+    "troyhip_stat", "troyhip_build_id", "troyhip_plain_to_ntt", "troyhip_decrypt", "troyhip_apply_key_switching", "troyhip_negacyclic_shift", "troyhip_divide_by_poly_modulus_degree",
 ]
 
 _lib = None
@@ -84,6 +84,7 @@ def load(path=None):
     lib = C.CDLL(p)
     lib.troyhip_last_error.restype = C.c_char_p
     lib.troyhip_build_info.restype = C.c_char_p
+    lib.troyhip_build_id.restype = C.c_char_p
     if path is None:
         info = lib.troyhip_build_info().decode()
         if info != "gfx950":
@@ -96,3 +97,16 @@ def check(lib, rc):
     if rc != OK:
         msg = lib.troyhip_last_error().decode()
         raise _EXC.get(rc, TroyHipError)(rc, msg)
+
+
+def stat(name, lib=None):
+    """path counter of the library (troyhip_stat): 'ks_fp_launches', 'ks_int_launches', 'ntt1_fp_launches', 'ntt1_int_launches'"""
+    lib = lib or load()
+    v = C.c_uint64(0)
+    check(lib, lib.troyhip_stat(name.encode(), C.byref(v)))
+    return int(v.value)
+
+
+def build_id(lib=None):
+    """hash of the sources the loaded library was built from (troyhip_build_id) -- profiles/*_traffic.json are stamped with it"""
+    return (lib or load()).troyhip_build_id().decode()

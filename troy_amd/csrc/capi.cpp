@@ -4,6 +4,7 @@
 #include "../../include/troyhip.h"
 #include "evaluator.h"
 #include "kernels.h"
+#include "build_id.h"
 #include "hostcrypto.h"
 #include <algorithm>
 #include <atomic>
@@ -65,26 +66,29 @@ struct Timer { hipEvent_t a, b; };
 
 #ifndef TROYHIP_CPU_EMUL
 namespace troyhip { namespace ktime {
-bool enabled = false;
+std::atomic<bool> enabled{false};
 thread_local const char *tag = nullptr;
 namespace {
 struct Rec { std::string name; hipEvent_t a, b; };
 std::vector<Rec> recs;
 std::mutex kmu;
+thread_local hipEvent_t open_stop = nullptr; // the stop event of the record THIS thread opened (two host threads launching concurrently
+                                             // would otherwise attach their stop to each other's record)
 }
 void begin(const char *name, hipStream_t s) {
-    std::lock_guard<std::mutex> g(kmu);
     Rec r;
     r.name = tag ? tag : name;
     tag = nullptr;
     HIP_CHECK(hipEventCreate(&r.a));
     HIP_CHECK(hipEventCreate(&r.b));
     HIP_CHECK(hipEventRecord(r.a, s));
+    open_stop = r.b;
+    std::lock_guard<std::mutex> g(kmu);
     recs.push_back(r);
 }
 void end(hipStream_t s) {
-    std::lock_guard<std::mutex> g(kmu);
-    if (!recs.empty()) HIP_CHECK(hipEventRecord(recs.back().b, s));
+    if (open_stop) HIP_CHECK(hipEventRecord(open_stop, s));
+    open_stop = nullptr;
 }
 static std::string report() {
     std::lock_guard<std::mutex> g(kmu);
@@ -131,6 +135,7 @@ const char *troyhip_build_info(void) {
     return "gfx950";
 #endif
 }
+const char *troyhip_build_id(void) { return TROYHIP_BUILD_ID; }
 // KernelProvider::malloc / free behind the reference's MemoryPoolCuda policy (src/utils/memorypool_cuda.cuh:40-58): a freed
 // block is kept and handed out again to a request of size <= block <= 2 * size; everything cached is released when the device
 // runs short.  hipMalloc / hipFree synchronise the device, a pooled pair does not.  troyhip_free carries no stream, so reuse is
@@ -260,6 +265,14 @@ int troyhip_test_modarith(int op, const uint64_t *a, const uint64_t *b, const ui
     });
 }
 /* per-kernel timing (rt.h): enable, run the launches to be measured, then fetch the report (JSON text, launch order; resets) */
+int troyhip_stat(const char *name, uint64_t *value) {
+    return guard([&] {
+        if (!name || !value) throw Error(ST_INVALID_ARGUMENT, "null");
+        for (int i = 0; i < stats::COUNT; i++)
+            if (std::strcmp(name, stats::name(i)) == 0) { *value = stats::counter(i); return; }
+        throw Error(ST_INVALID_ARGUMENT, std::string("no such counter: ") + name);
+    }, false);
+}
 int troyhip_ktime_enable(int on) {
 #ifndef TROYHIP_CPU_EMUL
     return guard([&] { ktime::enabled = on != 0; });

@@ -1,5 +1,6 @@
 // context.cpp -- see context.h.
 #include "context.h"
+#include "fpmod.h"
 #include "kernels.h"
 #include <algorithm>
 #include <cstdlib>
@@ -225,6 +226,12 @@ static bool lean_allowed() {
     static const bool on = [] { const char *e = std::getenv("TROYHIP_BFLY"); return !(e && std::strcmp(e, "guarded") == 0); }();
     return on;
 }
+// TROYHIP_FP64=off: no prime takes the FP64 instances (tests / A-B runs against the integer kernels)
+static bool fp_allowed() {
+    static const bool on = [] { const char *e = std::getenv("TROYHIP_FP64"); return !(e && std::strcmp(e, "off") == 0); }();
+    return on;
+}
+static bool fp_prime(u64 p) { return fp_allowed() && p < (u64(1) << TROY_FP_MAX_BITS); }
 LimbMap Context::ct_map(int limbs) const {
     LimbMap m;
     std::memset(&m, 0, sizeof(m));
@@ -232,6 +239,7 @@ LimbMap Context::ct_map(int limbs) const {
     m.period = (uint32_t)limbs;
     m.inner = 1;
     for (int i = 0; lean_allowed() && i < limbs && i < 64; i++) m.lean |= (u64)(primes[i] >= (u64(1) << 33) && primes[i] < (u64(1) << 58)) << i;
+    for (int i = 0; i < limbs && i < 64; i++) m.fp |= (u64)fp_prime(primes[i]) << i;
     return m;
 }
 LimbMap Context::ids_map(const std::vector<uint8_t> &ids, uint32_t inner) const {
@@ -242,6 +250,7 @@ LimbMap Context::ids_map(const std::vector<uint8_t> &ids, uint32_t inner) const 
     m.period = (uint32_t)ids.size();
     m.inner = inner;
     for (size_t i = 0; lean_allowed() && i < ids.size(); i++) m.lean |= (u64)(primes[ids[i]] >= (u64(1) << 33) && primes[ids[i]] < (u64(1) << 58)) << i;
+    for (size_t i = 0; i < ids.size(); i++) m.fp |= (u64)fp_prime(primes[ids[i]]) << i;
     return m;
 }
 LimbMap Context::single_map(int id) const { return ids_map({(uint8_t)id}); }
@@ -268,6 +277,16 @@ void Context::upload_tables() {
         d.root = upload(tb.root, dev_allocs_);
         d.iroot = upload(tb.iroot, dev_allocs_);
         d.aux = Shoup{0, 0};
+        d.root_fp = d.iroot_fp = nullptr;
+        if (fp_prime(tb.p)) { // the same twiddles as pairs of doubles (w, w / p): both exact / correctly rounded on the host (fpmod.h)
+            auto to_fp = [&](const std::vector<Shoup> &v) {
+                std::vector<Shoup> f(v.size());
+                for (size_t j = 0; j < v.size(); j++) f[j] = Shoup{fp_bits((double)v[j].op), fp_bits((double)v[j].op / (double)tb.p)};
+                return f;
+            };
+            d.root_fp = upload(to_fp(tb.root), dev_allocs_);
+            d.iroot_fp = upload(to_fp(tb.iroot), dev_allocs_);
+        }
     }
     d_desc = upload(h_desc, dev_allocs_);
     if (scheme == SCHEME_CKKS) { // per-slot inverses of the prime a divide-and-round drops, for the fused correction transform (ntt1.hip)

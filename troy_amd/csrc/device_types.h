@@ -13,6 +13,9 @@ struct PrimeDesc {
     const Shoup *root;       // [N] forward twiddles, bit-reversed order (src/utils/ntt.cpp:38-43)
     const Shoup *iroot;      // [N] inverse twiddles, scrambled order   (src/utils/ntt.cpp:49-54)
     Shoup aux;               // free for derived tables (Context::d_desc_md: q_special^-1 mod p); appended last -- behz.hip indexes the words above
+    // primes below 2^50 only (else nullptr): the same tables as pairs of doubles (w, w / p) for the FP64 butterflies (fpmod.h), as bit patterns
+    const Shoup *root_fp;
+    const Shoup *iroot_fp;
 };
 __host__ __device__ inline Mod mod_of(const PrimeDesc &d) { return Mod{d.p, d.cr0, d.cr1}; }
 
@@ -21,6 +24,7 @@ struct LimbMap {
     uint8_t id[64];
     uint32_t period, inner;
     uint64_t lean; // bit i: the prime of slot i lies in [2^33, 2^58) -- guard-free butterflies apply (bfly.h); host-side dispatch only
+    uint64_t fp;   // bit i: the prime of slot i lies below 2^50 and has FP64 tables -- the FP64 instances apply (fpmod.h); host-side dispatch only
 };
 
 #define TROY_BUF_OOB 0x80000000u // an offset no buffer range reaches (ranges are < 2^31 bytes)

@@ -22,6 +22,7 @@
 //     stores the BEHZ ciphertext tensor.
 #include "kernels.h"
 #include "bfly.h"
+#include "fpmod.h"
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -58,6 +59,12 @@ namespace troyhip {
 #endif
 #ifndef N2_FRESH_MD
 #define N2_FRESH_MD 15
+#endif
+#ifndef N2_FRESH_FP_MAC
+#define N2_FRESH_FP_MAC 15
+#endif
+#ifndef N2_FP_MAC_WAVES
+#define N2_FP_MAC_WAVES 3 // waves per SIMD of the FP64 key-switch fused kernel (16 doubles of accumulators per thread)
 #endif
 #define N2_THREADS 256
 #define N2_LOGT 11
@@ -102,6 +109,14 @@ struct Ntt2Args {
     int md_base_polys = 1;
     int skip_diag = 0;             // CKKS key switch: the (digit k == output slot) rows are not expanded -- the second pass takes them from mac_target         // 2: component 1 reads base[b] + dl * N too (relinearize out of place)
     unsigned md_dl = 0;
+    // the prime slots this launch covers: workgroup group index -> slot = sel[index] (a launch per prime class: the FP64 instances take the
+    // primes below 2^50, the integer instances the rest; partial inverse launches take a range)
+    uint8_t sel[64];
+    unsigned nsel = 0;
+    // FP64 instances (ntt2_fp_kernel, fpmod.h)
+    u64 fp_src_wide = 0;       // bit k: the residues of source digit k do not fit a double exactly (prime >= 2^50): integer Barrett step before the conversion
+    unsigned fp_red_mask = 0;  // bit r: the values are reduced before round r of this pass (fp_plan)
+    unsigned fp_acc_every = 0; // the key-switch accumulators are reduced every this many rows (0: never)
 };
 
 __device__ __forceinline__ unsigned n2_opaque(unsigned v) {
@@ -207,6 +222,28 @@ template <int INV, int STRIDED, int NS, int LOGC, int LS, int R, bool HOISTP = t
     // every stage = exactly four independent butterflies per thread -> one ct_bfly4 / gs_bfly4 call
     // lean (forward only, wave-uniform): the prime is below 2^58 -- guard-free butterflies, every stage adds at most 3p to the
     // value bound (8p at the input of the first pass + 3p * 17 stages at most = 59p < 2^64); the caller reduces with barrett64
+    // FP64 form (fpmod.h): x holds the bit patterns of doubles, tw those of (w, w / p); forward stages only
+    __device__ static __forceinline__ void compute_fp(u64 (&x)[8], const Shoup (&tw)[G][NTW], const FpPrime &fc) {
+        static_assert(!INV, "the FP64 butterflies are built for the forward passes");
+#pragma unroll
+        for (int st = 0; st < R; st++) {
+#pragma unroll
+            for (int u = 0; u < G; u++) {
+                const int half = (1 << R) >> (st + 1);
+#pragma unroll
+                for (int blk = 0; blk < (1 << st); blk++)
+#pragma unroll
+                    for (int k = 0; k < half; k++) {
+                        const int ix = (u << R) + blk * 2 * half + k, iy = ix + half;
+                        const Shoup &w = tw[u][(1 << st) - 1 + blk];
+                        const double X = fp_of_bits(x[ix]);
+                        const double v = fp_mulmod_wp(fp_of_bits(x[iy]), fp_of_bits(w.op), fp_of_bits(w.quo), fc);
+                        x[ix] = fp_bits(X + v);
+                        x[iy] = fp_bits(X - v);
+                    }
+            }
+        }
+    }
     __device__ static __forceinline__ void compute(u64 (&x)[8], const Shoup (&tw)[G][NTW], const PrimeDesc &pd, const bool lean = false) {
         if (N2_EXP & 4) {
 #pragma unroll
@@ -513,8 +550,11 @@ template <> struct Plan<9> { static constexpr int r[4] = {3, 3, 3, 0}; };
 template <> struct Plan<10> { static constexpr int r[4] = {3, 3, 3, 1}; };
 template <> struct Plan<11> { static constexpr int r[4] = {3, 3, 3, 2}; };
 
-template <int INV, int STRIDED, int NS, int LOGC, int FINAL, int REDUCE, int MAC = 0>
-__global__ __launch_bounds__(N2_THREADS, MAC == 2 ? N2_TENSOR_WAVES : MAC ? N2_MAC_WAVES : N2_MIN_WAVES) void ntt2_kernel(Ntt2Args a) {
+// FP = 1: the FP64 instances (ntt2_fp_kernel below; fpmod.h) -- x then holds the bit patterns of doubles (exact integers, signed lazy range), the
+// twiddles are (w, w / p) from PrimeDesc::root_fp, every data movement (HBM, LDS, LDS-DMA) is the same 64-bit traffic as in the integer form
+template <int INV, int STRIDED, int NS, int LOGC, int FINAL, int REDUCE, int MAC, int FP>
+__device__ __forceinline__ void ntt2_body(const Ntt2Args &a) {
+    static_assert(!FP || (!INV && ((STRIDED && REDUCE && !FINAL) || MAC == 1 || MAC == 3)), "FP64 instances: the forward pair of key switching");
     __shared__ u64 lds[2][N2_T];
     using P = Plan<NS>;
     // NS == 9, contiguous: every 512-point sub-transform is owned by ONE wave in every round (thread t's points never
@@ -534,6 +574,7 @@ __global__ __launch_bounds__(N2_THREADS, MAC == 2 ? N2_TENSOR_WAVES : MAC ? N2_M
                           : (!STRIDED && NS == 10)                       ? 63                        // N = 2^17
                           : (FINAL >= 3 && NS >= 6)                      ? N2_FRESH_MD               // mod-down epilogues: room for their operands
                           : MAC == 2                                     ? N2_FRESH_TENSOR           // tensor pass: 168 VGPRs = 3 waves per SIMD
+                          : (FP && MAC)                                  ? N2_FRESH_FP_MAC           // FP64 key-switch pass: 184 -> 168 VGPRs = 3 waves per SIMD
                           : (STRIDED && !INV && !REDUCE && NS >= 4 && NS <= 6) ? 15                  // plain strided forward pass: room for the register prefetch (PF)
                                                                          : 0;
     auto round_sync = [&]() {
@@ -558,10 +599,13 @@ __global__ __launch_bounds__(N2_THREADS, MAC == 2 ? N2_TENSOR_WAVES : MAC ? N2_M
     const unsigned grp = blockIdx.x >> a.tiles_per_row_log;
     // group order: prime slot major (workgroups in flight share the twiddles, and in the fused key-switch pass the key window),
     // or slot FASTEST (the first key-switch pass: the L+1 readers of one source digit run together and hit in L2)
-    const unsigned slot = a.slot_fastest ? grp % a.map.period : a.slot_begin + grp / a.chunks, chunk = a.slot_fastest ? grp / a.map.period : grp % a.chunks;
-    const PrimeDesc pd = a.primes[a.map.id[slot]];
+    const unsigned sidx = a.slot_fastest ? grp % a.nsel : grp / a.chunks, chunk = a.slot_fastest ? grp / a.nsel : grp % a.chunks;
+    const unsigned slot = (unsigned)__builtin_amdgcn_readfirstlane((int)a.sel[sidx]);
+    PrimeDesc pd = a.primes[a.map.id[slot]];
+    if constexpr (FP) { pd.root = pd.root_fp; pd.iroot = pd.iroot_fp; }
+    const FpPrime fc = make_fp_prime(FP ? pd.p : 1);
     const Mod m = mod_of(pd);
-    const bool need_reduce = REDUCE && (a.src_bound == 0 || (pd.p >> 61) != 0 || a.src_bound > 8 * pd.p);
+    const bool need_reduce = !FP && REDUCE && (a.src_bound == 0 || (pd.p >> 61) != 0 || a.src_bound > 8 * pd.p);
     const bool lean = !INV && ((a.map.lean >> slot) & 1); // wave-uniform: prime below 2^58 -> guard-free forward butterflies (bfly.h)
     const int logn = a.logn;
     const int k1 = STRIDED ? NS : logn - NS;
@@ -580,6 +624,15 @@ __global__ __launch_bounds__(N2_THREADS, MAC == 2 ? N2_TENSOR_WAVES : MAC ? N2_M
     const unsigned m_begin = chunk * a.rows_per_wg;
     const unsigned m_end = (m_begin + a.rows_per_wg < a.m_total) ? m_begin + a.rows_per_wg : a.m_total;
     const unsigned inner = a.map.inner, period = a.map.period;
+    // FP64 instances: reduce the eight values before round r where the host's bound walk says so (fp_plan, fpmod.h; wave-uniform)
+    auto fp_guard = [&](u64 (&v)[8], int r) {
+        if constexpr (FP) {
+            if ((a.fp_red_mask >> r) & 1) {
+#pragma unroll
+                for (int e = 0; e < 8; e++) v[e] = fp_bits(fp_reduce(fp_of_bits(v[e]), fc));
+            }
+        }
+    };
     // software pipeline over the rows of this group: the loads of row mm+1 are in flight while row mm is transformed
     // row mm = o * inner + k: (o, k) is carried along the row loop (one division per workgroup, not three per row)
     auto row_ptrs = [&](unsigned mm, unsigned o, unsigned k, u64 *&row, const u64 *&in) {
@@ -611,6 +664,44 @@ __global__ __launch_bounds__(N2_THREADS, MAC == 2 ? N2_TENSOR_WAVES : MAC ? N2_M
 #pragma unroll
                 for (int e = 0; e < 4; e++) macc[cpt][g][e] = Acc128{0, 0, 0, 0};
     }
+    // FP64 instances: one double per accumulator (the products are reduced modulo p as they are formed: 6 + 1 instructions per term and two
+    // for the key word's conversion, against 10 for the 128-bit integer form -- and 32 VGPRs of accumulators instead of 64)
+    double facc[2][FP ? 8 : 1];
+    if constexpr (FP) {
+#pragma unroll
+        for (int cpt = 0; cpt < 2; cpt++)
+#pragma unroll
+            for (int e = 0; e < 8; e++) facc[cpt][e] = 0.0;
+    }
+    auto mac_row = [&](const u64 (&xr)[8], const ulonglong2 (&kw)[2][KS ? 4 : 1], unsigned row_no) {
+        if constexpr (FP && KS) {
+#pragma unroll
+            for (int cpt = 0; cpt < 2; cpt++)
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    const u64 kword = (e & 1) ? kw[cpt][e >> 1].y : kw[cpt][e >> 1].x;
+                    facc[cpt][e] += fp_mulmod_pinv(fp_of_bits(xr[e]), fp_from_u64(kword), fc);
+                }
+            if (a.fp_acc_every && (row_no + 1) % a.fp_acc_every == 0) { // wave-uniform; the sums stay below 2^53 (launch_ntt2_ks_mac)
+#pragma unroll
+                for (int cpt = 0; cpt < 2; cpt++)
+#pragma unroll
+                    for (int e = 0; e < 8; e++) facc[cpt][e] = fp_reduce(facc[cpt][e], fc);
+            }
+        } else if constexpr (KS) {
+#pragma unroll
+            for (int cpt = 0; cpt < 2; cpt++) {
+#pragma unroll
+                for (int g = 0; g < 2; g++) {
+                    const ulonglong2 k01 = kw[cpt][2 * g], k23 = kw[cpt][2 * g + 1];
+                    const u64 kk[4] = {k01.x, k01.y, k23.x, k23.y};
+                    const u64 xx[4] = {xr[4 * g], xr[4 * g + 1], xr[4 * g + 2], xr[4 * g + 3]};
+                    mac128x4(macc[cpt][g], xx, kk);
+                }
+            }
+        }
+        (void)row_no;
+    };
     // read once: indexing the argument block with `slot` is a memory load, and inside the row loop it sat, with its wait, in front of the key loads
     const unsigned key_limb = KS ? (unsigned)__builtin_amdgcn_readfirstlane((int)a.mac_key_limb[slot]) : 0;
     u64 *const wave_stage = lds[1] + 512 * (threadIdx.x >> 6);
@@ -661,17 +752,21 @@ __global__ __launch_bounds__(N2_THREADS, MAC == 2 ? N2_TENSOR_WAVES : MAC ? N2_M
             }
             if (!diag) {
                 u64 *buf = lds[0];
-                Rd0::compute(x, tw0, pd, lean);
-                Rd0::lds_write(x, buf, threadIdx.x);
+                fp_guard(x, 0);
+                if constexpr (FP) Rd0::compute_fp(x, tw0, fc); else Rd0::compute(x, tw0, pd, lean);
+                Rd0::lds_write(x, buf, (FRESH & 1) ? n2_opaque(threadIdx.x) : threadIdx.x);
                 round_sync();
-                Rd1::lds_read(x, buf, threadIdx.x);
-                Rd1::compute(x, tw1, pd, lean);
-                Rd1::lds_write(x, buf, threadIdx.x);
+                Rd1::lds_read(x, buf, (FRESH & 2) ? n2_opaque(threadIdx.x) : threadIdx.x);
+                fp_guard(x, 1);
+                if constexpr (FP) Rd1::compute_fp(x, tw1, fc); else Rd1::compute(x, tw1, pd, lean);
+                Rd1::lds_write(x, buf, (FRESH & 4) ? n2_opaque(threadIdx.x) : threadIdx.x);
                 round_sync();
                 if constexpr (!Rd2::HOIST) Rd2::load_tw(tw2, pd, tile, logn, s_first);
-                Rd2::lds_read(x, buf, threadIdx.x);
-                Rd2::compute(x, tw2, pd, lean);
-                if (!a.mac_lazy && lean) {
+                Rd2::lds_read(x, buf, (FRESH & 8) ? n2_opaque(threadIdx.x) : threadIdx.x);
+                fp_guard(x, 2);
+                if constexpr (FP) Rd2::compute_fp(x, tw2, fc); else Rd2::compute(x, tw2, pd, lean);
+                if constexpr (FP) {
+                } else if (!a.mac_lazy && lean) {
 #pragma unroll
                     for (int e = 0; e < 8; e++) x[e] = barrett64(x[e], m);
                 } else if (!a.mac_lazy) {
@@ -688,17 +783,12 @@ __global__ __launch_bounds__(N2_THREADS, MAC == 2 ? N2_TENSOR_WAVES : MAC ? N2_M
                 const ulonglong2 *tp = reinterpret_cast<const ulonglong2 *>(a.mac_target + (u64)ro * a.mac_tstride + ((u64)rk << logn) + ((u64)tile << N2_LOGT) + 8 * threadIdx.x);
 #pragma unroll
                 for (int e = 0; e < 4; e++) { const ulonglong2 v = tp[e]; x[2 * e] = v.x; x[2 * e + 1] = v.y; }
-            }
+                if constexpr (FP) {
 #pragma unroll
-            for (int cpt = 0; cpt < 2; cpt++) {
-#pragma unroll
-                for (int g = 0; g < 2; g++) {
-                    const ulonglong2 k01 = kv[cpt][2 * g], k23 = kv[cpt][2 * g + 1];
-                    const u64 kk[4] = {k01.x, k01.y, k23.x, k23.y};
-                    const u64 xx[4] = {x[4 * g], x[4 * g + 1], x[4 * g + 2], x[4 * g + 3]};
-                    mac128x4(macc[cpt][g], xx, kk);
+                    for (int e = 0; e < 8; e++) x[e] = fp_bits(fp_from_u64(x[e]));
                 }
             }
+            mac_row(x, kv, mm - m_begin);
             ro = no;
             rk = nk;
             continue;
@@ -719,7 +809,16 @@ __global__ __launch_bounds__(N2_THREADS, MAC == 2 ? N2_TENSOR_WAVES : MAC ? N2_M
             for (int e = 0; e < 8; e++) x[e] = barrett64(x[e], m);
         }
         if constexpr (!Rd0::HOIST) Rd0::load_tw(tw0, pd, tile, logn, s_first);
-        Rd0::compute(x, tw0, pd, lean);
+        if constexpr (FP && REDUCE) { // the digit's residues become doubles: exact below 2^52; a wide source prime (>= 2^50) is reduced modulo this row's prime first
+            if ((a.fp_src_wide >> rk) & 1) {
+#pragma unroll
+                for (int e = 0; e < 8; e++) x[e] = barrett64(x[e], m);
+            }
+#pragma unroll
+            for (int e = 0; e < 8; e++) x[e] = fp_bits(fp_from_u64(x[e]));
+        }
+        fp_guard(x, 0);
+        if constexpr (FP) Rd0::compute_fp(x, tw0, fc); else Rd0::compute(x, tw0, pd, lean);
         if constexpr (NR == 1) {
             if constexpr (FINAL >= 3) Rd0::template md_write<FINAL>(x, a, mm, slot, tile, logn, m, pd);
             else Rd0::template g_write<FINAL>(x, row, tile, logn, m, lean);
@@ -735,7 +834,8 @@ __global__ __launch_bounds__(N2_THREADS, MAC == 2 ? N2_TENSOR_WAVES : MAC ? N2_M
                     Rd0::template g_read<REDUCE>(xn, nin, tile, logn, m, n2_opaque(threadIdx.x));
                 }
             }
-            Rd1::compute(x, tw1, pd, lean);
+            fp_guard(x, 1);
+            if constexpr (FP) Rd1::compute_fp(x, tw1, fc); else Rd1::compute(x, tw1, pd, lean);
             if constexpr (NR == 2) {
                 if constexpr (FINAL >= 3) Rd1::template md_write<FINAL>(x, a, mm, slot, tile, logn, m, pd);
                 else Rd1::template g_write<FINAL>(x, row, tile, logn, m, lean);
@@ -744,13 +844,15 @@ __global__ __launch_bounds__(N2_THREADS, MAC == 2 ? N2_TENSOR_WAVES : MAC ? N2_M
                 round_sync();
                 if constexpr (!Rd2::HOIST) Rd2::load_tw(tw2, pd, tile, logn, s_first);
                 Rd2::lds_read(x, buf, (FRESH & 8) ? n2_opaque(threadIdx.x) : threadIdx.x);
-                Rd2::compute(x, tw2, pd, lean);
+                fp_guard(x, 2);
+                if constexpr (FP) Rd2::compute_fp(x, tw2, fc); else Rd2::compute(x, tw2, pd, lean);
                 if constexpr (NR == 3 && MAC == 2) {
                     Rd2::tensor_epilogue(x, tx, mm, a.tensor_out, period, slot, tile, logn, m, WAVE_PRIVATE ? buf : nullptr, lean);
                 } else if constexpr (NR == 3 && KS) {
                     // the transform of digit k of (o, slot) stays in registers: acc_c += x (.) key[k][c][limb(slot)].  x is lazy, in
                     // [0, 8p); it is only normalised when dl * 8p * p could overflow the 128-bit accumulator (mac_lazy == 0)
-                    if (!a.mac_lazy && lean) {
+                    if constexpr (FP) {
+                    } else if (!a.mac_lazy && lean) {
 #pragma unroll
                         for (int e = 0; e < 8; e++) x[e] = barrett64(x[e], m);
                     } else if (!a.mac_lazy) {
@@ -763,16 +865,7 @@ __global__ __launch_bounds__(N2_THREADS, MAC == 2 ? N2_TENSOR_WAVES : MAC ? N2_M
                             for (int i = 0; i < 4; i++) x[4 * h + i] = v[i];
                         }
                     }
-#pragma unroll
-                    for (int cpt = 0; cpt < 2; cpt++) {
-#pragma unroll
-                        for (int g = 0; g < 2; g++) {
-                            const ulonglong2 k01 = kv[cpt][2 * g], k23 = kv[cpt][2 * g + 1];
-                            const u64 kk[4] = {k01.x, k01.y, k23.x, k23.y};
-                            const u64 xx[4] = {x[4 * g], x[4 * g + 1], x[4 * g + 2], x[4 * g + 3]};
-                            mac128x4(macc[cpt][g], xx, kk);
-                        }
-                    }
+                    mac_row(x, kv, mm - m_begin);
                 } else if constexpr (NR == 3) {
                     if constexpr (FINAL >= 3) Rd2::template md_write<FINAL>(x, a, mm, slot, tile, logn, m, pd);
                     else Rd2::template g_write<FINAL>(x, row, tile, logn, m, lean, WAVE_PRIVATE ? buf : nullptr);
@@ -781,7 +874,8 @@ __global__ __launch_bounds__(N2_THREADS, MAC == 2 ? N2_TENSOR_WAVES : MAC ? N2_M
                     round_sync();
                     if constexpr (!Rd3::HOIST) Rd3::load_tw(tw3, pd, tile, logn, s_first);
                     Rd3::lds_read(x, buf, (FRESH & 32) ? n2_opaque(threadIdx.x) : threadIdx.x);
-                    Rd3::compute(x, tw3, pd, lean);
+                    fp_guard(x, 3);
+                    if constexpr (FP) Rd3::compute_fp(x, tw3, fc); else Rd3::compute(x, tw3, pd, lean);
                     Rd3::template g_write<FINAL>(x, row, tile, logn, m, lean);
                 }
             }
@@ -811,13 +905,28 @@ __global__ __launch_bounds__(N2_THREADS, MAC == 2 ? N2_TENSOR_WAVES : MAC ? N2_M
 #pragma unroll
             for (int e = 0; e < 4; e++) {
                 ulonglong2 v;
-                const Acc128 &p0 = macc[cpt][e >> 1][2 * (e & 1)], &p1 = macc[cpt][e >> 1][2 * (e & 1) + 1];
-                v.x = barrett128(mk64(p0.a0, p0.a1), mk64(p0.a2, p0.a3), m);
-                v.y = barrett128(mk64(p1.a0, p1.a1), mk64(p1.a2, p1.a3), m);
+                if constexpr (FP) {
+                    v.x = fp_canonical(facc[cpt][2 * e], fc, m.p);
+                    v.y = fp_canonical(facc[cpt][2 * e + 1], fc, m.p);
+                } else {
+                    const Acc128 &p0 = macc[cpt][e >> 1][2 * (e & 1)], &p1 = macc[cpt][e >> 1][2 * (e & 1) + 1];
+                    v.x = barrett128(mk64(p0.a0, p0.a1), mk64(p0.a2, p0.a3), m);
+                    v.y = barrett128(mk64(p1.a0, p1.a1), mk64(p1.a2, p1.a3), m);
+                }
                 op[e] = v;
             }
         }
     }
+}
+
+template <int INV, int STRIDED, int NS, int LOGC, int FINAL, int REDUCE, int MAC = 0>
+__global__ __launch_bounds__(N2_THREADS, MAC == 2 ? N2_TENSOR_WAVES : MAC ? N2_MAC_WAVES : N2_MIN_WAVES) void ntt2_kernel(Ntt2Args a) {
+    ntt2_body<INV, STRIDED, NS, LOGC, FINAL, REDUCE, MAC, 0>(a);
+}
+// the FP64 instances (primes below 2^50): a kernel name of their own, so that profiles and bench.py's per-kernel accounting tell the two apart
+template <int INV, int STRIDED, int NS, int LOGC, int FINAL, int REDUCE, int MAC = 0>
+__global__ __launch_bounds__(N2_THREADS, MAC ? N2_FP_MAC_WAVES : N2_MIN_WAVES) void ntt2_fp_kernel(Ntt2Args a) {
+    ntt2_body<INV, STRIDED, NS, LOGC, FINAL, REDUCE, MAC, 1>(a);
 }
 
 // ---- host side ----
@@ -887,6 +996,8 @@ void launch_ntt2_slots(u64 *data, const u64 *src, u64 src_ostride, bool src_redu
     a.src_same_layout = 0;
     a.slot_fastest = 0;
     a.slot_begin = slot_begin;
+    a.nsel = slot_count;
+    for (unsigned i = 0; i < slot_count; i++) a.sel[i] = (uint8_t)(slot_begin + i);
     if (md) {
         a.md_ct = md->ct; a.md_ct_bstride = md->ct_bstride; a.md_dl = md->dl; a.md_qk = md->qk; a.md_half = md->half;
         a.md_share = md->share;
@@ -925,8 +1036,20 @@ void launch_ntt2_slots(u64 *data, const u64 *src, u64 src_ostride, bool src_redu
 // Key switching: forward transform of every (digit, output prime) pair with the inner product against the key fused into the
 // second pass.  D receives only the first pass; acc [outer][2][period][N] the reduced sums.  Rows are grouped per (o, slot):
 // a workgroup takes all `inner` digits of one group, so its 16 accumulators see every term.
+// The output primes are split into two classes, each with its own pair of launches: primes below 2^50 (map.fp) run the FP64 instances
+// (ntt2_fp_kernel: 8-instruction butterflies, D holds doubles for those slots), the rest the integer instances.  host_primes = the
+// context's prime registry (indexed by map.id; digit k is a residue of host_primes[k]).
+template <int NS> static void launch_ks_first(const Ntt2Args &first, unsigned blocks, bool fp, bool skip_diag, hipStream_t stream) {
+    constexpr int LOGC = N2_LOGT - NS;
+    if (!fp) { launch_strided<0, NS>(first, blocks, false, true, stream, -1, skip_diag); return; }
+    N2_KTAG("ntt2_fp_kernel<0, 1, %d, %d, 0, %d, 0>", NS, LOGC, skip_diag ? 2 : 1);
+    if (skip_diag) TROY_LAUNCH(HIP_KERNEL_NAME(ntt2_fp_kernel<0, 1, NS, LOGC, 0, 2>), dim3(blocks), dim3(N2_THREADS), 0, stream, first);
+    else TROY_LAUNCH(HIP_KERNEL_NAME(ntt2_fp_kernel<0, 1, NS, LOGC, 0, 1>), dim3(blocks), dim3(N2_THREADS), 0, stream, first);
+    launch_check("ntt2_fp_kernel(ks first pass)");
+}
 void launch_ntt2_ks_mac(u64 *D, const u64 *src, u64 src_ostride, const PrimeDesc *primes, const LimbMap &map, size_t rows, int logn, const u64 *key, u64 *acc,
-                        const uint8_t *key_limb, unsigned K, const u64 *ckks_target, u64 t_bstride, bool lazy, u64 src_bound, hipStream_t stream) {
+                        const uint8_t *key_limb, unsigned K, const u64 *ckks_target, u64 t_bstride, bool lazy, u64 src_bound, const u64 *host_primes,
+                        hipStream_t stream) {
     if (rows == 0) return;
     if (!ntt2_supported(logn) || logn - 9 > 7 || logn - 9 < 3) throw Error(ST_LOGIC_ERROR, "ntt2 ks_mac: unsupported size");
     const size_t per_outer = (size_t)map.period * map.inner;
@@ -942,30 +1065,72 @@ void launch_ntt2_ks_mac(u64 *D, const u64 *src, u64 src_ostride, const PrimeDesc
     a.m_total = (unsigned)(rows / per_outer * map.inner);
     a.rows_per_wg = map.inner;
     a.chunks = a.m_total / a.rows_per_wg;
-    const unsigned blocks = (unsigned)((map.period * a.chunks) << a.tiles_per_row_log);
-    Ntt2Args first = a;
-    first.src = src; first.src_ostride = src_ostride; first.src_reduce = 1; first.src_bound = src_bound;
-    first.slot_fastest = 1;
     const bool skip_diag = ckks_target != nullptr; // CKKS: rows (digit k == output slot) are the NTT-form input, not expanded
-    first.skip_diag = skip_diag;
-    switch (k1) {
-    case 3: launch_strided<0, 3>(first, blocks, false, true, stream, -1, skip_diag); break;
-    case 4: launch_strided<0, 4>(first, blocks, false, true, stream, -1, skip_diag); break;
-    case 5: launch_strided<0, 5>(first, blocks, false, true, stream, -1, skip_diag); break;
-    case 6: launch_strided<0, 6>(first, blocks, false, true, stream, -1, skip_diag); break;
-    default: launch_strided<0, 7>(first, blocks, false, true, stream, -1, skip_diag); break;
+    for (int cls = 0; cls < 2; cls++) {
+        a.nsel = 0;
+        for (unsigned i = 0; i < map.period; i++)
+            if ((int)((map.fp >> i) & 1) == cls) a.sel[a.nsel++] = (uint8_t)i;
+        if (!a.nsel) continue;
+        const bool fp = cls == 1;
+        stats::counter(fp ? stats::KS_FP_LAUNCHES : stats::KS_INT_LAUNCHES)++;
+        const unsigned blocks = (unsigned)((a.nsel * a.chunks) << a.tiles_per_row_log);
+        a.fp_src_wide = 0; a.fp_red_mask = 0; a.fp_acc_every = 0;
+        unsigned mask2 = 0;
+        if (fp) { // walk the value bound through both passes (fpmod.h): where to reduce, how often the accumulators must be
+            if (!host_primes) throw Error(ST_LOGIC_ERROR, "ntt2 ks_mac: the FP64 class needs the host prime list");
+            u64 pmax = 0, pmin = ~0ull, src_narrow_max = 0;
+            for (unsigned i = 0; i < a.nsel; i++) { const u64 p = host_primes[map.id[a.sel[i]]]; pmax = std::max(pmax, p); pmin = std::min(pmin, p); }
+            for (unsigned k = 0; k < map.inner; k++) {
+                if (host_primes[k] >> TROY_FP_MAX_BITS) a.fp_src_wide |= u64(1) << k; else src_narrow_max = std::max(src_narrow_max, host_primes[k]);
+            }
+            const double b_in = std::max(1.0, (double)src_narrow_max / (double)pmin);
+            int r1[4], n1 = 0;
+            switch (k1) {
+            case 3: for (int r : Plan<3>::r) if (r) r1[n1++] = r; break;
+            case 4: for (int r : Plan<4>::r) if (r) r1[n1++] = r; break;
+            case 5: for (int r : Plan<5>::r) if (r) r1[n1++] = r; break;
+            case 6: for (int r : Plan<6>::r) if (r) r1[n1++] = r; break;
+            default: for (int r : Plan<7>::r) if (r) r1[n1++] = r; break;
+            }
+            const FpPlan p1 = fp_plan(pmax, b_in, r1, n1);
+            const int r2[3] = {3, 3, 3};
+            const FpPlan p2 = fp_plan(pmax, p1.out_bound, r2, 3);
+            a.fp_red_mask = p1.mask;
+            mask2 = p2.mask;
+            const double lim = 0x1p53 / (double)pmax * 0.98, tb = 0.5 + 3.0 * std::max(p2.out_bound, 1.0) * (double)pmax * 0x1p-53;
+            const double n = std::floor((lim - 0.5 - 0x1p-40) / tb);
+            if (n < 1.0) throw Error(ST_LOGIC_ERROR, "ntt2 ks_mac: FP64 accumulator bound");
+            a.fp_acc_every = n >= (double)map.inner ? 0u : (unsigned)n;
+        }
+        Ntt2Args first = a;
+        first.src = src; first.src_ostride = src_ostride; first.src_reduce = 1; first.src_bound = src_bound;
+        first.slot_fastest = 1;
+        first.skip_diag = skip_diag;
+        switch (k1) {
+        case 3: launch_ks_first<3>(first, blocks, fp, skip_diag, stream); break;
+        case 4: launch_ks_first<4>(first, blocks, fp, skip_diag, stream); break;
+        case 5: launch_ks_first<5>(first, blocks, fp, skip_diag, stream); break;
+        case 6: launch_ks_first<6>(first, blocks, fp, skip_diag, stream); break;
+        default: launch_ks_first<7>(first, blocks, fp, skip_diag, stream); break;
+        }
+        Ntt2Args second = a;
+        second.fp_red_mask = mask2;
+        second.mac_key = key; second.mac_acc = acc; second.mac_target = ckks_target; second.mac_tstride = t_bstride; second.mac_K = K;
+        second.mac_lazy = lazy;
+        std::memcpy(second.mac_key_limb, key_limb, map.period);
+        if (fp) {
+            N2_KTAG("ntt2_fp_kernel<0, 0, 9, 0, 1, 0, %d>", skip_diag ? 3 : 1);
+            if (skip_diag) TROY_LAUNCH(HIP_KERNEL_NAME(ntt2_fp_kernel<0, 0, 9, 0, 1, 0, 3>), dim3(blocks), dim3(N2_THREADS), 0, stream, second);
+            else TROY_LAUNCH(HIP_KERNEL_NAME(ntt2_fp_kernel<0, 0, 9, 0, 1, 0, 1>), dim3(blocks), dim3(N2_THREADS), 0, stream, second);
+        } else if (skip_diag) {
+            N2_KTAG("ntt2_kernel<0, 0, 9, 0, 1, 0, 3>");
+            TROY_LAUNCH(HIP_KERNEL_NAME(ntt2_kernel<0, 0, 9, 0, 1, 0, 3>), dim3(blocks), dim3(N2_THREADS), 0, stream, second);
+        } else {
+            N2_KTAG("ntt2_kernel<0, 0, 9, 0, 1, 0, 1>");
+            TROY_LAUNCH(HIP_KERNEL_NAME(ntt2_kernel<0, 0, 9, 0, 1, 0, 1>), dim3(blocks), dim3(N2_THREADS), 0, stream, second);
+        }
+        launch_check("ntt2_kernel(ks_mac)");
     }
-    a.mac_key = key; a.mac_acc = acc; a.mac_target = ckks_target; a.mac_tstride = t_bstride; a.mac_K = K;
-    a.mac_lazy = lazy;
-    std::memcpy(a.mac_key_limb, key_limb, map.period);
-    if (skip_diag) {
-        N2_KTAG("ntt2_kernel<0, 0, 9, 0, 1, 0, 3>");
-        TROY_LAUNCH(HIP_KERNEL_NAME(ntt2_kernel<0, 0, 9, 0, 1, 0, 3>), dim3(blocks), dim3(N2_THREADS), 0, stream, a);
-    } else {
-        N2_KTAG("ntt2_kernel<0, 0, 9, 0, 1, 0, 1>");
-        TROY_LAUNCH(HIP_KERNEL_NAME(ntt2_kernel<0, 0, 9, 0, 1, 0, 1>), dim3(blocks), dim3(N2_THREADS), 0, stream, a);
-    }
-    launch_check("ntt2_kernel(ks_mac)");
 }
 
 // BFV/BEHZ multiply, both bases: forward transforms of two size-2 operands with the ciphertext tensor fused into the second
@@ -989,6 +1154,8 @@ void launch_ntt2_tensor(u64 *xa, const u64 *src_a, u64 *xb, const u64 *src_b, u6
         a.logn = logn;
         a.tiles_per_row_log = (unsigned)(logn - N2_LOGT);
         a.m_total = (unsigned)(batch * 2);
+        a.nsel = map.period;
+        for (unsigned i = 0; i < map.period; i++) a.sel[i] = (uint8_t)i;
         a.rows_per_wg = a.m_total < 8 ? a.m_total : 8;
         a.chunks = (a.m_total + a.rows_per_wg - 1) / a.rows_per_wg;
         if (src) { a.src = src; a.src_same_layout = 1; }
@@ -1009,6 +1176,8 @@ void launch_ntt2_tensor(u64 *xa, const u64 *src_a, u64 *xb, const u64 *src_b, u6
     a.logn = logn;
     a.tiles_per_row_log = (unsigned)(logn - N2_LOGT);
     a.m_total = (unsigned)(batch * 4);
+    a.nsel = map.period;
+    for (unsigned i = 0; i < map.period; i++) a.sel[i] = (uint8_t)i;
     a.rows_per_wg = 4;
     a.chunks = (unsigned)batch;
     const unsigned blocks = (unsigned)((map.period * a.chunks) << a.tiles_per_row_log);

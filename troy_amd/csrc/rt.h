@@ -19,10 +19,11 @@
 // Per-kernel timing on demand (troyhip_ktime_enable / troyhip_ktime_report, capi.cpp): when enabled, every launch is bracketed by
 // HIP events on ITS OWN stream and accumulated under the kernel's name -- bench.py's roofline.per_kernel comes from here, live.
 // Disabled (the default) it costs one predictable branch per launch.
+#include <atomic>
 namespace troyhip { namespace ktime {
-extern bool enabled;
+extern std::atomic<bool> enabled;
 extern thread_local const char *tag; // optional name for the next launch (template instances share one source text)
-void begin(const char *name, hipStream_t s);
+void begin(const char *name, hipStream_t s); // remembers the record it opened per THREAD: end() closes that one, whatever other threads launched meanwhile
 void end(hipStream_t s);
 } }
 #define TROY_LAUNCH(kernel, grid, block, shmem, stream, ...)                          \
@@ -34,6 +35,14 @@ void end(hipStream_t s);
 #endif
 
 namespace troyhip {
+
+// Path counters (troyhip_stat, include/troyhip.h): which kernel class a launcher chose.  The parity tests read them so that a test of
+// the FP64 instances cannot pass on the integer kernels (or the other way round) without saying so.
+namespace stats {
+enum { KS_FP_LAUNCHES, KS_INT_LAUNCHES, NTT1_FP_LAUNCHES, NTT1_INT_LAUNCHES, COUNT };
+inline uint64_t &counter(int i) { static uint64_t c[COUNT] = {}; return c[i]; }
+inline const char *name(int i) { static const char *n[COUNT] = {"ks_fp_launches", "ks_int_launches", "ntt1_fp_launches", "ntt1_int_launches"}; return n[i]; }
+}
 
 typedef uint64_t u64;
 typedef uint32_t u32;
