@@ -148,6 +148,10 @@ int troyhip_host_encrypt_symmetric(const troyhip_context *ctx, uint64_t seed_lo,
 /* Decryptor::decrypt.  BFV/BGV: N plaintext coefficients;  CKKS: the [limbs][N] RNS plaintext (NTT form) */
 int troyhip_host_decrypt(const troyhip_context *ctx, const uint64_t *secret_key, const uint64_t *ct, int size, int limbs, int is_ntt_form,
                          uint64_t correction_factor, uint64_t *plain_out);
+/* BatchEncoder::encode / decode (src/batchencoder.cpp:84-190; CUDA twin src/batchencoder_cuda.cu): `count` <= N slot values modulo t in the reference's
+ * 2 x (N/2) matrix order <-> the plaintext polynomial [N] in coefficient form.  BFV / BGV with a batching plain modulus (t prime, t = 1 mod 2N). */
+int troyhip_host_batch_encode(const troyhip_context *ctx, const uint64_t *values, uint64_t count, uint64_t *plain_out);
+int troyhip_host_batch_decode(const troyhip_context *ctx, const uint64_t *plain, uint64_t n_coeffs, uint64_t *values_out);
 
 /* ---- kernel_util (src/kernelutils.cuh:562-672) ----
  * rows limb-polynomials of N coefficients at `data`; row r is reduced modulo row_primes[(r / inner) % period].

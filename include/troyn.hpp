@@ -17,6 +17,7 @@
 #include <algorithm>
 #include <array>
 #include <cmath>
+#include <complex>
 #include <cstdint>
 #include <istream>
 #include <ostream>
@@ -577,6 +578,44 @@ private:
     DeviceArray sk_;
 };
 
+// BatchEncoderCuda (src/batchencoder_cuda.cuh:12-86; CPU twin src/batchencoder.cpp:14-245): the 2 x (N/2) matrix of slot values modulo t <-> the plaintext
+// polynomial.  Integer work on the host (troyhip_host_batch_encode / _decode: scatter by the 3^i index map + negacyclic NTT modulo t).
+class BatchEncoder {
+public:
+    explicit BatchEncoder(const SEALContext &c) : c_(c), slots_(c.polyModulusDegree()) {
+        const SchemeType s = c.parms().scheme();
+        if (s != SchemeType::bfv && s != SchemeType::bgv) throw std::invalid_argument("unsupported scheme"); // batchencoder.cpp:23-26
+    }
+    size_t slotCount() const noexcept { return slots_; }
+    void encode(const std::vector<uint64_t> &values, Plaintext &destination) const {
+        if (values.size() > slots_) throw std::invalid_argument("values_matrix size is too large");
+        destination = Plaintext();
+        destination.resize(slots_);
+        check(troyhip_host_batch_encode(c_.handle(), values.data(), values.size(), destination.data()));
+    }
+    void encode(const std::vector<int64_t> &values, Plaintext &destination) const { // negative values are stored as t + value (batchencoder.cpp:133-137)
+        const uint64_t t = c_.parms().plainModulus().value();
+        std::vector<uint64_t> u(values.size());
+        for (size_t i = 0; i < values.size(); i++) u[i] = values[i] < 0 ? t + (uint64_t)values[i] : (uint64_t)values[i];
+        encode(u, destination);
+    }
+    void decode(const Plaintext &plain, std::vector<uint64_t> &destination) const {
+        if (plain.isNttForm()) throw std::invalid_argument("plain cannot be in NTT form");
+        destination.assign(slots_, 0);
+        check(troyhip_host_batch_decode(c_.handle(), plain.data(), plain.coeffCount(), destination.data()));
+    }
+    void decode(const Plaintext &plain, std::vector<int64_t> &destination) const { // values above t / 2 come back negative (batchencoder.cpp:215-243)
+        std::vector<uint64_t> u;
+        decode(plain, u);
+        const uint64_t t = c_.parms().plainModulus().value(), half = (t + 1) >> 1;
+        destination.resize(slots_);
+        for (size_t i = 0; i < slots_; i++) destination[i] = u[i] >= half ? (int64_t)u[i] - (int64_t)t : (int64_t)u[i];
+    }
+private:
+    const SEALContext &c_;
+    size_t slots_;
+};
+
 // CKKSEncoderCuda (src/ckks_cuda.cuh:13-113), the coefficient packing app/LinearHelperCKKS.cuh is built on: encodePolynomial puts
 // round(value * scale) into the polynomial's COEFFICIENTS (no canonical embedding) and leaves the plaintext in NTT form at the
 // chosen level; decodePolynomial inverts it.  The per-coefficient integer work runs here on the host exactly as the reference's
@@ -587,6 +626,56 @@ public:
         if (c.parms().scheme() != SchemeType::ckks) throw std::invalid_argument("unsupported scheme"); // src/ckks.cpp:22-25
     }
     size_t slotCount() const noexcept { return slots_; }
+
+    // encode / decode of N/2 complex slots (src/ckks_cuda.cuh:43-110; CPU twin src/ckks.cpp:98-260, 388-487): the canonical embedding -- slot i is
+    // the value of the plaintext polynomial at zeta^(3^i), its conjugate at zeta^(-3^i), zeta = exp(i pi / N).  Double-precision FFT on the
+    // host (the reference's own encoder is floating point too: results agree to rounding, not bit for bit); the coefficients then go
+    // through encodePolynomial / decodePolynomial, i.e. the same exact integer packing and the GPU transforms.
+    void encode(const std::vector<std::complex<double>> &values, const ParmsID &parms_id, double scale, Plaintext &destination) const {
+        if (values.size() > slots_) throw std::invalid_argument("values_size is too large");
+        const size_t n = slots_ * 2;
+        const int logn = log2_of(n);
+        std::vector<std::complex<double>> a(n, 0.0);
+        for (size_t i = 0; i < values.size(); i++) { a[index_map(i, logn)] = values[i]; a[index_map(i + slots_, logn)] = std::conj(values[i]); }
+        // inverse of the forward stage (j, j + t) -> (u + v W, u - v W): u = (x + y) / 2, v = (x - y) conj(W) / 2; the halvings are one 1 / n at the end
+        for (size_t m = n >> 1, t = 1; m >= 1; m >>= 1, t <<= 1)
+            for (size_t i = 0; i < m; i++) {
+                const std::complex<double> w = std::conj(root(reverse_bits(m + i, logn), n));
+                for (size_t j = 2 * i * t; j < 2 * i * t + t; j++) { const auto x = a[j], y = a[j + t]; a[j] = x + y; a[j + t] = (x - y) * w; }
+            }
+        std::vector<double> coeffs(n);
+        for (size_t i = 0; i < n; i++) coeffs[i] = a[i].real() / (double)n;
+        encodePolynomial(coeffs, parms_id, scale, destination);
+    }
+    void encode(const std::vector<std::complex<double>> &values, double scale, Plaintext &destination) const { encode(values, c_.firstParmsID(), scale, destination); }
+    void encode(const std::vector<double> &values, const ParmsID &parms_id, double scale, Plaintext &destination) const {
+        encode(std::vector<std::complex<double>>(values.begin(), values.end()), parms_id, scale, destination);
+    }
+    void encode(const std::vector<double> &values, double scale, Plaintext &destination) const { encode(values, c_.firstParmsID(), scale, destination); }
+    void encode(double value, const ParmsID &parms_id, double scale, Plaintext &destination) const { // the constant polynomial (src/ckks.cpp:262-330)
+        encodePolynomial(std::vector<double>{value}, parms_id, scale, destination);
+    }
+    void encode(double value, double scale, Plaintext &destination) const { encode(value, c_.firstParmsID(), scale, destination); }
+    void decode(const Plaintext &plain, std::vector<std::complex<double>> &destination) const {
+        std::vector<double> coeffs;
+        decodePolynomial(plain, coeffs);
+        const size_t n = slots_ * 2;
+        const int logn = log2_of(n);
+        std::vector<std::complex<double>> a(coeffs.begin(), coeffs.end());
+        for (size_t m = 1, t = n >> 1; m < n; m <<= 1, t >>= 1)
+            for (size_t i = 0; i < m; i++) {
+                const std::complex<double> w = root(reverse_bits(m + i, logn), n);
+                for (size_t j = 2 * i * t; j < 2 * i * t + t; j++) { const auto u = a[j], v = a[j + t] * w; a[j] = u + v; a[j + t] = u - v; }
+            }
+        destination.resize(slots_);
+        for (size_t i = 0; i < slots_; i++) destination[i] = a[index_map(i, logn)];
+    }
+    void decode(const Plaintext &plain, std::vector<double> &destination) const {
+        std::vector<std::complex<double>> c;
+        decode(plain, c);
+        destination.resize(c.size());
+        for (size_t i = 0; i < c.size(); i++) destination[i] = c[i].real();
+    }
 
     // ckks_cuda.cu:455-575 encodePolynomialInternal
     void encodePolynomial(const std::vector<double> &values, const ParmsID &parms_id, double scale, Plaintext &destination) const {
@@ -701,6 +790,20 @@ public:
         }
     }
 private:
+    static int log2_of(size_t n) { int l = 0; while ((size_t(1) << l) < n) l++; return l; }
+    static size_t reverse_bits(size_t x, int bits) { size_t r = 0; for (int b = 0; b < bits; b++) r |= ((x >> b) & 1) << (bits - 1 - b); return r; }
+    static std::complex<double> root(size_t k, size_t n) { // exp(2 pi i k / 2n)
+        const double ang = 3.14159265358979323846264338327950288 * (double)k / (double)n;
+        return {std::cos(ang), std::sin(ang)};
+    }
+    // matrix_reps_index_map_ (src/ckks.cpp:50-69): slot i -> bit-reversed (3^i - 1) / 2, slot i + N/2 -> bit-reversed (2N - 3^i - 1) / 2
+    size_t index_map(size_t i, int logn) const {
+        const uint64_t m = (uint64_t)slots_ * 4;
+        uint64_t pos = 1, base = 3;
+        for (size_t e = i % slots_; e; e >>= 1, base = base * base & (m - 1))
+            if (e & 1) pos = pos * base & (m - 1);
+        return reverse_bits((size_t)((i < slots_ ? pos - 1 : m - pos - 1) >> 1), logn);
+    }
     static uint64_t pow2_mod(unsigned e, uint64_t p) {
         unsigned __int128 r = 1, b = 2 % p;
         for (; e; e >>= 1, b = b * b % p)

@@ -17,8 +17,11 @@ def _build(out, libdir, libfile, src=SRC):
     subprocess.run(cmd, check=True, capture_output=True, text=True)
 
 
-def _run(exe):
-    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+TIMETEST = os.path.join(ROOT, "tests", "cpp", "test_troyn_timetest.cpp")  # the op sequences of the reference's test/timetest.cu, incl. every out-of-place form
+
+
+def _run(exe, *args):
+    r = subprocess.run([exe, *args], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "ALL OK" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
     assert "FAIL" not in r.stdout
 
@@ -49,3 +52,17 @@ def test_troyn_app_on_gpu(tmp_path):
     exe = str(tmp_path / "test_troyn_app")
     _build(exe, os.path.join(ROOT, "troy_amd"), "libtroyhip.so", APP)
     _run(exe)
+
+
+def test_troyn_timetest_on_emulator(tmp_path):
+    subprocess.check_call(["make", "-s", "-j8", "-C", os.path.join(ROOT, "troy_amd", "csrc"), "emul"])
+    exe = str(tmp_path / "test_troyn_timetest_emul")
+    _build(exe, os.path.join(ROOT, "tests", "emul"), "libtroyhip_emul.so", TIMETEST)
+    _run(exe, "4096")
+
+
+@pytest.mark.gpu
+def test_troyn_timetest_on_gpu(tmp_path):
+    exe = str(tmp_path / "test_troyn_timetest")
+    _build(exe, os.path.join(ROOT, "troy_amd"), "libtroyhip.so", TIMETEST)
+    _run(exe, "8192")

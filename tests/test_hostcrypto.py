@@ -207,3 +207,32 @@ def test_encrypt_symmetric_ckks_every_level(ta):
             got = oracle.ntt_standalone(N, p, back[l], 3).astype(object)
             centred = np.array([int(v) - p if int(v) > p // 2 else int(v) for v in got])
             assert np.max(np.abs(centred - coeffs)) < 64           # one fresh error term (|e| <= 21 for the centred binomial)
+
+
+def test_batch_encoder_against_reference_fixtures(ta):
+    """BatchEncoder (src/batchencoder.cpp) pinned on what the reference itself produced: the cfgA fixture holds slot values and the plaintexts
+    the reference's encoder made of them (N = 4096); the real-key fixtures hold a decrypted product whose decoding the generator checked
+    against the slot-wise product rotated by one (N = 128, BFV and BGV)."""
+    f = np.load(os.path.join(GOLDEN, "cfgA_bfv_n4096_k3.npz"))
+    primes, t = [int(x) for x in f["primes"]], int(f["t"])
+    ctx = ta.SEALContext(ta.BFV, 4096, primes, t, host_only=True)
+    be = ta.BatchEncoder(ctx)
+    for k in ("1", "2"):
+        assert np.array_equal(be.encode(f["values" + k]), f["plain" + k])
+        assert np.array_equal(be.decode(f["plain" + k]), f["values" + k])
+    assert np.array_equal(be.decode(f["decrypted"]), (f["values1"] + f["values2"]) % np.uint64(t))
+    short = be.encode(f["values1"][:5])                   # fewer values than slots: the rest are zero
+    assert np.array_equal(be.decode(short), np.concatenate([f["values1"][:5], np.zeros(4096 - 5, dtype=np.uint64)]))
+    for nm, scheme in (("bfv", ta.BFV), ("bgv", ta.BGV)):
+        g = np.load(os.path.join(GOLDEN, f"realkey_{nm}.npz"))
+        primes, t, N = [int(x) for x in g["primes"]], int(g["t"]), 128
+        be = ta.BatchEncoder(ta.SEALContext(scheme, N, primes, t, host_only=True))
+        prod = (g["values1"] * g["values2"]) % np.uint64(t)
+        expect = np.concatenate([np.roll(prod[:N // 2], -1), np.roll(prod[N // 2:], -1)])
+        assert np.array_equal(be.decode(g["decrypted"]), expect)
+    if ref.available():                                   # and live against the reference's encoder where it is built
+        rng = np.random.default_rng(5)
+        R = ref.Ref(ref.BGV, 128, primes, t, seed=3)
+        v = rng.integers(0, t, 128, dtype=np.uint64)
+        assert np.array_equal(be.encode(v), R.batch_encode(v))
+        assert np.array_equal(be.decode(R.batch_encode(v)), v)

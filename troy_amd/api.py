@@ -888,3 +888,30 @@ class Decryptor:
         out = np.zeros(limbs * N if ctx.scheme == CKKS else N, dtype=np.uint64)
         capi.check(self.lib, self.lib.troyhip_host_decrypt(ctx.h, _u64p(self.sk), _u64p(ct), size, limbs, int(is_ntt_form), C.c_uint64(correction_factor), _u64p(out)))
         return out.reshape(limbs, N) if ctx.scheme == CKKS else out
+
+
+class BatchEncoder:
+    """BatchEncoder::encode / decode (src/batchencoder.cpp:84-190): the 2 x (N/2) slot matrix modulo t <-> the plaintext polynomial, on the
+    host (troyhip_host_batch_encode / _decode)."""
+
+    def __init__(self, context):
+        if context.scheme == CKKS:
+            raise capi.InvalidArgument(capi.INVALID_ARGUMENT, "unsupported scheme")  # batchencoder.cpp:23-26
+        self.context, self.lib = context, context.lib
+
+    def slotCount(self):
+        return self.context.N
+
+    def encode(self, values):
+        v = np.ascontiguousarray(np.asarray(values, dtype=np.int64) % np.int64(self.context.plain_modulus), dtype=np.uint64)
+        if v.size > self.context.N:
+            raise capi.InvalidArgument(capi.INVALID_ARGUMENT, "values_matrix size is too large")
+        out = np.zeros(self.context.N, dtype=np.uint64)
+        capi.check(self.lib, self.lib.troyhip_host_batch_encode(self.context.h, _u64p(v), C.c_uint64(v.size), _u64p(out)))
+        return out
+
+    def decode(self, plain):
+        p = np.ascontiguousarray(plain, dtype=np.uint64)
+        out = np.zeros(self.context.N, dtype=np.uint64)
+        capi.check(self.lib, self.lib.troyhip_host_batch_decode(self.context.h, _u64p(p), C.c_uint64(p.size), _u64p(out)))
+        return out

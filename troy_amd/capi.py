@@ -62,7 +62,7 @@ SYMBOLS = [
     "troyhip_negate", "troyhip_add", "troyhip_sub", "troyhip_multiply", "troyhip_relinearize", "troyhip_relinearize_keys", "troyhip_relinearize_to", "troyhip_switch_key",
     "troyhip_mod_switch_to_next", "troyhip_rescale_to_next", "troyhip_apply_galois", "troyhip_rotate",
     "troyhip_transform_to_ntt", "troyhip_transform_from_ntt", "troyhip_multiply_plain_ntt", "troyhip_add_plain", "troyhip_multiply_plain",
-    "troyhip_stat", "troyhip_build_id", "troyhip_plain_to_ntt", "troyhip_decrypt", "troyhip_apply_key_switching", "troyhip_negacyclic_shift", "troyhip_divide_by_poly_modulus_degree",
+    "troyhip_stat", "troyhip_build_id", "troyhip_host_batch_encode", "troyhip_host_batch_decode", "troyhip_plain_to_ntt", "troyhip_decrypt", "troyhip_apply_key_switching", "troyhip_negacyclic_shift", "troyhip_divide_by_poly_modulus_degree",
 ]
 
 _lib = None

@@ -413,6 +413,13 @@ int troyhip_host_decrypt(const troyhip_context *ctx, const uint64_t *secret_key,
     return guard([&] { hostcrypto::decrypt(ctx->ctx, secret_key, ct, size, limbs, is_ntt_form != 0, correction_factor, plain_out); }, false);
 }
 
+int troyhip_host_batch_encode(const troyhip_context *ctx, const uint64_t *values, uint64_t count, uint64_t *plain_out) {
+    return guard([&] { hostcrypto::batch_encode(ctx->ctx, values, count, plain_out); }, false);
+}
+int troyhip_host_batch_decode(const troyhip_context *ctx, const uint64_t *plain, uint64_t n_coeffs, uint64_t *values_out) {
+    return guard([&] { hostcrypto::batch_decode(ctx->ctx, plain, n_coeffs, values_out); }, false);
+}
+
 int troyhip_ntt(troyhip_context *ctx, uint64_t *data, uint64_t rows, const uint64_t *row_primes, int period, int inner, int inverse, void *stream) {
     return guard([&] {
         Context &c = ctx->ctx;

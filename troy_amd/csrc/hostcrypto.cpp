@@ -9,6 +9,9 @@
 // reference's own Decryptor -- to the same plaintext.  Decryption is deterministic and bit-exact.
 // Nothing here touches the GPU; a host-only context (troyhip_context_create_host) is enough.
 #include "hostcrypto.h"
+#include <map>
+#include <memory>
+#include <mutex>
 #include <cstring>
 
 namespace troyhip {
@@ -358,6 +361,54 @@ void decrypt(const Context &c, const u64 *sk, const u64 *ct, int size, int limbs
             out[k] = d;
         }
     }
+}
+
+// ------------------------------------------------------------------ BatchEncoder (src/batchencoder.cpp)
+// slot i of the 2 x (N/2) matrix sits at the bit-reversed position of the exponent 3^i (row 0) / -3^i (row 1) of the primitive 2N-th root
+// (populateMatrixRepsIndexMap, batchencoder.cpp:61-81); encode = scatter + inverse negacyclic NTT modulo t, decode = NTT + gather.  The table
+// modulo t is the reference's plainNTTTables: minimal primitive root, SEAL order (host::NttTable).
+namespace {
+struct PlainTables {
+    host::NttTable tb;
+    std::vector<uint32_t> index_map;
+};
+const PlainTables &plain_tables(const Context &c) {
+    static std::mutex mu;
+    static std::map<std::pair<u64, int>, std::unique_ptr<PlainTables>> cache;
+    if (c.scheme == SCHEME_CKKS) throw Error(ST_INVALID_ARGUMENT, "unsupported scheme");
+    if (c.t < 2 || !host::is_prime(c.t) || (c.t - 1) % (2 * c.N)) throw Error(ST_LOGIC_ERROR, "batching is not enabled for the encryption parameters"); // batchencoder.cpp:93-96
+    std::lock_guard<std::mutex> g(mu);
+    auto &slot = cache[{c.t, c.logn}];
+    if (!slot) {
+        slot.reset(new PlainTables);
+        slot->tb.build(c.logn, c.t);
+        const size_t n = c.N, row = n >> 1, m = n << 1;
+        slot->index_map.resize(n);
+        u64 pos = 1;
+        for (size_t i = 0; i < row; i++) {
+            slot->index_map[i] = host::reverse_bits((uint32_t)((pos - 1) >> 1), c.logn);
+            slot->index_map[row | i] = host::reverse_bits((uint32_t)((m - pos - 1) >> 1), c.logn);
+            pos = (pos * 3) & (m - 1);
+        }
+    }
+    return *slot;
+}
+} // namespace
+void batch_encode(const Context &c, const u64 *values, size_t count, u64 *plain) {
+    const PlainTables &pt = plain_tables(c);
+    if (count > c.N) throw Error(ST_INVALID_ARGUMENT, "values_matrix size is too large");
+    for (size_t i = 0; i < c.N; i++) plain[i] = 0;
+    for (size_t i = 0; i < count; i++) {
+        plain[pt.index_map[i]] = values[i] % c.t; // the reference stores the word as it is (release build); the residue is what the transform sees
+    }
+    ntt_inverse(plain, pt.tb);
+}
+void batch_decode(const Context &c, const u64 *plain, size_t n_coeffs, u64 *values) {
+    const PlainTables &pt = plain_tables(c);
+    std::vector<u64> tmp(c.N, 0);
+    for (size_t i = 0; i < n_coeffs && i < c.N; i++) tmp[i] = plain[i];
+    ntt_forward(tmp.data(), pt.tb);
+    for (size_t i = 0; i < c.N; i++) values[i] = tmp[pt.index_map[i]];
 }
 
 } // namespace hostcrypto
