@@ -59,8 +59,11 @@ const char *troyhip_build_info(void);               /* "gfx950" for the product 
 int troyhip_malloc(void **out, size_t bytes);       /* KernelProvider::malloc */
 int troyhip_free(void *p);                          /* KernelProvider::free */
 /* malloc/free go through a caching pool with the reference's MemoryPoolCuda policy (src/utils/memorypool_cuda.cuh:40-58): a freed
- * block serves a later request of size <= block <= 2 * size.  Reuse is stream-ordered: do not free a buffer that work on ANOTHER
- * stream still uses.  troyhip_pool_release synchronises the device and returns every cached block to the driver. */
+ * block serves a later request of size <= block <= 2 * size.  Reuse is ordered against the default stream, every stream made by
+ * troyhip_stream_create and every stream announced with troyhip_stream_register: a block freed while work on one of THOSE streams still
+ * uses it is not handed out before that work has passed.  A stream the library was never told about is not covered -- register it
+ * (a caller-created hipStream_t, a torch / RCCL stream) or synchronise it before freeing.  troyhip_pool_release synchronises the
+ * device and returns every cached block to the driver. */
 int troyhip_pool_release(void);
 int troyhip_copy_h2d(void *dst, const void *src, size_t bytes, void *stream);   /* KernelProvider::copy */
 int troyhip_copy_d2h(void *dst, const void *src, size_t bytes, void *stream);   /* KernelProvider::retrieve */
@@ -71,6 +74,10 @@ int troyhip_stream_synchronize(void *stream);
  * scratch arena is not shared between concurrent operations) -- use one context per stream to overlap independent batches */
 int troyhip_stream_create(void **stream);
 int troyhip_stream_destroy(void *stream);
+/* a stream created elsewhere that will run work on buffers of troyhip_malloc: the pool then orders reuse against it too;
+ * unregister (synchronises the stream) before destroying it.  No reference counterpart (the reference has one stream). */
+int troyhip_stream_register(void *stream);
+int troyhip_stream_unregister(void *stream);
 int troyhip_mem_info(size_t *free_bytes, size_t *total_bytes);
 /* HIP-event timers on the caller's stream (bench.py roofline measurement) */
 /* TEST SUPPORT: runs one primitive of the device arithmetic (kernelutils.cuh:94-404 counterparts in modarith.h / bfly.h) on n device

@@ -730,6 +730,29 @@ def check_modswitch_as_first_op(cfg_name, batch=2):
                 assert np.array_equal(got2[b], orc.impl.eval(op, R.Ct(xs2[b], ntt)).data), ("grow", b)
 
 
+def check_rescale_onto_itself(cfg, batch=3):
+    """troyhip_rescale_to_next / troyhip_mod_switch_to_next called straight through the C ABI with the OUTPUT batch laid over the input
+    batch (a strided input -- capacity 3 -- rescaled onto its own buffer with a dense output stride): the rows a later item still reads are
+    overwritten by an earlier item's result unless the input is staged.  Result against the same op into a fresh buffer."""
+    import ctypes as C
+    be = GpuBackend(cfg, batch=batch)
+    scheme, N = cfg["scheme"], cfg["N"]
+    ntt = scheme == CKKS
+    L = len(be.primes) - 1
+    xs = synth.uniform_ct(881, be.primes[:L], 2, N, batch)
+    fresh = be.api.Ciphertext.from_numpy(be.ctx, xs, ntt, 1.0, 1, capacity=3)
+    want = (be.ev.rescaleToNext(fresh) if scheme == CKKS else be.ev.modSwitchToNext(fresh)).cpu()
+    c = be.api.Ciphertext.from_numpy(be.ctx, xs, ntt, 1.0, 1, capacity=3)
+    si, so = c.struct(), c.struct()
+    so.batch_stride = 2 * (L - 1) * N          # dense output items over the strided input items
+    fn = be.api.KernelProvider.lib().troyhip_rescale_to_next if scheme == CKKS else be.api.KernelProvider.lib().troyhip_mod_switch_to_next
+    capi_mod = __import__("troy_amd.capi", fromlist=["check"])
+    capi_mod.check(be.api.KernelProvider.lib(), fn(be.ctx.h, C.byref(si), C.byref(so), C.c_uint64(batch), None))
+    be.api.synchronize()
+    got = c.buf.to_numpy(batch * 2 * (L - 1) * N).reshape(batch, 2, L - 1, N)
+    assert np.array_equal(got, want)
+
+
 def check_general_sizes(cfg_name, batch=2):
     """GPU product against golden_sizes.json (generated from the reference itself)"""
     import json

@@ -128,6 +128,12 @@ def test_emulated_ckks_two_round_strided_plans(N, bits, emul_api, oracle_lib):
     assert not cases.compare(got, exp)
 
 
+@pytest.mark.parametrize("cfg", [dict(scheme=cases.CKKS, N=128, bits=[40, 40, 40, 40], tbits=0), dict(scheme=cases.BGV, N=128, bits=[40, 36, 36, 40], tbits=10),
+                                 dict(scheme=cases.CKKS, N=32768, bits=[40, 40, 40], tbits=0)])
+def test_emulated_rescale_onto_itself(cfg, emul_api):
+    cases.check_rescale_onto_itself(cfg, batch=2 if cfg["N"] > 4096 else 3)
+
+
 def test_emulated_size_limits(emul_api):
     cases.check_size_limits("bfv_n64_k3")
     cases.check_size_limits("ckks_n128_k6")

@@ -511,7 +511,7 @@ def test_behz_kernel_forms_agree(env, gpu, oracle_lib):
     assert out.stdout.split()[-len(Ks):] == here
 
 
-@pytest.mark.parametrize("env", [{"TROYHIP_KS": "split"}, {"TROYHIP_TENSOR": "split"}, {"TROYHIP_BEHZ": "valu"}, {"TROYHIP_MODDOWN": "split"}])
+@pytest.mark.parametrize("env", [{"TROYHIP_KS": "split"}, {"TROYHIP_TENSOR": "split"}, {"TROYHIP_BEHZ": "valu"}, {"TROYHIP_MODDOWN": "split"}, {"TROYHIP_FP64": "off"}])
 def test_unfused_kernel_paths_agree(env, gpu):
     """the unfused key-switch inner product, the unfused tensor, the VALU BEHZ kernels and the element-wise BFV / BGV mod-down instead of
     the inverse transform's epilogue (environment switches, read once per process) give the same limbs as the default path, which the
@@ -530,7 +530,7 @@ def test_unfused_kernel_paths_agree(env, gpu):
     assert out.stdout.split()[-len(names):] == here
 
 
-@pytest.mark.parametrize("env", [{"TROYHIP_NTT": "single"}, {"TROYHIP_NTT": "twopass"}, {"TROYHIP_BFLY": "guarded"}, {"TROYHIP_NTT": "single", "TROYHIP_BFLY": "guarded"},
+@pytest.mark.parametrize("env", [{"TROYHIP_NTT": "single"}, {"TROYHIP_NTT": "twopass"}, {"TROYHIP_BFLY": "guarded"}, {"TROYHIP_NTT": "single", "TROYHIP_BFLY": "guarded"}, {"TROYHIP_FP64": "off"},
                                  {"TROYHIP_NTT": "single", "TROYHIP_MODDOWN": "split"}, {"TROYHIP_NTT": "single", "TROYHIP_CORR": "split"}])
 def test_ntt_forms_agree_at_headline_size(env, gpu):
     """N = 2^15: the single-pass transform forced at a small batch (by default it takes launches of four rows per CU and more), the
@@ -650,3 +650,58 @@ def test_context_is_owned_by_one_stream(gpu):
     r2 = ev2.multiply(a, b)
     gpu.synchronize(s2)
     assert np.array_equal(r1.cpu(), r2.cpu())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [dict(scheme=cases.CKKS, N=32768, bits=[60, 40, 40, 60], tbits=0), dict(scheme=cases.CKKS, N=8192, bits=[50, 40, 40], tbits=0),
+                                 dict(scheme=cases.BGV, N=8192, bits=[40, 36, 36, 40], tbits=20), dict(scheme=cases.BFV, N=4096, bits=[36, 36, 37], tbits=20)])
+def test_rescale_onto_itself(cfg, gpu):
+    """a strided batch rescaled / mod-switched onto its own buffer through the C ABI (overlapping input and output ranges)"""
+    cases.check_rescale_onto_itself(cfg, batch=5)
+
+
+@pytest.mark.parametrize("N,bits,scheme", [(8192, [60, 40, 40, 40, 60], cases.CKKS), (16384, [50, 49, 50, 48, 55], cases.BGV), (65536, [60, 50, 50, 60], cases.BGV),
+                                           (32768, [60, 40, 50, 30, 60], cases.CKKS), (4096, [36, 36, 37], cases.BFV), (8192, [50, 50, 50, 50], cases.CKKS)])
+def test_fp64_key_switch_instances_vs_oracle(N, bits, scheme, gpu):
+    """the FP64 instances of the key-switch forward pair (ntt2_fp_kernel: primes below 2^50) against the oracle, limb for limb: mixed prime
+    sizes (FP64 and integer classes in one key switch, wide source digits into narrow output primes and the reverse), 50-bit primes (the bound
+    walk must place reductions), all-narrow sets -- and the path counter proves the FP64 kernels are what ran"""
+    from troy_amd import capi
+    cfg = dict(scheme=scheme, N=N, bits=bits, tbits=0 if scheme == cases.CKKS else 20)
+    before = capi.stat("ks_fp_launches")
+    got = cases.scenario(cases.GpuBackend(cfg, batch=2), cfg, light=True)
+    exp = cases.scenario(cases.oracle_backend(cfg), cfg, light=True)
+    assert not cases.compare(got, exp)
+    assert capi.stat("ks_fp_launches") > before, "the FP64 key-switch instances did not run"
+
+
+@pytest.mark.parametrize("bits", [[50, 50, 50, 50, 50, 50, 50, 60], [40] * 7 + [60], [50, 30, 50, 30, 45, 60]])
+def test_fp64_key_switch_extreme_residues(bits, gpu):
+    """worst-case operands for the FP64 value bounds: every ciphertext and key residue at p - 1 (largest magnitude through every stage and
+    the largest accumulator sums), at (p - 1) / 2 and alternating p - 1 / 0, relinearize and rotate at the top level against the oracle"""
+    from oracle import ref as R
+    from troy_amd import capi
+    N = 8192
+    cfg = dict(scheme=cases.BGV, N=N, bits=bits, tbits=20)
+    be, orc = cases.GpuBackend(cfg, batch=3), cases.oracle_backend(cfg)
+    primes = be.primes
+    L, K = len(primes) - 1, len(primes)
+    pk = np.array(primes, dtype=np.uint64)
+    key = np.empty((L, 2, K, N), dtype=np.uint64)
+    key[:] = (pk - np.uint64(1))[None, None, :, None]
+    be.set_relin_key(key)
+    orc.set_relin_key(key)
+    pl = pk[:L]
+    x = np.empty((3, 3, L, N), dtype=np.uint64)
+    x[0] = (pl - np.uint64(1))[None, :, None]
+    x[1] = ((pl - np.uint64(1)) // np.uint64(2))[None, :, None]
+    x[2] = (pl - np.uint64(1))[None, :, None]
+    x[2, :, :, 1::2] = 0
+    before = capi.stat("ks_fp_launches")
+    c = be.api.Ciphertext.from_numpy(be.ctx, x, False, 1.0, 1)
+    be.ev.relinearizeInplace(c, be.rlk)
+    got = c.cpu()
+    assert capi.stat("ks_fp_launches") > before
+    for b in range(3):
+        want = orc.impl.eval(R.OP_RELIN, R.Ct(x[b], False)).data
+        assert np.array_equal(got[b], want), (bits, b)

@@ -139,16 +139,18 @@ const char *troyhip_build_id(void) { return TROYHIP_BUILD_ID; }
 // KernelProvider::malloc / free behind the reference's MemoryPoolCuda policy (src/utils/memorypool_cuda.cuh:40-58): a freed
 // block is kept and handed out again to a request of size <= block <= 2 * size; everything cached is released when the device
 // runs short.  hipMalloc / hipFree synchronise the device, a pooled pair does not.  troyhip_free carries no stream, so reuse is
-// made safe for ANY stream: a freed block is stamped with an event on the default stream and on every stream created through
-// troyhip_stream_create, and is handed out again only once all of them have passed (a block dropped by the host while a kernel
-// on some stream still reads it is therefore never overwritten; the reference's pool leaves this to the caller).  Thread-safe.
+// ordered against every stream the pool KNOWS: the default stream, the streams created through troyhip_stream_create and the
+// streams announced with troyhip_stream_register (a caller's own hipStream_t, a torch / RCCL stream).  A freed block is stamped
+// with an event on each of them and is handed out again only once all have passed, so a block dropped by the host while a kernel
+// on a known stream still reads it is never overwritten (the reference's pool leaves this to the caller).  Work on a stream the
+// pool was never told about is NOT covered: register it, or synchronise it before freeing what it uses.  Thread-safe.
 namespace {
 struct DevicePool {
-    struct Block { void *p; std::vector<hipEvent_t> pending; };
+    struct Block { void *p; std::vector<std::pair<hipStream_t, hipEvent_t>> pending; }; // (stream, its free-point event)
     std::mutex mu;
     std::multimap<size_t, Block> free_blocks;
     std::map<void *, size_t> live;
-    std::vector<hipStream_t> streams;   // the non-default streams handed out by troyhip_stream_create
+    std::vector<hipStream_t> streams;   // the non-default streams the pool orders reuse against (troyhip_stream_create / _register)
     std::vector<hipEvent_t> spare_events;
     hipEvent_t new_event() {
         if (!spare_events.empty()) { hipEvent_t e = spare_events.back(); spare_events.pop_back(); return e; }
@@ -156,13 +158,13 @@ struct DevicePool {
         HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         return e;
     }
-    bool quiescent(Block &b) { // every stream has passed the point at which the block was freed
-        while (!b.pending.empty()) {
-            if (hipEventQuery(b.pending.back()) != hipSuccess) { (void)hipGetLastError(); return false; }
-            spare_events.push_back(b.pending.back());
-            b.pending.pop_back();
+    bool quiescent(Block &b) { // every tracked stream has passed the point at which the block was freed
+        for (size_t i = b.pending.size(); i-- > 0;) {
+            if (hipEventQuery(b.pending[i].second) != hipSuccess) { (void)hipGetLastError(); continue; }
+            spare_events.push_back(b.pending[i].second);
+            b.pending.erase(b.pending.begin() + (long)i);
         }
-        return true;
+        return b.pending.empty();
     }
     void *get(size_t bytes) {
         std::lock_guard<std::mutex> g(mu);
@@ -179,9 +181,9 @@ struct DevicePool {
         // block per step -- take a pending block and make every stream wait for the point at which it was freed (stream-ordered reuse).
         for (auto it = free_blocks.lower_bound(bytes); it != free_blocks.end() && it->first <= 2 * bytes; ++it) {
             Block &b = it->second;
-            for (hipEvent_t e : b.pending) {
-                for (size_t i = 0; i <= streams.size(); i++) HIP_CHECK(hipStreamWaitEvent(i ? streams[i - 1] : (hipStream_t) nullptr, e, 0));
-                spare_events.push_back(e);
+            for (auto &se : b.pending) {
+                for (size_t i = 0; i <= streams.size(); i++) HIP_CHECK(hipStreamWaitEvent(i ? streams[i - 1] : (hipStream_t) nullptr, se.second, 0));
+                spare_events.push_back(se.second);
             }
             b.pending.clear();
             void *p = b.p;
@@ -207,8 +209,9 @@ struct DevicePool {
 #ifndef TROYHIP_CPU_EMUL
         for (size_t i = 0; i <= streams.size(); i++) {
             hipEvent_t e = new_event();
-            HIP_CHECK(hipEventRecord(e, i ? streams[i - 1] : (hipStream_t) nullptr));
-            b.pending.push_back(e);
+            hipStream_t st = i ? streams[i - 1] : (hipStream_t) nullptr;
+            HIP_CHECK(hipEventRecord(e, st));
+            b.pending.emplace_back(st, e);
         }
 #endif
         free_blocks.emplace(it->second, std::move(b));
@@ -216,16 +219,23 @@ struct DevicePool {
     }
     void release_locked() { // callers have synchronised the device (or are out of memory: hipFree synchronises)
         for (auto &kv : free_blocks) {
-            for (hipEvent_t e : kv.second.pending) spare_events.push_back(e);
+            for (auto &se : kv.second.pending) spare_events.push_back(se.second);
             (void)hipFree(kv.second.p);
         }
         free_blocks.clear();
     }
     void release() { std::lock_guard<std::mutex> g(mu); release_locked(); }
-    void add_stream(hipStream_t s) { std::lock_guard<std::mutex> g(mu); streams.push_back(s); }
-    void remove_stream(hipStream_t s) {
+    void add_stream(hipStream_t s) {
         std::lock_guard<std::mutex> g(mu);
-        for (auto &kv : free_blocks) quiescent(kv.second); // events recorded on the dying stream must be retired before it goes
+        if (s && std::find(streams.begin(), streams.end(), s) == streams.end()) streams.push_back(s);
+    }
+    void remove_stream(hipStream_t s) { // the caller has synchronised `s`: exactly its free-point events are complete, and they go with it
+        std::lock_guard<std::mutex> g(mu);
+        for (auto &kv : free_blocks) {
+            auto &pd = kv.second.pending;
+            for (size_t i = pd.size(); i-- > 0;)
+                if (pd[i].first == s) { spare_events.push_back(pd[i].second); pd.erase(pd.begin() + (long)i); }
+        }
         streams.erase(std::remove(streams.begin(), streams.end(), s), streams.end());
     }
     static DevicePool &instance() { static DevicePool p; return p; }
@@ -247,6 +257,13 @@ int troyhip_memset_zero(void *dst, size_t bytes, void *stream) { return guard([&
 int troyhip_stream_synchronize(void *stream) { return guard([&] { HIP_CHECK(hipStreamSynchronize((hipStream_t)stream)); }); }
 int troyhip_stream_create(void **stream) {
     return guard([&] { hipStream_t st; HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking)); DevicePool::instance().add_stream(st); *stream = (void *)st; });
+}
+int troyhip_stream_register(void *stream) { return guard([&] { DevicePool::instance().add_stream((hipStream_t)stream); }); }
+int troyhip_stream_unregister(void *stream) {
+    return guard([&] {
+        HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
+        DevicePool::instance().remove_stream((hipStream_t)stream);
+    });
 }
 int troyhip_stream_destroy(void *stream) {
     return guard([&] {

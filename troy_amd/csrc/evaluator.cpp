@@ -483,7 +483,7 @@ void Evaluator::mod_switch_scale(const CtBatch &in, CtBatch &out, u64 batch, hip
     {   // everything this op carves, reserved up front: take() can only grow an EMPTY arena (a rescale as the first op on a fresh
         // context, or at a larger batch than the ops before it, used to fail with "scratch arena exhausted inside an op")
         size_t need = 4 * 32;
-        if (!dense_in) need += batch * in.size * pw;
+        need += batch * in.size * pw; // staging copy of a strided or overlapping input
         if (!dense_out) need += batch * in.size * npw;
         if (c.scheme == SCHEME_CKKS) need += batch * in.size * N + batch * in.size * npw;
         c.arena.reserve(need);
@@ -492,7 +492,13 @@ void Evaluator::mod_switch_scale(const CtBatch &in, CtBatch &out, u64 batch, hip
     // CKKS through the fused correction transform reads a strided batch (a relinearized ciphertext keeps its three-polynomial stride) as it lies
     const bool ckks_fused = c.scheme == SCHEME_CKKS && c.level(L).d_inv_qlast && corr_fused() && primes_at_least_33_bits(c, nl) &&
                             ntt1_supported(c.logn, c.ct_map(nl), batch * in.size * nl);
-    if (!dense_in && !ckks_fused) {
+    // the output ranges [out.data + b out.bstride, + size npw) must not overlap what a later row still reads: when the two batches share memory
+    // (a direct C-ABI caller rescaling a strided batch onto itself) the input is staged first, as every strided input was before the fused path
+    const u64 *in_end = in.data + (batch - 1) * in.bstride + (u64)in.size * pw, *out_end = out.data + (batch - 1) * out.bstride + (u64)in.size * npw;
+    const bool overlaps = out.data < in_end && in.data < out_end;
+    bool staged = false;
+    if ((!dense_in && !ckks_fused) || overlaps) {
+        staged = true;
         u64 *tmp = c.arena.take(batch * in.size * pw);
         launch_copy_strided(in.data, in.bstride, tmp, in.size * pw, in.size * pw, batch, s);
         src = tmp;
@@ -501,14 +507,14 @@ void Evaluator::mod_switch_scale(const CtBatch &in, CtBatch &out, u64 batch, hip
     if (dst == src) throw Error(ST_INVALID_ARGUMENT, "mod switch cannot run in place");
     if (c.scheme == SCHEME_CKKS) {
         u64 *last = c.arena.take(batch * in.size * N), *corr = c.arena.take(batch * in.size * npw);
-        if (ckks_fused && !dense_in) launch_gather_limb(src, last, c.logn, pw, (u64)nl, batch * in.size, s, (u64)in.size, in.bstride);
+        if (ckks_fused && !dense_in && !staged) launch_gather_limb(src, last, c.logn, pw, (u64)nl, batch * in.size, s, (u64)in.size, in.bstride);
         else launch_gather_limb(src, last, c.logn, pw, (u64)nl, batch * in.size, s);
         launch_ntt(last, c.d_desc, c.single_map(L - 1), batch * in.size, c.logn, true, s);
         const LimbMap cmap = c.ct_map(nl);
         const Level &lvl = c.level(L);
         if (ckks_fused) {
             Ntt1Corr cr{last, src, (u64)pw, dst, (u64)in.size * npw, (u64)npw, (unsigned)in.size, lvl.d_inv_qlast, c.primes[L - 1], a.half, false};
-            if (!dense_in) cr.in_gstride = in.bstride;
+            if (!dense_in && !staged) cr.in_gstride = in.bstride;
             launch_ntt1(nullptr, nullptr, c.d_desc, cmap, batch * in.size * nl, false, s, ~0ull, nullptr, &cr);
         } else {
             launch_rescale_stepA(last, N, corr, a, s);

@@ -106,8 +106,8 @@ struct Ntt2Args {
     const u64 *md_share = nullptr; // BGV: [o][N] 128-bit integers al + k_t qk (ks_bgv_share_kernel, poly.hip)
     const u64 *md_base = nullptr;  // not null: accumulate onto (base[b], 0) instead of onto what ct holds
     u64 md_base_bstride = 0;
-    int md_base_polys = 1;
-    int skip_diag = 0;             // CKKS key switch: the (digit k == output slot) rows are not expanded -- the second pass takes them from mac_target         // 2: component 1 reads base[b] + dl * N too (relinearize out of place)
+    int md_base_polys = 1;         // 2: component 1 reads base[b] + dl * N too (relinearize out of place)
+    int skip_diag = 0;             // CKKS key switch: the (digit k == output slot) rows are not expanded -- the second pass takes them from mac_target
     unsigned md_dl = 0;
     // the prime slots this launch covers: workgroup group index -> slot = sel[index] (a launch per prime class: the FP64 instances take the
     // primes below 2^50, the integer instances the rest; partial inverse launches take a range)
@@ -648,6 +648,7 @@ __device__ __forceinline__ void ntt2_body(const Ntt2Args &a) {
         if ((N2_EXP & 8) && !STRIDED) in = a.data + ((r & 63) << logn); // probe: the contiguous pass reads a 16 MB window (L2-resident input)
     };
     constexpr bool DMA = N2_DMA && WAVE_PRIVATE && !(N2_EXP & 1);
+    static_assert(MAC != 3 || DMA, "the CKKS key-switch pass (MAC = 3) takes its rows from the LDS-DMA staging area: build it with N2_DMA = 1 and without the no-HBM probe");
     // plain strided forward passes of two rounds: the next row is requested into a second register set before the last round's butterflies
     // (the registers come from forming the LDS addresses per row, FRESH, so the kernel stays at four waves per SIMD): -2 % on that pass.
     // Not the digit-reducing first pass of key switching, whose L2-resident sources arrive fast enough anyway: +6 % there.
