@@ -79,6 +79,9 @@ int troyhip_stream_destroy(void *stream);
 int troyhip_stream_register(void *stream);
 int troyhip_stream_unregister(void *stream);
 int troyhip_mem_info(size_t *free_bytes, size_t *total_bytes);
+/* "0000:c1:00.0"-style PCI address of a device (hipDeviceGetPCIBusId): bench.py reports it per rank and binds the rank's host thread to the
+ * device's NUMA node (one process per GPU) */
+int troyhip_device_pci_bus_id(int device, char *out, size_t capacity);
 /* HIP-event timers on the caller's stream (bench.py roofline measurement) */
 /* TEST SUPPORT: runs one primitive of the device arithmetic (kernelutils.cuh:94-404 counterparts in modarith.h / bfly.h) on n device
  * operands.  op: 0 barrett64(a), 1 barrett128(a = lo, b = hi), 2 mulmod(a, b), 3 mul_shoup(a, w = b, quotient c), 4 mul_lazy (result

@@ -53,7 +53,7 @@ class ContextInfo(C.Structure):
 SYMBOLS = [
     "troyhip_initialize", "troyhip_is_initialized", "troyhip_last_error", "troyhip_build_info", "troyhip_malloc",
     "troyhip_free", "troyhip_pool_release", "troyhip_copy_h2d", "troyhip_copy_d2h", "troyhip_copy_d2d", "troyhip_memset_zero",
-    "troyhip_stream_synchronize", "troyhip_stream_create", "troyhip_stream_destroy", "troyhip_stream_register", "troyhip_stream_unregister", "troyhip_mem_info", "troyhip_timer_create", "troyhip_timer_destroy",
+    "troyhip_stream_synchronize", "troyhip_stream_create", "troyhip_stream_destroy", "troyhip_stream_register", "troyhip_stream_unregister", "troyhip_mem_info", "troyhip_device_pci_bus_id", "troyhip_timer_create", "troyhip_timer_destroy",
     "troyhip_timer_start", "troyhip_timer_stop", "troyhip_timer_elapsed_ms", "troyhip_coeff_modulus_create",
     "troyhip_plain_modulus_batching", "troyhip_context_create", "troyhip_context_create_host", "troyhip_context_destroy",
     "troyhip_host_keygen", "troyhip_host_relin_key", "troyhip_host_galois_key", "troyhip_host_encrypt", "troyhip_host_encrypt_symmetric", "troyhip_multiply_plain_accumulate", "troyhip_host_decrypt", "troyhip_context_info",

@@ -272,6 +272,17 @@ int troyhip_stream_destroy(void *stream) {
         HIP_CHECK(hipStreamDestroy((hipStream_t)stream));
     });
 }
+int troyhip_device_pci_bus_id(int device, char *out, size_t capacity) {
+    return guard([&] {
+        if (!out || capacity < 16) throw Error(ST_INVALID_ARGUMENT, "pci bus id buffer");
+#ifndef TROYHIP_CPU_EMUL
+        HIP_CHECK(hipDeviceGetPCIBusId(out, (int)capacity, device));
+#else
+        (void)device;
+        std::snprintf(out, capacity, "emul");
+#endif
+    }, false);
+}
 int troyhip_mem_info(size_t *free_bytes, size_t *total_bytes) { return guard([&] { HIP_CHECK(hipMemGetInfo(free_bytes, total_bytes)); }); }
 
 /* device-side probes of the scalar modular arithmetic and the butterfly forms (selftest.hip); all pointers are DEVICE buffers */
