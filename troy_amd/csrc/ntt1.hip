@@ -81,6 +81,20 @@ struct Ntt1Args {
 // together).  Conflict-free for: j = 64 r + lane (rounds A/B, 8-byte accesses), j = 64 (lane / 4) + 4 r + lane % 4 (round C),
 // j = 256 g + 4 lane + {0, 2} (round D, 16-byte reads), j = 128 i + 2 lane (lane-linear 16-byte staging).
 __device__ __forceinline__ unsigned sw1(unsigned j) { return j ^ (((j >> 6) & 7u) << 2) ^ (((j >> 5) & 1u) << 1); }
+// The inverse transform also WRITES 16 bytes per lane at j = 8 u + 2 q (its first round leaves a thread's eight consecutive coefficients);
+// ds_write_b128 is served in groups of 8 consecutive lanes, and under sw1 lanes l and l + 2 of a group meet in one bank (2-way:
+// SQ_LDS_BANK_CONFLICT = 34 % of the inverse kernel's LDS cycles in round 2, 0 in the forward kernel, which only reads that pattern).  One more
+// term -- bit 2 ^= bit 4 -- separates them and keeps every other pattern conflict-free (tools/lds_banks.py); it is no involution any more
+// (bit 4 is both a source and a target), so the LDS-DMA staging, which needs "which element belongs at position x", uses sw2_inv.
+#ifndef N1_INV_SWZ
+#define N1_INV_SWZ 2
+#endif
+__device__ __forceinline__ unsigned sw2(unsigned j) { return N1_INV_SWZ == 2 ? sw1(j) ^ (((j >> 4) & 1u) << 2) : sw1(j); }
+__device__ __forceinline__ unsigned sw2_inv(unsigned x) { // bits 5.. are untouched by sw2: undo bit 4 first, then the term it feeds
+    if (N1_INV_SWZ != 2) return sw1(x);
+    const unsigned y = sw1(x);
+    return y ^ (((y >> 4) & 1u) << 2);
+}
 
 // twiddle loads.  The table pointers come out of a PrimeDesc that was itself loaded from memory, so the compiler would use flat
 // loads; the tables are read-only global memory: per-lane entries go through global loads, workgroup-/wave-uniform entries
@@ -434,7 +448,7 @@ template <bool LEAN, bool CR> __global__ __launch_bounds__(N1_THREADS) void ntt1
 }
 
 // the first 10 inverse stages (14..5) of sub-block sb: input y (this lane's coefficients 8 u + r, u = lane + 64 i, in y[8 i + r]),
-// result left in the wave's region (position sw1(j))
+// result left in the wave's region (position sw2(j))
 template <bool LEAN> __device__ __forceinline__ void inv_subblock(u64 (&yin)[16], u64 *R, const unsigned sb, const unsigned lane_in, const PrimeDesc &pd, const PrimeConst &pc) {
     const Shoup none{0, 0};
     const unsigned lane = opaque(lane_in);
@@ -458,7 +472,7 @@ template <bool LEAN> __device__ __forceinline__ void inv_subblock(u64 (&yin)[16]
             ulonglong2 v;
             v.x = y[2 * q];
             v.y = y[2 * q + 1];
-            *reinterpret_cast<ulonglong2 *>(R + sw1(8 * u + 2 * q)) = v;
+            *reinterpret_cast<ulonglong2 *>(R + sw2(8 * u + 2 * q)) = v;
         }
         N1_SCHED_FENCE();
     }
@@ -476,17 +490,17 @@ template <bool LEAN> __device__ __forceinline__ void inv_subblock(u64 (&yin)[16]
         for (unsigned it = 0; it < 2; it++) {
             u64 y[8];
 #pragma unroll
-            for (int r = 0; r < 8; r++) y[r] = R[sw1(64 * h + 8 * r + 4 * it + low)];
+            for (int r = 0; r < 8; r++) y[r] = R[sw2(64 * h + 8 * r + 4 * it + low)];
             inv_stages<1, 3, false, false, LEAN ? 16 : 0>(y, [&](int st, int, int blk) { return st == 0 ? t11[blk] : (st == 1 ? t10[blk] : t9); }, none, pc); // 16p -> 32p -> (halved) 32p -> 64p
 #pragma unroll
-            for (int r = 0; r < 8; r++) R[sw1(64 * h + 8 * r + 4 * it + low)] = y[r];
+            for (int r = 0; r < 8; r++) R[sw2(64 * h + 8 * r + 4 * it + low)] = y[r];
         }
     }
     TROY_WAVE_SYNC();
     {   // round B': stages 8..5, registers = j6..j9 (bit 0 = j6); twiddles depend on (sb, register) only
         u64 y[16];
 #pragma unroll
-        for (int r = 0; r < 16; r++) y[r] = R[sw1(64 * r + lane)];
+        for (int r = 0; r < 16; r++) y[r] = R[sw2(64 * r + lane)];
         if (LEAN) { // 64p -> 4p, then four stages -> 64p
 #pragma unroll
             for (int q = 0; q < 4; q++) {
@@ -498,7 +512,7 @@ template <bool LEAN> __device__ __forceinline__ void inv_subblock(u64 (&yin)[16]
         }
         inv_stages<1, 4, false, true, LEAN ? 4 : 0>(y, [&](int st, int, int blk) { return ld_tw_uniform(pd.iroot + (N1_N - (512u >> st) + 1) + ((8 * sb) >> st) + blk); }, none, pc);
 #pragma unroll
-        for (int r = 0; r < 16; r++) R[sw1(64 * r + lane)] = y[r];
+        for (int r = 0; r < 16; r++) R[sw2(64 * r + lane)] = y[r];
     }
 }
 
@@ -527,7 +541,7 @@ template <bool LEAN, bool MD> __global__ __launch_bounds__(N1_THREADS) void ntt1
     auto stage_issue = [&](const u64 *sub) {
         const unsigned l = opaque(lane);
 #pragma unroll
-        for (int i = 0; i < 8; i++) TROY_GLDS16(sub + sw1(128 * i + 2 * l), region + 128 * i);
+        for (int i = 0; i < 8; i++) TROY_GLDS16(sub + sw2_inv(128 * i + 2 * l), region + 128 * i);
     };
     auto load16 = [&](u64 (&y)[16], const u64 *sub) { // y[8 i + r] = coefficient 8 (lane + 64 i) + r
 #pragma unroll
@@ -546,7 +560,7 @@ template <bool LEAN, bool MD> __global__ __launch_bounds__(N1_THREADS) void ntt1
         return a.src + (u64)o * a.src_ostride + ((u64)(slot * inner + k) << N1_LOGN);
     };
     stage_issue(in_of(m_begin) + 1024 * wv);
-    const u64 *const rlo = lds + sw1(tid), *const rhi = rlo + 8 * 1024;
+    const u64 *const rlo = lds + sw2(tid), *const rhi = rlo + 8 * 1024;
     for (unsigned mm = m_begin; mm < m_end; mm++) {
         u64 *const row = a.data + row_of(mm);
         u64 x[32]; // x[r] = coefficient tid of sub-block r after its 10 stages
@@ -558,7 +572,7 @@ template <bool LEAN, bool MD> __global__ __launch_bounds__(N1_THREADS) void ntt1
         for (int i = 0; i < 2; i++)
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(region + sw1(8 * (ol + 64 * i) + 2 * q));
+                const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(region + sw2(8 * (ol + 64 * i) + 2 * q));
                 y[8 * i + 2 * q] = v.x;
                 y[8 * i + 2 * q + 1] = v.y;
             }

@@ -54,6 +54,12 @@ namespace troyhip {
 #ifndef N2_TENSOR_WAVES
 #define N2_TENSOR_WAVES 3 // waves per SIMD of the tensor fused kernel: with the LDS addresses formed per row (N2_FRESH_TENSOR) it fits 168 VGPRs
 #endif                    // (196 with hoisted addresses = 2 waves): 1183 -> 1044 us per step, headline +3 %
+#ifndef N2_TENSOR_HOIST1
+#define N2_TENSOR_HOIST1 1 // tensor fused kernel: keep the per-lane twiddles of round 1 / round 2 in registers (0: re-read them per row)
+#endif
+#ifndef N2_TENSOR_HOIST2
+#define N2_TENSOR_HOIST2 1
+#endif
 #ifndef N2_FRESH_TENSOR
 #define N2_FRESH_TENSOR 15
 #endif
@@ -591,8 +597,8 @@ __device__ __forceinline__ void ntt2_body(const Ntt2Args &a) {
     constexpr int Q2 = NR > 2 ? (INV ? P::r[NR - 3] : R2) : 0;
     constexpr int Q3 = NR > 3 ? (INV ? P::r[NR - 4] : R3) : 0;
     using Rd0 = Round<INV, STRIDED, NS, LOGC, 0, Q0>;
-    using Rd1 = Round<INV, STRIDED, NS, LOGC, Q0, Q1 ? Q1 : 1>;
-    using Rd2 = Round<INV, STRIDED, NS, LOGC, Q0 + Q1, Q2 ? Q2 : 1, (MAC != 1 && MAC != 3) || N2_MAC_HOIST>;
+    using Rd1 = Round<INV, STRIDED, NS, LOGC, Q0, Q1 ? Q1 : 1, MAC != 2 || N2_TENSOR_HOIST1>;
+    using Rd2 = Round<INV, STRIDED, NS, LOGC, Q0 + Q1, Q2 ? Q2 : 1, (MAC == 2 ? N2_TENSOR_HOIST2 : (MAC != 1 && MAC != 3) || N2_MAC_HOIST)>;
     using Rd3 = Round<INV, STRIDED, NS, LOGC, Q0 + Q1 + Q2, Q3 ? Q3 : 1>;
 
     const unsigned tile = blockIdx.x & ((1u << a.tiles_per_row_log) - 1);
