@@ -502,17 +502,22 @@ def algorithmic_bytes(w, B):
     kbx, kb1, kb2 = (L + 4) // 4, (L + 3) // 4, (nb + 3) // 4  # k-blocks: extension (L limbs + r), floor stage 1, stage 2 (|B| limbs + alpha)
     small_x, small_f = kbx <= 2 and nb <= 8, kb2 <= 2           # the everything-in-registers kernels of behz2.hip
     add(f"behz2s_extend_kernel<{kbx}, {(nb + 3) // 4}>" if small_x else f"behz2_extend_kernel<{kbx}>", 2 * 2 * B * (L + nb) * P)
-    add(f"ntt2_kernel<0, 1, {k1}, {logc}, 0, 0, 0>", 2 * (2 * B * L) * 2 * P + 2 * (2 * B * nb) * 2 * P)
-    add("ntt2_kernel<0, 0, 9, 0, 1, 0, 2>", 7 * B * (L + nb) * P)
-    inv_rows = 3 * B * (L + nb) + 2 * B * (L + 1)
+    qs_all = [int(p) for p in w.ctx.coeff_modulus]
+    q_primes, special, bsk_primes = qs_all[:L], qs_all[-1:], [1 << 60] * nb  # the BEHZ auxiliary primes are 61 bits: integer kernels
+    _by_prime_class(add, f"ntt2_kernel<0, 1, {k1}, {logc}, 0, 0, 0>", q_primes + bsk_primes, 2 * (2 * B) * 2 * P)
+    _by_prime_class(add, "ntt2_kernel<0, 0, 9, 0, 1, 0, 2>", q_primes + bsk_primes, 7 * B * P)
     md_split = os.environ.get("TROYHIP_MODDOWN", "")[:1] == "s"
     if two_pass:
         # with the mod-down fused (the default) the last pass of the L data limbs of the accumulators reads ct as well and writes ct instead
         # of acc (+ the special limb once per (ciphertext, accumulator)); the special limb goes through both passes on its own
-        add("ntt2_kernel<1, 0, 9, 0, 0, 0, 0>", inv_rows * 2 * P)
-        add(f"ntt2_kernel<1, 1, {k1}, {logc}, 2, 0, 0>", (inv_rows if md_split else inv_rows - 2 * B * L) * 2 * P)
+        _by_prime_class(add, "ntt2_kernel<1, 0, 9, 0, 0, 0, 0>", q_primes, (3 * B + 2 * B) * 2 * P)       # multiply: 3 polynomials; key switch: 2 accumulators
+        _by_prime_class(add, "ntt2_kernel<1, 0, 9, 0, 0, 0, 0>", bsk_primes, 3 * B * 2 * P)
+        _by_prime_class(add, "ntt2_kernel<1, 0, 9, 0, 0, 0, 0>", special, 2 * B * 2 * P)
+        _by_prime_class(add, f"ntt2_kernel<1, 1, {k1}, {logc}, 2, 0, 0>", q_primes, ((3 * B + 2 * B) if md_split else 3 * B) * 2 * P)
+        _by_prime_class(add, f"ntt2_kernel<1, 1, {k1}, {logc}, 2, 0, 0>", bsk_primes, 3 * B * 2 * P)
+        _by_prime_class(add, f"ntt2_kernel<1, 1, {k1}, {logc}, 2, 0, 0>", special, 2 * B * 2 * P)
         if not md_split:
-            add(f"ntt2_kernel<1, 1, {k1}, {logc}, 3, 0, 0>", 2 * B * L * 3 * P + 2 * B * P)
+            _by_prime_class(add, f"ntt2_kernel<1, 1, {k1}, {logc}, 3, 0, 0>", q_primes, 2 * B * 3 * P + 2 * B * P / L)
     else:
         # the single-pass inverse runs as two launches by prime class: guard-free rounds below 2^58, guarded butterflies for the rest
         qs = [int(p) for p in w.ctx.coeff_modulus]
@@ -537,6 +542,20 @@ def algorithmic_bytes(w, B):
 
 
 FP_MAX_BITS = 50  # troy_amd/csrc/fpmod.h: primes below 2^50 run the FP64 instances (ntt2_fp_kernel) unless TROYHIP_FP64=off
+
+
+def _fp_on():
+    return os.environ.get("TROYHIP_FP64", "") != "off"
+
+
+def _by_prime_class(add, name, primes, per_limb_bytes):
+    """bytes of a two-pass kernel split over its two launches: the limbs whose prime lies below 2^50 run the FP64 instance (same template
+    arguments, kernel name ntt2_fp_kernel), the others the integer one"""
+    nf = sum(1 for p in primes if _fp_on() and int(p) < (1 << FP_MAX_BITS))
+    if nf:
+        add(name.replace("ntt2_kernel", "ntt2_fp_kernel"), nf * per_limb_bytes)
+    if len(primes) - nf:
+        add(name, (len(primes) - nf) * per_limb_bytes)
 
 
 def _ks_forward_pair(add, w, B, l, logn, ckks):
@@ -566,11 +585,12 @@ def _ks_two_pass(add, w, B, L, P, logn, kind):
     k1 = logn - 9 if logn - 9 <= 7 else 7
     logc = 11 - k1
     _ks_forward_pair(add, w, B, L, logn, False)                                                                 # digits read once, (L+1) L expanded limbs written and read, the key once, 2 (L+1) accumulator limbs written
-    add("ntt2_kernel<1, 0, 9, 0, 0, 0, 0>", 2 * B * (L + 1) * 2 * P)                                            # first inverse pass of every accumulator limb
-    add(f"ntt2_kernel<1, 1, {k1}, {logc}, 2, 0, 0>", 2 * B * 2 * P)                                             # the special limb's last pass
+    qs = [int(p) for p in w.ctx.coeff_modulus]
+    _by_prime_class(add, "ntt2_kernel<1, 0, 9, 0, 0, 0, 0>", qs[:L] + qs[-1:], 2 * B * 2 * P)                   # first inverse pass of every accumulator limb
+    _by_prime_class(add, f"ntt2_kernel<1, 1, {k1}, {logc}, 2, 0, 0>", qs[-1:], 2 * B * 2 * P)                    # the special limb's last pass
     if kind == 4:
         add("ks_bgv_share_kernel", 2 * B * 3 * P)                                                               # special limb read, 128-bit shares written
-    add(f"ntt2_kernel<1, 1, {k1}, {logc}, {kind}, 0, 0>", 2 * B * L * 3 * P + 2 * B * (2 if kind == 4 else 1) * P)  # acc + ct read, ct written, shares / special limb once
+    _by_prime_class(add, f"ntt2_kernel<1, 1, {k1}, {logc}, {kind}, 0, 0>", qs[:L], 2 * B * 3 * P + 2 * B * (2 if kind == 4 else 1) * P / L)  # acc + ct read, ct written, shares / special limb once
 
 
 def algorithmic_bytes_relin_rot(w, B):
@@ -616,8 +636,8 @@ def algorithmic_bytes_ckks_chain(w, B):
         # CKKS: the l rows (digit k == output slot) are the NTT-form input itself: not expanded by the first pass, read from the target by the second
         _ks_forward_pair(add, w, B, l, 15, True)
         add("gather_limb_kernel", 2 * B * 2 * P)
-        add("ntt2_kernel<1, 0, 9, 0, 0, 0, 0>", 2 * B * 2 * P)                                       # the special limb of the accumulators (2 B rows: two-pass)
-        add("ntt2_kernel<1, 1, 6, 5, 2, 0, 0>", 2 * B * 2 * P)
+        _by_prime_class(add, "ntt2_kernel<1, 0, 9, 0, 0, 0, 0>", qs[-1:], 2 * B * 2 * P)              # the special limb of the accumulators (2 B rows: two-pass)
+        _by_prime_class(add, "ntt2_kernel<1, 1, 6, 5, 2, 0, 0>", qs[-1:], 2 * B * 2 * P)
         by_class("ntt1_fwd_kernel", "true", range(l), 2 * B * 3 * P)                                # per row: accumulator + ciphertext read, ciphertext written
         add("ntt1_fwd_kernel<true, true>", 2 * B * P)                                                # the coefficient-form special limb, once per item
 
@@ -626,8 +646,8 @@ def algorithmic_bytes_ckks_chain(w, B):
         add("tensor_kernel<2, 2>", B * l * 7 * P)
         ks(l)
         add("gather_limb_kernel", 2 * B * 2 * P)                                                     # rescale: dropped limb out, inverse, correction transform
-        add("ntt2_kernel<1, 0, 9, 0, 0, 0, 0>", 2 * B * 2 * P)
-        add("ntt2_kernel<1, 1, 6, 5, 2, 0, 0>", 2 * B * 2 * P)
+        _by_prime_class(add, "ntt2_kernel<1, 0, 9, 0, 0, 0, 0>", qs[l - 1:l], 2 * B * 2 * P)
+        _by_prime_class(add, "ntt2_kernel<1, 1, 6, 5, 2, 0, 0>", qs[l - 1:l], 2 * B * 2 * P)
         by_class("ntt1_fwd_kernel", "true", range(l - 1), 2 * B * 2 * P)
         add("ntt1_fwd_kernel<true, true>", 2 * B * P)
         add("galois_ntt_kernel", 2 * B * (l - 1) * 2 * P)

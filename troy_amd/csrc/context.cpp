@@ -232,6 +232,12 @@ static bool fp_allowed() {
     return on;
 }
 static bool fp_prime(u64 p) { return fp_allowed() && p < (u64(1) << TROY_FP_MAX_BITS); }
+// the FP64 twins of the two scalar constants of a descriptor; call again whenever inv_n / iroot_last_scaled are rescaled
+static void set_fp_consts(PrimeDesc &d) {
+    auto pair = [&](const Shoup &w) { return Shoup{fp_bits((double)w.op), fp_bits((double)w.op / (double)d.p)}; };
+    d.inv_n_fp = d.root_fp ? pair(d.inv_n) : Shoup{0, 0};
+    d.iroot_last_scaled_fp = d.root_fp ? pair(d.iroot_last_scaled) : Shoup{0, 0};
+}
 LimbMap Context::ct_map(int limbs) const {
     LimbMap m;
     std::memset(&m, 0, sizeof(m));
@@ -240,6 +246,7 @@ LimbMap Context::ct_map(int limbs) const {
     m.inner = 1;
     for (int i = 0; lean_allowed() && i < limbs && i < 64; i++) m.lean |= (u64)(primes[i] >= (u64(1) << 33) && primes[i] < (u64(1) << 58)) << i;
     for (int i = 0; i < limbs && i < 64; i++) m.fp |= (u64)fp_prime(primes[i]) << i;
+    m.host_primes = primes.data();
     return m;
 }
 LimbMap Context::ids_map(const std::vector<uint8_t> &ids, uint32_t inner) const {
@@ -251,6 +258,7 @@ LimbMap Context::ids_map(const std::vector<uint8_t> &ids, uint32_t inner) const 
     m.inner = inner;
     for (size_t i = 0; lean_allowed() && i < ids.size(); i++) m.lean |= (u64)(primes[ids[i]] >= (u64(1) << 33) && primes[ids[i]] < (u64(1) << 58)) << i;
     for (size_t i = 0; i < ids.size(); i++) m.fp |= (u64)fp_prime(primes[ids[i]]) << i;
+    m.host_primes = primes.data();
     return m;
 }
 LimbMap Context::single_map(int id) const { return ids_map({(uint8_t)id}); }
@@ -287,6 +295,7 @@ void Context::upload_tables() {
             d.root_fp = upload(to_fp(tb.root), dev_allocs_);
             d.iroot_fp = upload(to_fp(tb.iroot), dev_allocs_);
         }
+        set_fp_consts(d);
     }
     d_desc = upload(h_desc, dev_allocs_);
     if (scheme == SCHEME_CKKS) { // per-slot inverses of the prime a divide-and-round drops, for the fused correction transform (ntt1.hip)
@@ -312,6 +321,7 @@ void Context::upload_tables() {
             d.inv_n = make_shoup(host::mul_mod(d.inv_n.op, f, d.p), d.p);
             d.iroot_last_scaled = make_shoup(host::mul_mod(d.iroot_last_scaled.op, f, d.p), d.p);
             d.aux = make_shoup(f, d.p);
+            set_fp_consts(d);
         }
         d_desc_md = upload(md, dev_allocs_);
     }
@@ -459,6 +469,7 @@ void Context::upload_tables() {
                 auto scale = [&](PrimeDesc &d, u64 f) {
                     d.inv_n = make_shoup(host::mul_mod(d.inv_n.op, f % d.p, d.p), d.p);
                     d.iroot_last_scaled = make_shoup(host::mul_mod(d.iroot_last_scaled.op, f % d.p, d.p), d.p);
+                    set_fp_consts(d);
                 };
                 for (int l = 0; l < L; l++) scale(fd[l], floor_pre[l].op);
                 for (int o = 0; o < nBsk; o++) scale(fd[lv.bsk_ids[o]], f1t[o].op);

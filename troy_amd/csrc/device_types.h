@@ -16,6 +16,7 @@ struct PrimeDesc {
     // primes below 2^50 only (else nullptr): the same tables as pairs of doubles (w, w / p) for the FP64 butterflies (fpmod.h), as bit patterns
     const Shoup *root_fp;
     const Shoup *iroot_fp;
+    Shoup inv_n_fp, iroot_last_scaled_fp; // (w, w / p) of inv_n / iroot_last_scaled as they stand in THIS descriptor (the derived tables rescale them)
 };
 __host__ __device__ inline Mod mod_of(const PrimeDesc &d) { return Mod{d.p, d.cr0, d.cr1}; }
 
@@ -25,6 +26,8 @@ struct LimbMap {
     uint32_t period, inner;
     uint64_t lean; // bit i: the prime of slot i lies in [2^33, 2^58) -- guard-free butterflies apply (bfly.h); host-side dispatch only
     uint64_t fp;   // bit i: the prime of slot i lies below 2^50 and has FP64 tables -- the FP64 instances apply (fpmod.h); host-side dispatch only
+    const uint64_t *host_primes; // HOST pointer (never dereferenced on the device): the context's prime registry, indexed by id[] -- the launchers
+                                 // walk the FP64 value bounds with it; nullptr: integer kernels only
 };
 
 #define TROY_BUF_OOB 0x80000000u // an offset no buffer range reaches (ranges are < 2^31 bytes)

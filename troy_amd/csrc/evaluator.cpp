@@ -335,7 +335,7 @@ void Evaluator::switch_key(CtBatch &ct, const u64 *target, u64 t_bstride, const 
             lazy = lazy && (long double)dl * bound * p * p < 3.0e38L; // 2^128 = 3.4e38
         }
         launch_ntt2_ks_mac(D, coeff_target, ct_tb, c.d_desc, ks_map, batch * rl * dl, c.logn, key.data, acc, a.key_limb, (unsigned)K,
-                           mac_target, t_bstride, lazy, src_bound, c.primes.data(), s);
+                           mac_target, t_bstride, lazy, src_bound, s);
     } else {
         if (ntt2_supported(c.logn)) {
             launch_ntt2(D, coeff_target, ct_tb, true, c.d_desc, c.ids_map(out_ids, (uint32_t)dl), batch * rl * dl, c.logn, false, s, false, src_bound);

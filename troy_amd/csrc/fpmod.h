@@ -89,4 +89,23 @@ inline FpPlan fp_plan(u64 pmax, double b_in, const int *rounds, int n_rounds) {
     return out;
 }
 
+// inverse (Gentleman-Sande) stages: X' = X + Y doubles the bound per stage (Y' comes out of a multiplication, below 1/2 + 2 b p 2^-52 <= 5/2);
+// a stage's outputs must stay within 2^53, i.e. a round of R stages needs 2^R b <= lim.  Reduction sites: before each round.
+inline FpPlan fp_plan_inv(u64 pmax, double b_in, const int *rounds, int n_rounds) {
+    const double p = (double)pmax, lim = 0x1p53 / p;
+    FpPlan out{0, b_in};
+    double b = b_in;
+    for (int r = 0; r < n_rounds; r++) {
+        double t = std::ldexp(b, rounds[r]);
+        if (t > lim) {
+            out.mask |= 1u << r;
+            t = std::ldexp(0.5 + 0x1p-40, rounds[r]);
+            if (t > lim) { out.mask = ~0u; out.out_bound = -1.0; return out; } // cannot be scheduled at round granularity: the caller keeps the integer kernels
+        }
+        b = t < 2.5 ? 2.5 : t;
+    }
+    out.out_bound = b;
+    return out;
+}
+
 } // namespace troyhip

@@ -229,8 +229,28 @@ template <int INV, int STRIDED, int NS, int LOGC, int LS, int R, bool HOISTP = t
     // lean (forward only, wave-uniform): the prime is below 2^58 -- guard-free butterflies, every stage adds at most 3p to the
     // value bound (8p at the input of the first pass + 3p * 17 stages at most = 59p < 2^64); the caller reduces with barrett64
     // FP64 form (fpmod.h): x holds the bit patterns of doubles, tw those of (w, w / p); forward stages only
-    __device__ static __forceinline__ void compute_fp(u64 (&x)[8], const Shoup (&tw)[G][NTW], const FpPrime &fc) {
-        static_assert(!INV, "the FP64 butterflies are built for the forward passes");
+    __device__ static __forceinline__ void compute_fp(u64 (&x)[8], const Shoup (&tw)[G][NTW], const FpPrime &fc, const Shoup inv_n = Shoup{0, 0}) {
+        if constexpr (INV) { // Gentleman-Sande: X' = X + Y, Y' = (X - Y) w; the last stage of the transform multiplies both outputs (N^-1 folded in)
+#pragma unroll
+            for (int st = 0; st < R; st++) {
+                const int dist = 1 << st, off = (1 << R) - ((1 << R) >> st);
+                const bool last = STRIDED && (LS + st == NS - 1);
+#pragma unroll
+                for (int u = 0; u < G; u++)
+#pragma unroll
+                    for (int blk = 0; blk < ((1 << R) >> (st + 1)); blk++)
+#pragma unroll
+                        for (int k = 0; k < dist; k++) {
+                            const int ix = (u << R) + blk * 2 * dist + k, iy = ix + dist;
+                            const Shoup &w = tw[u][off + blk];
+                            const double X = fp_of_bits(x[ix]), Y = fp_of_bits(x[iy]);
+                            const double sum = X + Y, dif = X - Y;
+                            x[ix] = fp_bits(last ? fp_mulmod_wp(sum, fp_of_bits(inv_n.op), fp_of_bits(inv_n.quo), fc) : sum);
+                            x[iy] = fp_bits(fp_mulmod_wp(dif, fp_of_bits(w.op), fp_of_bits(w.quo), fc));
+                        }
+            }
+            return;
+        }
 #pragma unroll
         for (int st = 0; st < R; st++) {
 #pragma unroll
@@ -374,9 +394,12 @@ template <int INV, int STRIDED, int NS, int LOGC, int LS, int R, bool HOISTP = t
     // ([0, 8p)) of this thread's 8 consecutive coefficients.  Rows 0..2 are parked canonical in tx; row 3 completes the
     // tensor (evaluator.cpp:626-702: every product reduced, the two middle products added modulo p).
     __device__ static __forceinline__ void tensor_epilogue(u64 (&x)[8], u64 (&tx)[3][8], unsigned mm, u64 *out, unsigned period, unsigned slot, unsigned tile, int logn,
-                                                           const Mod &m, u64 *xchg, const bool lean) {
+                                                           const Mod &m, u64 *xchg, const bool lean, const FpPrime *fc = nullptr) {
         const PrimeConst pc = make_prime_const(m.p);
-        if (lean) { // guard-free transform: values below 59p
+        if (fc) {
+#pragma unroll
+            for (int e = 0; e < 8; e++) x[e] = fp_canonical(fp_of_bits(x[e]), *fc, m.p);
+        } else if (lean) { // guard-free transform: values below 59p
             lean_final<8>(x, make_lean_final(m.p, m.cr1), pc);
         } else {
 #pragma unroll
@@ -452,8 +475,13 @@ template <int INV, int STRIDED, int NS, int LOGC, int LS, int R, bool HOISTP = t
         (void)m;
     }
     // FINAL: 0 keep lazy range, 1 forward final ([0,8p) -> [0,p)), 2 inverse final ([0,4p) -> [0,p))
-    template <int FINAL> __device__ static __forceinline__ void g_write(u64 (&x)[8], u64 *row, unsigned tile, int logn, const Mod &m, const bool lean, u64 *xchg = nullptr) {
+    template <int FINAL> __device__ static __forceinline__ void g_write(u64 (&x)[8], u64 *row, unsigned tile, int logn, const Mod &m, const bool lean, u64 *xchg = nullptr,
+                                                                        const FpPrime *fc = nullptr) {
         const u64 p = m.p;
+        if (FINAL && fc) { // FP64 instance: the doubles become canonical words, then the common store code (which skips its own reduction)
+#pragma unroll
+            for (int e = 0; e < 8; e++) x[e] = fp_canonical(fp_of_bits(x[e]), *fc, p);
+        }
         if (N2_EXP & 1) {
             u64 acc = 0;
 #pragma unroll
@@ -461,7 +489,8 @@ template <int INV, int STRIDED, int NS, int LOGC, int LS, int R, bool HOISTP = t
             if (acc == 0x123456789abcdefull) row[threadIdx.x] = acc; // never true in practice; keeps the work alive
             return;
         }
-        if (FINAL == 1 && lean) { // guard-free forward transform: values below 59p
+        if (FINAL && fc) {
+        } else if (FINAL == 1 && lean) { // guard-free forward transform: values below 59p
             lean_final<8>(x, make_lean_final(m.p, m.cr1), make_prime_const(p));
         } else if (FINAL) {
             const PrimeConst pc = make_prime_const(p);
@@ -504,7 +533,7 @@ template <int INV, int STRIDED, int NS, int LOGC, int LS, int R, bool HOISTP = t
     //   BGV: ct[b][k][slot][n] += x - [al + k_t qk]_p qk^-1,   k_t = -al qk^-1 mod t; the integer al + k_t qk comes from md_share
     // every term canonical before the final addition, as in the element-wise kernel: same residues, same stored values.
     template <int FINAL> __device__ static __forceinline__ void md_write(u64 (&x)[8], const Ntt2Args &a, unsigned o, unsigned slot, unsigned tile, int logn, const Mod &m,
-                                                                         const PrimeDesc &pd) {
+                                                                         const PrimeDesc &pd, const FpPrime *fc = nullptr) {
         static_assert(INV && STRIDED && G == 1, "the mod-down epilogue belongs to the last inverse pass");
         const u64 p = m.p;
         const PrimeConst pc = make_prime_const(p);
@@ -517,7 +546,12 @@ template <int INV, int STRIDED, int NS, int LOGC, int LS, int R, bool HOISTP = t
 #pragma unroll
         for (int h = 0; h < 2; h++) {
             u64 v[4] = {x[4 * h], x[4 * h + 1], x[4 * h + 2], x[4 * h + 3]};
-            reduce4_from_4p(v, pc);
+            if (fc) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) v[i] = fp_canonical(fp_of_bits(v[i]), *fc, p);
+            } else {
+                reduce4_from_4p(v, pc);
+            }
             u64 al[4], ah[4], c[4];
             unsigned n[4];
 #pragma unroll
@@ -560,7 +594,7 @@ template <> struct Plan<11> { static constexpr int r[4] = {3, 3, 3, 2}; };
 // twiddles are (w, w / p) from PrimeDesc::root_fp, every data movement (HBM, LDS, LDS-DMA) is the same 64-bit traffic as in the integer form
 template <int INV, int STRIDED, int NS, int LOGC, int FINAL, int REDUCE, int MAC, int FP>
 __device__ __forceinline__ void ntt2_body(const Ntt2Args &a) {
-    static_assert(!FP || (!INV && ((STRIDED && REDUCE && !FINAL) || MAC == 1 || MAC == 3)), "FP64 instances: the forward pair of key switching");
+    static_assert(!FP || !(INV && MAC), "FP64 instances: every pass of the two-pass transform and its fusions");
     __shared__ u64 lds[2][N2_T];
     using P = Plan<NS>;
     // NS == 9, contiguous: every 512-point sub-transform is owned by ONE wave in every round (thread t's points never
@@ -608,8 +642,10 @@ __device__ __forceinline__ void ntt2_body(const Ntt2Args &a) {
     const unsigned sidx = a.slot_fastest ? grp % a.nsel : grp / a.chunks, chunk = a.slot_fastest ? grp / a.nsel : grp % a.chunks;
     const unsigned slot = (unsigned)__builtin_amdgcn_readfirstlane((int)a.sel[sidx]);
     PrimeDesc pd = a.primes[a.map.id[slot]];
-    if constexpr (FP) { pd.root = pd.root_fp; pd.iroot = pd.iroot_fp; }
-    const FpPrime fc = make_fp_prime(FP ? pd.p : 1);
+    if constexpr (FP) { pd.root = pd.root_fp; pd.iroot = pd.iroot_fp; pd.inv_n = pd.inv_n_fp; pd.iroot_last_scaled = pd.iroot_last_scaled_fp; }
+    const FpPrime fc_ = make_fp_prime(FP ? pd.p : 1);
+    const FpPrime &fc = fc_;
+    const FpPrime *const fcp = FP ? &fc_ : nullptr;
     const Mod m = mod_of(pd);
     const bool need_reduce = !FP && REDUCE && (a.src_bound == 0 || (pd.p >> 61) != 0 || a.src_bound > 8 * pd.p);
     const bool lean = !INV && ((a.map.lean >> slot) & 1); // wave-uniform: prime below 2^58 -> guard-free forward butterflies (bfly.h)
@@ -760,18 +796,18 @@ __device__ __forceinline__ void ntt2_body(const Ntt2Args &a) {
             if (!diag) {
                 u64 *buf = lds[0];
                 fp_guard(x, 0);
-                if constexpr (FP) Rd0::compute_fp(x, tw0, fc); else Rd0::compute(x, tw0, pd, lean);
+                if constexpr (FP) Rd0::compute_fp(x, tw0, fc, pd.inv_n); else Rd0::compute(x, tw0, pd, lean);
                 Rd0::lds_write(x, buf, (FRESH & 1) ? n2_opaque(threadIdx.x) : threadIdx.x);
                 round_sync();
                 Rd1::lds_read(x, buf, (FRESH & 2) ? n2_opaque(threadIdx.x) : threadIdx.x);
                 fp_guard(x, 1);
-                if constexpr (FP) Rd1::compute_fp(x, tw1, fc); else Rd1::compute(x, tw1, pd, lean);
+                if constexpr (FP) Rd1::compute_fp(x, tw1, fc, pd.inv_n); else Rd1::compute(x, tw1, pd, lean);
                 Rd1::lds_write(x, buf, (FRESH & 4) ? n2_opaque(threadIdx.x) : threadIdx.x);
                 round_sync();
                 if constexpr (!Rd2::HOIST) Rd2::load_tw(tw2, pd, tile, logn, s_first);
                 Rd2::lds_read(x, buf, (FRESH & 8) ? n2_opaque(threadIdx.x) : threadIdx.x);
                 fp_guard(x, 2);
-                if constexpr (FP) Rd2::compute_fp(x, tw2, fc); else Rd2::compute(x, tw2, pd, lean);
+                if constexpr (FP) Rd2::compute_fp(x, tw2, fc, pd.inv_n); else Rd2::compute(x, tw2, pd, lean);
                 if constexpr (FP) {
                 } else if (!a.mac_lazy && lean) {
 #pragma unroll
@@ -823,12 +859,15 @@ __device__ __forceinline__ void ntt2_body(const Ntt2Args &a) {
             }
 #pragma unroll
             for (int e = 0; e < 8; e++) x[e] = fp_bits(fp_from_u64(x[e]));
+        } else if constexpr (FP && ((!INV && STRIDED) || (INV && !STRIDED))) { // first pass of a plain transform: canonical residues of this row's own prime
+#pragma unroll
+            for (int e = 0; e < 8; e++) x[e] = fp_bits(fp_from_u64(x[e]));
         }
         fp_guard(x, 0);
-        if constexpr (FP) Rd0::compute_fp(x, tw0, fc); else Rd0::compute(x, tw0, pd, lean);
+        if constexpr (FP) Rd0::compute_fp(x, tw0, fc, pd.inv_n); else Rd0::compute(x, tw0, pd, lean);
         if constexpr (NR == 1) {
-            if constexpr (FINAL >= 3) Rd0::template md_write<FINAL>(x, a, mm, slot, tile, logn, m, pd);
-            else Rd0::template g_write<FINAL>(x, row, tile, logn, m, lean);
+            if constexpr (FINAL >= 3) Rd0::template md_write<FINAL>(x, a, mm, slot, tile, logn, m, pd, fcp);
+            else Rd0::template g_write<FINAL>(x, row, tile, logn, m, lean, nullptr, fcp);
         } else {
             Rd0::lds_write(x, buf, (FRESH & 1) ? n2_opaque(threadIdx.x) : threadIdx.x);
             round_sync();
@@ -842,19 +881,19 @@ __device__ __forceinline__ void ntt2_body(const Ntt2Args &a) {
                 }
             }
             fp_guard(x, 1);
-            if constexpr (FP) Rd1::compute_fp(x, tw1, fc); else Rd1::compute(x, tw1, pd, lean);
+            if constexpr (FP) Rd1::compute_fp(x, tw1, fc, pd.inv_n); else Rd1::compute(x, tw1, pd, lean);
             if constexpr (NR == 2) {
-                if constexpr (FINAL >= 3) Rd1::template md_write<FINAL>(x, a, mm, slot, tile, logn, m, pd);
-                else Rd1::template g_write<FINAL>(x, row, tile, logn, m, lean);
+                if constexpr (FINAL >= 3) Rd1::template md_write<FINAL>(x, a, mm, slot, tile, logn, m, pd, fcp);
+                else Rd1::template g_write<FINAL>(x, row, tile, logn, m, lean, nullptr, fcp);
             } else {
                 Rd1::lds_write(x, buf, (FRESH & 4) ? n2_opaque(threadIdx.x) : threadIdx.x);
                 round_sync();
                 if constexpr (!Rd2::HOIST) Rd2::load_tw(tw2, pd, tile, logn, s_first);
                 Rd2::lds_read(x, buf, (FRESH & 8) ? n2_opaque(threadIdx.x) : threadIdx.x);
                 fp_guard(x, 2);
-                if constexpr (FP) Rd2::compute_fp(x, tw2, fc); else Rd2::compute(x, tw2, pd, lean);
+                if constexpr (FP) Rd2::compute_fp(x, tw2, fc, pd.inv_n); else Rd2::compute(x, tw2, pd, lean);
                 if constexpr (NR == 3 && MAC == 2) {
-                    Rd2::tensor_epilogue(x, tx, mm, a.tensor_out, period, slot, tile, logn, m, WAVE_PRIVATE ? buf : nullptr, lean);
+                    Rd2::tensor_epilogue(x, tx, mm, a.tensor_out, period, slot, tile, logn, m, WAVE_PRIVATE ? buf : nullptr, lean, fcp);
                 } else if constexpr (NR == 3 && KS) {
                     // the transform of digit k of (o, slot) stays in registers: acc_c += x (.) key[k][c][limb(slot)].  x is lazy, in
                     // [0, 8p); it is only normalised when dl * 8p * p could overflow the 128-bit accumulator (mac_lazy == 0)
@@ -874,16 +913,16 @@ __device__ __forceinline__ void ntt2_body(const Ntt2Args &a) {
                     }
                     mac_row(x, kv, mm - m_begin);
                 } else if constexpr (NR == 3) {
-                    if constexpr (FINAL >= 3) Rd2::template md_write<FINAL>(x, a, mm, slot, tile, logn, m, pd);
-                    else Rd2::template g_write<FINAL>(x, row, tile, logn, m, lean, WAVE_PRIVATE ? buf : nullptr);
+                    if constexpr (FINAL >= 3) Rd2::template md_write<FINAL>(x, a, mm, slot, tile, logn, m, pd, fcp);
+                    else Rd2::template g_write<FINAL>(x, row, tile, logn, m, lean, WAVE_PRIVATE ? buf : nullptr, fcp);
                 } else {
                     Rd2::lds_write(x, buf, (FRESH & 16) ? n2_opaque(threadIdx.x) : threadIdx.x);
                     round_sync();
                     if constexpr (!Rd3::HOIST) Rd3::load_tw(tw3, pd, tile, logn, s_first);
                     Rd3::lds_read(x, buf, (FRESH & 32) ? n2_opaque(threadIdx.x) : threadIdx.x);
                     fp_guard(x, 3);
-                    if constexpr (FP) Rd3::compute_fp(x, tw3, fc); else Rd3::compute(x, tw3, pd, lean);
-                    Rd3::template g_write<FINAL>(x, row, tile, logn, m, lean);
+                    if constexpr (FP) Rd3::compute_fp(x, tw3, fc, pd.inv_n); else Rd3::compute(x, tw3, pd, lean);
+                    Rd3::template g_write<FINAL>(x, row, tile, logn, m, lean, nullptr, fcp);
                 }
             }
         }
@@ -944,27 +983,59 @@ bool ntt2_supported(int logn) { return logn >= 12 && logn <= 17; }
 #else
 #define N2_KTAG(...)
 #endif
-template <int INV, int STRIDED, int NS, int LOGC, int FINAL, int REDUCE> static void launch_one(const Ntt2Args &a, unsigned blocks, hipStream_t s) {
+template <int INV, int STRIDED, int NS, int LOGC, int FINAL, int REDUCE> static void launch_one(const Ntt2Args &a, unsigned blocks, hipStream_t s, bool fp = false) {
+    if (fp) {
+        N2_KTAG("ntt2_fp_kernel<%d, %d, %d, %d, %d, %d, 0>", INV, STRIDED, NS, LOGC, FINAL, REDUCE);
+        TROY_LAUNCH(HIP_KERNEL_NAME(ntt2_fp_kernel<INV, STRIDED, NS, LOGC, FINAL, REDUCE>), dim3(blocks), dim3(N2_THREADS), 0, s, a);
+        launch_check("ntt2_fp_kernel");
+        return;
+    }
     N2_KTAG("ntt2_kernel<%d, %d, %d, %d, %d, %d, 0>", INV, STRIDED, NS, LOGC, FINAL, REDUCE); // the instance's name as rocprofv3 prints it
     TROY_LAUNCH(HIP_KERNEL_NAME(ntt2_kernel<INV, STRIDED, NS, LOGC, FINAL, REDUCE>), dim3(blocks), dim3(N2_THREADS), 0, s, a);
     launch_check("ntt2_kernel");
 }
-template <int INV, int NS> static void launch_contig(const Ntt2Args &a, unsigned blocks, bool final_pass, hipStream_t s) {
-    if (final_pass) launch_one<INV, 0, NS, 0, INV ? 2 : 1, 0>(a, blocks, s);
-    else launch_one<INV, 0, NS, 0, 0, 0>(a, blocks, s);
+template <int INV, int NS> static void launch_contig(const Ntt2Args &a, unsigned blocks, bool final_pass, hipStream_t s, bool fp = false) {
+    if (final_pass) launch_one<INV, 0, NS, 0, INV ? 2 : 1, 0>(a, blocks, s, fp);
+    else launch_one<INV, 0, NS, 0, 0, 0>(a, blocks, s, fp);
 }
-template <int INV, int NS> static void launch_strided(const Ntt2Args &a, unsigned blocks, bool final_pass, bool reduce, hipStream_t s, int md_kind = -1, bool skip_diag = false) {
+template <int INV, int NS> static void launch_strided(const Ntt2Args &a, unsigned blocks, bool final_pass, bool reduce, hipStream_t s, int md_kind = -1, bool skip_diag = false,
+                                                      bool fp = false) {
     constexpr int LOGC = N2_LOGT - NS;
     if (INV) { // the strided pass is the last inverse pass
-        if (md_kind == 0) launch_one<1, 1, NS, LOGC, 3, 0>(a, blocks, s);
-        else if (md_kind == 2) launch_one<1, 1, NS, LOGC, 4, 0>(a, blocks, s);
-        else launch_one<1, 1, NS, LOGC, 2, 0>(a, blocks, s);
+        if (md_kind == 0) launch_one<1, 1, NS, LOGC, 3, 0>(a, blocks, s, fp);
+        else if (md_kind == 2) launch_one<1, 1, NS, LOGC, 4, 0>(a, blocks, s, fp);
+        else launch_one<1, 1, NS, LOGC, 2, 0>(a, blocks, s, fp);
     } else {
         (void)final_pass;
-        if (reduce && skip_diag) launch_one<0, 1, NS, LOGC, 0, 2>(a, blocks, s);
-        else if (reduce) launch_one<0, 1, NS, LOGC, 0, 1>(a, blocks, s);
-        else launch_one<0, 1, NS, LOGC, 0, 0>(a, blocks, s);
+        if (reduce && skip_diag) launch_one<0, 1, NS, LOGC, 0, 2>(a, blocks, s, fp);
+        else if (reduce) launch_one<0, 1, NS, LOGC, 0, 1>(a, blocks, s, fp);
+        else launch_one<0, 1, NS, LOGC, 0, 0>(a, blocks, s, fp);
     }
+}
+// stages per round of the two passes, in execution order (forward: Plan<>::r as written; inverse: reversed)
+static int pass_rounds(int ns, bool inverse, int (&out)[4]) {
+    const int *r = nullptr;
+    switch (ns) {
+    case 3: r = Plan<3>::r; break;
+    case 4: r = Plan<4>::r; break;
+    case 5: r = Plan<5>::r; break;
+    case 6: r = Plan<6>::r; break;
+    case 7: r = Plan<7>::r; break;
+    case 9: r = Plan<9>::r; break;
+    case 10: r = Plan<10>::r; break;
+    default: r = Plan<11>::r; break;
+    }
+    int n = 0;
+    for (int i = 0; i < 4; i++) if (r[i]) n++;
+    for (int i = 0; i < n; i++) out[i] = inverse ? r[n - 1 - i] : r[i];
+    return n;
+}
+// the output slots of a launch by class: FP64 instances for the primes below 2^50 (map.fp), the integer instances for the rest
+static unsigned select_class(const LimbMap &map, unsigned slot_begin, unsigned slot_count, bool fp, uint8_t (&sel)[64]) {
+    unsigned n = 0;
+    for (unsigned i = slot_begin; i < slot_begin + slot_count; i++)
+        if ((bool)((map.fp >> i) & 1) == fp) sel[n++] = (uint8_t)i;
+    return n;
 }
 
 // rows are laid out r = (o * period + i) * inner + k; src (optional, forward only): item o, digit k at src + o*src_ostride + k*N
@@ -973,9 +1044,11 @@ void launch_ntt2(u64 *data, const u64 *src, u64 src_ostride, bool src_reduce, co
     launch_ntt2_slots(data, src, src_ostride, src_reduce, primes, map, rows, logn, inverse, stream, src_same_layout, src_bound, 0, map.period, nullptr);
 }
 // the general form: only the prime slots [slot_begin, slot_begin + slot_count) of the pattern; md (inverse, inner == 1): the last pass ends in
-// the key-switch mod-down instead of storing (Ntt2ModDown, kernels.h)
+// the key-switch mod-down instead of storing (Ntt2ModDown, kernels.h).  host_primes (the context's registry, indexed by map.id) switches the
+// FP64 instances on for the slots in map.fp: without it every slot takes the integer kernels.
 void launch_ntt2_slots(u64 *data, const u64 *src, u64 src_ostride, bool src_reduce, const PrimeDesc *primes, const LimbMap &map, size_t rows, int logn,
                        bool inverse, hipStream_t stream, bool src_same_layout, u64 src_bound, unsigned slot_begin, unsigned slot_count, const Ntt2ModDown *md) {
+    const u64 *host_primes = map.host_primes;
     if (rows == 0 || slot_count == 0) return;
     if (slot_begin + slot_count > map.period) throw Error(ST_INVALID_ARGUMENT, "ntt2: slot range");
     const bool partial = slot_begin != 0 || slot_count != map.period;
@@ -1003,40 +1076,62 @@ void launch_ntt2_slots(u64 *data, const u64 *src, u64 src_ostride, bool src_redu
     a.src_same_layout = 0;
     a.slot_fastest = 0;
     a.slot_begin = slot_begin;
-    a.nsel = slot_count;
-    for (unsigned i = 0; i < slot_count; i++) a.sel[i] = (uint8_t)(slot_begin + i);
     if (md) {
         a.md_ct = md->ct; a.md_ct_bstride = md->ct_bstride; a.md_dl = md->dl; a.md_qk = md->qk; a.md_half = md->half;
         a.md_share = md->share;
         a.md_base = md->base; a.md_base_bstride = md->base_bstride; a.md_base_polys = md->base_polys;
         if (md->kind == 2 && !md->share) throw Error(ST_LOGIC_ERROR, "ntt2: the BGV mod-down needs the special limb's shares");
     }
-    const unsigned blocks = (unsigned)((slot_count * a.chunks) << a.tiles_per_row_log);
-    auto contig = [&](auto inv_tag, bool final_pass) {
-        constexpr int INV = decltype(inv_tag)::value;
-        if (k2 == 9) launch_contig<INV, 9>(a, blocks, final_pass, stream);
-        else if (k2 == 10) launch_contig<INV, 10>(a, blocks, final_pass, stream);
-        else throw Error(ST_LOGIC_ERROR, "ntt2 plan");
-    };
-    auto strided = [&](auto inv_tag, const Ntt2Args &args, bool reduce) {
-        constexpr int INV = decltype(inv_tag)::value;
-        switch (k1) {
-        case 3: launch_strided<INV, 3>(args, blocks, false, reduce, stream, md ? md->kind : -1); break;
-        case 4: launch_strided<INV, 4>(args, blocks, false, reduce, stream, md ? md->kind : -1); break;
-        case 5: launch_strided<INV, 5>(args, blocks, false, reduce, stream, md ? md->kind : -1); break;
-        case 6: launch_strided<INV, 6>(args, blocks, false, reduce, stream, md ? md->kind : -1); break;
-        case 7: launch_strided<INV, 7>(args, blocks, false, reduce, stream, md ? md->kind : -1); break;
-        default: throw Error(ST_LOGIC_ERROR, "ntt2 plan");
+    // the digit-reducing form of the first pass (unfused key switch) keeps the integer kernels: its FP64 twin lives in launch_ntt2_ks_mac
+    const bool fp_ok = host_primes && !(src && src_reduce);
+    for (int cls = 0; cls < 2; cls++) {
+        const bool fp = cls == 1;
+        if (fp && !fp_ok) break;
+        a.nsel = 0;
+        if (fp_ok) a.nsel = select_class(map, slot_begin, slot_count, fp, a.sel);
+        else for (unsigned i = 0; i < slot_count; i++) a.sel[a.nsel++] = (uint8_t)(slot_begin + i);
+        if (!a.nsel) continue;
+        stats::counter(fp ? stats::NTT2_FP_LAUNCHES : stats::NTT2_INT_LAUNCHES)++;
+        unsigned mask1 = 0, mask2 = 0; // reduction sites of the first and of the second pass in execution order (fpmod.h)
+        if (fp) {
+            u64 pmax = 0;
+            for (unsigned i = 0; i < a.nsel; i++) pmax = std::max(pmax, host_primes[map.id[a.sel[i]]]);
+            int r1[4], r2[4];
+            const int n1 = pass_rounds(inverse ? k2 : k1, inverse, r1), n2 = pass_rounds(inverse ? k1 : k2, inverse, r2);
+            const FpPlan p1 = inverse ? fp_plan_inv(pmax, 1.0, r1, n1) : fp_plan(pmax, 1.0, r1, n1);
+            const FpPlan p2 = inverse ? fp_plan_inv(pmax, p1.out_bound, r2, n2) : fp_plan(pmax, p1.out_bound, r2, n2);
+            if (p1.out_bound < 0 || p2.out_bound < 0) throw Error(ST_LOGIC_ERROR, "ntt2: FP64 bound walk");
+            mask1 = p1.mask; mask2 = p2.mask;
         }
-    };
-    if (!inverse) {
-        Ntt2Args first = a;
-        if (src) { first.src = src; first.src_ostride = src_ostride; first.src_reduce = src_reduce; first.src_bound = src_bound; first.src_same_layout = src_same_layout; first.slot_fastest = src_reduce && !src_same_layout; }
-        strided(std::integral_constant<int, 0>{}, first, src && src_reduce);
-        contig(std::integral_constant<int, 0>{}, true);
-    } else {
-        contig(std::integral_constant<int, 1>{}, false);
-        strided(std::integral_constant<int, 1>{}, a, false);
+        const unsigned blocks = (unsigned)((a.nsel * a.chunks) << a.tiles_per_row_log);
+        auto contig = [&](auto inv_tag, const Ntt2Args &args, bool final_pass) {
+            constexpr int INV = decltype(inv_tag)::value;
+            if (k2 == 9) launch_contig<INV, 9>(args, blocks, final_pass, stream, fp);
+            else if (k2 == 10) launch_contig<INV, 10>(args, blocks, final_pass, stream, fp);
+            else throw Error(ST_LOGIC_ERROR, "ntt2 plan");
+        };
+        auto strided = [&](auto inv_tag, const Ntt2Args &args, bool reduce) {
+            constexpr int INV = decltype(inv_tag)::value;
+            switch (k1) {
+            case 3: launch_strided<INV, 3>(args, blocks, false, reduce, stream, md ? md->kind : -1, false, fp); break;
+            case 4: launch_strided<INV, 4>(args, blocks, false, reduce, stream, md ? md->kind : -1, false, fp); break;
+            case 5: launch_strided<INV, 5>(args, blocks, false, reduce, stream, md ? md->kind : -1, false, fp); break;
+            case 6: launch_strided<INV, 6>(args, blocks, false, reduce, stream, md ? md->kind : -1, false, fp); break;
+            case 7: launch_strided<INV, 7>(args, blocks, false, reduce, stream, md ? md->kind : -1, false, fp); break;
+            default: throw Error(ST_LOGIC_ERROR, "ntt2 plan");
+            }
+        };
+        Ntt2Args first = a, second = a;
+        first.fp_red_mask = mask1;
+        second.fp_red_mask = mask2;
+        if (!inverse) {
+            if (src) { first.src = src; first.src_ostride = src_ostride; first.src_reduce = src_reduce; first.src_bound = src_bound; first.src_same_layout = src_same_layout; first.slot_fastest = src_reduce && !src_same_layout; }
+            strided(std::integral_constant<int, 0>{}, first, src && src_reduce);
+            contig(std::integral_constant<int, 0>{}, second, true);
+        } else {
+            contig(std::integral_constant<int, 1>{}, first, false);
+            strided(std::integral_constant<int, 1>{}, second, false);
+        }
     }
 }
 
@@ -1055,8 +1150,8 @@ template <int NS> static void launch_ks_first(const Ntt2Args &first, unsigned bl
     launch_check("ntt2_fp_kernel(ks first pass)");
 }
 void launch_ntt2_ks_mac(u64 *D, const u64 *src, u64 src_ostride, const PrimeDesc *primes, const LimbMap &map, size_t rows, int logn, const u64 *key, u64 *acc,
-                        const uint8_t *key_limb, unsigned K, const u64 *ckks_target, u64 t_bstride, bool lazy, u64 src_bound, const u64 *host_primes,
-                        hipStream_t stream) {
+                        const uint8_t *key_limb, unsigned K, const u64 *ckks_target, u64 t_bstride, bool lazy, u64 src_bound, hipStream_t stream) {
+    const u64 *host_primes = map.host_primes;
     if (rows == 0) return;
     if (!ntt2_supported(logn) || logn - 9 > 7 || logn - 9 < 3) throw Error(ST_LOGIC_ERROR, "ntt2 ks_mac: unsupported size");
     const size_t per_outer = (size_t)map.period * map.inner;
@@ -1147,50 +1242,77 @@ bool ntt2_tensor_supported(int logn) { return ntt2_supported(logn) && logn - 9 >
 bool ntt2_ks_mac_supported(int logn) { return ntt2_tensor_supported(logn); }
 void launch_ntt2_tensor(u64 *xa, const u64 *src_a, u64 *xb, const u64 *src_b, u64 *out, const PrimeDesc *primes, const LimbMap &map, size_t batch, int logn,
                         hipStream_t stream) {
+    const u64 *host_primes = map.host_primes;
     if (!batch) return;
     if (!ntt2_tensor_supported(logn) || map.inner != 1) throw Error(ST_LOGIC_ERROR, "ntt2 tensor: unsupported shape");
     const int k1 = logn - 9;
     const bool same = xa == xb; // squaring: one operand, transformed once
-    for (int part = 0; part < (same ? 1 : 2); part++) { // first pass of both operands (rows = batch * 2 * limbs each)
+    for (int cls = 0; cls < 2; cls++) { // one set of launches per prime class (FP64 instances below 2^50)
+        const bool fp = cls == 1;
+        if (fp && !host_primes) break;
+        uint8_t sel[64];
+        unsigned nsel = 0;
+        if (host_primes) nsel = select_class(map, 0, map.period, fp, sel);
+        else for (unsigned i = 0; i < map.period; i++) sel[nsel++] = (uint8_t)i;
+        if (!nsel) continue;
+        stats::counter(fp ? stats::NTT2_FP_LAUNCHES : stats::NTT2_INT_LAUNCHES)++;
+        unsigned mask1 = 0, mask2 = 0;
+        if (fp) {
+            u64 pmax = 0;
+            for (unsigned i = 0; i < nsel; i++) pmax = std::max(pmax, host_primes[map.id[sel[i]]]);
+            int r1[4], r2[4];
+            const int n1 = pass_rounds(k1, false, r1), n2 = pass_rounds(9, false, r2);
+            const FpPlan p1 = fp_plan(pmax, 1.0, r1, n1), p2 = fp_plan(pmax, p1.out_bound, r2, n2);
+            mask1 = p1.mask; mask2 = p2.mask;
+        }
+        for (int part = 0; part < (same ? 1 : 2); part++) { // first pass of both operands (rows = batch * 2 * limbs each)
+            Ntt2Args a;
+            std::memset(&a, 0, sizeof(a));
+            a.data = part ? xb : xa;
+            const u64 *src = part ? src_b : src_a;
+            a.primes = primes;
+            a.map = map;
+            a.logn = logn;
+            a.tiles_per_row_log = (unsigned)(logn - N2_LOGT);
+            a.m_total = (unsigned)(batch * 2);
+            a.nsel = nsel;
+            std::memcpy(a.sel, sel, sizeof(sel));
+            a.fp_red_mask = mask1;
+            a.rows_per_wg = a.m_total < 8 ? a.m_total : 8;
+            a.chunks = (a.m_total + a.rows_per_wg - 1) / a.rows_per_wg;
+            if (src) { a.src = src; a.src_same_layout = 1; }
+            const unsigned blocks = (unsigned)((nsel * a.chunks) << a.tiles_per_row_log);
+            switch (k1) {
+            case 3: launch_strided<0, 3>(a, blocks, false, false, stream, -1, false, fp); break;
+            case 4: launch_strided<0, 4>(a, blocks, false, false, stream, -1, false, fp); break;
+            case 5: launch_strided<0, 5>(a, blocks, false, false, stream, -1, false, fp); break;
+            case 6: launch_strided<0, 6>(a, blocks, false, false, stream, -1, false, fp); break;
+            default: launch_strided<0, 7>(a, blocks, false, false, stream, -1, false, fp); break;
+            }
+        }
         Ntt2Args a;
         std::memset(&a, 0, sizeof(a));
-        a.data = part ? xb : xa;
-        const u64 *src = part ? src_b : src_a;
+        a.data = xa; a.tensor_b = xb; a.tensor_out = out;
         a.primes = primes;
         a.map = map;
         a.logn = logn;
         a.tiles_per_row_log = (unsigned)(logn - N2_LOGT);
-        a.m_total = (unsigned)(batch * 2);
-        a.nsel = map.period;
-        for (unsigned i = 0; i < map.period; i++) a.sel[i] = (uint8_t)i;
-        a.rows_per_wg = a.m_total < 8 ? a.m_total : 8;
-        a.chunks = (a.m_total + a.rows_per_wg - 1) / a.rows_per_wg;
-        if (src) { a.src = src; a.src_same_layout = 1; }
-        const unsigned blocks = (unsigned)((map.period * a.chunks) << a.tiles_per_row_log);
-        switch (k1) {
-        case 3: launch_strided<0, 3>(a, blocks, false, false, stream); break;
-        case 4: launch_strided<0, 4>(a, blocks, false, false, stream); break;
-        case 5: launch_strided<0, 5>(a, blocks, false, false, stream); break;
-        case 6: launch_strided<0, 6>(a, blocks, false, false, stream); break;
-        default: launch_strided<0, 7>(a, blocks, false, false, stream); break;
+        a.m_total = (unsigned)(batch * 4);
+        a.nsel = nsel;
+        std::memcpy(a.sel, sel, sizeof(sel));
+        a.fp_red_mask = mask2;
+        a.rows_per_wg = 4;
+        a.chunks = (unsigned)batch;
+        const unsigned blocks = (unsigned)((nsel * a.chunks) << a.tiles_per_row_log);
+        if (fp) {
+            N2_KTAG("ntt2_fp_kernel<0, 0, 9, 0, 1, 0, 2>");
+            TROY_LAUNCH(HIP_KERNEL_NAME(ntt2_fp_kernel<0, 0, 9, 0, 1, 0, 2>), dim3(blocks), dim3(N2_THREADS), 0, stream, a);
+        } else {
+            N2_KTAG("ntt2_kernel<0, 0, 9, 0, 1, 0, 2>");
+            TROY_LAUNCH(HIP_KERNEL_NAME(ntt2_kernel<0, 0, 9, 0, 1, 0, 2>), dim3(blocks), dim3(N2_THREADS), 0, stream, a);
         }
+        launch_check("ntt2_kernel(tensor)");
     }
-    Ntt2Args a;
-    std::memset(&a, 0, sizeof(a));
-    a.data = xa; a.tensor_b = xb; a.tensor_out = out;
-    a.primes = primes;
-    a.map = map;
-    a.logn = logn;
-    a.tiles_per_row_log = (unsigned)(logn - N2_LOGT);
-    a.m_total = (unsigned)(batch * 4);
-    a.nsel = map.period;
-    for (unsigned i = 0; i < map.period; i++) a.sel[i] = (uint8_t)i;
-    a.rows_per_wg = 4;
-    a.chunks = (unsigned)batch;
-    const unsigned blocks = (unsigned)((map.period * a.chunks) << a.tiles_per_row_log);
-    N2_KTAG("ntt2_kernel<0, 0, 9, 0, 1, 0, 2>");
-    TROY_LAUNCH(HIP_KERNEL_NAME(ntt2_kernel<0, 0, 9, 0, 1, 0, 2>), dim3(blocks), dim3(N2_THREADS), 0, stream, a);
-    launch_check("ntt2_kernel(tensor)");
 }
 
 } // namespace troyhip
