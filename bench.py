@@ -624,12 +624,17 @@ def algorithmic_bytes_ckks_chain(w, B):
     def add(name, b):
         t[name] = t.get(name, 0) + b
 
-    def by_class(kernel, tail, slots, per_slot):  # rows of the prime slots split into the guard-free and the guarded launch
-        nl = sum(1 for i in slots if lean[i])
+    fpc = [_fp_on() and (1 << 33) <= p < (1 << FP_MAX_BITS) for p in qs]  # the FP64 instances of the single-pass kernels (ntt1_*_fp_kernel)
+
+    def by_class(kernel, tail, slots, per_slot):  # rows of the prime slots split into the FP64, the guard-free and the guarded launch
+        nf = sum(1 for i in slots if fpc[i])
+        nl = sum(1 for i in slots if lean[i] and not fpc[i])
+        if nf:
+            add(f"{kernel.replace('_kernel', '_fp_kernel')}<{tail}>", nf * per_slot)
         if nl:
             add(f"{kernel}<true, {tail}>", nl * per_slot)
-        if len(slots) - nl:
-            add(f"{kernel}<false, {tail}>", (len(slots) - nl) * per_slot)
+        if len(slots) - nl - nf:
+            add(f"{kernel}<false, {tail}>", (len(slots) - nl - nf) * per_slot)
 
     def ks(l):
         by_class("ntt1_inv_kernel", "false", range(l), B * 2 * P)                                   # the target to coefficient form, out of place
@@ -639,7 +644,7 @@ def algorithmic_bytes_ckks_chain(w, B):
         _by_prime_class(add, "ntt2_kernel<1, 0, 9, 0, 0, 0, 0>", qs[-1:], 2 * B * 2 * P)              # the special limb of the accumulators (2 B rows: two-pass)
         _by_prime_class(add, "ntt2_kernel<1, 1, 6, 5, 2, 0, 0>", qs[-1:], 2 * B * 2 * P)
         by_class("ntt1_fwd_kernel", "true", range(l), 2 * B * 3 * P)                                # per row: accumulator + ciphertext read, ciphertext written
-        add("ntt1_fwd_kernel<true, true>", 2 * B * P)                                                # the coefficient-form special limb, once per item
+        by_class("ntt1_fwd_kernel", "true", range(1), 2 * B * P)                                     # the coefficient-form special limb, once per item (booked on the first slot's class)
 
     for d in range(w.wl["depth"]):
         l = w.L - d
@@ -649,7 +654,7 @@ def algorithmic_bytes_ckks_chain(w, B):
         _by_prime_class(add, "ntt2_kernel<1, 0, 9, 0, 0, 0, 0>", qs[l - 1:l], 2 * B * 2 * P)
         _by_prime_class(add, "ntt2_kernel<1, 1, 6, 5, 2, 0, 0>", qs[l - 1:l], 2 * B * 2 * P)
         by_class("ntt1_fwd_kernel", "true", range(l - 1), 2 * B * 2 * P)
-        add("ntt1_fwd_kernel<true, true>", 2 * B * P)
+        by_class("ntt1_fwd_kernel", "true", range(1), 2 * B * P)
         add("galois_ntt_kernel", 2 * B * (l - 1) * 2 * P)
         add("copy_strided_kernel", B * (l - 1) * 2 * P)
         add("zero_strided_kernel", B * (l - 1) * P)

@@ -28,6 +28,22 @@ TROY_HD double fp_from_u64(u64 x) { return fp_of_bits(x | 0x4330000000000000ull)
 // d = an integer in [0, 2^52)
 TROY_HD u64 fp_to_u64(double d) { return fp_bits(d + 4503599627370496.0) & 0x000fffffffffffffull; }
 
+#if defined(__HIP_DEVICE_COMPILE__) && __HIP_DEVICE_COMPILE__ && !defined(TROYHIP_CPU_EMUL)
+// the prime is wave-uniform: keep (p, 1 / p) in scalar registers (the conversion and the division run on the vector unit, whose results the
+// compiler would otherwise hold in four VGPRs for the whole kernel)
+__device__ __forceinline__ FpPrime make_fp_prime_uniform(u64 p) {
+    const FpPrime v = make_fp_prime(p);
+    auto uni = [](double d) {
+        const u64 b = __builtin_bit_cast(u64, d);
+        const u64 r = ((u64)(unsigned)__builtin_amdgcn_readfirstlane((int)(b >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)b);
+        return __builtin_bit_cast(double, r);
+    };
+    return FpPrime{uni(v.p), uni(v.pinv)};
+}
+#else
+TROY_HD FpPrime make_fp_prime_uniform(u64 p) { return make_fp_prime(p); }
+#endif
+
 // y * w mod p for a table constant w with wp = w / p (correctly rounded): |result| <= (1/2 + |y| 2^-52) p
 TROY_HD double fp_mulmod_wp(double y, double w, double wp, const FpPrime &c) {
 #ifdef __clang__
@@ -70,18 +86,19 @@ TROY_HD u64 fp_canonical(double x, const FpPrime &c, u64 p) {
 // b + 1/2 + b p 2^-52 (X + v; v from fp_mulmod_wp with |y| <= b p).  fp_plan walks the rounds of a pass (stages per round given) and
 // sets bit r of the mask when the values must be reduced (to 1/2 + 2^-40) before round r so that no value reaches `lim`.
 struct FpPlan { unsigned mask; double out_bound; };
-inline double fp_stage_bound(double b, double p) { return b + 0.5 + b * p * 0x1p-52; }
-inline FpPlan fp_plan(u64 pmax, double b_in, const int *rounds, int n_rounds) {
+// c = 1: twiddle pairs (w, w / p), fp_mulmod_wp;  c = 1.5: single-double twiddles, fp_mulmod_pinv (three roundings in the quotient estimate)
+inline double fp_stage_bound(double b, double p, double c = 1.0) { return b + 0.5 + c * b * p * 0x1p-52; }
+inline FpPlan fp_plan(u64 pmax, double b_in, const int *rounds, int n_rounds, double c = 1.0) {
     const double p = (double)pmax, lim = 0x1p53 / p * 0.98; // 2 % slack for the "+1" terms
     FpPlan out{0, b_in};
     double b = b_in;
     for (int r = 0; r < n_rounds; r++) {
         double t = b;
-        for (int s = 0; s < rounds[r]; s++) t = fp_stage_bound(t, p);
+        for (int s = 0; s < rounds[r]; s++) t = fp_stage_bound(t, p, c);
         if (t >= lim) {
             out.mask |= 1u << r;
             t = 0.5 + 0x1p-40;
-            for (int s = 0; s < rounds[r]; s++) t = fp_stage_bound(t, p);
+            for (int s = 0; s < rounds[r]; s++) t = fp_stage_bound(t, p, c);
         }
         b = t;
     }

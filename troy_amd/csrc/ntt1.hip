@@ -24,6 +24,7 @@
 // instead of 20; other primes keep the guarded forms.
 #include "kernels.h"
 #include "bfly.h"
+#include "fpmod.h"
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -60,6 +61,8 @@ struct Ntt1Args {
     const u64 *md_base;   // accumulate onto (base[b], 0) instead of onto ct (Ntt1ModDown::base)
     u64 md_base_bstride;
     unsigned md_dl;
+    unsigned fp_red_mask; // FP64 instances (ntt1_*_fp_kernel, fpmod.h): bit r = reduce the values before round r (forward: A, B, C1, C2; inverse:
+                          // D', C', B', A', the last stage of A'); walked on the host (fp_plan / fp_plan_inv)
     u64 *dbg;             // development builds (-DN1_TIMING): s_memtime stamps of wave 0 of workgroup dbg_block
     unsigned dbg_block;
 };
@@ -86,6 +89,9 @@ __device__ __forceinline__ unsigned sw1(unsigned j) { return j ^ (((j >> 6) & 7u
 // SQ_LDS_BANK_CONFLICT = 34 % of the inverse kernel's LDS cycles in round 2, 0 in the forward kernel, which only reads that pattern).  One more
 // term -- bit 2 ^= bit 4 -- separates them and keeps every other pattern conflict-free (tools/lds_banks.py); it is no involution any more
 // (bit 4 is both a source and a target), so the LDS-DMA staging, which needs "which element belongs at position x", uses sw2_inv.
+#ifndef N1_FP_FENCE_B
+#define N1_FP_FENCE_B 2 // FP64 forward kernel, round B (16 values in registers next to the waiting half): butterflies in flight between scheduling fences
+#endif
 #ifndef N1_INV_SWZ
 #define N1_INV_SWZ 2
 #endif
@@ -113,6 +119,15 @@ __device__ __forceinline__ Shoup ld_tw_uniform(const Shoup *p) {
     return Shoup{v.x, v.y};
 }
 #endif
+// FP64 tables, per-lane entries: only the first double (w) of the pair is fetched -- half the twiddle registers of the sub-block rounds; the
+// quotient then comes from the rounded product and 1 / p (fp_mulmod_pinv)
+__device__ __forceinline__ Shoup ld_tw8(const Shoup *base, unsigned idx) {
+#ifdef TROYHIP_CPU_EMUL
+    return Shoup{base[idx].op, 0};
+#else
+    return Shoup{((const __attribute__((address_space(1))) u64 *)base)[2 * idx], 0};
+#endif
+}
 
 // keeps the LDS / table address arithmetic of a sub-block inside the row loop: hoisted out of it, the ~40 lane-dependent
 // addresses of the three rounds would have to live (and be spilled) across the whole kernel; recomputing them costs a few XORs
@@ -225,18 +240,66 @@ template <int G, int R, bool LAST, bool UNI, int B0 = 0, class TW> __device__ __
     }
 }
 
+// ---- FP64 forms (fpmod.h; primes in [2^33, 2^50)): y holds the bit patterns of doubles (exact integers, signed lazy range), tw the pairs
+// (w, w / p) of PrimeDesc::root_fp / iroot_fp.  Eight instructions per butterfly; the bound walk (where to reduce) is the host's.
+template <int G, int R, bool PINV = false, int FENCE = 4, class TW> __device__ __forceinline__ void fp_fwd_stages(u64 (&y)[G << R], const TW &tw, const FpPrime &fc) {
+#pragma unroll
+    for (int st = 0; st < R; st++) {
+        const int half = (1 << R) >> (st + 1);
+#pragma unroll
+        for (int b = 0; b < (G << (R - 1)); b++) {
+            const int g = b >> (R - 1), r = b & ((1 << (R - 1)) - 1);
+            const int blk = r / half, k = r % half;
+            const int ix = (g << R) + blk * 2 * half + k;
+            const Shoup w = tw(st, g, blk);
+            const double X = fp_of_bits(y[ix]);
+            const double v = PINV ? fp_mulmod_pinv(fp_of_bits(y[ix + half]), fp_of_bits(w.op), fc) : fp_mulmod_wp(fp_of_bits(y[ix + half]), fp_of_bits(w.op), fp_of_bits(w.quo), fc);
+            y[ix] = fp_bits(X + v);
+            y[ix + half] = fp_bits(X - v);
+            if ((b & (FENCE - 1)) == FENCE - 1) N1_SCHED_FENCE(); // FENCE butterflies at a time (four in the integer form): more in flight only multiplies the temporaries
+        }
+    }
+}
+// ST0 / ST1: the stages [ST0, ST1) of the R-stage round (the last stage of the transform is run on its own so that a reduction fits in front of it)
+template <int G, int R, bool LAST, int ST0, int ST1, bool PINV = false, class TW> __device__ __forceinline__ void fp_inv_stages(u64 (&y)[G << R], const TW &tw, const Shoup inv_n, const FpPrime &fc) {
+#pragma unroll
+    for (int st = ST0; st < ST1; st++) {
+        const int dist = 1 << st;
+#pragma unroll
+        for (int b = 0; b < (G << (R - 1)); b++) {
+            const int g = b >> (R - 1), r = b & ((1 << (R - 1)) - 1);
+            const int blk = r / dist, k = r % dist;
+            const int ix = (g << R) + blk * 2 * dist + k;
+            const Shoup w = tw(st, g, blk);
+            const double X = fp_of_bits(y[ix]), Y = fp_of_bits(y[ix + dist]);
+            const double sum = X + Y, dif = X - Y;
+            y[ix] = fp_bits(LAST && st == R - 1 ? fp_mulmod_wp(sum, fp_of_bits(inv_n.op), fp_of_bits(inv_n.quo), fc) : sum);
+            y[ix + dist] = fp_bits(PINV ? fp_mulmod_pinv(dif, fp_of_bits(w.op), fc) : fp_mulmod_wp(dif, fp_of_bits(w.op), fp_of_bits(w.quo), fc));
+            if ((b & 3) == 3) N1_SCHED_FENCE();
+        }
+    }
+}
+template <int NV> __device__ __forceinline__ void fp_reduce_all(u64 (&y)[NV], const FpPrime &fc) {
+#pragma unroll
+    for (int i = 0; i < NV; i++) y[i] = fp_bits(fp_reduce(fp_of_bits(y[i]), fc));
+}
+
 // the last 10 forward stages (5..14) of sub-block sb (coefficients 1024 sb .. 1024 sb + 1023), in place in the wave's region,
 // result canonical to `out` (the sub-block's 1024 coefficients in HBM)
-template <bool LEAN, bool CR> __device__ __forceinline__ void fwd_subblock(u64 *R, const unsigned sb, const unsigned lane_in, const PrimeDesc &pd, const PrimeConst &pc, const Mod &m,
+template <bool LEAN, bool CR, bool FP> __device__ __forceinline__ void fwd_subblock(u64 *R, const unsigned sb, const unsigned lane_in, const PrimeDesc &pd, const PrimeConst &pc, const Mod &m,
                                                                   u64 *out, const Ntt1Args &a, const unsigned mm, const unsigned m_begin, const int stamp0, const bool hf_last,
-                                                                  const u64 *cr_in = nullptr, const Shoup cr_inv = Shoup{0, 0}, const u64 *cr_acc = nullptr) {
-    (void)a; (void)mm; (void)m_begin; (void)stamp0; (void)hf_last;
+                                                                  const FpPrime &fc, const u64 *cr_in = nullptr, const Shoup cr_inv = Shoup{0, 0}, const u64 *cr_acc = nullptr) {
+    (void)a; (void)mm; (void)m_begin; (void)stamp0; (void)hf_last; (void)fc;
     const unsigned lane = opaque(lane_in);
     N1_PRIO(3);
     {   // round B: stages 5..8 on 16 values, registers = j9..j6, lane = j5..j0; twiddles depend on (sb, register) only: scalar loads
         u64 y[16];
 #pragma unroll
         for (int r = 0; r < 16; r++) y[r] = R[sw1(64 * r + lane)];
+        if constexpr (FP) {
+            if (a.fp_red_mask & 2u) fp_reduce_all<16>(y, fc);
+            fp_fwd_stages<1, 4, false, N1_FP_FENCE_B>(y, [&](int st, int, int blk) { return ld_tw_uniform(pd.root + (32u << st) + (sb << st) + blk); }, fc);
+        } else
         fwd_stages<1, 4, LEAN, true>(y, [&](int st, int, int blk) { return ld_tw_uniform(pd.root + (32u << st) + (sb << st) + blk); }, pc);
 #pragma unroll
         for (int r = 0; r < 16; r++) R[sw1(64 * r + lane)] = y[r];
@@ -249,17 +312,21 @@ template <bool LEAN, bool CR> __device__ __forceinline__ void fwd_subblock(u64 *
         // the seven twiddles
         const unsigned h = lane >> 2, low = lane & 3;
         const unsigned b9 = 16 * sb + h;
-        const Shoup t9 = ld_tw(pd.root, 512 + b9);
+        const Shoup t9 = FP ? ld_tw8(pd.root, 512 + b9) : ld_tw(pd.root, 512 + b9);
         Shoup t10[2], t11[4];
 #pragma unroll
-        for (int i = 0; i < 2; i++) t10[i] = ld_tw(pd.root, 1024 + 2 * b9 + i);
+        for (int i = 0; i < 2; i++) t10[i] = FP ? ld_tw8(pd.root, 1024 + 2 * b9 + i) : ld_tw(pd.root, 1024 + 2 * b9 + i);
 #pragma unroll
-        for (int i = 0; i < 4; i++) t11[i] = ld_tw(pd.root, 2048 + 4 * b9 + i);
+        for (int i = 0; i < 4; i++) t11[i] = FP ? ld_tw8(pd.root, 2048 + 4 * b9 + i) : ld_tw(pd.root, 2048 + 4 * b9 + i);
 #pragma unroll 1
         for (unsigned it = 0; it < 2; it++) {
             u64 y[8];
 #pragma unroll
             for (int r = 0; r < 8; r++) y[r] = R[sw1(64 * h + 8 * r + 4 * it + low)];
+            if constexpr (FP) {
+                if (a.fp_red_mask & 4u) fp_reduce_all<8>(y, fc);
+                fp_fwd_stages<1, 3, true>(y, [&](int st, int, int blk) { return st == 0 ? t9 : (st == 1 ? t10[blk] : t11[blk]); }, fc);
+            } else
             fwd_stages<1, 3, LEAN, false>(y, [&](int st, int, int blk) { return st == 0 ? t9 : (st == 1 ? t10[blk] : t11[blk]); }, pc);
 #pragma unroll
             for (int r = 0; r < 8; r++) R[sw1(64 * h + 8 * r + 4 * it + low)] = y[r];
@@ -275,20 +342,28 @@ template <bool LEAN, bool CR> __device__ __forceinline__ void fwd_subblock(u64 *
         const unsigned u = lane + 64 * it;
         u64 y[8];
         const unsigned b12 = 128 * sb + u;
-        const Shoup t12 = ld_tw(pd.root, 4096 + b12);
+        const Shoup t12 = FP ? ld_tw8(pd.root, 4096 + b12) : ld_tw(pd.root, 4096 + b12);
         Shoup t13[2], t14[4];
 #pragma unroll
-        for (int i = 0; i < 2; i++) t13[i] = ld_tw(pd.root, 8192 + 2 * b12 + i);
+        for (int i = 0; i < 2; i++) t13[i] = FP ? ld_tw8(pd.root, 8192 + 2 * b12 + i) : ld_tw(pd.root, 8192 + 2 * b12 + i);
 #pragma unroll
-        for (int i = 0; i < 4; i++) t14[i] = ld_tw(pd.root, 16384 + 4 * b12 + i);
+        for (int i = 0; i < 4; i++) t14[i] = FP ? ld_tw8(pd.root, 16384 + 4 * b12 + i) : ld_tw(pd.root, 16384 + 4 * b12 + i);
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(R + sw1(8 * u + 2 * q));
             y[2 * q] = v.x;
             y[2 * q + 1] = v.y;
         }
+        if constexpr (FP) {
+            if (a.fp_red_mask & 8u) fp_reduce_all<8>(y, fc);
+            fp_fwd_stages<1, 3, true>(y, [&](int st, int, int blk) { return st == 0 ? t12 : (st == 1 ? t13[blk] : t14[blk]); }, fc);
+#pragma unroll
+            for (int i = 0; i < 8; i++) y[i] = fp_canonical(fp_of_bits(y[i]), fc, m.p);
+        } else {
         fwd_stages<1, 3, LEAN, false>(y, [&](int st, int, int blk) { return st == 0 ? t12 : (st == 1 ? t13[blk] : t14[blk]); }, pc);
-        if (LEAN) {
+        }
+        if (FP) {
+        } else if (LEAN) {
             lean_final<8>(y, make_lean_final(m.p, m.cr1), pc);
         } else {
 #pragma unroll
@@ -337,7 +412,7 @@ template <bool LEAN, bool CR> __device__ __forceinline__ void fwd_subblock(u64 *
     }
 }
 
-template <bool LEAN, bool CR> __global__ __launch_bounds__(N1_THREADS) void ntt1_fwd_kernel(Ntt1Args a) {
+template <bool LEAN, bool CR, bool FP> __device__ __forceinline__ void ntt1_fwd_body(const Ntt1Args &a) {
     // 16 regions of 8 KiB + 32 KiB in which four of the sixteen registers of the waiting half are parked (the other twelve stay in
     // VGPRs): all 160 KiB of the CU
     __shared__ __attribute__((aligned(16))) u64 lds[20 * 1024];
@@ -349,7 +424,9 @@ template <bool LEAN, bool CR> __global__ __launch_bounds__(N1_THREADS) void ntt1
 #endif
     // the byte tables of the argument block are read with vector loads: tell the compiler the results are wave-uniform
     const unsigned slot = uniform_u32(a.slots[blockIdx.x / a.chunks]), chunk = blockIdx.x % a.chunks;
-    const PrimeDesc pd = a.primes[uniform_u32(a.map.id[slot])];
+    PrimeDesc pd = a.primes[uniform_u32(a.map.id[slot])];
+    if constexpr (FP) pd.root = pd.root_fp;
+    const FpPrime fc = make_fp_prime_uniform(FP ? pd.p : 1);
     const PrimeConst pc = make_prime_const(pd.p);
     const Mod m = mod_of(pd);
     const unsigned m_begin = chunk * a.rows_per_wg;
@@ -394,13 +471,31 @@ template <bool LEAN, bool CR> __global__ __launch_bounds__(N1_THREADS) void ntt1
                 csub4(v, a.cr_qx);
                 lite_reduce4(v, (u32)pd.cr1, pc);
 #pragma unroll
-                for (int i = 0; i < 4; i++) xx[4 * (g & 3) + i] = v[i] + cr_add;
+                for (int i = 0; i < 4; i++) xx[4 * (g & 3) + i] = FP ? fp_bits(fp_from_u64(v[i]) + (double)cr_add) : v[i] + cr_add; // FP64: 4p < 2^52 converts exactly
             }
+        } else if constexpr (FP) { // canonical residues become doubles (exact below 2^52)
+#pragma unroll
+            for (int r = 0; r < 16; r++) { xe[r] = fp_bits(fp_from_u64(xe[r])); xo[r] = fp_bits(fp_from_u64(xo[r])); }
+        }
+        if constexpr (FP) {
+            if (a.fp_red_mask & 1u) { fp_reduce_all<16>(xe, fc); fp_reduce_all<16>(xo, fc); }
         }
         N1_STAMP(0);
         // round A: stages 0..3 on the even and on the odd registers (the odd ones were requested last), then stage 4 across
         auto twA = [&](int st, int, int blk) { return ld_tw_uniform((pd.root + (1u << st) + blk)); };
         N1_PRIO(1);
+        if constexpr (FP) {
+            fp_fwd_stages<1, 4>(xe, twA, fc);
+            fp_fwd_stages<1, 4>(xo, twA, fc);
+#pragma unroll
+            for (int r = 0; r < 16; r++) { // stage 4: (xe[r], xo[r]) with the twiddle of block r
+                const Shoup w = ld_tw_uniform((pd.root + 16 + r));
+                const double X = fp_of_bits(xe[r]);
+                const double v = fp_mulmod_wp(fp_of_bits(xo[r]), fp_of_bits(w.op), fp_of_bits(w.quo), fc);
+                xe[r] = fp_bits(X + v);
+                xo[r] = fp_bits(X - v);
+            }
+        } else {
         fwd_stages<1, 4, LEAN, true>(xe, twA, pc);
         N1_PRIO(0);
         fwd_stages<1, 4, LEAN, true>(xo, twA, pc);
@@ -414,6 +509,7 @@ template <bool LEAN, bool CR> __global__ __launch_bounds__(N1_THREADS) void ntt1
 #pragma unroll
             for (int i = 0; i < 4; i++) { xe[4 * c + i] = X[i]; xo[4 * c + i] = Y[i]; }
             N1_SCHED_FENCE();
+        }
         }
         N1_STAMP(1);
         // sub-block 2 r' (2 r' + 1) = xe[r'] (xo[r']) of all threads; half hf = sub-blocks 16 hf .. 16 hf + 15
@@ -439,19 +535,28 @@ template <bool LEAN, bool CR> __global__ __launch_bounds__(N1_THREADS) void ntt1
             __syncthreads();
             N1_STAMP(3 + 6 * hf);
             if (hf == 1 && mm + 1 < m_end) load_half(xe, in_row(mm + 1), 0); // all 32 registers are free now: request the next limb's even half
-            fwd_subblock<LEAN, CR>(region, 16 * hf + wv, lane, pd, pc, m, out + 1024 * (16 * hf + wv), a, mm, m_begin, 4 + 6 * hf, hf == 1, CR ? cin + 1024 * (16 * hf + wv) : nullptr, cr_inv,
+            fwd_subblock<LEAN, CR, FP>(region, 16 * hf + wv, lane, pd, pc, m, out + 1024 * (16 * hf + wv), a, mm, m_begin, 4 + 6 * hf, hf == 1, fc, CR ? cin + 1024 * (16 * hf + wv) : nullptr, cr_inv,
                                    CR && cacc ? cacc + 1024 * (16 * hf + wv) : nullptr);
             N1_STAMP(7 + 6 * hf);
         }
         if (mm + 1 < m_end) load_half(xo, in_row(mm + 1), 1);
     }
 }
+template <bool LEAN, bool CR> __global__ __launch_bounds__(N1_THREADS) void ntt1_fwd_kernel(Ntt1Args a) { ntt1_fwd_body<LEAN, CR, false>(a); }
+// the FP64 instances (primes in [2^33, 2^50)): kernels of their own name, as in ntt2.hip
+template <bool CR> __global__ __launch_bounds__(N1_THREADS) void ntt1_fwd_fp_kernel(Ntt1Args a) { ntt1_fwd_body<true, CR, true>(a); }
 
 // the first 10 inverse stages (14..5) of sub-block sb: input y (this lane's coefficients 8 u + r, u = lane + 64 i, in y[8 i + r]),
 // result left in the wave's region (position sw2(j))
-template <bool LEAN> __device__ __forceinline__ void inv_subblock(u64 (&yin)[16], u64 *R, const unsigned sb, const unsigned lane_in, const PrimeDesc &pd, const PrimeConst &pc) {
+template <bool LEAN, bool FP> __device__ __forceinline__ void inv_subblock(u64 (&yin)[16], u64 *R, const unsigned sb, const unsigned lane_in, const PrimeDesc &pd, const PrimeConst &pc,
+                                                                  const FpPrime &fc, const unsigned fp_mask) {
     const Shoup none{0, 0};
     const unsigned lane = opaque(lane_in);
+    (void)fc; (void)fp_mask;
+    if constexpr (FP) { // canonical residues become doubles (round D' never needs a reduction: 8 p < 2^53)
+#pragma unroll
+        for (int i = 0; i < 16; i++) yin[i] = fp_bits(fp_from_u64(yin[i]));
+    }
     // round D': stages 14, 13, 12 on 8 consecutive coefficients
 #pragma unroll
     for (int it = 0; it < 2; it++) {
@@ -462,10 +567,12 @@ template <bool LEAN> __device__ __forceinline__ void inv_subblock(u64 (&yin)[16]
         const unsigned b12 = 128 * sb + u;
         Shoup t14[4], t13[2];
 #pragma unroll
-        for (int i = 0; i < 4; i++) t14[i] = ld_tw(pd.iroot, 1 + 4 * b12 + i);
+        for (int i = 0; i < 4; i++) t14[i] = FP ? ld_tw8(pd.iroot, 1 + 4 * b12 + i) : ld_tw(pd.iroot, 1 + 4 * b12 + i);
 #pragma unroll
-        for (int i = 0; i < 2; i++) t13[i] = ld_tw(pd.iroot, 16385 + 2 * b12 + i);
-        const Shoup t12 = ld_tw(pd.iroot, 24577 + b12);
+        for (int i = 0; i < 2; i++) t13[i] = FP ? ld_tw8(pd.iroot, 16385 + 2 * b12 + i) : ld_tw(pd.iroot, 16385 + 2 * b12 + i);
+        const Shoup t12 = FP ? ld_tw8(pd.iroot, 24577 + b12) : ld_tw(pd.iroot, 24577 + b12);
+        if constexpr (FP) fp_inv_stages<1, 3, false, 0, 3, true>(y, [&](int st, int, int blk) { return st == 0 ? t14[blk] : (st == 1 ? t13[blk] : t12); }, none, fc);
+        else
         inv_stages<1, 3, false, false, LEAN ? 2 : 0>(y, [&](int st, int, int blk) { return st == 0 ? t14[blk] : (st == 1 ? t13[blk] : t12); }, none, pc); // inputs below 2p (stored limbs are canonical) -> 16p
 #pragma unroll
         for (int q = 0; q < 4; q++) {
@@ -482,15 +589,19 @@ template <bool LEAN> __device__ __forceinline__ void inv_subblock(u64 (&yin)[16]
         const unsigned b9 = 16 * sb + h;
         Shoup t11[4], t10[2];
 #pragma unroll
-        for (int i = 0; i < 4; i++) t11[i] = ld_tw(pd.iroot, 28673 + 4 * b9 + i);
+        for (int i = 0; i < 4; i++) t11[i] = FP ? ld_tw8(pd.iroot, 28673 + 4 * b9 + i) : ld_tw(pd.iroot, 28673 + 4 * b9 + i);
 #pragma unroll
-        for (int i = 0; i < 2; i++) t10[i] = ld_tw(pd.iroot, 30721 + 2 * b9 + i);
-        const Shoup t9 = ld_tw(pd.iroot, 31745 + b9);
+        for (int i = 0; i < 2; i++) t10[i] = FP ? ld_tw8(pd.iroot, 30721 + 2 * b9 + i) : ld_tw(pd.iroot, 30721 + 2 * b9 + i);
+        const Shoup t9 = FP ? ld_tw8(pd.iroot, 31745 + b9) : ld_tw(pd.iroot, 31745 + b9);
 #pragma unroll 1
         for (unsigned it = 0; it < 2; it++) {
             u64 y[8];
 #pragma unroll
             for (int r = 0; r < 8; r++) y[r] = R[sw2(64 * h + 8 * r + 4 * it + low)];
+            if constexpr (FP) {
+                if (fp_mask & 2u) fp_reduce_all<8>(y, fc);
+                fp_inv_stages<1, 3, false, 0, 3, true>(y, [&](int st, int, int blk) { return st == 0 ? t11[blk] : (st == 1 ? t10[blk] : t9); }, none, fc);
+            } else
             inv_stages<1, 3, false, false, LEAN ? 16 : 0>(y, [&](int st, int, int blk) { return st == 0 ? t11[blk] : (st == 1 ? t10[blk] : t9); }, none, pc); // 16p -> 32p -> (halved) 32p -> 64p
 #pragma unroll
             for (int r = 0; r < 8; r++) R[sw2(64 * h + 8 * r + 4 * it + low)] = y[r];
@@ -501,7 +612,7 @@ template <bool LEAN> __device__ __forceinline__ void inv_subblock(u64 (&yin)[16]
         u64 y[16];
 #pragma unroll
         for (int r = 0; r < 16; r++) y[r] = R[sw2(64 * r + lane)];
-        if (LEAN) { // 64p -> 4p, then four stages -> 64p
+        if (LEAN && !FP) { // 64p -> 4p, then four stages -> 64p
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 u64 v[4] = {y[4 * q], y[4 * q + 1], y[4 * q + 2], y[4 * q + 3]};
@@ -510,13 +621,17 @@ template <bool LEAN> __device__ __forceinline__ void inv_subblock(u64 (&yin)[16]
                 for (int i = 0; i < 4; i++) y[4 * q + i] = v[i];
             }
         }
+        if constexpr (FP) {
+            if (fp_mask & 4u) fp_reduce_all<16>(y, fc);
+            fp_inv_stages<1, 4, false, 0, 4>(y, [&](int st, int, int blk) { return ld_tw_uniform(pd.iroot + (N1_N - (512u >> st) + 1) + ((8 * sb) >> st) + blk); }, none, fc);
+        } else
         inv_stages<1, 4, false, true, LEAN ? 4 : 0>(y, [&](int st, int, int blk) { return ld_tw_uniform(pd.iroot + (N1_N - (512u >> st) + 1) + ((8 * sb) >> st) + blk); }, none, pc);
 #pragma unroll
         for (int r = 0; r < 16; r++) R[sw2(64 * r + lane)] = y[r];
     }
 }
 
-template <bool LEAN, bool MD> __global__ __launch_bounds__(N1_THREADS) void ntt1_inv_kernel(Ntt1Args a) {
+template <bool LEAN, bool MD, bool FP> __device__ __forceinline__ void ntt1_inv_body(const Ntt1Args &a) {
     __shared__ __attribute__((aligned(16))) u64 lds[16 * 1024];
     const unsigned tid = threadIdx.x, lane = tid & 63;
 #ifdef TROYHIP_CPU_EMUL
@@ -526,7 +641,9 @@ template <bool LEAN, bool MD> __global__ __launch_bounds__(N1_THREADS) void ntt1
 #endif
     // the byte tables of the argument block are read with vector loads: tell the compiler the results are wave-uniform
     const unsigned slot = uniform_u32(a.slots[blockIdx.x / a.chunks]), chunk = blockIdx.x % a.chunks;
-    const PrimeDesc pd = a.primes[uniform_u32(a.map.id[slot])];
+    PrimeDesc pd = a.primes[uniform_u32(a.map.id[slot])];
+    if constexpr (FP) { pd.iroot = pd.iroot_fp; pd.inv_n = pd.inv_n_fp; pd.iroot_last_scaled = pd.iroot_last_scaled_fp; }
+    const FpPrime fc = make_fp_prime_uniform(FP ? pd.p : 1);
     const PrimeConst pc = make_prime_const(pd.p);
     const unsigned m_begin = chunk * a.rows_per_wg;
     const unsigned m_end = (m_begin + a.rows_per_wg < a.m_total) ? m_begin + a.rows_per_wg : a.m_total;
@@ -579,7 +696,7 @@ template <bool LEAN, bool MD> __global__ __launch_bounds__(N1_THREADS) void ntt1
         TROY_WAVE_SYNC();
 #pragma unroll
         for (int hf = 0; hf < 2; hf++) {
-            inv_subblock<LEAN>(hf ? y1 : y, region, 16 * hf + wv, lane, pd, pc);
+            inv_subblock<LEAN, FP>(hf ? y1 : y, region, 16 * hf + wv, lane, pd, pc, fc, a.fp_red_mask);
             __syncthreads();
 #pragma unroll
             for (int r = 0; r < 8; r++) { x[16 * hf + r] = rlo[1024 * r]; x[16 * hf + 8 + r] = rhi[1024 * r]; }
@@ -587,7 +704,7 @@ template <bool LEAN, bool MD> __global__ __launch_bounds__(N1_THREADS) void ntt1
         }
         if (mm + 1 < m_end) stage_issue(in_of(mm + 1) + 1024 * wv); // the regions are free during round A'
         // round A': stages 4..0 across the 32 sub-blocks, N^-1 folded into the last one
-        if (LEAN) { // 64p -> 4p; the five stages reach 32p after three, the fourth halves its sums, the last one multiplies everything by N^-1
+        if (LEAN && !FP) { // 64p -> 4p; the five stages reach 32p after three, the fourth halves its sums, the last one multiplies everything by N^-1
 #pragma unroll
             for (int q = 0; q < 8; q++) {
                 u64 v[4] = {x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]};
@@ -596,13 +713,23 @@ template <bool LEAN, bool MD> __global__ __launch_bounds__(N1_THREADS) void ntt1
                 for (int i = 0; i < 4; i++) x[4 * q + i] = v[i];
             }
         }
-        inv_stages<1, 5, true, true, LEAN ? 4 : 0>(x, [&](int st, int, int blk) { return st == 4 ? pd.iroot_last_scaled : ld_tw_uniform((pd.iroot + (N1_N - (32u >> st) + 1) + blk)); }, pd.inv_n, pc);
+        auto twA = [&](int st, int, int blk) { return st == 4 ? pd.iroot_last_scaled : ld_tw_uniform((pd.iroot + (N1_N - (32u >> st) + 1) + blk)); };
+        if constexpr (FP) {
+            if (a.fp_red_mask & 8u) fp_reduce_all<32>(x, fc);
+            fp_inv_stages<1, 5, true, 0, 4>(x, twA, pd.inv_n, fc);
+            if (a.fp_red_mask & 16u) fp_reduce_all<32>(x, fc);
+            fp_inv_stages<1, 5, true, 4, 5>(x, twA, pd.inv_n, fc);
+#pragma unroll
+            for (int i = 0; i < 32; i++) x[i] = fp_canonical(fp_of_bits(x[i]), fc, pd.p);
+        } else {
+        inv_stages<1, 5, true, true, LEAN ? 4 : 0>(x, twA, pd.inv_n, pc);
 #pragma unroll
         for (int q = 0; q < 8; q++) {
             u64 v[4] = {x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]};
             reduce4_from_4p(v, pc);
 #pragma unroll
             for (int i = 0; i < 4; i++) x[4 * q + i] = v[i];
+        }
         }
         if (MD) { // x = acc qk^-1 mod p (canonical): add the special limb's share and accumulate into the ciphertext (inner == 1 here)
             const unsigned t = opaque(tid);
@@ -641,6 +768,8 @@ template <bool LEAN, bool MD> __global__ __launch_bounds__(N1_THREADS) void ntt1
         }
     }
 }
+template <bool LEAN, bool MD> __global__ __launch_bounds__(N1_THREADS) void ntt1_inv_kernel(Ntt1Args a) { ntt1_inv_body<LEAN, MD, false>(a); }
+template <bool MD> __global__ __launch_bounds__(N1_THREADS) void ntt1_inv_fp_kernel(Ntt1Args a) { ntt1_inv_body<true, MD, true>(a); }
 
 // ---- host side ----
 
@@ -716,21 +845,48 @@ void launch_ntt1(u64 *data, const u64 *src, const PrimeDesc *primes, const LimbM
     // inputs (every stored limb is).  Tried and rejected: both classes in one kernel behind a workgroup-uniform branch (the merged
     // function spills 40-120 registers), the smaller class forked onto a companion stream (concurrent kernels interleave their
     // workgroups and lose the per-prime locality: 0.34 -> 0.28 at B=64).
-    struct Cls { Ntt1Args a; bool lean; } cls[2];
+    // a third class since round 3: the FP64 instances for the primes in [2^33, 2^50) (map.fp within map.lean; fpmod.h), when the map
+    // carries the host prime list the bound walk needs
+    struct Cls { Ntt1Args a; bool lean, fp; } cls[3];
     int ncls = 0;
-    for (int lean = 1; lean >= 0; lean--) {
+    const u64 fp_slots = map.host_primes ? (map.fp & map.lean) : 0;
+    for (int kind = 2; kind >= 0; kind--) { // 2: FP64, 1: guard-free integer, 0: guarded integer
         a.nslots = 0;
-        for (unsigned i = 0; i < map.period; i++)
-            if ((int)((map.lean >> i) & 1) == lean && ((slot_mask >> i) & 1)) a.slots[a.nslots++] = (uint8_t)i;
+        u64 pmax = 0;
+        for (unsigned i = 0; i < map.period; i++) {
+            if (!((slot_mask >> i) & 1)) continue;
+            const int k = ((fp_slots >> i) & 1) ? 2 : (int)((map.lean >> i) & 1);
+            if (k != kind) continue;
+            a.slots[a.nslots++] = (uint8_t)i;
+            if (kind == 2) pmax = std::max(pmax, map.host_primes[map.id[i]]);
+        }
         if (!a.nslots) continue;
+        a.fp_red_mask = 0;
+        if (kind == 2) { // where the values are reduced (fpmod.h): forward rounds A, B, C1, C2 from canonical inputs (the correction form starts below 5p);
+                         // inverse rounds D', C', B', the first four stages of A', its last stage
+            const int fwd_rounds[4] = {5, 4, 3, 3}, inv_rounds[5] = {3, 3, 4, 4, 1};
+            const FpPlan pl = inverse ? fp_plan_inv(pmax, 1.0, inv_rounds, 5) : fp_plan(pmax, cr ? 5.0 : 1.0, fwd_rounds, 4, 1.5);
+            if (pl.out_bound < 0) throw Error(ST_LOGIC_ERROR, "ntt1: FP64 bound walk");
+            a.fp_red_mask = pl.mask;
+        }
+        stats::counter(kind == 2 ? stats::NTT1_FP_LAUNCHES : stats::NTT1_INT_LAUNCHES)++;
         a.rows_per_wg = plan(a.nslots);
         a.chunks = (a.m_total + a.rows_per_wg - 1) / a.rows_per_wg;
         cls[ncls].a = a;
-        cls[ncls++].lean = lean != 0;
+        cls[ncls].lean = kind != 0;
+        cls[ncls++].fp = kind == 2;
     }
     auto launch = [&](const Cls &k, hipStream_t st) {
         const Ntt1Args &x = k.a;
         const dim3 grid(x.nslots * x.chunks);
+        if (k.fp) {
+            if (inverse) {
+                if (x.md_ct) TROY_LAUNCH(HIP_KERNEL_NAME(ntt1_inv_fp_kernel<true>), grid, dim3(N1_THREADS), 0, st, x);
+                else TROY_LAUNCH(HIP_KERNEL_NAME(ntt1_inv_fp_kernel<false>), grid, dim3(N1_THREADS), 0, st, x);
+            } else if (x.cr_last) TROY_LAUNCH(HIP_KERNEL_NAME(ntt1_fwd_fp_kernel<true>), grid, dim3(N1_THREADS), 0, st, x);
+            else TROY_LAUNCH(HIP_KERNEL_NAME(ntt1_fwd_fp_kernel<false>), grid, dim3(N1_THREADS), 0, st, x);
+            return;
+        }
         if (inverse) {
             if (x.md_ct) {
                 if (k.lean) TROY_LAUNCH(HIP_KERNEL_NAME(ntt1_inv_kernel<true, true>), grid, dim3(N1_THREADS), 0, st, x);

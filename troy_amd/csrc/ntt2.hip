@@ -643,7 +643,7 @@ __device__ __forceinline__ void ntt2_body(const Ntt2Args &a) {
     const unsigned slot = (unsigned)__builtin_amdgcn_readfirstlane((int)a.sel[sidx]);
     PrimeDesc pd = a.primes[a.map.id[slot]];
     if constexpr (FP) { pd.root = pd.root_fp; pd.iroot = pd.iroot_fp; pd.inv_n = pd.inv_n_fp; pd.iroot_last_scaled = pd.iroot_last_scaled_fp; }
-    const FpPrime fc_ = make_fp_prime(FP ? pd.p : 1);
+    const FpPrime fc_ = make_fp_prime_uniform(FP ? pd.p : 1);
     const FpPrime &fc = fc_;
     const FpPrime *const fcp = FP ? &fc_ : nullptr;
     const Mod m = mod_of(pd);
