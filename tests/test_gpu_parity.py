@@ -162,12 +162,15 @@ def test_single_pass_ntt_vs_oracle_incl_extremes(gpu, oracle_lib):
         x[r] = primes[r % len(primes)] - 1
         if r >= rows - len(primes):
             x[r, 1::2] = 0
+    from troy_amd import capi
+    fp0 = capi.stat("ntt1_fp_launches")
     for mode, inverse in ((1, False), (3, True)):
         buf = gpu.DeviceBuffer.from_numpy(x)
         ctx.ntt(buf, rows, primes, inverse=inverse)
         y = buf.to_numpy().reshape(rows, N)
         for r in range(rows):
             assert np.array_equal(y[r], oracle_lib.ntt_standalone(N, primes[r % len(primes)], x[r], mode)), (mode, r)
+    assert capi.stat("ntt1_fp_launches") == fp0 + 2, "the 40- and 50-bit rows did not run the FP64 single-pass instances"
 
 
 def test_cfgA_add_on_device(gpu):
@@ -705,3 +708,28 @@ def test_fp64_key_switch_extreme_residues(bits, gpu):
     for b in range(3):
         want = orc.impl.eval(R.OP_RELIN, R.Ct(x[b], False)).data
         assert np.array_equal(got[b], want), (bits, b)
+
+
+@pytest.mark.parametrize("logn", [12, 13, 14, 16, 17])
+def test_fp64_two_pass_transform_extremes(logn, gpu, oracle_lib):
+    """the FP64 instances of the plain two-pass transform (ntt2_fp_kernel, primes below 2^50) against the oracle: 50-, 49-, 40- and 36-bit primes
+    next to a 60-bit one (integer class in the same call), uniform rows, every residue p - 1 and p - 1 / 0 alternating -- the inputs that drive
+    the signed lazy values of the FP64 butterflies (forward: + p / 2 per stage and more; inverse: doubling per stage) to their bounds"""
+    from troy_amd import capi, synth
+    N = 1 << logn
+    primes = gpu.CoeffModulus.Create(N, [50, 40, 60, 49, 36])
+    ctx = gpu.SEALContext(gpu.CKKS, N, primes, 0)
+    rows = 3 * len(primes)
+    x = synth.uniform_rows(logn, primes, rows, N)
+    for r in range(len(primes), rows):
+        x[r] = primes[r % len(primes)] - 1
+        if r >= 2 * len(primes):
+            x[r, 1::2] = 0
+    fp0 = capi.stat("ntt2_fp_launches")
+    for mode, inverse in ((1, False), (3, True)):
+        buf = gpu.DeviceBuffer.from_numpy(x)
+        ctx.ntt(buf, rows, primes, inverse=inverse)
+        y = buf.to_numpy().reshape(rows, N)
+        for r in range(rows):
+            assert np.array_equal(y[r], oracle_lib.ntt_standalone(N, primes[r % len(primes)], x[r], mode)), (mode, r)
+    assert capi.stat("ntt2_fp_launches") == fp0 + 2

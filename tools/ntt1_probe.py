@@ -16,7 +16,7 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 lib = capi.load(os.environ.get("TROYHIP_LIB")) if os.environ.get("TROYHIP_LIB") else capi.load()
 api.KernelProvider.initialize(0, _lib=lib)
-N, bits = 32768, [60] + [58] * 13 + [60]
+N, bits = 32768, eval(os.environ.get("PROBE_BITS", "[60] + [58] * 13 + [60]"))
 primes = ta.CoeffModulus.Create(N, bits)
 ctx = ta.SEALContext(capi.BFV, N, primes, ta.PlainModulus.Batching(N, 20))
 K, L = len(primes), len(primes) - 1

@@ -89,6 +89,9 @@ __device__ __forceinline__ unsigned sw1(unsigned j) { return j ^ (((j >> 6) & 7u
 // SQ_LDS_BANK_CONFLICT = 34 % of the inverse kernel's LDS cycles in round 2, 0 in the forward kernel, which only reads that pattern).  One more
 // term -- bit 2 ^= bit 4 -- separates them and keeps every other pattern conflict-free (tools/lds_banks.py); it is no involution any more
 // (bit 4 is both a source and a target), so the LDS-DMA staging, which needs "which element belongs at position x", uses sw2_inv.
+#ifndef N1_FP_EARLY_ODD
+#define N1_FP_EARLY_ODD 0 // measured: 4421 -> 4948 us per 26 880 rows (the request costs 52 B more scratch than it hides latency)
+#endif
 #ifndef N1_FP_FENCE_B
 #define N1_FP_FENCE_B 2 // FP64 forward kernel, round B (16 values in registers next to the waiting half): butterflies in flight between scheduling fences
 #endif
@@ -286,9 +289,10 @@ template <int NV> __device__ __forceinline__ void fp_reduce_all(u64 (&y)[NV], co
 
 // the last 10 forward stages (5..14) of sub-block sb (coefficients 1024 sb .. 1024 sb + 1023), in place in the wave's region,
 // result canonical to `out` (the sub-block's 1024 coefficients in HBM)
-template <bool LEAN, bool CR, bool FP> __device__ __forceinline__ void fwd_subblock(u64 *R, const unsigned sb, const unsigned lane_in, const PrimeDesc &pd, const PrimeConst &pc, const Mod &m,
+template <bool LEAN, bool CR, bool FP, class AfterB> __device__ __forceinline__ void fwd_subblock(u64 *R, const unsigned sb, const unsigned lane_in, const PrimeDesc &pd, const PrimeConst &pc, const Mod &m,
                                                                   u64 *out, const Ntt1Args &a, const unsigned mm, const unsigned m_begin, const int stamp0, const bool hf_last,
-                                                                  const FpPrime &fc, const u64 *cr_in = nullptr, const Shoup cr_inv = Shoup{0, 0}, const u64 *cr_acc = nullptr) {
+                                                                  const FpPrime &fc, const AfterB &after_round_b, const u64 *cr_in = nullptr, const Shoup cr_inv = Shoup{0, 0},
+                                                                  const u64 *cr_acc = nullptr) {
     (void)a; (void)mm; (void)m_begin; (void)stamp0; (void)hf_last; (void)fc;
     const unsigned lane = opaque(lane_in);
     N1_PRIO(3);
@@ -306,6 +310,7 @@ template <bool LEAN, bool CR, bool FP> __device__ __forceinline__ void fwd_subbl
     }
     TROY_WAVE_SYNC();
     N1_STAMP(stamp0);
+    after_round_b(); // FP64 instances: the next row's odd half is requested here (sixteen values are gone from the registers: room for it)
     N1_SCHED_FENCE(); // the twiddle loads below stay below: hoisted over round B they would not fit the register budget
     N1_PRIO(2);
     {   // round C1: stages 9..11 on 8 values, registers = j5 j4 j3, lane = (j9..j6, j1 j0), iteration = j2; both iterations share
@@ -535,11 +540,15 @@ template <bool LEAN, bool CR, bool FP> __device__ __forceinline__ void ntt1_fwd_
             __syncthreads();
             N1_STAMP(3 + 6 * hf);
             if (hf == 1 && mm + 1 < m_end) load_half(xe, in_row(mm + 1), 0); // all 32 registers are free now: request the next limb's even half
-            fwd_subblock<LEAN, CR, FP>(region, 16 * hf + wv, lane, pd, pc, m, out + 1024 * (16 * hf + wv), a, mm, m_begin, 4 + 6 * hf, hf == 1, fc, CR ? cin + 1024 * (16 * hf + wv) : nullptr, cr_inv,
-                                   CR && cacc ? cacc + 1024 * (16 * hf + wv) : nullptr);
+            // the FP64 instances compute faster than the odd half of the next row arrives when it is requested at the end of the row (plain
+            // transform 167 ns per limb with 74 % VALU-busy): they request it after round B of the second half, under rounds C1 / C2
+            constexpr bool EARLY_ODD = FP && N1_FP_EARLY_ODD;
+            auto after_b = [&]() { if (EARLY_ODD && hf == 1 && mm + 1 < m_end) load_half(xo, in_row(mm + 1), 1); };
+            fwd_subblock<LEAN, CR, FP>(region, 16 * hf + wv, lane, pd, pc, m, out + 1024 * (16 * hf + wv), a, mm, m_begin, 4 + 6 * hf, hf == 1, fc, after_b, CR ? cin + 1024 * (16 * hf + wv) : nullptr,
+                                       cr_inv, CR && cacc ? cacc + 1024 * (16 * hf + wv) : nullptr);
             N1_STAMP(7 + 6 * hf);
         }
-        if (mm + 1 < m_end) load_half(xo, in_row(mm + 1), 1);
+        if (!(FP && N1_FP_EARLY_ODD) && mm + 1 < m_end) load_half(xo, in_row(mm + 1), 1);
     }
 }
 template <bool LEAN, bool CR> __global__ __launch_bounds__(N1_THREADS) void ntt1_fwd_kernel(Ntt1Args a) { ntt1_fwd_body<LEAN, CR, false>(a); }
