@@ -503,7 +503,7 @@ def algorithmic_bytes(w, B):
     small_x, small_f = kbx <= 2 and nb <= 8, kb2 <= 2           # the everything-in-registers kernels of behz2.hip
     add(f"behz2s_extend_kernel<{kbx}, {(nb + 3) // 4}>" if small_x else f"behz2_extend_kernel<{kbx}>", 2 * 2 * B * (L + nb) * P)
     qs_all = [int(p) for p in w.ctx.coeff_modulus]
-    q_primes, special, bsk_primes = qs_all[:L], qs_all[-1:], [1 << 60] * nb  # the BEHZ auxiliary primes are 61 bits: integer kernels
+    q_primes, special, bsk_primes = qs_all[:L], qs_all[-1:], [int(p) for p in w.ctx.behz_bases(L)[0]]  # the auxiliary base as the library chose it (hostmath.cpp)
     _by_prime_class(add, f"ntt2_kernel<0, 1, {k1}, {logc}, 0, 0, 0>", q_primes + bsk_primes, 2 * (2 * B) * 2 * P)
     _by_prime_class(add, "ntt2_kernel<0, 0, 9, 0, 1, 0, 2>", q_primes + bsk_primes, 7 * B * P)
     md_split = os.environ.get("TROYHIP_MODDOWN", "")[:1] == "s"
@@ -519,20 +519,26 @@ def algorithmic_bytes(w, B):
         if not md_split:
             _by_prime_class(add, f"ntt2_kernel<1, 1, {k1}, {logc}, 3, 0, 0>", q_primes, 2 * B * 3 * P + 2 * B * P / L)
     else:
-        # the single-pass inverse runs as two launches by prime class: guard-free rounds below 2^58, guarded butterflies for the rest
+        # the single-pass inverse runs as up to three launches by prime class: FP64 rounds for the primes in [2^33, 2^50), guard-free integer rounds
+        # below 2^58, guarded butterflies for the rest
         qs = [int(p) for p in w.ctx.coeff_modulus]
-        lean_q = sum(1 for p in qs[:L] if (1 << 33) <= p < (1 << 58))          # Bsk primes are 61 bits: guarded
-        lean_k = sum(1 for p in qs[:L + 1] if (1 << 33) <= p < (1 << 58))
         fused_md = os.environ.get("TROYHIP_MODDOWN", "") [:1] != "s" and all(p >= 1 << 33 for p in qs[:L])
+
+        def n1(tail, primes, per_limb):
+            for p in primes:
+                if _fp_on() and (1 << 33) <= p < (1 << FP_MAX_BITS):
+                    add(f"ntt1_inv_fp_kernel<{tail}>", per_limb)
+                else:
+                    add(f"ntt1_inv_kernel<{'true' if (1 << 33) <= p < (1 << 58) else 'false'}, {tail}>", per_limb)
         # multiply: 3 polynomials in both bases; key switch: 2 accumulators over the L + 1 key primes.  With the mod-down fused (the
         # default) the special limb is transformed on its own and the L data limbs leave through the epilogue: read acc and ct, write ct,
         # plus the special limb once per (ciphertext, accumulator)
-        add("ntt1_inv_kernel<true, false>", 3 * B * lean_q * 2 * P + (0 if fused_md else 2 * B * lean_k * 2 * P))
-        add("ntt1_inv_kernel<false, false>", 3 * B * ((L - lean_q) + nb) * 2 * P + (2 * B * 2 * P if fused_md else 2 * B * (L + 1 - lean_k) * 2 * P))
+        n1("false", q_primes + bsk_primes, 3 * B * 2 * P)
+        n1("false", special, 2 * B * 2 * P)
         if fused_md:
-            add("ntt1_inv_kernel<true, true>", 2 * B * lean_q * 3 * P + (2 * B * P if lean_q else 0))
-            if L - lean_q:
-                add("ntt1_inv_kernel<false, true>", 2 * B * (L - lean_q) * 3 * P + (0 if lean_q else 2 * B * P))
+            n1("true", q_primes, 2 * B * 3 * P + 2 * B * P / L)
+        else:
+            n1("false", q_primes, 2 * B * 2 * P)
     add(f"behz2{'s' if small_f else ''}_floor_sk_kernel<{kb1}, {kb2}, {fast}>", 3 * B * (2 * L + nb) * P)
     # relinearize: digit decomposition + first pass, second pass with the inner product against the key, inverse, mod-down
     _ks_forward_pair(add, w, B, L, logn, False)

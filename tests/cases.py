@@ -730,6 +730,47 @@ def check_modswitch_as_first_op(cfg_name, batch=2):
                 assert np.array_equal(got2[b], orc.impl.eval(op, R.Ct(xs2[b], ntt)).data), ("grow", b)
 
 
+def _is_prime(n):
+    if n < 2:
+        return False
+    for q in (2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37):
+        if n % q == 0:
+            return n == q
+    d, r = n - 1, 0
+    while d % 2 == 0:
+        d //= 2
+        r += 1
+    for a in (2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37):  # deterministic below 3.3e24
+        x = pow(a, d, n)
+        if x in (1, n - 1):
+            continue
+        for _ in range(r - 1):
+            x = x * x % n
+            if x == n - 1:
+                break
+        else:
+            return False
+    return True
+
+
+def check_aux_base(bsk, gamma, golden_level, key_primes, N):
+    """The auxiliary base B u {m_sk} of the BEHZ multiplication is internal (troy_amd/csrc/hostmath.cpp, RnsLevel::build: the product's limbs do not
+    depend on it).  Either it IS the reference's (TROYHIP_AUX_BASE=reference: equality with the golden file), or it is the library's own choice: as
+    many primes as the reference takes, NTT-friendly, pairwise distinct, none of them a key prime, all of one size class (below 2^50 for the FP64
+    butterflies or below 2^58 for the guard-free integer ones).  gamma (decryption) is always the reference's."""
+    assert str(gamma) == golden_level["gamma"]
+    if [str(x) for x in bsk] == golden_level["bsk"]:
+        return "reference"
+    bsk = [int(x) for x in bsk]
+    assert len(bsk) == len(golden_level["bsk"]), "the auxiliary base may not cost an extra limb"
+    assert len(set(bsk)) == len(bsk) and not set(bsk) & {int(p) for p in key_primes}
+    bits = {p.bit_length() for p in bsk}
+    assert bits in ({50}, {58}), bits
+    for p in bsk:
+        assert (p - 1) % (2 * N) == 0 and _is_prime(p), p
+    return "own-%d" % bits.pop()
+
+
 def check_rescale_onto_itself(cfg, batch=3):
     """troyhip_rescale_to_next / troyhip_mod_switch_to_next called straight through the C ABI with the OUTPUT batch laid over the input
     batch (a strided input -- capacity 3 -- rescaled onto its own buffer with a dense output stride): the rows a later item still reads are

@@ -33,7 +33,7 @@ def test_emulated_kernels_match_reference(name, emul_api, golden_hashes, golden_
     assert [str(p) for p in be.primes] == gp["primes"] and str(be.t) == gp["plain_modulus"]
     for limbs, lv in gp["levels"].items():
         bsk, gamma = be.ctx.behz_bases(int(limbs))
-        assert [str(x) for x in bsk] == lv["bsk"] and str(gamma) == lv["gamma"]
+        cases.check_aux_base(bsk, gamma, lv, be.primes, cfg["N"])  # the reference's base under TROYHIP_AUX_BASE=reference, else the library's own class
     for p in be.primes:
         t, g = be.ctx.ntt_tables(p), gp["tables"][str(p)]
         for k in ("root_op", "root_quo", "inv_op", "inv_quo"):
@@ -134,6 +134,37 @@ def test_emulated_rescale_onto_itself(cfg, emul_api):
     cases.check_rescale_onto_itself(cfg, batch=2 if cfg["N"] > 4096 else 3)
 
 
+def test_emulated_auxiliary_base_independence(tmp_path, golden_params, golden_hashes):
+    """the BEHZ auxiliary base is internal: with the reference's 61-bit base (TROYHIP_AUX_BASE=reference) the tables equal the reference's and every
+    scenario output equals the golden hashes -- the same hashes the default base (own primes of the guard-free / FP64 class) reproduces in
+    test_emulated_kernels_match_reference.  Child process: the switch is read once."""
+    import json
+    import subprocess
+    import sys
+    names = ["bfv_n64_k3", "bfv_n128_k4", "bfv_n128_k5_60", "cfgA_bfv_n4096_k3"]
+    script = tmp_path / "aux.py"
+    script.write_text(
+        "import sys, json; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "from troy_amd import api, capi\n"
+        "lib = capi.load(%r)\n"
+        "api.KernelProvider.initialize(0, _lib=lib)\n"
+        "import cases\n"
+        "out = {}\n"
+        "for name in %r:\n"
+        "    cfg = cases.CONFIGS[name]\n"
+        "    be = cases.GpuBackend(cfg, batch=1)\n"
+        "    lv = {str(l): [[str(x) for x in be.ctx.behz_bases(l)[0]], str(be.ctx.behz_bases(l)[1])] for l in range(be.ctx.last_limbs, len(be.primes) + 1)}\n"
+        "    out[name] = dict(levels=lv, hashes={k: cases.sha(m.data) for k, m in cases.scenario(be, cfg).items()})\n"
+        "print('RESULT ' + json.dumps(out))\n" % (ROOT, os.path.join(ROOT, "tests"), EMUL, names))
+    r = subprocess.run([sys.executable, str(script)], env=dict(os.environ, TROYHIP_AUX_BASE="reference"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    got = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:])
+    for name in names:
+        for limbs, lv in golden_params[name]["levels"].items():
+            assert got[name]["levels"][limbs] == [lv["bsk"], lv["gamma"]], (name, limbs)
+        assert got[name]["hashes"] == {k: v["sha256"] for k, v in golden_hashes[name].items()}, name
+
+
 def test_emulated_size_limits(emul_api):
     cases.check_size_limits("bfv_n64_k3")
     cases.check_size_limits("ckks_n128_k6")
@@ -218,6 +249,7 @@ def test_emulated_single_pass_ntt_row_loop_and_prime_classes(oracle_lib, tmp_pat
         "assert np.array_equal(buf2.to_numpy().reshape(rows2, N), e)\n"
         "print('ok')\n" % (ROOT, os.path.join(ROOT, 'tests'), EMUL))
     for rpw in ("3", "1"):
-        env = dict(os.environ, TROYHIP_NTT1_RPW=rpw, TROYHIP_NTT="single")  # small launches go to the two-pass kernels by default
+        # small launches go to the two-pass kernels by default; the reference's auxiliary base supplies the 61-bit prime of the guarded class
+        env = dict(os.environ, TROYHIP_NTT1_RPW=rpw, TROYHIP_NTT="single", TROYHIP_AUX_BASE="reference")
         out = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=900)
         assert out.returncode == 0 and "ok" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]

@@ -35,7 +35,7 @@ def test_context_tables_match_reference(name, gpu, golden_params):
     assert [be.ctx.key_limbs - be.ctx.last_limbs + 1, be.ctx.first_limbs, be.ctx.last_limbs] == gp["chain"]
     for limbs, lv in gp["levels"].items():
         bsk, gamma = be.ctx.behz_bases(int(limbs))
-        assert [str(x) for x in bsk] == lv["bsk"] and str(gamma) == lv["gamma"]
+        cases.check_aux_base(bsk, gamma, lv, be.primes, cfg["N"])  # internal base: the reference's under TROYHIP_AUX_BASE=reference (test below), else the library's own class
     for p in be.primes:
         t, g = be.ctx.ntt_tables(p), gp["tables"][str(p)]
         assert str(t["root"]) == g["root"] and [str(x) for x in t["inv_degree"]] == g["inv_degree"]
@@ -149,28 +149,32 @@ def test_ntt_properties_at_full_size(gpu):
 
 def test_single_pass_ntt_vs_oracle_incl_extremes(gpu, oracle_lib):
     """ntt1.hip (N = 2^15) against the oracle, row by row: uniform rows, every residue p - 1, and p - 1 / 0 alternating -- the inputs
-    that drive the guard-free rounds (forward: +3p per stage; inverse: the bound doubles per stage between lite reductions) to their
-    largest values -- for primes of both butterfly classes (40 / 50 / 58 bits guard-free, 60 / 61 bits guarded)"""
-    from troy_amd import synth
+    that drive the guard-free rounds (forward: +3p per stage; inverse: the bound doubles per stage between lite reductions) and the FP64
+    rounds to their largest values -- for primes of every butterfly class (40 / 50 bits FP64, 58 bits guard-free, 60 / 61 bits guarded)"""
+    from troy_amd import capi, synth
     N = 32768
     kp = gpu.CoeffModulus.Create(N, [60, 50, 58, 40, 60])
     ctx = gpu.SEALContext(gpu.BFV, N, kp, gpu.PlainModulus.Batching(N, 20))
-    primes = kp[:4] + [int(ctx.behz_bases(4)[0][0])]
-    rows = 206 * len(primes)  # 1030 rows: at least four per CU, the size from which the single-pass kernel is used
-    x = synth.uniform_rows(77, primes, rows, N)
-    for r in range(rows - 2 * len(primes), rows):
-        x[r] = primes[r % len(primes)] - 1
-        if r >= rows - len(primes):
-            x[r, 1::2] = 0
-    from troy_amd import capi
-    fp0 = capi.stat("ntt1_fp_launches")
-    for mode, inverse in ((1, False), (3, True)):
-        buf = gpu.DeviceBuffer.from_numpy(x)
-        ctx.ntt(buf, rows, primes, inverse=inverse)
-        y = buf.to_numpy().reshape(rows, N)
-        for r in range(rows):
-            assert np.array_equal(y[r], oracle_lib.ntt_standalone(N, primes[r % len(primes)], x[r], mode)), (mode, r)
-    assert capi.stat("ntt1_fp_launches") == fp0 + 2, "the 40- and 50-bit rows did not run the FP64 single-pass instances"
+    # four 60-bit data primes: no narrower auxiliary class fits without an extra limb, so this context keeps the reference's 61-bit primes
+    kp61 = gpu.CoeffModulus.Create(N, [60] * 5)
+    ctx61 = gpu.SEALContext(gpu.BFV, N, kp61, gpu.PlainModulus.Batching(N, 20))
+    aux = [int(x) for x in ctx61.behz_bases(4)[0]]
+    assert aux[0] >> 60 == 1, "expected the 61-bit auxiliary class at this level"
+    for c, primes, fp_expected in ((ctx, kp[:4], 2), (ctx61, [aux[0], kp61[1]], 0)):
+        rows = (1030 // len(primes) + 1) * len(primes)  # at least four rows per CU: the size from which the single-pass kernel is used
+        x = synth.uniform_rows(77, primes, rows, N)
+        for r in range(rows - 2 * len(primes), rows):
+            x[r] = primes[r % len(primes)] - 1
+            if r >= rows - len(primes):
+                x[r, 1::2] = 0
+        fp0 = capi.stat("ntt1_fp_launches")
+        for mode, inverse in ((1, False), (3, True)):
+            buf = gpu.DeviceBuffer.from_numpy(x)
+            c.ntt(buf, rows, primes, inverse=inverse)
+            y = buf.to_numpy().reshape(rows, N)
+            for r in range(rows):
+                assert np.array_equal(y[r], oracle_lib.ntt_standalone(N, primes[r % len(primes)], x[r], mode)), (mode, r)
+        assert capi.stat("ntt1_fp_launches") == fp0 + fp_expected, "FP64 single-pass instances: the 40- and 50-bit rows take them, 60- / 61-bit rows never"
 
 
 def test_cfgA_add_on_device(gpu):
@@ -514,7 +518,8 @@ def test_behz_kernel_forms_agree(env, gpu, oracle_lib):
     assert out.stdout.split()[-len(Ks):] == here
 
 
-@pytest.mark.parametrize("env", [{"TROYHIP_KS": "split"}, {"TROYHIP_TENSOR": "split"}, {"TROYHIP_BEHZ": "valu"}, {"TROYHIP_MODDOWN": "split"}, {"TROYHIP_FP64": "off"}])
+@pytest.mark.parametrize("env", [{"TROYHIP_KS": "split"}, {"TROYHIP_TENSOR": "split"}, {"TROYHIP_BEHZ": "valu"}, {"TROYHIP_MODDOWN": "split"}, {"TROYHIP_FP64": "off"},
+                                 {"TROYHIP_AUX_BASE": "reference"}, {"TROYHIP_AUX_BASE": "reference", "TROYHIP_BEHZ": "valu"}])
 def test_unfused_kernel_paths_agree(env, gpu):
     """the unfused key-switch inner product, the unfused tensor, the VALU BEHZ kernels and the element-wise BFV / BGV mod-down instead of
     the inverse transform's epilogue (environment switches, read once per process) give the same limbs as the default path, which the
@@ -533,7 +538,7 @@ def test_unfused_kernel_paths_agree(env, gpu):
     assert out.stdout.split()[-len(names):] == here
 
 
-@pytest.mark.parametrize("env", [{"TROYHIP_NTT": "single"}, {"TROYHIP_NTT": "twopass"}, {"TROYHIP_BFLY": "guarded"}, {"TROYHIP_NTT": "single", "TROYHIP_BFLY": "guarded"}, {"TROYHIP_FP64": "off"},
+@pytest.mark.parametrize("env", [{"TROYHIP_NTT": "single"}, {"TROYHIP_NTT": "twopass"}, {"TROYHIP_BFLY": "guarded"}, {"TROYHIP_NTT": "single", "TROYHIP_BFLY": "guarded"}, {"TROYHIP_FP64": "off"}, {"TROYHIP_AUX_BASE": "reference"},
                                  {"TROYHIP_NTT": "single", "TROYHIP_MODDOWN": "split"}, {"TROYHIP_NTT": "single", "TROYHIP_CORR": "split"}])
 def test_ntt_forms_agree_at_headline_size(env, gpu):
     """N = 2^15: the single-pass transform forced at a small batch (by default it takes launches of four rows per CU and more), the
@@ -733,3 +738,28 @@ def test_fp64_two_pass_transform_extremes(logn, gpu, oracle_lib):
         for r in range(rows):
             assert np.array_equal(y[r], oracle_lib.ntt_standalone(N, primes[r % len(primes)], x[r], mode)), (mode, r)
     assert capi.stat("ntt2_fp_launches") == fp0 + 2
+
+
+def test_auxiliary_base_reference_mode_matches_golden_tables(gpu, golden_params):
+    """TROYHIP_AUX_BASE=reference (child process: read once): the BEHZ bases of every level of every BFV configuration equal the reference's; the
+    default base's results are pinned by the golden hashes above and compared with this mode in test_unfused_kernel_paths_agree /
+    test_ntt_forms_agree_at_headline_size"""
+    import json
+    import subprocess
+    import sys
+    names = [n for n in cases.SMALL + cases.MEDIUM + cases.LARGE if cases.CONFIGS[n]["scheme"] == cases.BFV]
+    tests_dir = os.path.dirname(os.path.abspath(__file__))
+    code = ("import sys, json; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import troy_amd as ta, cases\n"
+            "ta.KernelProvider.initialize(0)\n"
+            "out = {}\n"
+            "for n in %r:\n"
+            "    be = cases.GpuBackend(cases.CONFIGS[n])\n"
+            "    out[n] = {str(l): [[str(x) for x in be.ctx.behz_bases(l)[0]], str(be.ctx.behz_bases(l)[1])] for l in range(be.ctx.last_limbs, len(be.primes) + 1)}\n"
+            "print('RESULT ' + json.dumps(out))\n") % (tests_dir, os.path.dirname(tests_dir), names)
+    r = subprocess.run([sys.executable, "-c", code], env={**os.environ, "TROYHIP_AUX_BASE": "reference"}, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    got = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")][-1][7:])
+    for n in names:
+        for limbs, lv in golden_params[n]["levels"].items():
+            assert got[n][limbs] == [lv["bsk"], lv["gamma"]], (n, limbs)

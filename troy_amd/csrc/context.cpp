@@ -267,7 +267,10 @@ void Context::build_level(int limbs) {
     Level &lv = levels[limbs];
     lv.limbs = limbs;
     std::vector<u64> q(primes.begin(), primes.begin() + limbs);
-    lv.rns.build(N, q, t);
+    // TROYHIP_AUX_BASE=reference: the reference's 61-bit auxiliary primes (tests: tables against the reference, results against the default)
+    static const bool aux_auto = [] { const char *e = std::getenv("TROYHIP_AUX_BASE"); return !(e && std::strcmp(e, "reference") == 0); }();
+    std::vector<u64> key_primes(primes.begin(), primes.begin() + K);
+    lv.rns.build(N, q, t, aux_auto && scheme == SCHEME_BFV, key_primes);
     for (u64 p : lv.rns.Bsk) lv.bsk_ids.push_back((uint8_t)register_prime(p));
 }
 

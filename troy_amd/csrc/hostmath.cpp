@@ -191,16 +191,41 @@ void BaseConv::build(const std::vector<u64> &in_, const std::vector<u64> &out_) 
     }
 }
 
-void RnsLevel::build(u64 N, const std::vector<u64> &q_, u64 t_) {
+// The auxiliary base B u {m_sk} of the BEHZ multiplication is INTERNAL: the product's limbs in base q do not depend on which primes it holds.
+// With R' the integer the extension + small Montgomery step produce (a function of the q-residues alone: rns.cpp:805-913), D the integer tensor
+// of two such R', the floor step leaves F = floor(t D / q) - alpha' (alpha' from the q-residues of t D alone, rns.cpp:915-960), and the
+// Shenoy-Kumaresan step returns F mod q EXACTLY whenever |F| fits the base (rns.cpp:962-1037) -- every residue in the auxiliary base is the residue
+// of one of these integers, so any base of pairwise coprime primes, coprime to q, with the reference's size margin gives the same limbs.
+// The reference takes 61-bit primes (rns.cpp:610-635); they land in the slowest butterfly class (range guards: 20 instructions).  aux_auto picks,
+// when it costs no extra limb under the reference's own size rule, primes below 2^50 (FP64 butterflies, fpmod.h) or below 2^58 (guard-free
+// integer butterflies); `exclude` = every key prime (the auxiliary primes must not repeat one).  gamma (decryption only) stays the reference's.
+void RnsLevel::build(u64 N, const std::vector<u64> &q_, u64 t_, bool aux_auto, const std::vector<u64> &exclude) {
     q = q_;
     t = t_;
     size_t nq = q.size();
     int t_bits = t ? 64 - __builtin_clzll(t) : 0;
+    const int need = 32 + t_bits + bit_length_of_product(q);
+    auto count_for = [&](int bits) { size_t n = nq; while (need >= bits * (int)n + bits) n++; return n; };
     size_t nB = nq;
-    if (32 + t_bits + bit_length_of_product(q) >= 61 * (int)nq + 61) nB++; // rns.cpp:610-615
+    if (need >= 61 * (int)nq + 61) nB++;                                   // rns.cpp:610-615
     auto aux = get_primes(2 * N, 61, nB + 2);                              // rns.cpp:629-635
-    m_sk = aux[0];
     gamma = aux[1];
+    aux_bits = 61;
+    if (aux_auto) {
+        for (int bits : {50, 58}) {
+            if (count_for(bits) != nB || (u64(1) << (bits - 1)) <= 2 * N) continue;
+            std::vector<u64> pool = get_primes(2 * N, bits, nB + 1 + exclude.size() + nq), pick;
+            for (u64 p : pool)
+                if (std::find(exclude.begin(), exclude.end(), p) == exclude.end() && std::find(q.begin(), q.end(), p) == q.end() && pick.size() < nB + 1) pick.push_back(p);
+            if (pick.size() < nB + 1) continue;
+            aux.assign(nB + 2, 0);
+            aux[0] = pick[0];
+            for (size_t i = 0; i < nB; i++) aux[2 + i] = pick[1 + i];
+            aux_bits = bits;
+            break;
+        }
+    }
+    m_sk = aux[0];
     B.assign(aux.begin() + 2, aux.begin() + 2 + nB);
     Bsk = B;
     Bsk.push_back(m_sk);

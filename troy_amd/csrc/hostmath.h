@@ -62,7 +62,8 @@ struct RnsLevel {
     u64 inv_gamma_mod_t = 0;
     std::vector<u64> prod_tgamma_mod_q;
     u64 neg_inv_q_mod_t = 0, neg_inv_q_mod_gamma = 0;
-    void build(u64 N, const std::vector<u64> &q, u64 t);
+    int aux_bits = 61; // size class of B u {m_sk}: 61 = the reference's primes, 58 / 50 = the guard-free / FP64 classes (see build())
+    void build(u64 N, const std::vector<u64> &q, u64 t, bool aux_auto = false, const std::vector<u64> &exclude = {});
 };
 
 } // namespace host
