@@ -424,8 +424,10 @@ void Context::upload_tables() {
                 c->floor_frag2 = upload(pack_mfma_rows(f2, L), lv.dev_blocks);
             c->floor_msk_frag = upload(pack_mfma_rows(fm, 2), lv.dev_blocks);
         }
+        // the one-step quotient estimate of the behz2 epilogues holds for every output prime >= 2^33 (behz2.hip, header); the auxiliary primes are
+        // 61 bits in the reference's base and 58 or 50 bits in the library's own (RnsLevel::build)
         bool big_bsk = true;
-        for (u64 p : r.Bsk) big_bsk = big_bsk && p >= (u64(1) << 50);
+        for (u64 p : r.Bsk) big_bsk = big_bsk && p >= (u64(1) << 33);
         if (L <= 15 && nBsk <= 16 && big_bsk && behz_v2_enabled()) { // second matrix-core form: behz2.hip
             const int KBx = (L + 1 + 3) / 4, KB1 = (L + 3) / 4, KB2 = (nB + 1 + 3) / 4;
             std::vector<std::vector<u64>> xw(nBsk), f1w(nBsk), f2w(L), mtw(2), mskw(2);
