@@ -283,18 +283,21 @@ void launch_tensor(int s1, int s2, const u64 *a, const u64 *b, u64 *out, u64 a_b
 // ---------------------------------------------------------------- Galois (a-6 / A.11)
 // coefficient form: out[(i*g) mod N] = +-in[i]   (src/utils/galois.cpp:143-162).  One launch covers `batch` items of `limbs` rows
 // each; item b reads in + b * in_bstride and writes out + b * out_bstride.
+// Written as a GATHER: coefficient n goes to position n g mod N with the sign (-1)^floor(n g / N), i.e. output j takes input n0 = j g^-1 mod 2N when
+// n0 < N and the negated input n0 - N otherwise (exactly one of j, j + N is n g mod 2N for an n below N, g being odd).  The scatter form wrote 64
+// different cache lines per wave-store (0.28-0.30 of the HBM roofline at N = 2^16); scattered READS of a row that fits L2 are served from there and the
+// stores are whole lines.  elt_inv = g^-1 mod 2N comes from the host.
 __global__ __launch_bounds__(EW_THREADS) void galois_coeff_kernel(const u64 *in, u64 in_bstride, u64 *out, u64 out_bstride, const PrimeDesc *primes, LimbMap map, int logn,
-                                                                  uint32_t elt, u64 limbs, u64 total) {
+                                                                  uint32_t elt_inv, u64 limbs, u64 total) {
     u64 i = (u64)blockIdx.x * EW_THREADS + threadIdx.x;
     if (i >= total) return;
     const u64 N = u64(1) << logn;
-    u64 row = i >> logn, n = i & (N - 1), b = row / limbs, l = row % limbs;
+    u64 row = i >> logn, j = i & (N - 1), b = row / limbs, l = row % limbs;
     const u64 p = primes[map.id[l]].p;
-    u64 raw = n * elt;
-    u64 idx = raw & (N - 1);
-    u64 v = in[b * in_bstride + (l << logn) + n];
-    if ((raw >> logn) & 1) v = negmod(v, p);
-    out[b * out_bstride + (l << logn) + idx] = v;
+    const u64 n0 = (j * elt_inv) & (2 * N - 1);
+    u64 v = in[b * in_bstride + (l << logn) + (n0 & (N - 1))];
+    if (n0 >> logn) v = negmod(v, p);
+    out[b * out_bstride + (l << logn) + j] = v;
 }
 // kNegacyclicShiftPolyCoeffmod (kernelutils.cu; CPU polyarithsmallmod.cpp:128-152): out[(i + shift) mod N] = +-in[i]
 __global__ __launch_bounds__(EW_THREADS) void negacyclic_shift_kernel(const u64 *in, u64 in_bstride, u64 *out, u64 out_bstride, const PrimeDesc *primes, LimbMap map, int logn,
@@ -334,7 +337,12 @@ void launch_galois(bool ntt_form, const u64 *in, u64 in_bstride, u64 *out, u64 o
     if (!total) return;
     dim3 grid(ceil_div(total, EW_THREADS)), blk(EW_THREADS);
     if (ntt_form) TROY_LAUNCH(galois_ntt_kernel, grid, blk, 0, s, in, in_bstride, out, out_bstride, logn, elt, limbs, total);
-    else TROY_LAUNCH(galois_coeff_kernel, grid, blk, 0, s, in, in_bstride, out, out_bstride, primes, map, logn, elt, limbs, total);
+    else {
+        uint32_t inv = 1; // g^-1 mod 2N by Newton steps (g odd): x <- x (2 - g x), five steps reach 32 bits
+        for (int it = 0; it < 5; it++) inv *= 2u - elt * inv;
+        inv &= (uint32_t)((2u << logn) - 1);
+        TROY_LAUNCH(galois_coeff_kernel, grid, blk, 0, s, in, in_bstride, out, out_bstride, primes, map, logn, inv, limbs, total);
+    }
     launch_check("galois_kernel");
 }
 
