@@ -3,6 +3,8 @@
 # roofline launches, SQ counters of the default step, PMC HBM traffic stamped with the build id.  usage (on the GPU box): tools/r3_profiles.sh
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/final; mkdir -p $O
 cd $R
+# PMC traffic FIRST: the bench lines below then carry it (the file is tied to this build by its build id)
+bash tools/measure_traffic.sh 256 > $O/traffic.log 2>&1; tail -16 $O/traffic.log; cp gpurun_out/r03_traffic.json $O/ 2>/dev/null; cp gpurun_out/r03_traffic.json profiles/r03_traffic.json 2>/dev/null
 for W in bfv_n32768_l14 bfv_n8192_l4 ckks_n32768_chain bgv_n65536_relin_rot ckks_matmul_128; do
   timeout 900 python3 bench.py --workload $W 2> $O/bench_$W.err | tail -1 > $O/r03_bench_$W.json
   cut -c1-200 $O/r03_bench_$W.json
@@ -23,4 +25,3 @@ for W in bfv_n32768_l14 ckks_n32768_chain; do
   cut -c1-260 $O/r03_pmc_sq_$W.txt | head -16
 done
 cd $R
-bash tools/measure_traffic.sh 256 > $O/traffic.log 2>&1; tail -16 $O/traffic.log; cp gpurun_out/r03_traffic.json $O/ 2>/dev/null
