@@ -401,6 +401,7 @@ def ntt_roofline(ta, capi, lib, w, reps):
                                       "ntt2_kernel (strided pass + contiguous pass = one limb-transform per row)"),
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
             "algorithmic_bytes_per_launch": algo_bytes, "launch_us": round(per_launch_s * 1e6, 2), "limb_transforms_per_launch": rows,
+            "launch_batch": B, "launch_batch_cap": "min(batch_per_gpu, 128; 32 above N = 2^15): one lane's key-switch shape, B (L+1) L rows",
             "launch_kernels": [{"name": k["name"], "us": round(k["total_us"] / k["calls"], 1)} for k in kernels]}
     traffic = load_traffic()
     if traffic and traffic.get("N") == N:
