@@ -402,7 +402,11 @@ def ntt_roofline(ta, capi, lib, w, reps):
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
             "algorithmic_bytes_per_launch": algo_bytes, "launch_us": round(per_launch_s * 1e6, 2), "limb_transforms_per_launch": rows,
             "launch_batch": B, "launch_batch_cap": "min(batch_per_gpu, 128; 32 above N = 2^15): one lane's key-switch shape, B (L+1) L rows",
-            "launch_kernels": [{"name": k["name"], "us": round(k["total_us"] / k["calls"], 1)} for k in kernels]}
+            "launch_reps": reps,
+            "launch_kernels": [{"name": k["name"], "us": round(k["total_us"] / k["calls"], 1)} for k in kernels],
+            "launch_kernels_note": "one forward + one inverse launch under per-kernel events in front of the timed launches (third use of the buffer); launch_us is the "
+                                   "mean of the timed back-to-back launches.  A rocprofv3 --stats average over the whole command also contains the first, cold "
+                                   "launch of each kernel (about 15 % slower) and that instrumented one"}
     traffic = load_traffic()
     if traffic and traffic.get("N") == N:
         per_row = traffic.get("hbm_bytes_per_limb_transform", {}).get("ntt1" if single else "ntt2")
@@ -702,7 +706,8 @@ def main():
     ap.add_argument("--streams", type=int, default=0, help="split the batch over this many HIP streams (one context each); 0 = the workload's default")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-per-kernel", action="store_true")
-    ap.add_argument("--ntt-reps", type=int, default=10)
+    ap.add_argument("--ntt-reps", type=int, default=40,
+                    help="timed roofline launches (forward / inverse alternating); 40 keeps the two cold launches in front of them below 2 %% of a rocprofv3 average")
     ap.add_argument("--no-roofline", action="store_true", help="skip the roofline launches (PMC passes over the timed step only)")
     ap.add_argument("--roofline-only", action="store_true", help="skip the timed steps: only the roofline NTT launches run (for the rocprofv3 summary of exactly that kernel)")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed even for one rank (tests the RCCL path)")

@@ -17,6 +17,7 @@ for W in bfv_n32768_l14 bfv_n8192_l4 ckks_n32768_chain bgv_n65536_relin_rot ckks
 done
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_roofline -o p -- python3 $R/bench.py --roofline-only --no-cpu-baseline > $O/prof_roofline.log 2>&1
 f=$(find $O/prof_roofline -name 'p_kernel_stats.csv' | head -1); [ -n "$f" ] && cp $f $O/r03_roofline_kernel_stats.csv && python3 $R/tools/kstats.py $f 8
+t=$(find $O/prof_roofline -name 'p_kernel_trace.csv' | head -1); [ -n "$t" ] && python3 $R/tools/trace_steady.py $t ntt1_ 3 80 | tee $O/r03_roofline_trace_steady.txt
 tail -1 $O/prof_roofline.log | cut -c1-700
 # SQ counters (own passes, kernel trace only): the headline step and the CKKS chain step (FP64 instances)
 for W in bfv_n32768_l14 ckks_n32768_chain; do
