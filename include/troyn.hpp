@@ -19,6 +19,7 @@
 #include <cmath>
 #include <complex>
 #include <cstdint>
+#include <functional>
 #include <istream>
 #include <ostream>
 #include <map>
@@ -263,7 +264,49 @@ public:
         return dev_->get();
     }
     void adoptDevice(std::shared_ptr<DeviceArray> d) { dev_ = std::move(d); } // the encoder hands over the buffer it transformed
+    // PlaintextCuda::save / load (src/plaintext_cuda.cu:7-27): parms_id (32 bytes), coeff_count, scale, word count, words
+    void save(std::ostream &stream) const {
+        stream.write(reinterpret_cast<const char *>(parms_id_.data()), 32);
+        const size_t count = data_.size();
+        stream.write(reinterpret_cast<const char *>(&count), sizeof(size_t));
+        stream.write(reinterpret_cast<const char *>(&scale_), sizeof(double));
+        stream.write(reinterpret_cast<const char *>(&count), sizeof(size_t));
+        stream.write(reinterpret_cast<const char *>(data_.data()), (std::streamsize)(count * 8));
+    }
+    // a coefficient-form plaintext needs nothing else; an NTT-form one carries only the HASH of its level, which the overload
+    // with the context resolves
+    void load(std::istream &stream) { read(stream, nullptr); }
+    void load(std::istream &stream, const SEALContext &context) {
+        auto ids = context.levelIDs();
+        read(stream, [&](const uint64_t *hash) {
+            for (const ParmsID &id : *ids)
+                if (id.limbs && std::equal(hash, hash + 4, id.data())) return id.limbs;
+            throw std::invalid_argument("plain is not valid for encryption parameters");
+            return 0;
+        });
+    }
 private:
+    void read(std::istream &stream, const std::function<int(const uint64_t *)> &limbs_of) {
+        ParmsID id;
+        size_t count = 0, words = 0;
+        double scale = 1.0;
+        stream.read(reinterpret_cast<char *>(id.data()), 32);
+        stream.read(reinterpret_cast<char *>(&count), sizeof(size_t));
+        stream.read(reinterpret_cast<char *>(&scale), sizeof(double));
+        stream.read(reinterpret_cast<char *>(&words), sizeof(size_t));
+        if (!stream || words > (size_t(1) << 32)) throw std::invalid_argument("stream ended inside a plaintext");
+        std::vector<uint64_t> host(words);
+        stream.read(reinterpret_cast<char *>(host.data()), (std::streamsize)(words * 8));
+        if (!stream) throw std::invalid_argument("stream ended inside a plaintext");
+        if (id != parmsIDZero) {
+            if (!limbs_of) throw std::invalid_argument("an NTT-form plaintext is loaded with its context: load(stream, context)");
+            id.limbs = limbs_of(id.data());
+        }
+        dev_.reset();
+        data_ = std::move(host);
+        scale_ = scale;
+        parms_id_ = id;
+    }
     std::vector<uint64_t> data_;
     double scale_ = 1.0;
     ParmsID parms_id_;
@@ -495,6 +538,14 @@ public:
         createGaloisKeys(elts, gk);
     }
     GaloisKeys createGaloisKeys() const { GaloisKeys g; createGaloisKeys(g); return g; }
+    // the keys of fieldTraceInplace / packLWECiphertexts: X -> X^(N/2^k + 1), k = 0 .. log2(N) - 1 (src/keygenerator.cpp:350-358)
+    GaloisKeys createAutomorphismKeys() const {
+        std::vector<uint32_t> elts;
+        for (size_t n = c_.polyModulusDegree(); n >= 2; n >>= 1) elts.push_back((uint32_t)(n + 1));
+        GaloisKeys g;
+        createGaloisKeys(elts, g);
+        return g;
+    }
     void createGaloisKeys(const std::vector<int> &steps, GaloisKeys &gk) const {
         std::vector<uint32_t> elts;
         for (int s : steps) { uint32_t e; check(troyhip_galois_elt_from_step(c_.handle(), s, &e)); elts.push_back(e); }
@@ -603,6 +654,34 @@ public:
         if (plain.isNttForm()) throw std::invalid_argument("plain cannot be in NTT form");
         destination.assign(slots_, 0);
         check(troyhip_host_batch_decode(c_.handle(), plain.data(), plain.coeffCount(), destination.data()));
+    }
+    // encodePolynomial / decodePolynomial (src/batchencoder_cuda.cu:124-170, 267-286): the values ARE the coefficients (mod t), no slot
+    // transform -- the packing app/LinearHelper.cuh is built on.  As there: the unsigned form keeps values.size() coefficients, the signed
+    // form pads to N; decoding returns min(coeffCount, N) unsigned or N signed coefficients.
+    void encodePolynomial(const std::vector<uint64_t> &values, Plaintext &destination) const {
+        if (values.size() > slots_) throw std::invalid_argument("values_matrix size is too large");
+        const uint64_t t = c_.parms().plainModulus().value();
+        destination = Plaintext();
+        destination.resize(values.size());
+        uint64_t *d = destination.data();
+        for (size_t i = 0; i < values.size(); i++) d[i] = values[i] % t;
+    }
+    void encodePolynomial(const std::vector<int64_t> &values, Plaintext &destination) const {
+        if (values.size() > slots_) throw std::invalid_argument("values_matrix size is too large");
+        const uint64_t t = c_.parms().plainModulus().value();
+        destination = Plaintext();
+        destination.resize(slots_);
+        uint64_t *d = destination.data();
+        for (size_t i = 0; i < values.size(); i++) d[i] = values[i] < 0 ? t - ((uint64_t)(-values[i]) % t) : (uint64_t)values[i] % t;
+    }
+    void decodePolynomial(const Plaintext &plain, std::vector<uint64_t> &destination) const {
+        const size_t n = std::min(plain.coeffCount(), slots_);
+        destination.assign(plain.data(), plain.data() + n);
+    }
+    void decodePolynomial(const Plaintext &plain, std::vector<int64_t> &destination) const {
+        const uint64_t t = c_.parms().plainModulus().value(), half = t >> 1;
+        destination.assign(slots_, 0);
+        for (size_t i = 0; i < std::min(plain.coeffCount(), slots_); i++) destination[i] = plain[i] > half ? (int64_t)(plain[i] - t) : (int64_t)plain[i];
     }
     void decode(const Plaintext &plain, std::vector<int64_t> &destination) const { // values above t / 2 come back negative (batchencoder.cpp:215-243)
         std::vector<uint64_t> u;

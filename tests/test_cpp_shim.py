@@ -17,6 +17,7 @@ def _build(out, libdir, libfile, src=SRC):
     subprocess.run(cmd, check=True, capture_output=True, text=True)
 
 
+LINEAR = os.path.join(ROOT, "tests", "cpp", "test_troyn_linear.cpp")  # include/troyn_linear.hpp: the flows of the reference's test/app/linear.cu (BFV)
 TIMETEST = os.path.join(ROOT, "tests", "cpp", "test_troyn_timetest.cpp")  # the op sequences of the reference's test/timetest.cu, incl. every out-of-place form
 
 
@@ -66,3 +67,17 @@ def test_troyn_timetest_on_gpu(tmp_path):
     exe = str(tmp_path / "test_troyn_timetest")
     _build(exe, os.path.join(ROOT, "troy_amd"), "libtroyhip.so", TIMETEST)
     _run(exe, "8192")
+
+
+def test_troyn_linear_on_emulator(tmp_path):
+    subprocess.check_call(["make", "-s", "-j8", "-C", os.path.join(ROOT, "troy_amd", "csrc"), "emul"])
+    exe = str(tmp_path / "test_troyn_linear_emul")
+    _build(exe, os.path.join(ROOT, "tests", "emul"), "libtroyhip_emul.so", LINEAR)
+    _run(exe, "4096")
+
+
+@pytest.mark.gpu
+def test_troyn_linear_on_gpu(tmp_path):
+    exe = str(tmp_path / "test_troyn_linear")
+    _build(exe, os.path.join(ROOT, "troy_amd"), "libtroyhip.so", LINEAR)
+    _run(exe, "16384")  # the degree of the reference's own run (test/app/linear.cu:578)
