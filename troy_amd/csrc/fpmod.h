@@ -74,12 +74,20 @@ TROY_HD double fp_reduce(double x, const FpPrime &c) {
     const double q = __builtin_rint(x * c.pinv);
     return __builtin_fma(-q, c.p, x);
 }
-// ... -> the canonical residue in [0, p) as an integer word
+// ... -> the canonical residue in [0, p) as an integer word.  r = fp_reduce(x) is an exact integer with |r| <= p / 2 + |x| 2^-52 (the
+// quotient estimate is off by at most 1/2 + (|x| / p) 2^-52), i.e. |r| < p / 2 + 2 for |x| < 2^53: a non-negative r is already below p
+// and a negative one lands in [p / 2 - 2, p) after ONE addition of p -- no second range check.  The addition is an fma with a 0 / 1
+// multiplier (one select on its high word) onto r + 2^52, whose mantissa is the answer: 8 instructions where the select-add-convert-
+// compare-subtract form took 15
 TROY_HD u64 fp_canonical(double x, const FpPrime &c, u64 p) {
-    double r = fp_reduce(x, c); // [-p/2 - 1, p/2 + 1]
-    r = r < 0.0 ? r + c.p : r;  // [0, p + 1)
-    const u64 v = fp_to_u64(r);
-    return v >= p ? v - p : v;
+#ifdef __clang__
+#pragma clang fp contract(off)
+#endif
+    (void)p;
+    const double r = fp_reduce(x, c);
+    const double neg = fp_of_bits((u64)(r < 0.0 ? 0x3FF00000u : 0u) << 32); // 1.0 or 0.0
+    const double t = __builtin_fma(neg, c.p, r + 4503599627370496.0);        // 2^52 + r (+ p): both steps exact, result in [2^52, 2^52 + p)
+    return fp_bits(t) & 0x000fffffffffffffull;
 }
 
 // ---- host side: when to reduce.  Bounds are in units of p; `lim` = 2^53 / p.  A butterfly stage maps a bound b to
