@@ -538,6 +538,16 @@ public:
         createGaloisKeys(elts, gk);
     }
     GaloisKeys createGaloisKeys() const { GaloisKeys g; createGaloisKeys(g); return g; }
+    // createKeySwitchingKeys (src/keygenerator.cpp:360-366): ONE key, which takes a ciphertext under `new_key` to one under this generator's
+    // secret key (Evaluator::applyKeySwitchingInplace)
+    KSwitchKeys createKeySwitchingKeys(const SecretKey &new_key) const {
+        if (new_key.data.size() != sk_.data.size()) throw std::invalid_argument("new_key is not valid for encryption parameters");
+        std::vector<uint64_t> h(ksk_words());
+        check(troyhip_host_kswitch_key(c_.handle(), lo_, hi_, sk_.data.data(), new_key.data.data(), h.data()));
+        KSwitchKeys k;
+        k.upload(0, h);
+        return k;
+    }
     // the keys of fieldTraceInplace / packLWECiphertexts: X -> X^(N/2^k + 1), k = 0 .. log2(N) - 1 (src/keygenerator.cpp:350-358)
     GaloisKeys createAutomorphismKeys() const {
         std::vector<uint32_t> elts;

@@ -219,6 +219,22 @@ struct LinearTest { // test/app/linear.cu:158-187
         bool good = true;
         for (size_t j = 0; j < 8; j++) good = good && coeffs[j] == (unsigned __int128)(x[j] + 2 * (unsigned __int128)z[j]) * 3 % modulus;
         EXPECT(good, "Cipher2d addInplace / addPlain / multiplyScalarInplace");
+        // switch_key (LinearHelper.cuh:128-137): a grid encrypted under ANOTHER secret key, taken to ours by the key our generator makes for
+        // it (KeyGenerator::createKeySwitchingKeys, src/keygenerator.cpp:360-366)
+        KeyGenerator other(*context);
+        Encryptor theirs(*context, other.createPublicKey());
+        theirs.setSecretKey(other.secretKey());
+        auto foreign = a.encrypt(theirs);
+        decryptor->decrypt(foreign[0][0], p);
+        encoder->decodePolynomial(p, coeffs);
+        bool unreadable = false;
+        for (size_t j = 0; j < 8; j++) unreadable = unreadable || coeffs[j] != x[j];
+        foreign.switch_key(*evaluator, keygen->createKeySwitchingKeys(other.secretKey()));
+        decryptor->decrypt(foreign[0][0], p);
+        encoder->decodePolynomial(p, coeffs);
+        good = unreadable;
+        for (size_t j = 0; j < 8; j++) good = good && coeffs[j] == x[j];
+        EXPECT(good, "Cipher2d switch_key with createKeySwitchingKeys: another key's ciphertexts decrypt under ours");
         LinearHelper::Cipher2d ragged = ca;
         ragged.data.pop_back();
         EXPECT(throws<std::invalid_argument>([&] { ragged.addInplace(*evaluator, cb); }), "shape mismatch: invalid_argument");

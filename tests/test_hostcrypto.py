@@ -104,6 +104,29 @@ def test_own_keys_roundtrip_and_keyswitch(scheme, bits, tbits, ta):
         assert np.array_equal(dec.decrypt(c3.data, correction_factor=c3.correction_factor), m2)
 
 
+@pytest.mark.parametrize("scheme,bits,tbits", [(1, [40, 40, 40, 40], 10), (3, [40, 36, 36, 40], 10)])
+def test_create_keyswitching_keys(scheme, bits, tbits, ta):
+    """KeyGenerator::createKeySwitchingKeys (src/keygenerator.cpp:360-366): a ciphertext under ANOTHER secret key, switched with the key
+    this generator makes for it (the oracle's applyKeySwitching), decrypts under this generator's secret key"""
+    N = 128
+    primes = ta.CoeffModulus.Create(N, bits)
+    t = ta.PlainModulus.Batching(N, tbits)
+    ctx = ta.SEALContext(scheme, N, primes, t, host_only=True)
+    mine, other = ta.KeyGenerator(ctx, seed=(5, 6)), ta.KeyGenerator(ctx, seed=(7, 8))
+    assert not np.array_equal(mine.secretKey(), other.secretKey())
+    ksk = mine.createKeySwitchingKeys(other.secretKey())
+    assert ksk.shape == (len(primes) - 1, 2, len(primes), N)
+    m = np.random.default_rng(9).integers(0, t, N, dtype=np.uint64)
+    c = ta.Encryptor(ctx, other.createPublicKey(), seed=(1, 2)).encrypt(m)
+    assert not np.array_equal(ta.Decryptor(ctx, mine.secretKey()).decrypt(c), m)   # not ours yet
+    O = oracle.Oracle(scheme, N, primes, t)
+    O.set_kswitch_key(0, ksk)
+    switched = O.eval(ref.OP_APPLY_KEYSWITCH, ref.Ct(c))
+    assert np.array_equal(ta.Decryptor(ctx, mine.secretKey()).decrypt(switched.data, correction_factor=switched.correction_factor), m)
+    with pytest.raises(Exception):
+        mine.createKeySwitchingKeys(other.secretKey()[:-1])
+
+
 def test_ckks_roundtrip(ta):
     N, bits = 128, [40, 30, 30, 40]
     primes = ta.CoeffModulus.Create(N, bits)

@@ -819,6 +819,16 @@ class KeyGenerator:
         capi.check(self.lib, self.lib.troyhip_host_relin_key(self.context.h, C.c_uint64(self.seed[0]), C.c_uint64(self.seed[1]), _u64p(self._sk), _u64p(out)))
         return out
 
+    def createKeySwitchingKeys(self, new_key):
+        """KeyGenerator::createKeySwitchingKeys (src/keygenerator.cpp:360-366): the host key array that takes a ciphertext under `new_key`
+        (another generator's secretKey()) to one under this generator's secret key; KSwitchKeys.set(0, .) + applyKeySwitchingInplace use it"""
+        new_key = np.ascontiguousarray(new_key, dtype=np.uint64)
+        if new_key.shape != self._sk.shape:
+            raise capi.InvalidArgument(capi.INVALID_ARGUMENT, "new_key is not valid for encryption parameters")
+        out = self._ksk()
+        capi.check(self.lib, self.lib.troyhip_host_kswitch_key(self.context.h, C.c_uint64(self.seed[0]), C.c_uint64(self.seed[1]), _u64p(self._sk), _u64p(new_key), _u64p(out)))
+        return out
+
     def createGaloisKeys(self, galois_elts):
         """returns {elt: host key array}"""
         keys = {}

@@ -422,6 +422,12 @@ int troyhip_host_galois_key(const troyhip_context *ctx, uint64_t seed_lo, uint64
         hostcrypto::keygen_kswitch(ctx->ctx, rng, secret_key, src.data(), out);
     }, false);
 }
+int troyhip_host_kswitch_key(const troyhip_context *ctx, uint64_t seed_lo, uint64_t seed_hi, const uint64_t *secret_key, const uint64_t *new_key, uint64_t *out) {
+    return guard([&] {
+        hostcrypto::Rng rng(seed_lo, seed_hi, (u64)5 << 32);
+        hostcrypto::keygen_kswitch(ctx->ctx, rng, secret_key, new_key, out);
+    }, false);
+}
 int troyhip_host_encrypt(const troyhip_context *ctx, uint64_t seed_lo, uint64_t seed_hi, const uint64_t *public_key, const uint64_t *plain,
                          uint64_t n_coeffs, int limbs, uint64_t *ct_out) {
     return guard([&] {
