@@ -147,6 +147,10 @@ int troyhip_random_bytes(void *out, size_t n);
 int troyhip_host_keygen(const troyhip_context *ctx, uint64_t seed_lo, uint64_t seed_hi, uint64_t *secret_key, uint64_t *public_key); /* KeyGenerator(ctx), createPublicKey */
 int troyhip_host_relin_key(const troyhip_context *ctx, uint64_t seed_lo, uint64_t seed_hi, const uint64_t *secret_key, uint64_t *out);  /* createRelinKeys */
 int troyhip_host_galois_key(const troyhip_context *ctx, uint64_t seed_lo, uint64_t seed_hi, const uint64_t *secret_key, uint32_t galois_elt, uint64_t *out); /* createGaloisKeys({elt}) */
+/* Encryptor::encryptZero(parms_id) / encryptZeroSymmetric(parms_id) (src/encryptor.cpp:88-150, src/encryptor_cuda.cuh:170-320): an encryption of
+ * zero at ANY data level (`limbs` primes) of any scheme; key = the public key (symmetric == 0) or the secret key; ct_out [2][limbs][N], NTT form
+ * for CKKS and coefficient form otherwise, scale 1, correction factor 1 */
+int troyhip_host_encrypt_zero(const troyhip_context *ctx, uint64_t seed_lo, uint64_t seed_hi, const uint64_t *key, int symmetric, int limbs, uint64_t *ct_out);
 /* KeyGenerator::createKeySwitchingKeys(new_key) (src/keygenerator.cpp:294-329, 360-366): the key that takes a ciphertext under `new_key`
  * ([key_limbs][N], NTT form, as troyhip_host_keygen writes a secret key) to one under `secret_key`; layout of `out` as troyhip_host_relin_key */
 int troyhip_host_kswitch_key(const troyhip_context *ctx, uint64_t seed_lo, uint64_t seed_hi, const uint64_t *secret_key, const uint64_t *new_key, uint64_t *out);

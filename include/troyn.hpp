@@ -239,6 +239,22 @@ public:
     // "1x^10 + 2"-style constructor of the reference is not reproduced; use setCoeff
     void resize(size_t n) { dev_.reset(); data_.resize(n, 0); }
     size_t coeffCount() const { return data_.size(); }
+    // setZero / capacity / reserve / shrinkToFit / release (src/plaintext_cuda.cuh:73-165)
+    void setZero(size_t start_coeff, size_t length) {
+        if (!length) return;
+        if (start_coeff + length - 1 >= data_.size()) throw std::out_of_range("length must be non-negative and start_coeff + length - 1 must be within [0, coeff_count)");
+        dev_.reset();
+        std::fill(data_.begin() + (std::ptrdiff_t)start_coeff, data_.begin() + (std::ptrdiff_t)(start_coeff + length), 0);
+    }
+    void setZero(size_t start_coeff) {
+        if (start_coeff >= data_.size()) throw std::out_of_range("start_coeff must be within [0, coeff_count)");
+        setZero(start_coeff, data_.size() - start_coeff);
+    }
+    void setZero() { dev_.reset(); std::fill(data_.begin(), data_.end(), 0); }
+    size_t capacity() const noexcept { return data_.capacity(); }
+    void reserve(size_t capacity) { data_.reserve(capacity); }
+    void shrinkToFit() { data_.shrink_to_fit(); }
+    void release() noexcept { dev_.reset(); std::vector<uint64_t>().swap(data_); parms_id_ = ParmsID(); scale_ = 1.0; }
     uint64_t *data() { dev_.reset(); return data_.data(); }
     const uint64_t *data() const { return data_.data(); }
     uint64_t &operator[](size_t i) { dev_.reset(); return data_[i]; }
@@ -344,6 +360,26 @@ public:
         d_.batch_stride = words;
         d_.size = (int)size;
         d_.limbs = (int)limbs;
+    }
+    // reserve / sizeCapacity / release / isTransparent (src/ciphertext_cuda.cuh:53, 141-180; src/ciphertext.h:438-443).  A ciphertext that owns
+    // its storage always has room for max(size, 3) polynomials (see resize); reserve grows that
+    size_t sizeCapacity() const noexcept { return d_.limbs && n_ ? (size_t)d_.batch_stride / ((size_t)d_.limbs * n_) : 0; }
+    void reserve(size_t size_capacity) {
+        if (size_capacity < 2) throw std::invalid_argument("invalid size_capacity");
+        if (!d_.limbs || !n_ || size_capacity <= sizeCapacity()) return;
+        const size_t keep = size();
+        auto fresh = std::make_shared<DeviceArray>(size_capacity * (size_t)d_.limbs * n_);
+        if (d_.data) check(troyhip_copy_d2d(fresh->get(), d_.data, keep * (size_t)d_.limbs * n_ * 8, nullptr));
+        store_ = std::move(fresh);
+        own_ = true;
+        d_.data = store_->get();
+        d_.batch_stride = size_capacity * (size_t)d_.limbs * n_;
+    }
+    void release() noexcept { store_.reset(); own_ = true; d_ = troyhip_ct{nullptr, 0, 0, 0, 0, 1.0, 1}; }
+    bool isTransparent() const {
+        if (!d_.data || size() < 2) return true;
+        const std::vector<uint64_t> h = toHost();
+        return std::all_of(h.begin() + (std::ptrdiff_t)((size_t)d_.limbs * n_), h.end(), [](uint64_t w) { return w == 0; });
     }
     std::vector<uint64_t> toHost() const { // CiphertextCuda::cpu / toHost: [size][limbs][N]
         std::vector<uint64_t> h(size() * coeffModulusSize() * n_);
@@ -456,6 +492,7 @@ public:
         keys_[index] = a;
     }
     const std::map<size_t, std::shared_ptr<DeviceArray>> &all() const { return keys_; }
+    void clear() { keys_.clear(); } // src/kswitchkeys_cuda.cuh
 protected:
     std::map<size_t, std::shared_ptr<DeviceArray>> keys_;
 };
@@ -596,7 +633,34 @@ public:
         run(troyhip_host_encrypt_symmetric, sk_.data, plain, dst);
     }
     Ciphertext encryptSymmetric(const Plaintext &plain) const { Ciphertext d; encryptSymmetric(plain, d); return d; }
+    // encryptZero / encryptZeroSymmetric (src/encryptor_cuda.cuh:170-237, 292-320; src/encryptor.cpp:88-150): zero at the first data level or at
+    // the level `parms_id` names -- the asymmetric form encrypts one level up and divides by the extra prime, as the reference does
+    void encryptZero(const ParmsID &parms_id, Ciphertext &dst) const {
+        if (pk_.data.empty()) throw std::logic_error("public key is not set");
+        zero(pk_.data, 0, parms_id, dst);
+    }
+    void encryptZero(Ciphertext &dst) const { encryptZero(c_.firstParmsID(), dst); }
+    Ciphertext encryptZero(const ParmsID &parms_id) const { Ciphertext d; encryptZero(parms_id, d); return d; }
+    Ciphertext encryptZero() const { return encryptZero(c_.firstParmsID()); }
+    void encryptZeroSymmetric(const ParmsID &parms_id, Ciphertext &dst) const {
+        if (sk_.data.empty()) throw std::logic_error("secret key is not set");
+        zero(sk_.data, 1, parms_id, dst);
+    }
+    void encryptZeroSymmetric(Ciphertext &dst) const { encryptZeroSymmetric(c_.firstParmsID(), dst); }
+    Ciphertext encryptZeroSymmetric(const ParmsID &parms_id) const { Ciphertext d; encryptZeroSymmetric(parms_id, d); return d; }
+    Ciphertext encryptZeroSymmetric() const { return encryptZeroSymmetric(c_.firstParmsID()); }
 private:
+    void zero(const std::vector<uint64_t> &key, int symmetric, const ParmsID &id, Ciphertext &dst) const {
+        if (!c_.getContextData(id) || id.limbs > (int)c_.firstLimbs()) throw std::invalid_argument("parms_id is not valid for encryption parameters");
+        const size_t N = c_.polyModulusDegree();
+        const bool ckks = c_.parms().scheme() == SchemeType::ckks;
+        std::vector<uint64_t> h((size_t)2 * id.limbs * N);
+        uint64_t s[2] = {lo_ + (++counter_), hi_};
+        if (!seeded_) check(troyhip_random_bytes(s, sizeof(s)));
+        check(troyhip_host_encrypt_zero(c_.handle(), s[0], s[1], key.data(), symmetric, id.limbs, h.data()));
+        dst.fromHost(h, N, (size_t)id.limbs, 2, ckks, 1.0, 1);
+        dst.bind(c_);
+    }
     template <class F> void run(F fn, const std::vector<uint64_t> &key, const Plaintext &plain, Ciphertext &dst) const {
         const size_t N = c_.polyModulusDegree();
         const bool ckks = c_.parms().scheme() == SchemeType::ckks;

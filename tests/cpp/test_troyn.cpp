@@ -83,6 +83,45 @@ static void scenario(SchemeType scheme, size_t n, std::vector<int> bits, int tbi
     decryptor.decrypt(a, out);
     EXPECT(out == pa, "encrypt -> decrypt");
 
+    // encryptZero / encryptZeroSymmetric at the first and at the last level (src/encryptor_cuda.cuh:170-320), and the small members around
+    // them: Ciphertext::isTransparent / reserve / sizeCapacity / release, Plaintext::setZero / release
+    {
+        Encryptor both(context, pk, keygen.secretKey());
+        Ciphertext z = both.encryptZero(), zs = both.encryptZeroSymmetric(), zl, zsl;
+        both.encryptZero(context.lastParmsID(), zl);
+        both.encryptZeroSymmetric(context.lastParmsID(), zsl);
+        bool zeros = true;
+        for (const Ciphertext *ct : {&z, &zs, &zl, &zsl}) {
+            decryptor.decrypt(*ct, out);
+            zeros = zeros && out == Plaintext(Poly(n, 0)) && !ct->isTransparent() && ct->size() == 2 && !ct->isNttForm();
+        }
+        EXPECT(zeros, "encryptZero / encryptZeroSymmetric decrypt to zero at the first and at the last level");
+        EXPECT(z.parmsID() == context.firstParmsID() && zl.parmsID() == context.lastParmsID() && zl.coeffModulusSize() < z.coeffModulusSize(),
+               "encryptZero(parms_id) lands on that level");
+        evaluator.addInplace(z, a);
+        decryptor.decrypt(z, out);
+        EXPECT(out == pa, "an encryption of zero is an additive identity");
+        bool thrown = false;
+        try { both.encryptZero(context.keyParmsID(), zl); } catch (const std::invalid_argument &) { thrown = true; }
+        EXPECT(thrown, "encryptZero at the key level: invalid_argument");
+        Ciphertext grown = a;
+        grown.reserve(5);
+        decryptor.decrypt(grown, out);
+        EXPECT(grown.sizeCapacity() == 5 && grown.size() == 2 && out == pa, "Ciphertext::reserve keeps the polynomials");
+        grown.release();
+        EXPECT(grown.size() == 0 && grown.isTransparent(), "Ciphertext::release");
+        Plaintext pz = pa;
+        pz.setZero(n / 2);
+        bool tail = true;
+        for (size_t i = 0; i < n; i++) tail = tail && pz[i] == (i < n / 2 ? pa[i] : 0);
+        pz.setZero(0, 1);
+        EXPECT(tail && pz[0] == 0, "Plaintext::setZero(start) / setZero(start, length)");
+        thrown = false;
+        try { pz.setZero(n); } catch (const std::out_of_range &) { thrown = true; }
+        pz.release();
+        EXPECT(thrown && pz.coeffCount() == 0, "Plaintext::setZero out of range: out_of_range; release");
+    }
+
     // add / sub / negate
     evaluator.add(a, b, c);
     decryptor.decrypt(c, out);

@@ -127,6 +127,33 @@ def test_create_keyswitching_keys(scheme, bits, tbits, ta):
         mine.createKeySwitchingKeys(other.secretKey()[:-1])
 
 
+@pytest.mark.parametrize("scheme,bits,tbits", [(1, [40, 40, 40, 40], 10), (3, [40, 36, 36, 40], 10), (2, [40, 30, 30, 40], 0)])
+def test_encrypt_zero_every_level(scheme, bits, tbits, ta):
+    """Encryptor::encryptZero / encryptZeroSymmetric (src/encryptor.cpp:88-150): zero at every data level of every scheme decrypts to zero; the
+    key level is refused"""
+    N = 128
+    primes = ta.CoeffModulus.Create(N, bits)
+    t = ta.PlainModulus.Batching(N, tbits) if tbits else 0
+    ctx = ta.SEALContext(scheme, N, primes, t, host_only=True)
+    kg = ta.KeyGenerator(ctx, seed=(5, 6))
+    enc, dec = ta.Encryptor(ctx, kg.createPublicKey(), seed=(3, 4)), ta.Decryptor(ctx, kg.secretKey())
+    enc.setSecretKey(kg.secretKey())
+    assert enc.encryptZero().shape == (2, ctx.first_limbs, N)
+    for limbs in range(ctx.last_limbs, ctx.first_limbs + 1):
+        for z in (enc.encryptZero(limbs), enc.encryptZeroSymmetric(limbs)):
+            assert z.shape == (2, limbs, N) and z.any()
+            d = dec.decrypt(z)
+            if scheme == 2:  # CKKS: the RNS plaintext is the (small) noise polynomial, not zero: within a few bits of 0 modulo every prime
+                for l in range(limbs):  # ... after the inverse transform (the decryption is an NTT-form RNS plaintext)
+                    noise = oracle.ntt_standalone(N, primes[l], d[l], 3)
+                    centred = np.minimum(noise, np.uint64(primes[l]) - noise)
+                    assert int(centred.max()) < 1 << 16
+            else:
+                assert not d.any()
+    with pytest.raises(Exception):
+        enc.encryptZero(len(primes))
+
+
 def test_ckks_roundtrip(ta):
     N, bits = 128, [40, 30, 30, 40]
     primes = ta.CoeffModulus.Create(N, bits)

@@ -882,6 +882,29 @@ class Encryptor:
         return self._run(self.lib.troyhip_host_encrypt_symmetric, self.sk, plain)
 
 
+    def _zero(self, key, symmetric, limbs):
+        ctx = self.context
+        limbs = ctx.first_limbs if limbs is None else int(limbs)
+        out = np.zeros((2, limbs, ctx.N), dtype=np.uint64)
+        self.counter += 1
+        lo, hi = struct.unpack("<QQ", os.urandom(16)) if self.seed is None else ((self.seed[0] + self.counter) & (2**64 - 1), self.seed[1])
+        capi.check(self.lib, self.lib.troyhip_host_encrypt_zero(ctx.h, C.c_uint64(lo), C.c_uint64(hi), _u64p(key), int(symmetric), limbs, _u64p(out)))
+        return out
+
+    def encryptZero(self, limbs=None):
+        """Encryptor::encryptZero(parms_id) (src/encryptor_cuda.cuh:170-237): zero under the public key at the level with `limbs` primes (default: the
+        first data level) -> uint64 [2][limbs][N], NTT form for CKKS, scale 1"""
+        if self.pk is None:
+            raise RuntimeError("public key is not set")
+        return self._zero(self.pk, False, limbs)
+
+    def encryptZeroSymmetric(self, limbs=None):
+        """Encryptor::encryptZeroSymmetric(parms_id) (src/encryptor_cuda.cuh:292-320)"""
+        if getattr(self, "sk", None) is None:
+            raise RuntimeError("secret key is not set")
+        return self._zero(self.sk, True, limbs)
+
+
 class Decryptor:
     """Decryptor::decrypt (src/decryptor.cpp:115-371), on the CPU; deterministic."""
 

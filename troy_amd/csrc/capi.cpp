@@ -422,6 +422,13 @@ int troyhip_host_galois_key(const troyhip_context *ctx, uint64_t seed_lo, uint64
         hostcrypto::keygen_kswitch(ctx->ctx, rng, secret_key, src.data(), out);
     }, false);
 }
+int troyhip_host_encrypt_zero(const troyhip_context *ctx, uint64_t seed_lo, uint64_t seed_hi, const uint64_t *key, int symmetric, int limbs, uint64_t *ct_out) {
+    return guard([&] {
+        hostcrypto::Rng rng(seed_lo, seed_hi, (u64)(symmetric ? 7 : 6) << 32);
+        if (symmetric) hostcrypto::encrypt_zero_symmetric(ctx->ctx, rng, key, limbs, ct_out);
+        else hostcrypto::encrypt_zero(ctx->ctx, rng, key, limbs, ct_out);
+    }, false);
+}
 int troyhip_host_kswitch_key(const troyhip_context *ctx, uint64_t seed_lo, uint64_t seed_hi, const uint64_t *secret_key, const uint64_t *new_key, uint64_t *out) {
     return guard([&] {
         hostcrypto::Rng rng(seed_lo, seed_hi, (u64)5 << 32);

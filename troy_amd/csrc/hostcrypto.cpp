@@ -242,11 +242,18 @@ static void add_message(const Context &c, const Polys &P, const u64 *plain, size
 // coefficient form.  CKKS: plain = [limbs][N] RNS polynomial in NTT form, output [2][limbs][N] NTT form.
 void encrypt(const Context &c, Rng &rng, const u64 *pk, const u64 *plain, size_t n_coeffs, int limbs, u64 *ct) {
     Polys P(c);
-    const size_t N = c.N, K = c.K;
-    const bool ntt_out = c.scheme == SCHEME_CKKS;
     if (c.scheme != SCHEME_CKKS) limbs = c.first_limbs;
     if (!c.is_data_level(limbs)) throw Error(ST_INVALID_ARGUMENT, "plain is not valid for encryption parameters");
-    if (c.scheme != SCHEME_CKKS && n_coeffs > N) throw Error(ST_INVALID_ARGUMENT, "plain is not valid for encryption parameters");
+    if (c.scheme != SCHEME_CKKS && n_coeffs > c.N) throw Error(ST_INVALID_ARGUMENT, "plain is not valid for encryption parameters");
+    encrypt_zero(c, rng, pk, limbs, ct);
+    add_message(c, P, plain, n_coeffs, limbs, ct);
+}
+// Encryptor::encryptZero(parms_id) (encryptor.cpp:88-150 with is_asymmetric == true): any data level of any scheme
+void encrypt_zero(const Context &c, Rng &rng, const u64 *pk, int limbs, u64 *ct) {
+    Polys P(c);
+    const size_t N = c.N, K = c.K;
+    const bool ntt_out = c.scheme == SCHEME_CKKS;
+    if (!c.is_data_level(limbs)) throw Error(ST_INVALID_ARGUMENT, "parms_id is not valid for encryption parameters");
     // encrypt zero at the level above (one more prime) when it exists, then divide by that prime (encryptor.cpp:118-150)
     const bool has_prev = limbs < (int)K;
     const int el = has_prev ? limbs + 1 : limbs;
@@ -271,18 +278,24 @@ void encrypt(const Context &c, Rng &rng, const u64 *pk, const u64 *plain, size_t
         if (has_prev) host_mod_switch(c, el, src, ntt_out);
         std::memcpy(ct + (size_t)j * limbs * N, src, sizeof(u64) * limbs * N);
     }
-    add_message(c, P, plain, n_coeffs, limbs, ct);
 }
 
 // encryptor.cpp:88-148 with is_asymmetric == false + rlwe.cpp:234-345: (c0, c1) = (-(a*s + e) + message, a) sampled directly at
 // the level of the plaintext (no switch from the level above); BFV/BGV leave coefficient form, CKKS stays in NTT form
 void encrypt_symmetric(const Context &c, Rng &rng, const u64 *sk, const u64 *plain, size_t n_coeffs, int limbs, u64 *ct) {
     Polys P(c);
+    if (c.scheme != SCHEME_CKKS) limbs = c.first_limbs;
+    if (!c.is_data_level(limbs)) throw Error(ST_INVALID_ARGUMENT, "plain is not valid for encryption parameters");
+    if (c.scheme != SCHEME_CKKS && n_coeffs > c.N) throw Error(ST_INVALID_ARGUMENT, "plain is not valid for encryption parameters");
+    encrypt_zero_symmetric(c, rng, sk, limbs, ct);
+    add_message(c, P, plain, n_coeffs, limbs, ct);
+}
+// Encryptor::encryptZeroSymmetric(parms_id) (encryptor.cpp:88-148 with is_asymmetric == false): any data level of any scheme
+void encrypt_zero_symmetric(const Context &c, Rng &rng, const u64 *sk, int limbs, u64 *ct) {
+    Polys P(c);
     const size_t N = c.N;
     const bool ntt_out = c.scheme == SCHEME_CKKS;
-    if (!ntt_out) limbs = c.first_limbs;
-    if (!c.is_data_level(limbs)) throw Error(ST_INVALID_ARGUMENT, "plain is not valid for encryption parameters");
-    if (!ntt_out && n_coeffs > N) throw Error(ST_INVALID_ARGUMENT, "plain is not valid for encryption parameters");
+    if (!c.is_data_level(limbs)) throw Error(ST_INVALID_ARGUMENT, "parms_id is not valid for encryption parameters");
     u64 *c0 = ct, *c1 = ct + (size_t)limbs * N;
     encrypt_zero_symmetric_ntt(P, rng, sk, limbs, c0, c1, c.scheme == SCHEME_BGV ? c.t : 1);
     if (!ntt_out)
@@ -290,7 +303,6 @@ void encrypt_symmetric(const Context &c, Rng &rng, const u64 *sk, const u64 *pla
             ntt_inverse(c0 + (size_t)l * N, c.tables[l]);
             ntt_inverse(c1 + (size_t)l * N, c.tables[l]);
         }
-    add_message(c, P, plain, n_coeffs, limbs, ct);
 }
 
 // decryptor.cpp:115-371.  ct [size][limbs][N]; BFV/BGV: N plaintext coefficients; CKKS: [limbs][N] RNS plaintext (NTT form)

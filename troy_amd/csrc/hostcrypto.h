@@ -26,6 +26,8 @@ void relin_source(const Context &c, const u64 *sk, u64 *out);
 void galois_source(const Context &c, const u64 *sk, uint32_t elt, u64 *out);
 void encrypt(const Context &c, Rng &rng, const u64 *pk, const u64 *plain, size_t n_coeffs, int limbs, u64 *ct);
 void encrypt_symmetric(const Context &c, Rng &rng, const u64 *sk, const u64 *plain, size_t n_coeffs, int limbs, u64 *ct);
+void encrypt_zero(const Context &c, Rng &rng, const u64 *pk, int limbs, u64 *ct);           // [2][limbs][N]: any data level
+void encrypt_zero_symmetric(const Context &c, Rng &rng, const u64 *sk, int limbs, u64 *ct);
 void decrypt(const Context &c, const u64 *sk, const u64 *ct, int size, int limbs, bool is_ntt, u64 correction_factor, u64 *out);
 // BatchEncoder (src/batchencoder.cpp:61-190): `count` <= N slot values modulo t <-> the plaintext polynomial [N] (coefficient form)
 void batch_encode(const Context &c, const u64 *values, size_t count, u64 *plain);
