@@ -286,3 +286,31 @@ def test_batch_encoder_against_reference_fixtures(ta):
         v = rng.integers(0, t, 128, dtype=np.uint64)
         assert np.array_equal(be.encode(v), R.batch_encode(v))
         assert np.array_equal(be.decode(R.batch_encode(v)), v)
+
+
+def test_polynomial_packing_and_automorphism_keys(ta):
+    """BatchEncoder::encodePolynomial / decodePolynomial (src/batchencoder_cuda.cu:124-170, 267-286) and createAutomorphismKeys
+    (src/keygenerator.cpp:350-358) of the Python mirror"""
+    N = 128
+    primes = ta.CoeffModulus.Create(N, [40, 40, 40])
+    t = ta.PlainModulus.Batching(N, 12)
+    ctx = ta.SEALContext(ta.BFV, N, primes, t, host_only=True)
+    be = ta.BatchEncoder(ctx)
+    p = be.encodePolynomial(np.array([1, t + 5, 7], dtype=np.uint64))
+    assert p.dtype == np.uint64 and list(p) == [1, 5, 7]
+    assert list(be.decodePolynomial(p)) == [1, 5, 7]
+    s = be.encodePolynomial(np.array([-1, 2, -3], dtype=np.int64))
+    assert s.size == N and list(s[:4]) == [t - 1, 2, t - 3, 0]
+    assert list(be.decodePolynomial(s, signed=True)[:4]) == [-1, 2, -3, 0]
+    with pytest.raises(Exception):
+        be.encodePolynomial(np.zeros(N + 1, dtype=np.uint64))
+    kg = ta.KeyGenerator(ctx, seed=(5, 6))
+    keys = kg.createAutomorphismKeys()
+    assert sorted(keys) == [3, 5, 9, 17, 33, 65, 129] and all(k.shape == (2, 2, 3, N) for k in keys.values())
+    # the key for X -> X^(N + 1) really switches sigma(s) back to s: apply the automorphism with the oracle and decrypt
+    m = np.random.default_rng(1).integers(0, t, N, dtype=np.uint64)
+    c = ta.Encryptor(ctx, kg.createPublicKey(), seed=(1, 2)).encrypt(m)
+    O = oracle.Oracle(ta.BFV, N, primes, t)
+    O.set_kswitch_key(N + 1, keys[N + 1])
+    rot = O.eval(ref.OP_APPLY_GALOIS, ref.Ct(c), iarg=N + 1)
+    assert np.array_equal(ta.Decryptor(ctx, kg.secretKey()).decrypt(rot.data), oracle.apply_galois(N, N + 1, t, m))

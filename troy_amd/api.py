@@ -829,6 +829,15 @@ class KeyGenerator:
         capi.check(self.lib, self.lib.troyhip_host_kswitch_key(self.context.h, C.c_uint64(self.seed[0]), C.c_uint64(self.seed[1]), _u64p(self._sk), _u64p(new_key), _u64p(out)))
         return out
 
+    def createAutomorphismKeys(self):
+        """KeyGenerator::createAutomorphismKeys (src/keygenerator.cpp:350-358): the keys of fieldTraceInplace / packLWECiphertexts,
+        X -> X^(N / 2^k + 1) for k = 0 .. log2(N) - 1; returns {elt: host key array}"""
+        elts, n = [], self.context.N
+        while n >= 2:
+            elts.append(n + 1)
+            n >>= 1
+        return self.createGaloisKeys(elts)
+
     def createGaloisKeys(self, galois_elts):
         """returns {elt: host key array}"""
         keys = {}
@@ -947,4 +956,27 @@ class BatchEncoder:
         p = np.ascontiguousarray(plain, dtype=np.uint64)
         out = np.zeros(self.context.N, dtype=np.uint64)
         capi.check(self.lib, self.lib.troyhip_host_batch_decode(self.context.h, _u64p(p), C.c_uint64(p.size), _u64p(out)))
+        return out
+
+    def encodePolynomial(self, values):
+        """BatchEncoderCuda::encodePolynomial (src/batchencoder_cuda.cu:124-170): the values ARE the coefficients, modulo t.  Unsigned input keeps
+        len(values) coefficients; signed input (any negative value, or a signed dtype) is padded to N, negative v stored as t - |v|"""
+        v = np.asarray(values)
+        if v.size > self.context.N:
+            raise capi.InvalidArgument(capi.INVALID_ARGUMENT, "values_matrix size is too large")
+        t = int(self.context.plain_modulus)
+        if v.dtype.kind == "i":
+            out = np.zeros(self.context.N, dtype=np.uint64)
+            out[:v.size] = [(t - (-int(x)) % t) if x < 0 else int(x) % t for x in v.ravel()]
+            return out
+        return (v.astype(np.uint64).ravel() % np.uint64(t)).astype(np.uint64)
+
+    def decodePolynomial(self, plain, signed=False):
+        """decodePolynomial (src/batchencoder_cuda.cu:267-286): min(len(plain), N) coefficients; signed=True: N centred values"""
+        p = np.ascontiguousarray(plain, dtype=np.uint64).ravel()[:self.context.N]
+        if not signed:
+            return p.copy()
+        t = int(self.context.plain_modulus)
+        out = np.zeros(self.context.N, dtype=np.int64)
+        out[:p.size] = [int(x) - t if int(x) > t >> 1 else int(x) for x in p]
         return out
