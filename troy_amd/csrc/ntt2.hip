@@ -648,7 +648,11 @@ __device__ __forceinline__ void ntt2_body(const Ntt2Args &a) {
     const FpPrime *const fcp = FP ? &fc_ : nullptr;
     const Mod m = mod_of(pd);
     const bool need_reduce = !FP && REDUCE && (a.src_bound == 0 || (pd.p >> 61) != 0 || a.src_bound > 8 * pd.p);
+#ifdef N2_CENSUS_LEAN // tools/isa_census.py --flags=-DN2_CENSUS_LEAN: the guard-free path alone, so that a loop's count is one path's count (never shipped)
+    const bool lean = !INV;
+#else
     const bool lean = !INV && ((a.map.lean >> slot) & 1); // wave-uniform: prime below 2^58 -> guard-free forward butterflies (bfly.h)
+#endif
     const int logn = a.logn;
     const int k1 = STRIDED ? NS : logn - NS;
     const int s_first = INV ? (STRIDED ? k1 - 1 : logn - 1) : (STRIDED ? 0 : k1);
