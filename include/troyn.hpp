@@ -56,6 +56,42 @@ public:
     uint64_t value() const { return value_; }
     bool isZero() const { return value_ == 0; }
     int bitCount() const { return value_ ? 64 - __builtin_clzll(value_) : 0; } // src/modulus.h: bit_count_
+    size_t uint64Count() const { return value_ ? 1 : 0; }
+    // is_prime_ (src/modulus.cpp:80-121 via util::isPrime): Miller-Rabin with the twelve bases that decide every 64-bit integer
+    bool isPrime() const {
+        const uint64_t n = value_;
+        if (n < 2) return false;
+        for (uint64_t p : {2ull, 3ull, 5ull, 7ull, 11ull, 13ull, 17ull, 19ull, 23ull, 29ull, 31ull, 37ull}) {
+            if (n == p) return true;
+            if (n % p == 0) return false;
+        }
+        uint64_t d = n - 1;
+        int r = 0;
+        while (!(d & 1)) { d >>= 1; r++; }
+        auto mul = [n](uint64_t a, uint64_t b) { return (uint64_t)((unsigned __int128)a * b % n); };
+        for (uint64_t a : {2ull, 3ull, 5ull, 7ull, 11ull, 13ull, 17ull, 19ull, 23ull, 29ull, 31ull, 37ull}) {
+            uint64_t x = 1, b = a % n, e = d;
+            for (; e; e >>= 1, b = mul(b, b))
+                if (e & 1) x = mul(x, b);
+            if (x == 1 || x == n - 1) continue;
+            bool witness = true;
+            for (int i = 1; i < r && witness; i++) {
+                x = mul(x, x);
+                if (x == n - 1) witness = false;
+            }
+            if (witness) return false;
+        }
+        return true;
+    }
+    // const_ratio_ (src/modulus.h:16-24): floor(2^128 / value) as two words, then 2^128 mod value
+    std::array<uint64_t, 3> constRatio() const {
+        if (!value_) return {{0, 0, 0}};
+        const unsigned __int128 top = ~(unsigned __int128)0; // 2^128 - 1
+        unsigned __int128 q = top / value_;
+        uint64_t r = (uint64_t)(top % value_) + 1;           // 2^128 = q value + r
+        if (r == value_) { q += 1; r = 0; }
+        return {{(uint64_t)q, (uint64_t)(q >> 64), r}};
+    }
 private:
     uint64_t value_;
 };
@@ -103,6 +139,18 @@ struct ParmsID : std::array<uint64_t, 4> {
     bool operator!=(const ParmsID &o) const { return !(*this == o); }
 };
 static const ParmsID parmsIDZero{}; // src/encryptionparams.h: parmsIDZero
+
+// EncryptionParameterQualifiers (src/context.h:22-215): what the context found out about a level's parameters.  A context that was
+// constructed has valid parameters (invalid ones throw from the constructor), so parameter_error is always success here.
+struct EncryptionParameterQualifiers {
+    enum class ErrorType : int { none = -1, success = 0 };
+    ErrorType parameter_error = ErrorType::success;
+    bool parametersSet() const noexcept { return parameter_error == ErrorType::success; }
+    const char *parameterErrorName() const noexcept { return "success"; }
+    const char *parameterErrorMessage() const noexcept { return "valid"; }
+    bool using_fft = true, using_ntt = true, using_batching = false, using_fast_plain_lift = false, using_descending_modulus_chain = false;
+    SecurityLevel sec_level = SecurityLevel::none;
+};
 
 class ContextData; // below
 
@@ -180,6 +228,22 @@ public:
         for (size_t i = q.size(); i-- > 0;)
             if (q[i]) return (int)(64 * i) + 64 - __builtin_clzll(q[i]);
         return 0;
+    }
+    // qualifiers() (src/context_cuda.cuh:92, src/context.cpp:286-305, 364-368, 411-417): batching = t is a prime congruent to 1 modulo 2N (an NTT
+    // modulo t exists); fast plain lift = every prime of the level exceeds t; descending chain = the level's primes strictly decrease
+    EncryptionParameterQualifiers qualifiers() const {
+        EncryptionParameterQualifiers q;
+        const auto &primes = parms_.coeffModulus();
+        const uint64_t t = parms_.plainModulus().value(), N = parms_.polyModulusDegree();
+        if (parms_.scheme() == SchemeType::ckks) q.using_batching = true;
+        else {
+            q.using_batching = t > 2 && t % (2 * N) == 1 && Modulus(t).isPrime();
+            q.using_fast_plain_lift = true;
+            for (auto &m : primes) q.using_fast_plain_lift = q.using_fast_plain_lift && m.value() > t;
+        }
+        q.using_descending_modulus_chain = true;
+        for (size_t i = 0; i + 1 < primes.size(); i++) q.using_descending_modulus_chain = q.using_descending_modulus_chain && primes[i].value() > primes[i + 1].value();
+        return q;
     }
     size_t chainIndex() const { return limbs_ == c_->keyLimbs() ? (c_->using_keyswitching() ? c_->firstLimbs() - c_->lastLimbs() + 1 : 0) : limbs_ - c_->lastLimbs(); }
     std::shared_ptr<const ContextData> nextContextData() const { // one prime fewer; none below the last level

@@ -122,6 +122,21 @@ static void scenario(SchemeType scheme, size_t n, std::vector<int> bits, int tbi
         EXPECT(thrown && pz.coeffCount() == 0, "Plaintext::setZero out of range: out_of_range; release");
     }
 
+    {   // Modulus::isPrime / constRatio (src/modulus.h:16-24) and ContextData::qualifiers() (src/context.cpp:286-305, 411-417)
+        const Modulus q0 = parms.coeffModulus()[0];
+        const std::array<uint64_t, 3> cr = q0.constRatio();
+        const unsigned __int128 back = (((unsigned __int128)cr[1] << 64) | cr[0]) * q0.value() + cr[2];
+        EXPECT(q0.isPrime() && !Modulus(q0.value() + 2 * n).isPrime() + !Modulus(q0.value() - 1).isPrime() >= 1 && !Modulus(1ull << 41).isPrime() &&
+                   Modulus(0xffffffffffc0001ull).isPrime() && !Modulus(0xffffffffffc0001ull * 3).isPrime() && back == 0 && cr[2] < q0.value(),
+               "Modulus::isPrime, constRatio (floor(2^128 / p) and the remainder)");
+        const EncryptionParameterQualifiers ql = context.firstContextData()->qualifiers();
+        bool descending = true;
+        for (size_t i = 0; i + 1 < parms.coeffModulus().size(); i++) descending = descending && parms.coeffModulus()[i].value() > parms.coeffModulus()[i + 1].value();
+        EXPECT(ql.parametersSet() && ql.using_batching && ql.using_fast_plain_lift && ql.using_ntt && ql.using_fft &&
+                   context.keyContextData()->qualifiers().using_descending_modulus_chain == descending,
+               "qualifiers(): batching prime, fast plain lift, descending chain");
+    }
+
     // add / sub / negate
     evaluator.add(a, b, c);
     decryptor.decrypt(c, out);
