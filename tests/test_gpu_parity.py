@@ -763,3 +763,36 @@ def test_auxiliary_base_reference_mode_matches_golden_tables(gpu, golden_params)
     for n in names:
         for limbs, lv in golden_params[n]["levels"].items():
             assert got[n][limbs] == [lv["bsk"], lv["gamma"]], (n, limbs)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scheme,bits", [(cases.BFV, [40, 40, 40]), (cases.CKKS, [50, 40, 50])])
+def test_empty_batch_is_a_noop(scheme, bits, gpu):
+    """batch = 0 (the reference has no batch: an empty one is this library's own edge): every entry point returns success, launches nothing and
+    leaves operands and metadata as they were"""
+    import ctypes as C
+    from troy_amd import api, capi, synth
+    lib = capi.load()
+    N = 4096
+    primes = gpu.CoeffModulus.Create(N, bits)
+    ctx = gpu.SEALContext(scheme, N, primes, gpu.PlainModulus.Batching(N, 20) if scheme != cases.CKKS else 0)
+    ntt = scheme == cases.CKKS
+    L = len(primes) - 1
+    x = synth.uniform_ct(1, primes[:L], 2, N, 2)
+    a, b = (api.Ciphertext.from_numpy(ctx, x, ntt, capacity=3) for _ in range(2))
+    key = api.DeviceBuffer.from_numpy(synth.uniform_kswitch_key(2, primes, N))
+    zero = C.c_uint64(0)
+    sa, sb, out = a.struct(), b.struct(), a.struct()
+    calls = {
+        "multiply": lambda: lib.troyhip_multiply(ctx.h, C.byref(sa), C.byref(sb), C.byref(out), zero, None),
+        "add": lambda: lib.troyhip_add(ctx.h, C.byref(sa), C.byref(sb), zero, None),
+        "sub": lambda: lib.troyhip_sub(ctx.h, C.byref(sa), C.byref(sb), zero, None),
+        "negate": lambda: lib.troyhip_negate(ctx.h, C.byref(sa), zero, None),
+        "apply_key_switching": lambda: lib.troyhip_apply_key_switching(ctx.h, C.byref(sa), C.c_void_p(key.ptr), zero, None),
+        "negacyclic_shift": lambda: lib.troyhip_negacyclic_shift(ctx.h, C.byref(sa), C.c_uint64(3), zero, None),
+    }
+    for name, call in calls.items():
+        assert call() == 0, (name, lib.troyhip_last_error())
+    gpu.synchronize()
+    assert np.array_equal(a.cpu(), x) and np.array_equal(b.cpu(), x)
+    ctx.ntt(api.DeviceBuffer(8), 0, primes[:1])  # a transform of zero rows

@@ -26,10 +26,14 @@ extern thread_local const char *tag; // optional name for the next launch (templ
 void begin(const char *name, hipStream_t s); // remembers the record it opened per THREAD: end() closes that one, whatever other threads launched meanwhile
 void end(hipStream_t s);
 } }
+// An empty grid (a batch of zero ciphertexts, a transform of zero rows) is no work, not an error: HIP rejects it as an invalid configuration,
+// so it is not launched at all.
 #define TROY_LAUNCH(kernel, grid, block, shmem, stream, ...)                          \
     do {                                                                              \
+        const dim3 troy_grid_ = dim3(grid);                                           \
+        if (!troy_grid_.x || !troy_grid_.y || !troy_grid_.z) break;                   \
         if (::troyhip::ktime::enabled) ::troyhip::ktime::begin(#kernel, stream);      \
-        kernel<<<grid, block, shmem, stream>>>(__VA_ARGS__);                          \
+        kernel<<<troy_grid_, block, shmem, stream>>>(__VA_ARGS__);                    \
         if (::troyhip::ktime::enabled) ::troyhip::ktime::end(stream);                 \
     } while (0)
 #endif
