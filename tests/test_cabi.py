@@ -79,3 +79,24 @@ def test_host_only_parameter_helpers():
     assert [int(x) for x in out] == [1099510890497, 68718346241, 68718428161, 68719230977, 1099511480321]
     bad = (ctypes.c_int * 1)(61)
     assert lib.troyhip_coeff_modulus_create(ctypes.c_uint64(8192), bad, 1, out.ctypes.data_as(ctypes.c_void_p)) == capi.INVALID_ARGUMENT
+
+
+def test_null_context_is_an_argument_error():
+    """a null context handle is refused like any other bad argument -- INVALID_ARGUMENT and a message, not a fault (host-side entry points: no
+    device needed; the device-side ones say NOT_INITIALIZED first, as every call does before KernelProvider::initialize)"""
+    import numpy as np
+    lib = ctypes.CDLL(capi.LIB_PATH)
+    lib.troyhip_last_error.restype = ctypes.c_char_p
+    buf = np.zeros(16, dtype=np.uint64)
+    p = buf.ctypes.data_as(ctypes.c_void_p)
+    z = ctypes.c_uint64(0)
+    for name, call in {
+        "host_keygen": lambda: lib.troyhip_host_keygen(None, z, z, p, p),
+        "host_relin_key": lambda: lib.troyhip_host_relin_key(None, z, z, p, p),
+        "host_kswitch_key": lambda: lib.troyhip_host_kswitch_key(None, z, z, p, p, p),
+        "host_encrypt_zero": lambda: lib.troyhip_host_encrypt_zero(None, z, z, p, 0, 1, p),
+        "host_batch_encode": lambda: lib.troyhip_host_batch_encode(None, p, z, p),
+        "context_parms_id": lambda: lib.troyhip_context_parms_id(None, 1, p),
+    }.items():
+        assert call() == capi.INVALID_ARGUMENT, name
+        assert lib.troyhip_last_error() == b"null context", name

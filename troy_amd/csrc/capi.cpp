@@ -45,6 +45,11 @@ template <class F> int guard(F f, bool need_init = true) {
         return TROYHIP_RUNTIME_ERROR;
     }
 }
+// a null context is an argument error like any other (every use below sits inside guard(): the caller gets INVALID_ARGUMENT, not a fault)
+template <class C> C *need(C *ctx) {
+    if (!ctx) throw Error(ST_INVALID_ARGUMENT, "null context");
+    return ctx;
+}
 CtBatch view(const troyhip_ct *c) {
     if (!c) throw Error(ST_INVALID_ARGUMENT, "null ciphertext descriptor");
     CtBatch b;
@@ -363,14 +368,14 @@ int troyhip_context_destroy(troyhip_context *ctx) { return guard([&] { delete ct
 int troyhip_context_info(const troyhip_context *ctx, troyhip_context_info_t *out) {
     return guard([&] {
         if (!ctx || !out) throw Error(ST_INVALID_ARGUMENT, "null");
-        const Context &c = ctx->ctx;
+        const Context &c = need(ctx)->ctx;
         out->scheme = c.scheme; out->poly_modulus_degree = c.N; out->key_limbs = c.K;
         out->first_limbs = c.first_limbs; out->last_limbs = c.last_limbs; out->plain_modulus = c.t;
     }, false);
 }
 int troyhip_context_behz_bases(const troyhip_context *ctx, int limbs, uint64_t *bsk_out, int *bsk_size, uint64_t *gamma) {
     return guard([&] {
-        const host::RnsLevel &r = ctx->ctx.level(limbs).rns;
+        const host::RnsLevel &r = need(ctx)->ctx.level(limbs).rns;
         std::copy(r.Bsk.begin(), r.Bsk.end(), bsk_out);
         *bsk_size = (int)r.Bsk.size();
         *gamma = r.gamma;
@@ -379,119 +384,119 @@ int troyhip_context_behz_bases(const troyhip_context *ctx, int limbs, uint64_t *
 int troyhip_context_ntt_tables(const troyhip_context *ctx, uint64_t prime, uint64_t *rop, uint64_t *rquo, uint64_t *iop, uint64_t *iquo,
                                uint64_t *inv_degree2, uint64_t *root) {
     return guard([&] {
-        const Context &c = ctx->ctx;
+        const Context &c = need(ctx)->ctx;
         const host::NttTable &t = c.tables[c.prime_id(prime)];
         for (u64 i = 0; i < c.N; i++) { rop[i] = t.root[i].op; rquo[i] = t.root[i].quo; iop[i] = t.iroot[i].op; iquo[i] = t.iroot[i].quo; }
         inv_degree2[0] = t.inv_n.op; inv_degree2[1] = t.inv_n.quo;
         *root = t.psi;
     }, false);
 }
-int troyhip_context_release_stream(troyhip_context *ctx) { return guard([&] { ctx->ctx.arena.release_owner(); }); }
-int troyhip_context_reserve_scratch(troyhip_context *ctx, size_t words) { return guard([&] { ctx->ctx.arena.reset(); ctx->ctx.arena.reserve(words); }); }
+int troyhip_context_release_stream(troyhip_context *ctx) { return guard([&] { need(ctx)->ctx.arena.release_owner(); }); }
+int troyhip_context_reserve_scratch(troyhip_context *ctx, size_t words) { return guard([&] { need(ctx)->ctx.arena.reset(); need(ctx)->ctx.arena.reserve(words); }); }
 int troyhip_context_scratch_words(const troyhip_context *ctx, int op, int limbs, uint64_t batch, size_t *words) {
     return guard([&] {
-        if (op == 0) *words = ctx->ev.scratch_multiply(2, 2, limbs, batch);
-        else *words = ctx->ev.scratch_switch_key(limbs, batch) + 2 * batch * limbs * ctx->ctx.N + 128;
+        if (op == 0) *words = need(ctx)->ev.scratch_multiply(2, 2, limbs, batch);
+        else *words = need(ctx)->ev.scratch_switch_key(limbs, batch) + 2 * batch * limbs * need(ctx)->ctx.N + 128;
     });
 }
 int troyhip_galois_elt_from_step(const troyhip_context *ctx, int step, uint32_t *out) {
-    return guard([&] { *out = host::galois_elt_from_step(ctx->ctx.N, step); }, false);
+    return guard([&] { *out = host::galois_elt_from_step(need(ctx)->ctx.N, step); }, false);
 }
 
 // ---- CPU-side key generation / encryption / decryption (hostcrypto.cpp); all buffers are HOST memory ----
 int troyhip_host_keygen(const troyhip_context *ctx, uint64_t seed_lo, uint64_t seed_hi, uint64_t *secret_key, uint64_t *public_key) {
     return guard([&] {
         hostcrypto::Rng rng(seed_lo, seed_hi);
-        hostcrypto::keygen_secret(ctx->ctx, rng, secret_key);
-        if (public_key) hostcrypto::keygen_public(ctx->ctx, rng, secret_key, public_key);
+        hostcrypto::keygen_secret(need(ctx)->ctx, rng, secret_key);
+        if (public_key) hostcrypto::keygen_public(need(ctx)->ctx, rng, secret_key, public_key);
     }, false);
 }
 int troyhip_host_relin_key(const troyhip_context *ctx, uint64_t seed_lo, uint64_t seed_hi, const uint64_t *secret_key, uint64_t *out) {
     return guard([&] {
         hostcrypto::Rng rng(seed_lo, seed_hi, 1);
-        std::vector<u64> src((size_t)ctx->ctx.K * ctx->ctx.N);
-        hostcrypto::relin_source(ctx->ctx, secret_key, src.data());
-        hostcrypto::keygen_kswitch(ctx->ctx, rng, secret_key, src.data(), out);
+        std::vector<u64> src((size_t)need(ctx)->ctx.K * need(ctx)->ctx.N);
+        hostcrypto::relin_source(need(ctx)->ctx, secret_key, src.data());
+        hostcrypto::keygen_kswitch(need(ctx)->ctx, rng, secret_key, src.data(), out);
     }, false);
 }
 int troyhip_host_galois_key(const troyhip_context *ctx, uint64_t seed_lo, uint64_t seed_hi, const uint64_t *secret_key, uint32_t galois_elt, uint64_t *out) {
     return guard([&] {
         hostcrypto::Rng rng(seed_lo, seed_hi, ((u64)2 << 32) | galois_elt);
-        std::vector<u64> src((size_t)ctx->ctx.K * ctx->ctx.N);
-        hostcrypto::galois_source(ctx->ctx, secret_key, galois_elt, src.data());
-        hostcrypto::keygen_kswitch(ctx->ctx, rng, secret_key, src.data(), out);
+        std::vector<u64> src((size_t)need(ctx)->ctx.K * need(ctx)->ctx.N);
+        hostcrypto::galois_source(need(ctx)->ctx, secret_key, galois_elt, src.data());
+        hostcrypto::keygen_kswitch(need(ctx)->ctx, rng, secret_key, src.data(), out);
     }, false);
 }
 int troyhip_host_encrypt_zero(const troyhip_context *ctx, uint64_t seed_lo, uint64_t seed_hi, const uint64_t *key, int symmetric, int limbs, uint64_t *ct_out) {
     return guard([&] {
         hostcrypto::Rng rng(seed_lo, seed_hi, (u64)(symmetric ? 7 : 6) << 32);
-        if (symmetric) hostcrypto::encrypt_zero_symmetric(ctx->ctx, rng, key, limbs, ct_out);
-        else hostcrypto::encrypt_zero(ctx->ctx, rng, key, limbs, ct_out);
+        if (symmetric) hostcrypto::encrypt_zero_symmetric(need(ctx)->ctx, rng, key, limbs, ct_out);
+        else hostcrypto::encrypt_zero(need(ctx)->ctx, rng, key, limbs, ct_out);
     }, false);
 }
 int troyhip_host_kswitch_key(const troyhip_context *ctx, uint64_t seed_lo, uint64_t seed_hi, const uint64_t *secret_key, const uint64_t *new_key, uint64_t *out) {
     return guard([&] {
         hostcrypto::Rng rng(seed_lo, seed_hi, (u64)5 << 32);
-        hostcrypto::keygen_kswitch(ctx->ctx, rng, secret_key, new_key, out);
+        hostcrypto::keygen_kswitch(need(ctx)->ctx, rng, secret_key, new_key, out);
     }, false);
 }
 int troyhip_host_encrypt(const troyhip_context *ctx, uint64_t seed_lo, uint64_t seed_hi, const uint64_t *public_key, const uint64_t *plain,
                          uint64_t n_coeffs, int limbs, uint64_t *ct_out) {
     return guard([&] {
         hostcrypto::Rng rng(seed_lo, seed_hi, (u64)3 << 32);
-        hostcrypto::encrypt(ctx->ctx, rng, public_key, plain, n_coeffs, limbs, ct_out);
+        hostcrypto::encrypt(need(ctx)->ctx, rng, public_key, plain, n_coeffs, limbs, ct_out);
     }, false);
 }
 int troyhip_host_encrypt_symmetric(const troyhip_context *ctx, uint64_t seed_lo, uint64_t seed_hi, const uint64_t *secret_key, const uint64_t *plain,
                                    uint64_t n_coeffs, int limbs, uint64_t *ct_out) {
     return guard([&] {
         hostcrypto::Rng rng(seed_lo, seed_hi, (u64)4 << 32);
-        hostcrypto::encrypt_symmetric(ctx->ctx, rng, secret_key, plain, n_coeffs, limbs, ct_out);
+        hostcrypto::encrypt_symmetric(need(ctx)->ctx, rng, secret_key, plain, n_coeffs, limbs, ct_out);
     }, false);
 }
 int troyhip_host_decrypt(const troyhip_context *ctx, const uint64_t *secret_key, const uint64_t *ct, int size, int limbs, int is_ntt_form,
                          uint64_t correction_factor, uint64_t *plain_out) {
-    return guard([&] { hostcrypto::decrypt(ctx->ctx, secret_key, ct, size, limbs, is_ntt_form != 0, correction_factor, plain_out); }, false);
+    return guard([&] { hostcrypto::decrypt(need(ctx)->ctx, secret_key, ct, size, limbs, is_ntt_form != 0, correction_factor, plain_out); }, false);
 }
 
 int troyhip_host_batch_encode(const troyhip_context *ctx, const uint64_t *values, uint64_t count, uint64_t *plain_out) {
-    return guard([&] { hostcrypto::batch_encode(ctx->ctx, values, count, plain_out); }, false);
+    return guard([&] { hostcrypto::batch_encode(need(ctx)->ctx, values, count, plain_out); }, false);
 }
 int troyhip_host_batch_decode(const troyhip_context *ctx, const uint64_t *plain, uint64_t n_coeffs, uint64_t *values_out) {
-    return guard([&] { hostcrypto::batch_decode(ctx->ctx, plain, n_coeffs, values_out); }, false);
+    return guard([&] { hostcrypto::batch_decode(need(ctx)->ctx, plain, n_coeffs, values_out); }, false);
 }
 
 int troyhip_ntt(troyhip_context *ctx, uint64_t *data, uint64_t rows, const uint64_t *row_primes, int period, int inner, int inverse, void *stream) {
     return guard([&] {
-        Context &c = ctx->ctx;
+        Context &c = need(ctx)->ctx;
         launch_ntt(data, c.d_desc, map_from_primes(c, row_primes, period, inner), rows, c.logn, inverse != 0, (hipStream_t)stream);
     });
 }
 int troyhip_fill_uniform(troyhip_context *ctx, uint64_t *data, uint64_t rows, const uint64_t *row_primes, int period, int inner, uint64_t seed,
                          uint64_t row0, void *stream) {
     return guard([&] {
-        Context &c = ctx->ctx;
+        Context &c = need(ctx)->ctx;
         launch_fill_uniform(data, c.d_desc, map_from_primes(c, row_primes, period, inner), c.logn, seed, row0, rows, (hipStream_t)stream);
     });
 }
 
 int troyhip_negate(troyhip_context *ctx, troyhip_ct *a, uint64_t batch, void *stream) {
-    return guard([&] { CtBatch x = view(a); ctx->ev.negate(x, batch, (hipStream_t)stream); store(x, a); });
+    return guard([&] { CtBatch x = view(a); need(ctx)->ev.negate(x, batch, (hipStream_t)stream); store(x, a); });
 }
 int troyhip_add(troyhip_context *ctx, troyhip_ct *a, const troyhip_ct *b, uint64_t batch, void *stream) {
-    return guard([&] { CtBatch x = view(a); ctx->ev.add_sub(x, view(b), batch, false, (hipStream_t)stream); store(x, a); });
+    return guard([&] { CtBatch x = view(a); need(ctx)->ev.add_sub(x, view(b), batch, false, (hipStream_t)stream); store(x, a); });
 }
 int troyhip_sub(troyhip_context *ctx, troyhip_ct *a, const troyhip_ct *b, uint64_t batch, void *stream) {
-    return guard([&] { CtBatch x = view(a); ctx->ev.add_sub(x, view(b), batch, true, (hipStream_t)stream); store(x, a); });
+    return guard([&] { CtBatch x = view(a); need(ctx)->ev.add_sub(x, view(b), batch, true, (hipStream_t)stream); store(x, a); });
 }
 int troyhip_multiply(troyhip_context *ctx, const troyhip_ct *a, const troyhip_ct *b, troyhip_ct *out, uint64_t batch, void *stream) {
-    return guard([&] { CtBatch o = view(out); ctx->ev.multiply(view(a), view(b), o, batch, (hipStream_t)stream); store(o, out); });
+    return guard([&] { CtBatch o = view(out); need(ctx)->ev.multiply(view(a), view(b), o, batch, (hipStream_t)stream); store(o, out); });
 }
 int troyhip_relinearize(troyhip_context *ctx, troyhip_ct *ct, const uint64_t *relin_key, uint64_t batch, void *stream) {
     return guard([&] {
         if (!relin_key) throw Error(ST_INVALID_ARGUMENT, "not enough relinearization keys");
         CtBatch x = view(ct);
-        ctx->ev.relinearize(x, KsKey{relin_key}, batch, (hipStream_t)stream);
+        need(ctx)->ev.relinearize(x, KsKey{relin_key}, batch, (hipStream_t)stream);
         store(x, ct);
     });
 }
@@ -501,7 +506,7 @@ int troyhip_relinearize_keys(troyhip_context *ctx, troyhip_ct *ct, const uint64_
         KsKey keys[14];
         for (int i = 0; i < n_keys; i++) keys[i] = KsKey{relin_keys[i]};
         CtBatch x = view(ct);
-        ctx->ev.relinearize(x, keys, n_keys, batch, (hipStream_t)stream);
+        need(ctx)->ev.relinearize(x, keys, n_keys, batch, (hipStream_t)stream);
         store(x, ct);
     });
 }
@@ -512,30 +517,30 @@ int troyhip_relinearize_to(troyhip_context *ctx, const troyhip_ct *in, troyhip_c
         KsKey keys[14];
         for (int i = 0; i < n_keys; i++) keys[i] = KsKey{relin_keys[i]};
         CtBatch o = view(out);
-        ctx->ev.relinearize_to(view(in), o, keys, n_keys, batch, (hipStream_t)stream);
+        need(ctx)->ev.relinearize_to(view(in), o, keys, n_keys, batch, (hipStream_t)stream);
         store(o, out);
     });
 }
 int troyhip_switch_key(troyhip_context *ctx, troyhip_ct *ct, const uint64_t *target, uint64_t target_batch_stride, const uint64_t *kswitch_key,
                        uint64_t batch, void *stream) {
-    return guard([&] { CtBatch x = view(ct); ctx->ev.switch_key(x, target, target_batch_stride, KsKey{kswitch_key}, batch, (hipStream_t)stream); store(x, ct); });
+    return guard([&] { CtBatch x = view(ct); need(ctx)->ev.switch_key(x, target, target_batch_stride, KsKey{kswitch_key}, batch, (hipStream_t)stream); store(x, ct); });
 }
 int troyhip_mod_switch_to_next(troyhip_context *ctx, const troyhip_ct *in, troyhip_ct *out, uint64_t batch, void *stream) {
-    return guard([&] { CtBatch o = view(out); ctx->ev.mod_switch_to_next(view(in), o, batch, (hipStream_t)stream); store(o, out); });
+    return guard([&] { CtBatch o = view(out); need(ctx)->ev.mod_switch_to_next(view(in), o, batch, (hipStream_t)stream); store(o, out); });
 }
 int troyhip_rescale_to_next(troyhip_context *ctx, const troyhip_ct *in, troyhip_ct *out, uint64_t batch, void *stream) {
-    return guard([&] { CtBatch o = view(out); ctx->ev.rescale_to_next(view(in), o, batch, (hipStream_t)stream); store(o, out); });
+    return guard([&] { CtBatch o = view(out); need(ctx)->ev.rescale_to_next(view(in), o, batch, (hipStream_t)stream); store(o, out); });
 }
 int troyhip_apply_galois(troyhip_context *ctx, troyhip_ct *ct, uint32_t galois_elt, const uint64_t *galois_key, uint64_t batch, void *stream) {
-    return guard([&] { CtBatch x = view(ct); ctx->ev.apply_galois(x, galois_elt, KsKey{galois_key}, batch, (hipStream_t)stream); store(x, ct); });
+    return guard([&] { CtBatch x = view(ct); need(ctx)->ev.apply_galois(x, galois_elt, KsKey{galois_key}, batch, (hipStream_t)stream); store(x, ct); });
 }
 
 static void rotate_internal(troyhip_context *ctx, CtBatch &x, int steps, const uint32_t *elts, const uint64_t *const *keys, int n_keys, u64 batch, hipStream_t s) {
     if (steps == 0) return; // evaluator_cuda.cu:2140-2143
-    const u64 N = ctx->ctx.N;
+    const u64 N = need(ctx)->ctx.N;
     auto find = [&](uint32_t e) -> const uint64_t * { for (int i = 0; i < n_keys; i++) if (elts[i] == e) return keys[i]; return nullptr; };
     uint32_t elt = host::galois_elt_from_step(N, steps);
-    if (const uint64_t *k = find(elt)) { ctx->ev.apply_galois(x, elt, KsKey{k}, batch, s); return; }
+    if (const uint64_t *k = find(elt)) { need(ctx)->ev.apply_galois(x, elt, KsKey{k}, batch, s); return; }
     auto ns = host::naf(steps); // evaluator_cuda.cu:2152-2175
     if (ns.size() == 1) throw Error(ST_INVALID_ARGUMENT, "Galois key not present");
     for (int st : ns) if ((u64)std::abs(st) != (N >> 1)) rotate_internal(ctx, x, st, elts, keys, n_keys, batch, s);
@@ -545,11 +550,11 @@ int troyhip_rotate(troyhip_context *ctx, troyhip_ct *ct, int steps, int conjugat
     return guard([&] {
         CtBatch x = view(ct);
         if (conjugate) { // rotateColumns / complexConjugate: element 2N-1 (evaluator_cuda.cuh:399-420)
-            uint32_t elt = (uint32_t)(2 * ctx->ctx.N - 1);
+            uint32_t elt = (uint32_t)(2 * need(ctx)->ctx.N - 1);
             const uint64_t *k = nullptr;
             for (int i = 0; i < n_keys; i++) if (key_elts[i] == elt) k = keys[i];
             if (!k) throw Error(ST_INVALID_ARGUMENT, "Galois key not present");
-            ctx->ev.apply_galois(x, elt, KsKey{k}, batch, (hipStream_t)stream);
+            need(ctx)->ev.apply_galois(x, elt, KsKey{k}, batch, (hipStream_t)stream);
         } else {
             rotate_internal(ctx, x, steps, key_elts, keys, n_keys, batch, (hipStream_t)stream);
         }
@@ -557,13 +562,13 @@ int troyhip_rotate(troyhip_context *ctx, troyhip_ct *ct, int steps, int conjugat
     });
 }
 int troyhip_transform_to_ntt(troyhip_context *ctx, troyhip_ct *ct, uint64_t batch, void *stream) {
-    return guard([&] { CtBatch x = view(ct); ctx->ev.transform_to_ntt(x, batch, (hipStream_t)stream); store(x, ct); });
+    return guard([&] { CtBatch x = view(ct); need(ctx)->ev.transform_to_ntt(x, batch, (hipStream_t)stream); store(x, ct); });
 }
 int troyhip_transform_from_ntt(troyhip_context *ctx, troyhip_ct *ct, uint64_t batch, void *stream) {
-    return guard([&] { CtBatch x = view(ct); ctx->ev.transform_from_ntt(x, batch, (hipStream_t)stream); store(x, ct); });
+    return guard([&] { CtBatch x = view(ct); need(ctx)->ev.transform_from_ntt(x, batch, (hipStream_t)stream); store(x, ct); });
 }
 int troyhip_multiply_plain_ntt(troyhip_context *ctx, troyhip_ct *ct, const uint64_t *plain, double plain_scale, uint64_t batch, void *stream) {
-    return guard([&] { CtBatch x = view(ct); ctx->ev.multiply_plain_ntt(x, plain, plain_scale, batch, (hipStream_t)stream); store(x, ct); });
+    return guard([&] { CtBatch x = view(ct); need(ctx)->ev.multiply_plain_ntt(x, plain, plain_scale, batch, (hipStream_t)stream); store(x, ct); });
 }
 int troyhip_multiply_plain_accumulate(troyhip_context *ctx, const troyhip_ct *const *cts, const uint64_t *const *plains, int count, double plain_scale, troyhip_ct *out,
                                       uint64_t batch, void *stream) {
@@ -572,7 +577,7 @@ int troyhip_multiply_plain_accumulate(troyhip_context *ctx, const troyhip_ct *co
         CtBatch v[16];
         for (int i = 0; i < count; i++) v[i] = view(cts[i]);
         CtBatch o = view(out);
-        ctx->ev.multiply_plain_accumulate(v, plains, count, plain_scale, o, batch, (hipStream_t)stream);
+        need(ctx)->ev.multiply_plain_accumulate(v, plains, count, plain_scale, o, batch, (hipStream_t)stream);
         store(o, out);
     });
 }
@@ -580,26 +585,26 @@ int troyhip_add_plain(troyhip_context *ctx, troyhip_ct *ct, const uint64_t *plai
                       int subtract, uint64_t batch, void *stream) {
     return guard([&] {
         CtBatch x = view(ct);
-        ctx->ev.add_plain(x, plain, plain_coeff_count, plain_batch_stride, plain_scale, subtract != 0, batch, (hipStream_t)stream);
+        need(ctx)->ev.add_plain(x, plain, plain_coeff_count, plain_batch_stride, plain_scale, subtract != 0, batch, (hipStream_t)stream);
         store(x, ct);
     });
 }
 int troyhip_multiply_plain(troyhip_context *ctx, troyhip_ct *ct, const uint64_t *plain, uint64_t plain_coeff_count, uint64_t plain_batch_stride, uint64_t batch,
                            void *stream) {
-    return guard([&] { CtBatch x = view(ct); ctx->ev.multiply_plain(x, plain, plain_coeff_count, plain_batch_stride, batch, (hipStream_t)stream); store(x, ct); });
+    return guard([&] { CtBatch x = view(ct); need(ctx)->ev.multiply_plain(x, plain, plain_coeff_count, plain_batch_stride, batch, (hipStream_t)stream); store(x, ct); });
 }
 int troyhip_plain_to_ntt(troyhip_context *ctx, const uint64_t *plain, uint64_t plain_coeff_count, uint64_t plain_batch_stride, int limbs, uint64_t *out,
                          uint64_t count, void *stream) {
-    return guard([&] { ctx->ev.plain_to_ntt(plain, plain_coeff_count, plain_batch_stride, limbs, out, count, (hipStream_t)stream); });
+    return guard([&] { need(ctx)->ev.plain_to_ntt(plain, plain_coeff_count, plain_batch_stride, limbs, out, count, (hipStream_t)stream); });
 }
 int troyhip_apply_key_switching(troyhip_context *ctx, troyhip_ct *ct, const uint64_t *kswitch_key, uint64_t batch, void *stream) {
-    return guard([&] { CtBatch x = view(ct); ctx->ev.apply_key_switching(x, KsKey{kswitch_key}, batch, (hipStream_t)stream); store(x, ct); });
+    return guard([&] { CtBatch x = view(ct); need(ctx)->ev.apply_key_switching(x, KsKey{kswitch_key}, batch, (hipStream_t)stream); store(x, ct); });
 }
 int troyhip_negacyclic_shift(troyhip_context *ctx, troyhip_ct *ct, uint64_t shift, uint64_t batch, void *stream) {
-    return guard([&] { CtBatch x = view(ct); ctx->ev.negacyclic_shift(x, shift, batch, (hipStream_t)stream); store(x, ct); });
+    return guard([&] { CtBatch x = view(ct); need(ctx)->ev.negacyclic_shift(x, shift, batch, (hipStream_t)stream); store(x, ct); });
 }
 int troyhip_divide_by_poly_modulus_degree(troyhip_context *ctx, troyhip_ct *ct, uint64_t mul, uint64_t batch, void *stream) {
-    return guard([&] { CtBatch x = view(ct); ctx->ev.divide_by_degree(x, mul, batch, (hipStream_t)stream); store(x, ct); });
+    return guard([&] { CtBatch x = view(ct); need(ctx)->ev.divide_by_degree(x, mul, batch, (hipStream_t)stream); store(x, ct); });
 }
 int troyhip_random_bytes(void *out, size_t n) { // the reference seeds its PRNG from std::random_device (src/randomgen.cpp:23,72)
     return guard([&] {
@@ -623,13 +628,13 @@ int troyhip_blake2b(void *out, size_t outlen, const void *in, size_t inlen) {
 }
 int troyhip_context_parms_id(const troyhip_context *ctx, int limbs, uint64_t out[4]) {
     return guard([&] {
-        if (limbs < 1 || limbs > ctx->ctx.K) throw Error(ST_INVALID_ARGUMENT, "parms_id is not valid for the current context");
-        host::parms_id(ctx->ctx.scheme, ctx->ctx.N, ctx->ctx.primes, limbs, ctx->ctx.t, out);
+        if (limbs < 1 || limbs > need(ctx)->ctx.K) throw Error(ST_INVALID_ARGUMENT, "parms_id is not valid for the current context");
+        host::parms_id(need(ctx)->ctx.scheme, need(ctx)->ctx.N, need(ctx)->ctx.primes, limbs, need(ctx)->ctx.t, out);
     }, false);
 }
 int troyhip_decrypt(troyhip_context *ctx, const troyhip_ct *ct, const uint64_t *secret_key, uint64_t *plain_out, uint64_t plain_batch_stride, uint64_t batch,
                     void *stream) {
-    return guard([&] { CtBatch x = view(ct); ctx->ev.decrypt(x, secret_key, plain_out, plain_batch_stride, batch, (hipStream_t)stream); });
+    return guard([&] { CtBatch x = view(ct); need(ctx)->ev.decrypt(x, secret_key, plain_out, plain_batch_stride, batch, (hipStream_t)stream); });
 }
 
 } // extern "C"
