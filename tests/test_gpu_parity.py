@@ -484,6 +484,14 @@ def test_multiply_plain_accumulate(gpu):
     cases.check_multiply_plain_accumulate(N=8192, batch=5)
 
 
+@pytest.mark.parametrize("seed", list(range(201, 225)))
+def test_random_parameter_sets_tiny_rings(seed, gpu, oracle_lib):
+    """the same at N = 2 .. 64, where every tile of every kernel is larger than a polynomial (the scenario keeps the rotations that exist there:
+    |step| < N / 2); tools/tiny_soak.py is the long form (profiles/r03_random_soak.txt)"""
+    cfg, n = cases.check_random_config(seed, sizes=(2, 4, 8, 16, 32, 64), batch=3)
+    assert n is None or n > 5, cfg
+
+
 @pytest.mark.parametrize("seed", list(range(101, 109)))
 def test_random_parameter_sets_large(seed, gpu, oracle_lib):
     """the same at N = 8192 .. 32768 (multiply, relinearize, rotate / rescale at the first level): the two-pass transform with its fused
