@@ -804,3 +804,14 @@ def test_empty_batch_is_a_noop(scheme, bits, gpu):
     gpu.synchronize()
     assert np.array_equal(a.cpu(), x) and np.array_equal(b.cpu(), x)
     ctx.ntt(api.DeviceBuffer(8), 0, primes[:1])  # a transform of zero rows
+
+
+def test_host_threads_with_own_contexts(gpu):
+    """six host threads, each with its own context, evaluator and HIP stream, run multiply + relinearize + rotate of three schemes at once
+    (tools/threads_probe.py; ctypes drops the GIL inside the library): every thread's limbs equal the single-threaded run -- the shared state (the
+    caching device pool, the error slot, the launch timing) holds"""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(cases.ROOT if hasattr(cases, "ROOT") else os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "threads_probe.py"), "6", "8"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "0 failures" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
