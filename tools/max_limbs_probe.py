@@ -1,5 +1,5 @@
 """Many primes (the reference allows up to 64: SEAL_COEFF_MOD_COUNT_MAX, src/utils/defines.h): the light scenario (multiply, relinearize, rotate /
-rescale at the first level) at K = 20, 33, 48, 64 primes, product vs CPU oracle limb for limb.  usage: python tools/max_limbs_probe.py [N = 1024]"""
+rescale at the first level) at K = 20, 33, 48, 64 primes, product vs CPU oracle limb for limb.  usage: python tools/max_limbs_probe.py [N = 1024] [K list, e.g. 48,64]"""
 import os
 import sys
 import time
@@ -14,7 +14,7 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 ta.KernelProvider.initialize(0)
 bad = 0
 for scheme in (cases.BFV, cases.CKKS, cases.BGV):
-    for K in (20, 33, 48, 64):
+    for K in ([int(k) for k in sys.argv[2].split(',')] if len(sys.argv) > 2 else (20, 33, 48, 64)):
         cfg = dict(scheme=scheme, N=N, bits=[40] * (K - 1) + [45], tbits=16 if N <= 1024 else 20)
         t0 = time.time()
         try:
