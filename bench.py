@@ -512,42 +512,47 @@ def algorithmic_bytes(w, B):
     _by_prime_class(add, f"ntt2_kernel<0, 1, {k1}, {logc}, 0, 0, 0>", q_primes + bsk_primes, 2 * (2 * B) * 2 * P)
     _by_prime_class(add, "ntt2_kernel<0, 0, 9, 0, 1, 0, 2>", q_primes + bsk_primes, 7 * B * P)
     md_split = os.environ.get("TROYHIP_MODDOWN", "")[:1] == "s"
-    if two_pass:
-        # with the mod-down fused (the default) the last pass of the L data limbs of the accumulators reads ct as well and writes ct instead
-        # of acc (+ the special limb once per (ciphertext, accumulator)); the special limb goes through both passes on its own
-        _by_prime_class(add, "ntt2_kernel<1, 0, 9, 0, 0, 0, 0>", q_primes, (3 * B + 2 * B) * 2 * P)       # multiply: 3 polynomials; key switch: 2 accumulators
-        _by_prime_class(add, "ntt2_kernel<1, 0, 9, 0, 0, 0, 0>", bsk_primes, 3 * B * 2 * P)
-        _by_prime_class(add, "ntt2_kernel<1, 0, 9, 0, 0, 0, 0>", special, 2 * B * 2 * P)
-        _by_prime_class(add, f"ntt2_kernel<1, 1, {k1}, {logc}, 2, 0, 0>", q_primes, ((3 * B + 2 * B) if md_split else 3 * B) * 2 * P)
-        _by_prime_class(add, f"ntt2_kernel<1, 1, {k1}, {logc}, 2, 0, 0>", bsk_primes, 3 * B * 2 * P)
-        _by_prime_class(add, f"ntt2_kernel<1, 1, {k1}, {logc}, 2, 0, 0>", special, 2 * B * 2 * P)
-        if not md_split:
-            _by_prime_class(add, f"ntt2_kernel<1, 1, {k1}, {logc}, 3, 0, 0>", q_primes, 2 * B * 3 * P + 2 * B * P / L)
-    else:
-        # the single-pass inverse runs as up to three launches by prime class: FP64 rounds for the primes in [2^33, 2^50), guard-free integer rounds
-        # below 2^58, guarded butterflies for the rest
-        qs = [int(p) for p in w.ctx.coeff_modulus]
-        fused_md = os.environ.get("TROYHIP_MODDOWN", "") [:1] != "s" and all(p >= 1 << 33 for p in qs[:L])
+    # the library picks the single-pass inverse PER LAUNCH: N = 2^15 and at least four rows per CU (ntt1_supported, ntt1.hip) -- the multiply's three
+    # polynomials in both bases are one launch of 3 B (L + |Bsk|) rows, the key switch's two accumulators one of 2 B (L + 1): a small lane batch
+    # takes the two-pass kernels for the second while the first still runs single-pass
+    env_ntt = os.environ.get("TROYHIP_NTT", "")
 
-        def n1(tail, primes, per_limb):
-            for p in primes:
-                if _fp_on() and (1 << 33) <= p < (1 << FP_MAX_BITS):
-                    add(f"ntt1_inv_fp_kernel<{tail}>", per_limb)
-                else:
-                    add(f"ntt1_inv_kernel<{'true' if (1 << 33) <= p < (1 << 58) else 'false'}, {tail}>", per_limb)
-        # multiply: 3 polynomials in both bases; key switch: 2 accumulators over the L + 1 key primes.  With the mod-down fused (the
-        # default) the special limb is transformed on its own and the L data limbs leave through the epilogue: read acc and ct, write ct,
-        # plus the special limb once per (ciphertext, accumulator)
+    def single(rows):
+        return not two_pass and (env_ntt == "single" or rows >= 4 * 256)
+    qs = [int(p) for p in w.ctx.coeff_modulus]
+
+    def n1(tail, primes, per_limb):  # up to three launches by prime class: FP64 rounds for [2^33, 2^50), guard-free integer rounds below 2^58, guarded
+        for p in primes:
+            if _fp_on() and (1 << 33) <= p < (1 << FP_MAX_BITS):
+                add(f"ntt1_inv_fp_kernel<{tail}>", per_limb)
+            else:
+                add(f"ntt1_inv_kernel<{'true' if (1 << 33) <= p < (1 << 58) else 'false'}, {tail}>", per_limb)
+    # multiply: 3 polynomials in both bases
+    if single(3 * B * (L + nb)):
         n1("false", q_primes + bsk_primes, 3 * B * 2 * P)
+    else:
+        _by_prime_class(add, "ntt2_kernel<1, 0, 9, 0, 0, 0, 0>", q_primes + bsk_primes, 3 * B * 2 * P)
+        _by_prime_class(add, f"ntt2_kernel<1, 1, {k1}, {logc}, 2, 0, 0>", q_primes + bsk_primes, 3 * B * 2 * P)
+    # key switch: 2 accumulators over the L + 1 key primes.  With the mod-down fused (the default) the special limb is transformed on its own and the
+    # L data limbs leave through the epilogue: read acc and ct, write ct, plus the special limb once per (ciphertext, accumulator)
+    if single(2 * B * (L + 1)):
+        fused_md = not md_split and all(p >= 1 << 33 for p in qs[:L])
         n1("false", special, 2 * B * 2 * P)
         if fused_md:
             n1("true", q_primes, 2 * B * 3 * P + 2 * B * P / L)
         else:
             n1("false", q_primes, 2 * B * 2 * P)
+    else:
+        _by_prime_class(add, "ntt2_kernel<1, 0, 9, 0, 0, 0, 0>", q_primes + special, 2 * B * 2 * P)
+        _by_prime_class(add, f"ntt2_kernel<1, 1, {k1}, {logc}, 2, 0, 0>", special, 2 * B * 2 * P)
+        if md_split:
+            _by_prime_class(add, f"ntt2_kernel<1, 1, {k1}, {logc}, 2, 0, 0>", q_primes, 2 * B * 2 * P)
+        else:
+            _by_prime_class(add, f"ntt2_kernel<1, 1, {k1}, {logc}, 3, 0, 0>", q_primes, 2 * B * 3 * P + 2 * B * P / L)
     add(f"behz2{'s' if small_f else ''}_floor_sk_kernel<{kb1}, {kb2}, {fast}>", 3 * B * (2 * L + nb) * P)
     # relinearize: digit decomposition + first pass, second pass with the inner product against the key, inverse, mod-down
     _ks_forward_pair(add, w, B, L, logn, False)
-    if md_split or (not two_pass and not all(int(p) >= 1 << 33 for p in w.ctx.coeff_modulus[:L])):
+    if md_split or (single(2 * B * (L + 1)) and not all(int(p) >= 1 << 33 for p in w.ctx.coeff_modulus[:L])):
         add("ks_moddown_kernel<0>", B * (2 * (L + 1) + 4 * L) * P)
     return t
 
@@ -626,6 +631,8 @@ def algorithmic_bytes_ckks_chain(w, B):
     """configs[2] at N = 2^15 (single-pass transforms, fused correction): per level l = L .. L - depth + 1 a tensor, a key switch at l, the rescale
     to l - 1, two Galois permutations and a key switch at l - 1"""
     if w.N != 32768 or os.environ.get("TROYHIP_NTT") or os.environ.get("TROYHIP_CORR") or os.environ.get("TROYHIP_KS"):
+        return {}
+    if 2 * B * (w.L - w.wl.get("depth", 3)) < 4 * 256:  # a launch below four rows per CU takes the two-pass kernels (ntt1_supported): not modelled here
         return {}
     P = 8.0 * w.N
     qs = [int(p) for p in w.ctx.coeff_modulus]

@@ -588,6 +588,36 @@ def test_bench_rccl_single_rank(gpu):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("batch", [8, 64])
+def test_bench_accounts_for_every_kernel_at_small_batches(batch, gpu):
+    """the library picks the single-pass inverse per launch (at least four rows per CU): at a small lane batch the key switch's accumulators take the
+    two-pass kernels while the multiply's rows still run single-pass.  bench.py's byte table follows that rule -- every kernel of the step has its
+    fraction, the line verifies, and nothing raises (found with `--batch 64` under two ranks)"""
+    line = _run_bench(["--steps", "1", "--warmup", "0", "--batch", str(batch), "--no-cpu-baseline", "--ntt-reps", "1"])
+    assert line["verified"] is True and line["config"]["batch_per_gpu"] == batch
+    assert all(k.get("frac") for k in line["roofline"]["per_kernel"]), [k["name"] for k in line["roofline"]["per_kernel"] if not k.get("frac")]
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_share_one_gpu_over_gloo(gpu):
+    """the N > 1 path of bench.py with real device work on a one-GPU box: two ranks under torch.distributed.run share GPU 0 and rendezvous over gloo
+    (`--allow-gloo`, development only) -- barrier, MAX / MIN / SUM reductions, per-rank rates and placements, one JSON line from rank 0"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29541",
+                        os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--allow-gloo", "--batch", "16", "--workload", "bfv_n8192_l4",
+                        "--no-cpu-baseline", "--ntt-reps", "1"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["ranks"] == 2 and line["config"]["rendezvous"] == "gloo" and len(line["per_rank_ops_per_s"]) == 2
+    assert line["verified"] is True and len(line["rank_devices"]) == 2
+    assert abs(line["value"] - sum(line["per_rank_ops_per_s"])) / line["value"] < 0.2
+
+
+@pytest.mark.gpu
 def test_bench_self_launch_two_ranks(gpu):
     """`python bench.py --gpus 2` (no launcher): two ranks over RCCL; needs two devices"""
     import torch
