@@ -488,6 +488,10 @@ def algorithmic_bytes(w, B):
         return algorithmic_bytes_relin_rot(w, w.B)
     if w.wl["kind"] == "ckks_chain":
         return algorithmic_bytes_ckks_chain(w, w.B)
+    if w.wl["kind"] == "matmul":  # the same figures as matmul_roofline: per output block `count` ciphertext columns and plaintexts read, one column written
+        P, count = 8.0 * w.N * w.L, len(w.helper.encodedWeights)
+        blocks = len(w.helper.encodedWeights[0]) if count else 0
+        return {"mul_plain_acc_kernel": blocks * ((2 * count + 2) * w.B + count) * P, "mul_plain_kernel": blocks * count * (4 * w.B + 1) * P, "add_kernel": blocks * max(count - 1, 0) * 6 * w.B * P}
     if w.wl["kind"] != "mul_relin":
         return {}
     N, L = w.N, w.L
