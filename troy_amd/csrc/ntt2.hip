@@ -230,6 +230,11 @@ template <int INV, int STRIDED, int NS, int LOGC, int LS, int R, bool HOISTP = t
     // value bound (8p at the input of the first pass + 3p * 17 stages at most = 59p < 2^64); the caller reduces with barrett64
     // FP64 form (fpmod.h): x holds the bit patterns of doubles, tw those of (w, w / p); forward stages only
     __device__ static __forceinline__ void compute_fp(u64 (&x)[8], const Shoup (&tw)[G][NTW], const FpPrime &fc, const Shoup inv_n = Shoup{0, 0}) {
+        if (N2_EXP & 4) { // removal probe (tools/ntt_probe.sh): no butterflies
+#pragma unroll
+            for (int u = 0; u < G; u++) x[u] ^= tw[u][0].op;
+            return;
+        }
         if constexpr (INV) { // Gentleman-Sande: X' = X + Y, Y' = (X - Y) w; the last stage of the transform multiplies both outputs (N^-1 folded in)
 #pragma unroll
             for (int st = 0; st < R; st++) {
@@ -694,7 +699,7 @@ __device__ __forceinline__ void ntt2_body(const Ntt2Args &a) {
         if ((N2_EXP & 8) && !STRIDED) in = a.data + ((r & 63) << logn); // probe: the contiguous pass reads a 16 MB window (L2-resident input)
     };
     constexpr bool DMA = N2_DMA && WAVE_PRIVATE && !(N2_EXP & 1);
-    static_assert(MAC != 3 || DMA, "the CKKS key-switch pass (MAC = 3) takes its rows from the LDS-DMA staging area: build it with N2_DMA = 1 and without the no-HBM probe");
+    static_assert(MAC != 3 || DMA || (N2_EXP & 1), "the CKKS key-switch pass (MAC = 3) takes its rows from the LDS-DMA staging area: build it with N2_DMA = 1 and without the no-HBM probe");
     // plain strided forward passes of two rounds: the next row is requested into a second register set before the last round's butterflies
     // (the registers come from forming the LDS addresses per row, FRESH, so the kernel stays at four waves per SIMD): -2 % on that pass.
     // Not the digit-reducing first pass of key switching, whose L2-resident sources arrive fast enough anyway: +6 % there.
