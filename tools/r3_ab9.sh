@@ -1,6 +1,6 @@
 #!/bin/bash
 # same-box A/B of probe builds (tools/probe_libs/libtroyhip_<v>.so) over the workloads with a digit-expanding first pass
-for v in base onelds base onelds; do
+for v in ${VARIANTS:-base pffp base pffp}; do
   export TROYHIP_LIB=$PWD/tools/probe_libs/libtroyhip_$v.so
   for wl in ckks_n32768_chain bgv_n65536_relin_rot bfv_n32768_l14 bfv_n8192_l4; do
     timeout 600 python bench.py --workload $wl --steps 20 --warmup 3 --no-cpu-baseline --ntt-reps 2 2>/tmp/ab9.err | tail -1 > /tmp/ab9.json
