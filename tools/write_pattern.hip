@@ -23,6 +23,33 @@ template <int SEGW, bool VEC2> __global__ __launch_bounds__(256) void wr(uint64_
     }
 }
 
+// the pattern a column-tile fusion would need: 64 segments of 64 B (8 words), 4 KiB apart, per workgroup (512 words: two per thread); READ = 1: the same as loads
+template <int READ> __global__ __launch_bounds__(256) void seg64(uint64_t *buf, uint64_t salt) {
+    const unsigned tile = blockIdx.x & 63, row = blockIdx.x >> 6;
+    uint64_t *p = buf + ((uint64_t)row << 15);
+    uint64_t acc = 0;
+#pragma unroll
+    for (int e = 0; e < 2; e++) {
+        const unsigned q = threadIdx.x + 256 * e, idx = (q >> 3) * 512 + tile * 8 + (q & 7);
+        if (READ) acc ^= p[idx]; else p[idx] = salt + idx;
+    }
+    if (READ && acc == 0x123456789abcdefull) p[0] = acc;
+}
+template <int READ> static int run64(uint64_t *buf, unsigned rows) {
+    hipEvent_t a, b;
+    CHECK(hipEventCreate(&a)); CHECK(hipEventCreate(&b));
+    seg64<READ><<<rows << 6, 256>>>(buf, 1);
+    CHECK(hipDeviceSynchronize());
+    CHECK(hipEventRecord(a));
+    for (int i = 0; i < 5; i++) seg64<READ><<<rows << 6, 256>>>(buf, i);
+    CHECK(hipEventRecord(b));
+    CHECK(hipEventSynchronize(b));
+    float ms;
+    CHECK(hipEventElapsedTime(&ms, a, b));
+    std::printf("%-34s segments of    64 B,  8-byte %s: %7.1f GB/s\n", "column tile of 8 (64 x 64 B)", READ ? "loads " : "stores", 5.0 * rows * 262144.0 / (ms * 1e-3) / 1e9);
+    return 0;
+}
+
 template <int SEGW, bool VEC2> static int run(uint64_t *buf, unsigned rows, const char *what) {
     const unsigned tiles_log = 4; // 16 tiles of 2048 words per row
     hipEvent_t a, b;
@@ -51,6 +78,8 @@ int main() {
     if (run<512, true>(buf, rows, "4 x 4 KiB")) return 1;
     if (run<2048, true>(buf, rows, "contiguous 16 KiB tile")) return 1;
     if (run<2048, false>(buf, rows, "contiguous 16 KiB tile")) return 1;
+    if (run64<0>(buf, rows)) return 1;
+    if (run64<1>(buf, rows)) return 1;
     CHECK(hipFree(buf));
     return 0;
 }
