@@ -204,6 +204,44 @@ struct LinearTest { // test/app/linear.cu:158-187
         EXPECT(yDec == y, what);
     }
 
+    // the other operand placements (LinearHelper.cuh:470-492, 973-1033): plain inputs x encrypted weights, and every objective of the block search
+    void testReverseAndObjectives() {
+        const size_t batchSize = 3, inputDims = 20, outputDims = 12;
+        auto w = randomVector(inputDims * outputDims), x = randomVector(inputDims * batchSize), zero = vector<uint64_t>(batchSize * outputDims, 0);
+        const vector<uint64_t> expect = plainMatmul(x, w, zero, batchSize, inputDims, outputDims);
+        for (int objective = 0; objective < 3; objective++)
+            for (bool pack : {false, true}) {
+                LinearHelper::MatmulHelper helper(batchSize, inputDims, outputDims, slotCount, objective, pack);
+                auto wEnc = helper.encodeWeights(*encoder, w.data()).encrypt(*encryptor);
+                auto yEnc = helper.matmulReverse(*evaluator, helper.encodeInputs(*encoder, x.data()), wEnc);
+                if (pack) yEnc = helper.packOutputs(*evaluator, autok, yEnc);
+                char what[96];
+                std::snprintf(what, sizeof what, "matmulReverse (plain inputs, encrypted weights), objective %d%s", objective, pack ? ", packed" : "");
+                EXPECT(helper.decryptOutputs(*encoder, *decryptor, yEnc) == expect, what);
+            }
+        EXPECT(throws<std::runtime_error>([&] { LinearHelper::MatmulHelper(2, 4, 4, slotCount, 7, false); }), "an unknown objective: runtime_error");
+        // conv2d with encrypted weights, and with plain inputs x encrypted weights
+        const size_t ic = 2, oc = 2, ih = 7, iw = 6, kh = 3, kw = 2, yh = ih - kh + 1, yw = iw - kw + 1;
+        auto cw = randomVector(ic * oc * kh * kw), cx = randomVector(ic * ih * iw);
+        vector<uint64_t> cy(oc * yh * yw, 0);
+        for (size_t o = 0; o < oc; o++)
+            for (size_t i = 0; i < yh; i++)
+                for (size_t j = 0; j < yw; j++) {
+                    uint64_t acc = 0;
+                    for (size_t c = 0; c < ic; c++)
+                        for (size_t a = 0; a < kh; a++)
+                            for (size_t b = 0; b < kw; b++) acc = (acc + mulmod(cx[(c * ih + i + a) * iw + j + b], cw[((o * ic + c) * kh + a) * kw + b])) % modulus;
+                    cy[(o * yh + i) * yw + j] = acc;
+                }
+        LinearHelper::Conv2dHelper conv(1, ih, iw, kh, kw, ic, oc, slotCount);
+        auto cwEnc = conv.encodeWeights(*encoder, cw).encrypt(*encryptor);
+        auto viaCipher = conv.conv2dCipher(*evaluator, conv.encryptInputs(*encryptor, *encoder, cx), cwEnc);
+        viaCipher.relinearize(*evaluator, rlk);
+        EXPECT(conv.decryptOutputs(*encoder, *decryptor, viaCipher) == cy, "conv2dCipher (both operands encrypted), relinearized");
+        auto viaReverse = conv.conv2dReverse(*evaluator, conv.encodeInputs(*encoder, cx), cwEnc);
+        EXPECT(conv.decryptOutputs(*encoder, *decryptor, viaReverse) == cy, "conv2dReverse (plain inputs, encrypted weights)");
+    }
+
     void testCipher2d() { // the element-wise members of Cipher2d (LinearHelper.cuh:104-207)
         LinearHelper::MatmulHelper helper(2, 8, 4, slotCount, 0, false);
         auto x = randomVector(16), z = randomVector(16);
@@ -250,6 +288,7 @@ int main(int argc, char **argv) {
     LinearTest test(N, {60, 60, 60}, 1ul << 41); // test/app/linear.cu:578 (there N = 16384)
     test.testPolynomialEncoding();
     test.testCipher2d();
+    test.testReverseAndObjectives();
     test.testMatmulInts(4, 6, 8, false, false, "matmul 4 x 6 x 8, results as they come");
     test.testMatmulInts(4, 6, 8, true, false, "matmul 4 x 6 x 8, LWE-packed results");
     test.testMatmulInts(5, 37, 21, true, false, "matmul 5 x 37 x 21 (ragged blocks), LWE-packed results");
