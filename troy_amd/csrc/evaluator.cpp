@@ -105,7 +105,9 @@ void Evaluator::add_sub(CtBatch &a, const CtBatch &b_in, u64 batch, bool sub, hi
     CtBatch b = b_in;
     c.arena.begin(s);
     if (a.cf != b.cf) {
-        // BGV: balance the correction factors first (evaluator_cuda.cu:170-190)
+        // BGV: balance the correction factors first (evaluator_cuda.cu:170-190).  Without a plain modulus (CKKS) there is nothing to balance against:
+        // the reference's ciphertexts all carry factor 1 there; a descriptor that says otherwise is refused (it used to divide by zero)
+        if (!c.t) throw Error(ST_INVALID_ARGUMENT, "correction factor mismatch");
         u64 f, e1, e2;
         balance_correction(a.cf, b.cf, f, e1, e2);
         scalar_mul(a, e1, batch, s);
