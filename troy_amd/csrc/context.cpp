@@ -189,6 +189,7 @@ Context::Context(int scheme_, u64 N_, const std::vector<u64> &key_primes, u64 t_
         if (!host::is_prime(p) || (p - 1) % (2 * N)) throw Error(ST_INVALID_ARGUMENT, "coeff_modulus primes must be NTT-friendly primes");
         register_prime(p);
     }
+    if (scheme == SCHEME_CKKS && t_ != 0) throw Error(ST_INVALID_ARGUMENT, "plain_modulus must be zero"); // src/context.cpp:353-361 (invalid_plain_modulus_nonzero)
     if (scheme != SCHEME_CKKS) {
         if (t < 2 || (t >> 60)) throw Error(ST_INVALID_ARGUMENT, "plain_modulus is invalid");
         for (u64 p : key_primes) if (p % t == 0 || t % p == 0) throw Error(ST_INVALID_ARGUMENT, "plain_modulus must be coprime to coeff_modulus");
