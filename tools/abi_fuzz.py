@@ -31,6 +31,8 @@ for scheme, bits in ((capi.BFV, [40, 36, 36, 40]), (capi.CKKS, [50, 40, 40, 50])
     key = api.DeviceBuffer.from_numpy(synth.uniform_kswitch_key(3, primes, N))
     plain = api.DeviceBuffer.from_numpy(synth.uniform_rows(9, [primes[0]], 1, (K + 1) * N)[0])
 
+    pr = (C.c_uint64 * 3)(*[int(p) for p in primes[:3]])
+    bad_pr = (C.c_uint64 * 2)(int(primes[0]), 97)
     elts = (C.c_uint32 * 2)(3, 2 * N - 1)
     keys = (C.c_void_p * 2)(key.ptr, key.ptr)
 
@@ -39,6 +41,8 @@ for scheme, bits in ((capi.BFV, [40, 36, 36, 40]), (capi.CKKS, [50, 40, 40, 50])
         limbs = int(rng.choice([0, 1, K - 2, K - 1, K - 1, K - 1, K, K + 1]))
         dense = size * limbs * N
         stride = int(rng.choice([dense, dense, max(dense, 3 * max(limbs, 1) * N), words, 0, max(dense - 1, 0)]))
+        if rng.integers(0, 12) == 0:
+            return api.CtStruct(None, stride, size, limbs, int(rng.integers(0, 2)), 1.0, 1)  # no storage at all
         return api.CtStruct(buf.ptr, stride, size, limbs, int(rng.integers(0, 2)), float(rng.choice([1.0, 2.0 ** 20, 2.0 ** 40, 0.0, -1.0, float("inf")])),
                             int(rng.choice([1, 1, 3, 0])))
 
@@ -63,6 +67,13 @@ for scheme, bits in ((capi.BFV, [40, 36, 36, 40]), (capi.CKKS, [50, 40, 40, 50])
                                                                      C.c_uint64(B), None),
         "decrypt": lambda a, b, o: lib.troyhip_decrypt(ctx.h, C.byref(a), C.c_void_p(key.ptr), C.c_void_p(bufs[2].ptr), C.c_uint64(int(rng.choice([0, N, (K + 1) * N]))), C.c_uint64(B), None),
         "switch_key": lambda a, b, o: lib.troyhip_switch_key(ctx.h, C.byref(a), C.c_void_p(bufs[1].ptr), C.c_uint64(int(rng.choice([0, N, K * N, words]))), C.c_void_p(key.ptr), C.c_uint64(B), None),
+        "ntt": lambda a, b, o: lib.troyhip_ntt(ctx.h, C.c_void_p(bufs[2].ptr), C.c_uint64(int(rng.choice([0, 1, 2, 3, 6, 7]))), pr, int(rng.choice([0, 1, 2, 3, 65])), int(rng.choice([0, 1, 2, 3])),
+                                               int(rng.integers(0, 2)), None),
+        "ntt_foreign_prime": lambda a, b, o: lib.troyhip_ntt(ctx.h, C.c_void_p(bufs[2].ptr), C.c_uint64(2), bad_pr, 2, 1, 0, None),
+        "relinearize_keys": lambda a, b, o: lib.troyhip_relinearize_keys(ctx.h, C.byref(a), keys, int(rng.choice([-1, 0, 1, 2, 15])), C.c_uint64(B), None),
+        "plain_to_ntt": lambda a, b, o: lib.troyhip_plain_to_ntt(ctx.h, C.c_void_p(plain.ptr), C.c_uint64(int(rng.choice([0, 1, N, N + 1]))), C.c_uint64(int(rng.choice([0, N]))),
+                                                                 int(rng.choice([-1, 0, 1, K - 1, K, K + 1])), C.c_void_p(bufs[2].ptr), C.c_uint64(int(rng.integers(0, 3))), None),
+        "null_operands": lambda a, b, o: lib.troyhip_multiply(ctx.h, None, C.byref(b), C.byref(o), C.c_uint64(B), None) | lib.troyhip_add(ctx.h, C.byref(a), None, C.c_uint64(B), None),
         "multiply_plain_ntt": lambda a, b, o: lib.troyhip_multiply_plain_ntt(ctx.h, C.byref(a), C.c_void_p(plain.ptr), C.c_double(float(rng.choice([1.0, 2.0 ** 30, 0.0]))), C.c_uint64(B), None),
     }
     for _ in range(calls // 3):
@@ -76,10 +87,10 @@ for scheme, bits in ((capi.BFV, [40, 36, 36, 40]), (capi.CKKS, [50, 40, 40, 50])
             sys.exit(2)
         if rc == 0:  # what was accepted must have been a plausible operand: a real level, 1 .. 16 polynomials, items that do not overlap
             used = (a, b) if name in ("add", "sub", "multiply") else (a,)
-            if name in ("decrypt", "switch_key", "rotate"):
+            if name in ("decrypt", "switch_key", "rotate", "ntt", "ntt_foreign_prime", "plain_to_ntt", "null_operands"):
                 used = ()  # their operand rules differ (sizes up to the key powers at hand; a target instead of c1; rotation by 0 steps returns before any check, as the reference does)
             for d in used:
-                if not (1 <= d.limbs <= K - 1 and 1 <= d.size <= 16 and d.batch_stride >= d.size * d.limbs * N):
+                if not (1 <= d.limbs <= K - 1 and 1 <= d.size <= 16 and d.batch_stride >= d.size * d.limbs * N and d.data):
                     print("ACCEPTED AN IMPLAUSIBLE OPERAND", scheme, name, d.size, d.limbs, d.batch_stride, d.is_ntt_form)
                     sys.exit(3)
         stats[(name, rc)] = stats.get((name, rc), 0) + 1
