@@ -475,14 +475,37 @@ public:
         }
         return out;
     }
-    // the same ciphertexts, moved into one slab (device-to-device); they must agree in shape and metadata
-    static std::vector<Ciphertext> packBatch(const std::vector<Ciphertext> &items) {
+    // ... of `size` polynomials over `limbs` primes each (a product, the next level), the rest of the metadata from `like`
+    static std::vector<Ciphertext> allocateBatch(size_t count, const Ciphertext &like, size_t size, size_t limbs) {
+        Ciphertext shape;
+        shape.d_ = like.d_;
+        shape.d_.size = (int)size;
+        shape.d_.limbs = (int)limbs;
+        shape.n_ = like.n_;
+        shape.ids_ = like.ids_;
+        return allocateBatch(count, shape);
+    }
+    // the same ciphertexts, copied into one slab (device-to-device); they must agree in shape and metadata
+    static std::vector<Ciphertext> packBatch(const std::vector<const Ciphertext *> &items) {
         if (items.empty()) return {};
-        std::vector<Ciphertext> out = allocateBatch(items.size(), items[0]);
+        std::vector<Ciphertext> out = allocateBatch(items.size(), *items[0]);
         for (size_t b = 0; b < items.size(); b++) {
-            if (!items[b].sameShape(items[0])) throw std::invalid_argument("packBatch: ciphertexts of different shape");
-            check(troyhip_copy_d2d(out[b].d_.data, items[b].d_.data, out[b].d_.batch_stride * 8, nullptr));
+            if (!items[b]->sameShape(*items[0])) throw std::invalid_argument("packBatch: ciphertexts of different shape");
+            check(troyhip_copy_d2d(out[b].d_.data, items[b]->d_.data, out[b].d_.batch_stride * 8, nullptr));
         }
+        return out;
+    }
+    static std::vector<Ciphertext> packBatch(const std::vector<Ciphertext> &items) { return packBatch(pointers(items)); }
+    static std::vector<const Ciphertext *> pointers(const std::vector<Ciphertext> &items) {
+        std::vector<const Ciphertext *> out;
+        out.reserve(items.size());
+        for (const Ciphertext &c : items) out.push_back(&c);
+        return out;
+    }
+    static std::vector<Ciphertext *> pointers(std::vector<Ciphertext> &items) {
+        std::vector<Ciphertext *> out;
+        out.reserve(items.size());
+        for (Ciphertext &c : items) out.push_back(&c);
         return out;
     }
     // do these ciphertexts, in this order, form a dense run of one slab?
@@ -493,6 +516,18 @@ public:
         for (size_t b = 1; b < items.size(); b++) {
             const Ciphertext &c = *items[b];
             if (c.store_ != head.store_ || c.own_ || !c.sameShape(head) || c.d_.data != head.d_.data + b * head.d_.batch_stride) return false;
+        }
+        return true;
+    }
+    // ... or at least consecutive members of one slab with one common stride?  (A member may use fewer polynomials than its stride holds: what
+    // relinearizeInplaceBatch leaves of a batch of products.)  That is all a batched library call needs: (data, batch_stride) of the head.
+    static bool isRun(const std::vector<const Ciphertext *> &items) {
+        if (items.empty() || !items[0]->store_ || items[0]->own_) return false;
+        const Ciphertext &head = *items[0];
+        if (head.d_.batch_stride < head.size() * head.coeffModulusSize() * head.n_) return false;
+        for (size_t b = 1; b < items.size(); b++) {
+            const Ciphertext &c = *items[b];
+            if (c.store_ != head.store_ || c.own_ || !c.sameShape(head) || c.d_.batch_stride != head.d_.batch_stride || c.d_.data != head.d_.data + b * head.d_.batch_stride) return false;
         }
         return true;
     }
@@ -1174,13 +1209,16 @@ public:
     // ---- batched forms over slab members (Ciphertext::allocateBatch / packBatch): ONE library launch for the whole run of
     // ciphertexts, the same plaintext against each (no counterpart in the reference, which loops; used by troyn_app.hpp)
     std::vector<Ciphertext> multiplyPlainBatch(const std::vector<const Ciphertext *> &column, const Plaintext &plain) const {
-        if (!Ciphertext::isBatch(column)) throw std::invalid_argument("multiplyPlainBatch: the ciphertexts are not a dense run of one slab");
+        if (column.empty()) return {};
         const Ciphertext &head = *column[0];
         if (head.isNttForm() != plain.isNttForm() && c_.parms().scheme() != SchemeType::ckks) throw std::invalid_argument("NTT form mismatch");
         if (head.isNttForm() && plain.isNttForm() && head.parmsID() != plain.parmsID()) throw std::invalid_argument("encrypted_ntt and plain_ntt parameter mismatch");
         const size_t count = column.size();
-        std::vector<Ciphertext> out = Ciphertext::allocateBatch(count, head);
-        check(troyhip_copy_d2d(out[0].raw()->data, head.raw()->data, count * head.raw()->batch_stride * 8, nullptr));
+        std::vector<Ciphertext> out;
+        if (Ciphertext::isBatch(column)) { // a dense run of one slab: one copy
+            out = Ciphertext::allocateBatch(count, head);
+            check(troyhip_copy_d2d(out[0].raw()->data, head.raw()->data, count * head.raw()->batch_stride * 8, nullptr));
+        } else out = Ciphertext::packBatch(column); // anything else: one copy per ciphertext
         troyhip_ct t = *out[0].raw();
         if (head.isNttForm()) check(troyhip_multiply_plain_ntt(h(), &t, plain.device(), plain.scale(), count, nullptr));
         else check(troyhip_multiply_plain(h(), &t, plain.device(), plain.coeffCount(), 0, count, nullptr));
@@ -1223,6 +1261,118 @@ public:
         troyhip_ct t = *acc[0].raw();
         check(troyhip_add(h(), &t, x[0].raw(), acc.size(), nullptr));
         for (auto &c : acc) c.copyMeta(t);
+    }
+    // ---- the hot path, batched (round 4).  One ciphertext cannot fill 256 compute units: a single multiply + relinearize at N = 2^15 runs at a third
+    // of the rate a batch of 128 reaches.  Every method below is ONE library call over `count` independent ciphertexts of one shape -- the calls of
+    // src/evaluator_cuda.cuh:85-115,193-198,292-344 with the reference's checks and messages, on std::vector operands.  Operands that already are
+    // consecutive members of one slab (Ciphertext::allocateBatch, or the result of a ...Batch call) are used where they lie; anything else is
+    // packed into a slab first (one device copy per ciphertext -- small next to the operation).  Results are slab members: chains of ...Batch
+    // calls never copy.  The ...InplaceBatch forms take pointers, group consecutive items of equal shape, and leave every item a slab member.
+    std::vector<Ciphertext> multiplyBatch(const std::vector<const Ciphertext *> &a, const std::vector<const Ciphertext *> &b) const {
+        if (a.size() != b.size()) throw std::invalid_argument("multiplyBatch: operand counts differ");
+        if (a.empty()) return {};
+        std::vector<Ciphertext> pa, pb;
+        const bool square = a == b;
+        const troyhip_ct va = runOf(a, pa), vb = square ? va : runOf(b, pb);
+        std::vector<Ciphertext> out = Ciphertext::allocateBatch(a.size(), *a[0], a[0]->size() + b[0]->size() - 1, a[0]->coeffModulusSize());
+        troyhip_ct t = *out[0].raw();
+        check(troyhip_multiply(h(), &va, &vb, &t, a.size(), nullptr));
+        for (auto &c : out) c.copyMeta(t);
+        return out;
+    }
+    std::vector<Ciphertext> multiplyBatch(const std::vector<Ciphertext> &a, const std::vector<Ciphertext> &b) const { return multiplyBatch(Ciphertext::pointers(a), Ciphertext::pointers(b)); }
+    std::vector<Ciphertext> squareBatch(const std::vector<const Ciphertext *> &a) const { return multiplyBatch(a, a); }
+    std::vector<Ciphertext> squareBatch(const std::vector<Ciphertext> &a) const { return squareBatch(Ciphertext::pointers(a)); }
+    void multiplyInplaceBatch(const std::vector<Ciphertext *> &a, const std::vector<const Ciphertext *> &b) const {
+        std::vector<Ciphertext> out = multiplyBatch(std::vector<const Ciphertext *>(a.begin(), a.end()), b);
+        for (size_t i = 0; i < a.size(); i++) *a[i] = std::move(out[i]);
+    }
+    // relinearize(encrypted, relin_keys, destination) over a batch: from size 3 the operands are read where they lie (troyhip_relinearize_to)
+    std::vector<Ciphertext> relinearizeBatch(const std::vector<const Ciphertext *> &a, const RelinKeys &k) const {
+        if (a.empty()) return {};
+        std::vector<Ciphertext> pa;
+        const troyhip_ct va = runOf(a, pa);
+        const std::vector<const uint64_t *> keys = relinKeys(*a[0], k);
+        std::vector<Ciphertext> out = Ciphertext::allocateBatch(a.size(), *a[0], a[0]->size() == 3 ? 2 : a[0]->size(), a[0]->coeffModulusSize());
+        troyhip_ct t = *out[0].raw();
+        check(troyhip_relinearize_to(h(), &va, &t, keys.data(), (int)(a[0]->size() > 2 ? a[0]->size() - 2 : 0), a.size(), nullptr));
+        for (auto &c : out) c.copyMeta(t);
+        return out;
+    }
+    std::vector<Ciphertext> relinearizeBatch(const std::vector<Ciphertext> &a, const RelinKeys &k) const { return relinearizeBatch(Ciphertext::pointers(a), k); }
+    void relinearizeInplaceBatch(const std::vector<Ciphertext *> &items, const RelinKeys &k) const {
+        inplaceBatch(items, [&](troyhip_ct *v, size_t count, const Ciphertext &head) {
+            const std::vector<const uint64_t *> keys = relinKeys(head, k);
+            check(troyhip_relinearize_keys(h(), v, keys.data(), (int)(head.size() > 2 ? head.size() - 2 : 0), count, nullptr));
+        });
+    }
+    void relinearizeInplaceBatch(std::vector<Ciphertext> &items, const RelinKeys &k) const { relinearizeInplaceBatch(Ciphertext::pointers(items), k); }
+    void applyKeySwitchingInplaceBatch(const std::vector<Ciphertext *> &items, const KSwitchKeys &k) const {
+        if (k.all().size() != 1) throw std::invalid_argument("kswitch_keys.data().size() != 1");
+        const uint64_t *key = k.all().begin()->second->get();
+        inplaceBatch(items, [&](troyhip_ct *v, size_t count, const Ciphertext &) { check(troyhip_apply_key_switching(h(), v, key, count, nullptr)); });
+    }
+    std::vector<Ciphertext> modSwitchToNextBatch(const std::vector<const Ciphertext *> &a) const { return nextBatch(a, troyhip_mod_switch_to_next); }
+    std::vector<Ciphertext> modSwitchToNextBatch(const std::vector<Ciphertext> &a) const { return modSwitchToNextBatch(Ciphertext::pointers(a)); }
+    std::vector<Ciphertext> rescaleToNextBatch(const std::vector<const Ciphertext *> &a) const { return nextBatch(a, troyhip_rescale_to_next); }
+    std::vector<Ciphertext> rescaleToNextBatch(const std::vector<Ciphertext> &a) const { return rescaleToNextBatch(Ciphertext::pointers(a)); }
+    void modSwitchToNextInplaceBatch(const std::vector<Ciphertext *> &items) const { nextInplaceBatch(items, troyhip_mod_switch_to_next); }
+    void modSwitchToNextInplaceBatch(std::vector<Ciphertext> &items) const { modSwitchToNextInplaceBatch(Ciphertext::pointers(items)); }
+    void rescaleToNextInplaceBatch(const std::vector<Ciphertext *> &items) const { nextInplaceBatch(items, troyhip_rescale_to_next); }
+    void rescaleToNextInplaceBatch(std::vector<Ciphertext> &items) const { rescaleToNextInplaceBatch(Ciphertext::pointers(items)); }
+    void applyGaloisInplaceBatch(const std::vector<Ciphertext *> &items, uint32_t galois_elt, const GaloisKeys &gk) const {
+        if (!gk.hasKey(galois_elt)) throw std::invalid_argument("Galois key not present");
+        const uint64_t *key = gk.device(GaloisKeys::getIndex(galois_elt));
+        inplaceBatch(items, [&](troyhip_ct *v, size_t count, const Ciphertext &) { check(troyhip_apply_galois(h(), v, galois_elt, key, count, nullptr)); });
+    }
+    void applyGaloisInplaceBatch(std::vector<Ciphertext> &items, uint32_t galois_elt, const GaloisKeys &gk) const { applyGaloisInplaceBatch(Ciphertext::pointers(items), galois_elt, gk); }
+    void rotateRowsInplaceBatch(const std::vector<Ciphertext *> &items, int steps, const GaloisKeys &gk) const { need(SchemeType::ckks, false); rotateBatch(items, steps, 0, gk); }
+    void rotateRowsInplaceBatch(std::vector<Ciphertext> &items, int steps, const GaloisKeys &gk) const { rotateRowsInplaceBatch(Ciphertext::pointers(items), steps, gk); }
+    void rotateColumnsInplaceBatch(const std::vector<Ciphertext *> &items, const GaloisKeys &gk) const { need(SchemeType::ckks, false); rotateBatch(items, 0, 1, gk); }
+    void rotateColumnsInplaceBatch(std::vector<Ciphertext> &items, const GaloisKeys &gk) const { rotateColumnsInplaceBatch(Ciphertext::pointers(items), gk); }
+    void rotateVectorInplaceBatch(const std::vector<Ciphertext *> &items, int steps, const GaloisKeys &gk) const { need(SchemeType::ckks, true); rotateBatch(items, steps, 0, gk); }
+    void rotateVectorInplaceBatch(std::vector<Ciphertext> &items, int steps, const GaloisKeys &gk) const { rotateVectorInplaceBatch(Ciphertext::pointers(items), steps, gk); }
+    void complexConjugateInplaceBatch(const std::vector<Ciphertext *> &items, const GaloisKeys &gk) const { need(SchemeType::ckks, true); rotateBatch(items, 0, 1, gk); }
+    void complexConjugateInplaceBatch(std::vector<Ciphertext> &items, const GaloisKeys &gk) const { complexConjugateInplaceBatch(Ciphertext::pointers(items), gk); }
+    // the element-wise and transform calls over a batch (cheap per ciphertext, but a launch each when looped: 8-15 us apiece)
+    void negateInplaceBatch(const std::vector<Ciphertext *> &items) const {
+        inplaceBatch(items, [&](troyhip_ct *v, size_t count, const Ciphertext &) { check(troyhip_negate(h(), v, count, nullptr)); });
+    }
+    void addInplaceBatch(const std::vector<Ciphertext *> &acc, const std::vector<const Ciphertext *> &x) const { addsubBatch(acc, x, false); }
+    void subInplaceBatch(const std::vector<Ciphertext *> &acc, const std::vector<const Ciphertext *> &x) const { addsubBatch(acc, x, true); }
+    void transformToNttInplaceBatch(const std::vector<Ciphertext *> &items) const {
+        inplaceBatch(items, [&](troyhip_ct *v, size_t count, const Ciphertext &) { check(troyhip_transform_to_ntt(h(), v, count, nullptr)); });
+    }
+    void transformFromNttInplaceBatch(const std::vector<Ciphertext *> &items) const {
+        inplaceBatch(items, [&](troyhip_ct *v, size_t count, const Ciphertext &) { check(troyhip_transform_from_ntt(h(), v, count, nullptr)); });
+    }
+    void negacyclicShiftInplaceBatch(const std::vector<Ciphertext *> &items, size_t shift) const {
+        inplaceBatch(items, [&](troyhip_ct *v, size_t count, const Ciphertext &) { check(troyhip_negacyclic_shift(h(), v, shift, count, nullptr)); });
+    }
+    void divideByPolyModulusDegreeInplaceBatch(const std::vector<Ciphertext *> &items, uint64_t mul = 1) const {
+        inplaceBatch(items, [&](troyhip_ct *v, size_t count, const Ciphertext &) { check(troyhip_divide_by_poly_modulus_degree(h(), v, mul, count, nullptr)); });
+    }
+    // fieldTraceInplace (src/evaluator_cuda.cu:2278-2294) over a batch: log2(N) - logn rounds of (copy, automorphism X -> X^(N / 2^k + 1), add),
+    // each round one key switch over all the ciphertexts
+    void fieldTraceInplaceBatch(const std::vector<Ciphertext *> &items, const GaloisKeys &automorphism_keys, size_t logn) const {
+        if (items.empty()) return;
+        const std::vector<const Ciphertext *> view(items.begin(), items.end());
+        for (size_t poly_degree = c_.polyModulusDegree(); poly_degree > (size_t(1) << logn); poly_degree >>= 1) {
+            std::vector<Ciphertext> temp = Ciphertext::packBatch(view);
+            applyGaloisInplaceBatch(temp, (uint32_t)(poly_degree + 1), automorphism_keys);
+            addInplaceBatch(items, Ciphertext::pointers(const_cast<const std::vector<Ciphertext> &>(temp)));
+        }
+    }
+    void multiplyPlainInplaceBatch(const std::vector<Ciphertext *> &items, const Plaintext &plain) const { // one plaintext against every item
+        inplaceBatch(items, [&](troyhip_ct *v, size_t count, const Ciphertext &head) {
+            if (head.isNttForm() != plain.isNttForm() && c_.parms().scheme() != SchemeType::ckks) throw std::invalid_argument("NTT form mismatch");
+            if (head.isNttForm() && plain.isNttForm() && head.parmsID() != plain.parmsID()) throw std::invalid_argument("encrypted_ntt and plain_ntt parameter mismatch");
+            if (head.isNttForm()) check(troyhip_multiply_plain_ntt(h(), v, plain.device(), plain.scale(), count, nullptr));
+            else check(troyhip_multiply_plain(h(), v, plain.device(), plain.coeffCount(), 0, count, nullptr));
+        });
+    }
+    void addPlainInplaceBatch(const std::vector<Ciphertext *> &items, const Plaintext &plain) const {
+        inplaceBatch(items, [&](troyhip_ct *v, size_t count, const Ciphertext &) { check(troyhip_add_plain(h(), v, plain.device(), plain.coeffCount(), 0, plain.scale(), 0, count, nullptr)); });
     }
     // addPlainInplace / subPlainInplace (evaluator_cuda.cu:1654-1720)
     void addPlainInplace(Ciphertext &a, const Plaintext &plain) const { plain_addsub(a, plain, 0); }
@@ -1360,6 +1510,81 @@ private:
         check(fn(h(), a.raw(), out.raw(), 1, nullptr));
         out.bind(a);
         a = std::move(out);
+    }
+    // ---- batch plumbing
+    // the (data, stride) view of `items` as one batch: in place when they are a run of one slab, else packed into `packed` first
+    troyhip_ct runOf(const std::vector<const Ciphertext *> &items, std::vector<Ciphertext> &packed) const {
+        for (const Ciphertext *c : items)
+            if (!c->sameShape(*items[0])) throw std::invalid_argument("batch: ciphertexts of different shape");
+        if (items.size() == 1 || Ciphertext::isRun(items)) return *items[0]->raw();
+        packed = Ciphertext::packBatch(items);
+        return *packed[0].raw();
+    }
+    // fn(view, count, head) once per group of consecutive items of equal shape; afterwards every item of a group of two or more is a member of one slab
+    template <class F> void inplaceBatch(const std::vector<Ciphertext *> &items, F fn) const {
+        for (size_t i = 0; i < items.size();) {
+            size_t j = i + 1;
+            while (j < items.size() && items[j]->sameShape(*items[i])) j++;
+            const size_t count = j - i;
+            std::vector<const Ciphertext *> group(items.begin() + (long)i, items.begin() + (long)j);
+            if (count == 1 || Ciphertext::isRun(group)) {
+                troyhip_ct t = *items[i]->raw();
+                fn(&t, count, *items[i]);
+                for (size_t b = i; b < j; b++) items[b]->copyMeta(t);
+            } else {
+                std::vector<Ciphertext> packed = Ciphertext::packBatch(group);
+                troyhip_ct t = *packed[0].raw();
+                fn(&t, count, *items[i]);
+                for (size_t b = 0; b < count; b++) { packed[b].copyMeta(t); *items[i + b] = std::move(packed[b]); }
+            }
+            i = j;
+        }
+    }
+    std::vector<const uint64_t *> relinKeys(const Ciphertext &head, const RelinKeys &k) const {
+        const size_t need = head.size() > 2 ? head.size() - 2 : 0;
+        std::vector<const uint64_t *> keys(need ? need : 1, nullptr);
+        for (size_t i = 0; i < need; i++) {
+            if (!k.hasKey(i + 2)) throw std::invalid_argument("not enough relinearization keys");
+            keys[i] = k.device(RelinKeys::getIndex(i + 2));
+        }
+        return keys;
+    }
+    template <class F> std::vector<Ciphertext> nextBatch(const std::vector<const Ciphertext *> &a, F fn) const {
+        if (a.empty()) return {};
+        std::vector<Ciphertext> pa;
+        const troyhip_ct va = runOf(a, pa);
+        std::vector<Ciphertext> out = Ciphertext::allocateBatch(a.size(), *a[0], a[0]->size(), a[0]->coeffModulusSize() > 1 ? a[0]->coeffModulusSize() - 1 : 1);
+        troyhip_ct t = *out[0].raw();
+        check(fn(h(), &va, &t, a.size(), nullptr));
+        for (auto &c : out) c.copyMeta(t);
+        return out;
+    }
+    template <class F> void nextInplaceBatch(const std::vector<Ciphertext *> &items, F fn) const {
+        for (size_t i = 0; i < items.size();) {
+            size_t j = i + 1;
+            while (j < items.size() && items[j]->sameShape(*items[i])) j++;
+            std::vector<Ciphertext> out = nextBatch(std::vector<const Ciphertext *>(items.begin() + (long)i, items.begin() + (long)j), fn);
+            for (size_t b = i; b < j; b++) *items[b] = std::move(out[b - i]);
+            i = j;
+        }
+    }
+    void rotateBatch(const std::vector<Ciphertext *> &items, int steps, int conj, const GaloisKeys &gk) const {
+        std::vector<uint32_t> elts;
+        std::vector<const uint64_t *> ptrs;
+        for (auto &kv : gk.all()) { elts.push_back((uint32_t)(2 * kv.first + 1)); ptrs.push_back(kv.second->get()); }
+        inplaceBatch(items, [&](troyhip_ct *v, size_t count, const Ciphertext &) { check(troyhip_rotate(h(), v, steps, conj, elts.data(), ptrs.data(), (int)elts.size(), count, nullptr)); });
+    }
+    void addsubBatch(const std::vector<Ciphertext *> &acc, const std::vector<const Ciphertext *> &x, bool sub) const {
+        if (acc.size() != x.size()) throw std::invalid_argument("Size incorrect.");
+        for (size_t i = 0; i < acc.size();) { // groups in which both sides keep one shape
+            size_t j = i + 1;
+            while (j < acc.size() && acc[j]->sameShape(*acc[i]) && x[j]->sameShape(*x[i])) j++;
+            std::vector<Ciphertext> px;
+            const troyhip_ct vx = runOf(std::vector<const Ciphertext *>(x.begin() + (long)i, x.begin() + (long)j), px);
+            inplaceBatch(std::vector<Ciphertext *>(acc.begin() + (long)i, acc.begin() + (long)j),
+                         [&](troyhip_ct *v, size_t count, const Ciphertext &) { check((sub ? troyhip_sub : troyhip_add)(h(), v, &vx, count, nullptr)); });
+            i = j;
+        }
     }
     void rotate(Ciphertext &a, int steps, int conj, const GaloisKeys &gk) const {
         std::vector<uint32_t> elts;

@@ -86,22 +86,27 @@ public:
         read(stream, [&](Ciphertext &ct) { ct.load(stream, context); });
     }
 
-    void modSwitchToNext(const troyn::Evaluator &evaluator) {
-        each([&](Ciphertext &ct) { evaluator.modSwitchToNextInplace(ct); });
+    // every ciphertext of the grid, row-major
+    std::vector<Ciphertext *> all() {
+        std::vector<Ciphertext *> v;
+        each([&](Ciphertext &ct) { v.push_back(&ct); });
+        return v;
     }
-    void relinearize(const troyn::Evaluator &evaluator, const troyn::RelinKeys &rlk) {
-        each([&](Ciphertext &ct) { evaluator.relinearizeInplace(ct, rlk); });
-    }
-    void switch_key(const troyn::Evaluator &evaluator, const troyn::KSwitchKeys &ksk) {
-        each([&](Ciphertext &ct) { evaluator.applyKeySwitchingInplace(ct, ksk); });
-    }
+    // The reference loops over the grid one ciphertext at a time (LinearHelper.cuh:104-140); here the whole grid is ONE batched library call per
+    // operation (troyn::Evaluator::...InplaceBatch: the ciphertexts are gathered into a device slab once and stay its members) -- same limbs.
+    void modSwitchToNext(const troyn::Evaluator &evaluator) { evaluator.modSwitchToNextInplaceBatch(all()); }
+    void relinearize(const troyn::Evaluator &evaluator, const troyn::RelinKeys &rlk) { evaluator.relinearizeInplaceBatch(all(), rlk); }
+    void switch_key(const troyn::Evaluator &evaluator, const troyn::KSwitchKeys &ksk) { evaluator.applyKeySwitchingInplaceBatch(all(), ksk); }
     void multiplyScalarInplace(const troyn::BatchEncoder &encoder, const troyn::Evaluator &evaluator, uint64_t scalar) {
         Plaintext constant;
         encoder.encodePolynomial(std::vector<uint64_t>{scalar}, constant);
-        each([&](Ciphertext &ct) { evaluator.multiplyPlainInplace(ct, constant); });
+        evaluator.multiplyPlainInplaceBatch(all(), constant);
     }
     void addInplace(const troyn::Evaluator &evaluator, const Cipher2d &x) {
-        zip(x, [&](Ciphertext &c, const Ciphertext &o) { evaluator.addInplace(c, o); });
+        std::vector<Ciphertext *> mine;
+        std::vector<const Ciphertext *> theirs;
+        zip(x, [&](Ciphertext &c, const Ciphertext &o) { mine.push_back(&c); theirs.push_back(&o); }); // the reference's shape checks
+        evaluator.addInplaceBatch(mine, theirs);
     }
     void addPlainInplace(const troyn::Evaluator &evaluator, const Plain2d &x) {
         zip(x, [&](Ciphertext &c, const Plaintext &p) { evaluator.addPlainInplace(c, p); });
@@ -122,20 +127,47 @@ inline Cipher2d Plain2d::encrypt(const troyn::Encryptor &encryptor) const {
 }
 
 namespace detail {
-// ret[b][o] = sum_i product(b, i, o): the accumulation order of the reference (first product moved, the rest added in place)
-template <class P> inline Cipher2d accumulate(const troyn::Evaluator &evaluator, size_t rows, size_t outputs, size_t inputs, P product) {
+// ret[b][o] = sum_i product(b, i, o), accumulated in the reference's order (i = 0 moved, i = 1, 2, .. added in place: LinearHelper.cuh:392-470), with
+// ONE library call per input block i: the products of step i for every (b, o) are independent ciphertext operations of one
+// shape, so they go through the batched forms (troyn::Evaluator::multiplyBatch / multiplyPlainBatch) and are added into the accumulators as a
+// batch -- the limbs are those of the ciphertext-by-ciphertext loop.
+//   left(b, i) / right(i, o): the two factors of product (b, i, o)
+template <class L, class R> inline Cipher2d accumulateCipher(const troyn::Evaluator &evaluator, size_t rows, size_t outputs, size_t inputs, L left, R right) {
     Cipher2d ret;
     ret.data.resize(rows);
-    for (size_t b = 0; b < rows; b++) {
-        ret[b].resize(outputs);
-        for (size_t i = 0; i < inputs; i++)
-            for (size_t o = 0; o < outputs; o++) {
-                troyn::Ciphertext prod;
-                product(b, i, o, prod);
-                if (i == 0) ret[b][o] = std::move(prod);
-                else evaluator.addInplace(ret[b][o], prod);
-            }
+    for (auto &r : ret.data) r.resize(outputs);
+    if (!rows || !outputs) return ret;
+    std::vector<troyn::Ciphertext> acc;
+    std::vector<const troyn::Ciphertext *> x(rows * outputs), y(rows * outputs);
+    for (size_t i = 0; i < inputs; i++) {
+        for (size_t b = 0; b < rows; b++)
+            for (size_t o = 0; o < outputs; o++) { x[b * outputs + o] = &left(b, i); y[b * outputs + o] = &right(i, o); }
+        std::vector<troyn::Ciphertext> prod = evaluator.multiplyBatch(x, y);
+        if (i == 0) acc = std::move(prod);
+        else evaluator.addInplaceBatch(acc, prod);
     }
+    for (size_t b = 0; b < rows; b++)
+        for (size_t o = 0; o < outputs; o++) ret[b][o] = std::move(acc[b * outputs + o]);
+    return ret;
+}
+// ciphertext x plaintext, product (b, i, o) = ct(b, i, o) * pt(b, i, o): the ciphertexts that meet ONE plaintext go through one batched multiplyPlain --
+// over the batch rows b when the plaintext is a weight (overRows: pt does not depend on b), over the outputs o when the plaintexts are the inputs
+template <class C, class P> inline Cipher2d accumulatePlain(const troyn::Evaluator &evaluator, size_t rows, size_t outputs, size_t inputs, bool overRows, C ct, P pt) {
+    Cipher2d ret;
+    ret.data.resize(rows);
+    for (auto &r : ret.data) r.resize(outputs);
+    const size_t count = overRows ? rows : outputs, others = overRows ? outputs : rows;
+    std::vector<const troyn::Ciphertext *> column(count);
+    for (size_t i = 0; i < inputs && count; i++)
+        for (size_t j = 0; j < others; j++) {
+            for (size_t k = 0; k < count; k++) column[k] = overRows ? &ct(k, i, j) : &ct(j, i, k);
+            std::vector<troyn::Ciphertext> prod = evaluator.multiplyPlainBatch(column, overRows ? pt(0, i, j) : pt(j, i, 0));
+            for (size_t k = 0; k < count; k++) {
+                troyn::Ciphertext &d = overRows ? ret[k][j] : ret[j][k];
+                if (i == 0) d = std::move(prod[k]);
+                else evaluator.addInplace(d, prod[k]);
+            }
+        }
     return ret;
 }
 } // namespace detail
@@ -267,18 +299,18 @@ public:
     // ret[b][j] = sum_i a[b][i] * w[i][j]: encrypted inputs x plain weights, both encrypted, plain inputs x encrypted weights
     Cipher2d matmul(const troyn::Evaluator &evaluator, const Cipher2d &a, const Plain2d &w) {
         checkOperands(a.data.size(), w.data.size());
-        return detail::accumulate(evaluator, a.data.size(), outputBlocks(), w.data.size(),
-                                  [&](size_t b, size_t i, size_t o, Ciphertext &prod) { evaluator.multiplyPlain(a[b][i], w[i][o], prod); });
+        return detail::accumulatePlain(evaluator, a.data.size(), outputBlocks(), w.data.size(), true,
+                                       [&](size_t b, size_t i, size_t) -> const Ciphertext & { return a[b][i]; }, [&](size_t, size_t i, size_t o) -> const Plaintext & { return w[i][o]; });
     }
     Cipher2d matmulCipher(const troyn::Evaluator &evaluator, const Cipher2d &a, const Cipher2d &w) {
         checkOperands(a.data.size(), w.data.size());
-        return detail::accumulate(evaluator, a.data.size(), outputBlocks(), w.data.size(),
-                                  [&](size_t b, size_t i, size_t o, Ciphertext &prod) { evaluator.multiply(a[b][i], w[i][o], prod); });
+        return detail::accumulateCipher(evaluator, a.data.size(), outputBlocks(), w.data.size(),
+                                        [&](size_t b, size_t i) -> const Ciphertext & { return a[b][i]; }, [&](size_t i, size_t o) -> const Ciphertext & { return w[i][o]; });
     }
     Cipher2d matmulReverse(const troyn::Evaluator &evaluator, const Plain2d &a, const Cipher2d &w) {
         checkOperands(a.data.size(), w.data.size());
-        return detail::accumulate(evaluator, a.data.size(), outputBlocks(), w.data.size(),
-                                  [&](size_t b, size_t i, size_t o, Ciphertext &prod) { evaluator.multiplyPlain(w[i][o], a[b][i], prod); });
+        return detail::accumulatePlain(evaluator, a.data.size(), outputBlocks(), w.data.size(), false,
+                                       [&](size_t, size_t i, size_t o) -> const Ciphertext & { return w[i][o]; }, [&](size_t b, size_t i, size_t) -> const Plaintext & { return a[b][i]; });
     }
 
     // a bias / expected output in the layout of matmul's result (of packOutputs' result with packLwe): only the coefficients
@@ -346,24 +378,27 @@ public:
         const size_t lanes = inputBlock;
         size_t keep_log = 0;
         while ((size_t(1) << keep_log) != slotCount / lanes) keep_log++;
-        Ciphertext group, one, placed;
-        size_t lane = 0;
+        // The reference folds one result ciphertext at a time (shift, divide, log2(inputBlock) key switches, shift, add).  The ciphertexts are
+        // independent until the final additions, so here every step runs over ALL of them as one batched call: log2(inputBlock) key-switch
+        // launches in total instead of per ciphertext.  Each packed ciphertext still receives its lanes in the order 0, 1, ..: same limbs.
+        std::vector<const Ciphertext *> sources;
         for (const auto &row : cipher.data)
-            for (size_t j = 0; j < cipher.data[0].size(); j++) {
-                if (lanes > 1) evaluator.negacyclicShift(row[j], 2 * slotCount - (lanes - 1), one);
-                else one = row[j];
-                evaluator.divideByPolyModulusDegreeInplace(one, slotCount / lanes);
-                evaluator.fieldTraceInplace(one, autoKey, keep_log);
-                if (lane) evaluator.negacyclicShift(one, lane, placed);
-                else placed = one;
-                if (lane == 0) group = placed;
-                else evaluator.addInplace(group, placed);
-                if (++lane == lanes) {
-                    ret[0].push_back(std::move(group));
-                    lane = 0;
-                }
-            }
-        if (lane) ret[0].push_back(std::move(group));
+            for (size_t j = 0; j < cipher.data[0].size(); j++) sources.push_back(&row[j]);
+        std::vector<Ciphertext> one = Ciphertext::packBatch(sources);
+        const std::vector<Ciphertext *> all = Ciphertext::pointers(one);
+        if (lanes > 1) evaluator.negacyclicShiftInplaceBatch(all, 2 * slotCount - (lanes - 1));
+        evaluator.divideByPolyModulusDegreeInplaceBatch(all, slotCount / lanes);
+        evaluator.fieldTraceInplaceBatch(all, autoKey, keep_log);
+        const size_t total = one.size(), groups = ceilDiv(total, lanes);
+        std::vector<Ciphertext *> acc;
+        for (size_t lane = 0; lane < lanes && lane < total; lane++) {
+            std::vector<Ciphertext *> members;
+            for (size_t g = 0; g * lanes + lane < total; g++) members.push_back(&one[g * lanes + lane]);
+            if (lane == 0) { acc = members; continue; }
+            evaluator.negacyclicShiftInplaceBatch(members, lane);
+            evaluator.addInplaceBatch(std::vector<Ciphertext *>(acc.begin(), acc.begin() + (long)members.size()), std::vector<const Ciphertext *>(members.begin(), members.end()));
+        }
+        for (size_t g = 0; g < groups; g++) ret[0].push_back(std::move(*acc[g]));
         return ret;
     }
 
@@ -462,9 +497,7 @@ class Conv2dHelper {
                         if (y < outHeight() && x < outWidth()) f(resultCoeff(b - lb, c - lc, i, j), ((b * outputChannels + c) * outHeight() + y) * outWidth() + x);
                     }
     }
-    template <class P> Cipher2d accumulate(const troyn::Evaluator &evaluator, size_t inputs, P product) {
-        return detail::accumulate(evaluator, getTotalBatchSize(), outputGroups(), inputs, product);
-    }
+
 
 public:
     // blocks (b, h, w, ci, co) with b h w ci co <= N that minimise the ciphertexts that travel (LinearHelper.cuh:779-841): large blocks
@@ -550,16 +583,18 @@ public:
 
     // ret[b][oc] = sum_i a[b][i] * weights[oc][i]
     Cipher2d conv2d(const troyn::Evaluator &evaluator, const Cipher2d &a, const Plain2d &encodedWeights) {
-        return accumulate(evaluator, a.data.empty() ? 0 : a[0].size(),
-                          [&](size_t b, size_t i, size_t oc, Ciphertext &prod) { evaluator.multiplyPlain(a[b][i], encodedWeights[oc][i], prod); });
+        return detail::accumulatePlain(evaluator, getTotalBatchSize(), outputGroups(), a.data.empty() ? 0 : a[0].size(), true,
+                                       [&](size_t b, size_t i, size_t) -> const Ciphertext & { return a[b][i]; },
+                                       [&](size_t, size_t i, size_t oc) -> const Plaintext & { return encodedWeights[oc][i]; });
     }
     Cipher2d conv2dCipher(const troyn::Evaluator &evaluator, const Cipher2d &a, const Cipher2d &encodedWeights) {
-        return accumulate(evaluator, a.data.empty() ? 0 : a[0].size(),
-                          [&](size_t b, size_t i, size_t oc, Ciphertext &prod) { evaluator.multiply(a[b][i], encodedWeights[oc][i], prod); });
+        return detail::accumulateCipher(evaluator, getTotalBatchSize(), outputGroups(), a.data.empty() ? 0 : a[0].size(),
+                                        [&](size_t b, size_t i) -> const Ciphertext & { return a[b][i]; }, [&](size_t i, size_t oc) -> const Ciphertext & { return encodedWeights[oc][i]; });
     }
     Cipher2d conv2dReverse(const troyn::Evaluator &evaluator, const Plain2d &a, const Cipher2d &encodedWeights) {
-        return accumulate(evaluator, a.data.empty() ? 0 : a[0].size(),
-                          [&](size_t b, size_t i, size_t oc, Ciphertext &prod) { evaluator.multiplyPlain(encodedWeights[oc][i], a[b][i], prod); });
+        return detail::accumulatePlain(evaluator, getTotalBatchSize(), outputGroups(), a.data.empty() ? 0 : a[0].size(), false,
+                                       [&](size_t, size_t i, size_t oc) -> const Ciphertext & { return encodedWeights[oc][i]; },
+                                       [&](size_t b, size_t i, size_t) -> const Plaintext & { return a[b][i]; });
     }
 
     // a bias / expected output in the layout of conv2d's result.  As in the reference (LinearHelper.cuh:1035-1078) the coefficient

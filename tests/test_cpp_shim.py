@@ -81,3 +81,56 @@ def test_troyn_linear_on_gpu(tmp_path):
     exe = str(tmp_path / "test_troyn_linear")
     _build(exe, os.path.join(ROOT, "troy_amd"), "libtroyhip.so", LINEAR)
     _run(exe, "16384")  # the degree of the reference's own run (test/app/linear.cu:578)
+
+
+BATCH = os.path.join(ROOT, "tests", "cpp", "test_troyn_batch.cpp")  # the slab-batched Evaluator forms against the per-ciphertext forms, limb for limb
+BENCH = os.path.join(ROOT, "tests", "cpp", "bench_troyn.cpp")       # multiply + relinearize ops/s through troyn.hpp (single / loop / batch), each verified
+
+
+def test_troyn_batch_on_emulator(tmp_path):
+    subprocess.check_call(["make", "-s", "-j8", "-C", os.path.join(ROOT, "troy_amd", "csrc"), "emul"])
+    exe = str(tmp_path / "test_troyn_batch_emul")
+    _build(exe, os.path.join(ROOT, "tests", "emul"), "libtroyhip_emul.so", BATCH)
+    _run(exe, "1024", "3")
+
+
+@pytest.mark.gpu
+def test_troyn_batch_on_gpu(tmp_path):
+    exe = str(tmp_path / "test_troyn_batch")
+    _build(exe, os.path.join(ROOT, "troy_amd"), "libtroyhip.so", BATCH)
+    _run(exe, "8192", "7")
+    _run(exe, "32768", "3")  # the single-pass transforms and their fused epilogues under a strided batch
+
+
+def test_bench_troyn_on_emulator(tmp_path):
+    subprocess.check_call(["make", "-s", "-j8", "-C", os.path.join(ROOT, "troy_amd", "csrc"), "emul"])
+    exe = str(tmp_path / "bench_troyn_emul")
+    _build(exe, os.path.join(ROOT, "tests", "emul"), "libtroyhip_emul.so", BENCH)
+    _run(exe, "bfv_n4096_l2", "1", "1", "2")
+
+
+@pytest.mark.gpu
+def test_bench_troyn_on_gpu(tmp_path):
+    exe = str(tmp_path / "bench_troyn")
+    _build(exe, os.path.join(ROOT, "troy_amd"), "libtroyhip.so", BENCH)
+    r = subprocess.run([exe, "bfv_n8192_l4", "3", "1", "8", "40"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "ALL OK" in r.stdout and '"verified": false' not in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+@pytest.mark.gpu
+def test_troyn_timetest_time_mode_on_gpu(tmp_path):
+    exe = str(tmp_path / "test_troyn_timetest")
+    _build(exe, os.path.join(ROOT, "troy_amd"), "libtroyhip.so", TIMETEST)
+    r = subprocess.run([exe, "16384", "--time", "20", "--scheme", "bfv", "--tbits", "59"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "ALL OK" in r.stdout and "FAIL" not in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+    for label in ("Multiply-assign", "Relinearize-assign", "RelinearizeKeys-assign", "RotateRows-inplace", "Square-inplace", "Preallocate"):
+        assert label + ":" in r.stdout  # the reference's labels (test/timetest.cu)
+
+
+REF_TIMETEST = os.path.join(ROOT, "oracle", "_ref", "ref_timetest")
+
+
+@pytest.mark.skipif(not os.path.exists(REF_TIMETEST), reason="oracle/_ref/ref_timetest is built from /root/reference by oracle/Makefile")
+def test_timetest_source_against_the_reference_cpu_half():
+    """the SAME test source, compiled against the reference's own troy:: classes: every assertion the GPU build makes also holds on the reference"""
+    _run(REF_TIMETEST, "4096")

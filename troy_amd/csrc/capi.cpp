@@ -212,11 +212,23 @@ struct DevicePool {
         if (it == live.end()) { (void)hipFree(p); return; } // not ours (defensive)
         Block b{p, {}};
 #ifndef TROYHIP_CPU_EMUL
-        for (size_t i = 0; i <= streams.size(); i++) {
+        // a registered stream that was destroyed without troyhip_stream_unregister must not break free() for good: its record fails, the stream is
+        // dropped from the list (nothing can be running on it any more) and the block is cached all the same
+        for (size_t i = 0; i <= streams.size();) {
             hipEvent_t e = new_event();
             hipStream_t st = i ? streams[i - 1] : (hipStream_t) nullptr;
-            HIP_CHECK(hipEventRecord(e, st));
+            if (hipEventRecord(e, st) != hipSuccess) {
+                (void)hipGetLastError();
+                spare_events.push_back(e);
+                if (i) { streams.erase(streams.begin() + (long)(i - 1)); continue; }
+                // the default stream itself refuses: fall back to a device-wide wait, after which nothing is pending
+                (void)hipDeviceSynchronize();
+                for (auto &se : b.pending) spare_events.push_back(se.second);
+                b.pending.clear();
+                break;
+            }
             b.pending.emplace_back(st, e);
+            i++;
         }
 #endif
         free_blocks.emplace(it->second, std::move(b));
@@ -302,7 +314,7 @@ int troyhip_stat(const char *name, uint64_t *value) {
     return guard([&] {
         if (!name || !value) throw Error(ST_INVALID_ARGUMENT, "null");
         for (int i = 0; i < stats::COUNT; i++)
-            if (std::strcmp(name, stats::name(i)) == 0) { *value = stats::counter(i); return; }
+            if (std::strcmp(name, stats::name(i)) == 0) { *value = stats::counter(i).load(std::memory_order_relaxed); return; }
         throw Error(ST_INVALID_ARGUMENT, std::string("no such counter: ") + name);
     }, false);
 }

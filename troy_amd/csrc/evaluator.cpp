@@ -496,8 +496,11 @@ void Evaluator::mod_switch_scale(const CtBatch &in, CtBatch &out, u64 batch, hip
                             ntt1_supported(c.logn, c.ct_map(nl), batch * in.size * nl);
     // the output ranges [out.data + b out.bstride, + size npw) must not overlap what a later row still reads: when the two batches share memory
     // (a direct C-ABI caller rescaling a strided batch onto itself) the input is staged first, as every strided input was before the fused path
-    const u64 *in_end = in.data + (batch - 1) * in.bstride + (u64)in.size * pw, *out_end = out.data + (batch - 1) * out.bstride + (u64)in.size * npw;
-    const bool overlaps = out.data < in_end && in.data < out_end;
+    bool overlaps = false;
+    if (batch) { // an empty batch touches nothing (and (batch - 1) * stride would wrap)
+        const u64 *in_end = in.data + (batch - 1) * in.bstride + (u64)in.size * pw, *out_end = out.data + (batch - 1) * out.bstride + (u64)in.size * npw;
+        overlaps = out.data < in_end && in.data < out_end;
+    }
     bool staged = false;
     if ((!dense_in && !ckks_fused) || overlaps) {
         staged = true;

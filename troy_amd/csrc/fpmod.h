@@ -107,6 +107,7 @@ inline FpPlan fp_plan(u64 pmax, double b_in, const int *rounds, int n_rounds, do
             out.mask |= 1u << r;
             t = 0.5 + 0x1p-40;
             for (int s = 0; s < rounds[r]; s++) t = fp_stage_bound(t, p, c);
+            if (t >= lim) { out.mask = ~0u; out.out_bound = -1.0; return out; } // even a freshly reduced round passes the limit: no FP64 schedule (as fp_plan_inv)
         }
         b = t;
     }

@@ -214,9 +214,13 @@ void RnsLevel::build(u64 N, const std::vector<u64> &q_, u64 t_, bool aux_auto, c
     if (aux_auto) {
         for (int bits : {50, 58}) {
             if (count_for(bits) != nB || (u64(1) << (bits - 1)) <= 2 * N) continue;
-            std::vector<u64> pool = get_primes(2 * N, bits, nB + 1 + exclude.size() + nq), pick;
+            // candidates: not a key prime, not a prime of q, and not the plain modulus either (a batching t of this size class would otherwise
+            // become m_sk: harmless for the arithmetic -- no inverse of t modulo the base is ever taken -- but impossible in the reference, whose
+            // 61-bit base cannot meet a <= 60-bit t; excluded so that the two bases stay comparable case by case)
+            std::vector<u64> pool, pick;
+            try { pool = get_primes(2 * N, bits, nB + 2 + exclude.size() + nq); } catch (const std::exception &) { continue; } // too few primes of this size: next class / the reference's base
             for (u64 p : pool)
-                if (std::find(exclude.begin(), exclude.end(), p) == exclude.end() && std::find(q.begin(), q.end(), p) == q.end() && pick.size() < nB + 1) pick.push_back(p);
+                if (p != t && std::find(exclude.begin(), exclude.end(), p) == exclude.end() && std::find(q.begin(), q.end(), p) == q.end() && pick.size() < nB + 1) pick.push_back(p);
             if (pick.size() < nB + 1) continue;
             aux.assign(nB + 2, 0);
             aux[0] = pick[0];

@@ -878,7 +878,7 @@ void launch_ntt1(u64 *data, const u64 *src, const PrimeDesc *primes, const LimbM
             if (pl.out_bound < 0) throw Error(ST_LOGIC_ERROR, "ntt1: FP64 bound walk");
             a.fp_red_mask = pl.mask;
         }
-        stats::counter(kind == 2 ? stats::NTT1_FP_LAUNCHES : stats::NTT1_INT_LAUNCHES)++;
+        stats::counter(kind == 2 ? stats::NTT1_FP_LAUNCHES : stats::NTT1_INT_LAUNCHES).fetch_add(1, std::memory_order_relaxed);
         a.rows_per_wg = plan(a.nslots);
         a.chunks = (a.m_total + a.rows_per_wg - 1) / a.rows_per_wg;
         cls[ncls].a = a;

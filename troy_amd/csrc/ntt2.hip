@@ -1100,7 +1100,7 @@ void launch_ntt2_slots(u64 *data, const u64 *src, u64 src_ostride, bool src_redu
         if (fp_ok) a.nsel = select_class(map, slot_begin, slot_count, fp, a.sel);
         else for (unsigned i = 0; i < slot_count; i++) a.sel[a.nsel++] = (uint8_t)(slot_begin + i);
         if (!a.nsel) continue;
-        stats::counter(fp ? stats::NTT2_FP_LAUNCHES : stats::NTT2_INT_LAUNCHES)++;
+        stats::counter(fp ? stats::NTT2_FP_LAUNCHES : stats::NTT2_INT_LAUNCHES).fetch_add(1, std::memory_order_relaxed);
         unsigned mask1 = 0, mask2 = 0; // reduction sites of the first and of the second pass in execution order (fpmod.h)
         if (fp) {
             u64 pmax = 0;
@@ -1183,7 +1183,7 @@ void launch_ntt2_ks_mac(u64 *D, const u64 *src, u64 src_ostride, const PrimeDesc
             if ((int)((map.fp >> i) & 1) == cls) a.sel[a.nsel++] = (uint8_t)i;
         if (!a.nsel) continue;
         const bool fp = cls == 1;
-        stats::counter(fp ? stats::KS_FP_LAUNCHES : stats::KS_INT_LAUNCHES)++;
+        stats::counter(fp ? stats::KS_FP_LAUNCHES : stats::KS_INT_LAUNCHES).fetch_add(1, std::memory_order_relaxed);
         const unsigned blocks = (unsigned)((a.nsel * a.chunks) << a.tiles_per_row_log);
         a.fp_src_wide = 0; a.fp_red_mask = 0; a.fp_acc_every = 0;
         unsigned mask2 = 0;
@@ -1264,7 +1264,7 @@ void launch_ntt2_tensor(u64 *xa, const u64 *src_a, u64 *xb, const u64 *src_b, u6
         if (host_primes) nsel = select_class(map, 0, map.period, fp, sel);
         else for (unsigned i = 0; i < map.period; i++) sel[nsel++] = (uint8_t)i;
         if (!nsel) continue;
-        stats::counter(fp ? stats::NTT2_FP_LAUNCHES : stats::NTT2_INT_LAUNCHES)++;
+        stats::counter(fp ? stats::NTT2_FP_LAUNCHES : stats::NTT2_INT_LAUNCHES).fetch_add(1, std::memory_order_relaxed);
         unsigned mask1 = 0, mask2 = 0;
         if (fp) {
             u64 pmax = 0;

@@ -7,6 +7,7 @@
 // (troy_amd/capi.py refuses it) -- it is not a fallback path.
 #pragma once
 
+#include <atomic>
 #include <cstddef>
 #include <cstdint>
 #include <stdexcept>
@@ -44,7 +45,7 @@ namespace troyhip {
 // the FP64 instances cannot pass on the integer kernels (or the other way round) without saying so.
 namespace stats {
 enum { KS_FP_LAUNCHES, KS_INT_LAUNCHES, NTT1_FP_LAUNCHES, NTT1_INT_LAUNCHES, NTT2_FP_LAUNCHES, NTT2_INT_LAUNCHES, COUNT };
-inline uint64_t &counter(int i) { static uint64_t c[COUNT] = {}; return c[i]; }
+inline std::atomic<uint64_t> &counter(int i) { static std::atomic<uint64_t> c[COUNT]; return c[i]; } // host threads launch concurrently (one context per thread)
 inline const char *name(int i) { static const char *n[COUNT] = {"ks_fp_launches", "ks_int_launches", "ntt1_fp_launches", "ntt1_int_launches", "ntt2_fp_launches", "ntt2_int_launches"}; return n[i]; }
 }
 
