@@ -1094,9 +1094,17 @@ public:
         grow(a, a.size() + b.size() - 1);
         check(troyhip_multiply(h(), a.raw(), b.raw(), a.raw(), 1, nullptr));
     }
-    void multiply(const Ciphertext &a, const Ciphertext &b, Ciphertext &d) const { d = a; multiplyInplace(d, b); }
+    // the destination forms write a fresh ciphertext: the operands are read where they lie (the reference copies, then multiplies in place)
+    void multiply(const Ciphertext &a, const Ciphertext &b, Ciphertext &d) const {
+        if (&d == &a) { multiplyInplace(d, b); return; }
+        Ciphertext out;
+        out.resize(a.polyModulusDegree(), a.coeffModulusSize(), a.size() + b.size() - 1);
+        check(troyhip_multiply(h(), a.raw(), b.raw(), out.raw(), 1, nullptr));
+        out.bind(a);
+        d = std::move(out);
+    }
     void squareInplace(Ciphertext &a) const { multiplyInplace(a, a); }
-    void square(const Ciphertext &a, Ciphertext &d) const { d = a; squareInplace(d); }
+    void square(const Ciphertext &a, Ciphertext &d) const { multiply(a, a, d); }
     void relinearizeInplace(Ciphertext &a, const RelinKeys &k) const { // to size 2 from any size <= 16 (src/evaluator_cuda.cu:703-744)
         const size_t need = a.size() > 2 ? a.size() - 2 : 0;
         std::vector<const uint64_t *> keys(need ? need : 1, nullptr);

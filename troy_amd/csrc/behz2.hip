@@ -571,15 +571,19 @@ template <int KB1, int KB2, bool FAST2> __global__ __launch_bounds__(B2_THREADS)
     }
 }
 
-static unsigned b2_tiles_per_wg(u64 tiles) { return tiles >= 64 ? B2_TPW : 1; }
-// small-base kernels: a wave takes 32 columns per step, so the per-workgroup setup (fragments, per-lane constants) wants more steps
-static unsigned b2s_tiles_per_wg(u64 tiles) { return tiles >= 64 ? 16u : (tiles >= 16 ? (unsigned)(tiles / 4) : 1u); } // 8 / 16 / 32 / 64 at N = 8192: 389 / 352 / 347 / 390 us
+// tiles a workgroup walks (fragments and per-lane constants are set up once per workgroup); small launches -- a few polynomials -- take fewer, so that
+// the grid still covers the chip (plan_per_workgroup, kernels.h)
+static unsigned b2_tiles_per_wg(u64 tiles, u64 polys) { return plan_per_workgroup(tiles, tiles >= 64 ? B2_TPW : 1, polys); }
+// small-base kernels: a wave takes 32 columns per step, so the per-workgroup setup wants more steps
+static unsigned b2s_tiles_per_wg(u64 tiles, u64 polys) { // 8 / 16 / 32 / 64 at N = 8192 and a large batch: 389 / 352 / 347 / 390 us
+    return plan_per_workgroup(tiles, tiles >= 64 ? 16u : (tiles >= 16 ? (unsigned)(tiles / 4) : 1u), polys);
+}
 
 void launch_behz2_extend(const u64 *in, u64 in_pstride, u64 *out, u64 out_pstride, const PrimeDesc *primes, const BehzDev &c, u64 N, u64 polys, hipStream_t s) {
     const int kb = (c.L + 1 + 3) / 4;
     const bool small = c.f1s_frag && kb <= 2 && c.nBsk <= 8; // everything-in-registers form
     const u64 tiles = ceil_div(N, (u64)(small ? B2S_TILE : B2_TILE));
-    const unsigned tpw = small ? b2s_tiles_per_wg(tiles) : b2_tiles_per_wg(tiles);
+    const unsigned tpw = small ? b2s_tiles_per_wg(tiles, polys) : b2_tiles_per_wg(tiles, polys);
     for (u64 p0 = 0; p0 < polys; p0 += 65535) { // gridDim.y limit
         const u64 np = polys - p0 < 65535 ? polys - p0 : 65535;
         const dim3 grid((unsigned)ceil_div(tiles, (u64)tpw), (unsigned)np);
@@ -612,7 +616,7 @@ void launch_behz2_floor_sk(const u64 *dq, u64 dq_pstride, const u64 *db, u64 db_
     const int kb1 = (c.L + 3) / 4, kb2 = (c.nB + 1 + 3) / 4; // kb2 is kb1 or kb1 + 1 (nB is L or L + 1)
     const bool small = c.f1s_frag && kb2 <= 2;
     const u64 tiles = ceil_div(N, (u64)(small ? B2S_TILE : B2_TILE));
-    const unsigned tpw = small ? b2s_tiles_per_wg(tiles) : b2_tiles_per_wg(tiles);
+    const unsigned tpw = small ? b2s_tiles_per_wg(tiles, polys) : b2_tiles_per_wg(tiles, polys);
     for (u64 p0 = 0; p0 < polys; p0 += 65535) {
         const u64 np = polys - p0 < 65535 ? polys - p0 : 65535;
         const dim3 grid((unsigned)ceil_div(tiles, (u64)tpw), (unsigned)np);

@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 
 namespace troyhip {
 
@@ -172,6 +173,9 @@ void Evaluator::multiply(const CtBatch &a, const CtBatch &b, CtBatch &out, u64 b
     double new_scale = a.scale;
     u64 new_cf = a.cf;
     const bool same = (a.data == b.data && a.bstride == b.bstride && sa == sb);
+    // a batch of ONE has no stride: whatever capacity the ciphertext's allocation has (the host mirrors keep room for three polynomials), its
+    // polynomials are dense -- the single-ciphertext calls of the reference's interface take the fused, copy-free paths too
+    auto dense = [&](u64 bstride, u64 words) { return batch == 1 || bstride == words; };
 
     if (c.scheme == SCHEME_BFV) {
         if (a.ntt || b.ntt) throw Error(ST_INVALID_ARGUMENT, "encrypted1 or encrypted2 cannot be in NTT form");
@@ -183,7 +187,8 @@ void Evaluator::multiply(const CtBatch &a, const CtBatch &b, CtBatch &out, u64 b
         u64 *dq = c.arena.take(batch * ds * pw), *db = c.arena.take(batch * ds * bw);
         // BEHZ steps (1)-(3): extend q -> Bsk, forward NTT in both bases
         const LimbMap bmap = c.ids_map(lv.bsk_ids);
-        if (a.bstride == (u64)sa * pw && b.bstride == (u64)sb * pw) {
+        bool inverse_done = false;
+        if (dense(a.bstride, (u64)sa * pw) && dense(b.bstride, (u64)sb * pw)) {
             // dense operands are consumed in place: the extension reads them directly and the first NTT pass reads them
             // as its out-of-place source, so no staging copy is made.  Scratch layout: [a-part | b-part] in each base.
             // squaring (same operand twice): extended and transformed once, the tensor reads it as both factors
@@ -194,8 +199,20 @@ void Evaluator::multiply(const CtBatch &a, const CtBatch &b, CtBatch &out, u64 b
             if (!once) launch_behz_extend(b.data, pw, xb_b, bw, c.d_desc, *lv.behz, N, batch * sb, s);
             if (fused) {
                 // (3)+(4) in one pass pair per base: the second NTT pass keeps a0, a1, b0, b1 in registers and stores d0, d1, d2
-                launch_ntt2_tensor(xq_a, a.data, xq_b, b.data, dq, c.d_desc, qmap, batch, c.logn, s);
-                launch_ntt2_tensor(xb_a, nullptr, xb_b, nullptr, db, c.d_desc, bmap, batch, c.logn, s);
+                if (c.small_launch(batch * sp * (u64)(L + nb))) {
+                    // one ciphertext (or a few): steps (3)-(5) of the two bases are independent chains of small kernels -- side by side on two streams
+                    const PrimeDesc *idesc = behz_floor_prescaled(*lv.behz) ? lv.behz->floor_desc : c.d_desc;
+                    hipStream_t side = c.fork(s);
+                    launch_ntt2_tensor(xb_a, nullptr, xb_b, nullptr, db, c.d_desc, bmap, batch, c.logn, side);
+                    launch_ntt(db, idesc, bmap, batch * ds * nb, c.logn, true, side);
+                    launch_ntt2_tensor(xq_a, a.data, xq_b, b.data, dq, c.d_desc, qmap, batch, c.logn, s);
+                    launch_ntt(dq, idesc, qmap, batch * ds * L, c.logn, true, s);
+                    c.join(s);
+                    inverse_done = true;
+                } else {
+                    launch_ntt2_tensor(xq_a, a.data, xq_b, b.data, dq, c.d_desc, qmap, batch, c.logn, s);
+                    launch_ntt2_tensor(xb_a, nullptr, xb_b, nullptr, db, c.d_desc, bmap, batch, c.logn, s);
+                }
             } else {
                 launch_ntt_from(xq_a, a.data, c.d_desc, qmap, batch * sa * L, c.logn, s);
                 launch_ntt_from(xq_b, b.data, c.d_desc, qmap, batch * sb * L, c.logn, s);
@@ -215,11 +232,13 @@ void Evaluator::multiply(const CtBatch &a, const CtBatch &b, CtBatch &out, u64 b
             launch_tensor(sa, sb, xb, xb + sa * bw, db, sp * bw, sp * bw, c.d_desc, bmap, c.logn, nb, batch, s);
         }
         // (5) inverse NTT; when the floor kernel takes pre-scaled inputs, the factors of step (6) ride on the N^-1 constants
-        const PrimeDesc *idesc = behz_floor_prescaled(*lv.behz) ? lv.behz->floor_desc : c.d_desc;
-        launch_ntt(dq, idesc, qmap, batch * ds * L, c.logn, true, s);
-        launch_ntt(db, idesc, c.ids_map(lv.bsk_ids), batch * ds * nb, c.logn, true, s);
+        if (!inverse_done) {
+            const PrimeDesc *idesc = behz_floor_prescaled(*lv.behz) ? lv.behz->floor_desc : c.d_desc;
+            launch_ntt(dq, idesc, qmap, batch * ds * L, c.logn, true, s);
+            launch_ntt(db, idesc, c.ids_map(lv.bsk_ids), batch * ds * nb, c.logn, true, s);
+        }
         // (6)-(8) multiply by t, floor, Shenoy-Kumaresan back to base q
-        if (out.bstride == (u64)ds * pw) {
+        if (dense(out.bstride, (u64)ds * pw)) {
             launch_behz_floor_sk(dq, pw, db, bw, out.data, pw, c.d_desc, *lv.behz, N, batch * ds, s);
         } else {
             u64 *res = xq; // xq is dead by now and large enough (sp >= ds)
@@ -230,7 +249,7 @@ void Evaluator::multiply(const CtBatch &a, const CtBatch &b, CtBatch &out, u64 b
         if (!(a.ntt && b.ntt)) throw Error(ST_INVALID_ARGUMENT, "encrypted1 or encrypted2 must be in NTT form");
         new_scale = a.scale * b.scale;
         if (!scale_ok(new_scale, L)) throw Error(ST_INVALID_ARGUMENT, "scale out of bounds");
-        if (out.data != a.data && out.data != b.data && out.bstride == (u64)ds * pw) {
+        if (out.data != a.data && out.data != b.data && dense(out.bstride, (u64)ds * pw)) {
             // a fresh dense destination: the tensor writes it directly
             launch_tensor(sa, sb, a.data, b.data, out.data, a.bstride, b.bstride, c.d_desc, qmap, c.logn, L, batch, s);
         } else {
@@ -243,9 +262,9 @@ void Evaluator::multiply(const CtBatch &a, const CtBatch &b, CtBatch &out, u64 b
         // BGV (evaluator_cuda.cu:463-500): NTT -> tensor -> INTT.  Dense size-2 operands go through the fused transform + tensor
         // pass pair (consumed in place, like the q base of the BFV path); a fresh dense destination is written directly.
         const int sp = sa + sb;
-        const bool direct_out = out.data != a.data && out.data != b.data && out.bstride == (u64)ds * pw;
+        const bool direct_out = out.data != a.data && out.data != b.data && dense(out.bstride, (u64)ds * pw);
         u64 *d = direct_out ? out.data : c.arena.take(batch * ds * pw);
-        if (a.bstride == (u64)sa * pw && b.bstride == (u64)sb * pw && sa == 2 && sb == 2 && ntt2_tensor_supported(c.logn) && tensor_fused()) {
+        if (dense(a.bstride, (u64)sa * pw) && dense(b.bstride, (u64)sb * pw) && sa == 2 && sb == 2 && ntt2_tensor_supported(c.logn) && tensor_fused()) {
             u64 *xa = c.arena.take(batch * sa * pw), *xb = same ? xa : c.arena.take(batch * sb * pw);
             launch_ntt2_tensor(xa, a.data, xb, b.data, d, c.d_desc, qmap, batch, c.logn, s);
         } else {
@@ -392,17 +411,22 @@ void Evaluator::switch_key(CtBatch &ct, const u64 *target, u64 t_bstride, const 
             launch_ntt1(acc, nullptr, c.d_desc_md, amap, batch * 2 * rl, true, s, (u64(1) << dl) - 1, &md);
         } else if (md_two_pass) {
             // two-pass inverse, same shape: the special limb first, then the data limbs with the mod-down (BFV or BGV) as the last pass's epilogue
-            launch_ntt2_slots(acc, nullptr, 0, false, c.d_desc, amap, batch * 2 * rl, c.logn, true, s, false, 0, (unsigned)dl, 1, nullptr);
+            // a small launch brings the special limb to coefficient form (and forms the BGV shares) on the companion stream, beside the first pass of
+            // the data limbs, which does not need it yet: the streams meet in front of the pass that carries the mod-down
+            const bool side_by_side = c.small_launch(batch * 2 * rl);
+            hipStream_t sp_stream = side_by_side ? c.fork(s) : s;
+            launch_ntt2_slots(acc, nullptr, 0, false, c.d_desc, amap, batch * 2 * rl, c.logn, true, sp_stream, false, 0, (unsigned)dl, 1, nullptr);
             u64 *share = nullptr;
             if (c.scheme == SCHEME_BGV) { // what the special limb takes out of every data limb, once per coefficient (the CKKS part of the reservation is free)
                 share = c.arena.take(batch * 4 * N);
-                launch_ks_bgv_share(acc, share, a, s);
+                launch_ks_bgv_share(acc, share, a, sp_stream);
             }
             Ntt2ModDown md{c.scheme == SCHEME_BFV ? 0 : 2, ct.data, ct.bstride, (unsigned)dl, qk, a.half, share};
             md.base = base;
             md.base_bstride = base_bstride;
             md.base_polys = base_polys;
-            launch_ntt2_slots(acc, nullptr, 0, false, c.d_desc_md, amap, batch * 2 * rl, c.logn, true, s, false, 0, 0, (unsigned)dl, &md);
+            const std::function<void()> meet = [&]() { c.join(s); };
+            launch_ntt2_slots(acc, nullptr, 0, false, c.d_desc_md, amap, batch * 2 * rl, c.logn, true, s, false, 0, 0, (unsigned)dl, &md, side_by_side ? &meet : nullptr);
         } else {
             launch_ntt(acc, c.d_desc, amap, batch * 2 * rl, c.logn, true, s);
             launch_ks_moddown(c.scheme == SCHEME_BFV ? 0 : 2, acc, ct.data, ct.bstride, a, s);
@@ -481,7 +505,7 @@ void Evaluator::mod_switch_scale(const CtBatch &in, CtBatch &out, u64 batch, hip
     a.logn = c.logn; a.limbs = L; a.polys = batch * in.size;
 
     c.arena.begin(s);
-    const bool dense_in = in.bstride == (u64)in.size * pw, dense_out = out.bstride == (u64)in.size * npw;
+    const bool dense_in = batch == 1 || in.bstride == (u64)in.size * pw, dense_out = batch == 1 || out.bstride == (u64)in.size * npw; // one item has no stride
     {   // everything this op carves, reserved up front: take() can only grow an EMPTY arena (a rescale as the first op on a fresh
         // context, or at a larger batch than the ops before it, used to fail with "scratch arena exhausted inside an op")
         size_t need = 4 * 32;

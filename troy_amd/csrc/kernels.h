@@ -1,8 +1,20 @@
 // kernels.h -- launch interface of the gfx950 kernels (ntt.hip, poly.hip, behz.hip).
 #pragma once
 #include "device_types.h"
+#include <functional>
 
 namespace troyhip {
+
+// compute units of the current device (256 on MI355X), read once.  The launchers size their per-workgroup loops by it: a loop over many rows / tiles
+// per workgroup amortises twiddles and fragments when the launch is large, and starves the chip when it is small (a single ciphertext).
+unsigned device_cus();
+// the largest per-workgroup count <= cap (halving) that still leaves about four workgroups per compute unit; `groups` = workgroups per unit of count 1
+inline unsigned plan_per_workgroup(size_t units, unsigned cap, size_t groups) {
+    const size_t want = 4 * (size_t)device_cus();
+    unsigned r = cap ? cap : 1;
+    while (r > 1 && ((units + r - 1) / r) * groups < want) r = (r + 1) / 2;
+    return r;
+}
 
 // ---- ntt.hip ----
 void launch_ntt(u64 *data, const PrimeDesc *primes, const LimbMap &map, size_t rows, int logn, bool inverse, hipStream_t stream);
@@ -27,8 +39,11 @@ bool ntt2_supported(int logn);
 // base != nullptr: the ciphertext being accumulated into is (base, 0), i.e. ct[b][0] = base[b] + ..., ct[b][1] = ... (rotations: base = sigma(c0) in a
 // temporary; spares the copy into ct[b][0] and the zero fill of ct[b][1])
 struct Ntt2ModDown { int kind; u64 *ct; u64 ct_bstride; unsigned dl; u64 qk, half; const u64 *share; const u64 *base = nullptr; u64 base_bstride = 0; int base_polys = 1; };
+// before_last_pass (inverse): called once, after the first pass of the launch has been issued and before the pass that carries the epilogue (the
+// evaluator joins the stream on which the special limb was prepared there)
 void launch_ntt2_slots(u64 *data, const u64 *src, u64 src_ostride, bool src_reduce, const PrimeDesc *primes, const LimbMap &map, size_t rows, int logn,
-                       bool inverse, hipStream_t stream, bool src_same_layout, u64 src_bound, unsigned slot_begin, unsigned slot_count, const Ntt2ModDown *md);
+                       bool inverse, hipStream_t stream, bool src_same_layout, u64 src_bound, unsigned slot_begin, unsigned slot_count, const Ntt2ModDown *md,
+                       const std::function<void()> *before_last_pass = nullptr);
 void launch_ntt2(u64 *data, const u64 *src, u64 src_ostride, bool src_reduce, const PrimeDesc *primes, const LimbMap &map, size_t rows, int logn,
                  bool inverse, hipStream_t stream, bool src_same_layout = false, u64 src_bound = 0);
 

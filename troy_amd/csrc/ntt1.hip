@@ -782,7 +782,7 @@ template <bool MD> __global__ __launch_bounds__(N1_THREADS) void ntt1_inv_fp_ker
 
 // ---- host side ----
 
-static unsigned ntt1_cus() {
+unsigned device_cus() {
     static const unsigned cus = [] {
         int dev = 0, n = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
@@ -803,7 +803,7 @@ static int ntt1_mode() {
 }
 bool ntt1_supported(int logn, const LimbMap &map, size_t rows) {
     if (ntt1_mode() == 1 || logn != N1_LOGN || !rows || rows % ((size_t)map.period * map.inner)) return false;
-    return ntt1_mode() == 2 || rows >= 4 * (size_t)ntt1_cus();
+    return ntt1_mode() == 2 || rows >= 4 * (size_t)device_cus();
 }
 // rows laid out r = (o * period + i) * inner + k, prime map.id[i].  The forward transform is launched once per prime class:
 // guard-free butterflies for the slots in map.lean, guarded ones for the rest.
@@ -834,7 +834,7 @@ void launch_ntt1(u64 *data, const u64 *src, const PrimeDesc *primes, const LimbM
     // the un-overlapped first load and last store, about a third of a row): pick the rows per workgroup (they share the prime) that
     // minimises rounds x (rows + 1/3), with a small penalty for spreading the CUs over many primes at once.  A fixed "three workgroups
     // per CU" left mid-size launches with a mostly idle last round.
-    const unsigned cus = ntt1_cus();
+    const unsigned cus = device_cus();
     static const unsigned forced_rpw = [] { const char *e = std::getenv("TROYHIP_NTT1_RPW"); return e ? (unsigned)std::atoi(e) : 0u; }(); // tests: row loop at small batches
     auto plan = [&](unsigned nslots) { // -> rows per workgroup for a launch over `nslots` primes
         if (forced_rpw) return forced_rpw;

@@ -1056,8 +1056,10 @@ void launch_ntt2(u64 *data, const u64 *src, u64 src_ostride, bool src_reduce, co
 // the key-switch mod-down instead of storing (Ntt2ModDown, kernels.h).  host_primes (the context's registry, indexed by map.id) switches the
 // FP64 instances on for the slots in map.fp: without it every slot takes the integer kernels.
 void launch_ntt2_slots(u64 *data, const u64 *src, u64 src_ostride, bool src_reduce, const PrimeDesc *primes, const LimbMap &map, size_t rows, int logn,
-                       bool inverse, hipStream_t stream, bool src_same_layout, u64 src_bound, unsigned slot_begin, unsigned slot_count, const Ntt2ModDown *md) {
+                       bool inverse, hipStream_t stream, bool src_same_layout, u64 src_bound, unsigned slot_begin, unsigned slot_count, const Ntt2ModDown *md,
+                       const std::function<void()> *before_last_pass) {
     const u64 *host_primes = map.host_primes;
+    bool met = false;
     if (rows == 0 || slot_count == 0) return;
     if (slot_begin + slot_count > map.period) throw Error(ST_INVALID_ARGUMENT, "ntt2: slot range");
     const bool partial = slot_begin != 0 || slot_count != map.period;
@@ -1079,7 +1081,11 @@ void launch_ntt2_slots(u64 *data, const u64 *src, u64 src_ostride, bool src_redu
     a.logn = logn;
     a.tiles_per_row_log = (unsigned)(logn - N2_LOGT);
     a.m_total = (unsigned)(rows / per_outer * map.inner);
+    // rows per workgroup (they share the prime: twiddles loaded once): up to 8, or the digits of one key-switch group -- fewer when the launch is
+    // small, so that a single ciphertext still spreads over the chip (B = 1: 224 workgroups of four rows each left three quarters of the SIMDs'
+    // wave slots empty; one row each is 896 workgroups)
     a.rows_per_wg = a.m_total < 8 ? a.m_total : (map.inner > 1 ? (map.inner <= 16 ? map.inner : 8) : 8);
+    a.rows_per_wg = plan_per_workgroup(a.m_total, a.rows_per_wg, (size_t)slot_count << a.tiles_per_row_log);
     a.chunks = (a.m_total + a.rows_per_wg - 1) / a.rows_per_wg;
     a.src_reduce = 0;
     a.src_same_layout = 0;
@@ -1139,6 +1145,7 @@ void launch_ntt2_slots(u64 *data, const u64 *src, u64 src_ostride, bool src_redu
             contig(std::integral_constant<int, 0>{}, second, true);
         } else {
             contig(std::integral_constant<int, 1>{}, first, false);
+            if (before_last_pass && !met) { (*before_last_pass)(); met = true; }
             strided(std::integral_constant<int, 1>{}, second, false);
         }
     }
@@ -1217,12 +1224,16 @@ void launch_ntt2_ks_mac(u64 *D, const u64 *src, u64 src_ostride, const PrimeDesc
         first.src = src; first.src_ostride = src_ostride; first.src_reduce = 1; first.src_bound = src_bound;
         first.slot_fastest = 1;
         first.skip_diag = skip_diag;
+        // the first pass need not keep the digits of a group in one workgroup (only the accumulating second pass does): small launches split them
+        first.rows_per_wg = plan_per_workgroup(a.m_total, a.rows_per_wg, (size_t)a.nsel << a.tiles_per_row_log);
+        first.chunks = (a.m_total + first.rows_per_wg - 1) / first.rows_per_wg;
+        const unsigned blocks1 = (unsigned)((a.nsel * first.chunks) << a.tiles_per_row_log);
         switch (k1) {
-        case 3: launch_ks_first<3>(first, blocks, fp, skip_diag, stream); break;
-        case 4: launch_ks_first<4>(first, blocks, fp, skip_diag, stream); break;
-        case 5: launch_ks_first<5>(first, blocks, fp, skip_diag, stream); break;
-        case 6: launch_ks_first<6>(first, blocks, fp, skip_diag, stream); break;
-        default: launch_ks_first<7>(first, blocks, fp, skip_diag, stream); break;
+        case 3: launch_ks_first<3>(first, blocks1, fp, skip_diag, stream); break;
+        case 4: launch_ks_first<4>(first, blocks1, fp, skip_diag, stream); break;
+        case 5: launch_ks_first<5>(first, blocks1, fp, skip_diag, stream); break;
+        case 6: launch_ks_first<6>(first, blocks1, fp, skip_diag, stream); break;
+        default: launch_ks_first<7>(first, blocks1, fp, skip_diag, stream); break;
         }
         Ntt2Args second = a;
         second.fp_red_mask = mask2;
@@ -1287,7 +1298,7 @@ void launch_ntt2_tensor(u64 *xa, const u64 *src_a, u64 *xb, const u64 *src_b, u6
             a.nsel = nsel;
             std::memcpy(a.sel, sel, sizeof(sel));
             a.fp_red_mask = mask1;
-            a.rows_per_wg = a.m_total < 8 ? a.m_total : 8;
+            a.rows_per_wg = plan_per_workgroup(a.m_total, a.m_total < 8 ? a.m_total : 8, (size_t)nsel << a.tiles_per_row_log);
             a.chunks = (a.m_total + a.rows_per_wg - 1) / a.rows_per_wg;
             if (src) { a.src = src; a.src_same_layout = 1; }
             const unsigned blocks = (unsigned)((nsel * a.chunks) << a.tiles_per_row_log);
