@@ -253,3 +253,31 @@ def test_emulated_single_pass_ntt_row_loop_and_prime_classes(oracle_lib, tmp_pat
         env = dict(os.environ, TROYHIP_NTT1_RPW=rpw, TROYHIP_NTT="single", TROYHIP_AUX_BASE="reference")
         out = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=900)
         assert out.returncode == 0 and "ok" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+
+
+def test_emulated_small_launch_forms_agree(tmp_path):
+    """The merged forms of small launches (evaluator.cpp: both BEHZ bases through one launch per step, one first pass over the special limb and the
+    data limbs of a mod-down) against the per-base kernels of the large batch, in child processes (TROYHIP_SMALL is read once): same limbs through
+    multiply, relinearize and a rotation -- BFV and BGV, one ciphertext and a batch, squaring included"""
+    import sys
+    script = tmp_path / "w.py"
+    script.write_text(
+        "import sys, os; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import numpy as np\n"
+        "from troy_amd import api, capi, synth\n"
+        "lib = capi.load(%r)\n"
+        "api.KernelProvider.initialize(0, _lib=lib)\n"
+        "import cases\n"
+        "out = [cases.mul_relin_hash(n, batch=b) for n in ('cfgA_bfv_n4096_k3', 'bgv_n4096_k3') for b in (1, 3)]\n"
+        "cfg = cases.CONFIGS['cfgA_bfv_n4096_k3']\n"
+        "be = cases.GpuBackend(cfg)\n"
+        "x = synth.uniform_ct(5, be.primes[:2], 2, 4096, 2)\n"
+        "c = api.Ciphertext.from_numpy(be.ctx, x)\n"
+        "out.append(cases.sha(be.ev.multiply(c, c).cpu()))\n"   # squaring: one operand, extended and transformed once
+        "print(' '.join(out))\n" % (ROOT, os.path.join(ROOT, 'tests'), EMUL))
+    got = {}
+    for mode in ("split", "merged"):
+        out = subprocess.run([sys.executable, str(script)], env=dict(os.environ, TROYHIP_SMALL=mode), capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+        got[mode] = out.stdout.split()[-5:]
+    assert got["split"] == got["merged"] and len(got["split"]) == 5

@@ -527,7 +527,8 @@ def test_behz_kernel_forms_agree(env, gpu, oracle_lib):
 
 
 @pytest.mark.parametrize("env", [{"TROYHIP_KS": "split"}, {"TROYHIP_TENSOR": "split"}, {"TROYHIP_BEHZ": "valu"}, {"TROYHIP_MODDOWN": "split"}, {"TROYHIP_FP64": "off"},
-                                 {"TROYHIP_AUX_BASE": "reference"}, {"TROYHIP_AUX_BASE": "reference", "TROYHIP_BEHZ": "valu"}])
+                                 {"TROYHIP_AUX_BASE": "reference"}, {"TROYHIP_AUX_BASE": "reference", "TROYHIP_BEHZ": "valu"},
+                                 {"TROYHIP_SMALL": "split"}, {"TROYHIP_SMALL": "merged"}, {"TROYHIP_SMALL": "merged", "TROYHIP_FP64": "off"}])
 def test_unfused_kernel_paths_agree(env, gpu):
     """the unfused key-switch inner product, the unfused tensor, the VALU BEHZ kernels and the element-wise BFV / BGV mod-down instead of
     the inverse transform's epilogue (environment switches, read once per process) give the same limbs as the default path, which the
@@ -547,7 +548,8 @@ def test_unfused_kernel_paths_agree(env, gpu):
 
 
 @pytest.mark.parametrize("env", [{"TROYHIP_NTT": "single"}, {"TROYHIP_NTT": "twopass"}, {"TROYHIP_BFLY": "guarded"}, {"TROYHIP_NTT": "single", "TROYHIP_BFLY": "guarded"}, {"TROYHIP_FP64": "off"}, {"TROYHIP_AUX_BASE": "reference"},
-                                 {"TROYHIP_NTT": "single", "TROYHIP_MODDOWN": "split"}, {"TROYHIP_NTT": "single", "TROYHIP_CORR": "split"}])
+                                 {"TROYHIP_NTT": "single", "TROYHIP_MODDOWN": "split"}, {"TROYHIP_NTT": "single", "TROYHIP_CORR": "split"},
+                                 {"TROYHIP_SMALL": "split"}, {"TROYHIP_SMALL": "merged"}])
 def test_ntt_forms_agree_at_headline_size(env, gpu):
     """N = 2^15: the single-pass transform forced at a small batch (by default it takes launches of four rows per CU and more), the
     two-pass transform forced, guarded butterflies instead of the guard-free ones, the BFV mod-down in its own kernel instead of in the

@@ -634,9 +634,15 @@ static bool behz_use_mfma() {
     return v;
 }
 bool behz_floor_prescaled(const BehzDev &c) { return c.v2 && c.floor_desc && behz_use_mfma(); }
-void launch_behz_extend(const u64 *in, u64 in_pstride, u64 *out, u64 out_pstride, const PrimeDesc *primes, const BehzDev &c, u64 N, u64 polys, hipStream_t s) {
+void launch_behz_extend(const u64 *in, u64 in_pstride, u64 *out, u64 out_pstride, const PrimeDesc *primes, const BehzDev &c, u64 N, u64 polys, hipStream_t s, const u64 *in2,
+                        u64 split) {
     if (!polys) return;
-    if (c.v2 && behz_use_mfma()) return launch_behz2_extend(in, in_pstride, out, out_pstride, primes, c, N, polys, s);
+    if (c.v2 && behz_use_mfma()) return launch_behz2_extend(in, in_pstride, out, out_pstride, primes, c, N, polys, s, in2, split);
+    if (in2) { // the other forms take one operand per launch
+        launch_behz_extend(in, in_pstride, out, out_pstride, primes, c, N, split, s);
+        launch_behz_extend(in2, in_pstride, out + split * out_pstride, out_pstride, primes, c, N, polys - split, s);
+        return;
+    }
     const bool mfma = c.ext_frag && behz_use_mfma();
     const u64 tiles = ceil_div(N, (u64)BEHZ_TILE);
     const unsigned tpw = tiles >= 64 ? BEHZ_TPW : 1; // amortise the A-fragment loads over several tiles when there are enough workgroups

@@ -122,13 +122,14 @@ __device__ __forceinline__ void b2_patch(MfmaFrag &f, const B2Patch w, u64 digit
 // in [polys][L][N] -> out [polys][nBsk][N].  A 256-thread workgroup walks `tiles_per_wg` tiles of 64 coefficients of one polynomial;
 // wave w converts limbs w, w+4, .. to digits (LDS, double-buffered: one barrier per tile), evaluates the m_tilde row for its own
 // lanes and owns row-block w = outputs 4w .. 4w+3: a lane finishes outputs 4w + half (accumulators 0-7) and 4w + 2 + half (8-15).
+// polynomials from `split` on are read from in2 (the second operand of a product: both go through one launch when it is small)
 template <int KB> __global__ __launch_bounds__(B2_THREADS) void behz2_extend_kernel(const u64 *in, u64 in_pstride, u64 *out, u64 out_pstride, const PrimeDesc *primes, BehzDev c,
-                                                                                   u64 N, unsigned tiles_per_wg) {
+                                                                                   u64 N, unsigned tiles_per_wg, const u64 *in2, unsigned split) {
     __shared__ __attribute__((aligned(16))) u64 ydig[2][2 * KB * B2_TILE * 2]; // [buffer][limb pair][coefficient] 16-byte units
     const unsigned lane = threadIdx.x & 63, half = lane >> 5, cl = lane & 31;
     const int w = B2_UNIFORM((int)(threadIdx.x >> 6));
     const u64 poly = blockIdx.y;
-    const BufRsrc rin = make_rsrc(in + poly * in_pstride, (u32)((u64)c.L * N * 8));
+    const BufRsrc rin = make_rsrc(poly < split ? in + poly * in_pstride : in2 + (poly - split) * in_pstride, (u32)((u64)c.L * N * 8));
     const BufRsrc rout = make_rsrc(out + poly * out_pstride, (u32)((u64)c.nBsk * N * 8));
     const u32 n32 = (u32)N;
     const bool owner = w < ((c.nBsk + 3) >> 2);
@@ -369,11 +370,11 @@ __device__ __forceinline__ u64 b2_other_half(u64 v) { return __shfl_xor(v, 32); 
 template <int KB> struct B2Limbs { u64 p[KB][2]; Shoup pre[KB][2]; u32 row[KB][2]; };
 
 template <int KB, int RB> __global__ __launch_bounds__(B2_THREADS) void behz2s_extend_kernel(const u64 *in, u64 in_pstride, u64 *out, u64 out_pstride, const PrimeDesc *primes,
-                                                                                            BehzDev c, u64 N, unsigned tiles_per_wg) {
+                                                                                            BehzDev c, u64 N, unsigned tiles_per_wg, const u64 *in2, unsigned split) {
     const unsigned lane = threadIdx.x & 63, half = lane >> 5, cl = lane & 31;
     const unsigned w = threadIdx.x >> 6;
     const u64 poly = blockIdx.y;
-    const BufRsrc rin = make_rsrc(in + poly * in_pstride, (u32)((u64)c.L * N * 8));
+    const BufRsrc rin = make_rsrc(poly < split ? in + poly * in_pstride : in2 + (poly - split) * in_pstride, (u32)((u64)c.L * N * 8));
     const BufRsrc rout = make_rsrc(out + poly * out_pstride, (u32)((u64)c.nBsk * N * 8));
     const u32 n32 = (u32)N;
     MfmaFrag af[RB][KB], am[KB];
@@ -579,7 +580,10 @@ static unsigned b2s_tiles_per_wg(u64 tiles, u64 polys) { // 8 / 16 / 32 / 64 at 
     return plan_per_workgroup(tiles, tiles >= 64 ? 16u : (tiles >= 16 ? (unsigned)(tiles / 4) : 1u), polys);
 }
 
-void launch_behz2_extend(const u64 *in, u64 in_pstride, u64 *out, u64 out_pstride, const PrimeDesc *primes, const BehzDev &c, u64 N, u64 polys, hipStream_t s) {
+void launch_behz2_extend(const u64 *in, u64 in_pstride, u64 *out, u64 out_pstride, const PrimeDesc *primes, const BehzDev &c, u64 N, u64 polys, hipStream_t s, const u64 *in2,
+                         u64 split) {
+    if (!in2) split = polys;
+    if (in2 && polys > 65535) throw Error(ST_LOGIC_ERROR, "behz2 extend: the two-operand form is for small launches");
     const int kb = (c.L + 1 + 3) / 4;
     const bool small = c.f1s_frag && kb <= 2 && c.nBsk <= 8; // everything-in-registers form
     const u64 tiles = ceil_div(N, (u64)(small ? B2S_TILE : B2_TILE));
@@ -589,7 +593,8 @@ void launch_behz2_extend(const u64 *in, u64 in_pstride, u64 *out, u64 out_pstrid
         const dim3 grid((unsigned)ceil_div(tiles, (u64)tpw), (unsigned)np);
         const u64 *pi = in + p0 * in_pstride;
         u64 *po = out + p0 * out_pstride;
-#define B2S_EXT(KB_, RB_) TROY_LAUNCH(HIP_KERNEL_NAME(behz2s_extend_kernel<KB_, RB_>), grid, dim3(B2_THREADS), 0, s, pi, in_pstride, po, out_pstride, primes, c, N, tpw)
+        const unsigned sp = (unsigned)(split > p0 ? (split - p0 < 65535 ? split - p0 : 65535) : 0); // polynomials of this slice that come from `in`
+#define B2S_EXT(KB_, RB_) TROY_LAUNCH(HIP_KERNEL_NAME(behz2s_extend_kernel<KB_, RB_>), grid, dim3(B2_THREADS), 0, s, pi, in_pstride, po, out_pstride, primes, c, N, tpw, in2, sp)
         if (small) {
             const int rb = (c.nBsk + 3) / 4;
             if (kb == 1 && rb == 1) B2S_EXT(1, 1);
@@ -598,7 +603,7 @@ void launch_behz2_extend(const u64 *in, u64 in_pstride, u64 *out, u64 out_pstrid
             continue;
         }
 #undef B2S_EXT
-#define B2_EXT(KB_) TROY_LAUNCH(HIP_KERNEL_NAME(behz2_extend_kernel<KB_>), grid, dim3(B2_THREADS), 0, s, pi, in_pstride, po, out_pstride, primes, c, N, tpw)
+#define B2_EXT(KB_) TROY_LAUNCH(HIP_KERNEL_NAME(behz2_extend_kernel<KB_>), grid, dim3(B2_THREADS), 0, s, pi, in_pstride, po, out_pstride, primes, c, N, tpw, in2, sp)
         switch (kb) {
         case 1: B2_EXT(1); break;
         case 2: B2_EXT(2); break;

@@ -212,6 +212,10 @@ struct DevicePool {
         if (it == live.end()) { (void)hipFree(p); return; } // not ours (defensive)
         Block b{p, {}};
 #ifndef TROYHIP_CPU_EMUL
+        // With no stream registered the library knows ONE stream, the default one: whoever gets the block next uses it on that same stream, behind
+        // everything that still touches it -- stream order is the whole guarantee, no free-point event is needed (an event record is a barrier packet
+        // in the queue: 3-6 us between the kernels of consecutive operations, visible at one ciphertext per call).
+        if (streams.empty()) { free_blocks.emplace(it->second, std::move(b)); live.erase(it); return; }
         // a registered stream that was destroyed without troyhip_stream_unregister must not break free() for good: its record fails, the stream is
         // dropped from the list (nothing can be running on it any more) and the block is cached all the same
         for (size_t i = 0; i <= streams.size();) {
@@ -244,7 +248,17 @@ struct DevicePool {
     void release() { std::lock_guard<std::mutex> g(mu); release_locked(); }
     void add_stream(hipStream_t s) {
         std::lock_guard<std::mutex> g(mu);
-        if (s && std::find(streams.begin(), streams.end(), s) == streams.end()) streams.push_back(s);
+        if (!s || std::find(streams.begin(), streams.end(), s) != streams.end()) return;
+#ifndef TROYHIP_CPU_EMUL
+        if (streams.empty()) { // blocks cached so far carry no free-point event (put): from now on another stream may get them, so they wait for the default stream's work up to here
+            for (auto &kv : free_blocks) {
+                hipEvent_t e = new_event();
+                if (hipEventRecord(e, nullptr) != hipSuccess) { (void)hipGetLastError(); spare_events.push_back(e); (void)hipDeviceSynchronize(); break; }
+                kv.second.pending.emplace_back((hipStream_t) nullptr, e);
+            }
+        }
+#endif
+        streams.push_back(s);
     }
     void remove_stream(hipStream_t s) { // the caller has synchronised `s`: exactly its free-point events are complete, and they go with it
         std::lock_guard<std::mutex> g(mu);

@@ -211,32 +211,13 @@ Context::Context(int scheme_, u64 N_, const std::vector<u64> &key_primes, u64 t_
     if (has_device) upload_tables();
 }
 
-// TROYHIP_FORK=off: small operations stay on the caller's stream alone (tests / A-B runs of the companion stream)
-static bool fork_allowed() {
-    static const bool on = [] { const char *e = std::getenv("TROYHIP_FORK"); return !(e && std::strcmp(e, "off") == 0); }();
-    return on;
-}
-bool Context::small_launch(u64 rows) const {
-    // a limb row is N / 2048 workgroup tiles of the two-pass kernels; below about four workgroups per compute unit a kernel cannot hide its own latencies
-    return fork_allowed() && has_device && ((rows * N) >> 11) < 4 * (u64)device_cus();
-}
-hipStream_t Context::fork(hipStream_t s) {
-    if (!side_) {
-        HIP_CHECK(hipStreamCreateWithFlags(&side_, hipStreamNonBlocking));
-        HIP_CHECK(hipEventCreateWithFlags(&side_fork_, hipEventDisableTiming));
-        HIP_CHECK(hipEventCreateWithFlags(&side_join_, hipEventDisableTiming));
-    }
-    HIP_CHECK(hipEventRecord(side_fork_, s));
-    HIP_CHECK(hipStreamWaitEvent(side_, side_fork_, 0));
-    return side_;
-}
-void Context::join(hipStream_t s) {
-    HIP_CHECK(hipEventRecord(side_join_, side_));
-    HIP_CHECK(hipStreamWaitEvent(s, side_join_, 0));
-}
+// A launch of `rows` limb rows is SMALL when it leaves the chip mostly idle: a limb row is N / 2048 workgroup tiles of the two-pass kernels, and below about
+// eight workgroups per compute unit a kernel is bound by the latency of its own dependency chain.  Small operations take the merged forms (one launch over
+// the q-base and the B_sk-base rows, evaluator.cpp).  Measured and NOT kept for them: the two bases side by side on a companion stream -- a cross-stream
+// event wait costs 8-12 us on this runtime, more than the 15 us kernels it would overlap (B = 1: 0.256 -> 0.279 ms, profiles/r04_small_batch.txt).
+bool Context::small_launch(u64 rows) const { return has_device && ((rows * N) >> 11) < 8 * (u64)device_cus(); }
 
 Context::~Context() {
-    if (side_) { (void)hipStreamSynchronize(side_); (void)hipStreamDestroy(side_); (void)hipEventDestroy(side_fork_); (void)hipEventDestroy(side_join_); }
     for (void *p : dev_allocs_) (void)hipFree(p);
     for (auto &kv : levels) for (void *p : kv.second.dev_blocks) (void)hipFree(p);
 }

@@ -79,13 +79,7 @@ public:
     std::map<int, Level> levels; // by limb count, K .. last_limbs
     Arena arena;
 
-    // A SMALL operation (one ciphertext: every kernel a fraction of the chip, bound by the latency of its own dependency chain) runs its independent
-    // halves -- the q-base and the B_sk-base transforms of a BEHZ product, the special limb and the data limbs of a mod-down -- side by side: fork()
-    // returns a companion stream that starts after everything issued so far on `s`; join() makes `s` continue after everything issued on it.
-    // The caller sees one stream: nothing outlives the operation on the companion.  Large launches fill the chip alone and never fork.
-    hipStream_t fork(hipStream_t s);
-    void join(hipStream_t s);
-    bool small_launch(u64 rows) const; // would `rows` limb rows leave most of the chip idle?
+    bool small_launch(u64 rows) const; // would `rows` limb rows leave most of the chip idle?  (one ciphertext, a few small ones)
 
     const Level &level(int limbs) const;
     bool has_level(int limbs) const { return levels.count(limbs) != 0; }
@@ -100,8 +94,6 @@ private:
     void upload_tables();
     void build_level(int limbs);
     std::vector<void *> dev_allocs_;
-    hipStream_t side_ = nullptr;
-    hipEvent_t side_fork_ = nullptr, side_join_ = nullptr;
     template <class T> T *upload(const std::vector<T> &v, std::vector<void *> &owner);
 };
 

@@ -5,7 +5,6 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
-#include <functional>
 
 namespace troyhip {
 
@@ -30,6 +29,13 @@ static bool ks_moddown_fused() {
 static bool corr_fused() {
     static const bool v = [] { const char *e = getenv("TROYHIP_CORR"); return !(e && e[0] == 's'); }();
     return v;
+}
+// Small launches (Context::small_launch: one ciphertext, a few small ones) take merged forms: one launch over the q-base and the B_sk-base rows of a
+// product, one first pass over the special limb and the data limbs of a mod-down.  TROYHIP_SMALL=split keeps them on the kernels of the large batch,
+// TROYHIP_SMALL=merged uses the merged forms at every size (tests, measurements); read once
+static bool take_merged(const Context &c, u64 rows) {
+    static const int mode = [] { const char *e = getenv("TROYHIP_SMALL"); return !e ? 0 : (e[0] == 's' ? 1 : (e[0] == 'm' ? 2 : 0)); }();
+    return mode == 2 || (mode == 0 && c.small_launch(rows));
 }
 static bool primes_at_least_33_bits(const Context &c, int limbs) { // what the lazy reductions of the fused epilogues (lite_reduce4) take
     for (int l = 0; l < limbs; l++)
@@ -187,8 +193,33 @@ void Evaluator::multiply(const CtBatch &a, const CtBatch &b, CtBatch &out, u64 b
         u64 *dq = c.arena.take(batch * ds * pw), *db = c.arena.take(batch * ds * bw);
         // BEHZ steps (1)-(3): extend q -> Bsk, forward NTT in both bases
         const LimbMap bmap = c.ids_map(lv.bsk_ids);
-        bool inverse_done = false;
-        if (dense(a.bstride, (u64)sa * pw) && dense(b.bstride, (u64)sb * pw)) {
+        // A SMALL product (one ciphertext, a few small ones) runs both bases through the same launches: the scratch holds q and B_sk limbs of a polynomial
+        // behind each other ([poly][L + |Bsk|][N]), the forward pass takes the q limbs from the operands and the B_sk limbs from the extension, and
+        // transform + tensor, the inverse transform and the floor step each see ONE row set -- 7 launches instead of 13, each twice as wide.
+        // The large batch keeps the per-base launches.
+        const bool merged = dense(a.bstride, (u64)sa * pw) && dense(b.bstride, (u64)sb * pw) && sa == 2 && sb == 2 && ntt2_tensor_supported(c.logn) && tensor_fused() &&
+                            L + nb <= 64 && take_merged(c, batch * sp * (u64)(L + nb));
+        bool all_done = false;
+        if (merged) {
+            const u64 mw = (u64)(L + nb) * N; // words of one polynomial in both bases
+            std::vector<uint8_t> ids;
+            for (int l = 0; l < L; l++) ids.push_back((uint8_t)l);
+            ids.insert(ids.end(), lv.bsk_ids.begin(), lv.bsk_ids.end());
+            const LimbMap mmap = c.ids_map(ids);
+            u64 *X = xq, *D = dq; // the arena carved xq | xb | dq | db back to back: X spans the first two, D the last two
+            u64 *X_b = same ? X : X + batch * sa * mw;
+            if (same || batch * sp > 65535) {
+                launch_behz_extend(a.data, pw, X + (u64)L * N, mw, c.d_desc, *lv.behz, N, batch * sa, s);
+                if (!same) launch_behz_extend(b.data, pw, X_b + (u64)L * N, mw, c.d_desc, *lv.behz, N, batch * sb, s);
+            } else launch_behz_extend(a.data, pw, X + (u64)L * N, mw, c.d_desc, *lv.behz, N, batch * sp, s, b.data, batch * sa); // both operands: X_b follows X
+            launch_ntt2_tensor(X, a.data, X_b, b.data, D, c.d_desc, mmap, batch, c.logn, s, (unsigned)L);
+            const PrimeDesc *idesc = behz_floor_prescaled(*lv.behz) ? lv.behz->floor_desc : c.d_desc;
+            launch_ntt(D, idesc, mmap, batch * ds * (u64)(L + nb), c.logn, true, s);
+            u64 *res = dense(out.bstride, (u64)ds * pw) ? out.data : X; // X is dead by now and large enough
+            launch_behz_floor_sk(D, mw, D + (u64)L * N, mw, res, pw, c.d_desc, *lv.behz, N, batch * ds, s);
+            if (res != out.data) launch_copy_strided(res, ds * pw, out.data, out.bstride, ds * pw, batch, s);
+            all_done = true;
+        } else if (dense(a.bstride, (u64)sa * pw) && dense(b.bstride, (u64)sb * pw)) {
             // dense operands are consumed in place: the extension reads them directly and the first NTT pass reads them
             // as its out-of-place source, so no staging copy is made.  Scratch layout: [a-part | b-part] in each base.
             // squaring (same operand twice): extended and transformed once, the tensor reads it as both factors
@@ -199,20 +230,8 @@ void Evaluator::multiply(const CtBatch &a, const CtBatch &b, CtBatch &out, u64 b
             if (!once) launch_behz_extend(b.data, pw, xb_b, bw, c.d_desc, *lv.behz, N, batch * sb, s);
             if (fused) {
                 // (3)+(4) in one pass pair per base: the second NTT pass keeps a0, a1, b0, b1 in registers and stores d0, d1, d2
-                if (c.small_launch(batch * sp * (u64)(L + nb))) {
-                    // one ciphertext (or a few): steps (3)-(5) of the two bases are independent chains of small kernels -- side by side on two streams
-                    const PrimeDesc *idesc = behz_floor_prescaled(*lv.behz) ? lv.behz->floor_desc : c.d_desc;
-                    hipStream_t side = c.fork(s);
-                    launch_ntt2_tensor(xb_a, nullptr, xb_b, nullptr, db, c.d_desc, bmap, batch, c.logn, side);
-                    launch_ntt(db, idesc, bmap, batch * ds * nb, c.logn, true, side);
-                    launch_ntt2_tensor(xq_a, a.data, xq_b, b.data, dq, c.d_desc, qmap, batch, c.logn, s);
-                    launch_ntt(dq, idesc, qmap, batch * ds * L, c.logn, true, s);
-                    c.join(s);
-                    inverse_done = true;
-                } else {
-                    launch_ntt2_tensor(xq_a, a.data, xq_b, b.data, dq, c.d_desc, qmap, batch, c.logn, s);
-                    launch_ntt2_tensor(xb_a, nullptr, xb_b, nullptr, db, c.d_desc, bmap, batch, c.logn, s);
-                }
+                launch_ntt2_tensor(xq_a, a.data, xq_b, b.data, dq, c.d_desc, qmap, batch, c.logn, s);
+                launch_ntt2_tensor(xb_a, nullptr, xb_b, nullptr, db, c.d_desc, bmap, batch, c.logn, s);
             } else {
                 launch_ntt_from(xq_a, a.data, c.d_desc, qmap, batch * sa * L, c.logn, s);
                 launch_ntt_from(xq_b, b.data, c.d_desc, qmap, batch * sb * L, c.logn, s);
@@ -232,13 +251,14 @@ void Evaluator::multiply(const CtBatch &a, const CtBatch &b, CtBatch &out, u64 b
             launch_tensor(sa, sb, xb, xb + sa * bw, db, sp * bw, sp * bw, c.d_desc, bmap, c.logn, nb, batch, s);
         }
         // (5) inverse NTT; when the floor kernel takes pre-scaled inputs, the factors of step (6) ride on the N^-1 constants
-        if (!inverse_done) {
+        if (!all_done) {
             const PrimeDesc *idesc = behz_floor_prescaled(*lv.behz) ? lv.behz->floor_desc : c.d_desc;
             launch_ntt(dq, idesc, qmap, batch * ds * L, c.logn, true, s);
             launch_ntt(db, idesc, c.ids_map(lv.bsk_ids), batch * ds * nb, c.logn, true, s);
         }
         // (6)-(8) multiply by t, floor, Shenoy-Kumaresan back to base q
-        if (dense(out.bstride, (u64)ds * pw)) {
+        if (all_done) {
+        } else if (dense(out.bstride, (u64)ds * pw)) {
             launch_behz_floor_sk(dq, pw, db, bw, out.data, pw, c.d_desc, *lv.behz, N, batch * ds, s);
         } else {
             u64 *res = xq; // xq is dead by now and large enough (sp >= ds)
@@ -411,22 +431,25 @@ void Evaluator::switch_key(CtBatch &ct, const u64 *target, u64 t_bstride, const 
             launch_ntt1(acc, nullptr, c.d_desc_md, amap, batch * 2 * rl, true, s, (u64(1) << dl) - 1, &md);
         } else if (md_two_pass) {
             // two-pass inverse, same shape: the special limb first, then the data limbs with the mod-down (BFV or BGV) as the last pass's epilogue
-            // a small launch brings the special limb to coefficient form (and forms the BGV shares) on the companion stream, beside the first pass of
-            // the data limbs, which does not need it yet: the streams meet in front of the pass that carries the mod-down
-            const bool side_by_side = c.small_launch(batch * 2 * rl);
-            hipStream_t sp_stream = side_by_side ? c.fork(s) : s;
-            launch_ntt2_slots(acc, nullptr, 0, false, c.d_desc, amap, batch * 2 * rl, c.logn, true, sp_stream, false, 0, (unsigned)dl, 1, nullptr);
+            // the first pass is the same for every slot (N^-1 and qk^-1 ride on the last inverse stage): a small launch runs it over the special limb
+            // and the data limbs at once, then the two last passes -- three kernels instead of four, the tiny special-limb launch (2 batch rows) half gone
+            const bool one_first_pass = take_merged(c, batch * 2 * rl);
+            if (one_first_pass) {
+                launch_ntt2_slots(acc, nullptr, 0, false, c.d_desc, amap, batch * 2 * rl, c.logn, true, s, false, 0, 0, (unsigned)rl, nullptr, 1);
+                launch_ntt2_slots(acc, nullptr, 0, false, c.d_desc, amap, batch * 2 * rl, c.logn, true, s, false, 0, (unsigned)dl, 1, nullptr, 2);
+            } else {
+                launch_ntt2_slots(acc, nullptr, 0, false, c.d_desc, amap, batch * 2 * rl, c.logn, true, s, false, 0, (unsigned)dl, 1, nullptr);
+            }
             u64 *share = nullptr;
             if (c.scheme == SCHEME_BGV) { // what the special limb takes out of every data limb, once per coefficient (the CKKS part of the reservation is free)
                 share = c.arena.take(batch * 4 * N);
-                launch_ks_bgv_share(acc, share, a, sp_stream);
+                launch_ks_bgv_share(acc, share, a, s);
             }
             Ntt2ModDown md{c.scheme == SCHEME_BFV ? 0 : 2, ct.data, ct.bstride, (unsigned)dl, qk, a.half, share};
             md.base = base;
             md.base_bstride = base_bstride;
             md.base_polys = base_polys;
-            const std::function<void()> meet = [&]() { c.join(s); };
-            launch_ntt2_slots(acc, nullptr, 0, false, c.d_desc_md, amap, batch * 2 * rl, c.logn, true, s, false, 0, 0, (unsigned)dl, &md, side_by_side ? &meet : nullptr);
+            launch_ntt2_slots(acc, nullptr, 0, false, c.d_desc_md, amap, batch * 2 * rl, c.logn, true, s, false, 0, 0, (unsigned)dl, &md, one_first_pass ? 2u : 3u);
         } else {
             launch_ntt(acc, c.d_desc, amap, batch * 2 * rl, c.logn, true, s);
             launch_ks_moddown(c.scheme == SCHEME_BFV ? 0 : 2, acc, ct.data, ct.bstride, a, s);

@@ -1,7 +1,6 @@
 // kernels.h -- launch interface of the gfx950 kernels (ntt.hip, poly.hip, behz.hip).
 #pragma once
 #include "device_types.h"
-#include <functional>
 
 namespace troyhip {
 
@@ -24,8 +23,10 @@ void launch_ntt2_ks_mac(u64 *D, const u64 *src, u64 src_ostride, const PrimeDesc
 // BEHZ multiply: forward transforms of two size-2 operands + ciphertext tensor in one pass pair (ntt2.hip)
 bool ntt2_tensor_supported(int logn);
 bool ntt2_ks_mac_supported(int logn);
+// src_slots != 0 (both bases of a product in ONE launch): map covers the q primes followed by the B_sk primes; the first src_slots (= q) slots of every
+// polynomial are read from the operands src_a / src_b ([batch][2][src_slots][N]), the B_sk slots lie in xa / xb ([batch][2][period][N]) already
 void launch_ntt2_tensor(u64 *xa, const u64 *src_a, u64 *xb, const u64 *src_b, u64 *out, const PrimeDesc *primes, const LimbMap &map, size_t batch, int logn,
-                        hipStream_t stream);
+                        hipStream_t stream, unsigned src_slots = 0);
 // forward transform of `src` (same row layout, left untouched) into `data`
 void launch_ntt_from(u64 *data, const u64 *src, const PrimeDesc *primes, const LimbMap &map, size_t rows, int logn, hipStream_t stream);
 
@@ -39,11 +40,11 @@ bool ntt2_supported(int logn);
 // base != nullptr: the ciphertext being accumulated into is (base, 0), i.e. ct[b][0] = base[b] + ..., ct[b][1] = ... (rotations: base = sigma(c0) in a
 // temporary; spares the copy into ct[b][0] and the zero fill of ct[b][1])
 struct Ntt2ModDown { int kind; u64 *ct; u64 ct_bstride; unsigned dl; u64 qk, half; const u64 *share; const u64 *base = nullptr; u64 base_bstride = 0; int base_polys = 1; };
-// before_last_pass (inverse): called once, after the first pass of the launch has been issued and before the pass that carries the epilogue (the
-// evaluator joins the stream on which the special limb was prepared there)
+// passes: bit 0 = the first pass of the transform, bit 1 = the second (a caller that runs the first pass of several slot ranges as ONE launch and the second
+// passes separately: the key-switch mod-down of a small launch, whose special limb and data limbs differ only in the last pass)
 void launch_ntt2_slots(u64 *data, const u64 *src, u64 src_ostride, bool src_reduce, const PrimeDesc *primes, const LimbMap &map, size_t rows, int logn,
                        bool inverse, hipStream_t stream, bool src_same_layout, u64 src_bound, unsigned slot_begin, unsigned slot_count, const Ntt2ModDown *md,
-                       const std::function<void()> *before_last_pass = nullptr);
+                       unsigned passes = 3);
 void launch_ntt2(u64 *data, const u64 *src, u64 src_ostride, bool src_reduce, const PrimeDesc *primes, const LimbMap &map, size_t rows, int logn,
                  bool inverse, hipStream_t stream, bool src_same_layout = false, u64 src_bound = 0);
 
@@ -237,10 +238,13 @@ struct BehzDev {
     const PrimeDesc *floor_desc;
 };
 bool behz_floor_prescaled(const BehzDev &c);
-void launch_behz2_extend(const u64 *in, u64 in_pstride, u64 *out, u64 out_pstride, const PrimeDesc *primes, const BehzDev &c, u64 N, u64 polys, hipStream_t s);
+void launch_behz2_extend(const u64 *in, u64 in_pstride, u64 *out, u64 out_pstride, const PrimeDesc *primes, const BehzDev &c, u64 N, u64 polys, hipStream_t s,
+                         const u64 *in2 = nullptr, u64 split = 0);
 void launch_behz2_floor_sk(const u64 *dq, u64 dq_pstride, const u64 *db, u64 db_pstride, u64 *out, u64 out_pstride, const PrimeDesc *primes, const BehzDev &c, u64 N,
                            u64 polys, hipStream_t s);
-void launch_behz_extend(const u64 *in, u64 in_pstride, u64 *out, u64 out_pstride, const PrimeDesc *primes, const BehzDev &c, u64 N, u64 polys, hipStream_t s);
+// in2 != nullptr: polynomials [split, polys) are read from in2 (both operands of a small product through one launch; the outputs are one run)
+void launch_behz_extend(const u64 *in, u64 in_pstride, u64 *out, u64 out_pstride, const PrimeDesc *primes, const BehzDev &c, u64 N, u64 polys, hipStream_t s,
+                        const u64 *in2 = nullptr, u64 split = 0);
 void launch_behz_floor_sk(const u64 *dq, u64 dq_pstride, const u64 *db, u64 db_pstride, u64 *out, u64 out_pstride, const PrimeDesc *primes, const BehzDev &c, u64 N,
                           u64 polys, hipStream_t s);
 

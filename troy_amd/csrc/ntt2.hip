@@ -90,7 +90,11 @@ struct Ntt2Args {
     int src_reduce;       // reduce src values modulo the row prime (they are residues of another prime)
     u64 src_bound;        // exclusive upper bound of the src values (largest source prime): rows whose prime p has 8p > bound skip the reduction
     int slot_fastest;     // workgroup order, see the kernel
-    int src_same_layout;  // src has the row layout of data (plain out-of-place transform) instead of the digit broadcast
+    int src_same_layout;  // 1: src has the row layout of data (plain out-of-place transform) instead of the digit broadcast
+                          // 2: only the first src_slots prime slots of an item are read from an operand ([item][src_slots][N]: items below src_split from src,
+                          //    the others from src2); the remaining slots are transformed in place (BEHZ multiply, both bases in one launch)
+    const u64 *src2;
+    unsigned src_slots, src_split;
     // key-switch inner product fused into the last forward pass (MAC = 1): the workgroup's rows are the dl digits of one
     // (ciphertext o, output prime slot); instead of storing the transforms it accumulates  sum_k NTT(d_k) (.) key[k][c][slot]
     // MAC = 2: ciphertext tensor fused into the last forward pass: the workgroup's four rows are (a0, a1, b0, b1) of one
@@ -696,6 +700,10 @@ __device__ __forceinline__ void ntt2_body(const Ntt2Args &a) {
         const u64 r = ((u64)o * period + slot) * inner + k;
         row = a.data + (r << logn);
         in = (REDUCE || a.src) ? (a.src_same_layout ? a.src + (r << logn) : a.src + (u64)o * a.src_ostride + ((u64)k << logn)) : row;
+        if constexpr (!REDUCE && STRIDED && !INV) {
+            if (a.src_same_layout == 2) // wave-uniform: which buffer this row's prime slot lives in
+                in = slot >= a.src_slots ? row : (o < a.src_split ? a.src + (((u64)o * a.src_slots + slot) << logn) : a.src2 + (((u64)(o - a.src_split) * a.src_slots + slot) << logn));
+        }
         if ((N2_EXP & 8) && !STRIDED) in = a.data + ((r & 63) << logn); // probe: the contiguous pass reads a 16 MB window (L2-resident input)
     };
     constexpr bool DMA = N2_DMA && WAVE_PRIVATE && !(N2_EXP & 1);
@@ -1057,13 +1065,13 @@ void launch_ntt2(u64 *data, const u64 *src, u64 src_ostride, bool src_reduce, co
 // FP64 instances on for the slots in map.fp: without it every slot takes the integer kernels.
 void launch_ntt2_slots(u64 *data, const u64 *src, u64 src_ostride, bool src_reduce, const PrimeDesc *primes, const LimbMap &map, size_t rows, int logn,
                        bool inverse, hipStream_t stream, bool src_same_layout, u64 src_bound, unsigned slot_begin, unsigned slot_count, const Ntt2ModDown *md,
-                       const std::function<void()> *before_last_pass) {
+                       unsigned passes) {
     const u64 *host_primes = map.host_primes;
-    bool met = false;
     if (rows == 0 || slot_count == 0) return;
     if (slot_begin + slot_count > map.period) throw Error(ST_INVALID_ARGUMENT, "ntt2: slot range");
     const bool partial = slot_begin != 0 || slot_count != map.period;
-    if ((partial || md) && (!inverse || src)) throw Error(ST_LOGIC_ERROR, "ntt2: slot ranges and the mod-down epilogue belong to the in-place inverse transform");
+    if ((partial || md || passes != 3) && (!inverse || src)) throw Error(ST_LOGIC_ERROR, "ntt2: slot ranges, single passes and the mod-down epilogue belong to the in-place inverse transform");
+    if (md && !(passes & 2)) throw Error(ST_LOGIC_ERROR, "ntt2: the mod-down epilogue rides on the second pass");
     if (md && map.inner != 1) throw Error(ST_LOGIC_ERROR, "ntt2: the mod-down epilogue takes one row per (item, prime)");
     if (!ntt2_supported(logn)) throw Error(ST_LOGIC_ERROR, "ntt2: unsupported size");
     const size_t per_outer = (size_t)map.period * map.inner;
@@ -1089,6 +1097,7 @@ void launch_ntt2_slots(u64 *data, const u64 *src, u64 src_ostride, bool src_redu
     a.chunks = (a.m_total + a.rows_per_wg - 1) / a.rows_per_wg;
     a.src_reduce = 0;
     a.src_same_layout = 0;
+    a.src2 = nullptr; a.src_slots = 0; a.src_split = 0;
     a.slot_fastest = 0;
     a.slot_begin = slot_begin;
     if (md) {
@@ -1141,12 +1150,11 @@ void launch_ntt2_slots(u64 *data, const u64 *src, u64 src_ostride, bool src_redu
         second.fp_red_mask = mask2;
         if (!inverse) {
             if (src) { first.src = src; first.src_ostride = src_ostride; first.src_reduce = src_reduce; first.src_bound = src_bound; first.src_same_layout = src_same_layout; first.slot_fastest = src_reduce && !src_same_layout; }
-            strided(std::integral_constant<int, 0>{}, first, src && src_reduce);
-            contig(std::integral_constant<int, 0>{}, second, true);
+            if (passes & 1) strided(std::integral_constant<int, 0>{}, first, src && src_reduce);
+            if (passes & 2) contig(std::integral_constant<int, 0>{}, second, true);
         } else {
-            contig(std::integral_constant<int, 1>{}, first, false);
-            if (before_last_pass && !met) { (*before_last_pass)(); met = true; }
-            strided(std::integral_constant<int, 1>{}, second, false);
+            if (passes & 1) contig(std::integral_constant<int, 1>{}, first, false);
+            if (passes & 2) strided(std::integral_constant<int, 1>{}, second, false);
         }
     }
 }
@@ -1261,12 +1269,16 @@ void launch_ntt2_ks_mac(u64 *D, const u64 *src, u64 src_ostride, const PrimeDesc
 bool ntt2_tensor_supported(int logn) { return ntt2_supported(logn) && logn - 9 >= 3 && logn - 9 <= 7; } // 9-stage second pass
 bool ntt2_ks_mac_supported(int logn) { return ntt2_tensor_supported(logn); }
 void launch_ntt2_tensor(u64 *xa, const u64 *src_a, u64 *xb, const u64 *src_b, u64 *out, const PrimeDesc *primes, const LimbMap &map, size_t batch, int logn,
-                        hipStream_t stream) {
+                        hipStream_t stream, unsigned src_slots) {
     const u64 *host_primes = map.host_primes;
     if (!batch) return;
     if (!ntt2_tensor_supported(logn) || map.inner != 1) throw Error(ST_LOGIC_ERROR, "ntt2 tensor: unsupported shape");
     const int k1 = logn - 9;
     const bool same = xa == xb; // squaring: one operand, transformed once
+    // src_slots != 0: both bases of a BEHZ product in one launch -- the first src_slots slots of every polynomial come from the operands, the rest lie
+    // in xa / xb already; when the b-part follows the a-part in memory the first pass of both operands is ONE launch
+    const bool joint = src_slots && !same && xb == xa + ((batch * 2 * map.period) << logn);
+    if (src_slots && (!src_a || !src_b || src_slots > map.period)) throw Error(ST_LOGIC_ERROR, "ntt2 tensor: operands of the merged form");
     for (int cls = 0; cls < 2; cls++) { // one set of launches per prime class (FP64 instances below 2^50)
         const bool fp = cls == 1;
         if (fp && !host_primes) break;
@@ -1285,7 +1297,7 @@ void launch_ntt2_tensor(u64 *xa, const u64 *src_a, u64 *xb, const u64 *src_b, u6
             const FpPlan p1 = fp_plan(pmax, 1.0, r1, n1), p2 = fp_plan(pmax, p1.out_bound, r2, n2);
             mask1 = p1.mask; mask2 = p2.mask;
         }
-        for (int part = 0; part < (same ? 1 : 2); part++) { // first pass of both operands (rows = batch * 2 * limbs each)
+        for (int part = 0; part < (same || joint ? 1 : 2); part++) { // first pass of both operands (rows = batch * 2 * limbs each)
             Ntt2Args a;
             std::memset(&a, 0, sizeof(a));
             a.data = part ? xb : xa;
@@ -1294,13 +1306,14 @@ void launch_ntt2_tensor(u64 *xa, const u64 *src_a, u64 *xb, const u64 *src_b, u6
             a.map = map;
             a.logn = logn;
             a.tiles_per_row_log = (unsigned)(logn - N2_LOGT);
-            a.m_total = (unsigned)(batch * 2);
+            a.m_total = (unsigned)(batch * (joint ? 4 : 2));
             a.nsel = nsel;
             std::memcpy(a.sel, sel, sizeof(sel));
             a.fp_red_mask = mask1;
             a.rows_per_wg = plan_per_workgroup(a.m_total, a.m_total < 8 ? a.m_total : 8, (size_t)nsel << a.tiles_per_row_log);
             a.chunks = (a.m_total + a.rows_per_wg - 1) / a.rows_per_wg;
-            if (src) { a.src = src; a.src_same_layout = 1; }
+            if (src_slots) { a.src = src; a.src2 = src_b; a.src_same_layout = 2; a.src_slots = src_slots; a.src_split = joint ? (unsigned)(batch * 2) : ~0u; }
+            else if (src) { a.src = src; a.src_same_layout = 1; }
             const unsigned blocks = (unsigned)((nsel * a.chunks) << a.tiles_per_row_log);
             switch (k1) {
             case 3: launch_strided<0, 3>(a, blocks, false, false, stream, -1, false, fp); break;
