@@ -211,11 +211,11 @@ Context::Context(int scheme_, u64 N_, const std::vector<u64> &key_primes, u64 t_
     if (has_device) upload_tables();
 }
 
-// A launch of `rows` limb rows is SMALL when it leaves the chip mostly idle: a limb row is N / 2048 workgroup tiles of the two-pass kernels, and below about
-// eight workgroups per compute unit a kernel is bound by the latency of its own dependency chain.  Small operations take the merged forms (one launch over
-// the q-base and the B_sk-base rows, evaluator.cpp).  Measured and NOT kept for them: the two bases side by side on a companion stream -- a cross-stream
-// event wait costs 8-12 us on this runtime, more than the 15 us kernels it would overlap (B = 1: 0.256 -> 0.279 ms, profiles/r04_small_batch.txt).
-bool Context::small_launch(u64 rows) const { return has_device && ((rows * N) >> 11) < 8 * (u64)device_cus(); }
+// Small launches take the merged forms (one launch over the q-base and the B_sk-base rows of a product, one first pass for a mod-down: evaluator.cpp).
+// Measured and NOT kept for them (profiles/r04_small_batch.txt): the two bases side by side on a companion stream -- a cross-stream event wait costs
+// 8-12 us on this runtime, more than the 15 us kernels it would overlap (B = 1: 0.256 -> 0.279 ms); the digits of a key-switch group shared by two
+// workgroups that add their partial sums atomically -- device-scope 64-bit atomics cost far more than the halved row chain saves (0.210 -> 0.275 ms).
+bool Context::small_launch(u64 rows, unsigned per_cu) const { return has_device && ((rows * N) >> 11) < (u64)per_cu * device_cus(); }
 
 Context::~Context() {
     for (void *p : dev_allocs_) (void)hipFree(p);

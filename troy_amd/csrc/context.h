@@ -79,7 +79,9 @@ public:
     std::map<int, Level> levels; // by limb count, K .. last_limbs
     Arena arena;
 
-    bool small_launch(u64 rows) const; // would `rows` limb rows leave most of the chip idle?  (one ciphertext, a few small ones)
+    // does a launch over `rows` limb rows put fewer than `per_cu` workgroup tiles (2048 coefficients) on a compute unit?  (one ciphertext, a few small ones:
+    // kernels that cannot hide their own latencies -- the evaluator then merges launches that are separate at the large batch)
+    bool small_launch(u64 rows, unsigned per_cu = 64) const;
 
     const Level &level(int limbs) const;
     bool has_level(int limbs) const { return levels.count(limbs) != 0; }
