@@ -281,3 +281,70 @@ def test_emulated_small_launch_forms_agree(tmp_path):
         assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
         got[mode] = out.stdout.split()[-5:]
     assert got["split"] == got["merged"] and len(got["split"]) == 5
+
+
+def test_emulated_single_pass_ntt_small_sizes(oracle_lib, tmp_path):
+    """ntt1.hip at N = 2^12 .. 2^14 (ntt1s_*: the whole limb in LDS, the sub-block rounds of the N = 2^15 form under a shorter cross-sub-block round):
+    forward, inverse and extreme inputs for the three butterfly classes (FP64 below 2^50, guard-free below 2^58, guarded) against the oracle, with and
+    without the row loop; then multiply + relinearize + rotation through the single-pass kernels (the BFV mod-down epilogue included) against the
+    two-pass kernels.  Child processes: TROYHIP_NTT is read once."""
+    import sys
+    script = tmp_path / "w.py"
+    script.write_text(
+        "import sys, os, ctypes; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import numpy as np\n"
+        "from troy_amd import api, capi, synth\n"
+        "from oracle import oracle\n"
+        "lib = capi.load(%r)\n"
+        "api.KernelProvider.initialize(0, _lib=lib)\n"
+        "import cases\n"
+        "def launches():\n"
+        "    v, w = ctypes.c_uint64(), ctypes.c_uint64()\n"
+        "    lib.troyhip_stat(b'ntt1_fp_launches', ctypes.byref(v)); lib.troyhip_stat(b'ntt1_int_launches', ctypes.byref(w))\n"
+        "    return v.value + w.value\n"
+        "if sys.argv[1] == 'ntt':\n"
+        "  for logn in (12, 13, 14):\n"
+        "    N = 1 << logn\n"
+        "    kp = api.CoeffModulus.Create(N, [60, 50, 58, 40, 60])\n"
+        "    ctx = api.SEALContext(api.BFV, N, kp, api.PlainModulus.Batching(N, 20))\n"
+        "    primes = kp[:4] + [int(ctx.behz_bases(4)[0][0])]\n"   # + a 61-bit BEHZ prime (guarded butterflies)
+        "    rows = 3 * len(primes) * 2\n"
+        "    x = synth.uniform_rows(7, primes, rows, N, inner=2)\n"
+        "    buf = api.DeviceBuffer.from_numpy(x)\n"
+        "    l0 = launches()\n"
+        "    ctx.ntt(buf, rows, primes, inner=2)\n"
+        "    assert launches() >= l0 + 3\n"   # one launch per prime class
+        "    y = buf.to_numpy().reshape(rows, N)\n"
+        "    for r in range(rows):\n"
+        "        assert np.array_equal(y[r], oracle.ntt_standalone(N, primes[(r // 2) %% len(primes)], x[r], 1)), (logn, r)\n"
+        "    ctx.ntt(buf, rows, primes, inner=2, inverse=True)\n"
+        "    assert np.array_equal(buf.to_numpy().reshape(rows, N), x)\n"
+        "    rows2 = 2 * len(primes)\n"
+        "    e = np.zeros((rows2, N), dtype=np.uint64)\n"
+        "    for r in range(rows2):\n"
+        "        p = primes[(r // 2) %% len(primes)]\n"
+        "        e[r] = p - 1\n"
+        "        if r %% 2: e[r, 1::2] = 0\n"
+        "    buf2 = api.DeviceBuffer.from_numpy(e)\n"
+        "    ctx.ntt(buf2, rows2, primes, inner=2, inverse=True)\n"
+        "    z = buf2.to_numpy().reshape(rows2, N)\n"
+        "    for r in range(rows2):\n"
+        "        assert np.array_equal(z[r], oracle.ntt_standalone(N, primes[(r // 2) %% len(primes)], e[r], 3)), (logn, r)\n"
+        "    ctx.ntt(buf2, rows2, primes, inner=2)\n"
+        "    assert np.array_equal(buf2.to_numpy().reshape(rows2, N), e)\n"
+        "  print('ok')\n"
+        "else:\n"
+        "  l0 = launches()\n"
+        "  print(' '.join(cases.mul_relin_hash(n, batch=3) for n in ('cfgA_bfv_n4096_k3', 'cfgB_bfv_n8192_k5', 'bfv_n16384_k4')), launches() - l0)\n"
+        % (ROOT, os.path.join(ROOT, 'tests'), EMUL))
+    for rpw in ("2", "1"):
+        env = dict(os.environ, TROYHIP_NTT1_RPW=rpw, TROYHIP_NTT="single", TROYHIP_AUX_BASE="reference")
+        out = subprocess.run([sys.executable, str(script), "ntt"], env=env, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0 and "ok" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
+    got = {}
+    for mode in ("single", "twopass"):
+        out = subprocess.run([sys.executable, str(script), "ops"], env=dict(os.environ, TROYHIP_NTT=mode), capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+        got[mode] = out.stdout.split()[-4:]
+    assert got["single"][:3] == got["twopass"][:3]
+    assert int(got["single"][3]) >= 12 and int(got["twopass"][3]) == 0  # the single-pass kernels really ran (plain inverse, special limb, mod-down epilogue)

@@ -177,6 +177,39 @@ def test_single_pass_ntt_vs_oracle_incl_extremes(gpu, oracle_lib):
         assert capi.stat("ntt1_fp_launches") == fp0 + fp_expected, "FP64 single-pass instances: the 40- and 50-bit rows take them, 60- / 61-bit rows never"
 
 
+@pytest.mark.parametrize("logn", [12, 13, 14])
+def test_single_pass_ntt_small_sizes_vs_oracle(logn, gpu, oracle_lib):
+    """ntt1.hip at N = 2^12 .. 2^14 (ntt1s_*: the whole limb in LDS) against the oracle, row by row, at a launch large enough for the dispatcher to
+    take it by itself: uniform rows and the extreme rows of test_single_pass_ntt_vs_oracle_incl_extremes, primes of every butterfly class"""
+    from troy_amd import capi, synth
+    N = 1 << logn
+    kp = gpu.CoeffModulus.Create(N, [60, 50, 58, 40, 60])
+    ctx = gpu.SEALContext(gpu.BFV, N, kp, gpu.PlainModulus.Batching(N, 20))
+    kp61 = gpu.CoeffModulus.Create(N, [60] * 5)
+    ctx61 = gpu.SEALContext(gpu.BFV, N, kp61, gpu.PlainModulus.Batching(N, 20))
+    aux = [int(x) for x in ctx61.behz_bases(4)[0]]
+    assert aux[0] >> 60 == 1
+    need = 4 * 256 * {12: 4, 13: 2, 14: 1}[logn] + 8  # four rows per workgroup slot of the chip
+    for c, primes, fp_expected in ((ctx, kp[:4], 2), (ctx61, [aux[0], kp61[1]], 0)):
+        rows = (need // len(primes) + 1) * len(primes)
+        x = synth.uniform_rows(78, primes, rows, N)
+        for r in range(rows - 2 * len(primes), rows):
+            x[r] = primes[r % len(primes)] - 1
+            if r >= rows - len(primes):
+                x[r, 1::2] = 0
+        fp0, i0 = capi.stat("ntt1_fp_launches"), capi.stat("ntt1_int_launches")
+        for mode, inverse in ((1, False), (3, True)):
+            buf = gpu.DeviceBuffer.from_numpy(x)
+            c.ntt(buf, rows, primes, inverse=inverse)
+            y = buf.to_numpy().reshape(rows, N)
+            for r in list(range(0, rows, 37)) + list(range(rows - 2 * len(primes), rows)):  # a sample of the uniform rows, every extreme row
+                assert np.array_equal(y[r], oracle_lib.ntt_standalone(N, primes[r % len(primes)], x[r], mode)), (mode, r)
+            back = gpu.DeviceBuffer.from_numpy(y)
+            c.ntt(back, rows, primes, inverse=not inverse)
+            assert np.array_equal(back.to_numpy().reshape(rows, N), x), mode  # every row: the round trip
+        assert capi.stat("ntt1_fp_launches") == fp0 + 2 * fp_expected and capi.stat("ntt1_int_launches") > i0, "the single-pass kernels took these launches"
+
+
 def test_cfgA_add_on_device(gpu):
     f = np.load(os.path.join(GOLDEN, "cfgA_bfv_n4096_k3.npz"))
     cfg = cases.CONFIGS["cfgA_bfv_n4096_k3"]

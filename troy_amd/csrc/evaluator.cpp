@@ -349,7 +349,7 @@ void Evaluator::switch_key(CtBatch &ct, const u64 *target, u64 t_bstride, const 
     if (c.scheme == SCHEME_CKKS) { // bring the target to coefficient form (evaluator_cuda.cu:1215-1216)
         u64 *tt = c.arena.take(batch * dl * N);
         const LimbMap tmap = c.ct_map((int)dl);
-        if (ntt1_supported(c.logn, tmap, batch * dl)) { // out of place: the single-pass inverse reads the strided target itself
+        if (ntt1_supported(c.logn, tmap, batch * dl, 3)) { // out of place: the single-pass inverse reads the strided target itself
             launch_ntt1(tt, target, c.d_desc, tmap, batch * dl, true, s, ~0ull, nullptr, nullptr, t_bstride);
         } else {
             launch_copy_strided(target, t_bstride, tt, dl * N, dl * N, batch, s);
@@ -391,10 +391,10 @@ void Evaluator::switch_key(CtBatch &ct, const u64 *target, u64 t_bstride, const 
     const LimbMap amap_md = c.ids_map(out_ids);
     bool md_primes33 = true; // the single-pass epilogue's lazy reduction (lite_reduce4) wants primes of at least 33 bits
     for (u64 j = 0; j < dl; j++) md_primes33 = md_primes33 && c.primes[j] >= (u64(1) << 33);
-    const bool md_single = c.scheme == SCHEME_BFV && c.d_desc_md && md_primes33 && ntt1_supported(c.logn, amap_md, batch * 2 * rl) && ks_moddown_fused();
+    const bool md_single = c.scheme == SCHEME_BFV && c.d_desc_md && md_primes33 && ntt1_supported(c.logn, amap_md, batch * 2 * rl, 1) && ks_moddown_fused();
     const bool md_two_pass = c.scheme != SCHEME_CKKS && !md_single && c.d_desc_md && ntt2_supported(c.logn) && ks_moddown_fused();
     const bool ckks_single = c.scheme == SCHEME_CKKS && c.d_inv_qk && corr_fused() && primes_at_least_33_bits(c, (int)dl) &&
-                             ntt1_supported(c.logn, c.ct_map((int)dl), batch * 2 * dl);
+                             ntt1_supported(c.logn, c.ct_map((int)dl), batch * 2 * dl, 2);
     if (base && !md_two_pass && !md_single && !ckks_single) { // the fused epilogues take (base, 0) directly; the element-wise forms accumulate onto what ct holds
         if (base != ct.data) launch_copy_strided(base, base_bstride, ct.data, ct.bstride, (u64)base_polys * dl * N, batch, s);
         if (base_polys < 2) launch_zero_strided(ct.data + dl * N, ct.bstride, dl * N, batch, s);
@@ -423,12 +423,12 @@ void Evaluator::switch_key(CtBatch &ct, const u64 *target, u64 t_bstride, const 
         if (md_single) {
             // single-pass inverse: the special limb first, then the data limbs with the mod-down as their store epilogue (no acc round trip,
             // no separate memory-bound kernel)
-            launch_ntt1(acc, nullptr, c.d_desc, amap, batch * 2 * rl, true, s, u64(1) << dl, nullptr);
+            launch_ntt1(acc, nullptr, c.d_desc, amap, batch * 2 * rl, true, s, u64(1) << dl, nullptr, nullptr, 0, c.logn);
             Ntt1ModDown md{ct.data, ct.bstride, dl, qk, a.half};
             md.base = base;
             md.base_bstride = base_bstride;
             md.base_polys = base_polys;
-            launch_ntt1(acc, nullptr, c.d_desc_md, amap, batch * 2 * rl, true, s, (u64(1) << dl) - 1, &md);
+            launch_ntt1(acc, nullptr, c.d_desc_md, amap, batch * 2 * rl, true, s, (u64(1) << dl) - 1, &md, nullptr, 0, c.logn);
         } else if (md_two_pass) {
             // two-pass inverse, same shape: the special limb first, then the data limbs with the mod-down (BFV or BGV) as the last pass's epilogue
             // the first pass is the same for every slot (N^-1 and qk^-1 ride on the last inverse stage): a small launch runs it over the special limb
@@ -540,7 +540,7 @@ void Evaluator::mod_switch_scale(const CtBatch &in, CtBatch &out, u64 batch, hip
     const u64 *src = in.data;
     // CKKS through the fused correction transform reads a strided batch (a relinearized ciphertext keeps its three-polynomial stride) as it lies
     const bool ckks_fused = c.scheme == SCHEME_CKKS && c.level(L).d_inv_qlast && corr_fused() && primes_at_least_33_bits(c, nl) &&
-                            ntt1_supported(c.logn, c.ct_map(nl), batch * in.size * nl);
+                            ntt1_supported(c.logn, c.ct_map(nl), batch * in.size * nl, 2);
     // the output ranges [out.data + b out.bstride, + size npw) must not overlap what a later row still reads: when the two batches share memory
     // (a direct C-ABI caller rescaling a strided batch onto itself) the input is staged first, as every strided input was before the fused path
     bool overlaps = false;

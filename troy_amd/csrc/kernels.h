@@ -48,8 +48,9 @@ void launch_ntt2_slots(u64 *data, const u64 *src, u64 src_ostride, bool src_redu
 void launch_ntt2(u64 *data, const u64 *src, u64 src_ostride, bool src_reduce, const PrimeDesc *primes, const LimbMap &map, size_t rows, int logn,
                  bool inverse, hipStream_t stream, bool src_same_layout = false, u64 src_bound = 0);
 
-// ---- ntt1.hip (N = 2^15: one HBM round trip per limb-transform) ----
-bool ntt1_supported(int logn, const LimbMap &map, size_t rows);
+// ---- ntt1.hip (N = 2^12 .. 2^15: one HBM round trip per limb-transform) ----
+// feature: 0 plain transform, 1 the BFV mod-down epilogue (Ntt1ModDown), 2 the CKKS correction form (Ntt1Corr), 3 the inverse from a strided source
+bool ntt1_supported(int logn, const LimbMap &map, size_t rows, int feature = 0);
 // BFV mod-down by the special prime (ks_moddown_kernel<0>, evaluator.cpp:2528-2648) fused into the inverse transform of the key-switch
 // accumulators acc[o = 2 b + cpt][slot][N]: the slots below `dl` leave the kernel as  ct[b][cpt][slot] += (acc - [t']_q + [half]_q) qk^-1
 // instead of being stored; slot `dl` (the special limb) must already be in coefficient form.  `primes` is then Context::d_desc_md,
@@ -81,7 +82,7 @@ struct Ntt1Corr {
 };
 // slot_mask: only these prime slots of the row pattern are transformed
 void launch_ntt1(u64 *data, const u64 *src, const PrimeDesc *primes, const LimbMap &map, size_t rows, bool inverse, hipStream_t stream, u64 slot_mask = ~0ull,
-                 const Ntt1ModDown *md = nullptr, const Ntt1Corr *cr = nullptr, u64 src_ostride = 0);
+                 const Ntt1ModDown *md = nullptr, const Ntt1Corr *cr = nullptr, u64 src_ostride = 0, int logn = 15);
 
 // ---- poly.hip ----
 void launch_ew(int op, const u64 *a, const u64 *b, u64 *out, const PrimeDesc *primes, const LimbMap &map, int logn, u64 rows, hipStream_t s);

@@ -28,6 +28,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 namespace troyhip {
 
@@ -289,11 +290,14 @@ template <int NV> __device__ __forceinline__ void fp_reduce_all(u64 (&y)[NV], co
 
 // the last 10 forward stages (5..14) of sub-block sb (coefficients 1024 sb .. 1024 sb + 1023), in place in the wave's region,
 // result canonical to `out` (the sub-block's 1024 coefficients in HBM)
-template <bool LEAN, bool CR, bool FP, class AfterB> __device__ __forceinline__ void fwd_subblock(u64 *R, const unsigned sb, const unsigned lane_in, const PrimeDesc &pd, const PrimeConst &pc, const Mod &m,
+// LOGN: the transform's size; the sub-block rounds are its stages LOGN - 10 .. LOGN - 1 (N = 2^15: 5 .. 14 as the comments say; the smaller sizes of
+// ntt1s_*_body shift every stage number down, the code is the same: a sub-block is 1024 coefficients at every size)
+template <int LOGN, bool LEAN, bool CR, bool FP, class AfterB> __device__ __forceinline__ void fwd_subblock(u64 *R, const unsigned sb, const unsigned lane_in, const PrimeDesc &pd, const PrimeConst &pc, const Mod &m,
                                                                   u64 *out, const Ntt1Args &a, const unsigned mm, const unsigned m_begin, const int stamp0, const bool hf_last,
                                                                   const FpPrime &fc, const AfterB &after_round_b, const u64 *cr_in = nullptr, const Shoup cr_inv = Shoup{0, 0},
                                                                   const u64 *cr_acc = nullptr) {
     (void)a; (void)mm; (void)m_begin; (void)stamp0; (void)hf_last; (void)fc;
+    constexpr unsigned A = 1u << (LOGN - 10); // blocks of the first sub-block stage per sub-block row: root index of stage s = 2^s + block
     const unsigned lane = opaque(lane_in);
     N1_PRIO(3);
     {   // round B: stages 5..8 on 16 values, registers = j9..j6, lane = j5..j0; twiddles depend on (sb, register) only: scalar loads
@@ -302,9 +306,9 @@ template <bool LEAN, bool CR, bool FP, class AfterB> __device__ __forceinline__ 
         for (int r = 0; r < 16; r++) y[r] = R[sw1(64 * r + lane)];
         if constexpr (FP) {
             if (a.fp_red_mask & 2u) fp_reduce_all<16>(y, fc);
-            fp_fwd_stages<1, 4, false, N1_FP_FENCE_B>(y, [&](int st, int, int blk) { return ld_tw_uniform(pd.root + (32u << st) + (sb << st) + blk); }, fc);
+            fp_fwd_stages<1, 4, false, N1_FP_FENCE_B>(y, [&](int st, int, int blk) { return ld_tw_uniform(pd.root + (A << st) + (sb << st) + blk); }, fc);
         } else
-        fwd_stages<1, 4, LEAN, true>(y, [&](int st, int, int blk) { return ld_tw_uniform(pd.root + (32u << st) + (sb << st) + blk); }, pc);
+        fwd_stages<1, 4, LEAN, true>(y, [&](int st, int, int blk) { return ld_tw_uniform(pd.root + (A << st) + (sb << st) + blk); }, pc);
 #pragma unroll
         for (int r = 0; r < 16; r++) R[sw1(64 * r + lane)] = y[r];
     }
@@ -317,12 +321,12 @@ template <bool LEAN, bool CR, bool FP, class AfterB> __device__ __forceinline__ 
         // the seven twiddles
         const unsigned h = lane >> 2, low = lane & 3;
         const unsigned b9 = 16 * sb + h;
-        const Shoup t9 = FP ? ld_tw8(pd.root, 512 + b9) : ld_tw(pd.root, 512 + b9);
+        const Shoup t9 = FP ? ld_tw8(pd.root, 16 * A + b9) : ld_tw(pd.root, 16 * A + b9);
         Shoup t10[2], t11[4];
 #pragma unroll
-        for (int i = 0; i < 2; i++) t10[i] = FP ? ld_tw8(pd.root, 1024 + 2 * b9 + i) : ld_tw(pd.root, 1024 + 2 * b9 + i);
+        for (int i = 0; i < 2; i++) t10[i] = FP ? ld_tw8(pd.root, 32 * A + 2 * b9 + i) : ld_tw(pd.root, 32 * A + 2 * b9 + i);
 #pragma unroll
-        for (int i = 0; i < 4; i++) t11[i] = FP ? ld_tw8(pd.root, 2048 + 4 * b9 + i) : ld_tw(pd.root, 2048 + 4 * b9 + i);
+        for (int i = 0; i < 4; i++) t11[i] = FP ? ld_tw8(pd.root, 64 * A + 4 * b9 + i) : ld_tw(pd.root, 64 * A + 4 * b9 + i);
 #pragma unroll 1
         for (unsigned it = 0; it < 2; it++) {
             u64 y[8];
@@ -347,12 +351,12 @@ template <bool LEAN, bool CR, bool FP, class AfterB> __device__ __forceinline__ 
         const unsigned u = lane + 64 * it;
         u64 y[8];
         const unsigned b12 = 128 * sb + u;
-        const Shoup t12 = FP ? ld_tw8(pd.root, 4096 + b12) : ld_tw(pd.root, 4096 + b12);
+        const Shoup t12 = FP ? ld_tw8(pd.root, 128 * A + b12) : ld_tw(pd.root, 128 * A + b12);
         Shoup t13[2], t14[4];
 #pragma unroll
-        for (int i = 0; i < 2; i++) t13[i] = FP ? ld_tw8(pd.root, 8192 + 2 * b12 + i) : ld_tw(pd.root, 8192 + 2 * b12 + i);
+        for (int i = 0; i < 2; i++) t13[i] = FP ? ld_tw8(pd.root, 256 * A + 2 * b12 + i) : ld_tw(pd.root, 256 * A + 2 * b12 + i);
 #pragma unroll
-        for (int i = 0; i < 4; i++) t14[i] = FP ? ld_tw8(pd.root, 16384 + 4 * b12 + i) : ld_tw(pd.root, 16384 + 4 * b12 + i);
+        for (int i = 0; i < 4; i++) t14[i] = FP ? ld_tw8(pd.root, 512 * A + 4 * b12 + i) : ld_tw(pd.root, 512 * A + 4 * b12 + i);
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(R + sw1(8 * u + 2 * q));
@@ -544,7 +548,7 @@ template <bool LEAN, bool CR, bool FP> __device__ __forceinline__ void ntt1_fwd_
             // transform 167 ns per limb with 74 % VALU-busy): they request it after round B of the second half, under rounds C1 / C2
             constexpr bool EARLY_ODD = FP && N1_FP_EARLY_ODD;
             auto after_b = [&]() { if (EARLY_ODD && hf == 1 && mm + 1 < m_end) load_half(xo, in_row(mm + 1), 1); };
-            fwd_subblock<LEAN, CR, FP>(region, 16 * hf + wv, lane, pd, pc, m, out + 1024 * (16 * hf + wv), a, mm, m_begin, 4 + 6 * hf, hf == 1, fc, after_b, CR ? cin + 1024 * (16 * hf + wv) : nullptr,
+            fwd_subblock<N1_LOGN, LEAN, CR, FP>(region, 16 * hf + wv, lane, pd, pc, m, out + 1024 * (16 * hf + wv), a, mm, m_begin, 4 + 6 * hf, hf == 1, fc, after_b, CR ? cin + 1024 * (16 * hf + wv) : nullptr,
                                        cr_inv, CR && cacc ? cacc + 1024 * (16 * hf + wv) : nullptr);
             N1_STAMP(7 + 6 * hf);
         }
@@ -557,9 +561,10 @@ template <bool CR> __global__ __launch_bounds__(N1_THREADS) void ntt1_fwd_fp_ker
 
 // the first 10 inverse stages (14..5) of sub-block sb: input y (this lane's coefficients 8 u + r, u = lane + 64 i, in y[8 i + r]),
 // result left in the wave's region (position sw2(j))
-template <bool LEAN, bool FP> __device__ __forceinline__ void inv_subblock(u64 (&yin)[16], u64 *R, const unsigned sb, const unsigned lane_in, const PrimeDesc &pd, const PrimeConst &pc,
+template <int LOGN, bool LEAN, bool FP> __device__ __forceinline__ void inv_subblock(u64 (&yin)[16], u64 *R, const unsigned sb, const unsigned lane_in, const PrimeDesc &pd, const PrimeConst &pc,
                                                                   const FpPrime &fc, const unsigned fp_mask) {
     const Shoup none{0, 0};
+    constexpr unsigned NN = 1u << LOGN; // the inverse table keeps the stage with m blocks at offset N - 2 m + 1 (src/utils/ntt.cpp:49-54)
     const unsigned lane = opaque(lane_in);
     (void)fc; (void)fp_mask;
     if constexpr (FP) { // canonical residues become doubles (round D' never needs a reduction: 8 p < 2^53)
@@ -578,8 +583,8 @@ template <bool LEAN, bool FP> __device__ __forceinline__ void inv_subblock(u64 (
 #pragma unroll
         for (int i = 0; i < 4; i++) t14[i] = FP ? ld_tw8(pd.iroot, 1 + 4 * b12 + i) : ld_tw(pd.iroot, 1 + 4 * b12 + i);
 #pragma unroll
-        for (int i = 0; i < 2; i++) t13[i] = FP ? ld_tw8(pd.iroot, 16385 + 2 * b12 + i) : ld_tw(pd.iroot, 16385 + 2 * b12 + i);
-        const Shoup t12 = FP ? ld_tw8(pd.iroot, 24577 + b12) : ld_tw(pd.iroot, 24577 + b12);
+        for (int i = 0; i < 2; i++) t13[i] = FP ? ld_tw8(pd.iroot, NN / 2 + 1 + 2 * b12 + i) : ld_tw(pd.iroot, NN / 2 + 1 + 2 * b12 + i);
+        const Shoup t12 = FP ? ld_tw8(pd.iroot, NN - NN / 4 + 1 + b12) : ld_tw(pd.iroot, NN - NN / 4 + 1 + b12);
         if constexpr (FP) fp_inv_stages<1, 3, false, 0, 3, true>(y, [&](int st, int, int blk) { return st == 0 ? t14[blk] : (st == 1 ? t13[blk] : t12); }, none, fc);
         else
         inv_stages<1, 3, false, false, LEAN ? 2 : 0>(y, [&](int st, int, int blk) { return st == 0 ? t14[blk] : (st == 1 ? t13[blk] : t12); }, none, pc); // inputs below 2p (stored limbs are canonical) -> 16p
@@ -598,10 +603,10 @@ template <bool LEAN, bool FP> __device__ __forceinline__ void inv_subblock(u64 (
         const unsigned b9 = 16 * sb + h;
         Shoup t11[4], t10[2];
 #pragma unroll
-        for (int i = 0; i < 4; i++) t11[i] = FP ? ld_tw8(pd.iroot, 28673 + 4 * b9 + i) : ld_tw(pd.iroot, 28673 + 4 * b9 + i);
+        for (int i = 0; i < 4; i++) t11[i] = FP ? ld_tw8(pd.iroot, NN - NN / 8 + 1 + 4 * b9 + i) : ld_tw(pd.iroot, NN - NN / 8 + 1 + 4 * b9 + i);
 #pragma unroll
-        for (int i = 0; i < 2; i++) t10[i] = FP ? ld_tw8(pd.iroot, 30721 + 2 * b9 + i) : ld_tw(pd.iroot, 30721 + 2 * b9 + i);
-        const Shoup t9 = FP ? ld_tw8(pd.iroot, 31745 + b9) : ld_tw(pd.iroot, 31745 + b9);
+        for (int i = 0; i < 2; i++) t10[i] = FP ? ld_tw8(pd.iroot, NN - NN / 16 + 1 + 2 * b9 + i) : ld_tw(pd.iroot, NN - NN / 16 + 1 + 2 * b9 + i);
+        const Shoup t9 = FP ? ld_tw8(pd.iroot, NN - NN / 32 + 1 + b9) : ld_tw(pd.iroot, NN - NN / 32 + 1 + b9);
 #pragma unroll 1
         for (unsigned it = 0; it < 2; it++) {
             u64 y[8];
@@ -632,9 +637,9 @@ template <bool LEAN, bool FP> __device__ __forceinline__ void inv_subblock(u64 (
         }
         if constexpr (FP) {
             if (fp_mask & 4u) fp_reduce_all<16>(y, fc);
-            fp_inv_stages<1, 4, false, 0, 4>(y, [&](int st, int, int blk) { return ld_tw_uniform(pd.iroot + (N1_N - (512u >> st) + 1) + ((8 * sb) >> st) + blk); }, none, fc);
+            fp_inv_stages<1, 4, false, 0, 4>(y, [&](int st, int, int blk) { return ld_tw_uniform(pd.iroot + (NN - ((NN >> 6) >> st) + 1) + ((8 * sb) >> st) + blk); }, none, fc);
         } else
-        inv_stages<1, 4, false, true, LEAN ? 4 : 0>(y, [&](int st, int, int blk) { return ld_tw_uniform(pd.iroot + (N1_N - (512u >> st) + 1) + ((8 * sb) >> st) + blk); }, none, pc);
+        inv_stages<1, 4, false, true, LEAN ? 4 : 0>(y, [&](int st, int, int blk) { return ld_tw_uniform(pd.iroot + (NN - ((NN >> 6) >> st) + 1) + ((8 * sb) >> st) + blk); }, none, pc);
 #pragma unroll
         for (int r = 0; r < 16; r++) R[sw2(64 * r + lane)] = y[r];
     }
@@ -705,7 +710,7 @@ template <bool LEAN, bool MD, bool FP> __device__ __forceinline__ void ntt1_inv_
         TROY_WAVE_SYNC();
 #pragma unroll
         for (int hf = 0; hf < 2; hf++) {
-            inv_subblock<LEAN, FP>(hf ? y1 : y, region, 16 * hf + wv, lane, pd, pc, fc, a.fp_red_mask);
+            inv_subblock<N1_LOGN, LEAN, FP>(hf ? y1 : y, region, 16 * hf + wv, lane, pd, pc, fc, a.fp_red_mask);
             __syncthreads();
 #pragma unroll
             for (int r = 0; r < 8; r++) { x[16 * hf + r] = rlo[1024 * r]; x[16 * hf + 8 + r] = rhi[1024 * r]; }
@@ -780,6 +785,194 @@ template <bool LEAN, bool MD, bool FP> __device__ __forceinline__ void ntt1_inv_
 template <bool LEAN, bool MD> __global__ __launch_bounds__(N1_THREADS) void ntt1_inv_kernel(Ntt1Args a) { ntt1_inv_body<LEAN, MD, false>(a); }
 template <bool MD> __global__ __launch_bounds__(N1_THREADS) void ntt1_inv_fp_kernel(Ntt1Args a) { ntt1_inv_body<true, MD, true>(a); }
 
+
+// ---- N = 2^12 .. 2^14: the whole limb fits LDS (32 / 64 / 128 KiB), so the schedule is the same one without halves and parking.
+// T = N / 16 threads (4 / 8 / 16 waves), 16 coefficients per thread: value (g, h) of thread t is coefficient t + T (h G + g), G = 16 / NSUB.
+//   forward: round A = the first LOGA = LOGN - 10 stages on G groups of NSUB = 2^LOGA registers (workgroup-uniform twiddles), which splits the
+//   limb into NSUB sub-blocks of 1024 points -- value (g, h) lands in sub-block h at position t + T g; one barrier; wave w finishes sub-block w
+//   (rounds B, C1, C2 above: the same ten stages at every size) while the next row's sixteen loads are in flight;
+//   inverse: the mirror image -- sub-blocks first (their inputs straight from HBM), one barrier, round A' with N^-1 folded in.
+// Two to five workgroups share a compute unit (LDS), so the launch needs fewer rows than the N = 2^15 form to fill the chip.
+template <int LOGN, bool LEAN, bool FP> __device__ __forceinline__ void ntt1s_fwd_body(const Ntt1Args &a) {
+    constexpr int LOGA = LOGN - 10, NSUB = 1 << LOGA, T = 64 * NSUB, G = 16 >> LOGA;
+    __shared__ __attribute__((aligned(16))) u64 lds[NSUB * 1024];
+    const unsigned tid = threadIdx.x, lane = tid & 63;
+#ifdef TROYHIP_CPU_EMUL
+    const unsigned wv = tid >> 6;
+#else
+    const unsigned wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+#endif
+    const unsigned slot = uniform_u32(a.slots[blockIdx.x / a.chunks]), chunk = blockIdx.x % a.chunks;
+    PrimeDesc pd = a.primes[uniform_u32(a.map.id[slot])];
+    if constexpr (FP) pd.root = pd.root_fp;
+    const FpPrime fc = make_fp_prime_uniform(FP ? pd.p : 1);
+    const PrimeConst pc = make_prime_const(pd.p);
+    const Mod m = mod_of(pd);
+    const unsigned m_begin = chunk * a.rows_per_wg;
+    const unsigned m_end = (m_begin + a.rows_per_wg < a.m_total) ? m_begin + a.rows_per_wg : a.m_total;
+    const unsigned inner = a.map.inner, period = a.map.period;
+    auto row_of = [&](unsigned mm) -> u64 {
+        const unsigned o = mm / inner, k = mm - o * inner;
+        return (((u64)o * period + slot) * inner + k) << LOGN;
+    };
+    const u64 *in_base = a.src ? a.src : a.data;
+    u64 *const region = lds + 1024 * wv;
+    u64 y[16]; // y[(g << LOGA) + h]
+    auto load_row = [&](const u64 *rowp) {
+        const unsigned t = opaque(tid);
+#pragma unroll
+        for (int g = 0; g < G; g++)
+#pragma unroll
+            for (int h = 0; h < NSUB; h++) y[(g << LOGA) + h] = ld_g(rowp, t + T * (h * G + g));
+    };
+    load_row(in_base + row_of(m_begin));
+    const Ntt1Args &args = a;
+    for (unsigned mm = m_begin; mm < m_end; mm++) {
+        u64 *const out = a.data + row_of(mm);
+        if constexpr (FP) {
+#pragma unroll
+            for (int r = 0; r < 16; r++) y[r] = fp_bits(fp_from_u64(y[r]));
+            if (a.fp_red_mask & 1u) fp_reduce_all<16>(y, fc);
+        }
+        auto twA = [&](int st, int, int blk) { return ld_tw_uniform((pd.root + (1u << st) + blk)); };
+        if constexpr (FP) fp_fwd_stages<G, LOGA>(y, twA, fc);
+        else fwd_stages<G, LOGA, LEAN, true>(y, twA, pc);
+        if (mm != m_begin) __syncthreads(); // every wave is done with its region's previous content
+        {
+            const unsigned t = opaque(tid);
+#pragma unroll
+            for (int g = 0; g < G; g++)
+#pragma unroll
+                for (int h = 0; h < NSUB; h++) lds[1024 * h + sw1(t + T * g)] = y[(g << LOGA) + h];
+        }
+        __syncthreads();
+        if (mm + 1 < m_end) load_row(in_base + row_of(mm + 1)); // all sixteen registers are free: the next limb streams in under the sub-block rounds
+        fwd_subblock<LOGN, LEAN, false, FP>(region, wv, lane, pd, pc, m, out + 1024 * wv, args, mm, m_begin, 4, true, fc, [] {});
+    }
+}
+template <int LOGN, bool LEAN> __global__ __launch_bounds__(64 << (LOGN - 10), 4) void ntt1s_fwd_kernel(Ntt1Args a) { ntt1s_fwd_body<LOGN, LEAN, false>(a); }
+template <int LOGN> __global__ __launch_bounds__(64 << (LOGN - 10), 4) void ntt1s_fwd_fp_kernel(Ntt1Args a) { ntt1s_fwd_body<LOGN, true, true>(a); }
+
+template <int LOGN, bool LEAN, bool MD, bool FP> __device__ __forceinline__ void ntt1s_inv_body(const Ntt1Args &a) {
+    constexpr int LOGA = LOGN - 10, NSUB = 1 << LOGA, T = 64 * NSUB, G = 16 >> LOGA;
+    constexpr unsigned NN = 1u << LOGN;
+    __shared__ __attribute__((aligned(16))) u64 lds[NSUB * 1024];
+    const unsigned tid = threadIdx.x, lane = tid & 63;
+#ifdef TROYHIP_CPU_EMUL
+    const unsigned wv = tid >> 6;
+#else
+    const unsigned wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+#endif
+    const unsigned slot = uniform_u32(a.slots[blockIdx.x / a.chunks]), chunk = blockIdx.x % a.chunks;
+    PrimeDesc pd = a.primes[uniform_u32(a.map.id[slot])];
+    if constexpr (FP) { pd.iroot = pd.iroot_fp; pd.inv_n = pd.inv_n_fp; pd.iroot_last_scaled = pd.iroot_last_scaled_fp; }
+    const FpPrime fc = make_fp_prime_uniform(FP ? pd.p : 1);
+    const PrimeConst pc = make_prime_const(pd.p);
+    const unsigned m_begin = chunk * a.rows_per_wg;
+    const unsigned m_end = (m_begin + a.rows_per_wg < a.m_total) ? m_begin + a.rows_per_wg : a.m_total;
+    const unsigned inner = a.map.inner, period = a.map.period;
+    auto row_of = [&](unsigned mm) -> u64 {
+        const unsigned o = mm / inner, k = mm - o * inner;
+        return (((u64)o * period + slot) * inner + k) << LOGN;
+    };
+    u64 *const region = lds + 1024 * wv;
+    u64 y[16]; // the wave's sub-block input: y[8 i + r] = coefficient 8 (lane + 64 i) + r
+    auto load16 = [&](const u64 *sub) {
+        const unsigned l = opaque(lane);
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const ulonglong2 v = ld_g2(sub, 8 * (l + 64 * i) + 2 * q);
+                y[8 * i + 2 * q] = v.x;
+                y[8 * i + 2 * q + 1] = v.y;
+            }
+    };
+    load16(a.data + row_of(m_begin) + 1024 * wv);
+    for (unsigned mm = m_begin; mm < m_end; mm++) {
+        u64 *const row = a.data + row_of(mm);
+        if (mm != m_begin) __syncthreads(); // round A' of the previous row has read the regions
+        inv_subblock<LOGN, LEAN, FP>(y, region, wv, lane, pd, pc, fc, a.fp_red_mask);
+        __syncthreads();
+        u64 x[16]; // x[(g << LOGA) + h] = coefficient t + T g of sub-block h after its ten stages
+        {
+            const unsigned t = opaque(tid);
+#pragma unroll
+            for (int g = 0; g < G; g++)
+#pragma unroll
+                for (int h = 0; h < NSUB; h++) x[(g << LOGA) + h] = lds[1024 * h + sw2(t + T * g)];
+        }
+        if (mm + 1 < m_end) load16(a.data + row_of(mm + 1) + 1024 * wv); // the next row's sub-block input, in flight under round A'
+        if (LEAN && !FP) { // 64p -> 4p (the sub-block rounds leave 64p at most), as in the N = 2^15 form
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                u64 v[4] = {x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]};
+                lite_reduce4(v, (u32)pd.cr1, pc);
+#pragma unroll
+                for (int i = 0; i < 4; i++) x[4 * q + i] = v[i];
+            }
+        }
+        auto twA = [&](int st, int, int blk) { return st == LOGA - 1 ? pd.iroot_last_scaled : ld_tw_uniform((pd.iroot + (NN - ((unsigned)NSUB >> st) + 1) + blk)); };
+        if constexpr (FP) {
+            if (a.fp_red_mask & 8u) fp_reduce_all<16>(x, fc);
+            if constexpr (LOGA > 1) fp_inv_stages<G, LOGA, true, 0, LOGA - 1>(x, twA, pd.inv_n, fc);
+            if (a.fp_red_mask & 16u) fp_reduce_all<16>(x, fc);
+            fp_inv_stages<G, LOGA, true, LOGA - 1, LOGA>(x, twA, pd.inv_n, fc);
+#pragma unroll
+            for (int i = 0; i < 16; i++) x[i] = fp_canonical(fp_of_bits(x[i]), fc, pd.p);
+        } else {
+            inv_stages<G, LOGA, true, true, LEAN ? 4 : 0>(x, twA, pd.inv_n, pc);
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                u64 v[4] = {x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]};
+                reduce4_from_4p(v, pc);
+#pragma unroll
+                for (int i = 0; i < 4; i++) x[4 * q + i] = v[i];
+            }
+        }
+        const unsigned t = opaque(tid);
+        if (MD) { // the BFV mod-down by the special prime as the store epilogue (Ntt1ModDown; the N = 2^15 form above has the derivation)
+            const Mod m = mod_of(pd);
+            const u64 bias = pd.p * 4 + barrett64(a.md_half, m);
+            const u64 *special = a.data + (((u64)mm * period + a.md_dl) << LOGN);
+            u64 *dst = a.md_ct + (u64)(mm >> 1) * a.md_ct_bstride + (((u64)(mm & 1) * a.md_dl + slot) << LOGN);
+            const u64 *onto = !a.md_base ? dst : ((int)(mm & 1) >= a.md_base_polys) ? nullptr : a.md_base + (u64)(mm >> 1) * a.md_base_bstride + (((u64)(mm & 1) * a.md_dl + slot) << LOGN);
+            const Shoup iq[4] = {pd.aux, pd.aux, pd.aux, pd.aux};
+#pragma unroll
+            for (int q4 = 0; q4 < 4; q4++) {
+                u64 tl[4], c[4], q[4];
+                unsigned n[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int idx = 4 * q4 + i, g = idx >> LOGA, h = idx & (NSUB - 1);
+                    n[i] = t + T * (h * G + g);
+                    tl[i] = ld_g(special, n[i]) + a.md_half;
+                    c[i] = onto ? ld_g(onto, n[i]) : 0;
+                }
+                csub4(tl, a.md_qk);
+                lite_reduce4(tl, (u32)pd.cr1, pc);
+#pragma unroll
+                for (int i = 0; i < 4; i++) tl[i] = bias - tl[i];
+                mulhi_approx4_u(q, tl, iq);
+#pragma unroll
+                for (int i = 0; i < 4; i++) c[i] += mul_acc_u(x[4 * q4 + i], tl[i], pd.aux.op, q[i], pc.negp);
+                csub4(c, pc.four_p);
+                csub4(c, pc.two_p);
+                csub4(c, pc.p);
+#pragma unroll
+                for (int i = 0; i < 4; i++) st_g(dst, n[i], c[i]);
+            }
+        } else {
+#pragma unroll
+            for (int g = 0; g < G; g++)
+#pragma unroll
+                for (int h = 0; h < NSUB; h++) st_g(row, t + T * (h * G + g), x[(g << LOGA) + h]);
+        }
+    }
+}
+template <int LOGN, bool LEAN, bool MD> __global__ __launch_bounds__(64 << (LOGN - 10), 4) void ntt1s_inv_kernel(Ntt1Args a) { ntt1s_inv_body<LOGN, LEAN, MD, false>(a); }
+template <int LOGN, bool MD> __global__ __launch_bounds__(64 << (LOGN - 10), 4) void ntt1s_inv_fp_kernel(Ntt1Args a) { ntt1s_inv_body<LOGN, true, MD, true>(a); }
+
 // ---- host side ----
 
 unsigned device_cus() {
@@ -801,15 +994,24 @@ static int ntt1_mode() {
     }();
     return mode;
 }
-bool ntt1_supported(int logn, const LimbMap &map, size_t rows) {
-    if (ntt1_mode() == 1 || logn != N1_LOGN || !rows || rows % ((size_t)map.period * map.inner)) return false;
-    return ntt1_mode() == 2 || rows >= 4 * (size_t)device_cus();
+// workgroups of the single-pass kernels that share a compute unit: one at N = 2^15 / 2^14 (LDS), two at 2^13, four at 2^12 (16 waves)
+static unsigned ntt1_wgs_per_cu(int logn) { return logn >= 14 ? 1u : (logn == 13 ? 2u : 4u); }
+// feature: 0 the plain transform (in place, or forward from a source of the same layout), 1 the BFV mod-down epilogue, 2 the CKKS correction form,
+// 3 the inverse from a strided source.  N = 2^15 has them all, the smaller sizes (ntt1s_*) the first two.
+bool ntt1_supported(int logn, const LimbMap &map, size_t rows, int feature) {
+    if (ntt1_mode() == 1 || logn < 12 || logn > N1_LOGN || !rows || rows % ((size_t)map.period * map.inner)) return false;
+    if (logn != N1_LOGN && feature > 1) return false;
+    // the launch must give every workgroup slot of the chip about four rows: below that the per-row latency of a whole-limb workgroup shows and the
+    // two-pass kernels, which spread a row over N / 2048 small workgroups, are the better grain
+    return ntt1_mode() == 2 || rows >= 4 * (size_t)device_cus() * ntt1_wgs_per_cu(logn);
 }
 // rows laid out r = (o * period + i) * inner + k, prime map.id[i].  The forward transform is launched once per prime class:
 // guard-free butterflies for the slots in map.lean, guarded ones for the rest.
 void launch_ntt1(u64 *data, const u64 *src, const PrimeDesc *primes, const LimbMap &map, size_t rows, bool inverse, hipStream_t stream, u64 slot_mask,
-                 const Ntt1ModDown *md, const Ntt1Corr *cr, u64 src_ostride) {
+                 const Ntt1ModDown *md, const Ntt1Corr *cr, u64 src_ostride, int logn) {
     if (rows == 0) return;
+    if (logn < 12 || logn > N1_LOGN) throw Error(ST_LOGIC_ERROR, "ntt1: unsupported size");
+    if (logn != N1_LOGN && (cr || (src && inverse))) throw Error(ST_LOGIC_ERROR, "ntt1: the correction form and the strided source belong to N = 2^15");
     const size_t per_outer = (size_t)map.period * map.inner;
     if (rows % per_outer) throw Error(ST_INVALID_ARGUMENT, "ntt1: row count must be a multiple of the limb pattern");
     if (md && (!inverse || map.inner != 1 || md->dl >= map.period)) throw Error(ST_LOGIC_ERROR, "ntt1: the mod-down epilogue belongs to the inverse transform of [..][slot][N] accumulators");
@@ -834,7 +1036,7 @@ void launch_ntt1(u64 *data, const u64 *src, const PrimeDesc *primes, const LimbM
     // the un-overlapped first load and last store, about a third of a row): pick the rows per workgroup (they share the prime) that
     // minimises rounds x (rows + 1/3), with a small penalty for spreading the CUs over many primes at once.  A fixed "three workgroups
     // per CU" left mid-size launches with a mostly idle last round.
-    const unsigned cus = device_cus();
+    const unsigned cus = device_cus() * ntt1_wgs_per_cu(logn); // workgroup slots of the chip
     static const unsigned forced_rpw = [] { const char *e = std::getenv("TROYHIP_NTT1_RPW"); return e ? (unsigned)std::atoi(e) : 0u; }(); // tests: row loop at small batches
     auto plan = [&](unsigned nslots) { // -> rows per workgroup for a launch over `nslots` primes
         if (forced_rpw) return forced_rpw;
@@ -873,7 +1075,8 @@ void launch_ntt1(u64 *data, const u64 *src, const PrimeDesc *primes, const LimbM
         a.fp_red_mask = 0;
         if (kind == 2) { // where the values are reduced (fpmod.h): forward rounds A, B, C1, C2 from canonical inputs (the correction form starts below 5p);
                          // inverse rounds D', C', B', the first four stages of A', its last stage
-            const int fwd_rounds[4] = {5, 4, 3, 3}, inv_rounds[5] = {3, 3, 4, 4, 1};
+            const int la = logn - 10; // stages of the cross-sub-block round
+            const int fwd_rounds[4] = {la, 4, 3, 3}, inv_rounds[5] = {3, 3, 4, la - 1, 1};
             const FpPlan pl = inverse ? fp_plan_inv(pmax, 1.0, inv_rounds, 5) : fp_plan(pmax, cr ? 5.0 : 1.0, fwd_rounds, 4, 1.5);
             if (pl.out_bound < 0) throw Error(ST_LOGIC_ERROR, "ntt1: FP64 bound walk");
             a.fp_red_mask = pl.mask;
@@ -885,7 +1088,27 @@ void launch_ntt1(u64 *data, const u64 *src, const PrimeDesc *primes, const LimbM
         cls[ncls].lean = kind != 0;
         cls[ncls++].fp = kind == 2;
     }
+    auto launch_small = [&](const Cls &k, hipStream_t st, auto logn_tag) { // N = 2^12 .. 2^14 (ntt1s_*)
+        constexpr int LN = decltype(logn_tag)::value;
+        const Ntt1Args &x = k.a;
+        const dim3 grid(x.nslots * x.chunks), block(64u << (LN - 10));
+        if (k.fp) {
+            if (!inverse) TROY_LAUNCH(HIP_KERNEL_NAME(ntt1s_fwd_fp_kernel<LN>), grid, block, 0, st, x);
+            else if (x.md_ct) TROY_LAUNCH(HIP_KERNEL_NAME(ntt1s_inv_fp_kernel<LN, true>), grid, block, 0, st, x);
+            else TROY_LAUNCH(HIP_KERNEL_NAME(ntt1s_inv_fp_kernel<LN, false>), grid, block, 0, st, x);
+        } else if (!inverse) {
+            if (k.lean) TROY_LAUNCH(HIP_KERNEL_NAME(ntt1s_fwd_kernel<LN, true>), grid, block, 0, st, x);
+            else TROY_LAUNCH(HIP_KERNEL_NAME(ntt1s_fwd_kernel<LN, false>), grid, block, 0, st, x);
+        } else if (x.md_ct) {
+            if (k.lean) TROY_LAUNCH(HIP_KERNEL_NAME(ntt1s_inv_kernel<LN, true, true>), grid, block, 0, st, x);
+            else TROY_LAUNCH(HIP_KERNEL_NAME(ntt1s_inv_kernel<LN, false, true>), grid, block, 0, st, x);
+        } else if (k.lean) TROY_LAUNCH(HIP_KERNEL_NAME(ntt1s_inv_kernel<LN, true, false>), grid, block, 0, st, x);
+        else TROY_LAUNCH(HIP_KERNEL_NAME(ntt1s_inv_kernel<LN, false, false>), grid, block, 0, st, x);
+    };
     auto launch = [&](const Cls &k, hipStream_t st) {
+        if (logn == 14) { launch_small(k, st, std::integral_constant<int, 14>{}); return; }
+        if (logn == 13) { launch_small(k, st, std::integral_constant<int, 13>{}); return; }
+        if (logn == 12) { launch_small(k, st, std::integral_constant<int, 12>{}); return; }
         const Ntt1Args &x = k.a;
         const dim3 grid(x.nslots * x.chunks);
         if (k.fp) {
