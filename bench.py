@@ -396,8 +396,8 @@ def ntt_roofline(ta, capi, lib, w, reps):
     per_launch_s = ms.value / 1e3 / max(reps, 1)
     algo_bytes = 16.0 * N * rows
     achieved = algo_bytes / per_launch_s / 1e9
-    single = any("ntt1_" in k["name"] for k in kernels)
-    roof = {"bound": "hbm", "kernel": ("ntt1_fwd_kernel / ntt1_inv_kernel (single pass: one launch = one limb-transform per row)" if single else
+    single = any("ntt1_" in k["name"] or "ntt1s_" in k["name"] for k in kernels)
+    roof = {"bound": "hbm", "kernel": (("ntt1_fwd_kernel / ntt1_inv_kernel" if N == 32768 else "ntt1s_fwd_kernel / ntt1s_inv_kernel") + " (single pass: one launch = one limb-transform per row)" if single else
                                       "ntt2_kernel (strided pass + contiguous pass = one limb-transform per row)"),
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
             "algorithmic_bytes_per_launch": algo_bytes, "launch_us": round(per_launch_s * 1e6, 2), "limb_transforms_per_launch": rows,
@@ -503,7 +503,7 @@ def algorithmic_bytes(w, B):
     def add(name, b):
         t[name] = t.get(name, 0) + b
 
-    two_pass = logn != 15 or os.environ.get("TROYHIP_NTT") == "twopass"
+    two_pass = not 12 <= logn <= 15 or os.environ.get("TROYHIP_NTT") == "twopass"
     k1 = logn - 9 if logn - 9 <= 7 else 7
     logc = 11 - k1
     # multiply: extension of 4 polynomials, forward first passes (q: consumed in place, Bsk), tensor passes, inverse, floor/SK
@@ -521,16 +521,18 @@ def algorithmic_bytes(w, B):
     # takes the two-pass kernels for the second while the first still runs single-pass
     env_ntt = os.environ.get("TROYHIP_NTT", "")
 
-    def single(rows):
-        return not two_pass and (env_ntt == "single" or rows >= 4 * 256)
+    def single(rows):  # ntt1_supported (ntt1.hip): four rows per workgroup slot of the chip -- 1 / 1 / 2 / 4 slots per CU at N = 2^15 .. 2^12
+        return not two_pass and (env_ntt == "single" or rows >= 4 * 256 * {15: 1, 14: 1, 13: 2, 12: 4}[logn])
     qs = [int(p) for p in w.ctx.coeff_modulus]
 
     def n1(tail, primes, per_limb):  # up to three launches by prime class: FP64 rounds for [2^33, 2^50), guard-free integer rounds below 2^58, guarded
+        small = f"{logn}, " if logn != 15 else ""  # N = 2^12 .. 2^14: the ntt1s_* instances carry the size
+        stem = "ntt1s_inv" if logn != 15 else "ntt1_inv"
         for p in primes:
             if _fp_on() and (1 << 33) <= p < (1 << FP_MAX_BITS):
-                add(f"ntt1_inv_fp_kernel<{tail}>", per_limb)
+                add(f"{stem}_fp_kernel<{small}{tail}>", per_limb)
             else:
-                add(f"ntt1_inv_kernel<{'true' if (1 << 33) <= p < (1 << 58) else 'false'}, {tail}>", per_limb)
+                add(f"{stem}_kernel<{small}{'true' if (1 << 33) <= p < (1 << 58) else 'false'}, {tail}>", per_limb)
     # multiply: 3 polynomials in both bases
     if single(3 * B * (L + nb)):
         n1("false", q_primes + bsk_primes, 3 * B * 2 * P)

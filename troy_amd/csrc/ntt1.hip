@@ -1092,6 +1092,15 @@ void launch_ntt1(u64 *data, const u64 *src, const PrimeDesc *primes, const LimbM
         constexpr int LN = decltype(logn_tag)::value;
         const Ntt1Args &x = k.a;
         const dim3 grid(x.nslots * x.chunks), block(64u << (LN - 10));
+#ifndef TROYHIP_CPU_EMUL
+        if (ktime::enabled) { // the instance's name as rocprofv3 prints it (the launch macro would say "LN")
+            static thread_local char tagbuf[64];
+            if (k.fp) std::snprintf(tagbuf, sizeof(tagbuf), inverse ? "ntt1s_inv_fp_kernel<%d, %s>" : "ntt1s_fwd_fp_kernel<%d>", LN, x.md_ct ? "true" : "false");
+            else if (inverse) std::snprintf(tagbuf, sizeof(tagbuf), "ntt1s_inv_kernel<%d, %s, %s>", LN, k.lean ? "true" : "false", x.md_ct ? "true" : "false");
+            else std::snprintf(tagbuf, sizeof(tagbuf), "ntt1s_fwd_kernel<%d, %s>", LN, k.lean ? "true" : "false");
+            ktime::tag = tagbuf;
+        }
+#endif
         if (k.fp) {
             if (!inverse) TROY_LAUNCH(HIP_KERNEL_NAME(ntt1s_fwd_fp_kernel<LN>), grid, block, 0, st, x);
             else if (x.md_ct) TROY_LAUNCH(HIP_KERNEL_NAME(ntt1s_inv_fp_kernel<LN, true>), grid, block, 0, st, x);
