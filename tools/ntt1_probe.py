@@ -1,4 +1,4 @@
-"""Time the plain batched NTT of N = 2^15 (forward and inverse separately) at the key-switch shape of the benchmark
+"""Time the plain batched NTT of N = 2^15 (PROBE_N: another size; forward and inverse separately) at the key-switch shape of the benchmark
 (primes 60, 58 x 13, 60 bits; rows = B * 15 * 14).  TROYHIP_NTT=twopass selects ntt2.hip, default is ntt1.hip.
 usage: python tools/ntt1_probe.py [batch] [reps]"""
 import ctypes as C
@@ -16,7 +16,7 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 6
 lib = capi.load(os.environ.get("TROYHIP_LIB")) if os.environ.get("TROYHIP_LIB") else capi.load()
 api.KernelProvider.initialize(0, _lib=lib)
-N, bits = 32768, eval(os.environ.get("PROBE_BITS", "[60] + [58] * 13 + [60]"))
+N, bits = int(os.environ.get("PROBE_N", "32768")), eval(os.environ.get("PROBE_BITS", "[60] + [58] * 13 + [60]"))
 primes = ta.CoeffModulus.Create(N, bits)
 ctx = ta.SEALContext(capi.BFV, N, primes, ta.PlainModulus.Batching(N, 20))
 K, L = len(primes), len(primes) - 1

@@ -315,7 +315,8 @@ template <int LOGN, bool LEAN, bool CR, bool FP, class AfterB> __device__ __forc
     TROY_WAVE_SYNC();
     N1_STAMP(stamp0);
     after_round_b(); // FP64 instances: the next row's odd half is requested here (sixteen values are gone from the registers: room for it)
-    N1_SCHED_FENCE(); // the twiddle loads below stay below: hoisted over round B they would not fit the register budget
+    N1_SCHED_FENCE(); // the twiddle loads below stay below: hoisted over round B they would not fit the register budget (the FP64 instances, whose seven
+                      // twiddles are single doubles, were tried with them in front of round B at N <= 2^14, where they fit: no measurable change)
     N1_PRIO(2);
     {   // round C1: stages 9..11 on 8 values, registers = j5 j4 j3, lane = (j9..j6, j1 j0), iteration = j2; both iterations share
         // the seven twiddles
@@ -543,7 +544,15 @@ template <bool LEAN, bool CR, bool FP> __device__ __forceinline__ void ntt1_fwd_
             }
             __syncthreads();
             N1_STAMP(3 + 6 * hf);
-            if (hf == 1 && mm + 1 < m_end) load_half(xe, in_row(mm + 1), 0); // all 32 registers are free now: request the next limb's even half
+            if (hf == 1) {
+                if (mm + 1 < m_end) load_half(xe, in_row(mm + 1), 0); // all 32 registers are free now: request the next limb's even half
+                else {
+                    // the last row: say that the registers are dead -- otherwise the old values are live across the branch, and the compiler keeps them
+                    // alive by SPILLING eight of them in every row (64 B of scratch stores per thread and row for a reload that runs once)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) xe[r] = 0;
+                }
+            }
             // the FP64 instances compute faster than the odd half of the next row arrives when it is requested at the end of the row (plain
             // transform 167 ns per limb with 74 % VALU-busy): they request it after round B of the second half, under rounds C1 / C2
             constexpr bool EARLY_ODD = FP && N1_FP_EARLY_ODD;
@@ -552,7 +561,13 @@ template <bool LEAN, bool CR, bool FP> __device__ __forceinline__ void ntt1_fwd_
                                        cr_inv, CR && cacc ? cacc + 1024 * (16 * hf + wv) : nullptr);
             N1_STAMP(7 + 6 * hf);
         }
-        if (!(FP && N1_FP_EARLY_ODD) && mm + 1 < m_end) load_half(xo, in_row(mm + 1), 1);
+        if (!(FP && N1_FP_EARLY_ODD)) {
+            if (mm + 1 < m_end) load_half(xo, in_row(mm + 1), 1);
+            else {
+#pragma unroll
+                for (int r = 0; r < 16; r++) xo[r] = 0; // dead after the last row (see xe above)
+            }
+        }
     }
 }
 template <bool LEAN, bool CR> __global__ __launch_bounds__(N1_THREADS) void ntt1_fwd_kernel(Ntt1Args a) { ntt1_fwd_body<LEAN, CR, false>(a); }
