@@ -411,7 +411,7 @@ def ntt_roofline(ta, capi, lib, w, reps):
             "launch_kernels_note": "one forward + one inverse launch under per-kernel events in front of the timed launches (third use of the buffer); launch_us is the "
                                    "mean of the timed back-to-back launches.  A rocprofv3 --stats average over the whole command also contains the first, cold "
                                    "launch of each kernel (about 15 % slower) and that instrumented one"}
-    traffic = load_traffic()
+    traffic = load_traffic(w.name)
     if traffic and traffic.get("N") == N:
         per_row = traffic.get("hbm_bytes_per_limb_transform", {}).get("ntt1" if single else "ntt2")
         if per_row:
@@ -422,14 +422,14 @@ def ntt_roofline(ta, capi, lib, w, reps):
     return roof
 
 
-TRAFFIC_FILE = "r03_traffic.json"
+TRAFFIC_FILE = "r04_traffic_%s.json"  # one file per workload (tools/measure_traffic.sh <workload>)
 
 
-def load_traffic():
+def load_traffic(workload):
     """PMC HBM bytes per kernel (tools/measure_traffic.sh), valid only for the build they were measured on: the file carries the
     library's build id (troyhip_build_id: hash of the sources) and is ignored -- `traffic: null` -- when the loaded library differs"""
     try:
-        t = json.load(open(os.path.join(ROOT, "profiles", TRAFFIC_FILE)))
+        t = json.load(open(os.path.join(ROOT, "profiles", TRAFFIC_FILE % workload)))
     except Exception:
         return None
     try:
@@ -463,7 +463,7 @@ def per_kernel(ta, capi, lib, w):
     ks = ktime_report(capi, lib)
     capi.check(lib, lib.troyhip_ktime_enable(0))
     algo = algorithmic_bytes(w, w.profile_units)
-    tinfo = load_traffic() or {}
+    tinfo = load_traffic(w.name) or {}
     traffic = tinfo.get("per_kernel", {})
     out = []
     total_us = sum(k["total_us"] for k in ks) or 1.0
@@ -708,6 +708,13 @@ def matmul_roofline(ta, capi, lib, w):
     roof = {"bound": "hbm", "kernel": k["name"], "peak": HBM_PEAK_GBPS, "unit": "GB/s", "traffic": None, "launch_us": round(us, 2), "calls_per_step": k["calls"]}
     if per_call:
         roof.update(achieved=round(per_call / (us * 1e-6) / 1e9, 1), frac=round(per_call / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4), algorithmic_bytes_per_launch=per_call)
+    tinfo = load_traffic(w.name)  # PMC bytes of the same kernel over one step at the same batch (tools/measure_traffic.sh), per launch
+    tr = (tinfo or {}).get("per_kernel", {}).get(k["name"])
+    if tr and tinfo.get("batch") == w.B and tr.get("calls"):
+        roof["traffic"] = int(tr["hbm_bytes"] / tr["calls"])
+        if per_call:
+            roof["traffic_ratio"] = round(roof["traffic"] / per_call, 3)
+        roof["traffic_source"] = tinfo.get("source")
     return roof
 
 
@@ -782,6 +789,7 @@ def main():
         args.steps = wl.get("steps", 100)
     B = args.batch or wl["batch"]
     w = Workload(ta, capi, lib, wl, B, args.streams or wl["streams"], rank)
+    w.name = args.workload
     if not args.roofline_only:
         w.prime()
 
@@ -887,23 +895,28 @@ def cpu_baseline(w):
     if kind == "mul_relin":
         xa = synth.uniform_ct(0x5EED, primes[:L], 2, N)[0]
         xb = synth.uniform_ct(0x5EEE, primes[:L], 2, N)[0]
-        reps = 25 if N >= 32768 else 160  # about 5 s of single-core work at either size (0.2 s / 0.03 s per op)
+        reps = 12 if N >= 32768 else 80  # about 2.5 s of single-core work at either size (0.2 s / 0.03 s per op)
         if use_ref:
             secs = E.time_mul_relin(Ct(xa), Ct(xb), reps)
         else:
             secs = E.time_mul_relin(np.ascontiguousarray(xa), np.ascontiguousarray(xb), reps, 1)
         out = {"value": round(reps / secs, 3), "unit": "ops/s", "cores": 1, "kind": knd, "sample": f"{reps} multiply+relinearize ops, 1 thread, {what}"}
-        # the same work on all host cores, one evaluator per thread over disjoint ciphertexts (the port: its evaluators
-        # share nothing but read-only tables), one thread per PHYSICAL core (about 70 MB of working set each at N = 2^15), about 8 s.
+        # the same work on all host cores.  With the reference built here (oracle/_ref): N single-threaded PROCESSES, one reference
+        # evaluator each, pinned to distinct physical cores spread over the sockets, started together -- no shared allocator, no shared pages
+        # (round 3's threads of the port fell from 75 to 51 ops/s between 32 and 128 threads: allocator and page-fault contention in one
+        # address space, not the algorithm).  Without the reference: the port's thread pool as before.
         cores = physical_cores()
-        if cores > 1:
-            # the port is memory-bound well before every core is busy (about 70 MB of working set per thread at N = 2^15): sweep the thread
-            # count and report the BEST, about 3 s each (round 2 reported the largest count, which was the slowest)
+        if cores > 1 and use_ref:
+            try:
+                out["all_cores"] = _all_cores_reference(scheme, N, primes, t, L, cores)
+            except Exception as e:  # informational
+                out["all_cores"] = {"error": str(e)[:200]}
+        elif cores > 1:
             O = oracle.Oracle(scheme, N, primes, t)
             O.set_kswitch_key(0, rk)
             sweep = {}
-            for threads in sorted({min(cores, n) for n in (16, 32, 64, 128, cores)}):
-                reps_all = threads * (4 if N >= 32768 else 40)
+            for threads in sorted({min(cores, n) for n in (32, 64, cores)}):
+                reps_all = threads * (3 if N >= 32768 else 30)
                 secs = O.time_mul_relin(np.ascontiguousarray(xa), np.ascontiguousarray(xb), reps_all, threads)
                 sweep[threads] = round(reps_all / secs, 3)
             best = max(sweep, key=sweep.get)
@@ -955,6 +968,92 @@ def cpu_baseline(w):
         secs = time.perf_counter() - t0
         return {"value": round(n / secs, 3), "unit": "rows/s", "cores": 1, "kind": knd, "sample": f"{n} input rows ({rows_blk}x{cols_blk} multiplyPlain + adds each), 1 thread, {what}"}
     return None
+
+
+_WORKER = r"""
+import os, sys, time
+cpu, root = int(sys.argv[1]), sys.argv[2]
+try:
+    os.sched_setaffinity(0, {cpu})
+except OSError:
+    pass
+sys.path.insert(0, root)
+import numpy as np
+from oracle import ref
+from troy_amd import synth
+scheme, N, t, L = int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6])
+primes = [int(x) for x in sys.argv[7].split(",")]
+E = ref.Ref(scheme, N, primes, t)
+E.set_kswitch_key(0, synth.uniform_kswitch_key(0xC0FFEE, primes, N))
+a = ref.Ct(synth.uniform_ct(0x5EED + cpu, primes[:L], 2, N)[0])   # disjoint ciphertexts per worker
+b = ref.Ct(synth.uniform_ct(0x6EED + cpu, primes[:L], 2, N)[0])
+E.time_mul_relin(a, b, 1)                                          # first touch of every table and scratch page
+print("ready", flush=True)
+for line in sys.stdin:
+    w = line.split()
+    if not w or w[0] == "quit":
+        break
+    t0, reps = float(w[1]), int(w[2])
+    while time.time() < t0:
+        pass
+    start = time.time()
+    E.time_mul_relin(a, b, reps)
+    print("done %.6f %.6f" % (start, time.time()), flush=True)
+"""
+
+
+def _all_cores_reference(scheme, N, primes, t, L, cores):
+    """multiply + relinearize on the reference's own CPU path (oracle/_ref) in one single-threaded process per physical core: the processes set
+    up once, then run timed rounds with 32, 64 and all of them active (started together on a wall-clock mark); rate = ops of the round / (last
+    end - first start).  About 10 s in all."""
+    import subprocess
+    allowed = sorted(os.sched_getaffinity(0))
+    seen, cpus = set(), []
+    for cpu in allowed:  # one logical CPU per physical core, in CPU order (sockets / CCDs in their natural order)
+        try:
+            sib = open(f"/sys/devices/system/cpu/cpu{cpu}/topology/thread_siblings_list").read().strip()
+            core = min(int(x) for part in sib.split(",") for x in part.split("-"))
+        except (OSError, ValueError):
+            core = cpu
+        if core not in seen:
+            seen.add(core)
+            cpus.append(cpu)
+    n = len(cpus)
+    args = [str(scheme), str(N), str(t), str(L), ",".join(str(p) for p in primes)]
+    procs = [subprocess.Popen([sys.executable, "-c", _WORKER, str(c), ROOT] + args, stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True) for c in cpus]
+    try:
+        for p in procs:
+            if p.stdout.readline().strip() != "ready":
+                raise RuntimeError("a baseline worker did not start")
+        reps = 3 if N >= 32768 else 24
+        sweep = {}
+        for count in sorted({min(n, c) for c in (32, 64, n)}):
+            step = n / count
+            active = [procs[int(i * step)] for i in range(count)]  # spread evenly over the core list: both sockets at every count
+            t0 = time.time() + 0.2
+            for p in active:
+                p.stdin.write(f"run {t0:.6f} {reps}\n")
+                p.stdin.flush()
+            spans = [p.stdout.readline().split() for p in active]
+            first, last = min(float(x[1]) for x in spans), max(float(x[2]) for x in spans)
+            sweep[count] = round(count * reps / (last - first), 3)
+    finally:
+        for p in procs:
+            try:
+                p.stdin.write("quit\n")
+                p.stdin.flush()
+            except Exception:
+                pass
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except Exception:
+                p.kill()
+    best = max(sweep, key=sweep.get)
+    return {"value": sweep[best], "unit": "ops/s", "cores": best, "kind": "reference", "cpu": _cpu_model(), "physical_cores": n,
+            "process_sweep": {str(k): v for k, v in sweep.items()},
+            "sample": f"best of {sorted(sweep)} single-threaded processes ({best}), each the reference CPU path (src/troy_cpu.h, oracle/_ref) on its own physical core "
+                      f"over its own ciphertexts, {reps} multiply+relinearize ops per process and round, started together"}
 
 
 def bind_to_device_numa(capi, lib, device):
