@@ -895,7 +895,7 @@ def cpu_baseline(w):
     if kind == "mul_relin":
         xa = synth.uniform_ct(0x5EED, primes[:L], 2, N)[0]
         xb = synth.uniform_ct(0x5EEE, primes[:L], 2, N)[0]
-        reps = 12 if N >= 32768 else 80  # about 2.5 s of single-core work at either size (0.2 s / 0.03 s per op)
+        reps = 8 if N >= 32768 else 60  # about 2 s of single-core work at either size (0.2 s / 0.03 s per op)
         if use_ref:
             secs = E.time_mul_relin(Ct(xa), Ct(xb), reps)
         else:
@@ -984,7 +984,7 @@ from troy_amd import synth
 scheme, N, t, L = int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5]), int(sys.argv[6])
 primes = [int(x) for x in sys.argv[7].split(",")]
 E = ref.Ref(scheme, N, primes, t)
-E.set_kswitch_key(0, synth.uniform_kswitch_key(0xC0FFEE, primes, N))
+E.set_kswitch_key(0, np.load(sys.argv[8], mmap_mode="r"))            # the relinearization key, generated once by the parent
 a = ref.Ct(synth.uniform_ct(0x5EED + cpu, primes[:L], 2, N)[0])   # disjoint ciphertexts per worker
 b = ref.Ct(synth.uniform_ct(0x6EED + cpu, primes[:L], 2, N)[0])
 E.time_mul_relin(a, b, 1)                                          # first touch of every table and scratch page
@@ -1019,13 +1019,17 @@ def _all_cores_reference(scheme, N, primes, t, L, cores):
             seen.add(core)
             cpus.append(cpu)
     n = len(cpus)
-    args = [str(scheme), str(N), str(t), str(L), ",".join(str(p) for p in primes)]
+    import numpy as np
+    from troy_amd import synth
+    keyfile = f"/dev/shm/troy_bench_key_{os.getpid()}.npy" if os.path.isdir("/dev/shm") else os.path.join(ROOT, f".troy_bench_key_{os.getpid()}.npy")
+    np.save(keyfile, synth.uniform_kswitch_key(0xC0FFEE, primes, N))
+    args = [str(scheme), str(N), str(t), str(L), ",".join(str(p) for p in primes), keyfile]
     procs = [subprocess.Popen([sys.executable, "-c", _WORKER, str(c), ROOT] + args, stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True) for c in cpus]
     try:
         for p in procs:
             if p.stdout.readline().strip() != "ready":
                 raise RuntimeError("a baseline worker did not start")
-        reps = 3 if N >= 32768 else 24
+        reps = 2 if N >= 32768 else 16
         sweep = {}
         for count in sorted({min(n, c) for c in (32, 64, n)}):
             step = n / count
@@ -1049,6 +1053,10 @@ def _all_cores_reference(scheme, N, primes, t, L, cores):
                 p.wait(timeout=10)
             except Exception:
                 p.kill()
+        try:
+            os.remove(keyfile)
+        except OSError:
+            pass
     best = max(sweep, key=sweep.get)
     return {"value": sweep[best], "unit": "ops/s", "cores": best, "kind": "reference", "cpu": _cpu_model(), "physical_cores": n,
             "process_sweep": {str(k): v for k, v in sweep.items()},

@@ -541,66 +541,66 @@ def test_bfv_multiply_every_limb_count(K, big, gpu, oracle_lib):
     cases.check_bfv_multiply_limb_count(K, big=big)
 
 
-@pytest.mark.parametrize("env", [{"TROYHIP_BEHZ": "valu"}, {"TROYHIP_BEHZ": "mfma1"}, {"TROYHIP_BEHZ": "mfma1", "TROYHIP_BEHZ_FOLD": "0"}])
-def test_behz_kernel_forms_agree(env, gpu, oracle_lib):
-    """the VALU kernels and the first matrix-core form (16-shift rows, folded / unfolded correction term) are selected by environment
-    switches that are read once per process: a child process runs the same oracle comparison under each switch and must reproduce
-    this process's result hashes (default: the 8-shift form of behz2.hip)"""
-    import subprocess
-    import sys
-    Ks = [3, 6, 8, 15]
-    here = [cases.check_bfv_multiply_limb_count(K, big=K % 2 == 0) for K in Ks]
-    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
-            "import troy_amd as ta, cases\n"
-            "ta.KernelProvider.initialize(0)\n"
-            "print(' '.join(cases.check_bfv_multiply_limb_count(K, big=K %% 2 == 0) for K in %r))\n") % (os.path.dirname(os.path.abspath(__file__)), os.path.dirname(os.path.dirname(os.path.abspath(__file__))), Ks)
-    out = subprocess.run([sys.executable, "-c", code], env={**os.environ, **env}, capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0, out.stderr[-2000:]
-    assert out.stdout.split()[-len(Ks):] == here
+PROBES_LIB = os.path.join(ROOT, "tools", "probe_libs", "libtroyhip_probes.so")  # `make -C troy_amd/csrc probes` (__graft_entry__.build() makes it)
 
 
-@pytest.mark.parametrize("env", [{"TROYHIP_KS": "split"}, {"TROYHIP_TENSOR": "split"}, {"TROYHIP_BEHZ": "valu"}, {"TROYHIP_MODDOWN": "split"}, {"TROYHIP_FP64": "off"},
-                                 {"TROYHIP_AUX_BASE": "reference"}, {"TROYHIP_AUX_BASE": "reference", "TROYHIP_BEHZ": "valu"},
-                                 {"TROYHIP_SMALL": "split"}, {"TROYHIP_SMALL": "merged"}, {"TROYHIP_SMALL": "merged", "TROYHIP_FP64": "off"}])
-def test_unfused_kernel_paths_agree(env, gpu):
-    """the unfused key-switch inner product, the unfused tensor, the VALU BEHZ kernels and the element-wise BFV / BGV mod-down instead of
-    the inverse transform's epilogue (environment switches, read once per process) give the same limbs as the default path, which the
-    tests above pin against the oracle and the golden files"""
+def _hashes_in_child(names, env, timeout=900):
+    """cases.mul_relin_hash of `names` in a child process under `env` (the library reads its switches once per process)"""
     import subprocess
     import sys
-    names = ["cfgA_bfv_n4096_k3", "cfgB_bfv_n8192_k5", "bgv_n4096_k3", "ckks_n4096_k4", "bfv_n16384_k4"]
-    here = [cases.mul_relin_hash(n) for n in names]
     tests_dir = os.path.dirname(os.path.abspath(__file__))
     code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
             "import troy_amd as ta, cases\n"
             "ta.KernelProvider.initialize(0)\n"
             "print(' '.join(cases.mul_relin_hash(n) for n in %r))\n") % (tests_dir, os.path.dirname(tests_dir), names)
-    out = subprocess.run([sys.executable, "-c", code], env={**os.environ, **env}, capture_output=True, text=True, timeout=600)
+    out = subprocess.run([sys.executable, "-c", code], env={**os.environ, **env}, capture_output=True, text=True, timeout=timeout)
     assert out.returncode == 0, out.stderr[-2000:]
-    assert out.stdout.split()[-len(names):] == here
+    return out.stdout.split()[-len(names):]
 
 
-@pytest.mark.parametrize("env", [{"TROYHIP_NTT": "single"}, {"TROYHIP_NTT": "twopass"}, {"TROYHIP_BFLY": "guarded"}, {"TROYHIP_NTT": "single", "TROYHIP_BFLY": "guarded"}, {"TROYHIP_FP64": "off"}, {"TROYHIP_AUX_BASE": "reference"},
-                                 {"TROYHIP_NTT": "single", "TROYHIP_MODDOWN": "split"}, {"TROYHIP_NTT": "single", "TROYHIP_CORR": "split"},
+SMALL_NAMES = ["cfgA_bfv_n4096_k3", "cfgB_bfv_n8192_k5", "bgv_n4096_k3", "ckks_n4096_k4", "bfv_n16384_k4"]
+HEADLINE_NAMES = ["cfgNS_bfv_n32768_k15", "cfgC_ckks_n32768_k15"]
+
+
+@pytest.mark.parametrize("env", [{"TROYHIP_NTT": "single"}, {"TROYHIP_NTT": "twopass"}, {"TROYHIP_FP64": "off"}, {"TROYHIP_AUX_BASE": "reference"},
+                                 {"TROYHIP_SMALL": "split"}, {"TROYHIP_SMALL": "merged"}, {"TROYHIP_SMALL": "merged", "TROYHIP_FP64": "off"},
+                                 {"TROYHIP_NTT": "single", "TROYHIP_FP64": "off"}])
+def test_library_switches_agree(env, gpu):
+    """the FOUR switches the shipped library reads (rt.h: TROYHIP_NTT, TROYHIP_FP64, TROYHIP_AUX_BASE, TROYHIP_SMALL; read once per process): single-pass
+    against two-pass transforms at N = 2^12 .. 2^14, integer against FP64 instances, the reference's auxiliary base against the library's own, the
+    merged forms of small launches against the per-base kernels -- the same limbs through multiply, relinearize (rescale) and a rotation as the
+    default path, which the tests above pin against the oracle and the golden files"""
+    assert _hashes_in_child(SMALL_NAMES, env) == [cases.mul_relin_hash(n) for n in SMALL_NAMES]
+
+
+@pytest.mark.parametrize("env", [{"TROYHIP_NTT": "single"}, {"TROYHIP_NTT": "twopass"}, {"TROYHIP_FP64": "off"}, {"TROYHIP_AUX_BASE": "reference"},
                                  {"TROYHIP_SMALL": "split"}, {"TROYHIP_SMALL": "merged"}])
-def test_ntt_forms_agree_at_headline_size(env, gpu):
-    """N = 2^15: the single-pass transform forced at a small batch (by default it takes launches of four rows per CU and more), the
-    two-pass transform forced, guarded butterflies instead of the guard-free ones, the BFV mod-down in its own kernel instead of in the
-    inverse transform's epilogue, and the CKKS divide-and-round correction as element-wise kernels instead of inside the forward
-    transform (environment switches, read once per process) give the same limbs through multiply + relinearize as the default path, which the golden files pin on the reference"""
-    import subprocess
-    import sys
-    names = ["cfgNS_bfv_n32768_k15", "cfgC_ckks_n32768_k15"]
-    names = [n for n in names if n in cases.CONFIGS]
-    here = [cases.mul_relin_hash(n) for n in names]
-    tests_dir = os.path.dirname(os.path.abspath(__file__))
-    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
-            "import troy_amd as ta, cases\n"
-            "ta.KernelProvider.initialize(0)\n"
-            "print(' '.join(cases.mul_relin_hash(n) for n in %r))\n") % (tests_dir, os.path.dirname(tests_dir), names)
-    out = subprocess.run([sys.executable, "-c", code], env={**os.environ, **env}, capture_output=True, text=True, timeout=900)
-    assert out.returncode == 0, out.stderr[-2000:]
-    assert out.stdout.split()[-len(names):] == here and names
+def test_library_switches_agree_at_headline_size(env, gpu):
+    """the same at N = 2^15 (BFV headline parameters and the CKKS chain's): the single-pass transform forced at a small batch (by default it takes
+    launches of four rows per CU and more), the two-pass transform forced, ..."""
+    names = [n for n in HEADLINE_NAMES if n in cases.CONFIGS]
+    assert names and _hashes_in_child(names, env) == [cases.mul_relin_hash(n) for n in names]
+
+
+@pytest.mark.skipif(not os.path.exists(PROBES_LIB), reason="tools/probe_libs/libtroyhip_probes.so: make -C troy_amd/csrc probes")
+@pytest.mark.parametrize("env", [{"TROYHIP_KS": "split"}, {"TROYHIP_TENSOR": "split"}, {"TROYHIP_BEHZ": "valu"}, {"TROYHIP_MODDOWN": "split"},
+                                 {"TROYHIP_AUX_BASE": "reference", "TROYHIP_BEHZ": "valu"}, {"TROYHIP_BFLY": "guarded"}])
+def test_probe_build_fallback_forms_agree(env, gpu):
+    """The unfused kernels are the library's fallback for the shapes the fused ones do not take (N < 4096, N = 2^17, other ciphertext sizes, more
+    than 15 limbs: all exercised by the golden scenarios).  The PROBE build (-DTROYHIP_PROBES) can force them at a fused shape: the unfused key-switch
+    inner product, the unfused tensor, the VALU BEHZ kernels, the element-wise BFV / BGV mod-down, guarded butterflies everywhere -- same limbs as
+    the shipped library's default path"""
+    assert _hashes_in_child(SMALL_NAMES, {**env, "TROYHIP_LIB": PROBES_LIB}) == [cases.mul_relin_hash(n) for n in SMALL_NAMES]
+
+
+@pytest.mark.skipif(not os.path.exists(PROBES_LIB), reason="tools/probe_libs/libtroyhip_probes.so: make -C troy_amd/csrc probes")
+@pytest.mark.parametrize("env", [{"TROYHIP_BFLY": "guarded"}, {"TROYHIP_NTT": "single", "TROYHIP_BFLY": "guarded"}, {"TROYHIP_NTT": "single", "TROYHIP_MODDOWN": "split"},
+                                 {"TROYHIP_NTT": "single", "TROYHIP_CORR": "split"}])
+def test_probe_build_fallback_forms_agree_at_headline_size(env, gpu):
+    """N = 2^15 on the probe build: guarded butterflies instead of the guard-free ones, the BFV mod-down in its own kernel instead of in the inverse
+    transform's epilogue, the CKKS divide-and-round correction as element-wise kernels instead of inside the forward transform"""
+    names = [n for n in HEADLINE_NAMES if n in cases.CONFIGS]
+    assert names and _hashes_in_child(names, {**env, "TROYHIP_LIB": PROBES_LIB}) == [cases.mul_relin_hash(n) for n in names]
 
 
 def _run_bench(args, timeout=900):

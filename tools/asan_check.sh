@@ -12,7 +12,7 @@ LD_PRELOAD=$(gcc -print-file-name=libasan.so) TROYHIP_NTT=single python tools/as
 # UndefinedBehaviorSanitizer over the same drive (default kernels and the alternative forms)
 make -s -j8 -C troy_amd/csrc emul OBJDIR=/tmp/troy_build_ubsan EMUL_OUT=/tmp/libtroyhip_emul_ubsan.so \
      EMUL_FLAGS="-O1 -g -fsanitize=undefined -fno-sanitize-recover=undefined" EMUL_LDFLAGS="-fsanitize=undefined"
-for e in TROYHIP_NTT=single TROYHIP_BEHZ=mfma1 TROYHIP_BEHZ=valu TROYHIP_NTT=twopass; do
+for e in TROYHIP_NTT=single TROYHIP_BEHZ=valu TROYHIP_NTT=twopass; do
     env $e TROY_EMUL_LIB=/tmp/libtroyhip_emul_ubsan.so LD_PRELOAD=$(gcc -print-file-name=libubsan.so) python tools/asan_run.py
 done
 for t in test_troyn test_troyn_app; do

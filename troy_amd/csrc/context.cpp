@@ -50,62 +50,6 @@ static inline int8_t balanced_digit(u64 m, int j) {
 // output 2 rb + l / 32, see the D layout of the instruction)
 // bias (optional): limb `bias_slot` is the constant input 1 (digit 0 = 1); its column holds the 16 balanced digits of bias[o], one per shift
 typedef unsigned __int128 u128;
-static std::vector<uint8_t> pack_mfma_rows(const std::vector<u64> &entries, int n_out, int bias_slot = -1, const std::vector<u128> *bias = nullptr) {
-    const int RB = (n_out + 1) / 2;
-    std::vector<uint8_t> f((size_t)RB * 4 * 64 * 16, 0);
-    std::vector<int8_t> bd((size_t)n_out * 16, 0);
-    if (bias)
-        for (int o = 0; o < n_out; o++) {
-            u128 v = (*bias)[o];
-            for (int s = 0; s < 16; s++) {
-                int d = (int)(v & 0xFF);
-                v >>= 8;
-                if (d >= 128) { d -= 256; v += 1; }
-                bd[(size_t)o * 16 + s] = (int8_t)d;
-            }
-            if (v != 0) throw Error(ST_LOGIC_ERROR, "BEHZ bias does not fit 16 balanced digits");
-        }
-    for (int rb = 0; rb < RB; rb++)
-        for (int kb = 0; kb < 4; kb++)
-            for (int lane = 0; lane < 64; lane++) {
-                const int m = lane % 32, o = 2 * rb + (m / 4) % 2, s = (m / 8) * 4 + m % 4;
-                for (int t = 0; t < 16; t++) {
-                    const int k = 32 * kb + 16 * (lane / 32) + t, limb = k / 8, i = k % 8;
-                    int8_t v = 0;
-                    if (o < n_out) {
-                        if (limb == bias_slot) v = i == 0 ? bd[(size_t)o * 16 + s] : 0;
-                        else v = balanced_digit(entries[(size_t)o * 16 + limb], s - i);
-                    }
-                    f[(((size_t)rb * 4 + kb) * 64 + lane) * 16 + t] = (uint8_t)v;
-                }
-            }
-    return f;
-}
-// TROYHIP_BEHZ_FOLD=0 keeps the correction term in the epilogue at every size (tests compare both forms); read at context creation
-static bool behz_fold_enabled() {
-    const char *e = getenv("TROYHIP_BEHZ_FOLD");
-    return !(e && e[0] == '0');
-}
-// a multiple of p in [2^bits, 2^(bits+1)): added to a sum that may be negative by less than 2^bits, it changes nothing modulo p
-static u128 bias_multiple(u64 p, int bits) {
-    int len = 64 - __builtin_clzll(p);
-    return (u128)p << (bits + 1 - len);
-}
-// the m_tilde row only needs the result modulo 2^32: tile rows m with m % 8 < 4 carry shift m % 4, the rest is zero
-static std::vector<uint8_t> pack_mfma_mt(const std::vector<u64> &row) {
-    std::vector<uint8_t> f((size_t)4 * 64 * 16, 0);
-    for (int kb = 0; kb < 4; kb++)
-        for (int lane = 0; lane < 64; lane++) {
-            const int m = lane % 32;
-            if (m >= 8) continue;
-            const int s = m % 4;
-            for (int t = 0; t < 16; t++) {
-                const int k = 32 * kb + 16 * (lane / 32) + t, limb = k / 8, i = k % 8;
-                f[((size_t)kb * 64 + lane) * 16 + t] = (uint8_t)balanced_digit(row[limb], s - i);
-            }
-        }
-    return f;
-}
 
 // ---- second matrix-core form (behz2.hip).  W[o][limb] are the conversion-matrix entries of output o (already holding every folded
 // row factor); A-matrix row (o, s) holds at k = (limb, i) the balanced digit s of W[o][limb] 2^(8 i) mod p[o].  Tile row m of
@@ -148,10 +92,10 @@ static BehzK2 make_k2(u64 p) {
     k.mu = (u32)std::min<u128>(((u128)1 << (sh + 32)) / p, 0xFFFFFFFFu);
     return k;
 }
-// TROYHIP_BEHZ selects the base-conversion kernels: "valu", "mfma1" (16-shift Toeplitz rows) or, by default, the 8-shift form
+// probe builds: TROYHIP_BEHZ=valu keeps the matrix-core tables unbuilt (the VALU kernels then run at every size)
 static bool behz_v2_enabled() {
-    const char *e = getenv("TROYHIP_BEHZ");
-    return !(e && (e[0] == 'v' || strcmp(e, "mfma1") == 0));
+    const char *e = probe_env("TROYHIP_BEHZ");
+    return !(e && e[0] == 'v');
 }
 
 template <class T> T *Context::upload(const std::vector<T> &v, std::vector<void *> &owner) {
@@ -228,9 +172,9 @@ const Level &Context::level(int limbs) const {
     return it->second;
 }
 
-// TROYHIP_BFLY=guarded: no prime is treated as "lean" (tests / A-B runs of the guard-free butterflies)
+// probe builds: TROYHIP_BFLY=guarded -- no prime is treated as "lean" (A/B runs of the guard-free butterflies)
 static bool lean_allowed() {
-    static const bool on = [] { const char *e = std::getenv("TROYHIP_BFLY"); return !(e && std::strcmp(e, "guarded") == 0); }();
+    static const bool on = [] { const char *e = probe_env("TROYHIP_BFLY"); return !(e && std::strcmp(e, "guarded") == 0); }();
     return on;
 }
 // TROYHIP_FP64=off: no prime takes the FP64 instances (tests / A-B runs against the integer kernels)
@@ -384,53 +328,9 @@ void Context::upload_tables() {
         c->ext_mt_row = upload(mt_row, lv.dev_blocks);
         c->neg_inv_q_mod_mt = r.neg_inv_prod_q_mod_mtilde;
         c->ext_q = upload(ext_q, lv.dev_blocks);
-        if (L <= 16 && nBsk <= 16) { // matrix-core path (behz.hip): int8 balanced-digit Toeplitz form of the same matrices
-            std::vector<u64> em((size_t)nBsk * 16, 0), mt(16, 0);
-            for (int o = 0; o < nBsk; o++)
-                for (int l = 0; l < L; l++) em[(size_t)o * 16 + l] = host::mul_mod(r.q_to_Bsk.mat[o][l], r.inv_mtilde_mod_Bsk[o], r.Bsk[o]);
-            for (int l = 0; l < L; l++) mt[l] = mt_row[l];
-            c->ext_fold = (behz_fold_enabled() && (L % 4 == 1 || L % 4 == 2)) ? L % 4 : 0; // the two limbs after the last one are padding of the last k-block
-            if (c->ext_fold) { // |r q m_tilde^-1| < 2^31 * 2^61
-                std::vector<u128> bias(nBsk);
-                for (int o = 0; o < nBsk; o++) { em[(size_t)o * 16 + L] = ext_q[o]; bias[o] = bias_multiple(r.Bsk[o], 93); }
-                c->ext_frag = upload(pack_mfma_rows(em, nBsk, L + 1, &bias), lv.dev_blocks);
-            } else
-                c->ext_frag = upload(pack_mfma_rows(em, nBsk), lv.dev_blocks);
-            c->ext_mt_frag = upload(pack_mfma_mt(mt), lv.dev_blocks);
-        }
         c->floor_pre = upload(floor_pre, lv.dev_blocks);
         c->floor_mat3 = upload(floor_mat, lv.dev_blocks);
         c->floor_t3 = upload(floor_t, lv.dev_blocks);
-        if (L <= 16 && nBsk <= 16 && nB <= 16) {
-            std::vector<u64> f1((size_t)nBsk * 16, 0), traw(nBsk), f2((size_t)L * 16, 0), fm(2 * 16, 0);
-            for (int o = 0; o < nBsk; o++) {
-                const u64 p = r.Bsk[o];
-                u64 fscale = r.inv_prod_q_mod_Bsk[o];
-                if (o < nB) fscale = host::mul_mod(fscale, r.B_to_q.inv_punct[o], p);
-                traw[o] = host::mul_mod(t % p, fscale, p);
-                for (int l = 0; l < L; l++) {
-                    const u64 f = host::mul_mod(r.q_to_Bsk.mat[o][l], fscale, p);
-                    f1[(size_t)o * 16 + l] = f ? p - f : 0;
-                }
-            }
-            for (int l = 0; l < L; l++)
-                for (int b = 0; b < nB; b++) f2[(size_t)l * 16 + b] = r.B_to_q.mat[l][b];
-            for (int b = 0; b < nB; b++) fm[b] = fm[16 + b] = r.B_to_msk.mat[0][b];
-            c->floor_frag1 = upload(pack_mfma_rows(f1, nBsk), lv.dev_blocks);
-            c->floor_t = upload(traw, lv.dev_blocks);
-            c->floor_fold = (behz_fold_enabled() && (nB % 4 == 1 || nB % 4 == 2) && (nB + 3) / 4 == (std::max(L, nB) + 3) / 4) ? nB % 4 : 0;
-            if (c->floor_fold) { // |alpha (B mod q_l)| < 2^60 * 2^60
-                std::vector<u128> bias(L);
-                for (int l = 0; l < L; l++) {
-                    const u64 pb = r.prod_B_mod_q[l] % r.q[l];
-                    f2[(size_t)l * 16 + nB] = pb ? r.q[l] - pb : 0;
-                    bias[l] = bias_multiple(r.q[l], 121);
-                }
-                c->floor_frag2 = upload(pack_mfma_rows(f2, L, nB + 1, &bias), lv.dev_blocks);
-            } else
-                c->floor_frag2 = upload(pack_mfma_rows(f2, L), lv.dev_blocks);
-            c->floor_msk_frag = upload(pack_mfma_rows(fm, 2), lv.dev_blocks);
-        }
         // the one-step quotient estimate of the behz2 epilogues holds for every output prime >= 2^33 (behz2.hip, header); the auxiliary primes are
         // 61 bits in the reference's base and 58 or 50 bits in the library's own (RnsLevel::build)
         bool big_bsk = true;

@@ -8,26 +8,29 @@
 
 namespace troyhip {
 
-// TROYHIP_TENSOR=split keeps the ciphertext tensor of the BEHZ multiply in its own kernel (tests, measurements); read once
+// The fused forms below are what runs wherever the kernels support the shape; the unfused kernels are the fallback for the shapes they do not (N < 4096,
+// N = 2^17, ciphertext sizes other than 2 x 2, ...).  Probe builds (-DTROYHIP_PROBES: the CPU emulator build of the test suite, `make probes`) can force a
+// fallback at a fused shape: TROYHIP_TENSOR / TROYHIP_KS / TROYHIP_MODDOWN / TROYHIP_CORR = split.  The shipped library ignores them.
+// TROYHIP_TENSOR=split keeps the ciphertext tensor of the BEHZ multiply in its own kernel; read once
 static bool tensor_fused() {
-    static const bool v = [] { const char *e = getenv("TROYHIP_TENSOR"); return !(e && e[0] == 's'); }();
+    static const bool v = [] { const char *e = probe_env("TROYHIP_TENSOR"); return !(e && e[0] == 's'); }();
     return v;
 }
 // TROYHIP_KS=split keeps the transforms and the inner product in separate kernels (tests, measurements); read once
 static bool ks_fused() {
-    static const bool v = [] { const char *e = getenv("TROYHIP_KS"); return !(e && e[0] == 's'); }();
+    static const bool v = [] { const char *e = probe_env("TROYHIP_KS"); return !(e && e[0] == 's'); }();
     return v;
 }
 
 // TROYHIP_MODDOWN=split keeps the BFV mod-down in its own kernel behind the inverse transform (tests, measurements); read once
 static bool ks_moddown_fused() {
-    static const bool v = [] { const char *e = getenv("TROYHIP_MODDOWN"); return !(e && e[0] == 's'); }();
+    static const bool v = [] { const char *e = probe_env("TROYHIP_MODDOWN"); return !(e && e[0] == 's'); }();
     return v;
 }
 
 // TROYHIP_CORR=split keeps the CKKS divide-and-round correction as element-wise kernels around a plain transform (tests, measurements)
 static bool corr_fused() {
-    static const bool v = [] { const char *e = getenv("TROYHIP_CORR"); return !(e && e[0] == 's'); }();
+    static const bool v = [] { const char *e = probe_env("TROYHIP_CORR"); return !(e && e[0] == 's'); }();
     return v;
 }
 // Small launches (Context::small_launch: one ciphertext, a few small ones) take merged forms: one launch over the q-base and the B_sk-base rows of a

@@ -199,25 +199,12 @@ struct BehzDev {
     const u32 *ext_mt_row;            // [L]   (q/q_l) mod m_tilde = 2^32
     u64 neg_inv_q_mod_mt;             // -q^-1 mod 2^32
     const u64 *ext_q;                 // [nBsk]  q * m_tilde^-1 mod Bsk_o
-    // matrix-core form of the same matrices (behz.hip, "MFMA path"): A-fragments of v_mfma_i32_32x32x32_i8, 16 bytes per
-    // lane, [row-block][k-block][lane]; a row-block is 2 outputs x 16 byte-shifts, a k-block is 4 input limbs x 8 digits
-    const void *ext_frag;             // [ceil(nBsk/2)][4][64]
-    const void *ext_mt_frag;          // [4][64]  the m_tilde row (shifts 0..3 only)
-    // ext_fold / floor_fold: the padding limbs L, L+1 (nB, nB+1) of the last k-block carry the per-coefficient correction term as two
-    // more inputs -- the centred r (alpha) against the column q m_tilde^-1 (-(B mod q_l)), and the constant 1 against the digits of a
-    // multiple of the output prime that keeps the sum non-negative -- so the epilogue is recombine + reduce only
-    int ext_fold, floor_fold;         // 0: not folded; 1 / 2: limb count modulo 4 (selects where the two extra limbs sit in the fragment)
     // --- floor + Shenoy-Kumaresan ---
     const Shoup *floor_pre;           // [L]   (t * (q/q_l)^-1) mod q_l
     const Mat3 *floor_mat3;           // [nBsk][L]  -(q/q_l) * q^-1 [* (B/B_o)^-1 for o < nB] mod Bsk_o
     const Mat3 *floor_t3;             // [nBsk]     t * q^-1 [* (B/B_o)^-1] mod Bsk_o
     const Mat3 *B2q3;                 // [L][nB]   (B/B_b) mod q_l
     const Mat3 *B2msk3;               // [nB]      (B/B_b) mod m_sk
-    // matrix-core form (behz_floor_sk_mfma_kernel): same fragment layout as ext_frag
-    const void *floor_frag1;          // [ceil(nBsk/2)][4][64]  rows of floor_mat3
-    const u64 *floor_t;               // [nBsk]  t * q^-1 [* (B/B_o)^-1] mod Bsk_o (the db_o term is one 64 x 64 product)
-    const void *floor_frag2;          // [ceil(L/2)][4][64]     rows of B2q3 (K runs over the B limbs)
-    const void *floor_msk_frag;       // [4][64]                the B -> m_sk row, in both halves of the tile
     Shoup inv_B_mod_msk;
     const u64 *prod_B_mod_q;          // [L]
     // --- second matrix-core form (behz2.hip): rows reduced modulo the output prime, 8 byte-shifts per output, a row-block = 4 outputs;

@@ -90,9 +90,6 @@ __device__ __forceinline__ unsigned sw1(unsigned j) { return j ^ (((j >> 6) & 7u
 // SQ_LDS_BANK_CONFLICT = 34 % of the inverse kernel's LDS cycles in round 2, 0 in the forward kernel, which only reads that pattern).  One more
 // term -- bit 2 ^= bit 4 -- separates them and keeps every other pattern conflict-free (tools/lds_banks.py); it is no involution any more
 // (bit 4 is both a source and a target), so the LDS-DMA staging, which needs "which element belongs at position x", uses sw2_inv.
-#ifndef N1_FP_EARLY_ODD
-#define N1_FP_EARLY_ODD 0 // measured: 4421 -> 4948 us per 26 880 rows (the request costs 52 B more scratch than it hides latency)
-#endif
 #ifndef N1_FP_FENCE_B
 #define N1_FP_FENCE_B 2 // FP64 forward kernel, round B (16 values in registers next to the waiting half): butterflies in flight between scheduling fences
 #endif
@@ -292,9 +289,9 @@ template <int NV> __device__ __forceinline__ void fp_reduce_all(u64 (&y)[NV], co
 // result canonical to `out` (the sub-block's 1024 coefficients in HBM)
 // LOGN: the transform's size; the sub-block rounds are its stages LOGN - 10 .. LOGN - 1 (N = 2^15: 5 .. 14 as the comments say; the smaller sizes of
 // ntt1s_*_body shift every stage number down, the code is the same: a sub-block is 1024 coefficients at every size)
-template <int LOGN, bool LEAN, bool CR, bool FP, class AfterB> __device__ __forceinline__ void fwd_subblock(u64 *R, const unsigned sb, const unsigned lane_in, const PrimeDesc &pd, const PrimeConst &pc, const Mod &m,
+template <int LOGN, bool LEAN, bool CR, bool FP> __device__ __forceinline__ void fwd_subblock(u64 *R, const unsigned sb, const unsigned lane_in, const PrimeDesc &pd, const PrimeConst &pc, const Mod &m,
                                                                   u64 *out, const Ntt1Args &a, const unsigned mm, const unsigned m_begin, const int stamp0, const bool hf_last,
-                                                                  const FpPrime &fc, const AfterB &after_round_b, const u64 *cr_in = nullptr, const Shoup cr_inv = Shoup{0, 0},
+                                                                  const FpPrime &fc, const u64 *cr_in = nullptr, const Shoup cr_inv = Shoup{0, 0},
                                                                   const u64 *cr_acc = nullptr) {
     (void)a; (void)mm; (void)m_begin; (void)stamp0; (void)hf_last; (void)fc;
     constexpr unsigned A = 1u << (LOGN - 10); // blocks of the first sub-block stage per sub-block row: root index of stage s = 2^s + block
@@ -314,7 +311,6 @@ template <int LOGN, bool LEAN, bool CR, bool FP, class AfterB> __device__ __forc
     }
     TROY_WAVE_SYNC();
     N1_STAMP(stamp0);
-    after_round_b(); // FP64 instances: the next row's odd half is requested here (sixteen values are gone from the registers: room for it)
     N1_SCHED_FENCE(); // the twiddle loads below stay below: hoisted over round B they would not fit the register budget (the FP64 instances, whose seven
                       // twiddles are single doubles, were tried with them in front of round B at N <= 2^14, where they fit: no measurable change)
     N1_PRIO(2);
@@ -553,20 +549,16 @@ template <bool LEAN, bool CR, bool FP> __device__ __forceinline__ void ntt1_fwd_
                     for (int r = 0; r < 16; r++) xe[r] = 0;
                 }
             }
-            // the FP64 instances compute faster than the odd half of the next row arrives when it is requested at the end of the row (plain
-            // transform 167 ns per limb with 74 % VALU-busy): they request it after round B of the second half, under rounds C1 / C2
-            constexpr bool EARLY_ODD = FP && N1_FP_EARLY_ODD;
-            auto after_b = [&]() { if (EARLY_ODD && hf == 1 && mm + 1 < m_end) load_half(xo, in_row(mm + 1), 1); };
-            fwd_subblock<N1_LOGN, LEAN, CR, FP>(region, 16 * hf + wv, lane, pd, pc, m, out + 1024 * (16 * hf + wv), a, mm, m_begin, 4 + 6 * hf, hf == 1, fc, after_b, CR ? cin + 1024 * (16 * hf + wv) : nullptr,
+            // (the FP64 instances compute faster than the odd half of the next row arrives; requesting it earlier -- after round B of the second half --
+            // was measured twice, rounds 3 and 4: the 32 registers it holds through rounds C1 / C2 cost 36-52 B of scratch and 5 % of the kernel)
+            fwd_subblock<N1_LOGN, LEAN, CR, FP>(region, 16 * hf + wv, lane, pd, pc, m, out + 1024 * (16 * hf + wv), a, mm, m_begin, 4 + 6 * hf, hf == 1, fc, CR ? cin + 1024 * (16 * hf + wv) : nullptr,
                                        cr_inv, CR && cacc ? cacc + 1024 * (16 * hf + wv) : nullptr);
             N1_STAMP(7 + 6 * hf);
         }
-        if (!(FP && N1_FP_EARLY_ODD)) {
-            if (mm + 1 < m_end) load_half(xo, in_row(mm + 1), 1);
-            else {
+        if (mm + 1 < m_end) load_half(xo, in_row(mm + 1), 1);
+        else {
 #pragma unroll
-                for (int r = 0; r < 16; r++) xo[r] = 0; // dead after the last row (see xe above)
-            }
+            for (int r = 0; r < 16; r++) xo[r] = 0; // dead after the last row (see xe above)
         }
     }
 }
@@ -862,7 +854,7 @@ template <int LOGN, bool LEAN, bool FP> __device__ __forceinline__ void ntt1s_fw
         }
         __syncthreads();
         if (mm + 1 < m_end) load_row(in_base + row_of(mm + 1)); // all sixteen registers are free: the next limb streams in under the sub-block rounds
-        fwd_subblock<LOGN, LEAN, false, FP>(region, wv, lane, pd, pc, m, out + 1024 * wv, args, mm, m_begin, 4, true, fc, [] {});
+        fwd_subblock<LOGN, LEAN, false, FP>(region, wv, lane, pd, pc, m, out + 1024 * wv, args, mm, m_begin, 4, true, fc);
     }
 }
 template <int LOGN, bool LEAN> __global__ __launch_bounds__(64 << (LOGN - 10), 4) void ntt1s_fwd_kernel(Ntt1Args a) { ntt1s_fwd_body<LOGN, LEAN, false>(a); }
@@ -1052,7 +1044,7 @@ void launch_ntt1(u64 *data, const u64 *src, const PrimeDesc *primes, const LimbM
     // minimises rounds x (rows + 1/3), with a small penalty for spreading the CUs over many primes at once.  A fixed "three workgroups
     // per CU" left mid-size launches with a mostly idle last round.
     const unsigned cus = device_cus() * ntt1_wgs_per_cu(logn); // workgroup slots of the chip
-    static const unsigned forced_rpw = [] { const char *e = std::getenv("TROYHIP_NTT1_RPW"); return e ? (unsigned)std::atoi(e) : 0u; }(); // tests: row loop at small batches
+    static const unsigned forced_rpw = [] { const char *e = probe_env("TROYHIP_NTT1_RPW"); return e ? (unsigned)std::atoi(e) : 0u; }(); // tests: row loop at small batches
     auto plan = [&](unsigned nslots) { // -> rows per workgroup for a launch over `nslots` primes
         if (forced_rpw) return forced_rpw;
         unsigned best = 1;

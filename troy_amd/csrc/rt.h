@@ -10,6 +10,7 @@
 #include <atomic>
 #include <cstddef>
 #include <cstdint>
+#include <cstdlib>
 #include <stdexcept>
 #include <string>
 
@@ -40,6 +41,19 @@ void end(hipStream_t s);
 #endif
 
 namespace troyhip {
+
+// Environment switches.  The shipped library reads FOUR, each once (documented in DESIGN.md section 1): TROYHIP_NTT = single | twopass (which transform form
+// takes a launch), TROYHIP_FP64 = off (integer kernels for every prime), TROYHIP_AUX_BASE = reference (the reference's 61-bit BEHZ base),
+// TROYHIP_SMALL = split | merged (the merged forms of small launches never / always).  Everything else -- forcing an unfused fallback, guarded
+// butterflies, rows per workgroup -- exists only in probe builds (-DTROYHIP_PROBES: `make probes`, and the CPU emulator build of the test suite).
+inline const char *probe_env(const char *name) {
+#ifdef TROYHIP_PROBES
+    return std::getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
 
 // Path counters (troyhip_stat, include/troyhip.h): which kernel class a launcher chose.  The parity tests read them so that a test of
 // the FP64 instances cannot pass on the integer kernels (or the other way round) without saying so.
