@@ -514,7 +514,9 @@ def algorithmic_bytes(w, B):
     fast = "true" if all(int(p) >= 1 << 33 for p in w.ctx.coeff_modulus[:L]) else "false"
     kbx, kb1, kb2 = (L + 4) // 4, (L + 3) // 4, (nb + 3) // 4  # k-blocks: extension (L limbs + r), floor stage 1, stage 2 (|B| limbs + alpha)
     small_x, small_f = kbx <= 2 and nb <= 8, kb2 <= 2           # the everything-in-registers kernels of behz2.hip
-    add(f"behz2s_extend_kernel<{kbx}, {(nb + 3) // 4}>" if small_x else f"behz2_extend_kernel<{kbx}>", 2 * 2 * B * (L + nb) * P)
+    # small bases of narrow primes take the register-resident FP64 form (behz3.hip): every q prime in [2^33, 2^50), every auxiliary prime below 2^50, L <= 6
+    fp_behz = _fp_on() and L <= 6 and all((1 << 33) <= int(p) < (1 << FP_MAX_BITS) for p in w.ctx.coeff_modulus[:L]) and all(int(p) < (1 << FP_MAX_BITS) for p in w.ctx.behz_bases(L)[0])
+    add(f"behz3_extend_kernel<{L}, {nb}>" if fp_behz else (f"behz2s_extend_kernel<{kbx}, {(nb + 3) // 4}>" if small_x else f"behz2_extend_kernel<{kbx}>"), 2 * 2 * B * (L + nb) * P)
     qs_all = [int(p) for p in w.ctx.coeff_modulus]
     q_primes, special, bsk_primes = qs_all[:L], qs_all[-1:], [int(p) for p in w.ctx.behz_bases(L)[0]]  # the auxiliary base as the library chose it (hostmath.cpp)
     _by_prime_class(add, f"ntt2_kernel<0, 1, {k1}, {logc}, 0, 0, 0>", q_primes + bsk_primes, 2 * (2 * B) * 2 * P)
@@ -559,7 +561,7 @@ def algorithmic_bytes(w, B):
             _by_prime_class(add, f"ntt2_kernel<1, 1, {k1}, {logc}, 2, 0, 0>", q_primes, 2 * B * 2 * P)
         else:
             _by_prime_class(add, f"ntt2_kernel<1, 1, {k1}, {logc}, 3, 0, 0>", q_primes, 2 * B * 3 * P + 2 * B * P / L)
-    add(f"behz2{'s' if small_f else ''}_floor_sk_kernel<{kb1}, {kb2}, {fast}>", 3 * B * (2 * L + nb) * P)
+    add(f"behz3_floor_sk_kernel<{L}, {nb}>" if fp_behz else f"behz2{'s' if small_f else ''}_floor_sk_kernel<{kb1}, {kb2}, {fast}>", 3 * B * (2 * L + nb) * P)
     # relinearize: digit decomposition + first pass, second pass with the inner product against the key, inverse, mod-down
     _ks_forward_pair(add, w, B, L, logn, False)
     if md_split or (single(2 * B * (L + 1)) and not all(int(p) >= 1 << 33 for p in w.ctx.coeff_modulus[:L])):

@@ -541,6 +541,18 @@ def test_bfv_multiply_every_limb_count(K, big, gpu, oracle_lib):
     cases.check_bfv_multiply_limb_count(K, big=big)
 
 
+def test_behz_kernel_family_by_base(gpu, oracle_lib):
+    """which BEHZ kernels a base gets (path counters, troyhip_stat): small bases of narrow primes the register-resident FP64 form (behz3.hip), up to
+    15 limbs the matrix cores (behz2.hip), beyond that the VALU kernels (behz.hip) -- each against the oracle in check_bfv_multiply_limb_count"""
+    from troy_amd import capi
+    names = ("behz_fp_launches", "behz_mfma_launches", "behz_valu_launches")
+    for K, big, expect in ((3, False, 0), (5, False, 0), (7, False, 0), (5, True, 1), (9, False, 1), (16, True, 1), (18, False, 2)):
+        before = [capi.stat(n) for n in names]
+        cases.check_bfv_multiply_limb_count(K, big=big)
+        delta = [capi.stat(n) - b for n, b in zip(names, before)]
+        assert delta[expect] >= 2 and sum(delta) == delta[expect], (K, big, delta)
+
+
 PROBES_LIB = os.path.join(ROOT, "tools", "probe_libs", "libtroyhip_probes.so")  # `make -C troy_amd/csrc probes` (__graft_entry__.build() makes it)
 
 

@@ -263,6 +263,7 @@ void launch_behz_extend(const u64 *in, u64 in_pstride, u64 *out, u64 out_pstride
         launch_behz_extend(in2, in_pstride, out + split * out_pstride, out_pstride, primes, c, N, polys - split, s);
         return;
     }
+    stats::counter(stats::BEHZ_VALU_LAUNCHES).fetch_add(1, std::memory_order_relaxed);
     const size_t lds = (size_t)c.L * BEHZ_COEFFS * sizeof(u64);
     for (u64 p0 = 0; p0 < polys; p0 += 65535) { // gridDim.y limit
         const u64 np = polys - p0 < 65535 ? polys - p0 : 65535;
@@ -275,6 +276,7 @@ void launch_behz_floor_sk(const u64 *dq, u64 dq_pstride, const u64 *db, u64 db_p
                           u64 polys, hipStream_t s) {
     if (!polys) return;
     if (c.v2 && behz_use_mfma()) return launch_behz2_floor_sk(dq, dq_pstride, db, db_pstride, out, out_pstride, primes, c, N, polys, s);
+    stats::counter(stats::BEHZ_VALU_LAUNCHES).fetch_add(1, std::memory_order_relaxed);
     const size_t lds = (size_t)(c.L + c.nB + 1) * BEHZ_COEFFS * sizeof(u64);
     for (u64 p0 = 0; p0 < polys; p0 += 65535) {
         const u64 np = polys - p0 < 65535 ? polys - p0 : 65535;

@@ -574,6 +574,11 @@ template <int KB1, int KB2, bool FAST2> __global__ __launch_bounds__(B2_THREADS)
 
 // tiles a workgroup walks (fragments and per-lane constants are set up once per workgroup); small launches -- a few polynomials -- take fewer, so that
 // the grid still covers the chip (plan_per_workgroup, kernels.h)
+// probe builds: TROYHIP_BEHZ=mfma keeps the matrix-core kernels at the base sizes the register-resident FP64 form (behz3.hip) takes (A/B runs)
+static bool behz3_enabled() {
+    static const bool v = [] { const char *e = probe_env("TROYHIP_BEHZ"); return !(e && e[0] == 'm'); }();
+    return v;
+}
 static unsigned b2_tiles_per_wg(u64 tiles, u64 polys) { return plan_per_workgroup(tiles, tiles >= 64 ? B2_TPW : 1, polys); }
 // small-base kernels: a wave takes 32 columns per step, so the per-workgroup setup wants more steps
 static unsigned b2s_tiles_per_wg(u64 tiles, u64 polys) { // 8 / 16 / 32 / 64 at N = 8192 and a large batch: 389 / 352 / 347 / 390 us
@@ -582,7 +587,9 @@ static unsigned b2s_tiles_per_wg(u64 tiles, u64 polys) { // 8 / 16 / 32 / 64 at 
 
 void launch_behz2_extend(const u64 *in, u64 in_pstride, u64 *out, u64 out_pstride, const PrimeDesc *primes, const BehzDev &c, u64 N, u64 polys, hipStream_t s, const u64 *in2,
                          u64 split) {
+    if (behz3_supported(c) && behz3_enabled()) return launch_behz3_extend(in, in_pstride, out, out_pstride, c, N, polys, s, in2, split); // small bases of narrow primes
     if (!in2) split = polys;
+    stats::counter(stats::BEHZ_MFMA_LAUNCHES).fetch_add(1, std::memory_order_relaxed);
     if (in2 && polys > 65535) throw Error(ST_LOGIC_ERROR, "behz2 extend: the two-operand form is for small launches");
     const int kb = (c.L + 1 + 3) / 4;
     const bool small = c.f1s_frag && kb <= 2 && c.nBsk <= 8; // everything-in-registers form
@@ -618,6 +625,8 @@ void launch_behz2_extend(const u64 *in, u64 in_pstride, u64 *out, u64 out_pstrid
 
 void launch_behz2_floor_sk(const u64 *dq, u64 dq_pstride, const u64 *db, u64 db_pstride, u64 *out, u64 out_pstride, const PrimeDesc *primes, const BehzDev &c, u64 N,
                            u64 polys, hipStream_t s) {
+    if (behz3_supported(c) && behz3_enabled()) return launch_behz3_floor_sk(dq, dq_pstride, db, db_pstride, out, out_pstride, c, N, polys, s);
+    stats::counter(stats::BEHZ_MFMA_LAUNCHES).fetch_add(1, std::memory_order_relaxed);
     const int kb1 = (c.L + 3) / 4, kb2 = (c.nB + 1 + 3) / 4; // kb2 is kb1 or kb1 + 1 (nB is L or L + 1)
     const bool small = c.f1s_frag && kb2 <= 2;
     const u64 tiles = ceil_div(N, (u64)(small ? B2S_TILE : B2_TILE));

@@ -390,6 +390,29 @@ void Context::upload_tables() {
             c->f2_fast = 1;
             for (int l = 0; l < L; l++) c->f2_fast = c->f2_fast && r.q[l] >= (u64(1) << 33);
             c->v2 = 1;
+            // register-resident FP64 form for small bases of narrow primes (behz3.hip): the same folded rows as pairs of doubles (w, w / p)
+            bool narrow = fp_allowed() && L <= 6;
+            for (int l = 0; l < L; l++) narrow = narrow && r.q[l] >= (u64(1) << 33) && !(r.q[l] >> TROY_FP_MAX_BITS);
+            for (u64 p : r.Bsk) narrow = narrow && !(p >> TROY_FP_MAX_BITS);
+            if (narrow) {
+                auto pair = [](std::vector<double> &v, u64 w, u64 p) { v.push_back((double)w); v.push_back((double)w / (double)p); };
+                auto prime = [](std::vector<double> &v, u64 p) { v.push_back((double)p); v.push_back(1.0 / (double)p); };
+                std::vector<double> ex, fl;
+                for (int l = 0; l < L; l++) pair(ex, ext_pre[l].op, r.q[l]);
+                for (int l = 0; l < L; l++) prime(ex, r.q[l]);
+                for (int o = 0; o < nBsk; o++) prime(ex, r.Bsk[o]);
+                for (int o = 0; o < nBsk; o++)
+                    for (int l = 0; l <= L; l++) pair(ex, xw[o][l], r.Bsk[o]);          // E[o][0 .. L-1], C[o]
+                for (int l = 0; l < L; l++) prime(fl, r.q[l]);
+                for (int o = 0; o < nBsk; o++) prime(fl, r.Bsk[o]);
+                for (int o = 0; o < nBsk; o++)
+                    for (int l = 0; l < L; l++) pair(fl, f1w[o][l], r.Bsk[o]);
+                for (int b = 0; b < nB; b++) pair(fl, mskw[0][b], r.m_sk);
+                for (int l = 0; l < L; l++)
+                    for (int b = 0; b <= nB; b++) pair(fl, f2w[l][b], r.q[l]);          // G[l][0 .. nB-1], H[l]
+                c->fp_ext = upload(ex, lv.dev_blocks);
+                c->fp_floor = upload(fl, lv.dev_blocks);
+            }
         }
         c->B2q3 = upload(B2q, lv.dev_blocks);
         c->B2msk3 = upload(B2msk, lv.dev_blocks);

@@ -225,7 +225,12 @@ struct BehzDev {
     // prime table, whose N^-1 constants carry t (q/q_l)^-1 mod q_l (q limbs) resp. t q^-1 [(B/B_o)^-1 | B^-1] mod Bsk_o (Bsk limbs),
     // so the per-coefficient multiplications by those factors cost nothing (behz_floor_prescaled() tells the evaluator)
     const PrimeDesc *floor_desc;
+    // --- register-resident FP64 form (behz3.hip): small bases whose primes all lie below 2^50 -- the rows above as pairs of doubles (w, w / p); nullptr: not built
+    const double *fp_ext, *fp_floor;
 };
+bool behz3_supported(const BehzDev &c);
+void launch_behz3_extend(const u64 *in, u64 in_pstride, u64 *out, u64 out_pstride, const BehzDev &c, u64 N, u64 polys, hipStream_t s, const u64 *in2 = nullptr, u64 split = 0);
+void launch_behz3_floor_sk(const u64 *dq, u64 dq_pstride, const u64 *db, u64 db_pstride, u64 *out, u64 out_pstride, const BehzDev &c, u64 N, u64 polys, hipStream_t s);
 bool behz_floor_prescaled(const BehzDev &c);
 void launch_behz2_extend(const u64 *in, u64 in_pstride, u64 *out, u64 out_pstride, const PrimeDesc *primes, const BehzDev &c, u64 N, u64 polys, hipStream_t s,
                          const u64 *in2 = nullptr, u64 split = 0);
