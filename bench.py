@@ -605,9 +605,7 @@ def _ks_forward_pair(add, w, B, l, logn, ckks):
         diag = sum(1 for j in mine if ckks and j < l)
         nm = "ntt2_fp_kernel" if cls else "ntt2_kernel"
         add(f"{nm}<0, 1, {k1}, {logc}, 0, {2 if ckks else 1}, 0>", B * l * P + B * exp_rows * P)
-        # a tiny launch (fewer than two workgroups per compute unit in the accumulating pass, not CKKS) gives each key component a workgroup of its own (MAC = 5)
-        tiny = not ckks and os.environ.get("TROYHIP_SMALL", "")[:1] != "s" and (B * (l + 1) * (w.N >> 11) < 2 * 256 or os.environ.get("TROYHIP_SMALL", "")[:1] == "m")
-        add(f"{nm}<0, 0, 9, 0, 1, 0, {3 if ckks else (5 if tiny else 1)}>", B * exp_rows * P + 2 * len(mine) * l * P + B * diag * P + 2 * B * len(mine) * P)
+        add(f"{nm}<0, 0, 9, 0, 1, 0, {3 if ckks else 1}>", B * exp_rows * P + 2 * len(mine) * l * P + B * diag * P + 2 * B * len(mine) * P)
 
 
 def _ks_two_pass(add, w, B, L, P, logn, kind):

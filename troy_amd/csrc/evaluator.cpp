@@ -36,9 +36,9 @@ static bool corr_fused() {
 // Small launches (Context::small_launch: one ciphertext, a few small ones) take merged forms: one launch over the q-base and the B_sk-base rows of a
 // product, one first pass over the special limb and the data limbs of a mod-down.  TROYHIP_SMALL=split keeps them on the kernels of the large batch,
 // TROYHIP_SMALL=merged uses the merged forms at every size (tests, measurements); read once
-static bool take_merged(const Context &c, u64 rows, unsigned per_cu = 64) {
+static bool take_merged(const Context &c, u64 rows) {
     static const int mode = [] { const char *e = getenv("TROYHIP_SMALL"); return !e ? 0 : (e[0] == 's' ? 1 : (e[0] == 'm' ? 2 : 0)); }();
-    return mode == 2 || (mode == 0 && c.small_launch(rows, per_cu));
+    return mode == 2 || (mode == 0 && c.small_launch(rows));
 }
 static bool primes_at_least_33_bits(const Context &c, int limbs) { // what the lazy reductions of the fused epilogues (lite_reduce4) take
     for (int l = 0; l < limbs; l++)
@@ -378,11 +378,8 @@ void Evaluator::switch_key(CtBatch &ct, const u64 *target, u64 t_bstride, const 
             const long double bound = ((ks_map.lean >> i) & 1) ? 59.0L : 8.0L;
             lazy = lazy && (long double)dl * bound * p * p < 3.0e38L; // 2^128 = 3.4e38
         }
-        // one ciphertext: the accumulating pass is batch (L + 1) groups of N / 2048 workgroups, one wave per SIMD for dl rows in a row -- below two workgroups
-        // per compute unit each group is shared by two workgroups, one per key component
-        const bool split_components = c.scheme != SCHEME_CKKS && take_merged(c, batch * rl, 2);
         launch_ntt2_ks_mac(D, coeff_target, ct_tb, c.d_desc, ks_map, batch * rl * dl, c.logn, key.data, acc, a.key_limb, (unsigned)K,
-                           mac_target, t_bstride, lazy, src_bound, s, split_components);
+                           mac_target, t_bstride, lazy, src_bound, s);
     } else {
         if (ntt2_supported(c.logn)) {
             launch_ntt2(D, coeff_target, ct_tb, true, c.d_desc, c.ids_map(out_ids, (uint32_t)dl), batch * rl * dl, c.logn, false, s, false, src_bound);

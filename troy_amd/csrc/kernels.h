@@ -19,8 +19,7 @@ inline unsigned plan_per_workgroup(size_t units, unsigned cap, size_t groups) {
 void launch_ntt(u64 *data, const PrimeDesc *primes, const LimbMap &map, size_t rows, int logn, bool inverse, hipStream_t stream);
 // key switching: transforms of all (digit, output prime) pairs + inner product with the key in one pair of launches (ntt2.hip)
 void launch_ntt2_ks_mac(u64 *D, const u64 *src, u64 src_ostride, const PrimeDesc *primes, const LimbMap &map, size_t rows, int logn, const u64 *key, u64 *acc,
-                        const uint8_t *key_limb, unsigned K, const u64 *ckks_target, u64 t_bstride, bool lazy, u64 src_bound, hipStream_t stream,
-                        bool split_components = false); // BFV / BGV, tiny launches: one key component per workgroup in the accumulating pass (twice the workgroups)
+                        const uint8_t *key_limb, unsigned K, const u64 *ckks_target, u64 t_bstride, bool lazy, u64 src_bound, hipStream_t stream);
 // BEHZ multiply: forward transforms of two size-2 operands + ciphertext tensor in one pass pair (ntt2.hip)
 bool ntt2_tensor_supported(int logn);
 bool ntt2_ks_mac_supported(int logn);

@@ -612,10 +612,7 @@ __device__ __forceinline__ void ntt2_body(const Ntt2Args &a) {
     constexpr bool WAVE_PRIVATE = !STRIDED && NS == 9;
     // MAC = 1: key-switch inner product (BFV / BGV); MAC = 3: the same for CKKS, where the row of digit k == output slot is the NTT-form input
     // itself and is neither staged nor transformed; REDUCE = 2: the digit-reducing first pass of that key switch, which does not expand those rows
-    // MAC = 5: MAC = 1 with ONE key component per workgroup (two workgroups per group, each transforms the digits itself): for launches so small that the
-    // accumulating pass leaves three wave slots in four empty -- twice the waves, half the accumulate work per wave, no shared accumulator
-    constexpr bool KS = MAC == 1 || MAC == 3 || MAC == 5;
-    constexpr int NC = MAC == 5 ? 1 : 2; // key components accumulated by this workgroup
+    constexpr bool KS = MAC == 1 || MAC == 3;
     // Which LDS exchanges form their addresses per row instead of once per workgroup (bit 0: round 0 write, 1: round 1 read, 2: round 1
     // write, 3: round 2 read, 4: round 2 write, 5: round 3 read).  Hoisted, the eight swizzled addresses of an exchange live across the
     // whole row loop; in the instances at the 128-register limit the compiler spilled them, and a spill reload waits with vmcnt(0) --
@@ -644,13 +641,11 @@ __device__ __forceinline__ void ntt2_body(const Ntt2Args &a) {
     constexpr int Q3 = NR > 3 ? (INV ? P::r[NR - 4] : R3) : 0;
     using Rd0 = Round<INV, STRIDED, NS, LOGC, 0, Q0>;
     using Rd1 = Round<INV, STRIDED, NS, LOGC, Q0, Q1 ? Q1 : 1, MAC != 2 || N2_TENSOR_HOIST1>;
-    using Rd2 = Round<INV, STRIDED, NS, LOGC, Q0 + Q1, Q2 ? Q2 : 1, (MAC == 2 ? N2_TENSOR_HOIST2 : (MAC != 1 && MAC != 3 && MAC != 5) || N2_MAC_HOIST)>;
+    using Rd2 = Round<INV, STRIDED, NS, LOGC, Q0 + Q1, Q2 ? Q2 : 1, (MAC == 2 ? N2_TENSOR_HOIST2 : (MAC != 1 && MAC != 3) || N2_MAC_HOIST)>;
     using Rd3 = Round<INV, STRIDED, NS, LOGC, Q0 + Q1 + Q2, Q3 ? Q3 : 1>;
 
     const unsigned tile = blockIdx.x & ((1u << a.tiles_per_row_log) - 1);
-    const unsigned grp_all = blockIdx.x >> a.tiles_per_row_log;
-    const unsigned cpt0 = MAC == 5 ? (grp_all & 1u) : 0u;   // the key component of this workgroup (MAC = 5)
-    const unsigned grp = MAC == 5 ? grp_all >> 1 : grp_all;
+    const unsigned grp = blockIdx.x >> a.tiles_per_row_log;
     // group order: prime slot major (workgroups in flight share the twiddles, and in the fused key-switch pass the key window),
     // or slot FASTEST (the first key-switch pass: the L+1 readers of one source digit run together and hit in L2)
     const unsigned sidx = a.slot_fastest ? grp % a.nsel : grp / a.chunks, chunk = a.slot_fastest ? grp / a.nsel : grp % a.chunks;
@@ -720,10 +715,10 @@ __device__ __forceinline__ void ntt2_body(const Ntt2Args &a) {
     u64 xn[PF ? 8 : 1];
     static_assert(!MAC || (!INV && !STRIDED && NS == 9), "the inner product is fused into the forward contiguous pass");
     u64 tx[MAC == 2 ? 3 : 1][8]; // MAC = 2: the transforms of a0, a1, b0 while b1 is being computed
-    Acc128 macc[NC][2][4]; // [key component][group of four coefficients][coefficient]
+    Acc128 macc[2][2][4]; // [key component][group of four coefficients][coefficient]
     if (KS) {
 #pragma unroll
-        for (int cpt = 0; cpt < NC; cpt++)
+        for (int cpt = 0; cpt < 2; cpt++)
 #pragma unroll
             for (int g = 0; g < 2; g++)
 #pragma unroll
@@ -731,17 +726,17 @@ __device__ __forceinline__ void ntt2_body(const Ntt2Args &a) {
     }
     // FP64 instances: one double per accumulator (the products are reduced modulo p as they are formed: 6 + 1 instructions per term and two
     // for the key word's conversion, against 10 for the 128-bit integer form -- and 32 VGPRs of accumulators instead of 64)
-    double facc[NC][FP ? 8 : 1];
+    double facc[2][FP ? 8 : 1];
     if constexpr (FP) {
 #pragma unroll
-        for (int cpt = 0; cpt < NC; cpt++)
+        for (int cpt = 0; cpt < 2; cpt++)
 #pragma unroll
             for (int e = 0; e < 8; e++) facc[cpt][e] = 0.0;
     }
-    auto mac_row = [&](const u64 (&xr)[8], const ulonglong2 (&kw)[NC][KS ? 4 : 1], unsigned row_no) {
+    auto mac_row = [&](const u64 (&xr)[8], const ulonglong2 (&kw)[2][KS ? 4 : 1], unsigned row_no) {
         if constexpr (FP && KS) {
 #pragma unroll
-            for (int cpt = 0; cpt < NC; cpt++)
+            for (int cpt = 0; cpt < 2; cpt++)
 #pragma unroll
                 for (int e = 0; e < 8; e++) {
                     const u64 kword = (e & 1) ? kw[cpt][e >> 1].y : kw[cpt][e >> 1].x;
@@ -749,13 +744,13 @@ __device__ __forceinline__ void ntt2_body(const Ntt2Args &a) {
                 }
             if (a.fp_acc_every && (row_no + 1) % a.fp_acc_every == 0) { // wave-uniform; the sums stay below 2^53 (launch_ntt2_ks_mac)
 #pragma unroll
-                for (int cpt = 0; cpt < NC; cpt++)
+                for (int cpt = 0; cpt < 2; cpt++)
 #pragma unroll
                     for (int e = 0; e < 8; e++) facc[cpt][e] = fp_reduce(facc[cpt][e], fc);
             }
         } else if constexpr (KS) {
 #pragma unroll
-            for (int cpt = 0; cpt < NC; cpt++) {
+            for (int cpt = 0; cpt < 2; cpt++) {
 #pragma unroll
                 for (int g = 0; g < 2; g++) {
                     const ulonglong2 k01 = kw[cpt][2 * g], k23 = kw[cpt][2 * g + 1];
@@ -791,14 +786,14 @@ __device__ __forceinline__ void ntt2_body(const Ntt2Args &a) {
         const bool next_wanted = mm + 1 < m_end && !is_diag(nk);
         const bool skip_row = REDUCE == 2 && is_diag(rk); // nothing to expand: the body below is skipped as a whole, the software pipeline goes on
         if constexpr (DMA) TROY_WAIT_VMEM(); // this wave's staged row has landed (and its previous stores are out)
-        ulonglong2 kv[NC][KS ? 4 : 1]; // MAC: this row's key words, requested now -- BEFORE the next row's staging loads, so that the wait for them (vmcnt counts in
+        ulonglong2 kv[2][KS ? 4 : 1]; // MAC: this row's key words, requested now -- BEFORE the next row's staging loads, so that the wait for them (vmcnt counts in
         // order) does not include the staging loads' HBM latency -- and used after the three rounds
         auto load_keys = [&]() {
             const unsigned kk = rk;
             const u64 *kp = a.mac_key + ((((u64)kk * 2) * a.mac_K + key_limb) << logn) + ((u64)tile << N2_LOGT) + 8 * threadIdx.x;
 #pragma unroll
-            for (int cpt = 0; cpt < NC; cpt++) {
-                const ulonglong2 *kq = reinterpret_cast<const ulonglong2 *>(kp + ((u64)(cpt + cpt0) * a.mac_K << logn));
+            for (int cpt = 0; cpt < 2; cpt++) {
+                const ulonglong2 *kq = reinterpret_cast<const ulonglong2 *>(kp + ((u64)cpt * a.mac_K << logn));
 #pragma unroll
                 for (int e = 0; e < 4; e++) kv[cpt][KS ? e : 0] = kq[e];
             }
@@ -968,8 +963,8 @@ __device__ __forceinline__ void ntt2_body(const Ntt2Args &a) {
         const unsigned o = m_begin / inner;
         const u64 pos = ((u64)tile << N2_LOGT) + 8 * threadIdx.x;
 #pragma unroll
-        for (int cpt = 0; cpt < NC; cpt++) {
-            ulonglong2 *op = reinterpret_cast<ulonglong2 *>(a.mac_acc + ((((u64)o * 2 + cpt + cpt0) * period + slot) << logn) + pos);
+        for (int cpt = 0; cpt < 2; cpt++) {
+            ulonglong2 *op = reinterpret_cast<ulonglong2 *>(a.mac_acc + ((((u64)o * 2 + cpt) * period + slot) << logn) + pos);
 #pragma unroll
             for (int e = 0; e < 4; e++) {
                 ulonglong2 v;
@@ -1179,7 +1174,7 @@ template <int NS> static void launch_ks_first(const Ntt2Args &first, unsigned bl
     launch_check("ntt2_fp_kernel(ks first pass)");
 }
 void launch_ntt2_ks_mac(u64 *D, const u64 *src, u64 src_ostride, const PrimeDesc *primes, const LimbMap &map, size_t rows, int logn, const u64 *key, u64 *acc,
-                        const uint8_t *key_limb, unsigned K, const u64 *ckks_target, u64 t_bstride, bool lazy, u64 src_bound, hipStream_t stream, bool split_components) {
+                        const uint8_t *key_limb, unsigned K, const u64 *ckks_target, u64 t_bstride, bool lazy, u64 src_bound, hipStream_t stream) {
     const u64 *host_primes = map.host_primes;
     if (rows == 0) return;
     if (!ntt2_supported(logn) || logn - 9 > 7 || logn - 9 < 3) throw Error(ST_LOGIC_ERROR, "ntt2 ks_mac: unsupported size");
@@ -1254,16 +1249,12 @@ void launch_ntt2_ks_mac(u64 *D, const u64 *src, u64 src_ostride, const PrimeDesc
         second.mac_lazy = lazy;
         std::memcpy(second.mac_key_limb, key_limb, map.period);
         if (fp) {
-            N2_KTAG("ntt2_fp_kernel<0, 0, 9, 0, 1, 0, %d>", skip_diag ? 3 : (split_components ? 5 : 1));
+            N2_KTAG("ntt2_fp_kernel<0, 0, 9, 0, 1, 0, %d>", skip_diag ? 3 : 1);
             if (skip_diag) TROY_LAUNCH(HIP_KERNEL_NAME(ntt2_fp_kernel<0, 0, 9, 0, 1, 0, 3>), dim3(blocks), dim3(N2_THREADS), 0, stream, second);
-            else if (split_components) TROY_LAUNCH(HIP_KERNEL_NAME(ntt2_fp_kernel<0, 0, 9, 0, 1, 0, 5>), dim3(2 * blocks), dim3(N2_THREADS), 0, stream, second);
             else TROY_LAUNCH(HIP_KERNEL_NAME(ntt2_fp_kernel<0, 0, 9, 0, 1, 0, 1>), dim3(blocks), dim3(N2_THREADS), 0, stream, second);
         } else if (skip_diag) {
             N2_KTAG("ntt2_kernel<0, 0, 9, 0, 1, 0, 3>");
             TROY_LAUNCH(HIP_KERNEL_NAME(ntt2_kernel<0, 0, 9, 0, 1, 0, 3>), dim3(blocks), dim3(N2_THREADS), 0, stream, second);
-        } else if (split_components) { // one key component per workgroup (a launch that leaves most wave slots empty: one ciphertext)
-            N2_KTAG("ntt2_kernel<0, 0, 9, 0, 1, 0, 5>");
-            TROY_LAUNCH(HIP_KERNEL_NAME(ntt2_kernel<0, 0, 9, 0, 1, 0, 5>), dim3(2 * blocks), dim3(N2_THREADS), 0, stream, second);
         } else {
             N2_KTAG("ntt2_kernel<0, 0, 9, 0, 1, 0, 1>");
             TROY_LAUNCH(HIP_KERNEL_NAME(ntt2_kernel<0, 0, 9, 0, 1, 0, 1>), dim3(blocks), dim3(N2_THREADS), 0, stream, second);
