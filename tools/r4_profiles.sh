@@ -1,0 +1,28 @@
+#!/bin/bash
+# round-4 artefacts for profiles/ (profiles/README.md): PMC traffic of every workload (first: the bench lines then carry per_kernel[].traffic), the bench
+# line of every workload (verified, CPU baseline on the headline and configs[1]), rocprofv3 --kernel-trace --stats summaries of every workload's command
+# and of the roofline launches, the small-batch table through troyn.hpp, the reference's timetest on GPU and reference CPU, two ranks on one GPU.
+# usage (GPU box): tools/r4_profiles.sh        -> gpurun_out/final/  (copy what is judged into profiles/ with: cp gpurun_out/final/r04_* profiles/)
+R=$PWD; O=$R/gpurun_out/final; mkdir -p $O
+WLS="bfv_n32768_l14 bfv_n8192_l4 ckks_n32768_chain bgv_n65536_relin_rot ckks_matmul_128 bfv_n32768_l14_p49"
+for wl in $WLS; do
+  tools/measure_traffic.sh $wl > $O/traffic_$wl.log 2>&1
+  cp gpurun_out/r04_traffic_$wl.json $O/ 2>/dev/null && cp gpurun_out/r04_traffic_$wl.json profiles/
+done
+for wl in $WLS; do
+  extra="--no-cpu-baseline"; case $wl in bfv_n32768_l14|bfv_n8192_l4) extra="";; esac
+  python bench.py --workload $wl $extra > $O/r04_bench_$wl.json 2> $O/bench_$wl.err
+  (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$wl -o p -- python3 $R/bench.py --workload $wl --steps 5 --warmup 2 --no-cpu-baseline --no-verify > $O/prof_$wl.log 2>&1)
+  f=$(find $O/prof_$wl -name "p_kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/r04_${wl}_kernel_stats.csv
+  rm -rf $O/prof_$wl
+done
+for wl in bfv_n32768_l14 bfv_n32768_l14_p49; do
+  (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_rf_$wl -o p -- python3 $R/bench.py --workload $wl --roofline-only --no-cpu-baseline > $O/prof_rf_$wl.log 2>&1)
+  f=$(find $O/prof_rf_$wl -name "p_kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/r04_roofline_${wl}_kernel_stats.csv
+  rm -rf $O/prof_rf_$wl
+done
+tools/r4_small_batch.sh final > /dev/null 2>&1; cp $O/small_batch.txt $O/r04_small_batch.txt
+tools/r4_timetest.sh final 1 20 > /dev/null 2>&1; cp $O/timetest.txt $O/r04_timetest.txt
+python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29541 tools/dist_two_ranks.py bfv_n32768_l14 64 2>$O/dist.err | tail -1 > $O/r04_dist_two_ranks.txt
+python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29542 tools/dist_two_ranks.py bfv_n8192_l4 256 2>>$O/dist.err | tail -1 >> $O/r04_dist_two_ranks.txt
+ls -la $O | head -60
