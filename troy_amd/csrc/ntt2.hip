@@ -604,6 +604,9 @@ template <> struct Plan<11> { static constexpr int r[4] = {3, 3, 3, 2}; };
 template <int INV, int STRIDED, int NS, int LOGC, int FINAL, int REDUCE, int MAC, int FP>
 __device__ __forceinline__ void ntt2_body(const Ntt2Args &a) {
     static_assert(!FP || !(INV && MAC), "FP64 instances: every pass of the two-pass transform and its fusions");
+    // [0] the exchange buffer of the rounds, [1] the LDS-DMA staging area of the contiguous passes (one row ahead).  Two rows ahead in the key-switch passes
+    // (a third 16 KiB buffer, s_waitcnt vmcnt(4) for the older of two rows in flight) was measured in round 4: 1-2 % SLOWER on all four workloads --
+    // the wait at the top of a row is not what those passes are bound by
     __shared__ u64 lds[2][N2_T];
     using P = Plan<NS>;
     // NS == 9, contiguous: every 512-point sub-transform is owned by ONE wave in every round (thread t's points never
