@@ -616,25 +616,25 @@ def check_multiply_plain_accumulate(N=256, batch=3):
             raise AssertionError("multiplyPlainAccumulate accepted a bad argument")
 
 
-def random_config(seed, sizes=(256, 1024, 4096)):
+def random_config(seed, sizes=(256, 1024, 4096), pool=None):
     """a seeded random parameter set: scheme, N, 2..6 primes whose sizes sit on the thresholds the kernels branch on (2^33: BEHZ one-step
     reduction and guard-free butterflies start; 2^50: Bsk-sized; 2^58: guard-free butterflies end; 60 bits: largest allowed)"""
     rng = np.random.default_rng(seed)
     scheme = (BFV, CKKS, BGV)[seed % 3]  # balanced over consecutive seeds
     N = int(rng.choice(sizes))
     K = int(rng.integers(2, 7))
-    pool = [33, 34, 36, 40, 45, 49, 50, 51, 55, 57, 58, 59, 60]
+    pool = pool or [33, 34, 36, 40, 45, 49, 50, 51, 55, 57, 58, 59, 60]
     bits = [int(rng.choice(pool)) for _ in range(K)]
     if scheme == CKKS:  # rescaling divides by the last data prime: keep the primes at least as large as a sensible scale
         bits = [max(b, 36) for b in bits]
     return dict(scheme=scheme, N=N, bits=bits, tbits=int(rng.integers(14, 21)))
 
 
-def check_random_config(seed, sizes=(256, 1024, 4096), batch=2, light=False):
+def check_random_config(seed, sizes=(256, 1024, 4096), batch=2, light=False, pool=None):
     """the whole op list of `scenario` (every level, every op) on a random parameter set: product vs CPU oracle, limb for limb"""
     from oracle import oracle
     from troy_amd import api
-    cfg = random_config(seed, sizes)
+    cfg = random_config(seed, sizes, pool)
     if cfg["scheme"] != CKKS:  # not every size has a batching prime (N = 4096: none of 14 or 15 bits): both sides must say so, then move up
         while True:
             ours = theirs = None
