@@ -286,8 +286,13 @@ def _item(buf, words, index, shape):
     return buf.to_numpy(words, index * words).reshape(shape)
 
 
+def _picks(n):
+    """first, two interior and last index of a range of n"""
+    return sorted({0, n // 3, (2 * n) // 3, n - 1})
+
+
 def verify(w):
-    """items 0 and B-1 of the LAST step's results against the CPU oracle on the same inputs (downloaded from the device: the inputs are
+    """four items (first, two interior, last) of the LAST step's results against the CPU oracle on the same inputs (downloaded from the device: the inputs are
     generated there).  Test infrastructure in the checker's role only: nothing here is timed.  -> (True / False, what was compared)"""
     import numpy as np
     from oracle import oracle, ref as R
@@ -304,21 +309,22 @@ def verify(w):
         w.finish_pending()  # odd lanes hold a product waiting for its relinearization: complete their last op (same launch, untimed)
         w.sync_all()
         O.set_kswitch_key(0, key_host(w.key))
-        for lane, idx in ((0, 0), (S - 1, w.lanes[S - 1][2] - 1)):
+        for lane in _picks(S):
             cx, st, Bi, sa, sb, oi, ai, bi = w.lanes[lane]
+            idx = 0 if lane == 0 else (Bi - 1 if lane == S - 1 else Bi // 2)
             xa, xb = _item(ai.buf, ai.bstride, idx, (ai.capacity, L, N))[:2], _item(bi.buf, bi.bstride, idx, (bi.capacity, L, N))[:2]
             got = _item(oi.buf, oi.bstride, idx, (3, L, N))[:2]
             exp = O.eval(R.OP_RELIN, O.eval(R.OP_MULTIPLY, Ct(np.ascontiguousarray(xa)), Ct(np.ascontiguousarray(xb)))).data
             if not np.array_equal(got, exp):
                 return False, f"lane {lane} item {idx} differs from the oracle"
             checked.append(f"lane {lane} item {idx}")
-        return True, "multiply+relinearize of " + ", ".join(checked) + " (first and last ciphertext pair of the rank)"
+        return True, "multiply+relinearize of " + ", ".join(checked) + " (first, interior and last ciphertext pairs of the rank)"
     if kind == "ckks_chain":
         scale, depth = w.bs[0].scale, w.wl["depth"]
         O.set_kswitch_key(0, key_host(w.rlk.keys[0]))
         elt = w.ctx.galois_elt_from_step(1)
         O.set_kswitch_key(elt, key_host(w.gk.keys[w.ta.GaloisKeys.getIndex(elt)]))
-        for idx in (0, w.B - 1):
+        for idx in _picks(w.B):
             y = Ct(np.ascontiguousarray(_item(w.x0.buf, w.x0.bstride, idx, (w.x0.capacity, L, N))[:2]), True, scale)
             for d in range(depth):
                 b = Ct(np.ascontiguousarray(_item(w.bs[d].buf, w.bs[d].bstride, idx, (2, L - d, N))), True, scale)
@@ -334,7 +340,7 @@ def verify(w):
         O.set_kswitch_key(0, key_host(w.rlk.keys[0]))
         elt = w.ctx.galois_elt_from_step(1)
         O.set_kswitch_key(elt, key_host(w.gk.keys[w.ta.GaloisKeys.getIndex(elt)]))
-        for idx in (0, w.B - 1):
+        for idx in _picks(w.B):
             x3 = Ct(np.ascontiguousarray(_item(w.x3.buf, w.x3.bstride, idx, (3, L, N))), False)
             exp = O.eval(R.OP_ROTATE_ROWS, O.eval(R.OP_RELIN, x3), iarg=1).data
             got = _item(w.last.buf, w.last.bstride, idx, (w.last.capacity, L, N))[:2]
@@ -345,7 +351,7 @@ def verify(w):
     if kind == "matmul":
         scale = w.inputs[0].scale
         rows, cols = len(w.helper.encodedWeights), len(w.helper.encodedWeights[0])
-        for idx in (0, w.B - 1):
+        for idx in _picks(w.B):
             xs = [Ct(np.ascontiguousarray(_item(a.buf, a.bstride, idx, (2, L, N))), True, scale) for a in w.inputs]
             for j in (0, cols - 1):
                 acc = None

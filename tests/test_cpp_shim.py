@@ -134,3 +134,14 @@ REF_TIMETEST = os.path.join(ROOT, "oracle", "_ref", "ref_timetest")
 def test_timetest_source_against_the_reference_cpu_half():
     """the SAME test source, compiled against the reference's own troy:: classes: every assertion the GPU build makes also holds on the reference"""
     _run(REF_TIMETEST, "4096")
+
+
+def test_fp64_arithmetic_and_bound_walk_on_cpu(tmp_path):
+    """troy_amd/csrc/fpmod.h on the host: exact products within their stated magnitude, and a plain-loop model of the transforms under the masks of
+    fp_plan / fp_plan_inv -- every intermediate value an exact integer below 2^53 and below the walk's bound, final residues equal to the integer
+    transform's, unschedulable round shapes refused (tests/cpp/test_fp_plan.cpp)"""
+    exe = str(tmp_path / "test_fp_plan")
+    subprocess.run(["g++", "-std=c++17", "-O2", "-Wall", "-Werror", "-DTROYHIP_CPU_EMUL", "-I" + os.path.join(ROOT, "tests", "emul"), "-I" + os.path.join(ROOT, "troy_amd", "csrc"),
+                    "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "test_fp_plan.cpp"), "-o", exe], check=True, capture_output=True, text=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and " 0 failures" in r.stdout, r.stdout[-3000:]
