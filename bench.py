@@ -461,7 +461,7 @@ def ktime_report(capi, lib):
 
 def per_kernel(ta, capi, lib, w):
     """every kernel of ONE step of one lane, by the library's per-launch HIP events; algorithmic bytes (compulsory reads + writes
-    of the stage) where the table below knows the kernel; HBM traffic from profiles/r02_traffic.json (rocprofv3 PMC)"""
+    of the stage) where the table below knows the kernel; HBM traffic from profiles/r04_traffic_<workload>.json (rocprofv3 PMC, tools/measure_traffic.sh)"""
     w.sync_all()
     capi.check(lib, lib.troyhip_ktime_enable(1))
     w.profile_step()
@@ -484,7 +484,8 @@ def per_kernel(ta, capi, lib, w):
             e["frac"] = round(ab / (k["total_us"] * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4)
         tr = traffic.get(k["name"])
         if tr and ab and w.B == tinfo.get("batch") and w.N == tinfo.get("N"):  # PMC bytes of the same launches at the same batch, scaled to this lane
-            e["traffic"] = int(tr["hbm_bytes"] * w.profile_units / tinfo["batch"])
+            units_measured = tinfo["batch"] * (w.wl["depth"] if w.wl["kind"] == "ckks_chain" else 1)  # the PMC pass ran ONE whole step: B units, B x depth for the chain
+            e["traffic"] = int(tr["hbm_bytes"] * w.profile_units / units_measured)
             e["traffic_ratio"] = round(e["traffic"] / ab, 3)
         out.append(e)
     return out
