@@ -635,12 +635,22 @@ def test_bench_rccl_single_rank(gpu):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("batch", [8, 64])
+@pytest.mark.parametrize("batch", [1, 2, 8, 64])
 def test_bench_accounts_for_every_kernel_at_small_batches(batch, gpu):
     """the library picks the single-pass inverse per launch (at least four rows per CU): at a small lane batch the key switch's accumulators take the
     two-pass kernels while the multiply's rows still run single-pass.  bench.py's byte table follows that rule -- every kernel of the step has its
     fraction, the line verifies, and nothing raises (found with `--batch 64` under two ranks)"""
     line = _run_bench(["--steps", "1", "--warmup", "0", "--batch", str(batch), "--no-cpu-baseline", "--ntt-reps", "1"])
+    assert line["verified"] is True and line["config"]["batch_per_gpu"] == batch
+    assert all(k.get("frac") for k in line["roofline"]["per_kernel"]), [k["name"] for k in line["roofline"]["per_kernel"] if not k.get("frac")]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("workload,batch", [("bfv_n8192_l4", 1), ("bfv_n8192_l4", 8), ("bgv_n65536_relin_rot", 1)])
+def test_bench_accounts_for_every_kernel_of_one_ciphertext(workload, batch, gpu):
+    """one ciphertext (a few small ones) on one stream: the merged small-launch forms -- the byte table names the kernels that ran (a renamed
+    instance would raise) and the line verifies"""
+    line = _run_bench(["--steps", "1", "--warmup", "0", "--batch", str(batch), "--streams", "1", "--workload", workload, "--no-cpu-baseline", "--ntt-reps", "1"])
     assert line["verified"] is True and line["config"]["batch_per_gpu"] == batch
     assert all(k.get("frac") for k in line["roofline"]["per_kernel"]), [k["name"] for k in line["roofline"]["per_kernel"] if not k.get("frac")]
 
