@@ -21,6 +21,27 @@ for wl in bfv_n32768_l14 bfv_n32768_l14_p49; do
   f=$(find $O/prof_rf_$wl -name "p_kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/r04_roofline_${wl}_kernel_stats.csv
   rm -rf $O/prof_rf_$wl
 done
+# SQ counters (own passes, kernel trace only) over the roofline launches of the headline and of its 49-bit twin, and over one step of configs[1]
+SQ1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU"; SQ2="SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT"
+for wl in bfv_n32768_l14 bfv_n32768_l14_p49; do
+  : > $O/r04_pmc_sq_roofline_$wl.txt
+  for set in "$SQ1" "$SQ2"; do
+    rm -rf $O/pmc_$wl
+    (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --pmc $set --output-format csv -d $O/pmc_$wl -o p -- python3 $R/bench.py --workload $wl --roofline-only --batch 32 --ntt-reps 4 --no-cpu-baseline > $O/pmc_$wl.log 2>&1)
+    f=$(find $O/pmc_$wl -name "p_counter_collection.csv" | head -1); [ -n "$f" ] && python tools/pmc_summary.py $f | grep -v "fill_uniform\|copyBuffer" >> $O/r04_pmc_sq_roofline_$wl.txt
+  done
+  rm -rf $O/pmc_$wl
+done
+: > $O/r04_pmc_sq_bfv_n8192_l4.txt
+for set in "$SQ1" "$SQ2"; do
+  rm -rf $O/pmc_c1
+  (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --pmc $set --output-format csv -d $O/pmc_c1 -o p -- python3 $R/bench.py --workload bfv_n8192_l4 --steps 1 --warmup 0 --batch 256 --streams 1 --no-roofline --no-cpu-baseline --no-per-kernel --no-verify > $O/pmc_c1.log 2>&1)
+  f=$(find $O/pmc_c1 -name "p_counter_collection.csv" | head -1); [ -n "$f" ] && python tools/pmc_summary.py $f | grep -v "fill_uniform\|copyBuffer" >> $O/r04_pmc_sq_bfv_n8192_l4.txt
+done
+rm -rf $O/pmc_c1
+# kernel timeline of ONE ciphertext (and of eight) at the headline and configs[1]
+{ for a in "bfv_n32768_l14 1" "bfv_n32768_l14 8" "bfv_n8192_l4 1" "bfv_n8192_l4 8"; do echo "## $a"; tools/r4_b1_timeline.sh $a final 2>/dev/null | grep -v simple_timer; done; } > $O/r04_b1_timeline.txt
+rm -rf gpurun_out/b1tl_*_final
 tools/r4_small_batch.sh final > /dev/null 2>&1; cp $O/small_batch.txt $O/r04_small_batch.txt
 tools/r4_timetest.sh final 1 20 > /dev/null 2>&1; cp $O/timetest.txt $O/r04_timetest.txt
 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29541 tools/dist_two_ranks.py bfv_n32768_l14 64 2>$O/dist.err | tail -1 > $O/r04_dist_two_ranks.txt

@@ -24,5 +24,5 @@ for s in range(steps):
             gap[i] += (int(r["Start_Timestamp"]) - int(tail[k - 1]["End_Timestamp"])) / 1e3 / (steps if i else steps - 1)
 for i in range(per):
     r = tail[i]
-    print(f"{i:3d} {names[i][:64]:64s} grid {int(r['Grid_Size_X']) // max(int(r['Workgroup_Size_X']), 1):6d} x {r['Workgroup_Size_X']:>4s}  gap {gap[i]:6.1f} us  run {dur[i]:7.1f} us")
+    print(f"{i:3d} {names[i][:64]:64s} wgs {(int(r['Grid_Size_X']) // max(int(r['Workgroup_Size_X']), 1)) * int(r.get('Grid_Size_Y', 1) or 1) * int(r.get('Grid_Size_Z', 1) or 1):6d} x {r['Workgroup_Size_X']:>4s}  gap {gap[i]:6.1f} us  run {dur[i]:7.1f} us")
 print(f"per step: kernels {sum(dur):.1f} us + gaps {sum(gap):.1f} us = {sum(dur) + sum(gap):.1f} us")
