@@ -743,7 +743,8 @@ __device__ __forceinline__ void ntt2_body(const Ntt2Args &a) {
 #pragma unroll
                 for (int e = 0; e < 8; e++) {
                     const u64 kword = (e & 1) ? kw[cpt][e >> 1].y : kw[cpt][e >> 1].x;
-                    facc[cpt][e] += fp_mulmod_pinv(fp_of_bits(xr[e]), fp_from_u64(kword), fc);
+                    // N2_EXP & 16 (removal probe, wrong results): the key word taken as a double as it lies -- what storing the key as doubles would save
+                    facc[cpt][e] += fp_mulmod_pinv(fp_of_bits(xr[e]), (N2_EXP & 16) ? fp_of_bits(kword) : fp_from_u64(kword), fc);
                 }
             if (a.fp_acc_every && (row_no + 1) % a.fp_acc_every == 0) { // wave-uniform; the sums stay below 2^53 (launch_ntt2_ks_mac)
 #pragma unroll
