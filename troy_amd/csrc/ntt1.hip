@@ -93,6 +93,15 @@ __device__ __forceinline__ unsigned sw1(unsigned j) { return j ^ (((j >> 6) & 7u
 #ifndef N1_FP_FENCE_B
 #define N1_FP_FENCE_B 2 // FP64 forward kernel, round B (16 values in registers next to the waiting half): butterflies in flight between scheduling fences
 #endif
+#ifndef N1_FWD_STORE_VIA_LDS
+#define N1_FWD_STORE_VIA_LDS 1 // 0 (probe): the forward kernels store each thread's eight consecutive results directly
+#endif
+#ifndef N1_FWD_STORE_UNROLL
+#define N1_FWD_STORE_UNROLL 2
+#endif
+#ifndef N1_FP_ODD_EARLY
+#define N1_FP_ODD_EARLY 0 // 1 (probe): the odd half of a row is converted up front, as before round 4
+#endif
 #ifndef N1_INV_SWZ
 #define N1_INV_SWZ 2
 #endif
@@ -140,8 +149,16 @@ __device__ __forceinline__ unsigned opaque(unsigned v) {
 }
 #ifdef TROYHIP_CPU_EMUL
 #define N1_SCHED_FENCE()
+#define N1_PIN_LOADS()
+__device__ __forceinline__ void order_after(u64 &, const u64 &) {}
 #else
 #define N1_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+// loads written above this line are ISSUED above it: without it the compiler sinks a prefetch to its first use (there is no barrier or LDS operation
+// between the end of a row and the top of the next), i.e. issues it where it is needed
+#define N1_PIN_LOADS() asm volatile("" ::: "memory")
+// `later` is not touched before `earlier` has its final value (a data dependency the optimiser cannot see through): orders pure arithmetic, which
+// scheduling fences do not
+__device__ __forceinline__ void order_after(u64 &later, const u64 &earlier) { asm volatile("" : "+v"(later) : "v"(earlier)); }
 #endif
 
 __device__ __forceinline__ unsigned uniform_u32(unsigned v) {
@@ -413,7 +430,23 @@ template <int LOGN, bool LEAN, bool CR, bool FP> __device__ __forceinline__ void
             ulonglong2 v;
             v.x = y[2 * q];
             v.y = y[2 * q + 1];
-            st_g2(out, 8 * u + 2 * q, v);
+            if (N1_FWD_STORE_VIA_LDS) *reinterpret_cast<ulonglong2 *>(R + sw1(8 * u + 2 * q)) = v; // back where it was read from
+            else st_g2(out, 8 * u + 2 * q, v);
+        }
+    }
+    if (N1_FWD_STORE_VIA_LDS) {
+        // A thread ends with eight consecutive coefficients: stored from there, an instruction writes 16 bytes per lane every 64 bytes -- 64 partial
+        // lines, four instructions per line.  Through the wave's region (its content is dead now) the same data leaves lane-linearly: eight
+        // instructions of one contiguous KiB each.  (The inverse kernel's loads and stores are lane-linear by construction; this was the forward
+        // kernel's one scattered access.)
+        TROY_WAVE_SYNC();
+#pragma unroll 1
+        for (unsigned i = 0; i < 8; i += N1_FWD_STORE_UNROLL) { // a few at a time: the waiting half of the row and the next row's prefetch hold most of the registers
+#pragma unroll
+            for (unsigned k = 0; k < N1_FWD_STORE_UNROLL; k++) {
+                const unsigned j = 128 * (i + k) + 2 * lane;
+                st_g2(out, j, *reinterpret_cast<const ulonglong2 *>(R + sw1(j)));
+            }
         }
     }
 }
@@ -469,29 +502,40 @@ template <bool LEAN, bool CR, bool FP> __device__ __forceinline__ void ntt1_fwd_
                                 : ((int)(mm % a.cr_group) < a.cr_base_polys) ? a.cr_base + (u64)(mm / a.cr_group) * a.cr_base_gstride + (u64)(mm % a.cr_group) * a.cr_out_ostride + ((u64)slot << N1_LOGN)
                                                          : nullptr;
         const u64 *const cin = CR ? a.cr_in + (a.cr_in_gstride ? (u64)(mm / a.cr_group) * a.cr_in_gstride + (u64)(mm % a.cr_group) * a.cr_in_ostride : (u64)mm * a.cr_in_ostride) + ((u64)slot << N1_LOGN) : nullptr;
-        if (CR) { // corr = [(last + half) mod qx]_p + (p - [half]_p), the residue lazily below 4p: below 5p, inside what the butterflies take
+        // what the loaded words become before the first butterfly, one half at a time: the odd half was requested LAST (one row ahead of its use by
+        // a few hundred instructions only), so in the FP64 kernels -- where this step is the first use of the words -- it is prepared after the even
+        // half's four stages, whose ~520 instructions cover its HBM latency (prepared up front it cost 7 % of the row: s_waitcnt vmcnt(0) at the loop top)
+        auto prepare = [&](u64 (&xx)[16]) {
+            if (CR) { // corr = [(last + half) mod qx]_p + (p - [half]_p), the residue lazily below 4p: below 5p, inside what the butterflies take
 #pragma unroll
-            for (int g = 0; g < 8; g++) {
-                u64 (&xx)[16] = g < 4 ? xe : xo;
-                u64 v[4] = {xx[4 * (g & 3)] + a.cr_half, xx[4 * (g & 3) + 1] + a.cr_half, xx[4 * (g & 3) + 2] + a.cr_half, xx[4 * (g & 3) + 3] + a.cr_half};
-                csub4(v, a.cr_qx);
-                lite_reduce4(v, (u32)pd.cr1, pc);
+                for (int g = 0; g < 4; g++) {
+                    u64 v[4] = {xx[4 * g] + a.cr_half, xx[4 * g + 1] + a.cr_half, xx[4 * g + 2] + a.cr_half, xx[4 * g + 3] + a.cr_half};
+                    csub4(v, a.cr_qx);
+                    lite_reduce4(v, (u32)pd.cr1, pc);
 #pragma unroll
-                for (int i = 0; i < 4; i++) xx[4 * (g & 3) + i] = FP ? fp_bits(fp_from_u64(v[i]) + (double)cr_add) : v[i] + cr_add; // FP64: 4p < 2^52 converts exactly
+                    for (int i = 0; i < 4; i++) xx[4 * g + i] = FP ? fp_bits(fp_from_u64(v[i]) + (double)cr_add) : v[i] + cr_add; // FP64: 4p < 2^52 converts exactly
+                }
+            } else if constexpr (FP) { // canonical residues become doubles (exact below 2^52)
+#pragma unroll
+                for (int r = 0; r < 16; r++) xx[r] = fp_bits(fp_from_u64(xx[r]));
             }
-        } else if constexpr (FP) { // canonical residues become doubles (exact below 2^52)
-#pragma unroll
-            for (int r = 0; r < 16; r++) { xe[r] = fp_bits(fp_from_u64(xe[r])); xo[r] = fp_bits(fp_from_u64(xo[r])); }
-        }
-        if constexpr (FP) {
-            if (a.fp_red_mask & 1u) { fp_reduce_all<16>(xe, fc); fp_reduce_all<16>(xo, fc); }
-        }
+            if constexpr (FP) {
+                if (a.fp_red_mask & 1u) fp_reduce_all<16>(xx, fc);
+            }
+        };
+        prepare(xe);
+        if constexpr (!FP || N1_FP_ODD_EARLY) prepare(xo);
         N1_STAMP(0);
         // round A: stages 0..3 on the even and on the odd registers (the odd ones were requested last), then stage 4 across
         auto twA = [&](int st, int, int blk) { return ld_tw_uniform((pd.root + (1u << st) + blk)); };
         N1_PRIO(1);
         if constexpr (FP) {
             fp_fwd_stages<1, 4>(xe, twA, fc);
+            if constexpr (!N1_FP_ODD_EARLY) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) order_after(xo[r], xe[r]);
+                prepare(xo);
+            }
             fp_fwd_stages<1, 4>(xo, twA, fc);
 #pragma unroll
             for (int r = 0; r < 16; r++) { // stage 4: (xe[r], xo[r]) with the twiddle of block r
@@ -555,8 +599,10 @@ template <bool LEAN, bool CR, bool FP> __device__ __forceinline__ void ntt1_fwd_
                                        cr_inv, CR && cacc ? cacc + 1024 * (16 * hf + wv) : nullptr);
             N1_STAMP(7 + 6 * hf);
         }
-        if (mm + 1 < m_end) load_half(xo, in_row(mm + 1), 1);
-        else {
+        if (mm + 1 < m_end) {
+            load_half(xo, in_row(mm + 1), 1);
+            if constexpr (FP && !N1_FP_ODD_EARLY) N1_PIN_LOADS();
+        } else {
 #pragma unroll
             for (int r = 0; r < 16; r++) xo[r] = 0; // dead after the last row (see xe above)
         }
