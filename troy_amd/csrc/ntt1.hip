@@ -96,6 +96,9 @@ __device__ __forceinline__ unsigned sw1(unsigned j) { return j ^ (((j >> 6) & 7u
 #ifndef N1_FWD_STORE_VIA_LDS
 #define N1_FWD_STORE_VIA_LDS 1 // 0 (probe): the forward kernels store each thread's eight consecutive results directly
 #endif
+#ifndef N1_CR_LINEAR
+#define N1_CR_LINEAR 1 // 0 (probe): the divide-and-round epilogue on a thread's eight consecutive coefficients (16-byte loads every 64 bytes)
+#endif
 #ifndef N1_FWD_STORE_UNROLL
 #define N1_FWD_STORE_UNROLL 2
 #endif
@@ -397,7 +400,7 @@ template <int LOGN, bool LEAN, bool CR, bool FP> __device__ __forceinline__ void
                 for (int i = 0; i < 4; i++) y[4 * q + i] = v[i];
             }
         }
-        if (CR) { // y = NTT(corr), canonical: out = (in + p - y) * inv mod p, stored or added to what is there (Ntt1Corr)
+        if (CR && !(N1_FWD_STORE_VIA_LDS && N1_CR_LINEAR)) { // y = NTT(corr), canonical: out = (in + p - y) * inv mod p, stored or added to what is there (Ntt1Corr)
             const Shoup iq[4] = {cr_inv, cr_inv, cr_inv, cr_inv};
 #pragma unroll
             for (int h = 0; h < 2; h++) {
@@ -440,6 +443,29 @@ template <int LOGN, bool LEAN, bool CR, bool FP> __device__ __forceinline__ void
         // instructions of one contiguous KiB each.  (The inverse kernel's loads and stores are lane-linear by construction; this was the forward
         // kernel's one scattered access.)
         TROY_WAVE_SYNC();
+        if constexpr (CR && N1_CR_LINEAR) {
+            // the divide-and-round epilogue on the way out, in the same layout: y = NTT(corr), canonical; out = (in + p - y) * inv mod p, stored or added to
+            // what is there (Ntt1Corr) -- `in` and the accumulation target are read a contiguous KiB per instruction like the stores
+            const Shoup iq[4] = {cr_inv, cr_inv, cr_inv, cr_inv};
+#pragma unroll 1
+            for (unsigned i = 0; i < 8; i += 2) {
+                const unsigned j0 = 128 * i + 2 * lane, j1 = j0 + 128;
+                const ulonglong2 ya = *reinterpret_cast<const ulonglong2 *>(R + sw1(j0)), yb = *reinterpret_cast<const ulonglong2 *>(R + sw1(j1));
+                const ulonglong2 ia = ld_g2(cr_in, j0), ib = ld_g2(cr_in, j1);
+                u64 w[4] = {ia.x + pc.p - ya.x, ia.y + pc.p - ya.y, ib.x + pc.p - yb.x, ib.y + pc.p - yb.y}, q[4], r[4];
+                mulhi_approx4_u(q, w, iq);
+#pragma unroll
+                for (int e = 0; e < 4; e++) r[e] = mul_acc_u(0, w[e], cr_inv.op, q[e], pc.negp); // [0, 3p)
+                if (cr_acc) { // what the result is added to: the output itself, or the base polynomial of a rotation (null: nothing, start from zero)
+                    const ulonglong2 ca = ld_g2(cr_acc, j0), cb = ld_g2(cr_acc, j1);
+                    r[0] += ca.x; r[1] += ca.y; r[2] += cb.x; r[3] += cb.y;
+                }
+                csub4(r, pc.two_p);
+                csub4(r, pc.p);
+                st_g2(out, j0, ulonglong2{r[0], r[1]});
+                st_g2(out, j1, ulonglong2{r[2], r[3]});
+            }
+        } else {
 #pragma unroll 1
         for (unsigned i = 0; i < 8; i += N1_FWD_STORE_UNROLL) { // a few at a time: the waiting half of the row and the next row's prefetch hold most of the registers
 #pragma unroll
@@ -447,6 +473,7 @@ template <int LOGN, bool LEAN, bool CR, bool FP> __device__ __forceinline__ void
                 const unsigned j = 128 * (i + k) + 2 * lane;
                 st_g2(out, j, *reinterpret_cast<const ulonglong2 *>(R + sw1(j)));
             }
+        }
         }
     }
 }
