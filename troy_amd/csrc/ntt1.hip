@@ -109,6 +109,10 @@ __device__ __forceinline__ unsigned sw1(unsigned j) { return j ^ (((j >> 6) & 7u
 #define N1_INV_SWZ 2
 #endif
 __device__ __forceinline__ unsigned sw2(unsigned j) { return N1_INV_SWZ == 2 ? sw1(j) ^ (((j >> 4) & 1u) << 2) : sw1(j); }
+#ifndef N1_FWD_WB_SW1
+#define N1_FWD_WB_SW1 0 // 1 (probe): the forward kernels' write-back for the lane-linear stores under sw1 (2-way conflicted 16-byte writes)
+#endif
+__device__ __forceinline__ unsigned wb_swz(unsigned j) { return N1_FWD_WB_SW1 ? sw1(j) : sw2(j); }
 __device__ __forceinline__ unsigned sw2_inv(unsigned x) { // bits 5.. are untouched by sw2: undo bit 4 first, then the term it feeds
     if (N1_INV_SWZ != 2) return sw1(x);
     const unsigned y = sw1(x);
@@ -433,7 +437,7 @@ template <int LOGN, bool LEAN, bool CR, bool FP> __device__ __forceinline__ void
             ulonglong2 v;
             v.x = y[2 * q];
             v.y = y[2 * q + 1];
-            if (N1_FWD_STORE_VIA_LDS) *reinterpret_cast<ulonglong2 *>(R + sw1(8 * u + 2 * q)) = v; // back where it was read from
+            if (N1_FWD_STORE_VIA_LDS) *reinterpret_cast<ulonglong2 *>(R + wb_swz(8 * u + 2 * q)) = v; // into the eight slots it was read from (sw2: these 16-byte writes are 2-way conflicted under sw1)
             else st_g2(out, 8 * u + 2 * q, v);
         }
     }
@@ -450,7 +454,7 @@ template <int LOGN, bool LEAN, bool CR, bool FP> __device__ __forceinline__ void
 #pragma unroll 1
             for (unsigned i = 0; i < 8; i += 2) {
                 const unsigned j0 = 128 * i + 2 * lane, j1 = j0 + 128;
-                const ulonglong2 ya = *reinterpret_cast<const ulonglong2 *>(R + sw1(j0)), yb = *reinterpret_cast<const ulonglong2 *>(R + sw1(j1));
+                const ulonglong2 ya = *reinterpret_cast<const ulonglong2 *>(R + wb_swz(j0)), yb = *reinterpret_cast<const ulonglong2 *>(R + wb_swz(j1));
                 const ulonglong2 ia = ld_g2(cr_in, j0), ib = ld_g2(cr_in, j1);
                 u64 w[4] = {ia.x + pc.p - ya.x, ia.y + pc.p - ya.y, ib.x + pc.p - yb.x, ib.y + pc.p - yb.y}, q[4], r[4];
                 mulhi_approx4_u(q, w, iq);
@@ -471,7 +475,7 @@ template <int LOGN, bool LEAN, bool CR, bool FP> __device__ __forceinline__ void
 #pragma unroll
             for (unsigned k = 0; k < N1_FWD_STORE_UNROLL; k++) {
                 const unsigned j = 128 * (i + k) + 2 * lane;
-                st_g2(out, j, *reinterpret_cast<const ulonglong2 *>(R + sw1(j)));
+                st_g2(out, j, *reinterpret_cast<const ulonglong2 *>(R + wb_swz(j)));
             }
         }
         }
