@@ -48,8 +48,8 @@ namespace troyhip {
 #ifndef N2_DMA
 #define N2_DMA 1 // contiguous passes prefetch the next row with LDS-DMA
 #endif
-#ifndef N2_MAC_LINEAR
-#define N2_MAC_LINEAR 1 // key-switch inner product on the lane-linear layout (contiguous key loads and sum stores); 0 (probe): on a thread's eight consecutive coefficients
+#ifndef N2_MAC_STORE_LINEAR
+#define N2_MAC_STORE_LINEAR 1 // the key-switch sums are stored through the wave's exchange area (contiguous KiB per instruction); 0 (probe): from a thread's eight consecutive coefficients
 #endif
 #ifndef N2_COALESCED_STORE
 #define N2_COALESCED_STORE 1 // forward contiguous pass: transpose the last round through LDS, store 1 KiB per instruction
@@ -400,27 +400,6 @@ template <int INV, int STRIDED, int NS, int LOGC, int LS, int R, bool HOISTP = t
         for (int c = 0; c < 4; c++) {
             const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(wave_xchg + 128 * c + 2 * lane);
             *reinterpret_cast<ulonglong2 *>(dst + 128 * c) = v;
-        }
-    }
-    // The same transposition for values that stay in registers: afterwards x[2c], x[2c+1] are the coefficients 128 c + 2 unit_perm(lane) + {0, 1} of the
-    // wave's 512 -- the layout in which a wave reads or writes one contiguous KiB per instruction (the key-switch inner product takes its key words
-    // and leaves its sums that way; from a thread's eight consecutive coefficients every access was 16 bytes per lane every 64 bytes)
-    __device__ static __forceinline__ void to_lane_linear(u64 (&x)[8], u64 *wave_xchg) {
-        const unsigned lane = threadIdx.x & 63;
-        u64 *mine = wave_xchg + 128 * (lane >> 4) + 2 * (lane & 15);
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            ulonglong2 v;
-            v.x = x[2 * j];
-            v.y = x[2 * j + 1];
-            *reinterpret_cast<ulonglong2 *>(mine + 32 * j) = v;
-        }
-        TROY_WAVE_SYNC();
-#pragma unroll
-        for (int c = 0; c < 4; c++) {
-            const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(wave_xchg + 128 * c + 2 * lane);
-            x[2 * c] = v.x;
-            x[2 * c + 1] = v.y;
         }
     }
     // MAC = 2 epilogue of the forward contiguous pass: virtual row vr = mm % 4 of (a0, a1, b0, b1); x is the lazy transform
@@ -792,12 +771,11 @@ __device__ __forceinline__ void ntt2_body(const Ntt2Args &a) {
     };
     // read once: indexing the argument block with `slot` is a memory load, and inside the row loop it sat, with its wait, in front of the key loads
     const unsigned key_limb = KS ? (unsigned)__builtin_amdgcn_readfirstlane((int)a.mac_key_limb[slot]) : 0;
-    // where this thread's accumulators sit in the tile: pair c = 0..3 at mac_pos + 2 MAC_STEP c.  Lane-linear (N2_MAC_LINEAR): the transform is
-    // transposed through the wave's exchange area after its last round (Rd2::to_lane_linear), so that the key loads, the CKKS operand row and the stores
-    // of the sums are one contiguous KiB per wave and instruction; else the thread's eight consecutive coefficients
-    constexpr bool MAC_LINEAR = KS && N2_MAC_LINEAR && WAVE_PRIVATE;
-    constexpr unsigned MAC_STEP = MAC_LINEAR ? 64 : 1; // in 16-byte units
-    const unsigned mac_pos = MAC_LINEAR ? 512 * (threadIdx.x >> 6) + 2 * Rd2::unit_perm(threadIdx.x & 63) : 8 * threadIdx.x;
+    // the sums leave through the wave's exchange area, one contiguous KiB per wave and instruction (Rd2::store_via_lds): written from a thread's eight
+    // consecutive coefficients they were 16 bytes per lane every 64 bytes -- the access pattern that cost the single-pass forward kernel 9 % (ntt1.hip).
+    // Same-box A/B (tools/r4_ab_maclin.sh): accumulating pass -1..-3 % at the headline, -4 % in the CKKS chain, -8 % at configs[1], BGV N = 2^16 unchanged.
+    // (The key LOADS in that pattern are harmless: a per-row transposition that made them contiguous as well measured the same or 1-2 % slower.)
+    constexpr bool MAC_STORE_LINEAR = KS && N2_MAC_STORE_LINEAR && WAVE_PRIVATE;
     u64 *const wave_stage = lds[1] + 512 * (threadIdx.x >> 6);
     u64 x[8];
     unsigned ro = m_begin / inner, rk = m_begin - ro * inner; // (o, k) of the current row
@@ -824,12 +802,12 @@ __device__ __forceinline__ void ntt2_body(const Ntt2Args &a) {
         // order) does not include the staging loads' HBM latency -- and used after the three rounds
         auto load_keys = [&]() {
             const unsigned kk = rk;
-            const u64 *kp = a.mac_key + ((((u64)kk * 2) * a.mac_K + key_limb) << logn) + ((u64)tile << N2_LOGT) + mac_pos;
+            const u64 *kp = a.mac_key + ((((u64)kk * 2) * a.mac_K + key_limb) << logn) + ((u64)tile << N2_LOGT) + 8 * threadIdx.x;
 #pragma unroll
             for (int cpt = 0; cpt < 2; cpt++) {
                 const ulonglong2 *kq = reinterpret_cast<const ulonglong2 *>(kp + ((u64)cpt * a.mac_K << logn));
 #pragma unroll
-                for (int e = 0; e < 4; e++) kv[cpt][KS ? e : 0] = kq[MAC_STEP * e];
+                for (int e = 0; e < 4; e++) kv[cpt][KS ? e : 0] = kq[e];
             }
         };
         if constexpr (KS) load_keys();
@@ -873,11 +851,10 @@ __device__ __forceinline__ void ntt2_body(const Ntt2Args &a) {
                         for (int i = 0; i < 4; i++) x[4 * h + i] = v[i];
                     }
                 }
-                if constexpr (MAC_LINEAR) { TROY_WAVE_SYNC(); Rd2::to_lane_linear(x, buf + 512 * (threadIdx.x >> 6)); }
             } else { // the operand is the NTT-form input limb: no staged row, no transform
-                const ulonglong2 *tp = reinterpret_cast<const ulonglong2 *>(a.mac_target + (u64)ro * a.mac_tstride + ((u64)rk << logn) + ((u64)tile << N2_LOGT) + mac_pos);
+                const ulonglong2 *tp = reinterpret_cast<const ulonglong2 *>(a.mac_target + (u64)ro * a.mac_tstride + ((u64)rk << logn) + ((u64)tile << N2_LOGT) + 8 * threadIdx.x);
 #pragma unroll
-                for (int e = 0; e < 4; e++) { const ulonglong2 v = tp[MAC_STEP * e]; x[2 * e] = v.x; x[2 * e + 1] = v.y; }
+                for (int e = 0; e < 4; e++) { const ulonglong2 v = tp[e]; x[2 * e] = v.x; x[2 * e + 1] = v.y; }
                 if constexpr (FP) {
 #pragma unroll
                     for (int e = 0; e < 8; e++) x[e] = fp_bits(fp_from_u64(x[e]));
@@ -963,8 +940,7 @@ __device__ __forceinline__ void ntt2_body(const Ntt2Args &a) {
                             for (int i = 0; i < 4; i++) x[4 * h + i] = v[i];
                         }
                     }
-                    if constexpr (MAC_LINEAR) { TROY_WAVE_SYNC(); Rd2::to_lane_linear(x, buf + 512 * (threadIdx.x >> 6)); }
-                    mac_row(x, kv, mm - m_begin);
+                        mac_row(x, kv, mm - m_begin);
                 } else if constexpr (NR == 3) {
                     if constexpr (FINAL >= 3) Rd2::template md_write<FINAL>(x, a, mm, slot, tile, logn, m, pd, fcp);
                     else Rd2::template g_write<FINAL>(x, row, tile, logn, m, lean, WAVE_PRIVATE ? buf : nullptr, fcp);
@@ -997,10 +973,11 @@ __device__ __forceinline__ void ntt2_body(const Ntt2Args &a) {
     }
     if constexpr (KS) { // one reduction per output coefficient; acc[o][c][slot][N]
         const unsigned o = m_begin / inner;
-        const u64 pos = ((u64)tile << N2_LOGT) + mac_pos;
+        const u64 pos = ((u64)tile << N2_LOGT) + 8 * threadIdx.x;
 #pragma unroll
         for (int cpt = 0; cpt < 2; cpt++) {
             ulonglong2 *op = reinterpret_cast<ulonglong2 *>(a.mac_acc + ((((u64)o * 2 + cpt) * period + slot) << logn) + pos);
+            u64 lin[8];
 #pragma unroll
             for (int e = 0; e < 4; e++) {
                 ulonglong2 v;
@@ -1012,8 +989,14 @@ __device__ __forceinline__ void ntt2_body(const Ntt2Args &a) {
                     v.x = barrett128(mk64(p0.a0, p0.a1), mk64(p0.a2, p0.a3), m);
                     v.y = barrett128(mk64(p1.a0, p1.a1), mk64(p1.a2, p1.a3), m);
                 }
-                op[MAC_STEP * e] = v;
+                if constexpr (MAC_STORE_LINEAR) { lin[2 * e] = v.x; lin[2 * e + 1] = v.y; }
+                else op[e] = v;
             }
+            if constexpr (MAC_STORE_LINEAR) {
+                TROY_WAVE_SYNC();
+                Rd2::store_via_lds(lin, a.mac_acc + ((((u64)o * 2 + cpt) * period + slot) << logn), tile, lds[0] + 512 * (threadIdx.x >> 6));
+            }
+            (void)lin;
         }
     }
 }
