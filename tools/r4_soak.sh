@@ -6,7 +6,7 @@ out=gpurun_out/r04_random_soak.txt
 mkdir -p gpurun_out
 python - > $out <<'PY'
 from troy_amd import capi
-print("libtroyhip.so build", capi.load().troyhip_build_info().decode() if hasattr(capi.load(), "troyhip_build_info") else "")
+print("libtroyhip.so build", capi.build_id(), "(" + capi.load().troyhip_build_info().decode() + ")")
 PY
 run() { echo "\$ $*" >> $out; env "$@" >> $out 2>&1; }
 run python tools/random_soak.py 500000 3000
