@@ -70,7 +70,7 @@ struct Ntt1Args {
 // wave priority by progress: a wave that is ahead of the others in a barrier-to-barrier segment lowers its own priority, so the
 // four waves of a SIMD advance together (the arbiter otherwise serves the oldest wave first and the segment ends with one wave
 // per SIMD running alone)
-#if defined(N1_PRIO_ON) && !defined(TROYHIP_CPU_EMUL)
+#if !defined(N1_PRIO_OFF) && !defined(TROYHIP_CPU_EMUL) // forward kernels only; on since they store lane-linearly (round 4: integer forward -3 %, FP64 -1 %; before that neutral).  The same hints in the inverse kernels: FP64 +4 % SLOWER, integer neutral
 #define N1_PRIO(k) __builtin_amdgcn_s_setprio(k)
 #else
 #define N1_PRIO(k)
