@@ -1,3 +1,5 @@
+#!/bin/bash
+# SQ counters (four passes of four) over the roofline launches of the single-pass kernels: WLS="bfv_n32768_l14 bfv_n32768_l14_p49" tools/r4_sq_probe.sh -> gpurun_out/sqp/sq_<workload>.txt
 R=$PWD; O=$R/gpurun_out/sqp; mkdir -p $O
 SQ1="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU"; SQ2="SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT"; SQ3="SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_VMEM_RD"; SQ4="SQ_INST_CYCLES_VMEM_RD SQ_ACTIVE_INST_ANY SQ_WAVES SQ_INSTS_VMEM_WR"
 for wl in ${WLS:-bfv_n32768_l14_p49}; do
