@@ -1,7 +1,7 @@
 #!/bin/bash
 # bench.py over its flag space (workload x batch x streams): every line must verify and account for every kernel
-for wl in bfv_n32768_l14 bfv_n8192_l4 ckks_n32768_chain bgv_n65536_relin_rot ckks_matmul_128; do
-  for b in 0 8 48; do
+for wl in bfv_n32768_l14 bfv_n32768_l14_p49 bfv_n8192_l4 ckks_n32768_chain bgv_n65536_relin_rot ckks_matmul_128; do
+  for b in 0 1 8 48; do
     for s in 1 2 3; do
       out=$(timeout 600 python bench.py --workload $wl --batch $b --streams $s --steps 2 --warmup 1 --no-cpu-baseline --ntt-reps 2 2>/tmp/bm.err | tail -1)
       python - "$wl" "$b" "$s" <<PY || { echo "FAILED $wl batch $b streams $s"; tail -3 /tmp/bm.err; }
