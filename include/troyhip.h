@@ -61,9 +61,10 @@ int troyhip_free(void *p);                          /* KernelProvider::free */
 /* malloc/free go through a caching pool with the reference's MemoryPoolCuda policy (src/utils/memorypool_cuda.cuh:40-58): a freed
  * block serves a later request of size <= block <= 2 * size.  Reuse is ordered against the default stream, every stream made by
  * troyhip_stream_create and every stream announced with troyhip_stream_register: a block freed while work on one of THOSE streams still
- * uses it is not handed out before that work has passed.  A stream the library was never told about is not covered -- register it
- * (a caller-created hipStream_t, a torch / RCCL stream) or synchronise it before freeing.  troyhip_pool_release synchronises the
- * device and returns every cached block to the driver. */
+ * uses it is not handed out before that work has passed.  A stream made elsewhere (a caller-created hipStream_t, a torch / RCCL stream) is
+ * announced automatically the first time any entry point of this header is handed it; work the CALLER launches on such a stream before the
+ * library has ever seen it is not covered -- troyhip_stream_register it first, or synchronise it before troyhip_free.  troyhip_pool_release
+ * synchronises the device and returns every cached block to the driver. */
 int troyhip_pool_release(void);
 int troyhip_copy_h2d(void *dst, const void *src, size_t bytes, void *stream);   /* KernelProvider::copy */
 int troyhip_copy_d2h(void *dst, const void *src, size_t bytes, void *stream);   /* KernelProvider::retrieve */

@@ -21,6 +21,7 @@
 #include <cstdint>
 #include <functional>
 #include <istream>
+#include <limits>
 #include <ostream>
 #include <map>
 #include <memory>
@@ -57,6 +58,15 @@ public:
     bool isZero() const { return value_ == 0; }
     int bitCount() const { return value_ ? 64 - __builtin_clzll(value_) : 0; } // src/modulus.h: bit_count_
     size_t uint64Count() const { return value_ ? 1 : 0; }
+    uint64_t reduce(uint64_t v) const { // src/modulus.h:362-370
+        if (!value_) throw std::logic_error("cannot reduce modulo a zero modulus");
+        return v % value_;
+    }
+    bool operator==(const Modulus &o) const { return value_ == o.value_; }
+    bool operator!=(const Modulus &o) const { return value_ != o.value_; }
+    bool operator==(uint64_t v) const { return value_ == v; }
+    bool operator!=(uint64_t v) const { return value_ != v; }
+    bool operator<(const Modulus &o) const { return value_ < o.value_; }
     // is_prime_ (src/modulus.cpp:80-121 via util::isPrime): Miller-Rabin with the twelve bases that decide every 64-bit integer
     bool isPrime() const {
         const uint64_t n = value_;
@@ -96,7 +106,20 @@ private:
     uint64_t value_;
 };
 
-struct CoeffModulus { // src/modulus.h:485
+struct CoeffModulus { // src/modulus.h:440-520
+#include "troyn_hestd.inc"
+    // MaxBitCount (src/modulus.cpp:14-51): the largest total coefficient-modulus bit count the security standard allows at this degree
+    static int MaxBitCount(size_t poly_modulus_degree, SecurityLevel sec_level = SecurityLevel::tc128) {
+        return sec_level == SecurityLevel::none ? std::numeric_limits<int>::max() : stdMaxBits((int)sec_level, poly_modulus_degree);
+    }
+    // BFVDefault (src/modulus.cpp:53-78): the primes SEAL ships for the standard degrees
+    static std::vector<Modulus> BFVDefault(size_t poly_modulus_degree, SecurityLevel sec_level = SecurityLevel::tc128) {
+        if (!MaxBitCount(poly_modulus_degree, sec_level)) throw std::invalid_argument("non-standard poly_modulus_degree");
+        if (sec_level == SecurityLevel::none) throw std::invalid_argument("invalid security level");
+        const std::vector<uint64_t> primes = stdDefaultPrimes((int)sec_level, poly_modulus_degree);
+        if (primes.empty()) throw std::out_of_range("no default coefficient modulus for this poly_modulus_degree"); // map::at in the reference
+        return std::vector<Modulus>(primes.begin(), primes.end());
+    }
     static std::vector<Modulus> Create(size_t poly_modulus_degree, std::vector<int> bit_sizes) {
         std::vector<uint64_t> out(bit_sizes.size());
         check(troyhip_coeff_modulus_create(poly_modulus_degree, bit_sizes.data(), (int)bit_sizes.size(), out.data()));
@@ -159,9 +182,14 @@ public:
     using ContextDataCuda = ContextData; // the nested name user code spells (src/context_cuda.cuh:20)
     SEALContext(const EncryptionParameters &parms, bool expand_mod_chain = true, SecurityLevel sec = SecurityLevel::tc128) : parms_(parms) {
         (void)expand_mod_chain;
-        (void)sec; // SecurityLevel::none semantics: parameter security is not policed
         std::vector<uint64_t> q;
-        for (auto &m : parms.coeffModulus()) q.push_back(m.value());
+        int total_bits = 0;
+        for (auto &m : parms.coeffModulus()) { q.push_back(m.value()); total_bits += m.bitCount(); }
+        // src/context.cpp:181-197: with a security level, the key-level modulus must fit the standard's bound (the reference records
+        // ErrorType::invalid_parameters_insecure and every later use throws; here invalid parameters throw from the constructor)
+        if (sec != SecurityLevel::none && total_bits > CoeffModulus::MaxBitCount(parms.polyModulusDegree(), sec))
+            throw std::invalid_argument("encryption parameters are not set correctly: parameters are not compliant with HomomorphicEncryption.org security standard");
+        sec_ = sec;
         troyhip_context *c = nullptr;
         check(troyhip_context_create((int)parms.scheme(), parms.polyModulusDegree(), q.data(), (int)q.size(), parms.plainModulus().value(), &c));
         ctx_.reset(c, [](troyhip_context *p) { troyhip_context_destroy(p); });
@@ -194,8 +222,10 @@ public:
     size_t keyLimbs() const { return (size_t)info_.key_limbs; }
     size_t firstLimbs() const { return (size_t)info_.first_limbs; }
     size_t lastLimbs() const { return (size_t)info_.last_limbs; }
+    SecurityLevel securityLevel() const { return sec_; }
 private:
     EncryptionParameters parms_;
+    SecurityLevel sec_ = SecurityLevel::none;
     std::shared_ptr<troyhip_context> ctx_;
     troyhip_context_info_t info_{};
     std::shared_ptr<std::vector<ParmsID>> ids_;
@@ -241,6 +271,7 @@ public:
             q.using_fast_plain_lift = true;
             for (auto &m : primes) q.using_fast_plain_lift = q.using_fast_plain_lift && m.value() > t;
         }
+        q.sec_level = c_->securityLevel();
         q.using_descending_modulus_chain = true;
         for (size_t i = 0; i + 1 < primes.size(); i++) q.using_descending_modulus_chain = q.using_descending_modulus_chain && primes[i].value() > primes[i + 1].value();
         return q;
@@ -296,12 +327,125 @@ private:
     size_t n_ = 0;
 };
 
+// ---- serialization: a raw little-endian field dump (src/serialize.h savet / loadt)
+namespace wire {
+template <class T> inline void put(std::ostream &s, const T &v) { s.write(reinterpret_cast<const char *>(&v), sizeof(T)); }
+template <class T> inline T get(std::istream &s) {
+    T v{};
+    s.read(reinterpret_cast<char *>(&v), sizeof(T));
+    if (!s) throw std::invalid_argument("stream ended inside a serialized object");
+    return v;
+}
+inline void put_words(std::ostream &s, const uint64_t *w, size_t count) { s.write(reinterpret_cast<const char *>(w), (std::streamsize)(count * 8)); }
+inline void get_words(std::istream &s, uint64_t *w, size_t count) {
+    s.read(reinterpret_cast<char *>(w), (std::streamsize)(count * 8));
+    if (!s) throw std::invalid_argument("stream ended inside a serialized object");
+}
+// the fields CiphertextCuda::save writes ahead of the data (src/ciphertext_cuda.cu:16-25): parms_id, is_ntt_form, size, poly_modulus_degree,
+// coeff_modulus_size, scale, correction_factor, seed, terms
+struct CtFields { uint64_t id[4]; bool ntt; size_t size, n, limbs; double scale; uint64_t cf, seed; bool terms; };
+inline void put_fields(std::ostream &s, const CtFields &f) {
+    s.write(reinterpret_cast<const char *>(f.id), 32);
+    put<bool>(s, f.ntt); put<size_t>(s, f.size); put<size_t>(s, f.n); put<size_t>(s, f.limbs);
+    put<double>(s, f.scale); put<uint64_t>(s, f.cf); put<uint64_t>(s, f.seed); put<bool>(s, f.terms);
+}
+inline CtFields get_fields(std::istream &s) {
+    CtFields f;
+    s.read(reinterpret_cast<char *>(f.id), 32);
+    f.ntt = get<bool>(s); f.size = get<size_t>(s); f.n = get<size_t>(s); f.limbs = get<size_t>(s);
+    f.scale = get<double>(s); f.cf = get<uint64_t>(s); f.seed = get<uint64_t>(s); f.terms = get<bool>(s);
+    // sizes that cannot be a ciphertext (a corrupted or foreign stream) stop here, not in an allocation
+    if (!f.n || (f.n & (f.n - 1)) || f.n > (size_t(1) << 20) || f.limbs < 1 || f.limbs > 256 || f.size > 1024) throw std::invalid_argument("the stream does not hold a ciphertext");
+    return f;
+}
+} // namespace wire
+
 class Plaintext { // src/plaintext.h: host coefficients (BFV/BGV: mod t; CKKS / NTT-form multiplyPlain: [limbs][N])
 public:
     Plaintext() = default;
     explicit Plaintext(const std::vector<uint64_t> &coeffs) : data_(coeffs) {}
-    // "1x^10 + 2"-style constructor of the reference is not reproduced; use setCoeff
-    void resize(size_t n) { dev_.reset(); data_.resize(n, 0); }
+    // the hexadecimal polynomial form "7FFx^3 + 1x^1 + 3" (src/plaintext.h:126,246; src/plaintext_cuda.cuh:47-51,95-99)
+    Plaintext(const std::string &hex_poly) { *this = hex_poly; }
+    Plaintext &operator=(const std::string &hex_poly) {
+        if (isNttForm()) throw std::logic_error("cannot set an NTT transformed Plaintext");
+        // terms "<hex>[x^<dec>]" in strictly decreasing degree, joined by " + "; the constant term, if any, ends the string
+        struct Term { size_t begin, digits, power; };
+        std::vector<Term> terms;
+        const size_t len = hex_poly.size();
+        size_t at = 0, widest = 0;
+        long previous = -1; // degree of the term before (none yet)
+        auto hex_value = [](char c) { return c >= '0' && c <= '9' ? c - '0' : c >= 'A' && c <= 'F' ? c - 'A' + 10 : c >= 'a' && c <= 'f' ? c - 'a' + 10 : -1; };
+        while (at < len) {
+            Term t{at, 0, 0};
+            while (at < len && hex_value(hex_poly[at]) >= 0) at++;
+            t.digits = at - t.begin;
+            if (!t.digits) throw std::invalid_argument("unable to parse hex_poly");
+            size_t lead = t.begin; // significant bits of the coefficient: leading zero digits do not count
+            while (lead < at && hex_value(hex_poly[lead]) == 0) lead++;
+            if (lead < at) {
+                const int top = hex_value(hex_poly[lead]);
+                widest = std::max(widest, (at - lead - 1) * 4 + (top >= 8 ? 4 : top >= 4 ? 3 : top >= 2 ? 2 : 1));
+            }
+            if (at < len) { // "x^" and a decimal degree
+                if (hex_poly[at] != 'x' || at + 1 >= len || hex_poly[at + 1] != '^') throw std::invalid_argument("unable to parse hex_poly");
+                at += 2;
+                while (at < len && hex_poly[at] >= '0' && hex_poly[at] <= '9') {
+                    t.power = t.power * 10 + (size_t)(hex_poly[at++] - '0');
+                    if (t.power > (size_t(1) << 30)) throw std::invalid_argument("unable to parse hex_poly");
+                }
+            }
+            if (previous >= 0 && (long)t.power >= previous) throw std::invalid_argument("unable to parse hex_poly");
+            previous = (long)t.power;
+            terms.push_back(t);
+            if (at < len) {
+                if (hex_poly.compare(at, 3, " + ") != 0) throw std::invalid_argument("unable to parse hex_poly");
+                at += 3;
+            }
+        }
+        if (terms.empty() || !widest) { setZero(); return *this; } // "" and "0": the present coefficients are cleared, the count stays
+        if (widest > 64) throw std::invalid_argument("hex_poly has too large coefficients");
+        dev_.reset();
+        data_.assign(terms[0].power + 1, 0);
+        for (const Term &t : terms) {
+            uint64_t v = 0;
+            for (size_t i = t.begin; i < t.begin + t.digits; i++) v = (v << 4) | (uint64_t)hex_value(hex_poly[i]);
+            data_[t.power] = v;
+        }
+        return *this;
+    }
+    // the constant polynomial (src/plaintext.h:255-262): one coefficient, coefficient form
+    Plaintext &operator=(uint64_t const_coeff) {
+        dev_.reset();
+        data_.assign(1, const_coeff);
+        parms_id_ = ParmsID();
+        return *this;
+    }
+    // "7FFx^3 + 1x^1 + 3": upper-case hexadecimal coefficients, decreasing degree, zero terms left out, "0" for the zero polynomial (src/plaintext.h:491-498)
+    std::string to_string() const {
+        if (isNttForm()) throw std::invalid_argument("cannot convert NTT transformed plaintext to string");
+        static const char digits[] = "0123456789ABCDEF";
+        std::string out;
+        for (size_t i = data_.size(); i-- > 0;) {
+            if (!data_[i]) continue;
+            if (!out.empty()) out += " + ";
+            int shift = 60;
+            while (shift && !((data_[i] >> shift) & 15)) shift -= 4;
+            for (; shift >= 0; shift -= 4) out += digits[(data_[i] >> shift) & 15];
+            if (i) out += "x^" + std::to_string(i);
+        }
+        return out.empty() ? std::string("0") : out;
+    }
+    bool isZero() const { return std::all_of(data_.begin(), data_.end(), [](uint64_t w) { return w == 0; }); } // src/plaintext.h:426-429
+    size_t significantCoeffCount() const { size_t n = data_.size(); while (n && !data_[n - 1]) n--; return n; } // src/plaintext.h:450-457
+    size_t nonzeroCoeffCount() const { return (size_t)std::count_if(data_.begin(), data_.end(), [](uint64_t w) { return w != 0; }); }
+    // resize (src/plaintext_cuda.cuh:79-87): not for an NTT-form plaintext -- the library's own writers go through assignWords
+    void resize(size_t n) {
+        if (isNttForm()) throw std::logic_error("cannot reserve for an NTT transformed Plaintext");
+        dev_.reset();
+        data_.resize(n, 0);
+    }
+    void keepWords(size_t n) { dev_.reset(); data_.resize(n, 0); } // the first n words stay (an NTT-form plaintext drops its last limb)
+    void assignWords(size_t n) { dev_.reset(); parms_id_ = ParmsID(); data_.assign(n, 0); } // n zero words, coefficient form, whatever the object held
     size_t coeffCount() const { return data_.size(); }
     // setZero / capacity / reserve / shrinkToFit / release (src/plaintext_cuda.cuh:73-165)
     void setZero(size_t start_coeff, size_t length) {
@@ -323,12 +467,15 @@ public:
     const uint64_t *data() const { return data_.data(); }
     uint64_t &operator[](size_t i) { dev_.reset(); return data_[i]; }
     const uint64_t &operator[](size_t i) const { return data_[i]; }
+    // the same polynomial (leading zero coefficients ignored), the same form and level, scales that agree to rounding (src/plaintext.h:396-410)
     bool operator==(const Plaintext &o) const {
-        size_t n = std::max(data_.size(), o.data_.size());
-        for (size_t i = 0; i < n; i++)
-            if ((i < data_.size() ? data_[i] : 0) != (i < o.data_.size() ? o.data_[i] : 0)) return false;
-        return true;
+        if (isNttForm() != o.isNttForm() || (isNttForm() && parms_id_ != o.parms_id_)) return false;
+        const size_t n = significantCoeffCount();
+        if (n != o.significantCoeffCount() || !std::equal(data_.begin(), data_.begin() + (std::ptrdiff_t)n, o.data_.begin())) return false;
+        const double scale_max = std::max(std::max(std::fabs(scale_), std::fabs(o.scale_)), 1.0); // util::areClose (src/utils/common.h)
+        return std::fabs(scale_ - o.scale_) < std::numeric_limits<double>::epsilon() * scale_max;
     }
+    bool operator!=(const Plaintext &o) const { return !(*this == o); }
     double &scale() { return scale_; }
     double scale() const { return scale_; }
     bool isNttForm() const { return parms_id_.limbs != 0; }
@@ -578,8 +725,65 @@ private:
     std::shared_ptr<const std::vector<ParmsID>> ids_;
 };
 
-class SecretKey { public: std::vector<uint64_t> data; };  // [K][N] NTT form (host), src/secretkey.h
-class PublicKey { public: std::vector<uint64_t> data; };  // [2][K][N] NTT form (host), src/publickey.h
+// SecretKeyCuda (src/secretkey_cuda.cuh): [K][N] in NTT form at the key level, kept on the host (key generation and encryption run there).
+// save / load (:292-297) is the reference's plaintext format -- parms_id, coeff_count, scale, word count, words (src/plaintext_cuda.cu:7-27)
+class SecretKey {
+public:
+    std::vector<uint64_t> data;
+    ParmsID parms_id; // the key level (stamped by KeyGenerator; read back by load)
+    const ParmsID &parmsID() const noexcept { return parms_id; }
+    ParmsID &parmsID() noexcept { return parms_id; }
+    void save(std::ostream &stream) const {
+        stream.write(reinterpret_cast<const char *>(parms_id.data()), 32);
+        wire::put<size_t>(stream, data.size());
+        wire::put<double>(stream, 1.0);
+        wire::put<size_t>(stream, data.size());
+        wire::put_words(stream, data.data(), data.size());
+    }
+    void load(std::istream &stream) {
+        ParmsID id;
+        stream.read(reinterpret_cast<char *>(id.data()), 32);
+        const size_t count = wire::get<size_t>(stream);
+        (void)wire::get<double>(stream);
+        const size_t words = wire::get<size_t>(stream);
+        if (words != count || words > (size_t(1) << 32)) throw std::invalid_argument("the stream does not hold a secret key");
+        std::vector<uint64_t> host(words);
+        wire::get_words(stream, host.data(), words);
+        data = std::move(host);
+        parms_id = id; // the limb count behind the hash comes back when the key meets its context (limbs stays 0 until then)
+    }
+};
+// PublicKeyCuda (src/publickey_cuda.cuh): a size-2 ciphertext [2][K][N] in NTT form at the key level (host).  save / load (:252-257) is the
+// reference's ciphertext format (src/ciphertext_cuda.cu:16-43)
+class PublicKey {
+public:
+    std::vector<uint64_t> data;
+    ParmsID parms_id;
+    size_t poly_modulus_degree = 0, coeff_modulus_size = 0;
+    const ParmsID &parmsID() const noexcept { return parms_id; }
+    ParmsID &parmsID() noexcept { return parms_id; }
+    void save(std::ostream &stream) const {
+        if (data.empty() || !poly_modulus_degree) throw std::logic_error("the public key has not been generated");
+        wire::CtFields f{{parms_id[0], parms_id[1], parms_id[2], parms_id[3]}, true, 2, poly_modulus_degree, coeff_modulus_size, 1.0, 1, 0, false};
+        wire::put_fields(stream, f);
+        wire::put<size_t>(stream, data.size());
+        wire::put_words(stream, data.data(), data.size());
+    }
+    void load(std::istream &stream) {
+        const wire::CtFields f = wire::get_fields(stream);
+        if (f.terms) throw std::invalid_argument("Trying to load a termed ciphertext, but indices is not specified");
+        if (f.seed) throw std::invalid_argument("seed is not zero.");
+        const size_t words = wire::get<size_t>(stream);
+        if (f.size != 2 || words != 2 * f.limbs * f.n) throw std::invalid_argument("the stream does not hold a public key");
+        std::vector<uint64_t> host(words);
+        wire::get_words(stream, host.data(), words);
+        data = std::move(host);
+        std::copy(f.id, f.id + 4, parms_id.begin());
+        parms_id.limbs = (int)f.limbs;
+        poly_modulus_degree = f.n;
+        coeff_modulus_size = f.limbs;
+    }
+};
 
 class KSwitchKeys { // src/kswitchkeys_cuda.cuh:43-56: data()[index] on the device, uploaded from the host key
 public:
@@ -592,8 +796,68 @@ public:
     }
     const std::map<size_t, std::shared_ptr<DeviceArray>> &all() const { return keys_; }
     void clear() { keys_.clear(); } // src/kswitchkeys_cuda.cuh
+    // the key level and shape (stamped by KeyGenerator, read back by load): one key is [K - 1][2][K][N]
+    void describe(const ParmsID &key_parms_id, size_t poly_modulus_degree, size_t key_limbs) { parms_id_ = key_parms_id; n_ = poly_modulus_degree; limbs_ = key_limbs; }
+    const ParmsID &parmsID() const noexcept { return parms_id_; }
+    ParmsID &parmsID() noexcept { return parms_id_; }
+    size_t size() const noexcept { return keys_.size(); } // how many key indices hold a key (src/kswitchkeys.h: size())
+    // save / load (src/kswitchkeys_cuda.cuh:330-356): parms_id, the length of the index vector, and per index the digit count followed by one
+    // public-key-format ciphertext [2][K][N] per digit (an index without a key has digit count 0)
+    void save(std::ostream &stream) const {
+        stream.write(reinterpret_cast<const char *>(parms_id_.data()), 32);
+        const size_t slots = keys_.empty() ? 0 : keys_.rbegin()->first + 1;
+        wire::put<size_t>(stream, slots);
+        if (slots && (!n_ || limbs_ < 2)) throw std::logic_error("the key-switching keys have no shape: generate them with KeyGenerator or load them");
+        const size_t digits = limbs_ - 1, digit_words = 2 * limbs_ * n_;
+        std::vector<uint64_t> host(digits * digit_words);
+        for (size_t i = 0; i < slots; i++) {
+            auto it = keys_.find(i);
+            if (it == keys_.end()) { wire::put<size_t>(stream, 0); continue; }
+            if (it->second->size() != host.size()) throw std::logic_error("a key-switching key of unexpected size");
+            check(troyhip_copy_d2h(host.data(), it->second->get(), host.size() * 8, nullptr));
+            wire::put<size_t>(stream, digits);
+            for (size_t j = 0; j < digits; j++) {
+                wire::CtFields f{{parms_id_[0], parms_id_[1], parms_id_[2], parms_id_[3]}, true, 2, n_, limbs_, 1.0, 1, 0, false};
+                wire::put_fields(stream, f);
+                wire::put<size_t>(stream, digit_words);
+                wire::put_words(stream, host.data() + j * digit_words, digit_words);
+            }
+        }
+    }
+    void load(std::istream &stream) {
+        ParmsID id;
+        stream.read(reinterpret_cast<char *>(id.data()), 32);
+        const size_t slots = wire::get<size_t>(stream);
+        if (slots > (size_t(1) << 21)) throw std::invalid_argument("the stream does not hold key-switching keys");
+        std::map<size_t, std::shared_ptr<DeviceArray>> fresh;
+        size_t n = 0, limbs = 0;
+        for (size_t i = 0; i < slots; i++) {
+            const size_t digits = wire::get<size_t>(stream);
+            if (!digits) continue;
+            if (digits > 256) throw std::invalid_argument("the stream does not hold key-switching keys");
+            std::vector<uint64_t> host;
+            for (size_t j = 0; j < digits; j++) {
+                const wire::CtFields f = wire::get_fields(stream);
+                const size_t words = wire::get<size_t>(stream);
+                if (f.terms || f.seed || f.size != 2 || f.limbs != digits + 1 || words != 2 * f.limbs * f.n || (n && (f.n != n || f.limbs != limbs)))
+                    throw std::invalid_argument("the stream does not hold key-switching keys");
+                n = f.n; limbs = f.limbs;
+                host.resize(digits * words);
+                wire::get_words(stream, host.data() + j * words, words);
+            }
+            auto a = std::make_shared<DeviceArray>(host.size());
+            check(troyhip_copy_h2d(a->get(), host.data(), host.size() * 8, nullptr));
+            fresh[i] = a;
+        }
+        keys_ = std::move(fresh);
+        parms_id_ = id;
+        parms_id_.limbs = (int)limbs;
+        n_ = n; limbs_ = limbs;
+    }
 protected:
     std::map<size_t, std::shared_ptr<DeviceArray>> keys_;
+    ParmsID parms_id_;
+    size_t n_ = 0, limbs_ = 0;
 };
 class RelinKeys : public KSwitchKeys { // src/relinkeys_cuda.cuh:56-59
 public:
@@ -648,10 +912,12 @@ public:
     void createRelinKeys(RelinKeys &rlk) const {
         std::vector<uint64_t> h(ksk_words());
         check(troyhip_host_relin_key(c_.handle(), lo_, hi_, sk_.data.data(), h.data()));
+        rlk.describe(c_.keyParmsID(), c_.polyModulusDegree(), c_.keyLimbs());
         rlk.upload(RelinKeys::getIndex(2), h);
     }
     RelinKeys createRelinKeys() const { RelinKeys r; createRelinKeys(r); return r; }
     void createGaloisKeys(const std::vector<uint32_t> &galois_elts, GaloisKeys &gk) const {
+        gk.describe(c_.keyParmsID(), c_.polyModulusDegree(), c_.keyLimbs());
         for (uint32_t e : galois_elts) {
             std::vector<uint64_t> h(ksk_words());
             check(troyhip_host_galois_key(c_.handle(), lo_, hi_, sk_.data.data(), e, h.data()));
@@ -681,6 +947,7 @@ public:
         std::vector<uint64_t> h(ksk_words());
         check(troyhip_host_kswitch_key(c_.handle(), lo_, hi_, sk_.data.data(), new_key.data.data(), h.data()));
         KSwitchKeys k;
+        k.describe(c_.keyParmsID(), c_.polyModulusDegree(), c_.keyLimbs());
         k.upload(0, h);
         return k;
     }
@@ -703,6 +970,9 @@ private:
         sk_.data.resize(K * N);
         pk_.data.resize(2 * K * N);
         check(troyhip_host_keygen(c_.handle(), lo_, hi_, sk_.data.data(), pk_.data.data()));
+        sk_.parms_id = pk_.parms_id = c_.keyParmsID();
+        pk_.poly_modulus_degree = N;
+        pk_.coeff_modulus_size = K;
     }
     size_t ksk_words() const { const size_t K = c_.keyLimbs(); return (K - 1) * 2 * K * c_.polyModulusDegree(); }
     const SEALContext &c_;
@@ -721,8 +991,15 @@ public:
     Encryptor(const SEALContext &c, const PublicKey &pk, uint64_t seed_lo, uint64_t seed_hi = 0) : c_(c), pk_(pk), seeded_(true), lo_(seed_lo), hi_(seed_hi) {}
     void setPublicKey(const PublicKey &pk) { pk_ = pk; }
     void setSecretKey(const SecretKey &sk) { sk_ = sk; }
+    // The CPU reference refuses without a public key (src/encryptor.cpp:157-160); EncryptorCuda has no such check and its own caller
+    // test/evaluator_cuda.cu:2566-2569 (BFVKeySwitching) encrypts through an Encryptor that was given ONLY a secret key -- meaning "a
+    // ciphertext under that key".  An encryptor that holds just a secret key therefore encrypts symmetrically; one that holds neither throws.
     void encrypt(const Plaintext &plain, Ciphertext &dst) const {
-        if (pk_.data.empty()) throw std::logic_error("public key is not set"); // src/encryptor.cpp:157-160
+        if (pk_.data.empty()) {
+            if (sk_.data.empty()) throw std::logic_error("public key is not set");
+            run(troyhip_host_encrypt_symmetric, sk_.data, plain, dst);
+            return;
+        }
         run(troyhip_host_encrypt, pk_.data, plain, dst);
     }
     Ciphertext encrypt(const Plaintext &plain) const { Ciphertext d; encrypt(plain, d); return d; }
@@ -792,7 +1069,7 @@ public:
         const size_t words = ckks ? ct.coeffModulusSize() * N : N;
         DeviceArray out(words);
         check(troyhip_decrypt(c_.handle(), ct.raw(), sk_.get(), out.get(), words, 1, nullptr));
-        dst.resize(words);
+        dst.assignWords(words);
         check(troyhip_copy_d2h(dst.data(), out.get(), words * 8, nullptr));
         dst.setNttForm(ckks ? ct.parmsID() : parmsIDZero);
         if (ckks) dst.scale() = ct.scale();
@@ -908,6 +1185,31 @@ public:
         encodePolynomial(std::vector<double>{value}, parms_id, scale, destination);
     }
     void encode(double value, double scale, Plaintext &destination) const { encode(value, c_.firstParmsID(), scale, destination); }
+    // one complex value in every slot (src/ckks_cuda.cuh:54-64; src/ckks.h: encodeInternal(std::complex<double>, ...) fills the slot vector with it)
+    void encode(std::complex<double> value, const ParmsID &parms_id, double scale, Plaintext &destination) const {
+        encode(std::vector<std::complex<double>>(slots_, value), parms_id, scale, destination);
+    }
+    void encode(std::complex<double> value, double scale, Plaintext &destination) const { encode(value, c_.firstParmsID(), scale, destination); }
+    // an integer, exactly and without scaling (src/ckks_cuda.cuh:67-76, src/ckks_cuda.cu:733-790): the constant polynomial `value`, whose NTT form is
+    // `value` modulo the prime in every position of every limb; scale 1
+    void encode(std::int64_t value, const ParmsID &parms_id, Plaintext &destination) const {
+        auto level = c_.getContextData(parms_id);
+        if (!level) throw std::invalid_argument("parms_id is not valid for encryption parameters");
+        const uint64_t magnitude = value < 0 ? (uint64_t)0 - (uint64_t)value : (uint64_t)value;
+        const int bits = (magnitude ? 64 - __builtin_clzll(magnitude) : 0) + 2;
+        if (bits >= level->totalCoeffModulusBitCount()) throw std::invalid_argument("encoded value is too large");
+        const auto &q = level->parms().coeffModulus();
+        const size_t n = slots_ * 2;
+        destination.assignWords(q.size() * n);
+        uint64_t *d = destination.data();
+        for (size_t j = 0; j < q.size(); j++) {
+            const uint64_t p = q[j].value(), r = magnitude % p;
+            std::fill(d + j * n, d + (j + 1) * n, value < 0 && r ? p - r : r);
+        }
+        destination.setNttForm(parms_id);
+        destination.scale() = 1.0;
+    }
+    void encode(std::int64_t value, Plaintext &destination) const { encode(value, c_.firstParmsID(), destination); }
     void decode(const Plaintext &plain, std::vector<std::complex<double>> &destination) const {
         std::vector<double> coeffs;
         decodePolynomial(plain, coeffs);
@@ -968,7 +1270,7 @@ public:
         for (auto &m : q) primes.push_back(m.value());
         check(troyhip_copy_h2d(dev->get(), rns.data(), rns.size() * 8, nullptr));
         check(troyhip_ntt(c_.handle(), dev->get(), limbs, primes.data(), (int)limbs, 1, 0, nullptr));
-        destination.resize(limbs * n);
+        destination.assignWords(limbs * n);
         check(troyhip_copy_d2h(destination.data(), dev->get(), limbs * n * 8, nullptr));
         destination.adoptDevice(dev); // the transformed buffer doubles as the plaintext's device copy
         destination.setNttForm(parms_id);
@@ -1167,7 +1469,7 @@ public:
         auto nx = cd->nextContextData();
         if (!nx) throw std::invalid_argument("end of modulus switching chain reached");
         if (!scaleWithinBounds(plain.scale(), *nx)) throw std::invalid_argument("scale out of bounds");
-        plain.resize(nx->parms().coeffModulus().size() * c_.polyModulusDegree());
+        plain.keepWords(nx->parms().coeffModulus().size() * c_.polyModulusDegree());
         plain.setNttForm(nx->parmsID());
     }
     void modSwitchToNext(const Plaintext &plain, Plaintext &d) const { d = plain; modSwitchToNextInplace(d); }
@@ -1392,10 +1694,15 @@ public:
         if (plain.isNttForm()) throw std::invalid_argument("plain is already in NTT form");
         if (!c_.getContextData(parms_id)) throw std::invalid_argument("parms_id is not valid for the current context");
         const size_t n = c_.polyModulusDegree(), limbs = (size_t)parms_id.limbs;
+        if (!plain.coeffCount()) { // Plaintext("0") holds no coefficient at all: the zero polynomial, zero in every limb
+            plain.assignWords(limbs * n);
+            plain.setNttForm(parms_id);
+            return;
+        }
         DeviceArray p(plain.coeffCount()), out(limbs * n);
         check(troyhip_copy_h2d(p.get(), plain.data(), plain.coeffCount() * 8, nullptr));
         check(troyhip_plain_to_ntt(h(), p.get(), plain.coeffCount(), 0, (int)limbs, out.get(), 1, nullptr));
-        plain.resize(limbs * n);
+        plain.assignWords(limbs * n);
         check(troyhip_copy_d2h(plain.data(), out.get(), limbs * n * 8, nullptr));
         plain.setNttForm(parms_id);
     }
@@ -1605,13 +1912,6 @@ private:
 
 // ---- ciphertext serialization: a raw little-endian field dump (src/serialize.h savet/loadt)
 namespace wire {
-template <class T> inline void put(std::ostream &s, const T &v) { s.write(reinterpret_cast<const char *>(&v), sizeof(T)); }
-template <class T> inline T get(std::istream &s) {
-    T v{};
-    s.read(reinterpret_cast<char *>(&v), sizeof(T));
-    if (!s) throw std::invalid_argument("stream ended inside a ciphertext");
-    return v;
-}
 struct Header { bool ntt; size_t size, n, limbs; double scale; uint64_t cf, seed; bool terms; };
 inline void put_header(std::ostream &s, const uint64_t *id, const Ciphertext &ct, bool terms) {
     s.write(reinterpret_cast<const char *>(id), 32);

@@ -1198,3 +1198,31 @@ def check_save_terms(api):
         raise AssertionError("expected ValueError")
     except ValueError:
         pass
+
+
+def check_moddown_shared_first_pass(scheme, N=8192, bits=(46, 46, 46, 48), tbits=17, batch=1, seed=31, expect_fp_two_pass=True):
+    """the key-switch mod-down of a SMALL launch (one first inverse pass over the special limb and the data limbs, the last passes launched on their
+    own) with an FP64-class special prime LARGER than the FP64-class data primes: the separately launched last passes must plan their reductions
+    from the bound the shared first pass left, i.e. from the largest prime of all the slots (round-4 advisor finding).  Uniform and extreme rows."""
+    from oracle import ref
+    from troy_amd import capi, synth
+    cfg = {"scheme": scheme, "N": N, "bits": list(bits), "tbits": tbits}
+    be, ob = GpuBackend(cfg, batch=batch), oracle_backend(cfg)
+    L = len(be.primes) - 1
+    assert be.primes[-1] > max(be.primes[:L]) and be.primes[-1] < (1 << 50)
+    ntt = scheme == CKKS
+    top_key = np.stack([np.stack([np.stack([np.full(N, p - 1, dtype=np.uint64) for p in be.primes])] * 2)] * L)
+    for kind, rk in (("uniform", synth.uniform_kswitch_key(seed, be.primes, N)), ("extreme", top_key)):
+        be.set_relin_key(rk)
+        ob.set_relin_key(rk)
+        q = be.primes[:L]
+        rows = [synth.uniform_ct(seed + 1, q, 3, N, 1)[0],
+                np.stack([np.stack([np.full(N, p - 1, dtype=np.uint64) for p in q])] * 3),
+                np.stack([np.stack([(np.arange(N, dtype=np.uint64) & np.uint64(1)) * np.uint64(p - 1) for p in q])] * 3)]
+        for x in rows:
+            before = capi.stat("ntt2_fp_launches", be.api.KernelProvider._lib)
+            got = be.ev.relinearize(be.ct(x, ntt), be.rlk).cpu()[0]
+            exp = ob.relinearize(ref.Ct(x, ntt))
+            assert np.array_equal(got, exp.data), (kind, cfg)
+            if expect_fp_two_pass:
+                assert capi.stat("ntt2_fp_launches", be.api.KernelProvider._lib) > before, "the FP64 two-pass kernels did not run"

@@ -1,0 +1,109 @@
+"""The reference's OWN GPU callers, unchanged, against include/ -- the drop-in claim tested on the reference's files, not on re-typed copies.
+
+test/evaluator_cuda.cu (52 gtest cases), test/encryptor_cuda.cu (6), test/ckks_cuda.cu (2) -- the reference's only GPU acceptance tests
+ -- plus the three mains test/timetest.cu, test/app/linear.cu, test/app/linear_ckks.cu are compiled FROM WHERE THEY LIE under
+/root/reference by `make -C oracle dropin` (oracle/Makefile: each file goes through stdin with the working directory set to its twin under
+include/dropin/, so its `#include "../src/troy_cuda.cuh"` finds include/troy_cuda.cuh; googletest is tests/cpp/gtest_shim).  Nothing of the
+reference is copied into the repository; the built binaries live under oracle/_ref/dropin/ (git-ignored, travels to the GPU box like oracle/_ref).
+
+CPU suite (build container only: needs /root/reference): build, then all 60 cases on the host emulator build of the library; the mains must link.
+GPU suite: the same objects linked with libtroyhip.so -- the 60 cases and the three mains on the device.
+"""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+OUT = os.path.join(ROOT, "oracle", "_ref", "dropin")
+CASES = 60  # 52 + 6 + 2 TEST() blocks in the three reference files
+
+needs_reference = pytest.mark.skipif(not os.path.exists(os.path.join(REF, "test", "evaluator_cuda.cu")), reason="reference sources only exist in the build container")
+
+
+def _summary(stdout):
+    m = re.search(r"\[==========\] (\d+) tests ran, (\d+) failed", stdout)
+    assert m, stdout[-3000:]
+    return int(m.group(1)), int(m.group(2))
+
+
+@pytest.fixture(scope="module")
+def built():
+    subprocess.check_call(["make", "-s", "-j8", "-C", os.path.join(ROOT, "troy_amd", "csrc"), "emul"])
+    subprocess.check_call(["make", "-s", "-j8", "-C", os.path.join(ROOT, "oracle"), "dropin"])
+    return OUT
+
+
+@needs_reference
+def test_reference_sources_count_sixty_cases():
+    n = 0
+    for f in ("evaluator_cuda.cu", "encryptor_cuda.cu", "ckks_cuda.cu"):
+        n += len(re.findall(r"^\s*TEST\(", open(os.path.join(REF, "test", f)).read(), re.M))
+    assert n == CASES
+
+
+@needs_reference
+def test_reference_gpu_tests_pass_unchanged_on_emulator(built):
+    r = subprocess.run([os.path.join(built, "troytest_emul")], capture_output=True, text=True, timeout=1500, cwd=built)
+    ran, failed = _summary(r.stdout)
+    assert (ran, failed, r.returncode) == (CASES, 0, 0), r.stdout[-4000:]
+
+
+@needs_reference
+def test_reference_mains_link_unchanged(built):
+    # test/timetest.cu (N = 16384), test/app/linear.cu (N = 16384, 64 x 128 x 256) and linear_ckks.cu (56 x 56 convolution) take tens of minutes on
+    # the fiber emulator: there they only have to compile and link against include/ and the library's exports; the GPU suite runs them
+    for name in ("timetest", "linear", "linear_ckks"):
+        for flavour in ("emul", "gpu"):
+            assert os.access(os.path.join(built, "%s_%s" % (name, flavour)), os.X_OK)
+
+
+@needs_reference
+def test_default_modulus_tables_match_reference():
+    # include/troyn_hestd.inc is DATA generated from the reference's tables: every number of src/utils/globals.cpp and hestdparams.h must be in it
+    inc = open(os.path.join(ROOT, "include", "troyn_hestd.inc")).read().lower()
+    src = re.sub(r"/\*.*?\*/", "", open(os.path.join(REF, "src", "utils", "globals.cpp")).read(), flags=re.S)
+    primes = re.findall(r"0x[0-9a-fA-F]+", src)
+    assert len(primes) > 60
+    for p in primes:
+        assert p.lower() + "ull" in inc, p
+    for b in re.findall(r"return (\d+);", open(os.path.join(REF, "src", "utils", "hestdparams.h")).read()):
+        assert b == "0" or re.search(r"\b%s\b" % b, inc), b
+
+
+def _gpu_binary(name):
+    path = os.path.join(OUT, name + "_gpu")
+    if not os.access(path, os.X_OK):
+        pytest.skip("oracle/_ref/dropin was not prebuilt (build() does it where /root/reference exists)")
+    return path
+
+
+@pytest.mark.gpu
+def test_reference_gpu_tests_pass_unchanged_on_gpu():
+    r = subprocess.run([_gpu_binary("troytest")], capture_output=True, text=True, timeout=1500, cwd=OUT)
+    ran, failed = _summary(r.stdout)
+    assert (ran, failed, r.returncode) == (CASES, 0, 0), r.stdout[-4000:] + r.stderr[-2000:]
+
+
+@pytest.mark.gpu
+def test_reference_timetest_runs_unchanged_on_gpu():
+    r = subprocess.run([_gpu_binary("timetest")], capture_output=True, text=True, timeout=1500, cwd=OUT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    for label in ("Multiply", "Relinearize", "RotateRows", "ModSwitchToNext"):  # the timer labels of test/timetest.cu's BFV run
+        assert re.search(label, r.stdout, re.I), r.stdout[-3000:]
+
+
+@pytest.mark.gpu
+def test_reference_linear_apps_run_unchanged_on_gpu():
+    # test/app/linear.cu: BFV 64 x 128 x 256 matmul with ciphertext weights through app/LinearHelper.cuh's interface -- exact arithmetic modulo t
+    r = subprocess.run([_gpu_binary("linear")], capture_output=True, text=True, timeout=1500, cwd=OUT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    diffs = re.findall(r"Difference = (\S+)", r.stdout)
+    assert diffs and all(float(d) == 0 for d in diffs), r.stdout[-3000:]
+    # test/app/linear_ckks.cu: CKKS 1 x 256 x 64 x 56 x 56 convolution, scale 2^15 on two 50-bit primes -- approximate
+    r = subprocess.run([_gpu_binary("linear_ckks")], capture_output=True, text=True, timeout=1500, cwd=OUT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    diffs = re.findall(r"Difference = (\S+)", r.stdout)
+    assert diffs and all(float(d) < 1e-2 for d in diffs), r.stdout[-3000:]

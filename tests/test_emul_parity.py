@@ -112,6 +112,11 @@ def test_emulated_multiply_plain_accumulate(emul_api):
     cases.check_multiply_plain_accumulate(N=128, batch=2)
 
 
+@pytest.mark.parametrize("scheme", [1, 3])
+def test_emulated_moddown_shared_first_pass_fp_bounds(scheme, emul_api, oracle_lib):
+    cases.check_moddown_shared_first_pass(scheme, N=4096, bits=(44, 45, 49))
+
+
 @pytest.mark.parametrize("name", ["bfv_n64_k3", "ckks_n128_k6", "cfgA_bfv_n4096_k3", "bgv_n4096_k3", "ckks_n4096_k4"])
 def test_emulated_relinearize_out_of_place(name, emul_api):
     cases.check_relinearize_out_of_place(name, batch=2)

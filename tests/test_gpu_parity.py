@@ -502,6 +502,14 @@ def test_random_parameter_sets(seed, gpu, oracle_lib):
     assert n is None or n > 10, cfg
 
 
+@pytest.mark.parametrize("scheme", [1, 3])
+@pytest.mark.parametrize("N,bits", [(8192, (46, 46, 46, 48)), (4096, (44, 45, 49)), (16384, (40, 46, 46, 46, 49))])
+def test_moddown_shared_first_pass_fp_bounds(scheme, N, bits, gpu, oracle_lib):
+    """one ciphertext, FP64-class special prime above the FP64-class data primes: the mod-down's separately launched last passes plan from the
+    bound of the shared first pass (uniform and extreme rows and keys vs the oracle; the FP64 two-pass kernels must have run)"""
+    cases.check_moddown_shared_first_pass(scheme, N=N, bits=bits)
+
+
 @pytest.mark.parametrize("name", ["cfgA_bfv_n4096_k3", "cfgB_bfv_n8192_k5", "bgv_n4096_k3", "ckks_n4096_k4", "cfgNS_bfv_n32768_k15", "cfgC_ckks_n32768_k15"])
 def test_relinearize_out_of_place(name, gpu):
     """the destination form of relinearize (operand read in place from size 3, every mod-down epilogue accumulating onto (c0, c1) of the

@@ -125,6 +125,7 @@ static std::string report() {
 
 extern "C" {
 
+static std::atomic<uint64_t> g_stream_epoch{0}; // bumped whenever the pool forgets a stream: entry points then announce theirs again (on())
 int troyhip_initialize(int device) {
     return guard([&] {
         HIP_CHECK(hipSetDevice(device));
@@ -224,7 +225,7 @@ struct DevicePool {
             if (hipEventRecord(e, st) != hipSuccess) {
                 (void)hipGetLastError();
                 spare_events.push_back(e);
-                if (i) { streams.erase(streams.begin() + (long)(i - 1)); continue; }
+                if (i) { streams.erase(streams.begin() + (long)(i - 1)); g_stream_epoch.fetch_add(1, std::memory_order_release); continue; }
                 // the default stream itself refuses: fall back to a device-wide wait, after which nothing is pending
                 (void)hipDeviceSynchronize();
                 for (auto &se : b.pending) spare_events.push_back(se.second);
@@ -275,6 +276,22 @@ struct DevicePool {
 int troyhip_malloc(void **out, size_t bytes) { return guard([&] { if (!out) throw Error(ST_INVALID_ARGUMENT, "null"); *out = DevicePool::instance().get(bytes ? bytes : 8); }); }
 int troyhip_free(void *p) { return guard([&] { if (p) DevicePool::instance().put(p); }); }
 int troyhip_pool_release(void) { return guard([&] { HIP_CHECK(hipDeviceSynchronize()); DevicePool::instance().release(); }); }
+// A caller's stream the library was never told about (a hipStream_t made elsewhere, a torch / RCCL stream) is announced to the pool the first time an
+// entry point is handed it, so a block freed while that stream still reads it is not reused early (round-4 advisor: the pool records no free-point
+// events until a stream is registered).  One compare per call; a stream that was unregistered is announced again when it comes back.
+static inline hipStream_t on(void *stream) {
+    if (stream) {
+        static thread_local void *last = nullptr;
+        static thread_local uint64_t last_epoch = ~0ull;
+        const uint64_t epoch = g_stream_epoch.load(std::memory_order_acquire);
+        if (stream != last || epoch != last_epoch) {
+            DevicePool::instance().add_stream((hipStream_t)stream);
+            last = stream;
+            last_epoch = epoch;
+        }
+    }
+    return (hipStream_t)stream;
+}
 int troyhip_copy_h2d(void *dst, const void *src, size_t bytes, void *stream) {
     return guard([&] { HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream)); HIP_CHECK(hipStreamSynchronize((hipStream_t)stream)); });
 }
@@ -282,9 +299,9 @@ int troyhip_copy_d2h(void *dst, const void *src, size_t bytes, void *stream) {
     return guard([&] { HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream)); HIP_CHECK(hipStreamSynchronize((hipStream_t)stream)); });
 }
 int troyhip_copy_d2d(void *dst, const void *src, size_t bytes, void *stream) {
-    return guard([&] { HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream)); });
+    return guard([&] { HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, on(stream))); });
 }
-int troyhip_memset_zero(void *dst, size_t bytes, void *stream) { return guard([&] { HIP_CHECK(hipMemsetAsync(dst, 0, bytes, (hipStream_t)stream)); }); }
+int troyhip_memset_zero(void *dst, size_t bytes, void *stream) { return guard([&] { HIP_CHECK(hipMemsetAsync(dst, 0, bytes, on(stream))); }); }
 int troyhip_stream_synchronize(void *stream) { return guard([&] { HIP_CHECK(hipStreamSynchronize((hipStream_t)stream)); }); }
 int troyhip_stream_create(void **stream) {
     return guard([&] { hipStream_t st; HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking)); DevicePool::instance().add_stream(st); *stream = (void *)st; });
@@ -294,12 +311,14 @@ int troyhip_stream_unregister(void *stream) {
     return guard([&] {
         HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
         DevicePool::instance().remove_stream((hipStream_t)stream);
+        g_stream_epoch.fetch_add(1, std::memory_order_release);
     });
 }
 int troyhip_stream_destroy(void *stream) {
     return guard([&] {
         HIP_CHECK(hipStreamSynchronize((hipStream_t)stream));
         DevicePool::instance().remove_stream((hipStream_t)stream);
+        g_stream_epoch.fetch_add(1, std::memory_order_release);
         HIP_CHECK(hipStreamDestroy((hipStream_t)stream));
     });
 }
@@ -320,7 +339,7 @@ int troyhip_mem_info(size_t *free_bytes, size_t *total_bytes) { return guard([&]
 int troyhip_test_modarith(int op, const uint64_t *a, const uint64_t *b, const uint64_t *c, uint64_t p, uint64_t aux, uint64_t *out, uint64_t n, void *stream) {
     return guard([&] {
         if (!a || !out || p < 2 || (p >> 61)) throw Error(ST_INVALID_ARGUMENT, "modarith probe arguments");
-        launch_modarith_probe(op, a, b, c, p, aux, out, n, (hipStream_t)stream);
+        launch_modarith_probe(op, a, b, c, p, aux, out, n, on(stream));
     });
 }
 /* per-kernel timing (rt.h): enable, run the launches to be measured, then fetch the report (JSON text, launch order; resets) */
@@ -361,8 +380,8 @@ int troyhip_timer_create(void **timer) {
     });
 }
 int troyhip_timer_destroy(void *timer) { return guard([&] { Timer *t = (Timer *)timer; if (t) { (void)hipEventDestroy(t->a); (void)hipEventDestroy(t->b); delete t; } }); }
-int troyhip_timer_start(void *timer, void *stream) { return guard([&] { HIP_CHECK(hipEventRecord(((Timer *)timer)->a, (hipStream_t)stream)); }); }
-int troyhip_timer_stop(void *timer, void *stream) { return guard([&] { HIP_CHECK(hipEventRecord(((Timer *)timer)->b, (hipStream_t)stream)); }); }
+int troyhip_timer_start(void *timer, void *stream) { return guard([&] { HIP_CHECK(hipEventRecord(((Timer *)timer)->a, on(stream))); }); }
+int troyhip_timer_stop(void *timer, void *stream) { return guard([&] { HIP_CHECK(hipEventRecord(((Timer *)timer)->b, on(stream))); }); }
 int troyhip_timer_elapsed_ms(void *timer, float *ms) {
     return guard([&] { Timer *t = (Timer *)timer; HIP_CHECK(hipEventSynchronize(t->b)); HIP_CHECK(hipEventElapsedTime(ms, t->a, t->b)); });
 }
@@ -495,34 +514,34 @@ int troyhip_host_batch_decode(const troyhip_context *ctx, const uint64_t *plain,
 int troyhip_ntt(troyhip_context *ctx, uint64_t *data, uint64_t rows, const uint64_t *row_primes, int period, int inner, int inverse, void *stream) {
     return guard([&] {
         Context &c = need(ctx)->ctx;
-        launch_ntt(data, c.d_desc, map_from_primes(c, row_primes, period, inner), rows, c.logn, inverse != 0, (hipStream_t)stream);
+        launch_ntt(data, c.d_desc, map_from_primes(c, row_primes, period, inner), rows, c.logn, inverse != 0, on(stream));
     });
 }
 int troyhip_fill_uniform(troyhip_context *ctx, uint64_t *data, uint64_t rows, const uint64_t *row_primes, int period, int inner, uint64_t seed,
                          uint64_t row0, void *stream) {
     return guard([&] {
         Context &c = need(ctx)->ctx;
-        launch_fill_uniform(data, c.d_desc, map_from_primes(c, row_primes, period, inner), c.logn, seed, row0, rows, (hipStream_t)stream);
+        launch_fill_uniform(data, c.d_desc, map_from_primes(c, row_primes, period, inner), c.logn, seed, row0, rows, on(stream));
     });
 }
 
 int troyhip_negate(troyhip_context *ctx, troyhip_ct *a, uint64_t batch, void *stream) {
-    return guard([&] { CtBatch x = view(a); need(ctx)->ev.negate(x, batch, (hipStream_t)stream); store(x, a); });
+    return guard([&] { CtBatch x = view(a); need(ctx)->ev.negate(x, batch, on(stream)); store(x, a); });
 }
 int troyhip_add(troyhip_context *ctx, troyhip_ct *a, const troyhip_ct *b, uint64_t batch, void *stream) {
-    return guard([&] { CtBatch x = view(a); need(ctx)->ev.add_sub(x, view(b), batch, false, (hipStream_t)stream); store(x, a); });
+    return guard([&] { CtBatch x = view(a); need(ctx)->ev.add_sub(x, view(b), batch, false, on(stream)); store(x, a); });
 }
 int troyhip_sub(troyhip_context *ctx, troyhip_ct *a, const troyhip_ct *b, uint64_t batch, void *stream) {
-    return guard([&] { CtBatch x = view(a); need(ctx)->ev.add_sub(x, view(b), batch, true, (hipStream_t)stream); store(x, a); });
+    return guard([&] { CtBatch x = view(a); need(ctx)->ev.add_sub(x, view(b), batch, true, on(stream)); store(x, a); });
 }
 int troyhip_multiply(troyhip_context *ctx, const troyhip_ct *a, const troyhip_ct *b, troyhip_ct *out, uint64_t batch, void *stream) {
-    return guard([&] { CtBatch o = view(out); need(ctx)->ev.multiply(view(a), view(b), o, batch, (hipStream_t)stream); store(o, out); });
+    return guard([&] { CtBatch o = view(out); need(ctx)->ev.multiply(view(a), view(b), o, batch, on(stream)); store(o, out); });
 }
 int troyhip_relinearize(troyhip_context *ctx, troyhip_ct *ct, const uint64_t *relin_key, uint64_t batch, void *stream) {
     return guard([&] {
         if (!relin_key) throw Error(ST_INVALID_ARGUMENT, "not enough relinearization keys");
         CtBatch x = view(ct);
-        need(ctx)->ev.relinearize(x, KsKey{relin_key}, batch, (hipStream_t)stream);
+        need(ctx)->ev.relinearize(x, KsKey{relin_key}, batch, on(stream));
         store(x, ct);
     });
 }
@@ -532,7 +551,7 @@ int troyhip_relinearize_keys(troyhip_context *ctx, troyhip_ct *ct, const uint64_
         KsKey keys[14];
         for (int i = 0; i < n_keys; i++) keys[i] = KsKey{relin_keys[i]};
         CtBatch x = view(ct);
-        need(ctx)->ev.relinearize(x, keys, n_keys, batch, (hipStream_t)stream);
+        need(ctx)->ev.relinearize(x, keys, n_keys, batch, on(stream));
         store(x, ct);
     });
 }
@@ -543,22 +562,22 @@ int troyhip_relinearize_to(troyhip_context *ctx, const troyhip_ct *in, troyhip_c
         KsKey keys[14];
         for (int i = 0; i < n_keys; i++) keys[i] = KsKey{relin_keys[i]};
         CtBatch o = view(out);
-        need(ctx)->ev.relinearize_to(view(in), o, keys, n_keys, batch, (hipStream_t)stream);
+        need(ctx)->ev.relinearize_to(view(in), o, keys, n_keys, batch, on(stream));
         store(o, out);
     });
 }
 int troyhip_switch_key(troyhip_context *ctx, troyhip_ct *ct, const uint64_t *target, uint64_t target_batch_stride, const uint64_t *kswitch_key,
                        uint64_t batch, void *stream) {
-    return guard([&] { CtBatch x = view(ct); need(ctx)->ev.switch_key(x, target, target_batch_stride, KsKey{kswitch_key}, batch, (hipStream_t)stream); store(x, ct); });
+    return guard([&] { CtBatch x = view(ct); need(ctx)->ev.switch_key(x, target, target_batch_stride, KsKey{kswitch_key}, batch, on(stream)); store(x, ct); });
 }
 int troyhip_mod_switch_to_next(troyhip_context *ctx, const troyhip_ct *in, troyhip_ct *out, uint64_t batch, void *stream) {
-    return guard([&] { CtBatch o = view(out); need(ctx)->ev.mod_switch_to_next(view(in), o, batch, (hipStream_t)stream); store(o, out); });
+    return guard([&] { CtBatch o = view(out); need(ctx)->ev.mod_switch_to_next(view(in), o, batch, on(stream)); store(o, out); });
 }
 int troyhip_rescale_to_next(troyhip_context *ctx, const troyhip_ct *in, troyhip_ct *out, uint64_t batch, void *stream) {
-    return guard([&] { CtBatch o = view(out); need(ctx)->ev.rescale_to_next(view(in), o, batch, (hipStream_t)stream); store(o, out); });
+    return guard([&] { CtBatch o = view(out); need(ctx)->ev.rescale_to_next(view(in), o, batch, on(stream)); store(o, out); });
 }
 int troyhip_apply_galois(troyhip_context *ctx, troyhip_ct *ct, uint32_t galois_elt, const uint64_t *galois_key, uint64_t batch, void *stream) {
-    return guard([&] { CtBatch x = view(ct); need(ctx)->ev.apply_galois(x, galois_elt, KsKey{galois_key}, batch, (hipStream_t)stream); store(x, ct); });
+    return guard([&] { CtBatch x = view(ct); need(ctx)->ev.apply_galois(x, galois_elt, KsKey{galois_key}, batch, on(stream)); store(x, ct); });
 }
 
 static void rotate_internal(troyhip_context *ctx, CtBatch &x, int steps, const uint32_t *elts, const uint64_t *const *keys, int n_keys, u64 batch, hipStream_t s) {
@@ -580,21 +599,21 @@ int troyhip_rotate(troyhip_context *ctx, troyhip_ct *ct, int steps, int conjugat
             const uint64_t *k = nullptr;
             for (int i = 0; i < n_keys; i++) if (key_elts[i] == elt) k = keys[i];
             if (!k) throw Error(ST_INVALID_ARGUMENT, "Galois key not present");
-            need(ctx)->ev.apply_galois(x, elt, KsKey{k}, batch, (hipStream_t)stream);
+            need(ctx)->ev.apply_galois(x, elt, KsKey{k}, batch, on(stream));
         } else {
-            rotate_internal(ctx, x, steps, key_elts, keys, n_keys, batch, (hipStream_t)stream);
+            rotate_internal(ctx, x, steps, key_elts, keys, n_keys, batch, on(stream));
         }
         store(x, ct);
     });
 }
 int troyhip_transform_to_ntt(troyhip_context *ctx, troyhip_ct *ct, uint64_t batch, void *stream) {
-    return guard([&] { CtBatch x = view(ct); need(ctx)->ev.transform_to_ntt(x, batch, (hipStream_t)stream); store(x, ct); });
+    return guard([&] { CtBatch x = view(ct); need(ctx)->ev.transform_to_ntt(x, batch, on(stream)); store(x, ct); });
 }
 int troyhip_transform_from_ntt(troyhip_context *ctx, troyhip_ct *ct, uint64_t batch, void *stream) {
-    return guard([&] { CtBatch x = view(ct); need(ctx)->ev.transform_from_ntt(x, batch, (hipStream_t)stream); store(x, ct); });
+    return guard([&] { CtBatch x = view(ct); need(ctx)->ev.transform_from_ntt(x, batch, on(stream)); store(x, ct); });
 }
 int troyhip_multiply_plain_ntt(troyhip_context *ctx, troyhip_ct *ct, const uint64_t *plain, double plain_scale, uint64_t batch, void *stream) {
-    return guard([&] { CtBatch x = view(ct); need(ctx)->ev.multiply_plain_ntt(x, plain, plain_scale, batch, (hipStream_t)stream); store(x, ct); });
+    return guard([&] { CtBatch x = view(ct); need(ctx)->ev.multiply_plain_ntt(x, plain, plain_scale, batch, on(stream)); store(x, ct); });
 }
 int troyhip_multiply_plain_accumulate(troyhip_context *ctx, const troyhip_ct *const *cts, const uint64_t *const *plains, int count, double plain_scale, troyhip_ct *out,
                                       uint64_t batch, void *stream) {
@@ -603,7 +622,7 @@ int troyhip_multiply_plain_accumulate(troyhip_context *ctx, const troyhip_ct *co
         CtBatch v[16];
         for (int i = 0; i < count; i++) v[i] = view(cts[i]);
         CtBatch o = view(out);
-        need(ctx)->ev.multiply_plain_accumulate(v, plains, count, plain_scale, o, batch, (hipStream_t)stream);
+        need(ctx)->ev.multiply_plain_accumulate(v, plains, count, plain_scale, o, batch, on(stream));
         store(o, out);
     });
 }
@@ -611,26 +630,26 @@ int troyhip_add_plain(troyhip_context *ctx, troyhip_ct *ct, const uint64_t *plai
                       int subtract, uint64_t batch, void *stream) {
     return guard([&] {
         CtBatch x = view(ct);
-        need(ctx)->ev.add_plain(x, plain, plain_coeff_count, plain_batch_stride, plain_scale, subtract != 0, batch, (hipStream_t)stream);
+        need(ctx)->ev.add_plain(x, plain, plain_coeff_count, plain_batch_stride, plain_scale, subtract != 0, batch, on(stream));
         store(x, ct);
     });
 }
 int troyhip_multiply_plain(troyhip_context *ctx, troyhip_ct *ct, const uint64_t *plain, uint64_t plain_coeff_count, uint64_t plain_batch_stride, uint64_t batch,
                            void *stream) {
-    return guard([&] { CtBatch x = view(ct); need(ctx)->ev.multiply_plain(x, plain, plain_coeff_count, plain_batch_stride, batch, (hipStream_t)stream); store(x, ct); });
+    return guard([&] { CtBatch x = view(ct); need(ctx)->ev.multiply_plain(x, plain, plain_coeff_count, plain_batch_stride, batch, on(stream)); store(x, ct); });
 }
 int troyhip_plain_to_ntt(troyhip_context *ctx, const uint64_t *plain, uint64_t plain_coeff_count, uint64_t plain_batch_stride, int limbs, uint64_t *out,
                          uint64_t count, void *stream) {
-    return guard([&] { need(ctx)->ev.plain_to_ntt(plain, plain_coeff_count, plain_batch_stride, limbs, out, count, (hipStream_t)stream); });
+    return guard([&] { need(ctx)->ev.plain_to_ntt(plain, plain_coeff_count, plain_batch_stride, limbs, out, count, on(stream)); });
 }
 int troyhip_apply_key_switching(troyhip_context *ctx, troyhip_ct *ct, const uint64_t *kswitch_key, uint64_t batch, void *stream) {
-    return guard([&] { CtBatch x = view(ct); need(ctx)->ev.apply_key_switching(x, KsKey{kswitch_key}, batch, (hipStream_t)stream); store(x, ct); });
+    return guard([&] { CtBatch x = view(ct); need(ctx)->ev.apply_key_switching(x, KsKey{kswitch_key}, batch, on(stream)); store(x, ct); });
 }
 int troyhip_negacyclic_shift(troyhip_context *ctx, troyhip_ct *ct, uint64_t shift, uint64_t batch, void *stream) {
-    return guard([&] { CtBatch x = view(ct); need(ctx)->ev.negacyclic_shift(x, shift, batch, (hipStream_t)stream); store(x, ct); });
+    return guard([&] { CtBatch x = view(ct); need(ctx)->ev.negacyclic_shift(x, shift, batch, on(stream)); store(x, ct); });
 }
 int troyhip_divide_by_poly_modulus_degree(troyhip_context *ctx, troyhip_ct *ct, uint64_t mul, uint64_t batch, void *stream) {
-    return guard([&] { CtBatch x = view(ct); need(ctx)->ev.divide_by_degree(x, mul, batch, (hipStream_t)stream); store(x, ct); });
+    return guard([&] { CtBatch x = view(ct); need(ctx)->ev.divide_by_degree(x, mul, batch, on(stream)); store(x, ct); });
 }
 int troyhip_random_bytes(void *out, size_t n) { // the reference seeds its PRNG from std::random_device (src/randomgen.cpp:23,72)
     return guard([&] {
@@ -660,7 +679,7 @@ int troyhip_context_parms_id(const troyhip_context *ctx, int limbs, uint64_t out
 }
 int troyhip_decrypt(troyhip_context *ctx, const troyhip_ct *ct, const uint64_t *secret_key, uint64_t *plain_out, uint64_t plain_batch_stride, uint64_t batch,
                     void *stream) {
-    return guard([&] { CtBatch x = view(ct); need(ctx)->ev.decrypt(x, secret_key, plain_out, plain_batch_stride, batch, (hipStream_t)stream); });
+    return guard([&] { CtBatch x = view(ct); need(ctx)->ev.decrypt(x, secret_key, plain_out, plain_batch_stride, batch, on(stream)); });
 }
 
 } // extern "C"

@@ -210,6 +210,7 @@ void Evaluator::multiply(const CtBatch &a, const CtBatch &b, CtBatch &out, u64 b
             ids.insert(ids.end(), lv.bsk_ids.begin(), lv.bsk_ids.end());
             const LimbMap mmap = c.ids_map(ids);
             u64 *X = xq, *D = dq; // the arena carved xq | xb | dq | db back to back: X spans the first two, D the last two
+            if (xb != xq + batch * sp * pw || db != dq + batch * ds * pw) throw Error(ST_LOGIC_ERROR, "multiply: the merged scratch is not contiguous (arena alignment changed?)");
             u64 *X_b = same ? X : X + batch * sa * mw;
             if (same || batch * sp > 65535) {
                 launch_behz_extend(a.data, pw, X + (u64)L * N, mw, c.d_desc, *lv.behz, N, batch * sa, s);
@@ -353,7 +354,7 @@ void Evaluator::switch_key(CtBatch &ct, const u64 *target, u64 t_bstride, const 
         u64 *tt = c.arena.take(batch * dl * N);
         const LimbMap tmap = c.ct_map((int)dl);
         if (ntt1_supported(c.logn, tmap, batch * dl, 3)) { // out of place: the single-pass inverse reads the strided target itself
-            launch_ntt1(tt, target, c.d_desc, tmap, batch * dl, true, s, ~0ull, nullptr, nullptr, t_bstride);
+            launch_ntt1(tt, target, c.d_desc, tmap, batch * dl, c.logn, true, s, ~0ull, nullptr, nullptr, t_bstride);
         } else {
             launch_copy_strided(target, t_bstride, tt, dl * N, dl * N, batch, s);
             launch_ntt(tt, c.d_desc, tmap, batch * dl, c.logn, true, s);
@@ -415,7 +416,7 @@ void Evaluator::switch_key(CtBatch &ct, const u64 *target, u64 t_bstride, const 
             cr.base = base;
             cr.base_gstride = base_bstride;
             cr.base_polys = base_polys;
-            launch_ntt1(nullptr, nullptr, c.d_desc, cmap, batch * 2 * dl, false, s, ~0ull, nullptr, &cr);
+            launch_ntt1(nullptr, nullptr, c.d_desc, cmap, batch * 2 * dl, c.logn, false, s, ~0ull, nullptr, &cr);
         } else {
             launch_ks_ckks_corr(last, corr, a, s);
             launch_ntt(corr, c.d_desc, cmap, batch * 2 * dl, c.logn, false, s);
@@ -426,12 +427,12 @@ void Evaluator::switch_key(CtBatch &ct, const u64 *target, u64 t_bstride, const 
         if (md_single) {
             // single-pass inverse: the special limb first, then the data limbs with the mod-down as their store epilogue (no acc round trip,
             // no separate memory-bound kernel)
-            launch_ntt1(acc, nullptr, c.d_desc, amap, batch * 2 * rl, true, s, u64(1) << dl, nullptr, nullptr, 0, c.logn);
+            launch_ntt1(acc, nullptr, c.d_desc, amap, batch * 2 * rl, c.logn, true, s, u64(1) << dl);
             Ntt1ModDown md{ct.data, ct.bstride, dl, qk, a.half};
             md.base = base;
             md.base_bstride = base_bstride;
             md.base_polys = base_polys;
-            launch_ntt1(acc, nullptr, c.d_desc_md, amap, batch * 2 * rl, true, s, (u64(1) << dl) - 1, &md, nullptr, 0, c.logn);
+            launch_ntt1(acc, nullptr, c.d_desc_md, amap, batch * 2 * rl, c.logn, true, s, (u64(1) << dl) - 1, &md);
         } else if (md_two_pass) {
             // two-pass inverse, same shape: the special limb first, then the data limbs with the mod-down (BFV or BGV) as the last pass's epilogue
             // the first pass is the same for every slot (N^-1 and qk^-1 ride on the last inverse stage): a small launch runs it over the special limb
@@ -439,7 +440,8 @@ void Evaluator::switch_key(CtBatch &ct, const u64 *target, u64 t_bstride, const 
             const bool one_first_pass = take_merged(c, batch * 2 * rl);
             if (one_first_pass) {
                 launch_ntt2_slots(acc, nullptr, 0, false, c.d_desc, amap, batch * 2 * rl, c.logn, true, s, false, 0, 0, (unsigned)rl, nullptr, 1);
-                launch_ntt2_slots(acc, nullptr, 0, false, c.d_desc, amap, batch * 2 * rl, c.logn, true, s, false, 0, (unsigned)dl, 1, nullptr, 2);
+                // the second passes plan their FP64 reductions from the bound the SHARED first pass left: the largest prime of slots 0 .. rl, not of their own range
+                launch_ntt2_slots(acc, nullptr, 0, false, c.d_desc, amap, batch * 2 * rl, c.logn, true, s, false, 0, (unsigned)dl, 1, nullptr, 2, 0, (unsigned)rl);
             } else {
                 launch_ntt2_slots(acc, nullptr, 0, false, c.d_desc, amap, batch * 2 * rl, c.logn, true, s, false, 0, (unsigned)dl, 1, nullptr);
             }
@@ -452,7 +454,8 @@ void Evaluator::switch_key(CtBatch &ct, const u64 *target, u64 t_bstride, const 
             md.base = base;
             md.base_bstride = base_bstride;
             md.base_polys = base_polys;
-            launch_ntt2_slots(acc, nullptr, 0, false, c.d_desc_md, amap, batch * 2 * rl, c.logn, true, s, false, 0, 0, (unsigned)dl, &md, one_first_pass ? 2u : 3u);
+            launch_ntt2_slots(acc, nullptr, 0, false, c.d_desc_md, amap, batch * 2 * rl, c.logn, true, s, false, 0, 0, (unsigned)dl, &md, one_first_pass ? 2u : 3u, 0,
+                              one_first_pass ? (unsigned)rl : 0u);
         } else {
             launch_ntt(acc, c.d_desc, amap, batch * 2 * rl, c.logn, true, s);
             launch_ks_moddown(c.scheme == SCHEME_BFV ? 0 : 2, acc, ct.data, ct.bstride, a, s);
@@ -570,7 +573,7 @@ void Evaluator::mod_switch_scale(const CtBatch &in, CtBatch &out, u64 batch, hip
         if (ckks_fused) {
             Ntt1Corr cr{last, src, (u64)pw, dst, (u64)in.size * npw, (u64)npw, (unsigned)in.size, lvl.d_inv_qlast, c.primes[L - 1], a.half, false};
             if (!dense_in && !staged) cr.in_gstride = in.bstride;
-            launch_ntt1(nullptr, nullptr, c.d_desc, cmap, batch * in.size * nl, false, s, ~0ull, nullptr, &cr);
+            launch_ntt1(nullptr, nullptr, c.d_desc, cmap, batch * in.size * nl, c.logn, false, s, ~0ull, nullptr, &cr);
         } else {
             launch_rescale_stepA(last, N, corr, a, s);
             launch_ntt(corr, c.d_desc, cmap, batch * in.size * nl, c.logn, false, s);

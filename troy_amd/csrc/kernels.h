@@ -41,10 +41,12 @@ bool ntt2_supported(int logn);
 // temporary; spares the copy into ct[b][0] and the zero fill of ct[b][1])
 struct Ntt2ModDown { int kind; u64 *ct; u64 ct_bstride; unsigned dl; u64 qk, half; const u64 *share; const u64 *base = nullptr; u64 base_bstride = 0; int base_polys = 1; };
 // passes: bit 0 = the first pass of the transform, bit 1 = the second (a caller that runs the first pass of several slot ranges as ONE launch and the second
-// passes separately: the key-switch mod-down of a small launch, whose special limb and data limbs differ only in the last pass)
+// passes separately: the key-switch mod-down of a small launch, whose special limb and data limbs differ only in the last pass).
+// plan_begin / plan_count (with passes == 2): the slot range the shared FIRST pass ran over -- the FP64 bound walk of this launch assumes the largest
+// prime of that range, because that is the bound the lazy doubles it reads were left with
 void launch_ntt2_slots(u64 *data, const u64 *src, u64 src_ostride, bool src_reduce, const PrimeDesc *primes, const LimbMap &map, size_t rows, int logn,
                        bool inverse, hipStream_t stream, bool src_same_layout, u64 src_bound, unsigned slot_begin, unsigned slot_count, const Ntt2ModDown *md,
-                       unsigned passes = 3);
+                       unsigned passes = 3, unsigned plan_begin = 0, unsigned plan_count = 0);
 void launch_ntt2(u64 *data, const u64 *src, u64 src_ostride, bool src_reduce, const PrimeDesc *primes, const LimbMap &map, size_t rows, int logn,
                  bool inverse, hipStream_t stream, bool src_same_layout = false, u64 src_bound = 0);
 
@@ -81,8 +83,9 @@ struct Ntt1Corr {
     int base_polys = 1; // 2: members 0 and 1 of a group read base[g * base_gstride + {0, 1} * out_ostride ..] (relinearize out of place)
 };
 // slot_mask: only these prime slots of the row pattern are transformed
-void launch_ntt1(u64 *data, const u64 *src, const PrimeDesc *primes, const LimbMap &map, size_t rows, bool inverse, hipStream_t stream, u64 slot_mask = ~0ull,
-                 const Ntt1ModDown *md = nullptr, const Ntt1Corr *cr = nullptr, u64 src_ostride = 0, int logn = 15);
+// logn is mandatory (round-4 advisor): a caller at N = 2^12 .. 2^14 that forgot it would run the 2^15 kernel over rows 2 .. 8 times shorter
+void launch_ntt1(u64 *data, const u64 *src, const PrimeDesc *primes, const LimbMap &map, size_t rows, int logn, bool inverse, hipStream_t stream, u64 slot_mask = ~0ull,
+                 const Ntt1ModDown *md = nullptr, const Ntt1Corr *cr = nullptr, u64 src_ostride = 0);
 
 // ---- poly.hip ----
 void launch_ew(int op, const u64 *a, const u64 *b, u64 *out, const PrimeDesc *primes, const LimbMap &map, int logn, u64 rows, hipStream_t s);

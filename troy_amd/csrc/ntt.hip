@@ -188,7 +188,7 @@ static void plan(int logn, int &k1, int &k2) {
 
 void launch_ntt_from(u64 *data, const u64 *src, const PrimeDesc *primes, const LimbMap &map, size_t rows, int logn, hipStream_t stream) {
     if (rows == 0) return;
-    if (ntt1_supported(logn, map, rows)) { launch_ntt1(data, src, primes, map, rows, false, stream, ~0ull, nullptr, nullptr, 0, logn); return; }
+    if (ntt1_supported(logn, map, rows)) { launch_ntt1(data, src, primes, map, rows, logn, false, stream); return; }
     if (ntt2_supported(logn) && rows % ((size_t)map.period * map.inner) == 0) { // the first pass reads src, no copy
         launch_ntt2(data, src, 0, false, primes, map, rows, logn, false, stream, true);
         return;
@@ -198,7 +198,7 @@ void launch_ntt_from(u64 *data, const u64 *src, const PrimeDesc *primes, const L
 }
 void launch_ntt(u64 *data, const PrimeDesc *primes, const LimbMap &map, size_t rows, int logn, bool inverse, hipStream_t stream) {
     if (rows == 0) return;
-    if (ntt1_supported(logn, map, rows)) { launch_ntt1(data, nullptr, primes, map, rows, inverse, stream, ~0ull, nullptr, nullptr, 0, logn); return; } // N = 2^12 .. 2^15: single pass
+    if (ntt1_supported(logn, map, rows)) { launch_ntt1(data, nullptr, primes, map, rows, logn, inverse, stream); return; } // N = 2^12 .. 2^15: single pass
     if (ntt2_supported(logn) && rows % ((size_t)map.period * map.inner) == 0) { // production path for N >= 4096
         launch_ntt2(data, nullptr, 0, false, primes, map, rows, logn, inverse, stream);
         return;

@@ -1091,8 +1091,8 @@ bool ntt1_supported(int logn, const LimbMap &map, size_t rows, int feature) {
 }
 // rows laid out r = (o * period + i) * inner + k, prime map.id[i].  The forward transform is launched once per prime class:
 // guard-free butterflies for the slots in map.lean, guarded ones for the rest.
-void launch_ntt1(u64 *data, const u64 *src, const PrimeDesc *primes, const LimbMap &map, size_t rows, bool inverse, hipStream_t stream, u64 slot_mask,
-                 const Ntt1ModDown *md, const Ntt1Corr *cr, u64 src_ostride, int logn) {
+void launch_ntt1(u64 *data, const u64 *src, const PrimeDesc *primes, const LimbMap &map, size_t rows, int logn, bool inverse, hipStream_t stream, u64 slot_mask,
+                 const Ntt1ModDown *md, const Ntt1Corr *cr, u64 src_ostride) {
     if (rows == 0) return;
     if (logn < 12 || logn > N1_LOGN) throw Error(ST_LOGIC_ERROR, "ntt1: unsupported size");
     if (logn != N1_LOGN && (cr || (src && inverse))) throw Error(ST_LOGIC_ERROR, "ntt1: the correction form and the strided source belong to N = 2^15");

@@ -1084,8 +1084,9 @@ void launch_ntt2(u64 *data, const u64 *src, u64 src_ostride, bool src_reduce, co
 // FP64 instances on for the slots in map.fp: without it every slot takes the integer kernels.
 void launch_ntt2_slots(u64 *data, const u64 *src, u64 src_ostride, bool src_reduce, const PrimeDesc *primes, const LimbMap &map, size_t rows, int logn,
                        bool inverse, hipStream_t stream, bool src_same_layout, u64 src_bound, unsigned slot_begin, unsigned slot_count, const Ntt2ModDown *md,
-                       unsigned passes) {
+                       unsigned passes, unsigned plan_begin, unsigned plan_count) {
     const u64 *host_primes = map.host_primes;
+    if (plan_count && plan_begin + plan_count > map.period) throw Error(ST_INVALID_ARGUMENT, "ntt2: plan slot range");
     if (rows == 0 || slot_count == 0) return;
     if (slot_begin + slot_count > map.period) throw Error(ST_INVALID_ARGUMENT, "ntt2: slot range");
     const bool partial = slot_begin != 0 || slot_count != map.period;
@@ -1139,6 +1140,13 @@ void launch_ntt2_slots(u64 *data, const u64 *src, u64 src_ostride, bool src_redu
         if (fp) {
             u64 pmax = 0;
             for (unsigned i = 0; i < a.nsel; i++) pmax = std::max(pmax, host_primes[map.id[a.sel[i]]]);
+            // a pass launched on its own inherits the lazy doubles of a first pass that ran over MORE slots: the walk must assume the largest prime
+            // of every slot that shared that pass, or this launch would plan from a smaller bound than the data really carries
+            if (plan_count) {
+                uint8_t mates[64];
+                const unsigned n = select_class(map, plan_begin, plan_count, true, mates);
+                for (unsigned i = 0; i < n; i++) pmax = std::max(pmax, host_primes[map.id[mates[i]]]);
+            }
             int r1[4], r2[4];
             const int n1 = pass_rounds(inverse ? k2 : k1, inverse, r1), n2 = pass_rounds(inverse ? k1 : k2, inverse, r2);
             const FpPlan p1 = inverse ? fp_plan_inv(pmax, 1.0, r1, n1) : fp_plan(pmax, 1.0, r1, n1);
