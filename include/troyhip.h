@@ -164,6 +164,14 @@ int troyhip_host_encrypt(const troyhip_context *ctx, uint64_t seed_lo, uint64_t 
  * operand and result layout as troyhip_host_encrypt, (c0, c1) = (-(a s + e) + message, a) sampled at the plaintext's own level */
 int troyhip_host_encrypt_symmetric(const troyhip_context *ctx, uint64_t seed_lo, uint64_t seed_hi, const uint64_t *secret_key, const uint64_t *plain,
                                    uint64_t n_coeffs, int limbs, uint64_t *ct_out);
+/* The seeded form of a fresh symmetric ciphertext (src/utils/rlwe_cuda.cu:262-330 sets CiphertextCuda::seed(); src/ciphertext_cuda.cu:26-35 saves c0 alone;
+ * :145-190 load(stream, context) regenerates c1): c1 is a function of the public 64-bit `a_seed` (non-zero) alone.  plain == NULL: an encryption of zero
+ * at the level of `limbs` primes (encryptZeroSymmetric); otherwise operands and result as troyhip_host_encrypt_symmetric.  troyhip_host_expand_seed
+ * writes c1 [limbs][N] in the form the ciphertext stores it (NTT form for CKKS, coefficient form otherwise).  The wire format is the reference's; the
+ * seed -> c1 expansion is this library's (ChaCha20; the reference's is curand's XORWOW, which exists only inside that library). */
+int troyhip_host_encrypt_symmetric_seeded(const troyhip_context *ctx, uint64_t seed_lo, uint64_t seed_hi, uint64_t a_seed, const uint64_t *secret_key,
+                                          const uint64_t *plain, uint64_t n_coeffs, int limbs, uint64_t *ct_out);
+int troyhip_host_expand_seed(const troyhip_context *ctx, uint64_t a_seed, int limbs, uint64_t *c1_out);
 /* Decryptor::decrypt.  BFV/BGV: N plaintext coefficients;  CKKS: the [limbs][N] RNS plaintext (NTT form) */
 int troyhip_host_decrypt(const troyhip_context *ctx, const uint64_t *secret_key, const uint64_t *ct, int size, int limbs, int is_ntt_form,
                          uint64_t correction_factor, uint64_t *plain_out);

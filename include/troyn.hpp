@@ -560,6 +560,7 @@ public:
     // a ciphertext that owns its storage keeps capacity max(size, 3) polynomials so multiply / relinearize run in place
     void resize(size_t n, size_t limbs, size_t size) {
         n_ = n;
+        seed_ = 0;
         const size_t words = std::max<size_t>(size, 3) * limbs * n;
         if (!store_ || !own_ || store_->size() != words) {
             auto fresh = std::make_shared<DeviceArray>(words);
@@ -586,7 +587,7 @@ public:
         d_.data = store_->get();
         d_.batch_stride = size_capacity * (size_t)d_.limbs * n_;
     }
-    void release() noexcept { store_.reset(); own_ = true; d_ = troyhip_ct{nullptr, 0, 0, 0, 0, 1.0, 1}; }
+    void release() noexcept { store_.reset(); own_ = true; seed_ = 0; d_ = troyhip_ct{nullptr, 0, 0, 0, 0, 1.0, 1}; }
     bool isTransparent() const {
         if (!d_.data || size() < 2) return true;
         const std::vector<uint64_t> h = toHost();
@@ -683,8 +684,13 @@ public:
                d_.correction_factor == o.d_.correction_factor;
     }
     void copyMeta(const troyhip_ct &m) { d_.size = m.size; d_.limbs = m.limbs; d_.is_ntt_form = m.is_ntt_form; d_.scale = m.scale; d_.correction_factor = m.correction_factor; }
-    troyhip_ct *raw() { return &d_; }
+    troyhip_ct *raw() { seed_ = 0; return &d_; } // whoever takes the mutable view may rewrite the polynomials: c1 is no longer the seed's expansion
     const troyhip_ct *raw() const { return &d_; }
+    // seed() (src/ciphertext_cuda.cuh:189-190): non-zero for a fresh symmetric encryption, whose c1 is the expansion of this 64-bit seed -- save() then
+    // writes c0 alone and load(stream, context) regenerates c1.  The reference never clears it (an Evaluator op on such a ciphertext followed by
+    // save() would drop the modified c1); here every mutable access clears it.
+    uint64_t seed() const noexcept { return seed_; }
+    uint64_t &seed() noexcept { return seed_; }
     // wire format of CiphertextCuda::save / load / saveTerms / loadTerms (src/ciphertext_cuda.cu:16-143); the context supplies
     // the 256-bit parms_id the reference object carries itself (defined after Evaluator below)
     inline void save(std::ostream &stream, const SEALContext &context) const;
@@ -698,10 +704,10 @@ public:
     inline void saveTerms(std::ostream &stream, const class Evaluator &evaluator, const std::vector<size_t> &termIds) const;
     inline void loadTerms(std::istream &stream, const class Evaluator &evaluator, const std::vector<size_t> &termIds);
     // value semantics: a copy gets storage of its own (also when the source is a slab member)
-    Ciphertext(const Ciphertext &o) : d_(o.d_), n_(o.n_), ids_(o.ids_) { clone(o); }
+    Ciphertext(const Ciphertext &o) : d_(o.d_), n_(o.n_), ids_(o.ids_) { clone(o); seed_ = o.seed_; }
     Ciphertext(Ciphertext &&o) noexcept = default;
     Ciphertext &operator=(const Ciphertext &o) {
-        if (this != &o) { d_ = o.d_; n_ = o.n_; ids_ = o.ids_; clone(o); }
+        if (this != &o) { d_ = o.d_; n_ = o.n_; ids_ = o.ids_; clone(o); seed_ = o.seed_; }
         return *this;
     }
     Ciphertext &operator=(Ciphertext &&o) noexcept = default;
@@ -722,6 +728,7 @@ private:
     troyhip_ct d_{nullptr, 0, 0, 0, 0, 1.0, 1};
     size_t n_ = 0;
     bool ntt_shadow_ = false;
+    uint64_t seed_ = 0;
     std::shared_ptr<const std::vector<ParmsID>> ids_;
 };
 
@@ -1004,9 +1011,14 @@ public:
     }
     Ciphertext encrypt(const Plaintext &plain) const { Ciphertext d; encrypt(plain, d); return d; }
     // encryptSymmetric (src/encryptor_cuda.cuh:259-290): (-(a s + e) + m, a) at the plaintext's own level
+    // The ciphertext carries the seed its c1 was expanded from (dst.seed() != 0: src/utils/rlwe_cuda.cu:292-303), so save() writes half of it.
     void encryptSymmetric(const Plaintext &plain, Ciphertext &dst) const {
         if (sk_.data.empty()) throw std::logic_error("secret key is not set"); // src/encryptor.cpp:164-167
-        run(troyhip_host_encrypt_symmetric, sk_.data, plain, dst);
+        const uint64_t a_seed = fresh_a_seed();
+        run([a_seed](const troyhip_context *c, uint64_t lo, uint64_t hi, const uint64_t *key, const uint64_t *pl, uint64_t count, int limbs, uint64_t *out) {
+            return troyhip_host_encrypt_symmetric_seeded(c, lo, hi, a_seed, key, pl, count, limbs, out);
+        }, sk_.data, plain, dst);
+        dst.seed() = a_seed;
     }
     Ciphertext encryptSymmetric(const Plaintext &plain) const { Ciphertext d; encryptSymmetric(plain, d); return d; }
     // encryptZero / encryptZeroSymmetric (src/encryptor_cuda.cuh:170-237, 292-320; src/encryptor.cpp:88-150): zero at the first data level or at
@@ -1022,6 +1034,13 @@ public:
         if (sk_.data.empty()) throw std::logic_error("secret key is not set");
         zero(sk_.data, 1, parms_id, dst);
     }
+    // a public 64-bit seed for c1, never zero (zero means "not seeded" on the wire): from the deterministic stream of a seeded encryptor, else fresh
+    uint64_t fresh_a_seed() const {
+        uint64_t a = 0;
+        if (seeded_) a = (lo_ ^ 0x9E3779B97F4A7C15ull) + 0xD1B54A32D192ED03ull * (counter_ + 1);
+        else check(troyhip_random_bytes(&a, sizeof(a)));
+        return a ? a : 1;
+    }
     void encryptZeroSymmetric(Ciphertext &dst) const { encryptZeroSymmetric(c_.firstParmsID(), dst); }
     Ciphertext encryptZeroSymmetric(const ParmsID &parms_id) const { Ciphertext d; encryptZeroSymmetric(parms_id, d); return d; }
     Ciphertext encryptZeroSymmetric() const { return encryptZeroSymmetric(c_.firstParmsID()); }
@@ -1033,9 +1052,12 @@ private:
         std::vector<uint64_t> h((size_t)2 * id.limbs * N);
         uint64_t s[2] = {lo_ + (++counter_), hi_};
         if (!seeded_) check(troyhip_random_bytes(s, sizeof(s)));
-        check(troyhip_host_encrypt_zero(c_.handle(), s[0], s[1], key.data(), symmetric, id.limbs, h.data()));
+        const uint64_t a_seed = symmetric ? fresh_a_seed() : 0;
+        if (symmetric) check(troyhip_host_encrypt_symmetric_seeded(c_.handle(), s[0], s[1], a_seed, key.data(), nullptr, 0, id.limbs, h.data()));
+        else check(troyhip_host_encrypt_zero(c_.handle(), s[0], s[1], key.data(), 0, id.limbs, h.data()));
         dst.fromHost(h, N, (size_t)id.limbs, 2, ckks, 1.0, 1);
         dst.bind(c_);
+        dst.seed() = a_seed;
     }
     template <class F> void run(F fn, const std::vector<uint64_t> &key, const Plaintext &plain, Ciphertext &dst) const {
         const size_t N = c_.polyModulusDegree();
@@ -1916,7 +1938,15 @@ struct Header { bool ntt; size_t size, n, limbs; double scale; uint64_t cf, seed
 inline void put_header(std::ostream &s, const uint64_t *id, const Ciphertext &ct, bool terms) {
     s.write(reinterpret_cast<const char *>(id), 32);
     put<bool>(s, ct.isNttForm()); put<size_t>(s, ct.size()); put<size_t>(s, ct.polyModulusDegree()); put<size_t>(s, ct.coeffModulusSize());
-    put<double>(s, ct.scale()); put<uint64_t>(s, ct.correctionFactor()); put<uint64_t>(s, 0); put<bool>(s, terms);
+    put<double>(s, ct.scale()); put<uint64_t>(s, ct.correctionFactor()); put<uint64_t>(s, ct.seed()); put<bool>(s, terms);
+}
+// the data behind the header (src/ciphertext_cuda.cu:26-42): every polynomial -- or, for a seeded ciphertext, c0 alone
+inline void put_payload(std::ostream &s, const Ciphertext &ct) {
+    if (ct.seed() && ct.size() > 2) throw std::invalid_argument("Seed exists but size is not 2.");
+    const std::vector<uint64_t> h = ct.toHost();
+    const size_t words = ct.seed() ? ct.coeffModulusSize() * ct.polyModulusDegree() : h.size();
+    put<size_t>(s, words);
+    put_words(s, h.data(), words);
 }
 inline Header get_header(std::istream &s, const SEALContext &c) {
     uint64_t id[4], mine[4];
@@ -1927,7 +1957,6 @@ inline Header get_header(std::istream &s, const SEALContext &c) {
     if (h.n != c.polyModulusDegree() || h.limbs < 1 || h.limbs > c.keyLimbs() || h.size < 1) throw std::invalid_argument("encrypted is not valid for encryption parameters");
     check(troyhip_context_parms_id(c.handle(), (int)h.limbs, mine));
     if (!std::equal(id, id + 4, mine)) throw std::invalid_argument("encrypted is not valid for encryption parameters");
-    if (h.seed) throw std::invalid_argument("seed is not zero.");
     return h;
 }
 inline void put_header(std::ostream &s, const SEALContext &c, const Ciphertext &ct, bool terms) {
@@ -1939,19 +1968,19 @@ inline void put_header(std::ostream &s, const SEALContext &c, const Ciphertext &
 
 inline void Ciphertext::save(std::ostream &stream, const SEALContext &context) const {
     wire::put_header(stream, context, *this, false);
-    const std::vector<uint64_t> h = toHost();
-    wire::put<size_t>(stream, h.size());
-    stream.write(reinterpret_cast<const char *>(h.data()), (std::streamsize)(h.size() * 8));
+    wire::put_payload(stream, *this);
 }
+// load(stream, context) (src/ciphertext_cuda.cu:145-190): a seeded blob carries c0 alone, c1 is expanded from the seed; the loaded object is unseeded
 inline void Ciphertext::load(std::istream &stream, const SEALContext &context) {
     const wire::Header h = wire::get_header(stream, context);
     if (h.terms) throw std::invalid_argument("Trying to load a termed ciphertext, but indices is not specified");
-    const size_t words = wire::get<size_t>(stream);
-    if (words != h.size * h.limbs * h.n) throw std::invalid_argument("encrypted is not valid for encryption parameters");
-    std::vector<uint64_t> host(words);
-    stream.read(reinterpret_cast<char *>(host.data()), (std::streamsize)(words * 8));
-    if (!stream) throw std::invalid_argument("stream ended inside a ciphertext");
-    fromHost(host, h.n, h.limbs, h.size, h.ntt, h.scale, h.cf);
+    if (h.seed && h.size > 2) throw std::invalid_argument("Seed exists but size is not 2.");
+    const size_t words = wire::get<size_t>(stream), poly = h.limbs * h.n;
+    if (words != (h.seed ? poly : h.size * poly)) throw std::invalid_argument("encrypted is not valid for encryption parameters");
+    std::vector<uint64_t> host(h.seed ? 2 * poly : words);
+    wire::get_words(stream, host.data(), words);
+    if (h.seed) check(troyhip_host_expand_seed(context.handle(), h.seed, (int)h.limbs, host.data() + poly));
+    fromHost(host, h.n, h.limbs, h.seed ? 2 : h.size, h.ntt, h.scale, h.cf);
     bind(context);
 }
 inline void Ciphertext::saveTerms(std::ostream &stream, const SEALContext &context, const Evaluator &evaluator, const std::vector<size_t> &termIds) const {
@@ -1961,6 +1990,7 @@ inline void Ciphertext::saveTerms(std::ostream &stream, const SEALContext &conte
         evaluator.transformFromNttInplace(copy);
         h = copy.toHost();
     } else h = toHost();
+    if (seed()) throw std::invalid_argument("Seed is not zero."); // src/ciphertext_cuda.cu:66-68
     wire::put_header(stream, context, *this, true);
     const size_t n = polyModulusDegree(), limbs = coeffModulusSize();
     for (size_t id : termIds) {
@@ -1974,6 +2004,7 @@ inline void Ciphertext::saveTerms(std::ostream &stream, const SEALContext &conte
 inline void Ciphertext::loadTerms(std::istream &stream, const SEALContext &context, const Evaluator &evaluator, const std::vector<size_t> &termIds) {
     const wire::Header h = wire::get_header(stream, context);
     if (!h.terms) throw std::invalid_argument("Trying to load a normal ciphertext, but term indices is specified");
+    if (h.seed) throw std::invalid_argument("seed is not zero.");
     std::vector<uint64_t> host(h.size * h.limbs * h.n, 0); // unlisted coefficients of c0: zero
     for (size_t id : termIds) {
         if (id >= h.n) throw std::invalid_argument("term index out of range");
@@ -1990,9 +2021,7 @@ inline void Ciphertext::loadTerms(std::istream &stream, const SEALContext &conte
 inline void Ciphertext::save(std::ostream &stream) const {
     if (parmsID() == parmsIDZero) throw std::logic_error("the ciphertext has not met a context"); // nothing to put in the parms_id field
     wire::put_header(stream, parmsID().data(), *this, false);
-    const std::vector<uint64_t> h = toHost();
-    wire::put<size_t>(stream, h.size());
-    stream.write(reinterpret_cast<const char *>(h.data()), (std::streamsize)(h.size() * 8));
+    wire::put_payload(stream, *this);
 }
 inline void Ciphertext::load(std::istream &stream) { // src/ciphertext_cuda.cu:65-88: no validation without a context
     uint64_t id[4];

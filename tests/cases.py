@@ -1146,6 +1146,15 @@ def check_save_load(api):
     blob = s.getvalue()
     assert len(blob) == 32 + 1 + 8 * 3 + 8 + 8 + 8 + 1 + 8 + 2 * 2 * N * 8
     assert struct.unpack_from("<?QQQd", blob, 32) == (True, 2, N, 2, 2.0 ** 20)
+    # the whole blob against an independent construction: the REFERENCE's parms_id of this level (tests/golden/golden_wire.json, from oracle/_ref), the
+    # fields in the order of src/ciphertext_cuda.cu:16-25, the word count, the polynomials as uploaded ([poly][limb][N]); a permuted payload differs
+    import json
+    import os
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_wire.json")))["ckks"]
+    assert [int(p) for p in primes] == gold["primes"]
+    head = np.array(gold["parms_id"]["2"], dtype=np.uint64).tobytes() + struct.pack("<?QQQdQQ?Q", True, 2, N, 2, 2.0 ** 20, 1, 0, False, 2 * 2 * N)
+    assert blob == head + np.ascontiguousarray(x[1]).tobytes()
+    assert blob != head + np.ascontiguousarray(x[1][:, ::-1]).tobytes()
     back = api.Ciphertext.load(ctx, io.BytesIO(blob))
     assert np.array_equal(back.cpu()[0], x[1]) and back.is_ntt_form and back.scale == 2.0 ** 20
     other = api.SEALContext(api.CKKS, N, api.CoeffModulus.Create(N, [40, 30, 40]), 0)

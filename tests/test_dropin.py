@@ -91,7 +91,7 @@ def test_reference_gpu_tests_pass_unchanged_on_gpu():
 def test_reference_timetest_runs_unchanged_on_gpu():
     r = subprocess.run([_gpu_binary("timetest")], capture_output=True, text=True, timeout=1500, cwd=OUT)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-    for label in ("Multiply", "Relinearize", "RotateRows", "ModSwitchToNext"):  # the timer labels of test/timetest.cu's BFV run
+    for label in ("Encrypt", "Decrypt", "Multiply-inplace", "Relinearize-inplace", "Square-assign", "RotateRows-inplace", "MultiplyPlain-assign"):  # timer labels of its BFV run
         assert re.search(label, r.stdout, re.I), r.stdout[-3000:]
 
 
@@ -102,8 +102,10 @@ def test_reference_linear_apps_run_unchanged_on_gpu():
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     diffs = re.findall(r"Difference = (\S+)", r.stdout)
     assert diffs and all(float(d) == 0 for d in diffs), r.stdout[-3000:]
-    # test/app/linear_ckks.cu: CKKS 1 x 256 x 64 x 56 x 56 convolution, scale 2^15 on two 50-bit primes -- approximate
+    # test/app/linear_ckks.cu: CKKS 1 x 256 x 64 x 56 x 56 convolution of reals in [0, 10) at scale 2^15 -- approximate.  Each of the 256 products per
+    # output carries the two encoding roundings, (|x| + |w|) 2^-16 <= 30 * 1.5e-5, so the sum is within 256 * 4.6e-4 = 0.12 of the exact value at worst
+    # (a random walk of them: ~0.03, which is what the run prints); the reference itself only prints the number
     r = subprocess.run([_gpu_binary("linear_ckks")], capture_output=True, text=True, timeout=1500, cwd=OUT)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     diffs = re.findall(r"Difference = (\S+)", r.stdout)
-    assert diffs and all(float(d) < 1e-2 for d in diffs), r.stdout[-3000:]
+    assert diffs and all(float(d) < 0.12 for d in diffs), r.stdout[-3000:]

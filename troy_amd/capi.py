@@ -56,7 +56,7 @@ SYMBOLS = [
     "troyhip_stream_synchronize", "troyhip_stream_create", "troyhip_stream_destroy", "troyhip_stream_register", "troyhip_stream_unregister", "troyhip_mem_info", "troyhip_device_pci_bus_id", "troyhip_timer_create", "troyhip_timer_destroy",
     "troyhip_timer_start", "troyhip_timer_stop", "troyhip_timer_elapsed_ms", "troyhip_coeff_modulus_create",
     "troyhip_plain_modulus_batching", "troyhip_context_create", "troyhip_context_create_host", "troyhip_context_destroy",
-    "troyhip_host_keygen", "troyhip_host_relin_key", "troyhip_host_galois_key", "troyhip_host_kswitch_key", "troyhip_host_encrypt_zero", "troyhip_host_encrypt", "troyhip_host_encrypt_symmetric", "troyhip_multiply_plain_accumulate", "troyhip_host_decrypt", "troyhip_context_info",
+    "troyhip_host_keygen", "troyhip_host_relin_key", "troyhip_host_galois_key", "troyhip_host_kswitch_key", "troyhip_host_encrypt_zero", "troyhip_host_encrypt", "troyhip_host_encrypt_symmetric", "troyhip_host_encrypt_symmetric_seeded", "troyhip_host_expand_seed", "troyhip_multiply_plain_accumulate", "troyhip_host_decrypt", "troyhip_context_info",
     "troyhip_context_behz_bases", "troyhip_context_ntt_tables", "troyhip_test_modarith", "troyhip_ktime_enable", "troyhip_ktime_report", "troyhip_blake2b", "troyhip_random_bytes", "troyhip_context_parms_id", "troyhip_context_release_stream", "troyhip_context_reserve_scratch",
     "troyhip_context_scratch_words", "troyhip_galois_elt_from_step", "troyhip_ntt", "troyhip_fill_uniform",
     "troyhip_negate", "troyhip_add", "troyhip_sub", "troyhip_multiply", "troyhip_relinearize", "troyhip_relinearize_keys", "troyhip_relinearize_to", "troyhip_switch_key",

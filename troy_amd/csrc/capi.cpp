@@ -499,6 +499,16 @@ int troyhip_host_encrypt_symmetric(const troyhip_context *ctx, uint64_t seed_lo,
         hostcrypto::encrypt_symmetric(need(ctx)->ctx, rng, secret_key, plain, n_coeffs, limbs, ct_out);
     }, false);
 }
+int troyhip_host_encrypt_symmetric_seeded(const troyhip_context *ctx, uint64_t seed_lo, uint64_t seed_hi, uint64_t a_seed, const uint64_t *secret_key,
+                                          const uint64_t *plain, uint64_t n_coeffs, int limbs, uint64_t *ct_out) {
+    return guard([&] {
+        hostcrypto::Rng rng(seed_lo, seed_hi, (u64)(plain ? 4 : 7) << 32);
+        hostcrypto::encrypt_symmetric_seeded(need(ctx)->ctx, rng, a_seed, secret_key, plain, n_coeffs, limbs, ct_out);
+    }, false);
+}
+int troyhip_host_expand_seed(const troyhip_context *ctx, uint64_t a_seed, int limbs, uint64_t *c1_out) {
+    return guard([&] { hostcrypto::expand_seed(need(ctx)->ctx, a_seed, limbs, c1_out); }, false);
+}
 int troyhip_host_decrypt(const troyhip_context *ctx, const uint64_t *secret_key, const uint64_t *ct, int size, int limbs, int is_ntt_form,
                          uint64_t correction_factor, uint64_t *plain_out) {
     return guard([&] { hostcrypto::decrypt(need(ctx)->ctx, secret_key, ct, size, limbs, is_ntt_form != 0, correction_factor, plain_out); }, false);

@@ -131,9 +131,10 @@ void sample_uniform(const Polys &P, Rng &rng, int limbs, u64 *out) {
         for (size_t i = 0; i < P.N; i++) out[l * P.N + i] = rng.uniform_below(P.prime(l));
 }
 // (c0, c1) = (-(a*s + e), a) in NTT form over `limbs` primes: rlwe.cpp:234-331 encryptZeroSymmetric (NTT-form output)
-void encrypt_zero_symmetric_ntt(const Polys &P, Rng &rng, const u64 *sk, int limbs, u64 *c0, u64 *c1, u64 e_scale) {
+// a_rng: where the uniform polynomial `a` comes from -- the encryption's own stream, or a stream keyed by a public 64-bit seed alone (seeded form)
+void encrypt_zero_symmetric_ntt(const Polys &P, Rng &rng, const u64 *sk, int limbs, u64 *c0, u64 *c1, u64 e_scale, Rng *a_rng = nullptr) {
     const size_t N = P.N;
-    sample_uniform(P, rng, limbs, c1);
+    sample_uniform(P, a_rng ? *a_rng : rng, limbs, c1);
     std::vector<u64> e((size_t)limbs * N);
     sample_cbd(P, rng, limbs, e.data());
     for (int l = 0; l < limbs; l++) {
@@ -318,6 +319,38 @@ void encrypt_zero_symmetric(const Context &c, Rng &rng, const u64 *sk, int limbs
             ntt_inverse(c0 + (size_t)l * N, c.tables[l]);
             ntt_inverse(c1 + (size_t)l * N, c.tables[l]);
         }
+}
+
+// ---- seeded symmetric ciphertexts.  The reference expands the seed with curand (XORWOW states keyed by seed + index: src/utils/rlwe_cuda.cu:25-31,
+// 292-303), a generator that exists only inside that library; here the expander is the ChaCha20 stream keyed by (seed, 0) on its own nonce.  The
+// WIRE FORMAT (the seed field and a payload of c0 alone) is the reference's; the seed -> c1 map is each library's own, so seeded blobs are read
+// by the library that wrote them -- unseeded blobs are interchangeable.
+static Rng seed_stream(u64 a_seed) { return Rng(a_seed, 0, (u64)9 << 32); }
+void expand_seed(const Context &c, u64 a_seed, int limbs, u64 *c1) {
+    Polys P(c);
+    if (!c.is_data_level(limbs)) throw Error(ST_INVALID_ARGUMENT, "parms_id is not valid for encryption parameters");
+    if (!a_seed) throw Error(ST_INVALID_ARGUMENT, "the seed of a seeded ciphertext is not zero");
+    Rng a = seed_stream(a_seed);
+    sample_uniform(P, a, limbs, c1);
+    if (c.scheme != SCHEME_CKKS)
+        for (int l = 0; l < limbs; l++) ntt_inverse(c1 + (size_t)l * c.N, c.tables[l]);
+}
+void encrypt_symmetric_seeded(const Context &c, Rng &rng, u64 a_seed, const u64 *sk, const u64 *plain, size_t n_coeffs, int limbs, u64 *ct) {
+    Polys P(c);
+    const size_t N = c.N;
+    if (!a_seed) throw Error(ST_INVALID_ARGUMENT, "the seed of a seeded ciphertext is not zero");
+    if (plain && c.scheme != SCHEME_CKKS) limbs = c.first_limbs;
+    if (!c.is_data_level(limbs)) throw Error(ST_INVALID_ARGUMENT, plain ? "plain is not valid for encryption parameters" : "parms_id is not valid for encryption parameters");
+    if (plain && c.scheme != SCHEME_CKKS && n_coeffs > c.N) throw Error(ST_INVALID_ARGUMENT, "plain is not valid for encryption parameters");
+    Rng a = seed_stream(a_seed);
+    u64 *c0 = ct, *c1 = ct + (size_t)limbs * N;
+    encrypt_zero_symmetric_ntt(P, rng, sk, limbs, c0, c1, c.scheme == SCHEME_BGV ? c.t : 1, &a);
+    if (c.scheme != SCHEME_CKKS)
+        for (int l = 0; l < limbs; l++) {
+            ntt_inverse(c0 + (size_t)l * N, c.tables[l]);
+            ntt_inverse(c1 + (size_t)l * N, c.tables[l]);
+        }
+    if (plain) add_message(c, P, plain, n_coeffs, limbs, ct);
 }
 
 // decryptor.cpp:115-371.  ct [size][limbs][N]; BFV/BGV: N plaintext coefficients; CKKS: [limbs][N] RNS plaintext (NTT form)

@@ -28,6 +28,10 @@ void encrypt(const Context &c, Rng &rng, const u64 *pk, const u64 *plain, size_t
 void encrypt_symmetric(const Context &c, Rng &rng, const u64 *sk, const u64 *plain, size_t n_coeffs, int limbs, u64 *ct);
 void encrypt_zero(const Context &c, Rng &rng, const u64 *pk, int limbs, u64 *ct);           // [2][limbs][N]: any data level
 void encrypt_zero_symmetric(const Context &c, Rng &rng, const u64 *sk, int limbs, u64 *ct);
+// the seeded form (src/utils/rlwe_cuda.cu:262-330, src/ciphertext_cuda.cu:145-190): c1 is a function of a 64-bit seed alone -- expand_seed writes it in the form
+// the ciphertext stores it (NTT form for CKKS, coefficient form otherwise) -- so a fresh symmetric ciphertext travels as (seed, c0)
+void expand_seed(const Context &c, u64 a_seed, int limbs, u64 *c1);
+void encrypt_symmetric_seeded(const Context &c, Rng &rng, u64 a_seed, const u64 *sk, const u64 *plain, size_t n_coeffs, int limbs, u64 *ct); // plain == nullptr: zero
 void decrypt(const Context &c, const u64 *sk, const u64 *ct, int size, int limbs, bool is_ntt, u64 correction_factor, u64 *out);
 // BatchEncoder (src/batchencoder.cpp:61-190): `count` <= N slot values modulo t <-> the plaintext polynomial [N] (coefficient form)
 void batch_encode(const Context &c, const u64 *values, size_t count, u64 *plain);
