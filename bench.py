@@ -412,6 +412,8 @@ def ntt_roofline(ta, capi, lib, w, reps):
     single = any("ntt1_" in k["name"] or "ntt1s_" in k["name"] for k in kernels)
     roof = {"bound": "hbm", "kernel": (("ntt1_fwd_kernel / ntt1_inv_kernel" if N == 32768 else "ntt1s_fwd_kernel / ntt1s_inv_kernel") + " (single pass: one launch = one limb-transform per row)" if single else
                                       "ntt2_kernel (strided pass + contiguous pass = one limb-transform per row)"),
+            "kernel_note": "the plain transform, standalone, forward / inverse alternating.  Of this pair only the INVERSE kernel runs inside the timed multiply + relinearize step; the "
+                           "step's forward transforms are fused ntt2 passes (tensor, key-switch digit expansion and accumulation): see roofline.in_step for what the step runs",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
             "algorithmic_bytes_per_launch": algo_bytes, "launch_us": round(per_launch_s * 1e6, 2), "limb_transforms_per_launch": rows,
             "launch_batch": B, "launch_batch_cap": "min(batch_per_gpu, 128; 32 above N = 2^15): one lane's key-switch shape, B (L+1) L rows",
@@ -431,7 +433,7 @@ def ntt_roofline(ta, capi, lib, w, reps):
     return roof
 
 
-TRAFFIC_FILE = "r04_traffic_%s.json"  # one file per workload (tools/measure_traffic.sh <workload>)
+TRAFFIC_FILE = "r05_traffic_%s.json"  # one file per workload (tools/measure_traffic.sh <workload>)
 
 
 def load_traffic(workload):
@@ -464,7 +466,7 @@ def ktime_report(capi, lib):
 
 def per_kernel(ta, capi, lib, w):
     """every kernel of ONE step of one lane, by the library's per-launch HIP events; algorithmic bytes (compulsory reads + writes
-    of the stage) where the table below knows the kernel; HBM traffic from profiles/r04_traffic_<workload>.json (rocprofv3 PMC, tools/measure_traffic.sh)"""
+    of the stage) where the table below knows the kernel; HBM traffic from profiles/r05_traffic_<workload>.json (rocprofv3 PMC, tools/measure_traffic.sh)"""
     w.sync_all()
     capi.check(lib, lib.troyhip_ktime_enable(1))
     w.profile_step()
@@ -491,6 +493,29 @@ def per_kernel(ta, capi, lib, w):
             e["traffic"] = int(tr["hbm_bytes"] * w.profile_units / units_measured)
             e["traffic_ratio"] = round(e["traffic"] / ab, 3)
         out.append(e)
+    return out
+
+
+def in_step_roofline(kernels):
+    """the roofline of what the timed step RUNS (round-4 verdict: the standalone launches of `roofline` time the plain transform at the key-switch shape,
+    but the step's forward transforms are fused ntt2 passes -- the tensor pass, the digit-expanding pass, the accumulating pass of the key switch -- and
+    only its inverse transforms are the single-pass kernel).  From `per_kernel` (one lane's step under per-launch HIP events): every transform kernel of
+    the step with its compulsory stage bytes (operands read once, results written once, the key once per launch), the dominant one, and
+    the time-weighted fraction over all of them."""
+    ntt = [k for k in kernels if k["name"].startswith(("ntt1", "ntt2")) and k.get("algorithmic_bytes")]
+    if not ntt:
+        return None
+    total_us = sum(k["us"] for k in kernels) or 1.0
+    ntt.sort(key=lambda k: -k["us"])
+    dom = ntt[0]
+    nbytes, nus = sum(k["algorithmic_bytes"] for k in ntt), sum(k["us"] for k in ntt)
+    out = {"kernel": dom["name"], "us": dom["us"], "algorithmic_bytes": dom["algorithmic_bytes"], "frac": dom["frac"], "share_of_step": round(dom["us"] / total_us, 3),
+           "traffic_ratio": dom.get("traffic_ratio"),
+           "transform_kernels": [{"name": k["name"], "us": k["us"], "frac": k["frac"], "share_of_step": round(k["us"] / total_us, 3), "traffic_ratio": k.get("traffic_ratio")} for k in ntt],
+           "transform_share_of_step": round(nus / total_us, 3),
+           "weighted_frac": round(nbytes / (nus * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4),
+           "note": "fractions of the 8 TB/s HBM peak from the compulsory bytes of each fused stage; the key-switch passes and the tensor pass carry their element-wise work, "
+                   "so their bytes per transform exceed 16 B per coefficient"}
     return out
 
 
@@ -853,6 +878,9 @@ def main():
             roofline = ntt_roofline(ta, capi, lib, w, args.ntt_reps)
         if not args.no_per_kernel and not args.roofline_only:
             roofline["per_kernel"] = per_kernel(ta, capi, lib, w)
+            in_step = in_step_roofline(roofline["per_kernel"])
+            if in_step:
+                roofline["in_step"] = in_step
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

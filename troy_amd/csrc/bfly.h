@@ -43,6 +43,8 @@ __device__ __forceinline__ void mulhi_approx4(u64 (&q)[4], const u64 (&y)[4], co
 __device__ __forceinline__ u64 mul_acc(u64 acc, u64 y, u64 w, u64 q, u64 negp) { return acc + w * y + q * negp; }
 __device__ __forceinline__ void mulhi_approx4_u(u64 (&q)[4], const u64 (&y)[4], const Shoup (&w)[4]) { mulhi_approx4(q, y, w); }
 __device__ __forceinline__ u64 mul_acc_u(u64 acc, u64 y, u64 w, u64 q, u64 negp) { return mul_acc(acc, y, w, q, negp); }
+__device__ __forceinline__ void mulhi_exact4(u64 (&q)[4], const u64 (&y)[4], const Shoup (&w)[4]) { for (int i = 0; i < 4; i++) q[i] = (u64)(((u128)y[i] * w[i].quo) >> 64); }
+__device__ __forceinline__ void mulhi_exact4_u(u64 (&q)[4], const u64 (&y)[4], const Shoup (&w)[4]) { mulhi_exact4(q, y, w); }
 #else
 // x[i] = x[i] >= m ? x[i] - m : x[i]   (x < 2m).  m is wave-uniform; its high word must sit in a VGPR because
 // vcc + an SGPR would exceed the single constant-bus read a gfx9 VALU instruction may make.
@@ -124,6 +126,47 @@ __device__ __forceinline__ void sub4(u64 (&r)[4], const u64 (&a)[4], const u64 (
     }
 TROY_DEF_MULHI_APPROX4(mulhi_approx4, "v")
 TROY_DEF_MULHI_APPROX4(mulhi_approx4_u, "s")
+// q[i] = floor(y*wq/2^64) EXACTLY: the high word of the low x low product rides in on the first multiply-add's 64-bit addend -- one v_mul_hi_u32 more
+// per value than the approximate form.  With the exact Shoup quotient the lazy product w*y - q*p lies in [0,2p) instead of [0,3p): worth it where the
+// result is reduced to the canonical residue right away (the last stage of an inverse transform: one conditional subtraction instead of two).
+#define TROY_DEF_MULHI_EXACT4(NAME, TWC)                                                                                                      \
+    __device__ __forceinline__ void NAME(u64 (&q)[4], const u64 (&y)[4], const Shoup (&w)[4]) {                                               \
+        u64 s0, s1, s2, s3, sb, sc, sd;                                                                                                       \
+        u32 c0, c1, c2, c3;                                                                                                                   \
+        u64 l[4];                                                                                                                             \
+        _Pragma("unroll") for (int i = 0; i < 4; i++) {                                                                                       \
+            u32 h;                                                                                                                            \
+            asm("v_mul_hi_u32 %0, %1, %2" : "=v"(h) : "v"(lo32(y[i])), TWC(lo32(w[i].quo)));                                                  \
+            l[i] = mk64(h, 0);                                                                                                                \
+        }                                                                                                                                     \
+        asm("v_mad_u64_u32 %0, vcc, %12, %13, %27\n\t"                                                                                        \
+            "v_mad_u64_u32 %1, %8, %16, %17, %28\n\t"                                                                                         \
+            "v_mad_u64_u32 %2, %9, %20, %21, %29\n\t"                                                                                         \
+            "v_mad_u64_u32 %3, %10, %24, %25, %30\n\t"                                                                                        \
+            "v_mad_u64_u32 %0, vcc, %11, %14, %0\n\t"                                                                                         \
+            "v_mad_u64_u32 %1, %8, %15, %18, %1\n\t"                                                                                          \
+            "v_mad_u64_u32 %2, %9, %19, %22, %2\n\t"                                                                                          \
+            "v_mad_u64_u32 %3, %10, %23, %26, %3\n\t"                                                                                         \
+            "v_cndmask_b32 %4, 0, 1, vcc\n\t"                                                                                                 \
+            "v_cndmask_b32 %5, 0, 1, %8\n\t"                                                                                                  \
+            "v_cndmask_b32 %6, 0, 1, %9\n\t"                                                                                                  \
+            "v_cndmask_b32 %7, 0, 1, %10"                                                                                                     \
+            : "=&v"(s0), "=&v"(s1), "=&v"(s2), "=&v"(s3), "=&v"(c0), "=&v"(c1), "=&v"(c2), "=&v"(c3), "=&s"(sb), "=&s"(sc), "=&s"(sd)         \
+            : "v"(lo32(y[0])), "v"(hi32(y[0])), TWC(lo32(w[0].quo)), TWC(hi32(w[0].quo)), "v"(lo32(y[1])), "v"(hi32(y[1])), TWC(lo32(w[1].quo)), \
+              TWC(hi32(w[1].quo)), "v"(lo32(y[2])), "v"(hi32(y[2])), TWC(lo32(w[2].quo)), TWC(hi32(w[2].quo)), "v"(lo32(y[3])), "v"(hi32(y[3])), \
+              TWC(lo32(w[3].quo)), TWC(hi32(w[3].quo)), "v"(l[0]), "v"(l[1]), "v"(l[2]), "v"(l[3])                                            \
+            : "vcc");                                                                                                                         \
+        const u64 s[4] = {s0, s1, s2, s3};                                                                                                    \
+        const u32 c[4] = {c0, c1, c2, c3};                                                                                                    \
+        _Pragma("unroll") for (int i = 0; i < 4; i++) {                                                                                       \
+            const u64 hs = mk64(hi32(s[i]), c[i]);                                                                                            \
+            u64 d, sink;                                                                                                                      \
+            asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(sink) : "v"(hi32(y[i])), TWC(hi32(w[i].quo)), "v"(hs));                    \
+            q[i] = d;                                                                                                                         \
+        }                                                                                                                                     \
+    }
+TROY_DEF_MULHI_EXACT4(mulhi_exact4, "v")
+TROY_DEF_MULHI_EXACT4(mulhi_exact4_u, "s")
 // acc + w*y + q*negp (mod 2^64); no carry chains -> no hazards, one butterfly per block
 #define TROY_DEF_MUL_ACC(NAME, TWC)                                                                                                           \
     __device__ __forceinline__ u64 NAME(u64 acc, u64 y, u64 w, u64 q, u64 negp) {                                                             \
@@ -231,6 +274,34 @@ template <bool UNI = false> __device__ __forceinline__ void gs_bfly4_last_ng(u64
 #pragma unroll
     for (int i = 0; i < 4; i++) Y[i] = UNI ? mul_acc_u(0, d[i], w_scaled[i].op, q[i], c.negp) : mul_acc(0, d[i], w_scaled[i].op, q[i], c.negp);
 }
+// the same two with one kp PER butterfly (the caller tracks a bound per register: inv_stages_lean, ntt1.hip).  EXACT: the two multiplications of the
+// last stage use the exact quotient, outputs in [0,2p)
+template <bool UNI = false> __device__ __forceinline__ void gs_bfly4_ng_k(u64 (&X)[4], u64 (&Y)[4], const Shoup (&w)[4], const u64 (&kp)[4], const PrimeConst &c) {
+    u64 t[4], d[4], q[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) t[i] = X[i] + kp[i];
+    sub4(d, t, Y);
+#pragma unroll
+    for (int i = 0; i < 4; i++) X[i] = X[i] + Y[i];
+    if (UNI) mulhi_approx4_u(q, d, w); else mulhi_approx4(q, d, w);
+#pragma unroll
+    for (int i = 0; i < 4; i++) Y[i] = UNI ? mul_acc_u(0, d[i], w[i].op, q[i], c.negp) : mul_acc(0, d[i], w[i].op, q[i], c.negp);
+}
+template <bool UNI = false, bool EXACT = false> __device__ __forceinline__ void gs_bfly4_last_ng_k(u64 (&X)[4], u64 (&Y)[4], const Shoup (&w_scaled)[4], const Shoup inv_n, const u64 (&kp)[4], const PrimeConst &c) {
+    u64 s[4], t[4], d[4], q[4];
+    const Shoup wn[4] = {inv_n, inv_n, inv_n, inv_n};
+#pragma unroll
+    for (int i = 0; i < 4; i++) { s[i] = X[i] + Y[i]; t[i] = X[i] + kp[i]; }
+    sub4(d, t, Y);
+    if (EXACT) { if (UNI) mulhi_exact4_u(q, s, wn); else mulhi_exact4(q, s, wn); }
+    else { if (UNI) mulhi_approx4_u(q, s, wn); else mulhi_approx4(q, s, wn); }
+#pragma unroll
+    for (int i = 0; i < 4; i++) X[i] = UNI ? mul_acc_u(0, s[i], inv_n.op, q[i], c.negp) : mul_acc(0, s[i], inv_n.op, q[i], c.negp);
+    if (EXACT) { if (UNI) mulhi_exact4_u(q, d, w_scaled); else mulhi_exact4(q, d, w_scaled); }
+    else { if (UNI) mulhi_approx4_u(q, d, w_scaled); else mulhi_approx4(q, d, w_scaled); }
+#pragma unroll
+    for (int i = 0; i < 4; i++) Y[i] = UNI ? mul_acc_u(0, d[i], w_scaled[i].op, q[i], c.negp) : mul_acc(0, d[i], w_scaled[i].op, q[i], c.negp);
+}
 // any x < 2^64 -> the same residue in [0, 4p), for p >= 2^33: q = floor(hi32(x) * floor(2^64/p) / 2^32) is at most 2.5 below x / p
 // (never above).  4 instructions per value -- the price of dropping the range guard from several inverse stages in a row.
 __device__ __forceinline__ void lite_reduce4(u64 (&x)[4], u32 mu, const PrimeConst &c) {
@@ -239,6 +310,10 @@ __device__ __forceinline__ void lite_reduce4(u64 (&x)[4], u32 mu, const PrimeCon
         const u32 q = (u32)(((u64)hi32(x[i]) * mu) >> 32);
         x[i] += (u64)q * c.negp;
     }
+}
+__device__ __forceinline__ void lite_reduce1(u64 &x, u32 mu, const PrimeConst &c) {
+    const u32 q = (u32)(((u64)hi32(x) * mu) >> 32);
+    x += (u64)q * c.negp;
 }
 // end of a guard-free forward transform: x < 64p (46p after 15 stages, 59p in the two-pass form), p in [2^33, 2^58) -> canonical.
 // q = floor((x >> sh) * mu / 2^32) with sh = bitlen(p) - 26, mu = floor(2^(sh+32) / p) = floor(2^64 / p) >> (58 - bitlen(p)) is at most

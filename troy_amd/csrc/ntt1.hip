@@ -265,6 +265,59 @@ template <int G, int R, bool LAST, bool UNI, int B0 = 0, class TW> __device__ __
     }
 }
 
+// ---- the same R inverse stages for lean primes ([2^33, 2^58): 64p < 2^64) with a bound tracked PER REGISTER at compile time (round 5).  A sum output
+// carries bound(X) + bound(Y), a difference output leaves its multiplication below 3p -- so after a few stages only the registers that were a sum
+// several times in a row are large: 1 in 2^k after k stages.  inv_stages (above) tracks ONE bound per stage and therefore reduces every value before a
+// round (lite_reduce4 on all 16 / 32 registers) and halves every sum of a critical stage (csub4); here a register is reduced (lite_reduce1: any 64-bit
+// value -> below 4p, 4 instructions) only when ITS butterfly could leave 64 bits (bound(X) + bound(Y) > 64), and at the end of the round only the
+// registers above EXIT, which is the entry bound E of the next round (its values arrive through LDS from other lanes: every register may hold the
+// largest).  Per thread-row of the N = 2^15 transform: 26 reductions instead of 48 + 32 conditional subtractions (bounds: tools/inv_bounds.py).
+// All loops unroll completely, so bd[] folds to constants and the tests below cost nothing at run time.
+// EXACT (with LAST): exact quotients in the last stage, outputs below 2p.
+template <int G, int R, bool LAST, bool UNI, int E, int EXIT, bool EXACT = false, class TW>
+__device__ __forceinline__ void inv_stages_lean(u64 (&y)[G << R], const TW &tw, const Shoup inv_n, const u32 mu, const PrimeConst &pc) {
+    int bd[G << R];
+#pragma unroll
+    for (int i = 0; i < (G << R); i++) bd[i] = E;
+#pragma unroll
+    for (int st = 0; st < R; st++) {
+        const int dist = 1 << st;
+#pragma unroll
+        for (int c = 0; c < (G << (R - 1)) / 4; c++) {
+            u64 X[4], Y[4], kp[4];
+            Shoup w[4];
+            int ix[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const int b = 4 * c + i, g = b >> (R - 1), r = b & ((1 << (R - 1)) - 1);
+                const int blk = r / dist, k = r % dist;
+                ix[i] = (g << R) + blk * 2 * dist + k;
+                if (bd[ix[i]] + bd[ix[i] + dist] > 64) { // X + Y and X + kp - Y must stay below 2^64
+                    if (bd[ix[i]] > 4) { lite_reduce1(y[ix[i]], mu, pc); bd[ix[i]] = 4; }
+                    if (bd[ix[i] + dist] > 4) { lite_reduce1(y[ix[i] + dist], mu, pc); bd[ix[i] + dist] = 4; }
+                }
+                X[i] = y[ix[i]];
+                Y[i] = y[ix[i] + dist];
+                kp[i] = pc.p * (u64)bd[ix[i] + dist];
+                w[i] = tw(st, g, blk);
+            }
+            if (LAST && st == R - 1) gs_bfly4_last_ng_k<UNI, EXACT>(X, Y, w, inv_n, kp, pc);
+            else gs_bfly4_ng_k<UNI>(X, Y, w, kp, pc);
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                y[ix[i]] = X[i];
+                y[ix[i] + dist] = Y[i];
+                bd[ix[i]] = (LAST && st == R - 1) ? 3 : bd[ix[i]] + bd[ix[i] + dist];
+                bd[ix[i] + dist] = 3;
+            }
+            N1_SCHED_FENCE();
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < (G << R); i++)
+        if (bd[i] > EXIT) lite_reduce1(y[i], mu, pc);
+}
+
 // ---- FP64 forms (fpmod.h; primes in [2^33, 2^50)): y holds the bit patterns of doubles (exact integers, signed lazy range), tw the pairs
 // (w, w / p) of PrimeDesc::root_fp / iroot_fp.  Eight instructions per butterfly; the bound walk (where to reduce) is the host's.
 template <int G, int R, bool PINV = false, int FENCE = 4, class TW> __device__ __forceinline__ void fp_fwd_stages(u64 (&y)[G << R], const TW &tw, const FpPrime &fc) {
@@ -670,8 +723,10 @@ template <int LOGN, bool LEAN, bool FP> __device__ __forceinline__ void inv_subb
         for (int i = 0; i < 2; i++) t13[i] = FP ? ld_tw8(pd.iroot, NN / 2 + 1 + 2 * b12 + i) : ld_tw(pd.iroot, NN / 2 + 1 + 2 * b12 + i);
         const Shoup t12 = FP ? ld_tw8(pd.iroot, NN - NN / 4 + 1 + b12) : ld_tw(pd.iroot, NN - NN / 4 + 1 + b12);
         if constexpr (FP) fp_inv_stages<1, 3, false, 0, 3, true>(y, [&](int st, int, int blk) { return st == 0 ? t14[blk] : (st == 1 ? t13[blk] : t12); }, none, fc);
+        else if constexpr (LEAN) // inputs below 2p (stored limbs are canonical) -> 16p at most (register 0), no reduction
+        inv_stages_lean<1, 3, false, false, 2, 64>(y, [&](int st, int, int blk) { return st == 0 ? t14[blk] : (st == 1 ? t13[blk] : t12); }, none, (u32)pd.cr1, pc);
         else
-        inv_stages<1, 3, false, false, LEAN ? 2 : 0>(y, [&](int st, int, int blk) { return st == 0 ? t14[blk] : (st == 1 ? t13[blk] : t12); }, none, pc); // inputs below 2p (stored limbs are canonical) -> 16p
+        inv_stages<1, 3, false, false, 0>(y, [&](int st, int, int blk) { return st == 0 ? t14[blk] : (st == 1 ? t13[blk] : t12); }, none, pc);
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             ulonglong2 v;
@@ -699,8 +754,10 @@ template <int LOGN, bool LEAN, bool FP> __device__ __forceinline__ void inv_subb
             if constexpr (FP) {
                 if (fp_mask & 2u) fp_reduce_all<8>(y, fc);
                 fp_inv_stages<1, 3, false, 0, 3, true>(y, [&](int st, int, int blk) { return st == 0 ? t11[blk] : (st == 1 ? t10[blk] : t9); }, none, fc);
-            } else
-            inv_stages<1, 3, false, false, LEAN ? 16 : 0>(y, [&](int st, int, int blk) { return st == 0 ? t11[blk] : (st == 1 ? t10[blk] : t9); }, none, pc); // 16p -> 32p -> (halved) 32p -> 64p
+            } else if constexpr (LEAN) // 16p in; registers 0 and 4 are reduced before the third stage, register 1 on the way out: 8p out
+            inv_stages_lean<1, 3, false, false, 16, 8>(y, [&](int st, int, int blk) { return st == 0 ? t11[blk] : (st == 1 ? t10[blk] : t9); }, none, (u32)pd.cr1, pc);
+            else
+            inv_stages<1, 3, false, false, 0>(y, [&](int st, int, int blk) { return st == 0 ? t11[blk] : (st == 1 ? t10[blk] : t9); }, none, pc);
 #pragma unroll
             for (int r = 0; r < 8; r++) R[sw2(64 * h + 8 * r + 4 * it + low)] = y[r];
         }
@@ -710,20 +767,13 @@ template <int LOGN, bool LEAN, bool FP> __device__ __forceinline__ void inv_subb
         u64 y[16];
 #pragma unroll
         for (int r = 0; r < 16; r++) y[r] = R[sw2(64 * r + lane)];
-        if (LEAN && !FP) { // 64p -> 4p, then four stages -> 64p
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                u64 v[4] = {y[4 * q], y[4 * q + 1], y[4 * q + 2], y[4 * q + 3]};
-                lite_reduce4(v, (u32)pd.cr1, pc);
-#pragma unroll
-                for (int i = 0; i < 4; i++) y[4 * q + i] = v[i];
-            }
-        }
         if constexpr (FP) {
             if (fp_mask & 4u) fp_reduce_all<16>(y, fc);
             fp_inv_stages<1, 4, false, 0, 4>(y, [&](int st, int, int blk) { return ld_tw_uniform(pd.iroot + (NN - ((NN >> 6) >> st) + 1) + ((8 * sb) >> st) + blk); }, none, fc);
-        } else
-        inv_stages<1, 4, false, true, LEAN ? 4 : 0>(y, [&](int st, int, int blk) { return ld_tw_uniform(pd.iroot + (NN - ((NN >> 6) >> st) + 1) + ((8 * sb) >> st) + blk); }, none, pc);
+        } else if constexpr (LEAN) // 8p in, four registers reduced before the third stage, register 1 on the way out: 8p out
+        inv_stages_lean<1, 4, false, true, 8, 8>(y, [&](int st, int, int blk) { return ld_tw_uniform(pd.iroot + (NN - ((NN >> 6) >> st) + 1) + ((8 * sb) >> st) + blk); }, none, (u32)pd.cr1, pc);
+        else
+        inv_stages<1, 4, false, true, 0>(y, [&](int st, int, int blk) { return ld_tw_uniform(pd.iroot + (NN - ((NN >> 6) >> st) + 1) + ((8 * sb) >> st) + blk); }, none, pc);
 #pragma unroll
         for (int r = 0; r < 16; r++) R[sw2(64 * r + lane)] = y[r];
     }
@@ -802,15 +852,6 @@ template <bool LEAN, bool MD, bool FP> __device__ __forceinline__ void ntt1_inv_
         }
         if (mm + 1 < m_end) stage_issue(in_of(mm + 1) + 1024 * wv); // the regions are free during round A'
         // round A': stages 4..0 across the 32 sub-blocks, N^-1 folded into the last one
-        if (LEAN && !FP) { // 64p -> 4p; the five stages reach 32p after three, the fourth halves its sums, the last one multiplies everything by N^-1
-#pragma unroll
-            for (int q = 0; q < 8; q++) {
-                u64 v[4] = {x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]};
-                lite_reduce4(v, (u32)pd.cr1, pc);
-#pragma unroll
-                for (int i = 0; i < 4; i++) x[4 * q + i] = v[i];
-            }
-        }
         auto twA = [&](int st, int, int blk) { return st == 4 ? pd.iroot_last_scaled : ld_tw_uniform((pd.iroot + (N1_N - (32u >> st) + 1) + blk)); };
         if constexpr (FP) {
             if (a.fp_red_mask & 8u) fp_reduce_all<32>(x, fc);
@@ -819,8 +860,21 @@ template <bool LEAN, bool MD, bool FP> __device__ __forceinline__ void ntt1_inv_
             fp_inv_stages<1, 5, true, 4, 5>(x, twA, pd.inv_n, fc);
 #pragma unroll
             for (int i = 0; i < 32; i++) x[i] = fp_canonical(fp_of_bits(x[i]), fc, pd.p);
+        } else if constexpr (LEAN) {
+            // 8p in (the sub-block rounds' exit bound); four of the 32 registers are reduced on the way.  Plain stores: exact quotients in the last
+            // stage leave [0,2p) and ONE conditional subtraction makes the residue canonical; the mod-down epilogue takes the lazy [0,3p) as it is
+            inv_stages_lean<1, 5, true, true, 8, 64, !MD>(x, twA, pd.inv_n, (u32)pd.cr1, pc);
+            if (!MD) {
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    u64 v[4] = {x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]};
+                    csub4(v, pc.p);
+#pragma unroll
+                    for (int i = 0; i < 4; i++) x[4 * q + i] = v[i];
+                }
+            }
         } else {
-        inv_stages<1, 5, true, true, LEAN ? 4 : 0>(x, twA, pd.inv_n, pc);
+        inv_stages<1, 5, true, true, 0>(x, twA, pd.inv_n, pc);
 #pragma unroll
         for (int q = 0; q < 8; q++) {
             u64 v[4] = {x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]};
@@ -829,7 +883,7 @@ template <bool LEAN, bool MD, bool FP> __device__ __forceinline__ void ntt1_inv_
             for (int i = 0; i < 4; i++) x[4 * q + i] = v[i];
         }
         }
-        if (MD) { // x = acc qk^-1 mod p (canonical): add the special limb's share and accumulate into the ciphertext (inner == 1 here)
+        if (MD) { // x = acc qk^-1 mod p (lean primes: lazily below 3p, else canonical): add the special limb's share and accumulate into the ciphertext (inner == 1 here)
             const unsigned t = opaque(tid);
             const Mod m = mod_of(pd);
             const u64 bias = pd.p * 4 + barrett64(a.md_half, m);         // [half]_p + 4p: keeps the difference below positive
@@ -852,7 +906,7 @@ template <bool LEAN, bool MD, bool FP> __device__ __forceinline__ void ntt1_inv_
                 for (int i = 0; i < 4; i++) tl[i] = bias - tl[i];         // [half]_p - [t']_p + 4p, in (0, 5p)
                 mulhi_approx4_u(q, tl, iq);
 #pragma unroll
-                for (int i = 0; i < 4; i++) c[i] += mul_acc_u(x[4 * g + i], tl[i], pd.aux.op, q[i], pc.negp); // + acc qk^-1 + (..) qk^-1: below 5p
+                for (int i = 0; i < 4; i++) c[i] += mul_acc_u(x[4 * g + i], tl[i], pd.aux.op, q[i], pc.negp); // + acc qk^-1 (< 3p) + (..) qk^-1 (< 3p): below 7p
                 csub4(c, pc.four_p);
                 csub4(c, pc.two_p);
                 csub4(c, pc.p);
@@ -987,15 +1041,6 @@ template <int LOGN, bool LEAN, bool MD, bool FP> __device__ __forceinline__ void
                 for (int h = 0; h < NSUB; h++) x[(g << LOGA) + h] = lds[1024 * h + sw2(t + T * g)];
         }
         if (mm + 1 < m_end) load16(a.data + row_of(mm + 1) + 1024 * wv); // the next row's sub-block input, in flight under round A'
-        if (LEAN && !FP) { // 64p -> 4p (the sub-block rounds leave 64p at most), as in the N = 2^15 form
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                u64 v[4] = {x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]};
-                lite_reduce4(v, (u32)pd.cr1, pc);
-#pragma unroll
-                for (int i = 0; i < 4; i++) x[4 * q + i] = v[i];
-            }
-        }
         auto twA = [&](int st, int, int blk) { return st == LOGA - 1 ? pd.iroot_last_scaled : ld_tw_uniform((pd.iroot + (NN - ((unsigned)NSUB >> st) + 1) + blk)); };
         if constexpr (FP) {
             if (a.fp_red_mask & 8u) fp_reduce_all<16>(x, fc);
@@ -1004,8 +1049,19 @@ template <int LOGN, bool LEAN, bool MD, bool FP> __device__ __forceinline__ void
             fp_inv_stages<G, LOGA, true, LOGA - 1, LOGA>(x, twA, pd.inv_n, fc);
 #pragma unroll
             for (int i = 0; i < 16; i++) x[i] = fp_canonical(fp_of_bits(x[i]), fc, pd.p);
+        } else if constexpr (LEAN) { // as in the N = 2^15 form: 8p in, per-register bounds, exact last quotients for plain stores
+            inv_stages_lean<G, LOGA, true, true, 8, 64, !MD>(x, twA, pd.inv_n, (u32)pd.cr1, pc);
+            if (!MD) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    u64 v[4] = {x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]};
+                    csub4(v, pc.p);
+#pragma unroll
+                    for (int i = 0; i < 4; i++) x[4 * q + i] = v[i];
+                }
+            }
         } else {
-            inv_stages<G, LOGA, true, true, LEAN ? 4 : 0>(x, twA, pd.inv_n, pc);
+            inv_stages<G, LOGA, true, true, 0>(x, twA, pd.inv_n, pc);
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 u64 v[4] = {x[4 * q], x[4 * q + 1], x[4 * q + 2], x[4 * q + 3]};
