@@ -194,7 +194,20 @@ class Workload:
             for i in range(S):
                 (mul if i & 1 else relin)(i)
 
+        in_phase = os.environ.get("BENCH_LANE_PHASE") == "same"  # A/B of profiles/r05_overlap.txt: every lane multiplies, then every lane relinearizes
+
+        def step_same():
+            for i in range(S):
+                mul(i)
+            for i in range(S):
+                relin(i)
+
+        if in_phase:
+            step = step_same
+
         def prime():
+            if in_phase:
+                return
             for i in range(1, S, 2):
                 mul(i)  # the out-of-phase lanes start with a product to relinearize (untimed)
 

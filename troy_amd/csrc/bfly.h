@@ -43,6 +43,8 @@ __device__ __forceinline__ void mulhi_approx4(u64 (&q)[4], const u64 (&y)[4], co
 __device__ __forceinline__ u64 mul_acc(u64 acc, u64 y, u64 w, u64 q, u64 negp) { return acc + w * y + q * negp; }
 __device__ __forceinline__ void mulhi_approx4_u(u64 (&q)[4], const u64 (&y)[4], const Shoup (&w)[4]) { mulhi_approx4(q, y, w); }
 __device__ __forceinline__ u64 mul_acc_u(u64 acc, u64 y, u64 w, u64 q, u64 negp) { return mul_acc(acc, y, w, q, negp); }
+__device__ __forceinline__ u64 mul_acc0(u64 y, u64 w, u64 q, u64 negp) { return mul_acc(0, y, w, q, negp); }
+__device__ __forceinline__ u64 mul_acc0_u(u64 y, u64 w, u64 q, u64 negp) { return mul_acc(0, y, w, q, negp); }
 __device__ __forceinline__ void mulhi_exact4(u64 (&q)[4], const u64 (&y)[4], const Shoup (&w)[4]) { for (int i = 0; i < 4; i++) q[i] = (u64)(((u128)y[i] * w[i].quo) >> 64); }
 __device__ __forceinline__ void mulhi_exact4_u(u64 (&q)[4], const u64 (&y)[4], const Shoup (&w)[4]) { mulhi_exact4(q, y, w); }
 #else
@@ -94,6 +96,9 @@ __device__ __forceinline__ void sub4(u64 (&r)[4], const u64 (&a)[4], const u64 (
 // q~[i] = y1*q1 + floor((y1*q0 + y0*q1) / 2^32)  =  floor(y*wq/2^64) - {0,1}
 // TWC = "v": per-lane twiddles in VGPRs; TWC = "s": wave-uniform twiddles read straight from SGPRs (one scalar operand per
 // instruction, as the gfx9 constant bus allows) -- no v_mov copies and no VGPRs for them
+// (Round 5, measured and dropped: the pair (hi32(s), carry) the last multiply-add takes costs a v_mov per butterfly -- the compiler cannot place the carry
+// next to hi32(s) because gfx90a-class VGPR tuples must be even-aligned and hi32(s) is the ODD half of its own pair; the same rule rejects a hand-written
+// block with fixed scratch registers ("vgpr tuples must be 64 bit aligned").  Every alternative that avoids the pair costs at least one instruction more.)
 #define TROY_DEF_MULHI_APPROX4(NAME, TWC)                                                                                                     \
     __device__ __forceinline__ void NAME(u64 (&q)[4], const u64 (&y)[4], const Shoup (&w)[4]) {                                               \
         u64 s0, s1, s2, s3, sb, sc, sd;                                                                                                       \
@@ -186,6 +191,25 @@ TROY_DEF_MULHI_EXACT4(mulhi_exact4_u, "s")
     }
 TROY_DEF_MUL_ACC(mul_acc, "v")
 TROY_DEF_MUL_ACC(mul_acc_u, "s")
+// the same with acc = 0 (every inverse butterfly): the zero is the instruction's inline constant, not a register pair the compiler has to keep or re-make
+#define TROY_DEF_MUL_ACC0(NAME, TWC)                                                                                                          \
+    __device__ __forceinline__ u64 NAME(u64 y, u64 w, u64 q, u64 negp) {                                                                      \
+        const u32 y0 = lo32(y), y1 = hi32(y), w0 = lo32(w), w1 = hi32(w), d0 = lo32(q), d1 = hi32(q);                                         \
+        u64 a, r, sc0, sc1;                                                                                                                   \
+        u32 m0, m1, m2, m3, c0, h;                                                                                                            \
+        asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(a), "=s"(sc0) : TWC(w0), "v"(y0));                                                       \
+        asm("v_mul_lo_u32 %0, %1, %2" : "=v"(m0) : TWC(w0), "v"(y1));                                                                         \
+        asm("v_mul_lo_u32 %0, %1, %2" : "=v"(m1) : TWC(w1), "v"(y0));                                                                         \
+        asm("v_mul_lo_u32 %0, %1, %2" : "=v"(m2) : "v"(d0), "s"(hi32(negp)));                                                                 \
+        asm("v_mul_lo_u32 %0, %1, %2" : "=v"(m3) : "v"(d1), "s"(lo32(negp)));                                                                 \
+        asm("v_add3_u32 %0, %1, %2, %3" : "=v"(c0) : "v"(m0), "v"(m1), "v"(m2));                                                              \
+        asm("v_add3_u32 %0, %1, %2, %3" : "=v"(h) : "v"(hi32(a)), "v"(c0), "v"(m3));                                                          \
+        const u64 a2 = mk64(lo32(a), h);                                                                                                      \
+        asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(r), "=s"(sc1) : "v"(d0), "s"(lo32(negp)), "v"(a2));                                     \
+        return r;                                                                                                                             \
+    }
+TROY_DEF_MUL_ACC0(mul_acc0, "v")
+TROY_DEF_MUL_ACC0(mul_acc0_u, "s")
 #endif
 
 // Four forward butterflies (Cooley-Tukey, src/utils/dwthandler.h:88-204): X,Y in [0,8p) -> [0,8p)
@@ -212,7 +236,7 @@ template <bool UNI = false> __device__ __forceinline__ void gs_bfly4(u64 (&X)[4]
     csub4(s, c.four_p);
     if (UNI) mulhi_approx4_u(q, d, w); else mulhi_approx4(q, d, w);
 #pragma unroll
-    for (int i = 0; i < 4; i++) { X[i] = s[i]; Y[i] = UNI ? mul_acc_u(0, d[i], w[i].op, q[i], c.negp) : mul_acc(0, d[i], w[i].op, q[i], c.negp); }
+    for (int i = 0; i < 4; i++) { X[i] = s[i]; Y[i] = UNI ? mul_acc0_u(d[i], w[i].op, q[i], c.negp) : mul_acc0(d[i], w[i].op, q[i], c.negp); }
 }
 // last inverse stage with N^-1 folded in (dwthandler.h:289-330): -> [0,3p)
 template <bool UNI = false> __device__ __forceinline__ void gs_bfly4_last(u64 (&X)[4], u64 (&Y)[4], const Shoup (&w_scaled)[4], const Shoup inv_n, const PrimeConst &c) {
@@ -224,10 +248,10 @@ template <bool UNI = false> __device__ __forceinline__ void gs_bfly4_last(u64 (&
     csub4(s, c.four_p);
     if (UNI) mulhi_approx4_u(q, s, wn); else mulhi_approx4(q, s, wn);
 #pragma unroll
-    for (int i = 0; i < 4; i++) X[i] = UNI ? mul_acc_u(0, s[i], inv_n.op, q[i], c.negp) : mul_acc(0, s[i], inv_n.op, q[i], c.negp);
+    for (int i = 0; i < 4; i++) X[i] = UNI ? mul_acc0_u(s[i], inv_n.op, q[i], c.negp) : mul_acc0(s[i], inv_n.op, q[i], c.negp);
     if (UNI) mulhi_approx4_u(q, d, w_scaled); else mulhi_approx4(q, d, w_scaled);
 #pragma unroll
-    for (int i = 0; i < 4; i++) Y[i] = UNI ? mul_acc_u(0, d[i], w_scaled[i].op, q[i], c.negp) : mul_acc(0, d[i], w_scaled[i].op, q[i], c.negp);
+    for (int i = 0; i < 4; i++) Y[i] = UNI ? mul_acc0_u(d[i], w_scaled[i].op, q[i], c.negp) : mul_acc0(d[i], w_scaled[i].op, q[i], c.negp);
 }
 // ---- guard-free ("lean") butterflies: no conditional subtraction at all; the CALLER tracks the value bound (in units of p) per
 // stage and inserts a reduction (barrett_lite4) only where the next stage could leave 64 bits.  For the primes the
@@ -257,7 +281,7 @@ template <bool UNI = false> __device__ __forceinline__ void gs_bfly4_ng(u64 (&X)
     for (int i = 0; i < 4; i++) X[i] = X[i] + Y[i];
     if (UNI) mulhi_approx4_u(q, d, w); else mulhi_approx4(q, d, w);
 #pragma unroll
-    for (int i = 0; i < 4; i++) Y[i] = UNI ? mul_acc_u(0, d[i], w[i].op, q[i], c.negp) : mul_acc(0, d[i], w[i].op, q[i], c.negp);
+    for (int i = 0; i < 4; i++) Y[i] = UNI ? mul_acc0_u(d[i], w[i].op, q[i], c.negp) : mul_acc0(d[i], w[i].op, q[i], c.negp);
 }
 // last inverse stage, guard-free: bound(X), bound(Y) <= kp / p and bound(X) + bound(Y) < 2^64 / p; both outputs come out of a
 // multiplication (by N^-1, by the pre-scaled twiddle), i.e. in [0,3p) whatever the inputs were
@@ -269,10 +293,10 @@ template <bool UNI = false> __device__ __forceinline__ void gs_bfly4_last_ng(u64
     sub4(d, t, Y);
     if (UNI) mulhi_approx4_u(q, s, wn); else mulhi_approx4(q, s, wn);
 #pragma unroll
-    for (int i = 0; i < 4; i++) X[i] = UNI ? mul_acc_u(0, s[i], inv_n.op, q[i], c.negp) : mul_acc(0, s[i], inv_n.op, q[i], c.negp);
+    for (int i = 0; i < 4; i++) X[i] = UNI ? mul_acc0_u(s[i], inv_n.op, q[i], c.negp) : mul_acc0(s[i], inv_n.op, q[i], c.negp);
     if (UNI) mulhi_approx4_u(q, d, w_scaled); else mulhi_approx4(q, d, w_scaled);
 #pragma unroll
-    for (int i = 0; i < 4; i++) Y[i] = UNI ? mul_acc_u(0, d[i], w_scaled[i].op, q[i], c.negp) : mul_acc(0, d[i], w_scaled[i].op, q[i], c.negp);
+    for (int i = 0; i < 4; i++) Y[i] = UNI ? mul_acc0_u(d[i], w_scaled[i].op, q[i], c.negp) : mul_acc0(d[i], w_scaled[i].op, q[i], c.negp);
 }
 // the same two with one kp PER butterfly (the caller tracks a bound per register: inv_stages_lean, ntt1.hip).  EXACT: the two multiplications of the
 // last stage use the exact quotient, outputs in [0,2p)
@@ -285,7 +309,7 @@ template <bool UNI = false> __device__ __forceinline__ void gs_bfly4_ng_k(u64 (&
     for (int i = 0; i < 4; i++) X[i] = X[i] + Y[i];
     if (UNI) mulhi_approx4_u(q, d, w); else mulhi_approx4(q, d, w);
 #pragma unroll
-    for (int i = 0; i < 4; i++) Y[i] = UNI ? mul_acc_u(0, d[i], w[i].op, q[i], c.negp) : mul_acc(0, d[i], w[i].op, q[i], c.negp);
+    for (int i = 0; i < 4; i++) Y[i] = UNI ? mul_acc0_u(d[i], w[i].op, q[i], c.negp) : mul_acc0(d[i], w[i].op, q[i], c.negp);
 }
 template <bool UNI = false, bool EXACT = false> __device__ __forceinline__ void gs_bfly4_last_ng_k(u64 (&X)[4], u64 (&Y)[4], const Shoup (&w_scaled)[4], const Shoup inv_n, const u64 (&kp)[4], const PrimeConst &c) {
     u64 s[4], t[4], d[4], q[4];
@@ -296,11 +320,11 @@ template <bool UNI = false, bool EXACT = false> __device__ __forceinline__ void 
     if (EXACT) { if (UNI) mulhi_exact4_u(q, s, wn); else mulhi_exact4(q, s, wn); }
     else { if (UNI) mulhi_approx4_u(q, s, wn); else mulhi_approx4(q, s, wn); }
 #pragma unroll
-    for (int i = 0; i < 4; i++) X[i] = UNI ? mul_acc_u(0, s[i], inv_n.op, q[i], c.negp) : mul_acc(0, s[i], inv_n.op, q[i], c.negp);
+    for (int i = 0; i < 4; i++) X[i] = UNI ? mul_acc0_u(s[i], inv_n.op, q[i], c.negp) : mul_acc0(s[i], inv_n.op, q[i], c.negp);
     if (EXACT) { if (UNI) mulhi_exact4_u(q, d, w_scaled); else mulhi_exact4(q, d, w_scaled); }
     else { if (UNI) mulhi_approx4_u(q, d, w_scaled); else mulhi_approx4(q, d, w_scaled); }
 #pragma unroll
-    for (int i = 0; i < 4; i++) Y[i] = UNI ? mul_acc_u(0, d[i], w_scaled[i].op, q[i], c.negp) : mul_acc(0, d[i], w_scaled[i].op, q[i], c.negp);
+    for (int i = 0; i < 4; i++) Y[i] = UNI ? mul_acc0_u(d[i], w_scaled[i].op, q[i], c.negp) : mul_acc0(d[i], w_scaled[i].op, q[i], c.negp);
 }
 // any x < 2^64 -> the same residue in [0, 4p), for p >= 2^33: q = floor(hi32(x) * floor(2^64/p) / 2^32) is at most 2.5 below x / p
 // (never above).  4 instructions per value -- the price of dropping the range guard from several inverse stages in a row.

@@ -119,6 +119,8 @@ __device__ __forceinline__ unsigned sw2_inv(unsigned x) { // bits 5.. are untouc
     return y ^ (((y >> 4) & 1u) << 2);
 }
 
+__device__ __forceinline__ u64 *lds_at(u64 *lds_base, unsigned byte_off) { return reinterpret_cast<u64 *>(reinterpret_cast<char *>(lds_base) + byte_off); }
+
 // twiddle loads.  The table pointers come out of a PrimeDesc that was itself loaded from memory, so the compiler would use flat
 // loads; the tables are read-only global memory: per-lane entries go through global loads, workgroup-/wave-uniform entries
 // through the scalar cache (constant address space), 16 bytes each
@@ -366,25 +368,28 @@ template <int NV> __device__ __forceinline__ void fp_reduce_all(u64 (&y)[NV], co
 // result canonical to `out` (the sub-block's 1024 coefficients in HBM)
 // LOGN: the transform's size; the sub-block rounds are its stages LOGN - 10 .. LOGN - 1 (N = 2^15: 5 .. 14 as the comments say; the smaller sizes of
 // ntt1s_*_body shift every stage number down, the code is the same: a sub-block is 1024 coefficients at every size)
-template <int LOGN, bool LEAN, bool CR, bool FP> __device__ __forceinline__ void fwd_subblock(u64 *R, const unsigned sb, const unsigned lane_in, const PrimeDesc &pd, const PrimeConst &pc, const Mod &m,
+// LDS addresses: one per-lane byte offset per round, a literal XOR per access (sw1 and sw2 are linear over GF(2): see inv_subblock)
+template <int LOGN, bool LEAN, bool CR, bool FP> __device__ __forceinline__ void fwd_subblock(u64 *lds_base, const unsigned region_words, const unsigned sb, const unsigned lane_in, const PrimeDesc &pd, const PrimeConst &pc, const Mod &m,
                                                                   u64 *out, const Ntt1Args &a, const unsigned mm, const unsigned m_begin, const int stamp0, const bool hf_last,
                                                                   const FpPrime &fc, const u64 *cr_in = nullptr, const Shoup cr_inv = Shoup{0, 0},
                                                                   const u64 *cr_acc = nullptr) {
     (void)a; (void)mm; (void)m_begin; (void)stamp0; (void)hf_last; (void)fc;
     constexpr unsigned A = 1u << (LOGN - 10); // blocks of the first sub-block stage per sub-block row: root index of stage s = 2^s + block
     const unsigned lane = opaque(lane_in);
+    const unsigned rb = 8 * region_words;
     N1_PRIO(3);
     {   // round B: stages 5..8 on 16 values, registers = j9..j6, lane = j5..j0; twiddles depend on (sb, register) only: scalar loads
         u64 y[16];
+        const unsigned wb = rb + 8 * sw1(lane);
 #pragma unroll
-        for (int r = 0; r < 16; r++) y[r] = R[sw1(64 * r + lane)];
+        for (int r = 0; r < 16; r++) y[r] = *lds_at(lds_base, wb ^ (8 * sw1(64 * r)));
         if constexpr (FP) {
             if (a.fp_red_mask & 2u) fp_reduce_all<16>(y, fc);
             fp_fwd_stages<1, 4, false, N1_FP_FENCE_B>(y, [&](int st, int, int blk) { return ld_tw_uniform(pd.root + (A << st) + (sb << st) + blk); }, fc);
         } else
         fwd_stages<1, 4, LEAN, true>(y, [&](int st, int, int blk) { return ld_tw_uniform(pd.root + (A << st) + (sb << st) + blk); }, pc);
 #pragma unroll
-        for (int r = 0; r < 16; r++) R[sw1(64 * r + lane)] = y[r];
+        for (int r = 0; r < 16; r++) *lds_at(lds_base, wb ^ (8 * sw1(64 * r))) = y[r];
     }
     TROY_WAVE_SYNC();
     N1_STAMP(stamp0);
@@ -401,18 +406,20 @@ template <int LOGN, bool LEAN, bool CR, bool FP> __device__ __forceinline__ void
         for (int i = 0; i < 2; i++) t10[i] = FP ? ld_tw8(pd.root, 32 * A + 2 * b9 + i) : ld_tw(pd.root, 32 * A + 2 * b9 + i);
 #pragma unroll
         for (int i = 0; i < 4; i++) t11[i] = FP ? ld_tw8(pd.root, 64 * A + 4 * b9 + i) : ld_tw(pd.root, 64 * A + 4 * b9 + i);
+        const unsigned wc0 = rb + 8 * sw1(64 * h + low);
 #pragma unroll 1
         for (unsigned it = 0; it < 2; it++) {
             u64 y[8];
+            const unsigned wc = it ? wc0 ^ (8 * sw1(4)) : wc0;
 #pragma unroll
-            for (int r = 0; r < 8; r++) y[r] = R[sw1(64 * h + 8 * r + 4 * it + low)];
+            for (int r = 0; r < 8; r++) y[r] = *lds_at(lds_base, wc ^ (8 * sw1(8 * r)));
             if constexpr (FP) {
                 if (a.fp_red_mask & 4u) fp_reduce_all<8>(y, fc);
                 fp_fwd_stages<1, 3, true>(y, [&](int st, int, int blk) { return st == 0 ? t9 : (st == 1 ? t10[blk] : t11[blk]); }, fc);
             } else
             fwd_stages<1, 3, LEAN, false>(y, [&](int st, int, int blk) { return st == 0 ? t9 : (st == 1 ? t10[blk] : t11[blk]); }, pc);
 #pragma unroll
-            for (int r = 0; r < 8; r++) R[sw1(64 * h + 8 * r + 4 * it + low)] = y[r];
+            for (int r = 0; r < 8; r++) *lds_at(lds_base, wc ^ (8 * sw1(8 * r))) = y[r];
         }
     }
     TROY_WAVE_SYNC();
@@ -431,9 +438,10 @@ template <int LOGN, bool LEAN, bool CR, bool FP> __device__ __forceinline__ void
         for (int i = 0; i < 2; i++) t13[i] = FP ? ld_tw8(pd.root, 256 * A + 2 * b12 + i) : ld_tw(pd.root, 256 * A + 2 * b12 + i);
 #pragma unroll
         for (int i = 0; i < 4; i++) t14[i] = FP ? ld_tw8(pd.root, 512 * A + 4 * b12 + i) : ld_tw(pd.root, 512 * A + 4 * b12 + i);
+        const unsigned wr2 = rb + 8 * sw1(8 * lane) ^ (it ? 8 * sw1(512) : 0u), ww2 = rb + 8 * wb_swz(8 * lane) ^ (it ? 8 * wb_swz(512) : 0u);
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(R + sw1(8 * u + 2 * q));
+            const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(lds_at(lds_base, wr2 ^ (8 * sw1(2 * q))));
             y[2 * q] = v.x;
             y[2 * q + 1] = v.y;
         }
@@ -470,7 +478,7 @@ template <int LOGN, bool LEAN, bool CR, bool FP> __device__ __forceinline__ void
                 }
                 mulhi_approx4_u(q, w, iq);
 #pragma unroll
-                for (int i = 0; i < 4; i++) r[i] = mul_acc_u(0, w[i], cr_inv.op, q[i], pc.negp); // [0, 3p)
+                for (int i = 0; i < 4; i++) r[i] = mul_acc0_u(w[i], cr_inv.op, q[i], pc.negp); // [0, 3p)
                 if (cr_acc) { // what the result is added to: the output itself, or the base polynomial of a rotation (null: nothing, start from zero)
 #pragma unroll
                     for (int e = 0; e < 2; e++) {
@@ -490,7 +498,7 @@ template <int LOGN, bool LEAN, bool CR, bool FP> __device__ __forceinline__ void
             ulonglong2 v;
             v.x = y[2 * q];
             v.y = y[2 * q + 1];
-            if (N1_FWD_STORE_VIA_LDS) *reinterpret_cast<ulonglong2 *>(R + wb_swz(8 * u + 2 * q)) = v; // into the eight slots it was read from (sw2: these 16-byte writes are 2-way conflicted under sw1)
+            if (N1_FWD_STORE_VIA_LDS) *reinterpret_cast<ulonglong2 *>(lds_at(lds_base, ww2 ^ (8 * wb_swz(2 * q)))) = v; // into the eight slots it was read from (sw2: these 16-byte writes are 2-way conflicted under sw1)
             else st_g2(out, 8 * u + 2 * q, v);
         }
     }
@@ -504,6 +512,7 @@ template <int LOGN, bool LEAN, bool CR, bool FP> __device__ __forceinline__ void
             // the divide-and-round epilogue on the way out, in the same layout: y = NTT(corr), canonical; out = (in + p - y) * inv mod p, stored or added to
             // what is there (Ntt1Corr) -- `in` and the accumulation target are read a contiguous KiB per instruction like the stores
             const Shoup iq[4] = {cr_inv, cr_inv, cr_inv, cr_inv};
+            u64 *const R = lds_base + region_words;
 #pragma unroll 1
             for (unsigned i = 0; i < 8; i += 2) {
                 const unsigned j0 = 128 * i + 2 * lane, j1 = j0 + 128;
@@ -512,7 +521,7 @@ template <int LOGN, bool LEAN, bool CR, bool FP> __device__ __forceinline__ void
                 u64 w[4] = {ia.x + pc.p - ya.x, ia.y + pc.p - ya.y, ib.x + pc.p - yb.x, ib.y + pc.p - yb.y}, q[4], r[4];
                 mulhi_approx4_u(q, w, iq);
 #pragma unroll
-                for (int e = 0; e < 4; e++) r[e] = mul_acc_u(0, w[e], cr_inv.op, q[e], pc.negp); // [0, 3p)
+                for (int e = 0; e < 4; e++) r[e] = mul_acc0_u(w[e], cr_inv.op, q[e], pc.negp); // [0, 3p)
                 if (cr_acc) { // what the result is added to: the output itself, or the base polynomial of a rotation (null: nothing, start from zero)
                     const ulonglong2 ca = ld_g2(cr_acc, j0), cb = ld_g2(cr_acc, j1);
                     r[0] += ca.x; r[1] += ca.y; r[2] += cb.x; r[3] += cb.y;
@@ -523,6 +532,7 @@ template <int LOGN, bool LEAN, bool CR, bool FP> __device__ __forceinline__ void
                 st_g2(out, j1, ulonglong2{r[2], r[3]});
             }
         } else {
+        u64 *const R = lds_base + region_words;
 #pragma unroll 1
         for (unsigned i = 0; i < 8; i += N1_FWD_STORE_UNROLL) { // a few at a time: the waiting half of the row and the next row's prefetch hold most of the registers
 #pragma unroll
@@ -679,7 +689,7 @@ template <bool LEAN, bool CR, bool FP> __device__ __forceinline__ void ntt1_fwd_
             }
             // (the FP64 instances compute faster than the odd half of the next row arrives; requesting it earlier -- after round B of the second half --
             // was measured twice, rounds 3 and 4: the 32 registers it holds through rounds C1 / C2 cost 36-52 B of scratch and 5 % of the kernel)
-            fwd_subblock<N1_LOGN, LEAN, CR, FP>(region, 16 * hf + wv, lane, pd, pc, m, out + 1024 * (16 * hf + wv), a, mm, m_begin, 4 + 6 * hf, hf == 1, fc, CR ? cin + 1024 * (16 * hf + wv) : nullptr,
+            fwd_subblock<N1_LOGN, LEAN, CR, FP>(lds, 1024 * wv, 16 * hf + wv, lane, pd, pc, m, out + 1024 * (16 * hf + wv), a, mm, m_begin, 4 + 6 * hf, hf == 1, fc, CR ? cin + 1024 * (16 * hf + wv) : nullptr,
                                        cr_inv, CR && cacc ? cacc + 1024 * (16 * hf + wv) : nullptr);
             N1_STAMP(7 + 6 * hf);
         }
@@ -698,11 +708,16 @@ template <bool CR> __global__ __launch_bounds__(N1_THREADS) void ntt1_fwd_fp_ker
 
 // the first 10 inverse stages (14..5) of sub-block sb: input y (this lane's coefficients 8 u + r, u = lane + 64 i, in y[8 i + r]),
 // result left in the wave's region (position sw2(j))
-template <int LOGN, bool LEAN, bool FP> __device__ __forceinline__ void inv_subblock(u64 (&yin)[16], u64 *R, const unsigned sb, const unsigned lane_in, const PrimeDesc &pd, const PrimeConst &pc,
+// LDS addresses (round 5): sw2 is linear over GF(2) -- every term is a shifted bit field XORed in -- so for an index j = A + c whose lane-dependent part A and
+// compile-time part c occupy disjoint bits, sw2(j) = sw2(A) ^ sw2(c).  Each round forms ONE per-lane byte offset W = region + 8 sw2(A) and every access
+// is W ^ (8 sw2(c)) with a literal: one v_xor_b32 per LDS instruction instead of the three-input XOR plus shift-and-add the generic expression compiled to
+// (2 -> 1 VALU instructions on each of the ~180 LDS accesses of a thread-row).  The region is 8 KiB-aligned inside the array, so the XOR never reaches its bits.
+template <int LOGN, bool LEAN, bool FP> __device__ __forceinline__ void inv_subblock(u64 (&yin)[16], u64 *lds_base, const unsigned region_words, const unsigned sb, const unsigned lane_in, const PrimeDesc &pd, const PrimeConst &pc,
                                                                   const FpPrime &fc, const unsigned fp_mask) {
     const Shoup none{0, 0};
     constexpr unsigned NN = 1u << LOGN; // the inverse table keeps the stage with m blocks at offset N - 2 m + 1 (src/utils/ntt.cpp:49-54)
     const unsigned lane = opaque(lane_in);
+    const unsigned rb = 8 * region_words;
     (void)fc; (void)fp_mask;
     if constexpr (FP) { // canonical residues become doubles (round D' never needs a reduction: 8 p < 2^53)
 #pragma unroll
@@ -727,12 +742,13 @@ template <int LOGN, bool LEAN, bool FP> __device__ __forceinline__ void inv_subb
         inv_stages_lean<1, 3, false, false, 2, 64>(y, [&](int st, int, int blk) { return st == 0 ? t14[blk] : (st == 1 ? t13[blk] : t12); }, none, (u32)pd.cr1, pc);
         else
         inv_stages<1, 3, false, false, 0>(y, [&](int st, int, int blk) { return st == 0 ? t14[blk] : (st == 1 ? t13[blk] : t12); }, none, pc);
+        const unsigned wd = rb + 8 * sw2(8 * lane); // j = 8 (lane + 64 it) + 2 q: lane in bits 3..8, the rest in bits 1, 2, 9
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             ulonglong2 v;
             v.x = y[2 * q];
             v.y = y[2 * q + 1];
-            *reinterpret_cast<ulonglong2 *>(R + sw2(8 * u + 2 * q)) = v;
+            *reinterpret_cast<ulonglong2 *>(lds_at(lds_base, wd ^ (8 * sw2(512 * it + 2 * q)))) = v;
         }
         N1_SCHED_FENCE();
     }
@@ -746,11 +762,13 @@ template <int LOGN, bool LEAN, bool FP> __device__ __forceinline__ void inv_subb
 #pragma unroll
         for (int i = 0; i < 2; i++) t10[i] = FP ? ld_tw8(pd.iroot, NN - NN / 16 + 1 + 2 * b9 + i) : ld_tw(pd.iroot, NN - NN / 16 + 1 + 2 * b9 + i);
         const Shoup t9 = FP ? ld_tw8(pd.iroot, NN - NN / 32 + 1 + b9) : ld_tw(pd.iroot, NN - NN / 32 + 1 + b9);
+        const unsigned wc0 = rb + 8 * sw2(64 * h + low); // j = 64 h + 8 r + 4 it + low: lane in bits 0, 1, 6..9, (r, it) in bits 2..5
 #pragma unroll 1
         for (unsigned it = 0; it < 2; it++) {
             u64 y[8];
+            const unsigned wc = it ? wc0 ^ (8 * sw2(4)) : wc0;
 #pragma unroll
-            for (int r = 0; r < 8; r++) y[r] = R[sw2(64 * h + 8 * r + 4 * it + low)];
+            for (int r = 0; r < 8; r++) y[r] = *lds_at(lds_base, wc ^ (8 * sw2(8 * r)));
             if constexpr (FP) {
                 if (fp_mask & 2u) fp_reduce_all<8>(y, fc);
                 fp_inv_stages<1, 3, false, 0, 3, true>(y, [&](int st, int, int blk) { return st == 0 ? t11[blk] : (st == 1 ? t10[blk] : t9); }, none, fc);
@@ -759,14 +777,15 @@ template <int LOGN, bool LEAN, bool FP> __device__ __forceinline__ void inv_subb
             else
             inv_stages<1, 3, false, false, 0>(y, [&](int st, int, int blk) { return st == 0 ? t11[blk] : (st == 1 ? t10[blk] : t9); }, none, pc);
 #pragma unroll
-            for (int r = 0; r < 8; r++) R[sw2(64 * h + 8 * r + 4 * it + low)] = y[r];
+            for (int r = 0; r < 8; r++) *lds_at(lds_base, wc ^ (8 * sw2(8 * r))) = y[r];
         }
     }
     TROY_WAVE_SYNC();
     {   // round B': stages 8..5, registers = j6..j9 (bit 0 = j6); twiddles depend on (sb, register) only
         u64 y[16];
+        const unsigned wb = rb + 8 * sw2(lane); // j = 64 r + lane: lane in bits 0..5, r in bits 6..9
 #pragma unroll
-        for (int r = 0; r < 16; r++) y[r] = R[sw2(64 * r + lane)];
+        for (int r = 0; r < 16; r++) y[r] = *lds_at(lds_base, wb ^ (8 * sw2(64 * r)));
         if constexpr (FP) {
             if (fp_mask & 4u) fp_reduce_all<16>(y, fc);
             fp_inv_stages<1, 4, false, 0, 4>(y, [&](int st, int, int blk) { return ld_tw_uniform(pd.iroot + (NN - ((NN >> 6) >> st) + 1) + ((8 * sb) >> st) + blk); }, none, fc);
@@ -775,7 +794,7 @@ template <int LOGN, bool LEAN, bool FP> __device__ __forceinline__ void inv_subb
         else
         inv_stages<1, 4, false, true, 0>(y, [&](int st, int, int blk) { return ld_tw_uniform(pd.iroot + (NN - ((NN >> 6) >> st) + 1) + ((8 * sb) >> st) + blk); }, none, pc);
 #pragma unroll
-        for (int r = 0; r < 16; r++) R[sw2(64 * r + lane)] = y[r];
+        for (int r = 0; r < 16; r++) *lds_at(lds_base, wb ^ (8 * sw2(64 * r))) = y[r];
     }
 }
 
@@ -825,7 +844,9 @@ template <bool LEAN, bool MD, bool FP> __device__ __forceinline__ void ntt1_inv_
         return a.src + (u64)o * a.src_ostride + ((u64)(slot * inner + k) << N1_LOGN);
     };
     stage_issue(in_of(m_begin) + 1024 * wv);
-    const u64 *const rlo = lds + sw2(tid), *const rhi = rlo + 8 * 1024;
+    // two base registers for the 32 exchange reads: the immediate offset of a ds_read reaches 64 KiB, so rlo + 8 KiB r and rhi + 8 KiB r need nothing else.
+    // (rhi's base is made opaque: the compiler otherwise folds the 64 KiB into EIGHT per-lane addresses it keeps live across the row loop, and spills)
+    const u64 *const rlo = lds + sw2(tid), *const rhi = lds_at(lds, opaque(8 * (8 * 1024 + sw2(tid))));
     for (unsigned mm = m_begin; mm < m_end; mm++) {
         u64 *const row = a.data + row_of(mm);
         u64 x[32]; // x[r] = coefficient tid of sub-block r after its 10 stages
@@ -833,18 +854,19 @@ template <bool LEAN, bool MD, bool FP> __device__ __forceinline__ void ntt1_inv_
         load16(y1, in_of(mm) + 1024 * (16 + wv)); // second half's input: in flight while the first half is transformed
         TROY_WAIT_VMEM();                   // the staged first half has landed (vmcnt counts in order: this also waits for y1 -- see below)
         const unsigned ol = opaque(lane);   // recomputed per row: hoisted out of the loop these eight addresses are spilled
+        const unsigned ws = 8 * 1024 * wv + 8 * sw2(8 * ol); // as round D' of inv_subblock: one per-lane offset, a literal XOR per access
 #pragma unroll
         for (int i = 0; i < 2; i++)
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(region + sw2(8 * (ol + 64 * i) + 2 * q));
+                const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(lds_at(lds, ws ^ (8 * sw2(512 * i + 2 * q))));
                 y[8 * i + 2 * q] = v.x;
                 y[8 * i + 2 * q + 1] = v.y;
             }
         TROY_WAVE_SYNC();
 #pragma unroll
         for (int hf = 0; hf < 2; hf++) {
-            inv_subblock<N1_LOGN, LEAN, FP>(hf ? y1 : y, region, 16 * hf + wv, lane, pd, pc, fc, a.fp_red_mask);
+            inv_subblock<N1_LOGN, LEAN, FP>(hf ? y1 : y, lds, 1024 * wv, 16 * hf + wv, lane, pd, pc, fc, a.fp_red_mask);
             __syncthreads();
 #pragma unroll
             for (int r = 0; r < 8; r++) { x[16 * hf + r] = rlo[1024 * r]; x[16 * hf + 8 + r] = rhi[1024 * r]; }
@@ -985,7 +1007,7 @@ template <int LOGN, bool LEAN, bool FP> __device__ __forceinline__ void ntt1s_fw
         }
         __syncthreads();
         if (mm + 1 < m_end) load_row(in_base + row_of(mm + 1)); // all sixteen registers are free: the next limb streams in under the sub-block rounds
-        fwd_subblock<LOGN, LEAN, false, FP>(region, wv, lane, pd, pc, m, out + 1024 * wv, args, mm, m_begin, 4, true, fc);
+        fwd_subblock<LOGN, LEAN, false, FP>(lds, 1024 * wv, wv, lane, pd, pc, m, out + 1024 * wv, args, mm, m_begin, 4, true, fc);
     }
 }
 template <int LOGN, bool LEAN> __global__ __launch_bounds__(64 << (LOGN - 10), 4) void ntt1s_fwd_kernel(Ntt1Args a) { ntt1s_fwd_body<LOGN, LEAN, false>(a); }
@@ -1030,7 +1052,7 @@ template <int LOGN, bool LEAN, bool MD, bool FP> __device__ __forceinline__ void
     for (unsigned mm = m_begin; mm < m_end; mm++) {
         u64 *const row = a.data + row_of(mm);
         if (mm != m_begin) __syncthreads(); // round A' of the previous row has read the regions
-        inv_subblock<LOGN, LEAN, FP>(y, region, wv, lane, pd, pc, fc, a.fp_red_mask);
+        inv_subblock<LOGN, LEAN, FP>(y, lds, 1024 * wv, wv, lane, pd, pc, fc, a.fp_red_mask);
         __syncthreads();
         u64 x[16]; // x[(g << LOGA) + h] = coefficient t + T g of sub-block h after its ten stages
         {
