@@ -18,7 +18,6 @@ def _build(out, libdir, libfile, src=SRC):
 
 
 LINEAR = os.path.join(ROOT, "tests", "cpp", "test_troyn_linear.cpp")  # include/troyn_linear.hpp: the flows of the reference's test/app/linear.cu (BFV)
-TIMETEST = os.path.join(ROOT, "tests", "cpp", "test_troyn_timetest.cpp")  # the op sequences of the reference's test/timetest.cu, incl. every out-of-place form
 
 
 def _run(exe, *args):
@@ -53,20 +52,6 @@ def test_troyn_app_on_gpu(tmp_path):
     exe = str(tmp_path / "test_troyn_app")
     _build(exe, os.path.join(ROOT, "troy_amd"), "libtroyhip.so", APP)
     _run(exe)
-
-
-def test_troyn_timetest_on_emulator(tmp_path):
-    subprocess.check_call(["make", "-s", "-j8", "-C", os.path.join(ROOT, "troy_amd", "csrc"), "emul"])
-    exe = str(tmp_path / "test_troyn_timetest_emul")
-    _build(exe, os.path.join(ROOT, "tests", "emul"), "libtroyhip_emul.so", TIMETEST)
-    _run(exe, "4096")
-
-
-@pytest.mark.gpu
-def test_troyn_timetest_on_gpu(tmp_path):
-    exe = str(tmp_path / "test_troyn_timetest")
-    _build(exe, os.path.join(ROOT, "troy_amd"), "libtroyhip.so", TIMETEST)
-    _run(exe, "8192")
 
 
 def test_troyn_linear_on_emulator(tmp_path):
@@ -115,25 +100,6 @@ def test_bench_troyn_on_gpu(tmp_path):
     _build(exe, os.path.join(ROOT, "troy_amd"), "libtroyhip.so", BENCH)
     r = subprocess.run([exe, "bfv_n8192_l4", "3", "1", "8", "40"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "ALL OK" in r.stdout and '"verified": false' not in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
-
-
-@pytest.mark.gpu
-def test_troyn_timetest_time_mode_on_gpu(tmp_path):
-    exe = str(tmp_path / "test_troyn_timetest")
-    _build(exe, os.path.join(ROOT, "troy_amd"), "libtroyhip.so", TIMETEST)
-    r = subprocess.run([exe, "16384", "--time", "20", "--scheme", "bfv", "--tbits", "59"], capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0 and "ALL OK" in r.stdout and "FAIL" not in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
-    for label in ("Multiply-assign", "Relinearize-assign", "RelinearizeKeys-assign", "RotateRows-inplace", "Square-inplace", "Preallocate"):
-        assert label + ":" in r.stdout  # the reference's labels (test/timetest.cu)
-
-
-REF_TIMETEST = os.path.join(ROOT, "oracle", "_ref", "ref_timetest")
-
-
-@pytest.mark.skipif(not os.path.exists(REF_TIMETEST), reason="oracle/_ref/ref_timetest is built from /root/reference by oracle/Makefile")
-def test_timetest_source_against_the_reference_cpu_half():
-    """the SAME test source, compiled against the reference's own troy:: classes: every assertion the GPU build makes also holds on the reference"""
-    _run(REF_TIMETEST, "4096")
 
 
 def test_fp64_arithmetic_and_bound_walk_on_cpu(tmp_path):

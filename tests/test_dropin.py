@@ -69,8 +69,12 @@ def test_default_modulus_tables_match_reference():
     assert len(primes) > 60
     for p in primes:
         assert p.lower() + "ull" in inc, p
-    for b in re.findall(r"return (\d+);", open(os.path.join(REF, "src", "utils", "hestdparams.h")).read()):
-        assert b == "0" or re.search(r"\b%s\b" % b, inc), b
+    hs = open(os.path.join(REF, "src", "utils", "hestdparams.h")).read()
+    for sec in (128, 192, 256):  # the classical-security tables SecurityLevel::tc128 / tc192 / tc256 select (src/modulus.cpp:14-51)
+        body = re.search(r"seal_he_std_parms_%d_tc\(.*?\{(.*?)return 0;\s*\}" % sec, hs, re.S).group(1)
+        bits = re.findall(r"size_t\(\d+\):\s*return (\d+);", body)
+        assert len(bits) == 6
+        assert "{" + ", ".join(bits) + "}" in inc, (sec, bits)
 
 
 def _gpu_binary(name):

@@ -411,8 +411,16 @@ template <int INV, int STRIDED, int NS, int LOGC, int LS, int R, bool HOISTP = t
         if (fc) {
 #pragma unroll
             for (int e = 0; e < 8; e++) x[e] = fp_canonical(fp_of_bits(x[e]), *fc, m.p);
-        } else if (lean) { // guard-free transform: values below 59p
-            lean_final<8>(x, make_lean_final(m.p, m.cr1), pc);
+        } else if (lean) { // guard-free transform: values below 59p.  The products do not need canonical factors: below 4p each (lite_reduce4: 4 instructions
+            // per value against 10 for the canonical residue) a product is below 16 p^2 and the middle sum below 32 p^2 < 2^(2k+5), k = bit length of p <= 58;
+            // reduce_prod's quotient estimate floor((x >> (k-1)) mu / 2^64) keeps its error of at most 2 as long as x >> (k-1) < 2^64, i.e. up to 2^(k+63)
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                u64 v[4] = {x[4 * h], x[4 * h + 1], x[4 * h + 2], x[4 * h + 3]};
+                lite_reduce4(v, (u32)m.cr1, pc);
+#pragma unroll
+                for (int i = 0; i < 4; i++) x[4 * h + i] = v[i];
+            }
         } else {
 #pragma unroll
             for (int h = 0; h < 2; h++) {
@@ -432,8 +440,8 @@ template <int INV, int STRIDED, int NS, int LOGC, int LS, int R, bool HOISTP = t
                 }
             return;
         }
-        // all four operands are canonical: every product is below p^2 and the middle sum below 2 p^2, which reduce_prod takes
-        // directly -- (a0 b1 + a1 b0) mod p is the same residue as the reference's add of the two reduced products
+        // the four operands are canonical (guarded / FP64 transforms) or below 4p (guard-free): every product and the middle sum are within what
+        // reduce_prod takes -- (a0 b1 + a1 b0) mod p is the same residue as the reference's add of the two reduced products
         const unsigned b = mm >> 2;
         const ProdMod pm = make_prod_mod(m);
         u64 d[3][8];
