@@ -1,8 +1,8 @@
 #!/bin/bash
-# Round-4 parity soak on the GPU: random parameter sets, product vs CPU oracle limb for limb, under every value of the library switches that picks
-# a different kernel family (single-pass NTT of N = 2^12 .. 2^15, FP64 BEHZ of small bases, merged / split small launches).  Output: gpurun_out/r04_random_soak.txt
+# Round-5 parity soak (same counts as round 4) on the GPU: random parameter sets, product vs CPU oracle limb for limb, under every value of the library switches that picks
+# a different kernel family (single-pass NTT of N = 2^12 .. 2^15, FP64 BEHZ of small bases, merged / split small launches).  Output: gpurun_out/r05_random_soak.txt
 set -u
-out=gpurun_out/r04_random_soak.txt
+out=gpurun_out/r05_random_soak.txt
 mkdir -p gpurun_out
 python - > $out <<'PY'
 from troy_amd import capi

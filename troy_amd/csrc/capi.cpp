@@ -33,6 +33,11 @@ template <class F> int guard(F f, bool need_init = true) {
     try {
         if (need_init && !g_init.load()) throw Error(ST_NOT_INITIALIZED, "KernelProvider not initialized.");
         f();
+        // TROYHIP_SYNC=1 (the fifth documented switch): every entry point returns with the device idle -- what CUDA_LAUNCH_BLOCKING is to the reference.
+        // For callers that read host timers around single calls without synchronising (the reference's own test/timetest.cu does) and for debugging;
+        // the default is asynchronous, stream-ordered execution.
+        static const bool sync_calls = [] { const char *e = std::getenv("TROYHIP_SYNC"); return e && e[0] == '1'; }();
+        if (sync_calls && need_init && g_init.load()) HIP_CHECK(hipDeviceSynchronize());
         return TROYHIP_OK;
     } catch (const Error &e) {
         g_err = e.what();

@@ -42,9 +42,9 @@ void end(hipStream_t s);
 
 namespace troyhip {
 
-// Environment switches.  The shipped library reads FOUR, each once (documented in DESIGN.md section 8): TROYHIP_NTT = single | twopass (which transform form
+// Environment switches.  The shipped library reads FIVE, each once (documented in DESIGN.md section 8): TROYHIP_NTT = single | twopass (which transform form
 // takes a launch), TROYHIP_FP64 = off (integer kernels for every prime), TROYHIP_AUX_BASE = reference (the reference's 61-bit BEHZ base),
-// TROYHIP_SMALL = split | merged (the merged forms of small launches never / always).  Everything else -- forcing an unfused fallback, guarded
+// TROYHIP_SMALL = split | merged (the merged forms of small launches never / always), TROYHIP_SYNC = 1 (every entry point returns with the device idle: capi.cpp).  Everything else -- forcing an unfused fallback, guarded
 // butterflies, rows per workgroup -- exists only in probe builds (-DTROYHIP_PROBES: `make probes`, and the CPU emulator build of the test suite).
 inline const char *probe_env(const char *name) {
 #ifdef TROYHIP_PROBES
