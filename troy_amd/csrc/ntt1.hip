@@ -108,6 +108,9 @@ __device__ __forceinline__ unsigned sw1(unsigned j) { return j ^ (((j >> 6) & 7u
 #ifndef N1_INV_SWZ
 #define N1_INV_SWZ 2
 #endif
+#ifndef N1_INV_TOP
+#define N1_INV_TOP 0 // top of an inverse row: 0 request the second half, then drain; 1 drain, then request; 2 request, then wait for all but those eight loads
+#endif
 __device__ __forceinline__ unsigned sw2(unsigned j) { return N1_INV_SWZ == 2 ? sw1(j) ^ (((j >> 4) & 1u) << 2) : sw1(j); }
 #ifndef N1_FWD_WB_SW1
 #define N1_FWD_WB_SW1 0 // 1 (probe): the forward kernels' write-back for the lane-linear stores under sw1 (2-way conflicted 16-byte writes)
@@ -851,8 +854,16 @@ template <bool LEAN, bool MD, bool FP> __device__ __forceinline__ void ntt1_inv_
         u64 *const row = a.data + row_of(mm);
         u64 x[32]; // x[r] = coefficient tid of sub-block r after its 10 stages
         u64 y[16], y1[16];
+#if N1_INV_TOP == 0 || defined(TROYHIP_CPU_EMUL)
         load16(y1, in_of(mm) + 1024 * (16 + wv)); // second half's input: in flight while the first half is transformed
-        TROY_WAIT_VMEM();                   // the staged first half has landed (vmcnt counts in order: this also waits for y1 -- see below)
+        TROY_WAIT_VMEM();                   // the staged first half has landed (vmcnt counts in order: this also waits for y1)
+#elif N1_INV_TOP == 1 // probe: the second half requested AFTER the wait for the staged first half -- its latency sits under the first half's ten stages
+        TROY_WAIT_VMEM();
+        load16(y1, in_of(mm) + 1024 * (16 + wv));
+#else                 // probe: requested first, but the wait leaves its eight loads in flight (reads return in order: everything older has landed)
+        load16(y1, in_of(mm) + 1024 * (16 + wv));
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+#endif
         const unsigned ol = opaque(lane);   // recomputed per row: hoisted out of the loop these eight addresses are spilled
         const unsigned ws = 8 * 1024 * wv + 8 * sw2(8 * ol); // as round D' of inv_subblock: one per-lane offset, a literal XOR per access
 #pragma unroll
