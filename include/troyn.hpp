@@ -355,7 +355,7 @@ inline CtFields get_fields(std::istream &s) {
     f.ntt = get<bool>(s); f.size = get<size_t>(s); f.n = get<size_t>(s); f.limbs = get<size_t>(s);
     f.scale = get<double>(s); f.cf = get<uint64_t>(s); f.seed = get<uint64_t>(s); f.terms = get<bool>(s);
     // sizes that cannot be a ciphertext (a corrupted or foreign stream) stop here, not in an allocation
-    if (!f.n || (f.n & (f.n - 1)) || f.n > (size_t(1) << 20) || f.limbs < 1 || f.limbs > 256 || f.size > 1024) throw std::invalid_argument("the stream does not hold a ciphertext");
+    if (!f.n || (f.n & (f.n - 1)) || f.n > (size_t(1) << 17) || f.limbs < 1 || f.limbs > 64 || f.size > 1024) throw std::invalid_argument("the stream does not hold a ciphertext");
     return f;
 }
 } // namespace wire
@@ -391,7 +391,7 @@ public:
                 at += 2;
                 while (at < len && hex_poly[at] >= '0' && hex_poly[at] <= '9') {
                     t.power = t.power * 10 + (size_t)(hex_poly[at++] - '0');
-                    if (t.power > (size_t(1) << 30)) throw std::invalid_argument("unable to parse hex_poly");
+                    if (t.power >= (size_t(1) << 20)) throw std::invalid_argument("unable to parse hex_poly"); // no ring of this library is that large: refuse before allocating
                 }
             }
             if (previous >= 0 && (long)t.power >= previous) throw std::invalid_argument("unable to parse hex_poly");
@@ -521,7 +521,7 @@ private:
         stream.read(reinterpret_cast<char *>(&count), sizeof(size_t));
         stream.read(reinterpret_cast<char *>(&scale), sizeof(double));
         stream.read(reinterpret_cast<char *>(&words), sizeof(size_t));
-        if (!stream || words > (size_t(1) << 32)) throw std::invalid_argument("stream ended inside a plaintext");
+        if (!stream || words > (size_t(1) << 23)) throw std::invalid_argument("stream ended inside a plaintext");
         std::vector<uint64_t> host(words);
         stream.read(reinterpret_cast<char *>(host.data()), (std::streamsize)(words * 8));
         if (!stream) throw std::invalid_argument("stream ended inside a plaintext");
@@ -753,7 +753,7 @@ public:
         const size_t count = wire::get<size_t>(stream);
         (void)wire::get<double>(stream);
         const size_t words = wire::get<size_t>(stream);
-        if (words != count || words > (size_t(1) << 32)) throw std::invalid_argument("the stream does not hold a secret key");
+        if (words != count || words > (size_t(1) << 23)) throw std::invalid_argument("the stream does not hold a secret key"); // at most 64 limbs of 2^17 coefficients
         std::vector<uint64_t> host(words);
         wire::get_words(stream, host.data(), words);
         data = std::move(host);
@@ -2024,15 +2024,13 @@ inline void Ciphertext::save(std::ostream &stream) const {
     wire::put_payload(stream, *this);
 }
 inline void Ciphertext::load(std::istream &stream) { // src/ciphertext_cuda.cu:65-88: no validation without a context
-    uint64_t id[4];
-    stream.read(reinterpret_cast<char *>(id), 32);
-    const bool ntt = wire::get<bool>(stream);
-    const size_t size = wire::get<size_t>(stream), n = wire::get<size_t>(stream), limbs = wire::get<size_t>(stream);
-    const double scale = wire::get<double>(stream);
-    const uint64_t cf = wire::get<uint64_t>(stream), seed = wire::get<uint64_t>(stream);
-    const bool terms = wire::get<bool>(stream);
-    if (seed) throw std::invalid_argument("seed is not zero.");
-    if (terms) throw std::invalid_argument("Trying to load a termed ciphertext, but indices is not specified");
+    const wire::CtFields f = wire::get_fields(stream); // sizes no ring of this library has stop here, not in an allocation
+    const bool ntt = f.ntt;
+    const size_t size = f.size, n = f.n, limbs = f.limbs;
+    const double scale = f.scale;
+    const uint64_t cf = f.cf;
+    if (f.seed) throw std::invalid_argument("seed is not zero.");
+    if (f.terms) throw std::invalid_argument("Trying to load a termed ciphertext, but indices is not specified");
     const size_t words = wire::get<size_t>(stream);
     if (words != size * limbs * n) throw std::invalid_argument("encrypted is not valid for encryption parameters");
     std::vector<uint64_t> host(words);

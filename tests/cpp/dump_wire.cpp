@@ -6,6 +6,7 @@
 //   usage: dump_wire <outdir>
 #include "troy_cuda.cuh"
 #include <cstdio>
+#include <cstring>
 #include <fstream>
 #include <sstream>
 
@@ -196,6 +197,31 @@ static void run(const std::string &dir, const std::string &tag, SchemeType schem
         // a truncated stream is refused, not read past its end
         const std::string cut = saved(rlk).substr(0, saved(rlk).size() / 2);
         CHECK(throws<std::invalid_argument>([&] { std::istringstream t(cut); RelinKeys k; k.load(t); }));
+    }
+    { // every loader, every truncation point of interest, and absurd size fields: an exception, never a fault or a giant allocation
+        const std::string blobs[5] = {saved(ct), saved(pk), saved(sk), saved(rlk), sym_blob};
+        for (int which = 0; which < 5; which++) {
+            const std::string &b = blobs[which];
+            auto load_it = [&](const std::string &bytes) {
+                std::istringstream t(bytes);
+                if (which == 0) { Ciphertext c; c.load(t, context); }
+                else if (which == 1) { PublicKey k; k.load(t); }
+                else if (which == 2) { SecretKey k; k.load(t); }
+                else if (which == 3) { RelinKeys k; k.load(t); }
+                else { Ciphertext c; c.load(t, context); }
+            };
+            for (size_t cutpos : {size_t(0), size_t(7), size_t(32), size_t(33), size_t(41), size_t(57), size_t(74), size_t(82), b.size() / 3, b.size() - 9, b.size() - 1})
+                if (cutpos < b.size()) CHECK(throws<std::invalid_argument>([&] { load_it(b.substr(0, cutpos)); }));
+            for (size_t field : {size_t(32), size_t(33), size_t(40), size_t(41), size_t(49), size_t(57)}) { // a size field blown up to 2^61
+                if (field + 8 > b.size()) continue;
+                std::string bad = b;
+                const uint64_t huge = uint64_t(1) << 61;
+                std::memcpy(&bad[field], &huge, 8);
+                bool refused_or_loaded = true; // some offsets hit a double or a flag in one format and a size in another: it must not crash; a size must be refused
+                try { load_it(bad); } catch (const std::invalid_argument &) {} catch (const std::bad_alloc &) { refused_or_loaded = false; } catch (const std::length_error &) { refused_or_loaded = false; }
+                CHECK(refused_or_loaded);
+            }
+        }
     }
 }
 
