@@ -240,6 +240,7 @@ void Context::upload_tables() {
         d.iroot = upload(tb.iroot, dev_allocs_);
         d.aux = Shoup{0, 0};
         d.root_fp = d.iroot_fp = nullptr;
+        d.root_w = d.iroot_w = nullptr;
         if (fp_prime(tb.p)) { // the same twiddles as pairs of doubles (w, w / p): both exact / correctly rounded on the host (fpmod.h)
             auto to_fp = [&](const std::vector<Shoup> &v) {
                 std::vector<Shoup> f(v.size());
@@ -248,6 +249,11 @@ void Context::upload_tables() {
             };
             d.root_fp = upload(to_fp(tb.root), dev_allocs_);
             d.iroot_fp = upload(to_fp(tb.iroot), dev_allocs_);
+            std::vector<u64> rw(tb.root.size()), iw(tb.iroot.size(), 0); // compact w-only tables (device_types.h); the inverse one shifted by one entry
+            for (size_t j = 0; j < tb.root.size(); j++) rw[j] = fp_bits((double)tb.root[j].op);
+            for (size_t j = 0; j + 1 < tb.iroot.size(); j++) iw[j] = fp_bits((double)tb.iroot[j + 1].op);
+            d.root_w = upload(rw, dev_allocs_);
+            d.iroot_w = upload(iw, dev_allocs_);
         }
         set_fp_consts(d);
     }

@@ -17,6 +17,12 @@ struct PrimeDesc {
     const Shoup *root_fp;
     const Shoup *iroot_fp;
     Shoup inv_n_fp, iroot_last_scaled_fp; // (w, w / p) of inv_n / iroot_last_scaled as they stand in THIS descriptor (the derived tables rescale them)
+    // round 5: the per-lane rounds of the FP64 single-pass kernels use w alone (the quotient comes from 1 / p), so they read COMPACT tables of the doubles
+    // w (8-byte entries, bit patterns): half the bytes and the cache footprint of the pair tables, and the 4 / 2 consecutive entries a thread needs are
+    // one or two 16-byte loads.  root_w[j] = double(root[j].op);  iroot_w[j] = double(iroot[j + 1].op) -- shifted by the "+ 1" every inverse stage offset
+    // carries (src/utils/ntt.cpp:49-54), so that the groups of 4 and 2 are 32- and 16-byte aligned.  nullptr with root_fp.
+    const u64 *root_w;
+    const u64 *iroot_w;
 };
 __host__ __device__ inline Mod mod_of(const PrimeDesc &d) { return Mod{d.p, d.cr0, d.cr1}; }
 

@@ -132,7 +132,11 @@ __device__ __forceinline__ Shoup ld_tw(const Shoup *base, unsigned idx) { return
 __device__ __forceinline__ Shoup ld_tw_uniform(const Shoup *p) { return *p; }
 #else
 typedef unsigned long long troy_v2ull __attribute__((ext_vector_type(2)));
+#ifndef N1_EXP_NOTW
+#define N1_EXP_NOTW 0 // removal probe (wrong results): 1 = the per-lane twiddles are made up from the index instead of loaded -- what their latency costs
+#endif
 __device__ __forceinline__ Shoup ld_tw(const Shoup *base, unsigned idx) { // base is wave-uniform (SGPR pair), idx per lane: saddr + 32-bit offset
+    if (N1_EXP_NOTW) return Shoup{(u64)idx * 0x9E3779B97F4A7C15ull >> 8, (u64)idx * 0xD1B54A32D192ED03ull};
     const troy_v2ull v = ((const __attribute__((address_space(1))) troy_v2ull *)base)[idx];
     return Shoup{v.x, v.y};
 }
@@ -141,13 +145,35 @@ __device__ __forceinline__ Shoup ld_tw_uniform(const Shoup *p) {
     return Shoup{v.x, v.y};
 }
 #endif
-// FP64 tables, per-lane entries: only the first double (w) of the pair is fetched -- half the twiddle registers of the sub-block rounds; the
-// quotient then comes from the rounded product and 1 / p (fp_mulmod_pinv)
-__device__ __forceinline__ Shoup ld_tw8(const Shoup *base, unsigned idx) {
+// FP64 instances, per-lane twiddles: only the double w is needed -- half the twiddle registers of the sub-block rounds; the quotient then comes from the
+// rounded product and 1 / p (fp_mulmod_pinv).  They come from the compact tables (PrimeDesc::root_w / iroot_w: 8-byte entries): one entry, or 2 / 4 consecutive ones as one / two 16-byte loads (idx a multiple of
+// 2 / 4: the groups are aligned).  Round 5: a removal probe (N1_EXP_NOTW) put the per-lane twiddle loads at 10 % of the FP64 single-pass kernels (1 % of the
+// integer ones, whose 15-instruction butterflies hide them): from the pair tables a thread's 4 + 2 + 1 twiddles were seven 8-byte loads at a 16-byte stride.
+__device__ __forceinline__ Shoup ld_w1(const u64 *base, unsigned idx) {
 #ifdef TROYHIP_CPU_EMUL
-    return Shoup{base[idx].op, 0};
+    return Shoup{base[idx], 0};
 #else
-    return Shoup{((const __attribute__((address_space(1))) u64 *)base)[2 * idx], 0};
+    if (N1_EXP_NOTW) return Shoup{__builtin_bit_cast(u64, (double)(idx | 1u)), 0};
+    return Shoup{((const __attribute__((address_space(1))) u64 *)base)[idx], 0};
+#endif
+}
+__device__ __forceinline__ void ld_w2(const u64 *base, unsigned idx, Shoup (&t)[2]) {
+#ifdef TROYHIP_CPU_EMUL
+    t[0] = Shoup{base[idx], 0}; t[1] = Shoup{base[idx + 1], 0};
+#else
+    if (N1_EXP_NOTW) { t[0] = ld_w1(base, idx); t[1] = ld_w1(base, idx + 1); return; }
+    const troy_v2ull v = *(const __attribute__((address_space(1))) troy_v2ull *)((const __attribute__((address_space(1))) u64 *)base + idx);
+    t[0] = Shoup{v.x, 0}; t[1] = Shoup{v.y, 0};
+#endif
+}
+__device__ __forceinline__ void ld_w4(const u64 *base, unsigned idx, Shoup (&t)[4]) {
+#ifdef TROYHIP_CPU_EMUL
+    for (int i = 0; i < 4; i++) t[i] = Shoup{base[idx + i], 0};
+#else
+    if (N1_EXP_NOTW) { for (int i = 0; i < 4; i++) t[i] = ld_w1(base, idx + i); return; }
+    const __attribute__((address_space(1))) troy_v2ull *q = (const __attribute__((address_space(1))) troy_v2ull *)((const __attribute__((address_space(1))) u64 *)base + idx);
+    const troy_v2ull a = q[0], b = q[1];
+    t[0] = Shoup{a.x, 0}; t[1] = Shoup{a.y, 0}; t[2] = Shoup{b.x, 0}; t[3] = Shoup{b.y, 0};
 #endif
 }
 
@@ -403,12 +429,17 @@ template <int LOGN, bool LEAN, bool CR, bool FP> __device__ __forceinline__ void
         // the seven twiddles
         const unsigned h = lane >> 2, low = lane & 3;
         const unsigned b9 = 16 * sb + h;
-        const Shoup t9 = FP ? ld_tw8(pd.root, 16 * A + b9) : ld_tw(pd.root, 16 * A + b9);
+        const Shoup t9 = FP ? ld_w1(pd.root_w, 16 * A + b9) : ld_tw(pd.root, 16 * A + b9);
         Shoup t10[2], t11[4];
+        if constexpr (FP) {
+            ld_w2(pd.root_w, 32 * A + 2 * b9, t10);
+            ld_w4(pd.root_w, 64 * A + 4 * b9, t11);
+        } else {
 #pragma unroll
-        for (int i = 0; i < 2; i++) t10[i] = FP ? ld_tw8(pd.root, 32 * A + 2 * b9 + i) : ld_tw(pd.root, 32 * A + 2 * b9 + i);
+        for (int i = 0; i < 2; i++) t10[i] = ld_tw(pd.root, 32 * A + 2 * b9 + i);
 #pragma unroll
-        for (int i = 0; i < 4; i++) t11[i] = FP ? ld_tw8(pd.root, 64 * A + 4 * b9 + i) : ld_tw(pd.root, 64 * A + 4 * b9 + i);
+        for (int i = 0; i < 4; i++) t11[i] = ld_tw(pd.root, 64 * A + 4 * b9 + i);
+        }
         const unsigned wc0 = rb + 8 * sw1(64 * h + low);
 #pragma unroll 1
         for (unsigned it = 0; it < 2; it++) {
@@ -435,12 +466,17 @@ template <int LOGN, bool LEAN, bool CR, bool FP> __device__ __forceinline__ void
         const unsigned u = lane + 64 * it;
         u64 y[8];
         const unsigned b12 = 128 * sb + u;
-        const Shoup t12 = FP ? ld_tw8(pd.root, 128 * A + b12) : ld_tw(pd.root, 128 * A + b12);
+        const Shoup t12 = FP ? ld_w1(pd.root_w, 128 * A + b12) : ld_tw(pd.root, 128 * A + b12);
         Shoup t13[2], t14[4];
+        if constexpr (FP) {
+            ld_w2(pd.root_w, 256 * A + 2 * b12, t13);
+            ld_w4(pd.root_w, 512 * A + 4 * b12, t14);
+        } else {
 #pragma unroll
-        for (int i = 0; i < 2; i++) t13[i] = FP ? ld_tw8(pd.root, 256 * A + 2 * b12 + i) : ld_tw(pd.root, 256 * A + 2 * b12 + i);
+        for (int i = 0; i < 2; i++) t13[i] = ld_tw(pd.root, 256 * A + 2 * b12 + i);
 #pragma unroll
-        for (int i = 0; i < 4; i++) t14[i] = FP ? ld_tw8(pd.root, 512 * A + 4 * b12 + i) : ld_tw(pd.root, 512 * A + 4 * b12 + i);
+        for (int i = 0; i < 4; i++) t14[i] = ld_tw(pd.root, 512 * A + 4 * b12 + i);
+        }
         const unsigned wr2 = rb + 8 * sw1(8 * lane) ^ (it ? 8 * sw1(512) : 0u), ww2 = rb + 8 * wb_swz(8 * lane) ^ (it ? 8 * wb_swz(512) : 0u);
 #pragma unroll
         for (int q = 0; q < 4; q++) {
@@ -735,11 +771,16 @@ template <int LOGN, bool LEAN, bool FP> __device__ __forceinline__ void inv_subb
         for (int r = 0; r < 8; r++) y[r] = yin[8 * it + r];
         const unsigned b12 = 128 * sb + u;
         Shoup t14[4], t13[2];
+        if constexpr (FP) { // iroot_w is iroot shifted by the "+ 1" of every stage offset: the groups are aligned
+            ld_w4(pd.iroot_w, 4 * b12, t14);
+            ld_w2(pd.iroot_w, NN / 2 + 2 * b12, t13);
+        } else {
 #pragma unroll
-        for (int i = 0; i < 4; i++) t14[i] = FP ? ld_tw8(pd.iroot, 1 + 4 * b12 + i) : ld_tw(pd.iroot, 1 + 4 * b12 + i);
+        for (int i = 0; i < 4; i++) t14[i] = ld_tw(pd.iroot, 1 + 4 * b12 + i);
 #pragma unroll
-        for (int i = 0; i < 2; i++) t13[i] = FP ? ld_tw8(pd.iroot, NN / 2 + 1 + 2 * b12 + i) : ld_tw(pd.iroot, NN / 2 + 1 + 2 * b12 + i);
-        const Shoup t12 = FP ? ld_tw8(pd.iroot, NN - NN / 4 + 1 + b12) : ld_tw(pd.iroot, NN - NN / 4 + 1 + b12);
+        for (int i = 0; i < 2; i++) t13[i] = ld_tw(pd.iroot, NN / 2 + 1 + 2 * b12 + i);
+        }
+        const Shoup t12 = FP ? ld_w1(pd.iroot_w, NN - NN / 4 + b12) : ld_tw(pd.iroot, NN - NN / 4 + 1 + b12);
         if constexpr (FP) fp_inv_stages<1, 3, false, 0, 3, true>(y, [&](int st, int, int blk) { return st == 0 ? t14[blk] : (st == 1 ? t13[blk] : t12); }, none, fc);
         else if constexpr (LEAN) // inputs below 2p (stored limbs are canonical) -> 16p at most (register 0), no reduction
         inv_stages_lean<1, 3, false, false, 2, 64>(y, [&](int st, int, int blk) { return st == 0 ? t14[blk] : (st == 1 ? t13[blk] : t12); }, none, (u32)pd.cr1, pc);
@@ -760,11 +801,16 @@ template <int LOGN, bool LEAN, bool FP> __device__ __forceinline__ void inv_subb
         const unsigned h = lane >> 2, low = lane & 3;
         const unsigned b9 = 16 * sb + h;
         Shoup t11[4], t10[2];
+        if constexpr (FP) {
+            ld_w4(pd.iroot_w, NN - NN / 8 + 4 * b9, t11);
+            ld_w2(pd.iroot_w, NN - NN / 16 + 2 * b9, t10);
+        } else {
 #pragma unroll
-        for (int i = 0; i < 4; i++) t11[i] = FP ? ld_tw8(pd.iroot, NN - NN / 8 + 1 + 4 * b9 + i) : ld_tw(pd.iroot, NN - NN / 8 + 1 + 4 * b9 + i);
+        for (int i = 0; i < 4; i++) t11[i] = ld_tw(pd.iroot, NN - NN / 8 + 1 + 4 * b9 + i);
 #pragma unroll
-        for (int i = 0; i < 2; i++) t10[i] = FP ? ld_tw8(pd.iroot, NN - NN / 16 + 1 + 2 * b9 + i) : ld_tw(pd.iroot, NN - NN / 16 + 1 + 2 * b9 + i);
-        const Shoup t9 = FP ? ld_tw8(pd.iroot, NN - NN / 32 + 1 + b9) : ld_tw(pd.iroot, NN - NN / 32 + 1 + b9);
+        for (int i = 0; i < 2; i++) t10[i] = ld_tw(pd.iroot, NN - NN / 16 + 1 + 2 * b9 + i);
+        }
+        const Shoup t9 = FP ? ld_w1(pd.iroot_w, NN - NN / 32 + b9) : ld_tw(pd.iroot, NN - NN / 32 + 1 + b9);
         const unsigned wc0 = rb + 8 * sw2(64 * h + low); // j = 64 h + 8 r + 4 it + low: lane in bits 0, 1, 6..9, (r, it) in bits 2..5
 #pragma unroll 1
         for (unsigned it = 0; it < 2; it++) {
