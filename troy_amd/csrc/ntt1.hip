@@ -108,9 +108,13 @@ __device__ __forceinline__ unsigned sw1(unsigned j) { return j ^ (((j >> 6) & 7u
 #ifndef N1_INV_SWZ
 #define N1_INV_SWZ 2
 #endif
-#ifndef N1_INV_TOP
-#define N1_INV_TOP 0 // top of an inverse row: 0 request the second half, then drain; 1 drain, then request; 2 request, then wait for all but those eight loads
+#ifndef N1_INV_EXP
+#define N1_INV_EXP 0 // removal probes of the N = 2^15 inverse body (wrong results; tools/ntt_probe.sh name:-DN1_INV_EXP=k): 1 no global reads, 2 no global writes, 4 no workgroup barriers
 #endif
+#ifndef N1_INV_TOP
+#define N1_INV_TOP 0 // where an inverse row waits for its LDS-DMA staged half: 0 at the top of the row (after requesting the second half); probes, all measured
+#endif               // NEUTRAL in round 5 (profiles/r05_inv_probes.txt): 1 drain then request, 2 request then vmcnt(8), 3 wait BEFORE the previous row's stores
+
 __device__ __forceinline__ unsigned sw2(unsigned j) { return N1_INV_SWZ == 2 ? sw1(j) ^ (((j >> 4) & 1u) << 2) : sw1(j); }
 #ifndef N1_FWD_WB_SW1
 #define N1_FWD_WB_SW1 0 // 1 (probe): the forward kernels' write-back for the lane-linear stores under sw1 (2-way conflicted 16-byte writes)
@@ -872,11 +876,17 @@ template <bool LEAN, bool MD, bool FP> __device__ __forceinline__ void ntt1_inv_
     // LDS-DMA staging of a sub-block into the wave's region, already in sw1 order: instruction i fills bytes [1024 i, 1024 i + 1024)
     // of the region lane-linearly, so lane l fetches the 16-byte unit that belongs at position 128 i + 2 l (sw1 is an involution)
     auto stage_issue = [&](const u64 *sub) {
+        if (N1_INV_EXP & 1) return;
         const unsigned l = opaque(lane);
 #pragma unroll
         for (int i = 0; i < 8; i++) TROY_GLDS16(sub + sw2_inv(128 * i + 2 * l), region + 128 * i);
     };
     auto load16 = [&](u64 (&y)[16], const u64 *sub) { // y[8 i + r] = coefficient 8 (lane + 64 i) + r
+        if (N1_INV_EXP & 1) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) y[i] = (u64)(opaque(lane) + 64 * i) * 0x9E3779B97F4A7C15ull >> 7;
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < 2; i++)
 #pragma unroll
@@ -893,6 +903,9 @@ template <bool LEAN, bool MD, bool FP> __device__ __forceinline__ void ntt1_inv_
         return a.src + (u64)o * a.src_ostride + ((u64)(slot * inner + k) << N1_LOGN);
     };
     stage_issue(in_of(m_begin) + 1024 * wv);
+#if N1_INV_TOP == 3
+    TROY_WAIT_VMEM(); // the first row's staged half (every later row's is waited for in front of the previous row's stores, below)
+#endif
     // two base registers for the 32 exchange reads: the immediate offset of a ds_read reaches 64 KiB, so rlo + 8 KiB r and rhi + 8 KiB r need nothing else.
     // (rhi's base is made opaque: the compiler otherwise folds the 64 KiB into EIGHT per-lane addresses it keeps live across the row loop, and spills)
     const u64 *const rlo = lds + sw2(tid), *const rhi = lds_at(lds, opaque(8 * (8 * 1024 + sw2(tid))));
@@ -900,7 +913,12 @@ template <bool LEAN, bool MD, bool FP> __device__ __forceinline__ void ntt1_inv_
         u64 *const row = a.data + row_of(mm);
         u64 x[32]; // x[r] = coefficient tid of sub-block r after its 10 stages
         u64 y[16], y1[16];
-#if N1_INV_TOP == 0 || defined(TROYHIP_CPU_EMUL)
+#if N1_INV_TOP == 3
+        // probe: the staged half was waited for when nothing younger than it was in flight (before the previous row's stores), so no wait here has a fresh
+        // store in front of it.  Measured neutral: what the removal probe N1_INV_EXP = 2 attributes to the stores (10 % of the integer kernel, a third of the
+        // FP64 one) is their HBM traffic, not a drain at this point.
+        load16(y1, in_of(mm) + 1024 * (16 + wv));
+#elif N1_INV_TOP == 0 || defined(TROYHIP_CPU_EMUL)
         load16(y1, in_of(mm) + 1024 * (16 + wv)); // second half's input: in flight while the first half is transformed
         TROY_WAIT_VMEM();                   // the staged first half has landed (vmcnt counts in order: this also waits for y1)
 #elif N1_INV_TOP == 1 // probe: the second half requested AFTER the wait for the staged first half -- its latency sits under the first half's ten stages
@@ -924,10 +942,10 @@ template <bool LEAN, bool MD, bool FP> __device__ __forceinline__ void ntt1_inv_
 #pragma unroll
         for (int hf = 0; hf < 2; hf++) {
             inv_subblock<N1_LOGN, LEAN, FP>(hf ? y1 : y, lds, 1024 * wv, 16 * hf + wv, lane, pd, pc, fc, a.fp_red_mask);
-            __syncthreads();
+            if (N1_INV_EXP & 4) TROY_WAVE_SYNC(); else __syncthreads();
 #pragma unroll
             for (int r = 0; r < 8; r++) { x[16 * hf + r] = rlo[1024 * r]; x[16 * hf + 8 + r] = rhi[1024 * r]; }
-            __syncthreads();
+            if (N1_INV_EXP & 4) TROY_WAVE_SYNC(); else __syncthreads();
         }
         if (mm + 1 < m_end) stage_issue(in_of(mm + 1) + 1024 * wv); // the regions are free during round A'
         // round A': stages 4..0 across the 32 sub-blocks, N^-1 folded into the last one
@@ -970,6 +988,9 @@ template <bool LEAN, bool MD, bool FP> __device__ __forceinline__ void ntt1_inv_
             u64 *dst = a.md_ct + (u64)(mm >> 1) * a.md_ct_bstride + (((u64)(mm & 1) * a.md_dl + slot) << N1_LOGN);
             const u64 *onto = !a.md_base ? dst : ((int)(mm & 1) >= a.md_base_polys) ? nullptr : a.md_base + (u64)(mm >> 1) * a.md_base_bstride + (((u64)(mm & 1) * a.md_dl + slot) << N1_LOGN);
             const Shoup iq[4] = {pd.aux, pd.aux, pd.aux, pd.aux};
+#if N1_INV_TOP == 3
+            TROY_WAIT_VMEM(); // the next row's staged half has landed (issued a round ago): waited for HERE, before this row's first store
+#endif
 #pragma unroll
             for (int g = 0; g < 8; g++) { // four coefficients at a time through the butterfly building blocks (bfly.h); x[] stays in registers
                 u64 tl[4], c[4], q[4];
@@ -990,12 +1011,20 @@ template <bool LEAN, bool MD, bool FP> __device__ __forceinline__ void ntt1_inv_
                 csub4(c, pc.two_p);
                 csub4(c, pc.p);
 #pragma unroll
-                for (int i = 0; i < 4; i++) st_g(dst, t + 1024 * (4 * g + i), c[i]);
+                for (int i = 0; i < 4; i++) {
+                    // (keeping the 32 results in x[] and storing them after the last operand load -- no load ever waited for behind a store -- spills 200-300 B:
+                    // the epilogue's branches on `onto` leave the allocator no room.  The groups' own stores stay between their loads.)
+                    st_g(dst, t + 1024 * (4 * g + i), c[i]);
+                }
             }
         } else {
             const unsigned t = opaque(tid);
+#if N1_INV_TOP == 3
+            TROY_WAIT_VMEM(); // the next row's staged half has landed (issued a round ago): waited for HERE, while no store is in flight
+#endif
 #pragma unroll
-            for (int r = 0; r < 32; r++) st_g(row, t + 1024 * r, x[r]);
+            for (int r = 0; r < 32; r++)
+                if (!(N1_INV_EXP & 2) || x[r] == 0x123456789abcdefull) st_g(row, t + 1024 * r, x[r]);
         }
     }
 }
