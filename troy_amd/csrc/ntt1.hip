@@ -217,10 +217,20 @@ __device__ __forceinline__ void st_g(u64 *base, unsigned off, u64 v) { base[off]
 __device__ __forceinline__ ulonglong2 ld_g2(const u64 *base, unsigned off) { return *reinterpret_cast<const ulonglong2 *>(base + off); }
 __device__ __forceinline__ void st_g2(u64 *base, unsigned off, ulonglong2 v) { *reinterpret_cast<ulonglong2 *>(base + off) = v; }
 #else
-__device__ __forceinline__ u64 ld_g(const u64 *base, unsigned off) { return ((const __attribute__((address_space(1))) u64 *)base)[off]; }
-__device__ __forceinline__ void st_g(u64 *base, unsigned off, u64 v) { ((__attribute__((address_space(1))) u64 *)base)[off] = v; }
+#ifndef N1_NT
+#define N1_NT 0 // probe: non-temporal row accesses (1 stores, 2 loads, 3 both): the rows stream through once, the twiddle tables are what L2 should keep
+#endif
+__device__ __forceinline__ u64 ld_g(const u64 *base, unsigned off) {
+    if (N1_NT & 2) return __builtin_nontemporal_load(((const __attribute__((address_space(1))) u64 *)base) + off);
+    return ((const __attribute__((address_space(1))) u64 *)base)[off];
+}
+__device__ __forceinline__ void st_g(u64 *base, unsigned off, u64 v) {
+    if (N1_NT & 1) { __builtin_nontemporal_store(v, ((__attribute__((address_space(1))) u64 *)base) + off); return; }
+    ((__attribute__((address_space(1))) u64 *)base)[off] = v;
+}
 __device__ __forceinline__ ulonglong2 ld_g2(const u64 *base, unsigned off) { // off even: 16 bytes
-    const troy_v2ull v = *(const __attribute__((address_space(1))) troy_v2ull *)(((const __attribute__((address_space(1))) u64 *)base) + off);
+    const troy_v2ull v = (N1_NT & 2) ? __builtin_nontemporal_load((const __attribute__((address_space(1))) troy_v2ull *)(((const __attribute__((address_space(1))) u64 *)base) + off))
+                                     : *(const __attribute__((address_space(1))) troy_v2ull *)(((const __attribute__((address_space(1))) u64 *)base) + off);
     ulonglong2 r;
     r.x = v.x;
     r.y = v.y;
@@ -230,6 +240,7 @@ __device__ __forceinline__ void st_g2(u64 *base, unsigned off, ulonglong2 v) {
     troy_v2ull w;
     w.x = v.x;
     w.y = v.y;
+    if (N1_NT & 1) { __builtin_nontemporal_store(w, (__attribute__((address_space(1))) troy_v2ull *)(((__attribute__((address_space(1))) u64 *)base) + off)); return; }
     *(__attribute__((address_space(1))) troy_v2ull *)(((__attribute__((address_space(1))) u64 *)base) + off) = w;
 }
 #endif
