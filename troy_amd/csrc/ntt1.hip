@@ -213,15 +213,21 @@ __device__ __forceinline__ unsigned uniform_u32(unsigned v) {
 // data access with a wave-uniform base and a per-lane 32-bit element offset (global_load/store ... saddr form: no 64-bit address VGPRs)
 #ifdef TROYHIP_CPU_EMUL
 __device__ __forceinline__ u64 ld_g(const u64 *base, unsigned off) { return base[off]; }
+__device__ __forceinline__ u64 ld_g_fwd(const u64 *base, unsigned off) { return base[off]; }
 __device__ __forceinline__ void st_g(u64 *base, unsigned off, u64 v) { base[off] = v; }
 __device__ __forceinline__ ulonglong2 ld_g2(const u64 *base, unsigned off) { return *reinterpret_cast<const ulonglong2 *>(base + off); }
 __device__ __forceinline__ void st_g2(u64 *base, unsigned off, ulonglong2 v) { *reinterpret_cast<ulonglong2 *>(base + off) = v; }
 #else
 #ifndef N1_NT
-#define N1_NT 0 // probe: non-temporal row accesses (1 stores, 2 loads, 3 both): the rows stream through once, the twiddle tables are what L2 should keep
-#endif
+#define N1_NT 0 // probe: non-temporal row accesses (bit 0 stores, bit 1 every row load, bit 2 the forward kernels' row loads only).  Same-box A/B
+#endif          // (profiles/r05_inv_probes.txt): standalone, stores -1.5 % on the integer inverse and loads -2 % on the forward kernel (+2 % on the inverse);
+                // inside the steps the consumers of those rows lose what L2 / MALL held for them: headline +0.4 %, 49-bit twin -0.8 %, CKKS chain +-0.5 %.  Off.
 __device__ __forceinline__ u64 ld_g(const u64 *base, unsigned off) {
     if (N1_NT & 2) return __builtin_nontemporal_load(((const __attribute__((address_space(1))) u64 *)base) + off);
+    return ((const __attribute__((address_space(1))) u64 *)base)[off];
+}
+__device__ __forceinline__ u64 ld_g_fwd(const u64 *base, unsigned off) { // the forward kernels' row loads
+    if (N1_NT & 6) return __builtin_nontemporal_load(((const __attribute__((address_space(1))) u64 *)base) + off);
     return ((const __attribute__((address_space(1))) u64 *)base)[off];
 }
 __device__ __forceinline__ void st_g(u64 *base, unsigned off, u64 v) {
@@ -636,7 +642,7 @@ template <bool LEAN, bool CR, bool FP> __device__ __forceinline__ void ntt1_fwd_
     auto load_half = [&](u64 (&x)[16], const u64 *rowp, unsigned odd) {
         const unsigned t = opaque(tid); // the 16 offsets are formed here, next to the loads, not carried through the kernel
 #pragma unroll
-        for (int r = 0; r < 16; r++) x[r] = ld_g(rowp, t + 2048 * r + 1024 * odd);
+        for (int r = 0; r < 16; r++) x[r] = ld_g_fwd(rowp, t + 2048 * r + 1024 * odd);
     };
     load_half(xe, in_row(m_begin), 0);
     load_half(xo, in_row(m_begin), 1);
@@ -1080,7 +1086,7 @@ template <int LOGN, bool LEAN, bool FP> __device__ __forceinline__ void ntt1s_fw
 #pragma unroll
         for (int g = 0; g < G; g++)
 #pragma unroll
-            for (int h = 0; h < NSUB; h++) y[(g << LOGA) + h] = ld_g(rowp, t + T * (h * G + g));
+            for (int h = 0; h < NSUB; h++) y[(g << LOGA) + h] = ld_g_fwd(rowp, t + T * (h * G + g));
     };
     load_row(in_base + row_of(m_begin));
     const Ntt1Args &args = a;
