@@ -1,7 +1,7 @@
 #!/bin/bash
 # AddressSanitizer over the kernel sources, on the CPU: the emulator build of libtroyhip (tests/emul/hip_emul.h) compiled with
-# -fsanitize=address, driven through the BEHZ kernels at every limb count, random parameter sets, the single-pass NTT, and the two C++
-# shim tests.  LDS arrays are globals and device allocations are heap blocks there, so out-of-range indexing shows up.  (GPU sanitizers are
+# -fsanitize=address, driven through the BEHZ kernels at every limb count, random parameter sets, the single-pass NTT, the two C++
+# shim tests and the wire-format dumper.  LDS arrays are globals and device allocations are heap blocks there, so out-of-range indexing shows up.  (GPU sanitizers are
 # not available on the pool.)  usage: tools/asan_check.sh
 set -e
 cd "$(dirname "$0")/.."
@@ -19,3 +19,6 @@ for t in test_troyn test_troyn_app; do
     g++ -std=c++17 -O1 -g -fsanitize=address -fno-omit-frame-pointer -Iinclude tests/cpp/$t.cpp -o /tmp/${t}_asan /tmp/libtroyhip_emul_asan.so -Wl,-rpath,/tmp
     /tmp/${t}_asan | grep -E "FAIL|ALL OK"
 done
+# the serializers and their loader fuzz (truncated streams, oversized size fields)
+g++ -std=c++17 -O1 -g -fsanitize=address -fno-omit-frame-pointer -Iinclude tests/cpp/dump_wire.cpp -o /tmp/dump_wire_asan /tmp/libtroyhip_emul_asan.so -Wl,-rpath,/tmp
+mkdir -p /tmp/wire_asan && /tmp/dump_wire_asan /tmp/wire_asan | grep -E "FAIL|ALL OK"

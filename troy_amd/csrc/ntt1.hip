@@ -111,6 +111,9 @@ __device__ __forceinline__ unsigned sw1(unsigned j) { return j ^ (((j >> 6) & 7u
 #ifndef N1_INV_EXP
 #define N1_INV_EXP 0 // removal probes of the N = 2^15 inverse body (wrong results; tools/ntt_probe.sh name:-DN1_INV_EXP=k): 1 no global reads, 2 no global writes, 4 no workgroup barriers
 #endif
+#ifndef N1_NT_INV
+#define N1_NT_INV 0 // non-temporal stores in the INTEGER N = 2^15 inverse kernels: bit 0 the plain rows, bit 1 the mod-down epilogue's
+#endif
 #ifndef N1_INV_TOP
 #define N1_INV_TOP 0 // where an inverse row waits for its LDS-DMA staged half: 0 at the top of the row (after requesting the second half); probes, all measured
 #endif               // NEUTRAL in round 5 (profiles/r05_inv_probes.txt): 1 drain then request, 2 request then vmcnt(8), 3 wait BEFORE the previous row's stores
@@ -215,6 +218,7 @@ __device__ __forceinline__ unsigned uniform_u32(unsigned v) {
 __device__ __forceinline__ u64 ld_g(const u64 *base, unsigned off) { return base[off]; }
 __device__ __forceinline__ u64 ld_g_fwd(const u64 *base, unsigned off) { return base[off]; }
 __device__ __forceinline__ void st_g(u64 *base, unsigned off, u64 v) { base[off] = v; }
+template <bool NT> __device__ __forceinline__ void st_g_inv(u64 *base, unsigned off, u64 v) { base[off] = v; }
 __device__ __forceinline__ ulonglong2 ld_g2(const u64 *base, unsigned off) { return *reinterpret_cast<const ulonglong2 *>(base + off); }
 __device__ __forceinline__ void st_g2(u64 *base, unsigned off, ulonglong2 v) { *reinterpret_cast<ulonglong2 *>(base + off) = v; }
 #else
@@ -232,6 +236,11 @@ __device__ __forceinline__ u64 ld_g_fwd(const u64 *base, unsigned off) { // the 
 }
 __device__ __forceinline__ void st_g(u64 *base, unsigned off, u64 v) {
     if (N1_NT & 1) { __builtin_nontemporal_store(v, ((__attribute__((address_space(1))) u64 *)base) + off); return; }
+    ((__attribute__((address_space(1))) u64 *)base)[off] = v;
+}
+// the stores of the N = 2^15 inverse kernels; NT: streamed past L2's replacement order (N1_NT_INV below)
+template <bool NT> __device__ __forceinline__ void st_g_inv(u64 *base, unsigned off, u64 v) {
+    if (NT || (N1_NT & 1)) { __builtin_nontemporal_store(v, ((__attribute__((address_space(1))) u64 *)base) + off); return; }
     ((__attribute__((address_space(1))) u64 *)base)[off] = v;
 }
 __device__ __forceinline__ ulonglong2 ld_g2(const u64 *base, unsigned off) { // off even: 16 bytes
@@ -1031,7 +1040,7 @@ template <bool LEAN, bool MD, bool FP> __device__ __forceinline__ void ntt1_inv_
                 for (int i = 0; i < 4; i++) {
                     // (keeping the 32 results in x[] and storing them after the last operand load -- no load ever waited for behind a store -- spills 200-300 B:
                     // the epilogue's branches on `onto` leave the allocator no room.  The groups' own stores stay between their loads.)
-                    st_g(dst, t + 1024 * (4 * g + i), c[i]);
+                    st_g_inv<!FP && (N1_NT_INV & 2)>(dst, t + 1024 * (4 * g + i), c[i]);
                 }
             }
         } else {
@@ -1041,7 +1050,7 @@ template <bool LEAN, bool MD, bool FP> __device__ __forceinline__ void ntt1_inv_
 #endif
 #pragma unroll
             for (int r = 0; r < 32; r++)
-                if (!(N1_INV_EXP & 2) || x[r] == 0x123456789abcdefull) st_g(row, t + 1024 * r, x[r]);
+                if (!(N1_INV_EXP & 2) || x[r] == 0x123456789abcdefull) st_g_inv<!FP && (N1_NT_INV & 1)>(row, t + 1024 * r, x[r]);
         }
     }
 }
