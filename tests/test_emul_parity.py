@@ -253,9 +253,10 @@ def test_emulated_single_pass_ntt_row_loop_and_prime_classes(oracle_lib, tmp_pat
         "ctx.ntt(buf2, rows2, primes, inner=2)\n"
         "assert np.array_equal(buf2.to_numpy().reshape(rows2, N), e)\n"
         "print('ok')\n" % (ROOT, os.path.join(ROOT, 'tests'), EMUL))
-    for rpw in ("3", "1"):
-        # small launches go to the two-pass kernels by default; the reference's auxiliary base supplies the 61-bit prime of the guarded class
-        env = dict(os.environ, TROYHIP_NTT1_RPW=rpw, TROYHIP_NTT="single", TROYHIP_AUX_BASE="reference")
+    for rpw, xcd in (("3", "0"), ("1", "0"), ("3", "1"), ("1", "1")):
+        # small launches go to the two-pass kernels by default; the reference's auxiliary base supplies the 61-bit prime of the guarded class.
+        # TROYHIP_NTT1_XCD = 1: the XCD-aware workgroup -> (prime, chunk) mapping of large grids, with its padded last eighth, at this size
+        env = dict(os.environ, TROYHIP_NTT1_RPW=rpw, TROYHIP_NTT1_XCD=xcd, TROYHIP_NTT="single", TROYHIP_AUX_BASE="reference")
         out = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=900)
         assert out.returncode == 0 and "ok" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
 

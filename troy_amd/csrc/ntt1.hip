@@ -46,6 +46,7 @@ struct Ntt1Args {
     unsigned rows_per_wg;
     unsigned chunks;      // ceil(m_total / rows_per_wg)
     unsigned nslots;      // a launch covers the prime slots slots[0 .. nslots) of the pattern (one launch per prime class)
+    unsigned xcd_per;     // != 0: the grid is 8 * xcd_per workgroups and workgroup b takes unit (b % 8) * xcd_per + b / 8 of the slot-major list (n1_unit)
     uint8_t slots[64];
     // forward only: divide-and-round correction (Ntt1Corr): rows are BUILT from cr_last on load and COMBINED with cr_in on store
     const u64 *cr_last, *cr_in;
@@ -114,6 +115,31 @@ __device__ __forceinline__ unsigned sw1(unsigned j) { return j ^ (((j >> 6) & 7u
 #ifndef N1_NT_INV
 #define N1_NT_INV 0 // non-temporal stores in the INTEGER N = 2^15 inverse kernels: bit 0 the plain rows, bit 1 the mod-down epilogue's
 #endif
+// workgroup -> unit of the slot-major list (slot, chunk).  The hardware deals consecutive workgroups to the 8 XCDs in turn; with the flat mapping every XCD
+// therefore works on every prime in flight (2-4 at a time: each a 1 MiB twiddle table competing for that XCD's 4 MiB of L2 with the rows streaming through).
+// XCD-aware: XCD x walks its own contiguous eighth of the list, one prime at a time.
+#ifndef N1_XCD
+#define N1_XCD 1
+#endif
+__device__ __forceinline__ bool n1_unit(const Ntt1Args &a, unsigned &unit) {
+    unit = blockIdx.x;
+    if (a.xcd_per) {
+        unit = (blockIdx.x & 7u) * a.xcd_per + (blockIdx.x >> 3);
+        if (unit >= a.nslots * a.chunks) return false; // the padding of the last eighth
+    }
+    return true;
+}
+#ifndef N1_STAGGER
+#define N1_STAGGER 0 // probe: the workgroups of a launch's first round start N1_STAGGER x 3.9 us x ((blockIdx / 8) % 8) late -- are the CUs of an XCD phase-aligned (bursty traffic)?
+#endif
+__device__ __forceinline__ void n1_stagger() {
+#if N1_STAGGER && !defined(TROYHIP_CPU_EMUL)
+    if (blockIdx.x < 256) {
+        const unsigned ph = (blockIdx.x >> 3) & 7;
+        for (unsigned i = 0; i < ph * N1_STAGGER; i++) __builtin_amdgcn_s_sleep(127);
+    }
+#endif
+}
 #ifndef N1_INV_TOP
 #define N1_INV_TOP 0 // where an inverse row waits for its LDS-DMA staged half: 0 at the top of the row (after requesting the second half); probes, all measured
 #endif               // NEUTRAL in round 5 (profiles/r05_inv_probes.txt): 1 drain then request, 2 request then vmcnt(8), 3 wait BEFORE the previous row's stores
@@ -625,7 +651,9 @@ template <bool LEAN, bool CR, bool FP> __device__ __forceinline__ void ntt1_fwd_
     const unsigned wv = __builtin_amdgcn_readfirstlane(tid >> 6);
 #endif
     // the byte tables of the argument block are read with vector loads: tell the compiler the results are wave-uniform
-    const unsigned slot = uniform_u32(a.slots[blockIdx.x / a.chunks]), chunk = blockIdx.x % a.chunks;
+    unsigned unit;
+    if (!n1_unit(a, unit)) return;
+    const unsigned slot = uniform_u32(a.slots[unit / a.chunks]), chunk = unit % a.chunks;
     PrimeDesc pd = a.primes[uniform_u32(a.map.id[slot])];
     if constexpr (FP) pd.root = pd.root_fp;
     const FpPrime fc = make_fp_prime_uniform(FP ? pd.p : 1);
@@ -644,6 +672,7 @@ template <bool LEAN, bool CR, bool FP> __device__ __forceinline__ void ntt1_fwd_
     const Shoup cr_inv = CR ? Shoup{((const u64 *)(a.cr_inv + slot))[0], ((const u64 *)(a.cr_inv + slot))[1]} : Shoup{0, 0};
     const u64 cr_add = CR ? pd.p - barrett64(a.cr_half, m) : 0; // p - [half]_p
     u64 *const region = lds + 1024 * wv;
+    n1_stagger();
     // registers of round A: xe[r'] = coefficient 1024 (2 r') + tid, xo[r'] = coefficient 1024 (2 r' + 1) + tid
     u64 xe[16], xo[16];
     // loads and stores of round A: ONE wave-uniform base (the limb) plus a 32-bit per-thread offset (one v_add per access; 32
@@ -886,7 +915,9 @@ template <bool LEAN, bool MD, bool FP> __device__ __forceinline__ void ntt1_inv_
     const unsigned wv = __builtin_amdgcn_readfirstlane(tid >> 6);
 #endif
     // the byte tables of the argument block are read with vector loads: tell the compiler the results are wave-uniform
-    const unsigned slot = uniform_u32(a.slots[blockIdx.x / a.chunks]), chunk = blockIdx.x % a.chunks;
+    unsigned unit;
+    if (!n1_unit(a, unit)) return;
+    const unsigned slot = uniform_u32(a.slots[unit / a.chunks]), chunk = unit % a.chunks;
     PrimeDesc pd = a.primes[uniform_u32(a.map.id[slot])];
     if constexpr (FP) { pd.iroot = pd.iroot_fp; pd.inv_n = pd.inv_n_fp; pd.iroot_last_scaled = pd.iroot_last_scaled_fp; }
     const FpPrime fc = make_fp_prime_uniform(FP ? pd.p : 1);
@@ -928,6 +959,7 @@ template <bool LEAN, bool MD, bool FP> __device__ __forceinline__ void ntt1_inv_
         const unsigned o = mm / inner, k = mm - o * inner;
         return a.src + (u64)o * a.src_ostride + ((u64)(slot * inner + k) << N1_LOGN);
     };
+    n1_stagger();
     stage_issue(in_of(m_begin) + 1024 * wv);
 #if N1_INV_TOP == 3
     TROY_WAIT_VMEM(); // the first row's staged half (every later row's is waited for in front of the previous row's stores, below)
@@ -1074,7 +1106,9 @@ template <int LOGN, bool LEAN, bool FP> __device__ __forceinline__ void ntt1s_fw
 #else
     const unsigned wv = __builtin_amdgcn_readfirstlane(tid >> 6);
 #endif
-    const unsigned slot = uniform_u32(a.slots[blockIdx.x / a.chunks]), chunk = blockIdx.x % a.chunks;
+    unsigned unit;
+    if (!n1_unit(a, unit)) return;
+    const unsigned slot = uniform_u32(a.slots[unit / a.chunks]), chunk = unit % a.chunks;
     PrimeDesc pd = a.primes[uniform_u32(a.map.id[slot])];
     if constexpr (FP) pd.root = pd.root_fp;
     const FpPrime fc = make_fp_prime_uniform(FP ? pd.p : 1);
@@ -1135,7 +1169,9 @@ template <int LOGN, bool LEAN, bool MD, bool FP> __device__ __forceinline__ void
 #else
     const unsigned wv = __builtin_amdgcn_readfirstlane(tid >> 6);
 #endif
-    const unsigned slot = uniform_u32(a.slots[blockIdx.x / a.chunks]), chunk = blockIdx.x % a.chunks;
+    unsigned unit;
+    if (!n1_unit(a, unit)) return;
+    const unsigned slot = uniform_u32(a.slots[unit / a.chunks]), chunk = unit % a.chunks;
     PrimeDesc pd = a.primes[uniform_u32(a.map.id[slot])];
     if constexpr (FP) { pd.iroot = pd.iroot_fp; pd.inv_n = pd.inv_n_fp; pd.iroot_last_scaled = pd.iroot_last_scaled_fp; }
     const FpPrime fc = make_fp_prime_uniform(FP ? pd.p : 1);
@@ -1312,6 +1348,7 @@ void launch_ntt1(u64 *data, const u64 *src, const PrimeDesc *primes, const LimbM
     // per CU" left mid-size launches with a mostly idle last round.
     const unsigned cus = device_cus() * ntt1_wgs_per_cu(logn); // workgroup slots of the chip
     static const unsigned forced_rpw = [] { const char *e = probe_env("TROYHIP_NTT1_RPW"); return e ? (unsigned)std::atoi(e) : 0u; }(); // tests: row loop at small batches
+    static const int forced_xcd = [] { const char *e = probe_env("TROYHIP_NTT1_XCD"); return e ? std::atoi(e) : -1; }();
     auto plan = [&](unsigned nslots) { // -> rows per workgroup for a launch over `nslots` primes
         if (forced_rpw) return forced_rpw;
         unsigned best = 1;
@@ -1358,6 +1395,9 @@ void launch_ntt1(u64 *data, const u64 *src, const PrimeDesc *primes, const LimbM
         stats::counter(kind == 2 ? stats::NTT1_FP_LAUNCHES : stats::NTT1_INT_LAUNCHES).fetch_add(1, std::memory_order_relaxed);
         a.rows_per_wg = plan(a.nslots);
         a.chunks = (a.m_total + a.rows_per_wg - 1) / a.rows_per_wg;
+        // one prime, or a grid the chip holds at once: nothing to separate (probe builds: TROYHIP_NTT1_XCD = 1 always / 0 never, for the tests)
+        const bool xcd = forced_xcd >= 0 ? forced_xcd != 0 : (N1_XCD && a.nslots > 1 && a.nslots * a.chunks >= 2 * cus);
+        a.xcd_per = xcd ? (a.nslots * a.chunks + 7) / 8 : 0;
         cls[ncls].a = a;
         cls[ncls].lean = kind != 0;
         cls[ncls++].fp = kind == 2;
@@ -1365,7 +1405,7 @@ void launch_ntt1(u64 *data, const u64 *src, const PrimeDesc *primes, const LimbM
     auto launch_small = [&](const Cls &k, hipStream_t st, auto logn_tag) { // N = 2^12 .. 2^14 (ntt1s_*)
         constexpr int LN = decltype(logn_tag)::value;
         const Ntt1Args &x = k.a;
-        const dim3 grid(x.nslots * x.chunks), block(64u << (LN - 10));
+        const dim3 grid(x.xcd_per ? 8 * x.xcd_per : x.nslots * x.chunks), block(64u << (LN - 10));
 #ifndef TROYHIP_CPU_EMUL
         if (ktime::enabled) { // the instance's name as rocprofv3 prints it (the launch macro would say "LN")
             static thread_local char tagbuf[64];
@@ -1393,7 +1433,7 @@ void launch_ntt1(u64 *data, const u64 *src, const PrimeDesc *primes, const LimbM
         if (logn == 13) { launch_small(k, st, std::integral_constant<int, 13>{}); return; }
         if (logn == 12) { launch_small(k, st, std::integral_constant<int, 12>{}); return; }
         const Ntt1Args &x = k.a;
-        const dim3 grid(x.nslots * x.chunks);
+        const dim3 grid(x.xcd_per ? 8 * x.xcd_per : x.nslots * x.chunks);
         if (k.fp) {
             if (inverse) {
                 if (x.md_ct) TROY_LAUNCH(HIP_KERNEL_NAME(ntt1_inv_fp_kernel<true>), grid, dim3(N1_THREADS), 0, st, x);
