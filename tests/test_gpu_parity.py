@@ -177,6 +177,23 @@ def test_single_pass_ntt_vs_oracle_incl_extremes(gpu, oracle_lib):
         assert capi.stat("ntt1_fp_launches") == fp0 + fp_expected, "FP64 single-pass instances: the 40- and 50-bit rows take them, 60- / 61-bit rows never"
 
 
+def test_single_pass_ntt_xcd_order_vs_oracle(gpu, oracle_lib):
+    """a single-pass launch large enough for the XCD-aware workgroup order (ntt1.hip n1_unit: 15 primes x 200 rows -> more than two rounds of workgroups,
+    a list length that is not a multiple of 8: the padded last eighth) against the oracle, EVERY row, forward and inverse"""
+    from troy_amd import synth
+    N = 32768
+    kp = gpu.CoeffModulus.Create(N, [60] + [58] * 13 + [60])
+    ctx = gpu.SEALContext(gpu.BFV, N, kp, gpu.PlainModulus.Batching(N, 20))
+    rows = 15 * 201
+    x = synth.uniform_rows(78, kp, rows, N)
+    for mode, inverse in ((1, False), (3, True)):
+        buf = gpu.DeviceBuffer.from_numpy(x)
+        ctx.ntt(buf, rows, kp, inverse=inverse)
+        y = buf.to_numpy().reshape(rows, N)
+        for r in range(rows):
+            assert np.array_equal(y[r], oracle_lib.ntt_standalone(N, kp[r % 15], x[r], mode)), (mode, r)
+
+
 @pytest.mark.parametrize("logn", [12, 13, 14])
 def test_single_pass_ntt_small_sizes_vs_oracle(logn, gpu, oracle_lib):
     """ntt1.hip at N = 2^12 .. 2^14 (ntt1s_*: the whole limb in LDS) against the oracle, row by row, at a launch large enough for the dispatcher to
@@ -615,10 +632,12 @@ def test_probe_build_fallback_forms_agree(env, gpu):
 
 @pytest.mark.skipif(not os.path.exists(PROBES_LIB), reason="tools/probe_libs/libtroyhip_probes.so: make -C troy_amd/csrc probes")
 @pytest.mark.parametrize("env", [{"TROYHIP_BFLY": "guarded"}, {"TROYHIP_NTT": "single", "TROYHIP_BFLY": "guarded"}, {"TROYHIP_NTT": "single", "TROYHIP_MODDOWN": "split"},
-                                 {"TROYHIP_NTT": "single", "TROYHIP_CORR": "split"}])
+                                 {"TROYHIP_NTT": "single", "TROYHIP_CORR": "split"}, {"TROYHIP_NTT": "single", "TROYHIP_NTT1_XCD": "1"},
+                                 {"TROYHIP_NTT": "single", "TROYHIP_NTT1_XCD": "1", "TROYHIP_NTT1_RPW": "1"}, {"TROYHIP_NTT": "single", "TROYHIP_NTT1_XCD": "0"}])
 def test_probe_build_fallback_forms_agree_at_headline_size(env, gpu):
     """N = 2^15 on the probe build: guarded butterflies instead of the guard-free ones, the BFV mod-down in its own kernel instead of in the inverse
-    transform's epilogue, the CKKS divide-and-round correction as element-wise kernels instead of inside the forward transform"""
+    transform's epilogue, the CKKS divide-and-round correction as element-wise kernels instead of inside the forward transform, the XCD-aware
+    workgroup order of the single-pass kernels (ntt1.hip n1_unit: by default only grids of two rounds of workgroups and more) forced on and off"""
     names = [n for n in HEADLINE_NAMES if n in cases.CONFIGS]
     assert names and _hashes_in_child(names, {**env, "TROYHIP_LIB": PROBES_LIB}) == [cases.mul_relin_hash(n) for n in names]
 
