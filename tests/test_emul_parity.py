@@ -348,9 +348,15 @@ def test_emulated_single_pass_ntt_small_sizes(oracle_lib, tmp_path):
         out = subprocess.run([sys.executable, str(script), "ntt"], env=env, capture_output=True, text=True, timeout=900)
         assert out.returncode == 0 and "ok" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
     got = {}
-    for mode in ("single", "twopass"):
-        out = subprocess.run([sys.executable, str(script), "ops"], env=dict(os.environ, TROYHIP_NTT=mode), capture_output=True, text=True, timeout=900)
+    # xcd2 / xcd3: the XCD-aware workgroup order forced at this size, with the grouped list of the mod-down form (groups of 2 and of 3 primes: the
+    # number of data primes is not a multiple of either, so the short last group runs too), one row per workgroup
+    extra = {"single": {}, "twopass": {}, "xcd2": {"TROYHIP_NTT1_XCD": "1", "TROYHIP_NTT1_XCD_GROUP": "2", "TROYHIP_NTT1_RPW": "1"},
+             "xcd3": {"TROYHIP_NTT1_XCD": "1", "TROYHIP_NTT1_XCD_GROUP": "3"}}
+    for mode in ("single", "twopass", "xcd2", "xcd3"):
+        env = dict(os.environ, TROYHIP_NTT="twopass" if mode == "twopass" else "single", **extra[mode])
+        out = subprocess.run([sys.executable, str(script), "ops"], env=env, capture_output=True, text=True, timeout=900)
         assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
         got[mode] = out.stdout.split()[-4:]
-    assert got["single"][:3] == got["twopass"][:3]
+    assert got["single"][:3] == got["twopass"][:3] == got["xcd2"][:3] == got["xcd3"][:3]
     assert int(got["single"][3]) >= 12 and int(got["twopass"][3]) == 0  # the single-pass kernels really ran (plain inverse, special limb, mod-down epilogue)
+    assert int(got["xcd2"][3]) >= 12 and int(got["xcd3"][3]) >= 12

@@ -633,11 +633,13 @@ def test_probe_build_fallback_forms_agree(env, gpu):
 @pytest.mark.skipif(not os.path.exists(PROBES_LIB), reason="tools/probe_libs/libtroyhip_probes.so: make -C troy_amd/csrc probes")
 @pytest.mark.parametrize("env", [{"TROYHIP_BFLY": "guarded"}, {"TROYHIP_NTT": "single", "TROYHIP_BFLY": "guarded"}, {"TROYHIP_NTT": "single", "TROYHIP_MODDOWN": "split"},
                                  {"TROYHIP_NTT": "single", "TROYHIP_CORR": "split"}, {"TROYHIP_NTT": "single", "TROYHIP_NTT1_XCD": "1"},
-                                 {"TROYHIP_NTT": "single", "TROYHIP_NTT1_XCD": "1", "TROYHIP_NTT1_RPW": "1"}, {"TROYHIP_NTT": "single", "TROYHIP_NTT1_XCD": "0"}])
+                                 {"TROYHIP_NTT": "single", "TROYHIP_NTT1_XCD": "1", "TROYHIP_NTT1_RPW": "1"}, {"TROYHIP_NTT": "single", "TROYHIP_NTT1_XCD": "0"},
+                                 {"TROYHIP_NTT": "single", "TROYHIP_NTT1_XCD": "1", "TROYHIP_NTT1_XCD_GROUP": "3"}])
 def test_probe_build_fallback_forms_agree_at_headline_size(env, gpu):
     """N = 2^15 on the probe build: guarded butterflies instead of the guard-free ones, the BFV mod-down in its own kernel instead of in the inverse
     transform's epilogue, the CKKS divide-and-round correction as element-wise kernels instead of inside the forward transform, the XCD-aware
-    workgroup order of the single-pass kernels (ntt1.hip n1_unit: by default only grids of two rounds of workgroups and more) forced on and off"""
+    workgroup order of the single-pass kernels (ntt1.hip n1_unit: by default only grids of two rounds of workgroups and more) forced on and off, and its
+    grouped list (the mod-down and divide-and-round forms: several primes of the same rows back to back on one XCD) with a group size that leaves a short last group"""
     names = [n for n in HEADLINE_NAMES if n in cases.CONFIGS]
     assert names and _hashes_in_child(names, {**env, "TROYHIP_LIB": PROBES_LIB}) == [cases.mul_relin_hash(n) for n in names]
 

@@ -47,6 +47,7 @@ struct Ntt1Args {
     unsigned chunks;      // ceil(m_total / rows_per_wg)
     unsigned nslots;      // a launch covers the prime slots slots[0 .. nslots) of the pattern (one launch per prime class)
     unsigned xcd_per;     // != 0: the grid is 8 * xcd_per workgroups and workgroup b takes unit (b % 8) * xcd_per + b / 8 of the slot-major list (n1_unit)
+    unsigned xcd_group;   // > 1: that list is ordered (group of xcd_group primes, chunk, prime within the group)
     uint8_t slots[64];
     // forward only: divide-and-round correction (Ntt1Corr): rows are BUILT from cr_last on load and COMBINED with cr_in on store
     const u64 *cr_last, *cr_in;
@@ -121,11 +122,29 @@ __device__ __forceinline__ unsigned sw1(unsigned j) { return j ^ (((j >> 6) & 7u
 #ifndef N1_XCD
 #define N1_XCD 1
 #endif
-__device__ __forceinline__ bool n1_unit(const Ntt1Args &a, unsigned &unit) {
-    unit = blockIdx.x;
+// xcd_group > 1 (the forms whose rows of DIFFERENT primes read one shared row: the special limb of a mod-down, the dropped limb of a divide-and-round): the
+// list is ordered (group of xcd_group primes, chunk, prime within the group), so the workgroups an XCD starts back to back are the same rows under
+// xcd_group primes and the shared row is fetched into that L2 once for all of them -- at the price of xcd_group twiddle tables in it.
+#ifndef N1_XCD_GROUP_FP
+#define N1_XCD_GROUP_FP 4
+#endif
+#ifndef N1_XCD_GROUP_INT
+#define N1_XCD_GROUP_INT 4
+#endif
+__device__ __forceinline__ bool n1_unit(const Ntt1Args &a, unsigned &sidx, unsigned &chunk) {
+    unsigned q = blockIdx.x;
     if (a.xcd_per) {
-        unit = (blockIdx.x & 7u) * a.xcd_per + (blockIdx.x >> 3);
-        if (unit >= a.nslots * a.chunks) return false; // the padding of the last eighth
+        q = (blockIdx.x & 7u) * a.xcd_per + (blockIdx.x >> 3);
+        if (q >= a.nslots * a.chunks) return false; // the padding of the last eighth
+    }
+    if (!a.xcd_per || a.xcd_group <= 1) {
+        sidx = q / a.chunks;
+        chunk = q - sidx * a.chunks;
+    } else {
+        const unsigned gs = a.xcd_group * a.chunks, g = q / gs, r = q - g * gs, first = g * a.xcd_group;
+        const unsigned gsz = a.nslots - first < a.xcd_group ? a.nslots - first : a.xcd_group; // the last group may be short
+        chunk = r / gsz;
+        sidx = first + (r - chunk * gsz);
     }
     return true;
 }
@@ -651,9 +670,9 @@ template <bool LEAN, bool CR, bool FP> __device__ __forceinline__ void ntt1_fwd_
     const unsigned wv = __builtin_amdgcn_readfirstlane(tid >> 6);
 #endif
     // the byte tables of the argument block are read with vector loads: tell the compiler the results are wave-uniform
-    unsigned unit;
-    if (!n1_unit(a, unit)) return;
-    const unsigned slot = uniform_u32(a.slots[unit / a.chunks]), chunk = unit % a.chunks;
+    unsigned sidx, chunk;
+    if (!n1_unit(a, sidx, chunk)) return;
+    const unsigned slot = uniform_u32(a.slots[sidx]);
     PrimeDesc pd = a.primes[uniform_u32(a.map.id[slot])];
     if constexpr (FP) pd.root = pd.root_fp;
     const FpPrime fc = make_fp_prime_uniform(FP ? pd.p : 1);
@@ -915,9 +934,9 @@ template <bool LEAN, bool MD, bool FP> __device__ __forceinline__ void ntt1_inv_
     const unsigned wv = __builtin_amdgcn_readfirstlane(tid >> 6);
 #endif
     // the byte tables of the argument block are read with vector loads: tell the compiler the results are wave-uniform
-    unsigned unit;
-    if (!n1_unit(a, unit)) return;
-    const unsigned slot = uniform_u32(a.slots[unit / a.chunks]), chunk = unit % a.chunks;
+    unsigned sidx, chunk;
+    if (!n1_unit(a, sidx, chunk)) return;
+    const unsigned slot = uniform_u32(a.slots[sidx]);
     PrimeDesc pd = a.primes[uniform_u32(a.map.id[slot])];
     if constexpr (FP) { pd.iroot = pd.iroot_fp; pd.inv_n = pd.inv_n_fp; pd.iroot_last_scaled = pd.iroot_last_scaled_fp; }
     const FpPrime fc = make_fp_prime_uniform(FP ? pd.p : 1);
@@ -1106,9 +1125,9 @@ template <int LOGN, bool LEAN, bool FP> __device__ __forceinline__ void ntt1s_fw
 #else
     const unsigned wv = __builtin_amdgcn_readfirstlane(tid >> 6);
 #endif
-    unsigned unit;
-    if (!n1_unit(a, unit)) return;
-    const unsigned slot = uniform_u32(a.slots[unit / a.chunks]), chunk = unit % a.chunks;
+    unsigned sidx, chunk;
+    if (!n1_unit(a, sidx, chunk)) return;
+    const unsigned slot = uniform_u32(a.slots[sidx]);
     PrimeDesc pd = a.primes[uniform_u32(a.map.id[slot])];
     if constexpr (FP) pd.root = pd.root_fp;
     const FpPrime fc = make_fp_prime_uniform(FP ? pd.p : 1);
@@ -1169,9 +1188,9 @@ template <int LOGN, bool LEAN, bool MD, bool FP> __device__ __forceinline__ void
 #else
     const unsigned wv = __builtin_amdgcn_readfirstlane(tid >> 6);
 #endif
-    unsigned unit;
-    if (!n1_unit(a, unit)) return;
-    const unsigned slot = uniform_u32(a.slots[unit / a.chunks]), chunk = unit % a.chunks;
+    unsigned sidx, chunk;
+    if (!n1_unit(a, sidx, chunk)) return;
+    const unsigned slot = uniform_u32(a.slots[sidx]);
     PrimeDesc pd = a.primes[uniform_u32(a.map.id[slot])];
     if constexpr (FP) { pd.iroot = pd.iroot_fp; pd.inv_n = pd.inv_n_fp; pd.iroot_last_scaled = pd.iroot_last_scaled_fp; }
     const FpPrime fc = make_fp_prime_uniform(FP ? pd.p : 1);
@@ -1349,6 +1368,7 @@ void launch_ntt1(u64 *data, const u64 *src, const PrimeDesc *primes, const LimbM
     const unsigned cus = device_cus() * ntt1_wgs_per_cu(logn); // workgroup slots of the chip
     static const unsigned forced_rpw = [] { const char *e = probe_env("TROYHIP_NTT1_RPW"); return e ? (unsigned)std::atoi(e) : 0u; }(); // tests: row loop at small batches
     static const int forced_xcd = [] { const char *e = probe_env("TROYHIP_NTT1_XCD"); return e ? std::atoi(e) : -1; }();
+    static const int forced_group = [] { const char *e = probe_env("TROYHIP_NTT1_XCD_GROUP"); return e ? std::atoi(e) : 0; }();
     auto plan = [&](unsigned nslots) { // -> rows per workgroup for a launch over `nslots` primes
         if (forced_rpw) return forced_rpw;
         unsigned best = 1;
@@ -1398,6 +1418,7 @@ void launch_ntt1(u64 *data, const u64 *src, const PrimeDesc *primes, const LimbM
         // one prime, or a grid the chip holds at once: nothing to separate (probe builds: TROYHIP_NTT1_XCD = 1 always / 0 never, for the tests)
         const bool xcd = forced_xcd >= 0 ? forced_xcd != 0 : (N1_XCD && a.nslots > 1 && a.nslots * a.chunks >= 2 * cus);
         a.xcd_per = xcd ? (a.nslots * a.chunks + 7) / 8 : 0;
+        a.xcd_group = forced_group > 0 ? (unsigned)forced_group : !(a.md_ct || a.cr_last) ? 1u : kind == 2 ? N1_XCD_GROUP_FP : N1_XCD_GROUP_INT;
         cls[ncls].a = a;
         cls[ncls].lean = kind != 0;
         cls[ncls++].fp = kind == 2;
