@@ -23,7 +23,7 @@ for i, C in enumerate(("FETCH_SIZE", "WRITE_SIZE")):
             tot[name][i] += float(r["Counter_Value"]) * 1024 * (2 if i == 0 else 1)
             if i == 0: tot[name][2] += 1
 for name, (f, w, n) in sorted(tot.items()):
-    if name.startswith("ntt1"): print("%-8s %-36s calls %2d  fetch %7.3f GB  write %7.3f GB" % (v, name, n, f / 1e9, w / 1e9))
+    if name.startswith("ntt"): print("%-8s %-36s calls %2d  fetch %7.3f GB  write %7.3f GB" % (v, name, n, f / 1e9, w / 1e9))
 PY
 done
 unset TROYHIP_LIB
@@ -35,6 +35,6 @@ for ln in open("gpurun_out/r05_nt/ab.txt"):
     ln = ln.strip()
     if ln.startswith("=="): print(ln, end="  ")
     elif ln.startswith("{"):
-        d = json.loads(ln); print(d["value"], d["unit"], d["ms_per_step"], "ms", " ".join("%s %.0f" % (k["name"].replace("ntt1_", "").replace("_kernel", ""), k["us"]) for k in d["roofline"]["per_kernel"] if "ntt1" in k["name"]) if d.get("roofline") and d["roofline"].get("per_kernel") else "")
+        d = json.loads(ln); print(d["value"], d["unit"], d["ms_per_step"], "ms", " ".join("%s %.0f" % (k["name"].replace("_kernel", "").replace(" ", ""), k["us"]) for k in d["roofline"]["per_kernel"] if "ntt" in k["name"]) if d.get("roofline") and d["roofline"].get("per_kernel") else "")
 PY
 cat $out

@@ -42,6 +42,7 @@ struct LimbMap {
 #define TROY_DYN_LDS(type, name) static type name[160 * 1024 / sizeof(type)]
 // LDS-DMA: lane l of the wave copies 16 bytes from its own global address to (wave-uniform LDS base) + 16*l
 #define TROY_GLDS16(gptr, lds_base) memcpy((char *)(lds_base) + 16 * (threadIdx.x & 63), (const void *)(gptr), 16)
+#define TROY_GLDS16_POL(gptr, lds_base, pol) TROY_GLDS16(gptr, lds_base)
 // 32x32x32 int8 matrix-core product: c[16] += A-fragment x B-fragment (16 signed bytes per lane each)
 struct MfmaFrag { int8_t bytes[16]; };
 struct MfmaAcc { int32_t v[16]; };
@@ -75,14 +76,20 @@ __device__ __forceinline__ u64 buf_load_u64(BufRsrc r, u32 off) {
     const troy_v2u v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)off, 0, 0);
     return (u64)v.x | ((u64)v.y << 32);
 }
+#ifndef TROY_BUF_ST_POL
+#define TROY_BUF_ST_POL 0 // probe: cache policy of the buffer stores (BEHZ kernels): 2 = non-temporal
+#endif
 __device__ __forceinline__ void buf_store_u64(BufRsrc r, u32 off, u64 v) {
     troy_v2u d;
     d.x = (u32)v;
     d.y = (u32)(v >> 32);
-    __builtin_amdgcn_raw_buffer_store_b64(d, r, (int)off, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b64(d, r, (int)off, 0, TROY_BUF_ST_POL);
 }
 #define TROY_GLDS16(gptr, lds_base)                                                                                      \
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gptr), (__attribute__((address_space(3))) void *)(lds_base), 16, 0, 0)
+// the same with a cache-policy immediate (gfx940 encoding: 1 = sc0, 2 = nt, 16 = sc1); probes only (N1_DMA_POL, N2_DMA_POL)
+#define TROY_GLDS16_POL(gptr, lds_base, pol)                                                                             \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gptr), (__attribute__((address_space(3))) void *)(lds_base), 16, 0, pol)
 #define TROY_WAIT_VMEM() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #define TROY_WAIT_LDS() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 // LDS operations of one wave execute in order, so intra-wave exchange needs no s_barrier; this only stops the

@@ -113,6 +113,9 @@ __device__ __forceinline__ unsigned sw1(unsigned j) { return j ^ (((j >> 6) & 7u
 #ifndef N1_INV_EXP
 #define N1_INV_EXP 0 // removal probes of the N = 2^15 inverse body (wrong results; tools/ntt_probe.sh name:-DN1_INV_EXP=k): 1 no global reads, 2 no global writes, 4 no workgroup barriers
 #endif
+#ifndef N1_DMA_POL
+#define N1_DMA_POL 0 // probe: cache policy of the inverse kernels' LDS-DMA staged half (2 = non-temporal)
+#endif
 #ifndef N1_NT_INV
 #define N1_NT_INV 0 // non-temporal stores in the INTEGER N = 2^15 inverse kernels: bit 0 the plain rows, bit 1 the mod-down epilogue's
 #endif
@@ -955,7 +958,7 @@ template <bool LEAN, bool MD, bool FP> __device__ __forceinline__ void ntt1_inv_
         if (N1_INV_EXP & 1) return;
         const unsigned l = opaque(lane);
 #pragma unroll
-        for (int i = 0; i < 8; i++) TROY_GLDS16(sub + sw2_inv(128 * i + 2 * l), region + 128 * i);
+        for (int i = 0; i < 8; i++) TROY_GLDS16_POL(sub + sw2_inv(128 * i + 2 * l), region + 128 * i, N1_DMA_POL);
     };
     auto load16 = [&](u64 (&y)[16], const u64 *sub) { // y[8 i + r] = coefficient 8 (lane + 64 i) + r
         if (N1_INV_EXP & 1) {

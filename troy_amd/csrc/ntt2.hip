@@ -48,6 +48,11 @@ namespace troyhip {
 #ifndef N2_DMA
 #define N2_DMA 1 // contiguous passes prefetch the next row with LDS-DMA
 #endif
+#ifndef N2_DMA_POL
+#define N2_DMA_POL 2 // cache policy of the LDS-DMA row prefetch: 2 = non-temporal -- rows that are read once do not displace the key window (and the staged rows of
+                     // the neighbours) in L2: fetch of the key-switch accumulating pass 15.98 -> 14.25 GB per 256 ciphertexts (1.10x -> 1.00x its rows), of the tensor
+                     // pass 8.06 -> 7.89; -0.8 % / -2 % on the two kernels, +0.3-0.5 % on the 49-bit twin, the CKKS chain and BGV (profiles/r05_inv_probes.txt 5e).  0: default policy
+#endif
 #ifndef N2_MAC_STORE_LINEAR
 #define N2_MAC_STORE_LINEAR 1 // the key-switch sums are stored through the wave's exchange area (contiguous KiB per instruction); 0 (probe): from a thread's eight consecutive coefficients
 #endif
@@ -132,6 +137,37 @@ struct Ntt2Args {
     unsigned fp_acc_every = 0; // the key-switch accumulators are reduced every this many rows (0: never)
 };
 
+#ifndef N2_NT
+#define N2_NT 1 // non-temporal accesses.  bit 0 (ON): the stores of the forward STRIDED pass -- rows written once and read back by another kernel: the key switch's
+                // digit-expanding pass -2.5 %, headline +0.6 %, 49-bit twin +2 %, CKKS chain +1.3 %, BGV +0.6 % (profiles/r05_inv_probes.txt 5f).  Probes: bit 1 its loads
+                // (the L + 1 readers of a source digit lose their L2 hits: slower), bit 2 the inverse strided pass's stores, bit 3 the contiguous pass's stores
+                // (store_via_lds: transforms, tensor), bit 4 the key-switch sums
+#endif
+template <bool NT> __device__ __forceinline__ u64 n2_ld(const u64 *p) {
+#ifndef TROYHIP_CPU_EMUL
+    if (NT) return __builtin_nontemporal_load(p);
+#endif
+    return *p;
+}
+template <bool NT> __device__ __forceinline__ void n2_st2(u64 *p, ulonglong2 v) { // 16 bytes
+#ifndef TROYHIP_CPU_EMUL
+    if (NT) {
+        typedef u64 v2 __attribute__((ext_vector_type(2)));
+        v2 w;
+        w.x = v.x;
+        w.y = v.y;
+        __builtin_nontemporal_store(w, reinterpret_cast<v2 *>(p));
+        return;
+    }
+#endif
+    *reinterpret_cast<ulonglong2 *>(p) = v;
+}
+template <bool NT> __device__ __forceinline__ void n2_st(u64 *p, u64 v) {
+#ifndef TROYHIP_CPU_EMUL
+    if (NT) { __builtin_nontemporal_store(v, p); return; }
+#endif
+    *p = v;
+}
 __device__ __forceinline__ unsigned n2_opaque(unsigned v) {
 #ifndef TROYHIP_CPU_EMUL
     asm volatile("" : "+v"(v));
@@ -363,7 +399,7 @@ template <int INV, int STRIDED, int NS, int LOGC, int LS, int R, bool HOISTP = t
         const unsigned lane = threadIdx.x & 63, w = threadIdx.x >> 6;
         const u64 *src = row + ((size_t)tile << N2_LOGT) + 512 * w + 2 * (INV ? unit_perm(lane) : lane);
 #pragma unroll
-        for (int i = 0; i < 4; i++) TROY_GLDS16(src + 128 * i, wave_stage + 128 * i);
+        for (int i = 0; i < 4; i++) TROY_GLDS16_POL(src + 128 * i, wave_stage + 128 * i, N2_DMA_POL);
     }
     __device__ static __forceinline__ void stage_read(u64 (&x)[8], const u64 *wave_stage) {
         const unsigned lane = threadIdx.x & 63;
@@ -384,7 +420,7 @@ template <int INV, int STRIDED, int NS, int LOGC, int LS, int R, bool HOISTP = t
     // is four stores of 16 bytes every 64 bytes (each touching all 32 lines of the wave's 4 KiB); instead the wave
     // transposes through its private exchange area with the same unit permutation and issues four stores of one
     // contiguous 1 KiB each.
-    __device__ static __forceinline__ void store_via_lds(const u64 (&x)[8], u64 *row, unsigned tile, u64 *wave_xchg) {
+    template <bool NT = (N2_NT & 8) != 0> __device__ static __forceinline__ void store_via_lds(const u64 (&x)[8], u64 *row, unsigned tile, u64 *wave_xchg) {
         const unsigned lane = threadIdx.x & 63, w = threadIdx.x >> 6;
         u64 *mine = wave_xchg + 128 * (lane >> 4) + 2 * (lane & 15);
 #pragma unroll
@@ -399,7 +435,7 @@ template <int INV, int STRIDED, int NS, int LOGC, int LS, int R, bool HOISTP = t
 #pragma unroll
         for (int c = 0; c < 4; c++) {
             const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(wave_xchg + 128 * c + 2 * lane);
-            *reinterpret_cast<ulonglong2 *>(dst + 128 * c) = v;
+            n2_st2<NT>(dst + 128 * c, v);
         }
     }
     // MAC = 2 epilogue of the forward contiguous pass: virtual row vr = mm % 4 of (a0, a1, b0, b1); x is the lazy transform
@@ -489,7 +525,7 @@ template <int INV, int STRIDED, int NS, int LOGC, int LS, int R, bool HOISTP = t
                 }
             } else {
 #pragma unroll
-                for (int e = 0; e < (1 << R); e++) x[(u << R) + e] = row[g_index<STRIDED, NS, LOGC>(tile, elem(q, e), logn)];
+                for (int e = 0; e < (1 << R); e++) x[(u << R) + e] = n2_ld<STRIDED && !INV && (N2_NT & 2) != 0>(row + g_index<STRIDED, NS, LOGC>(tile, elem(q, e), logn));
             }
         }
         (void)m;
@@ -542,7 +578,7 @@ template <int INV, int STRIDED, int NS, int LOGC, int LS, int R, bool HOISTP = t
                 }
             } else {
 #pragma unroll
-                for (int e = 0; e < (1 << R); e++) row[g_index<STRIDED, NS, LOGC>(tile, elem(q, e), logn)] = x[(u << R) + e];
+                for (int e = 0; e < (1 << R); e++) n2_st<STRIDED && ((!INV && (N2_NT & 1) != 0) || (INV && (N2_NT & 4) != 0))>(row + g_index<STRIDED, NS, LOGC>(tile, elem(q, e), logn), x[(u << R) + e]);
             }
         }
     }
@@ -1002,7 +1038,7 @@ __device__ __forceinline__ void ntt2_body(const Ntt2Args &a) {
             }
             if constexpr (MAC_STORE_LINEAR) {
                 TROY_WAVE_SYNC();
-                Rd2::store_via_lds(lin, a.mac_acc + ((((u64)o * 2 + cpt) * period + slot) << logn), tile, lds[0] + 512 * (threadIdx.x >> 6));
+                Rd2::template store_via_lds<(N2_NT & 16) != 0>(lin, a.mac_acc + ((((u64)o * 2 + cpt) * period + slot) << logn), tile, lds[0] + 512 * (threadIdx.x >> 6));
             }
             (void)lin;
         }
