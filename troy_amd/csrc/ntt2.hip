@@ -141,7 +141,7 @@ struct Ntt2Args {
 #define N2_NT 1 // non-temporal accesses.  bit 0 (ON): the stores of the forward STRIDED pass -- rows written once and read back by another kernel: the key switch's
                 // digit-expanding pass -2.5 %, headline +0.6 %, 49-bit twin +2 %, CKKS chain +1.3 %, BGV +0.6 % (profiles/r05_inv_probes.txt 5f).  Probes: bit 1 its loads
                 // (the L + 1 readers of a source digit lose their L2 hits: slower), bit 2 the inverse strided pass's stores, bit 3 the contiguous pass's stores
-                // (store_via_lds: transforms, tensor), bit 4 the key-switch sums, bit 5 the loads of the forward strided pass where no other workgroup reads the same row (every use but the digit broadcast)
+                // (store_via_lds: transforms, tensor), bit 4 the key-switch sums
 #endif
 template <bool NT> __device__ __forceinline__ u64 n2_ld(const u64 *p) {
 #ifndef TROYHIP_CPU_EMUL
@@ -525,7 +525,7 @@ template <int INV, int STRIDED, int NS, int LOGC, int LS, int R, bool HOISTP = t
                 }
             } else {
 #pragma unroll
-                for (int e = 0; e < (1 << R); e++) x[(u << R) + e] = n2_ld<STRIDED && !INV && ((N2_NT & 2) != 0 || (!REDUCE && (N2_NT & 32) != 0))>(row + g_index<STRIDED, NS, LOGC>(tile, elem(q, e), logn));
+                for (int e = 0; e < (1 << R); e++) x[(u << R) + e] = n2_ld<STRIDED && !INV && (N2_NT & 2) != 0>(row + g_index<STRIDED, NS, LOGC>(tile, elem(q, e), logn));
             }
         }
         (void)m;
