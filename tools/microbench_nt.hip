@@ -1,0 +1,50 @@
+// microbench_nt.hip -- what the cache policy of streaming accesses is worth on gfx950: a copy / scale kernel over 4 GiB (16 bytes per lane, grid-stride in
+// 256 KiB rows like the limb kernels) with plain or non-temporal loads and stores, and with a small table every workgroup re-reads (does the stream evict it?).
+// Build: hipcc --offload-arch=gfx950 -O3 tools/microbench_nt.hip -o tools/microbench_nt
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+typedef unsigned long long u64;
+typedef u64 v2 __attribute__((ext_vector_type(2)));
+
+template <int POL> __global__ __launch_bounds__(256) void copy_kernel(const v2 *in, v2 *out, const v2 *table, size_t rows, int use_table) {
+    // one workgroup per 256 KiB row at a time (16384 x 16 B), 64 iterations of 256 threads
+    for (size_t r = blockIdx.x; r < rows; r += gridDim.x) {
+        const v2 *src = in + r * 16384;
+        v2 *dst = out + r * 16384;
+#pragma unroll 4
+        for (int i = 0; i < 64; i++) {
+            const unsigned k = threadIdx.x + 256 * i;
+            v2 v = (POL & 1) ? __builtin_nontemporal_load(src + k) : src[k];
+            if (use_table) { const v2 t = table[k & 32767]; v.x ^= t.x; v.y += t.y; } // a 512 KiB table shared by every row
+            if (POL & 2) __builtin_nontemporal_store(v, dst + k); else dst[k] = v;
+        }
+    }
+}
+int main() {
+    const size_t bytes = (size_t)4 << 30, rows = bytes / (256 << 10);
+    v2 *in, *out, *table;
+    hipMalloc(&in, bytes); hipMalloc(&out, bytes); hipMalloc(&table, 512 << 10);
+    hipMemset(in, 1, bytes); hipMemset(table, 3, 512 << 10);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    const char *names[4] = {"plain loads, plain stores", "NT loads,    plain stores", "plain loads, NT stores", "NT loads,    NT stores"};
+    for (int grid : {256 * 8, 256 * 4, 256 * 2})
+        for (int tab = 0; tab < 2; tab++)
+            for (int pol = 0; pol < 4; pol++) {
+                float best = 1e30f;
+                for (int rep = 0; rep < 5; rep++) {
+                    hipEventRecord(e0);
+                    switch (pol) {
+                    case 0: copy_kernel<0><<<grid, 256>>>(in, out, table, rows, tab); break;
+                    case 1: copy_kernel<1><<<grid, 256>>>(in, out, table, rows, tab); break;
+                    case 2: copy_kernel<2><<<grid, 256>>>(in, out, table, rows, tab); break;
+                    case 3: copy_kernel<3><<<grid, 256>>>(in, out, table, rows, tab); break;
+                    }
+                    hipEventRecord(e1); hipEventSynchronize(e1);
+                    float ms; hipEventElapsedTime(&ms, e0, e1);
+                    if (ms < best) best = ms;
+                }
+                printf("grid %5d  %s  %s  %7.3f ms  %6.2f TB/s (read + write)\n", grid, tab ? "with table" : "no table  ", names[pol], best, 2.0 * bytes / best / 1e9);
+            }
+    return 0;
+}
