@@ -487,6 +487,13 @@ def per_kernel(ta, capi, lib, w):
     ks = ktime_report(capi, lib)
     capi.check(lib, lib.troyhip_ktime_enable(0))
     algo = algorithmic_bytes(w, w.profile_units)
+    # the forward strided pass has a WIDE form (ntt2.hip n2_wide: 512 threads, twice the columns -- template argument LOGC + 1) that the library takes for
+    # launches that fill the chip twice over: same rows, same compulsory bytes, another instance name
+    import re
+    for n, b in list((algo or {}).items()):
+        m = re.match(r"(ntt2(?:_fp)?_kernel<0, 1, )(\d+), (\d+)(, 0, 0, 0>)$", n)
+        if m and m.group(2) == "6":
+            algo.setdefault("%s%s, %d%s" % (m.group(1), m.group(2), int(m.group(3)) + 1, m.group(4)), b)
     tinfo = load_traffic(w.name) or {}
     traffic = tinfo.get("per_kernel", {})
     out = []

@@ -92,7 +92,7 @@ int troyhip_test_modarith(int op, const uint64_t *a, const uint64_t *b, const ui
 /* per-kernel timing: while enabled every kernel launch is bracketed by HIP events on its own stream; the report is JSON text
  * [{"name", "calls", "total_us"}, ...] in first-launch order and clears the log (bench.py: roofline.per_kernel) */
 /* path counters ("ks_fp_launches", "ks_int_launches", "ntt1_fp_launches", "ntt1_int_launches", "ntt2_fp_launches", "ntt2_int_launches", "behz_fp_launches",
- * "behz_mfma_launches", "behz_valu_launches"): which kernel class the launchers chose so far in
+ * "behz_mfma_launches", "behz_valu_launches", "ntt2_wide_launches"): which kernel class the launchers chose so far in
  * this process -- the parity tests read them so that a test of the FP64 instances cannot pass on the integer kernels unnoticed.  No
  * reference counterpart (test / diagnostics support, like troyhip_ktime_*). */
 int troyhip_stat(const char *name, uint64_t *value);

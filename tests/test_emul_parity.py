@@ -261,6 +261,48 @@ def test_emulated_single_pass_ntt_row_loop_and_prime_classes(oracle_lib, tmp_pat
         assert out.returncode == 0 and "ok" in out.stdout, out.stdout[-2000:] + out.stderr[-3000:]
 
 
+def test_emulated_wide_strided_pass(oracle_lib, tmp_path):
+    """ntt2.hip: the WIDE form of the forward strided pass (N = 2^15: 512 threads own 4096 points, 64 columns x 64 rows), which the
+    library takes by itself only for launches that fill the chip twice over -- forced here (TROYHIP_NTT2_WIDE = 1, probe builds) for the plain transform of
+    every prime class against the oracle, and for multiply + relinearize + rotation (the tensor's first pass) against the narrow form."""
+    import sys
+    script = tmp_path / "w.py"
+    script.write_text(
+        "import sys, os, ctypes; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import numpy as np\n"
+        "from troy_amd import api, capi, synth\n"
+        "from oracle import oracle\n"
+        "lib = capi.load(%r)\n"
+        "api.KernelProvider.initialize(0, _lib=lib)\n"
+        "import cases\n"
+        "def wide():\n"
+        "    v = ctypes.c_uint64(); lib.troyhip_stat(b'ntt2_wide_launches', ctypes.byref(v)); return v.value\n"
+        "for logn in (15,):\n"
+        "    N = 1 << logn\n"
+        "    kp = api.CoeffModulus.Create(N, [60, 50, 58, 40, 60])\n"
+        "    ctx = api.SEALContext(api.BFV, N, kp, api.PlainModulus.Batching(N, 20))\n"
+        "    primes = kp[:4]\n"
+        "    rows = 2 * len(primes)\n"
+        "    x = synth.uniform_rows(7, primes, rows, N)\n"
+        "    x[rows - 1] = primes[(rows - 1) %% len(primes)] - 1\n"
+        "    buf = api.DeviceBuffer.from_numpy(x)\n"
+        "    ctx.ntt(buf, rows, primes)\n"
+        "    y = buf.to_numpy().reshape(rows, N)\n"
+        "    for r in range(rows):\n"
+        "        assert np.array_equal(y[r], oracle.ntt_standalone(N, primes[r %% len(primes)], x[r], 1)), (logn, r)\n"
+        "cases.CONFIGS['w_bfv'] = {'scheme': 1, 'N': 32768, 'bits': [60, 58, 60], 'tbits': 20}\n"      # integer classes (guarded + guard-free)
+        "cases.CONFIGS['w_ckks'] = {'scheme': 2, 'N': 32768, 'bits': [60, 40, 40, 60], 'tbits': 0}\n"   # FP64 class, with the rescale
+        "print(cases.mul_relin_hash('w_bfv', batch=1) + '/' + cases.mul_relin_hash('w_ckks', batch=1), wide())\n"
+        % (ROOT, os.path.join(ROOT, 'tests'), EMUL))
+    got = {}
+    for w in ("0", "1"):
+        out = subprocess.run([sys.executable, str(script)], env=dict(os.environ, TROYHIP_NTT="twopass", TROYHIP_NTT2_WIDE=w), capture_output=True, text=True, timeout=1800)
+        assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-3000:]
+        got[w] = out.stdout.split()[-2:]
+    assert got["0"][0] == got["1"][0]
+    assert int(got["0"][1]) == 0 and int(got["1"][1]) >= 3, got  # the wide form really ran: the plain transform's classes, the tensors' first passes
+
+
 def test_emulated_small_launch_forms_agree(tmp_path):
     """The merged forms of small launches (evaluator.cpp: both BEHZ bases through one launch per step, one first pass over the special limb and the
     data limbs of a mod-down) against the per-base kernels of the large batch, in child processes (TROYHIP_SMALL is read once): same limbs through

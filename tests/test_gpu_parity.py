@@ -194,6 +194,25 @@ def test_single_pass_ntt_xcd_order_vs_oracle(gpu, oracle_lib):
             assert np.array_equal(y[r], oracle_lib.ntt_standalone(N, kp[r % 15], x[r], mode)), (mode, r)
 
 
+def test_wide_strided_pass_at_a_large_batch(gpu):
+    """ntt2.hip: the tensor's first pass takes the WIDE strided form (512 threads, 64 columns x 64 rows) by itself once the launch fills the chip twice over.
+    64 pairs at the headline parameters: the path counter says it ran, and items 0, 31 and 63 of the batch equal the same pairs multiplied one at a time
+    (a launch that small takes the narrow form, which the reference hashes pin)."""
+    from troy_amd import api, capi, synth
+    cfg = cases.CONFIGS["cfgNS_bfv_n32768_k15"]
+    be = cases.GpuBackend(cfg)
+    L, N, B = len(be.primes) - 1, cfg["N"], 64
+    xa, xb = synth.uniform_ct(901, be.primes[:L], 2, N, B), synth.uniform_ct(902, be.primes[:L], 2, N, B)
+    w0 = capi.stat("ntt2_wide_launches")
+    big = be.ev.multiply(api.Ciphertext.from_numpy(be.ctx, xa, False), api.Ciphertext.from_numpy(be.ctx, xb, False)).cpu()
+    assert capi.stat("ntt2_wide_launches") > w0, "the wide strided pass did not run at 64 pairs"
+    w1 = capi.stat("ntt2_wide_launches")
+    for i in (0, 31, 63):
+        one = be.ev.multiply(api.Ciphertext.from_numpy(be.ctx, xa[i:i + 1], False), api.Ciphertext.from_numpy(be.ctx, xb[i:i + 1], False)).cpu()
+        assert np.array_equal(np.asarray(big)[i], np.asarray(one)[0]), i
+    assert capi.stat("ntt2_wide_launches") == w1, "one pair is expected to take the narrow form"
+
+
 @pytest.mark.parametrize("logn", [12, 13, 14])
 def test_single_pass_ntt_small_sizes_vs_oracle(logn, gpu, oracle_lib):
     """ntt1.hip at N = 2^12 .. 2^14 (ntt1s_*: the whole limb in LDS) against the oracle, row by row, at a launch large enough for the dispatcher to
@@ -634,12 +653,14 @@ def test_probe_build_fallback_forms_agree(env, gpu):
 @pytest.mark.parametrize("env", [{"TROYHIP_BFLY": "guarded"}, {"TROYHIP_NTT": "single", "TROYHIP_BFLY": "guarded"}, {"TROYHIP_NTT": "single", "TROYHIP_MODDOWN": "split"},
                                  {"TROYHIP_NTT": "single", "TROYHIP_CORR": "split"}, {"TROYHIP_NTT": "single", "TROYHIP_NTT1_XCD": "1"},
                                  {"TROYHIP_NTT": "single", "TROYHIP_NTT1_XCD": "1", "TROYHIP_NTT1_RPW": "1"}, {"TROYHIP_NTT": "single", "TROYHIP_NTT1_XCD": "0"},
-                                 {"TROYHIP_NTT": "single", "TROYHIP_NTT1_XCD": "1", "TROYHIP_NTT1_XCD_GROUP": "3"}])
+                                 {"TROYHIP_NTT": "single", "TROYHIP_NTT1_XCD": "1", "TROYHIP_NTT1_XCD_GROUP": "3"}, {"TROYHIP_NTT2_WIDE": "1"},
+                                 {"TROYHIP_NTT2_WIDE": "1", "TROYHIP_NTT": "twopass"}, {"TROYHIP_NTT2_WIDE": "0"}])
 def test_probe_build_fallback_forms_agree_at_headline_size(env, gpu):
     """N = 2^15 on the probe build: guarded butterflies instead of the guard-free ones, the BFV mod-down in its own kernel instead of in the inverse
     transform's epilogue, the CKKS divide-and-round correction as element-wise kernels instead of inside the forward transform, the XCD-aware
     workgroup order of the single-pass kernels (ntt1.hip n1_unit: by default only grids of two rounds of workgroups and more) forced on and off, and its
-    grouped list (the mod-down and divide-and-round forms: several primes of the same rows back to back on one XCD) with a group size that leaves a short last group"""
+    grouped list (the mod-down and divide-and-round forms: several primes of the same rows back to back on one XCD) with a group size that leaves a short last group,
+    the wide form of the forward strided pass (ntt2.hip n2_wide: by default only launches that fill the chip twice over) forced on and off"""
     names = [n for n in HEADLINE_NAMES if n in cases.CONFIGS]
     assert names and _hashes_in_child(names, {**env, "TROYHIP_LIB": PROBES_LIB}) == [cases.mul_relin_hash(n) for n in names]
 

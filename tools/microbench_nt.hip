@@ -21,6 +21,27 @@ template <int POL> __global__ __launch_bounds__(256) void copy_kernel(const v2 *
         }
     }
 }
+// the access pattern of the strided first pass (ntt2.hip, N = 2^15): a workgroup owns 32 columns x 64 rows of a limb = 64 runs of 256 bytes at a stride of 4 KiB,
+// 8-byte accesses, 8 per thread (thread t: column t % 32, rows t / 32 + 8 e); SEG = 64: the same with 64 columns x 32 rows (512-byte runs)
+template <int POL, int COLS> __global__ __launch_bounds__(256) void strided_kernel(const u64 *in, u64 *out, size_t tiles) {
+    constexpr int ROWS = 2048 / COLS, TPL = 32768 / 2048; // tiles per limb
+    for (size_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+        const size_t limb = t / TPL, tile = t % TPL;
+        const u64 *src = in + limb * 32768 + tile * COLS;
+        u64 *dst = out + limb * 32768 + tile * COLS;
+        u64 v[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const unsigned idx = (threadIdx.x / COLS + (256 / COLS) * e) * (32768 / ROWS) + threadIdx.x % COLS;
+            v[e] = (POL & 1) ? __builtin_nontemporal_load(src + idx) : src[idx];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const unsigned idx = (threadIdx.x / COLS + (256 / COLS) * e) * (32768 / ROWS) + threadIdx.x % COLS;
+            if (POL & 2) __builtin_nontemporal_store(v[e] + 1, dst + idx); else dst[idx] = v[e] + 1;
+        }
+    }
+}
 int main() {
     const size_t bytes = (size_t)4 << 30, rows = bytes / (256 << 10);
     v2 *in, *out, *table;
@@ -45,6 +66,22 @@ int main() {
                     if (ms < best) best = ms;
                 }
                 printf("grid %5d  %s  %s  %7.3f ms  %6.2f TB/s (read + write)\n", grid, tab ? "with table" : "no table  ", names[pol], best, 2.0 * bytes / best / 1e9);
+            }
+    for (int cols : {32, 64})
+        for (int grid : {256 * 16, 256 * 8, 256 * 4})
+            for (int pol = 0; pol < 4; pol++) {
+                float best = 1e30f;
+                const size_t tiles = bytes / (2048 * 8);
+                for (int rep = 0; rep < 5; rep++) {
+                    hipEventRecord(e0);
+#define L(P, C) strided_kernel<P, C><<<grid, 256>>>((const u64 *)in, (u64 *)out, tiles)
+                    if (cols == 32) { switch (pol) { case 0: L(0, 32); break; case 1: L(1, 32); break; case 2: L(2, 32); break; case 3: L(3, 32); break; } }
+                    else { switch (pol) { case 0: L(0, 64); break; case 1: L(1, 64); break; case 2: L(2, 64); break; case 3: L(3, 64); break; } }
+                    hipEventRecord(e1); hipEventSynchronize(e1);
+                    float ms; hipEventElapsedTime(&ms, e0, e1);
+                    if (ms < best) best = ms;
+                }
+                printf("strided %3d-byte runs  grid %5d  %s  %7.3f ms  %6.2f TB/s (read + write)\n", cols * 8, grid, names[pol], best, 2.0 * bytes / best / 1e9);
             }
     return 0;
 }

@@ -197,6 +197,7 @@ __device__ __forceinline__ Shoup to_sgpr(const Shoup w) {
 
 template <int INV, int STRIDED, int NS, int LOGC, int LS, int R, bool HOISTP = true> struct Round {
     static constexpr int G = 8 >> R;                       // groups per thread
+    static constexpr int THREADS = STRIDED ? (1 << (NS + LOGC - 3)) : N2_THREADS; // a strided pass owns 2^(NS + LOGC) points: 2048 (256 threads) or, wide, 4096 (512)
     static constexpr int NTW = (1 << R) - 1;               // twiddles per group
     static constexpr int LOGPF = NS + LOGC;                // log2 flattened size of one sub-transform
     // forward: first stage gap 2^LOGG, point distance 2^LOGD
@@ -218,7 +219,7 @@ template <int INV, int STRIDED, int NS, int LOGC, int LS, int R, bool HOISTP = t
     __device__ static __forceinline__ void load_tw(Shoup (&tw)[G][NTW], const PrimeDesc &pd, unsigned tile, int logn, int s_first) {
 #pragma unroll
         for (int u = 0; u < G; u++) {
-            const unsigned q = threadIdx.x + N2_THREADS * u;
+            const unsigned q = threadIdx.x + THREADS * u;
             unsigned j0 = g_index<STRIDED, NS, LOGC>(tile, base_of(q), logn);
             if (!INV) {
                 const int s = s_first + LS;
@@ -376,14 +377,14 @@ template <int INV, int STRIDED, int NS, int LOGC, int LS, int R, bool HOISTP = t
 #pragma unroll
         for (int u = 0; u < G; u++)
 #pragma unroll
-            for (int e = 0; e < (1 << R); e++) x[(u << R) + e] = lds[swz(elem(t + N2_THREADS * u, e))];
+            for (int e = 0; e < (1 << R); e++) x[(u << R) + e] = lds[swz(elem(t + THREADS * u, e))];
     }
     __device__ static __forceinline__ void lds_write(const u64 (&x)[8], u64 *lds, const unsigned t) {
         if (N2_EXP & 2) return;
 #pragma unroll
         for (int u = 0; u < G; u++)
 #pragma unroll
-            for (int e = 0; e < (1 << R); e++) lds[swz(elem(t + N2_THREADS * u, e))] = x[(u << R) + e];
+            for (int e = 0; e < (1 << R); e++) lds[swz(elem(t + THREADS * u, e))] = x[(u << R) + e];
     }
     // ---- LDS-DMA staging of the first round's input (contiguous passes): the next row streams into a wave-private
     // 4 KiB staging area while the current row is being transformed, without holding VGPRs for it.  Every DMA
@@ -515,7 +516,7 @@ template <int INV, int STRIDED, int NS, int LOGC, int LS, int R, bool HOISTP = t
         }
 #pragma unroll
         for (int u = 0; u < G; u++) {
-            const unsigned q = t + N2_THREADS * u;
+            const unsigned q = t + THREADS * u;
             if (LOGD == 0) {
 #pragma unroll
                 for (int e = 0; e < (1 << R); e += 2) {
@@ -567,7 +568,7 @@ template <int INV, int STRIDED, int NS, int LOGC, int LS, int R, bool HOISTP = t
         }
 #pragma unroll
         for (int u = 0; u < G; u++) {
-            const unsigned q = threadIdx.x + N2_THREADS * u;
+            const unsigned q = threadIdx.x + THREADS * u;
             if (LOGD == 0) {
 #pragma unroll
                 for (int e = 0; e < (1 << R); e += 2) {
@@ -654,7 +655,8 @@ __device__ __forceinline__ void ntt2_body(const Ntt2Args &a) {
     // [0] the exchange buffer of the rounds, [1] the LDS-DMA staging area of the contiguous passes (one row ahead).  Two rows ahead in the key-switch passes
     // (a third 16 KiB buffer, s_waitcnt vmcnt(4) for the older of two rows in flight) was measured in round 4: 1-2 % SLOWER on all four workloads --
     // the wait at the top of a row is not what those passes are bound by
-    __shared__ u64 lds[2][N2_T];
+    constexpr int LOGT = STRIDED ? NS + LOGC : N2_LOGT; // points of the workgroup's tile: N2_T, or 4096 for the wide strided passes (512 threads, 64 KiB of LDS)
+    __shared__ u64 lds[2][1 << LOGT];
     using P = Plan<NS>;
     // NS == 9, contiguous: every 512-point sub-transform is owned by ONE wave in every round (thread t's points never
     // leave [512*(t/64), 512*(t/64)+512), and the XOR swizzle only permutes address bits 0..4), so the LDS exchange
@@ -1046,12 +1048,12 @@ __device__ __forceinline__ void ntt2_body(const Ntt2Args &a) {
 }
 
 template <int INV, int STRIDED, int NS, int LOGC, int FINAL, int REDUCE, int MAC = 0>
-__global__ __launch_bounds__(N2_THREADS, MAC == 2 ? N2_TENSOR_WAVES : MAC ? N2_MAC_WAVES : N2_MIN_WAVES) void ntt2_kernel(Ntt2Args a) {
+__global__ __launch_bounds__(STRIDED ? (1 << (NS + LOGC - 3)) : N2_THREADS, MAC == 2 ? N2_TENSOR_WAVES : MAC ? N2_MAC_WAVES : N2_MIN_WAVES) void ntt2_kernel(Ntt2Args a) {
     ntt2_body<INV, STRIDED, NS, LOGC, FINAL, REDUCE, MAC, 0>(a);
 }
 // the FP64 instances (primes below 2^50): a kernel name of their own, so that profiles and bench.py's per-kernel accounting tell the two apart
 template <int INV, int STRIDED, int NS, int LOGC, int FINAL, int REDUCE, int MAC = 0>
-__global__ __launch_bounds__(N2_THREADS, MAC ? N2_FP_MAC_WAVES : N2_MIN_WAVES) void ntt2_fp_kernel(Ntt2Args a) {
+__global__ __launch_bounds__(STRIDED ? (1 << (NS + LOGC - 3)) : N2_THREADS, MAC ? N2_FP_MAC_WAVES : N2_MIN_WAVES) void ntt2_fp_kernel(Ntt2Args a) {
     ntt2_body<INV, STRIDED, NS, LOGC, FINAL, REDUCE, MAC, 1>(a);
 }
 
@@ -1063,15 +1065,27 @@ bool ntt2_supported(int logn) { return logn >= 12 && logn <= 17; }
 #else
 #define N2_KTAG(...)
 #endif
+// The forward strided pass is bound by HBM, and the part moves strided rows faster in longer runs: a copy in this pass's pattern reaches 4.9-5.1 TB/s with
+// 256-byte runs and 5.7-6.2 TB/s with 512-byte runs (profiles/r05_microbench_nt.txt).  Wide form (N = 2^15): 512 threads own 64 columns x 64 rows
+// = 4096 points (64 KiB of LDS with the double buffer, two workgroups per CU); taken when the launch still fills the chip twice over.
+#ifndef N2_WIDE
+#define N2_WIDE 1
+#endif
+static bool n2_wide(unsigned narrow_blocks) {
+    static const int forced = [] { const char *e = probe_env("TROYHIP_NTT2_WIDE"); return e ? std::atoi(e) : -1; }();
+    if (forced >= 0) return forced != 0;
+    return N2_WIDE && (narrow_blocks >> 1) >= 4u * device_cus();
+}
 template <int INV, int STRIDED, int NS, int LOGC, int FINAL, int REDUCE> static void launch_one(const Ntt2Args &a, unsigned blocks, hipStream_t s, bool fp = false) {
+    constexpr unsigned THREADS = STRIDED ? (1u << (NS + LOGC - 3)) : N2_THREADS;
     if (fp) {
         N2_KTAG("ntt2_fp_kernel<%d, %d, %d, %d, %d, %d, 0>", INV, STRIDED, NS, LOGC, FINAL, REDUCE);
-        TROY_LAUNCH(HIP_KERNEL_NAME(ntt2_fp_kernel<INV, STRIDED, NS, LOGC, FINAL, REDUCE>), dim3(blocks), dim3(N2_THREADS), 0, s, a);
+        TROY_LAUNCH(HIP_KERNEL_NAME(ntt2_fp_kernel<INV, STRIDED, NS, LOGC, FINAL, REDUCE>), dim3(blocks), dim3(THREADS), 0, s, a);
         launch_check("ntt2_fp_kernel");
         return;
     }
     N2_KTAG("ntt2_kernel<%d, %d, %d, %d, %d, %d, 0>", INV, STRIDED, NS, LOGC, FINAL, REDUCE); // the instance's name as rocprofv3 prints it
-    TROY_LAUNCH(HIP_KERNEL_NAME(ntt2_kernel<INV, STRIDED, NS, LOGC, FINAL, REDUCE>), dim3(blocks), dim3(N2_THREADS), 0, s, a);
+    TROY_LAUNCH(HIP_KERNEL_NAME(ntt2_kernel<INV, STRIDED, NS, LOGC, FINAL, REDUCE>), dim3(blocks), dim3(THREADS), 0, s, a);
     launch_check("ntt2_kernel");
 }
 template <int INV, int NS> static void launch_contig(const Ntt2Args &a, unsigned blocks, bool final_pass, hipStream_t s, bool fp = false) {
@@ -1087,6 +1101,17 @@ template <int INV, int NS> static void launch_strided(const Ntt2Args &a, unsigne
         else launch_one<1, 1, NS, LOGC, 2, 0>(a, blocks, s, fp);
     } else {
         (void)final_pass;
+        if constexpr (NS == 6) { // N = 2^15: 32 columns = 256-byte runs; the wide form doubles them (n2_wide).  (N = 2^16, NS = 7, 16 -> 32 columns: measured 4 % SLOWER on BGV)
+            // not the digit-expanding pass of the key switch (reduce): it writes L + 1 rows per row read and is bound by those writes -- measured
+            // 0-4 % SLOWER wide (2105-2110 -> 2118-2150 us at the headline, 2023-2035 -> 2105-2120 on the 49-bit twin); the plain pass: 1609-1636 -> 1432-1438
+            if (!reduce && n2_wide(blocks)) {
+                Ntt2Args w = a;
+                w.tiles_per_row_log = a.tiles_per_row_log - 1;
+                stats::counter(stats::NTT2_WIDE_LAUNCHES).fetch_add(1, std::memory_order_relaxed);
+                launch_one<0, 1, NS, LOGC + 1, 0, 0>(w, blocks >> 1, s, fp);
+                return;
+            }
+        }
         if (reduce && skip_diag) launch_one<0, 1, NS, LOGC, 0, 2>(a, blocks, s, fp);
         else if (reduce) launch_one<0, 1, NS, LOGC, 0, 1>(a, blocks, s, fp);
         else launch_one<0, 1, NS, LOGC, 0, 0>(a, blocks, s, fp);
@@ -1237,12 +1262,7 @@ void launch_ntt2_slots(u64 *data, const u64 *src, u64 src_ostride, bool src_redu
 // (ntt2_fp_kernel: 8-instruction butterflies, D holds doubles for those slots), the rest the integer instances.  host_primes = the
 // context's prime registry (indexed by map.id; digit k is a residue of host_primes[k]).
 template <int NS> static void launch_ks_first(const Ntt2Args &first, unsigned blocks, bool fp, bool skip_diag, hipStream_t stream) {
-    constexpr int LOGC = N2_LOGT - NS;
-    if (!fp) { launch_strided<0, NS>(first, blocks, false, true, stream, -1, skip_diag); return; }
-    N2_KTAG("ntt2_fp_kernel<0, 1, %d, %d, 0, %d, 0>", NS, LOGC, skip_diag ? 2 : 1);
-    if (skip_diag) TROY_LAUNCH(HIP_KERNEL_NAME(ntt2_fp_kernel<0, 1, NS, LOGC, 0, 2>), dim3(blocks), dim3(N2_THREADS), 0, stream, first);
-    else TROY_LAUNCH(HIP_KERNEL_NAME(ntt2_fp_kernel<0, 1, NS, LOGC, 0, 1>), dim3(blocks), dim3(N2_THREADS), 0, stream, first);
-    launch_check("ntt2_fp_kernel(ks first pass)");
+    launch_strided<0, NS>(first, blocks, false, true, stream, -1, skip_diag, fp); // (launch_one names and launches the FP64 instance)
 }
 void launch_ntt2_ks_mac(u64 *D, const u64 *src, u64 src_ostride, const PrimeDesc *primes, const LimbMap &map, size_t rows, int logn, const u64 *key, u64 *acc,
                         const uint8_t *key_limb, unsigned K, const u64 *ckks_target, u64 t_bstride, bool lazy, u64 src_bound, hipStream_t stream) {

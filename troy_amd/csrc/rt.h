@@ -58,9 +58,9 @@ inline const char *probe_env(const char *name) {
 // Path counters (troyhip_stat, include/troyhip.h): which kernel class a launcher chose.  The parity tests read them so that a test of
 // the FP64 instances cannot pass on the integer kernels (or the other way round) without saying so.
 namespace stats {
-enum { KS_FP_LAUNCHES, KS_INT_LAUNCHES, NTT1_FP_LAUNCHES, NTT1_INT_LAUNCHES, NTT2_FP_LAUNCHES, NTT2_INT_LAUNCHES, BEHZ_FP_LAUNCHES, BEHZ_MFMA_LAUNCHES, BEHZ_VALU_LAUNCHES, COUNT };
+enum { KS_FP_LAUNCHES, KS_INT_LAUNCHES, NTT1_FP_LAUNCHES, NTT1_INT_LAUNCHES, NTT2_FP_LAUNCHES, NTT2_INT_LAUNCHES, BEHZ_FP_LAUNCHES, BEHZ_MFMA_LAUNCHES, BEHZ_VALU_LAUNCHES, NTT2_WIDE_LAUNCHES, COUNT };
 inline std::atomic<uint64_t> &counter(int i) { static std::atomic<uint64_t> c[COUNT]; return c[i]; } // host threads launch concurrently (one context per thread)
-inline const char *name(int i) { static const char *n[COUNT] = {"ks_fp_launches", "ks_int_launches", "ntt1_fp_launches", "ntt1_int_launches", "ntt2_fp_launches", "ntt2_int_launches", "behz_fp_launches", "behz_mfma_launches", "behz_valu_launches"}; return n[i]; }
+inline const char *name(int i) { static const char *n[COUNT] = {"ks_fp_launches", "ks_int_launches", "ntt1_fp_launches", "ntt1_int_launches", "ntt2_fp_launches", "ntt2_int_launches", "behz_fp_launches", "behz_mfma_launches", "behz_valu_launches", "ntt2_wide_launches"}; return n[i]; }
 }
 
 typedef uint64_t u64;
