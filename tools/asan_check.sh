@@ -9,6 +9,9 @@ make -s -j8 -C troy_amd/csrc emul OBJDIR=/tmp/troy_build_asan EMUL_OUT=/tmp/libt
      EMUL_FLAGS="-O1 -g -fsanitize=address -fno-omit-frame-pointer" EMUL_LDFLAGS="-fsanitize=address"
 export ASAN_OPTIONS=detect_leaks=0:detect_stack_use_after_return=0   # ucontext fibers: no fake stacks
 LD_PRELOAD=$(gcc -print-file-name=libasan.so) TROYHIP_NTT=single python tools/asan_run.py
+# the launch shapes the library only takes for large grids, forced: the wide strided pass, the XCD-aware (grouped) workgroup order
+LD_PRELOAD=$(gcc -print-file-name=libasan.so) TROYHIP_NTT=twopass TROYHIP_NTT2_WIDE=1 python tools/asan_run.py
+LD_PRELOAD=$(gcc -print-file-name=libasan.so) TROYHIP_NTT=single TROYHIP_NTT1_XCD=1 TROYHIP_NTT1_XCD_GROUP=3 python tools/asan_run.py
 # UndefinedBehaviorSanitizer over the same drive (default kernels and the alternative forms)
 make -s -j8 -C troy_amd/csrc emul OBJDIR=/tmp/troy_build_ubsan EMUL_OUT=/tmp/libtroyhip_emul_ubsan.so \
      EMUL_FLAGS="-O1 -g -fsanitize=undefined -fno-sanitize-recover=undefined" EMUL_LDFLAGS="-fsanitize=undefined"
