@@ -42,6 +42,21 @@ template <int POL, int COLS> __global__ __launch_bounds__(256) void strided_kern
         }
     }
 }
+// the access pattern of the BEHZ conversions: a workgroup walks tiles of RUN bytes of ONE polynomial, reading the tile's position in 14 limb rows (256 KiB apart)
+// and writing it in 15 -- 29 streams with a stride of a limb.  RUN = 512 is the library's (64 coefficients); longer runs = fewer DRAM page visits per byte.
+template <int RUN> __global__ __launch_bounds__(256) void limbs_kernel(const u64 *in, u64 *out, size_t polys) {
+    constexpr int W = RUN / 8;                 // words per run
+    constexpr int TILES = 32768 / W;           // tiles per polynomial
+    for (size_t t = blockIdx.x; t < polys * TILES; t += gridDim.x) {
+        const size_t poly = t / TILES, tile = t % TILES;
+        const u64 *src = in + poly * 14 * 32768 + tile * W;
+        u64 *dst = out + poly * 15 * 32768 + tile * W;
+        // 256 threads: thread t handles word t % W of limbs t / W, t / W + 256 / W, ...
+        u64 acc = 0;
+        for (int l = threadIdx.x / W; l < 14; l += 256 / W) acc += src[(size_t)l * 32768 + threadIdx.x % W];
+        for (int l = threadIdx.x / W; l < 15; l += 256 / W) dst[(size_t)l * 32768 + threadIdx.x % W] = acc + l;
+    }
+}
 int main() {
     const size_t bytes = (size_t)4 << 30, rows = bytes / (256 << 10);
     v2 *in, *out, *table;
@@ -67,6 +82,23 @@ int main() {
                 }
                 printf("grid %5d  %s  %s  %7.3f ms  %6.2f TB/s (read + write)\n", grid, tab ? "with table" : "no table  ", names[pol], best, 2.0 * bytes / best / 1e9);
             }
+    {
+        const size_t polys = bytes / (15 * 32768 * 8);
+        for (int grid : {256 * 16, 256 * 8})
+            for (int run : {512, 1024, 2048}) {
+                float best = 1e30f;
+                for (int rep = 0; rep < 5; rep++) {
+                    hipEventRecord(e0);
+                    if (run == 512) limbs_kernel<512><<<grid, 256>>>((const u64 *)in, (u64 *)out, polys);
+                    else if (run == 1024) limbs_kernel<1024><<<grid, 256>>>((const u64 *)in, (u64 *)out, polys);
+                    else limbs_kernel<2048><<<grid, 256>>>((const u64 *)in, (u64 *)out, polys);
+                    hipEventRecord(e1); hipEventSynchronize(e1);
+                    float ms; hipEventElapsedTime(&ms, e0, e1);
+                    if (ms < best) best = ms;
+                }
+                printf("limb streams (14 in, 15 out, 256 KiB apart)  runs of %4d bytes  grid %5d  %7.3f ms  %6.2f TB/s (read + write)\n", run, grid, best, polys * 29.0 * 32768 * 8 / best / 1e9);
+            }
+    }
     for (int cols : {32, 64})
         for (int grid : {256 * 16, 256 * 8, 256 * 4})
             for (int pol = 0; pol < 4; pol++) {
