@@ -7,14 +7,15 @@
 typedef unsigned long long u64;
 typedef u64 v2 __attribute__((ext_vector_type(2)));
 
-template <int POL> __global__ __launch_bounds__(256) void copy_kernel(const v2 *in, v2 *out, const v2 *table, size_t rows, int use_table) {
-    // one workgroup per 256 KiB row at a time (16384 x 16 B), 64 iterations of 256 threads
+template <int POL> __global__ __launch_bounds__(256) void copy_kernel(const v2 *in, v2 *out, const v2 *table, size_t rows, int use_table, int rotate = 0) {
+    // one workgroup per 256 KiB row at a time (16384 x 16 B), 64 iterations of 256 threads; rotate: every workgroup starts its rows at another 4 KiB piece
+    const unsigned rot = rotate ? (blockIdx.x * 7u) & 63u : 0u;
     for (size_t r = blockIdx.x; r < rows; r += gridDim.x) {
         const v2 *src = in + r * 16384;
         v2 *dst = out + r * 16384;
 #pragma unroll 4
         for (int i = 0; i < 64; i++) {
-            const unsigned k = threadIdx.x + 256 * i;
+            const unsigned k = threadIdx.x + 256 * ((i + rot) & 63u);
             v2 v = (POL & 1) ? __builtin_nontemporal_load(src + k) : src[k];
             if (use_table) { const v2 t = table[k & 32767]; v.x ^= t.x; v.y += t.y; } // a 512 KiB table shared by every row
             if (POL & 2) __builtin_nontemporal_store(v, dst + k); else dst[k] = v;
@@ -99,6 +100,18 @@ int main() {
                 printf("limb streams (14 in, 15 out, 256 KiB apart)  runs of %4d bytes  grid %5d  %7.3f ms  %6.2f TB/s (read + write)\n", run, grid, best, polys * 29.0 * 32768 * 8 / best / 1e9);
             }
     }
+    for (int rot = 0; rot < 2; rot++)
+        for (int grid : {256 * 8, 256 * 4}) {
+            float best = 1e30f;
+            for (int rep = 0; rep < 5; rep++) {
+                hipEventRecord(e0);
+                copy_kernel<2><<<grid, 256>>>(in, out, table, rows, 0, rot);
+                hipEventRecord(e1); hipEventSynchronize(e1);
+                float ms; hipEventElapsedTime(&ms, e0, e1);
+                if (ms < best) best = ms;
+            }
+            printf("contiguous rows, NT stores, %s  grid %5d  %7.3f ms  %6.2f TB/s (read + write)\n", rot ? "rotated start per workgroup" : "every workgroup from offset 0 ", grid, best, 2.0 * bytes / best / 1e9);
+        }
     for (int cols : {32, 64})
         for (int grid : {256 * 16, 256 * 8, 256 * 4})
             for (int pol = 0; pol < 4; pol++) {
