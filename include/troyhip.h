@@ -63,8 +63,11 @@ int troyhip_free(void *p);                          /* KernelProvider::free */
  * troyhip_stream_create and every stream announced with troyhip_stream_register: a block freed while work on one of THOSE streams still
  * uses it is not handed out before that work has passed.  A stream made elsewhere (a caller-created hipStream_t, a torch / RCCL stream) is
  * announced automatically the first time any entry point of this header is handed it; work the CALLER launches on such a stream before the
- * library has ever seen it is not covered -- troyhip_stream_register it first, or synchronise it before troyhip_free.  troyhip_pool_release
- * synchronises the device and returns every cached block to the driver. */
+ * library has ever seen it is not covered -- troyhip_stream_register it first, or synchronise it before troyhip_free.  A stream the pool
+ * knows -- registered explicitly OR announced automatically -- must be released with troyhip_stream_unregister BEFORE its owner destroys it:
+ * every later troyhip_free records an event on each known stream, and a destroyed hipStream_t is a dangling handle (the pool drops a stream
+ * whose record fails, but whether the runtime fails cleanly on a dead handle is the runtime's business, not a guarantee of this interface).
+ * troyhip_pool_release synchronises the device and returns every cached block to the driver. */
 int troyhip_pool_release(void);
 int troyhip_copy_h2d(void *dst, const void *src, size_t bytes, void *stream);   /* KernelProvider::copy */
 int troyhip_copy_d2h(void *dst, const void *src, size_t bytes, void *stream);   /* KernelProvider::retrieve */

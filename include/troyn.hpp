@@ -183,8 +183,21 @@ public:
     SEALContext(const EncryptionParameters &parms, bool expand_mod_chain = true, SecurityLevel sec = SecurityLevel::tc128) : parms_(parms) {
         (void)expand_mod_chain;
         std::vector<uint64_t> q;
+        for (auto &m : parms.coeffModulus()) q.push_back(m.value());
+        // the bit count of the PRODUCT of the primes (total_coeff_modulus_bit_count_, src/context.cpp:180-183), which can be up to k - 1 bits
+        // below the sum of the primes' own bit counts
         int total_bits = 0;
-        for (auto &m : parms.coeffModulus()) { q.push_back(m.value()); total_bits += m.bitCount(); }
+        {
+            std::vector<uint64_t> prod{1};
+            for (uint64_t v : q) {
+                unsigned __int128 carry = 0;
+                for (auto &w : prod) { const unsigned __int128 t = (unsigned __int128)w * v + carry; w = (uint64_t)t; carry = t >> 64; }
+                if (carry) prod.push_back((uint64_t)carry);
+            }
+            while (prod.size() > 1 && !prod.back()) prod.pop_back();
+            total_bits = (int)(64 * (prod.size() - 1));
+            for (uint64_t t = prod.back(); t; t >>= 1) total_bits++;
+        }
         // src/context.cpp:181-197: with a security level, the key-level modulus must fit the standard's bound (the reference records
         // ErrorType::invalid_parameters_insecure and every later use throws; here invalid parameters throw from the constructor)
         if (sec != SecurityLevel::none && total_bits > CoeffModulus::MaxBitCount(parms.polyModulusDegree(), sec))
@@ -341,6 +354,21 @@ inline void get_words(std::istream &s, uint64_t *w, size_t count) {
     s.read(reinterpret_cast<char *>(w), (std::streamsize)(count * 8));
     if (!s) throw std::invalid_argument("stream ended inside a serialized object");
 }
+// `words` payload words into a vector that grows with what the stream really delivers (16 MiB at a time): a forged header cannot make the
+// loader allocate gigabytes for a stream of a few bytes
+inline std::vector<uint64_t> get_vector(std::istream &s, size_t words, size_t room = 0) {
+    std::vector<uint64_t> v;
+    const size_t step = size_t(1) << 21;
+    for (size_t at = 0; at < words;) {
+        const size_t n = std::min(step, words - at);
+        v.resize(at + n);
+        get_words(s, v.data() + at, n);
+        at += n;
+    }
+    v.resize(words + room, 0);
+    return v;
+}
+constexpr size_t max_ct_size = 16; // polynomials per ciphertext the library handles (relinearize: src/evaluator_cuda.cu:703-744 takes "any size <= 16")
 // the fields CiphertextCuda::save writes ahead of the data (src/ciphertext_cuda.cu:16-25): parms_id, is_ntt_form, size, poly_modulus_degree,
 // coeff_modulus_size, scale, correction_factor, seed, terms
 struct CtFields { uint64_t id[4]; bool ntt; size_t size, n, limbs; double scale; uint64_t cf, seed; bool terms; };
@@ -355,7 +383,7 @@ inline CtFields get_fields(std::istream &s) {
     f.ntt = get<bool>(s); f.size = get<size_t>(s); f.n = get<size_t>(s); f.limbs = get<size_t>(s);
     f.scale = get<double>(s); f.cf = get<uint64_t>(s); f.seed = get<uint64_t>(s); f.terms = get<bool>(s);
     // sizes that cannot be a ciphertext (a corrupted or foreign stream) stop here, not in an allocation
-    if (!f.n || (f.n & (f.n - 1)) || f.n > (size_t(1) << 17) || f.limbs < 1 || f.limbs > 64 || f.size > 1024) throw std::invalid_argument("the stream does not hold a ciphertext");
+    if (!f.n || (f.n & (f.n - 1)) || f.n > (size_t(1) << 17) || f.limbs < 1 || f.limbs > 64 || f.size > max_ct_size) throw std::invalid_argument("the stream does not hold a ciphertext");
     return f;
 }
 } // namespace wire
@@ -754,9 +782,7 @@ public:
         (void)wire::get<double>(stream);
         const size_t words = wire::get<size_t>(stream);
         if (words != count || words > (size_t(1) << 23)) throw std::invalid_argument("the stream does not hold a secret key"); // at most 64 limbs of 2^17 coefficients
-        std::vector<uint64_t> host(words);
-        wire::get_words(stream, host.data(), words);
-        data = std::move(host);
+        data = wire::get_vector(stream, words);
         parms_id = id; // the limb count behind the hash comes back when the key meets its context (limbs stays 0 until then)
     }
 };
@@ -782,9 +808,7 @@ public:
         if (f.seed) throw std::invalid_argument("seed is not zero.");
         const size_t words = wire::get<size_t>(stream);
         if (f.size != 2 || words != 2 * f.limbs * f.n) throw std::invalid_argument("the stream does not hold a public key");
-        std::vector<uint64_t> host(words);
-        wire::get_words(stream, host.data(), words);
-        data = std::move(host);
+        data = wire::get_vector(stream, words);
         std::copy(f.id, f.id + 4, parms_id.begin());
         parms_id.limbs = (int)f.limbs;
         poly_modulus_degree = f.n;
@@ -796,6 +820,14 @@ class KSwitchKeys { // src/kswitchkeys_cuda.cuh:43-56: data()[index] on the devi
 public:
     bool hasKeyIndex(size_t index) const { return keys_.count(index) != 0; }
     const uint64_t *device(size_t index) const { return keys_.at(index)->get(); }
+    // the key an evaluator hands to the key-switch kernels: it must have been generated (or saved) under the SAME context -- same key-level
+    // parms_id, [K - 1][2][K][N] words -- or the kernels would read past it (a loaded key can have any shape)
+    const uint64_t *device(size_t index, const ParmsID &key_parms_id, size_t key_limbs, size_t poly_modulus_degree) const {
+        const auto &a = keys_.at(index);
+        if (parms_id_ != key_parms_id || key_limbs < 2 || a->size() != (key_limbs - 1) * 2 * key_limbs * poly_modulus_degree)
+            throw std::invalid_argument("kswitch_keys is not valid for encryption parameters");
+        return a->get();
+    }
     void upload(size_t index, const std::vector<uint64_t> &host) {
         auto a = std::make_shared<DeviceArray>(host.size());
         check(troyhip_copy_h2d(a->get(), host.data(), host.size() * 8, nullptr));
@@ -835,13 +867,13 @@ public:
         ParmsID id;
         stream.read(reinterpret_cast<char *>(id.data()), 32);
         const size_t slots = wire::get<size_t>(stream);
-        if (slots > (size_t(1) << 21)) throw std::invalid_argument("the stream does not hold key-switching keys");
+        if (slots > (size_t(1) << 18)) throw std::invalid_argument("the stream does not hold key-switching keys");
         std::map<size_t, std::shared_ptr<DeviceArray>> fresh;
         size_t n = 0, limbs = 0;
         for (size_t i = 0; i < slots; i++) {
             const size_t digits = wire::get<size_t>(stream);
             if (!digits) continue;
-            if (digits > 256) throw std::invalid_argument("the stream does not hold key-switching keys");
+            if (digits > 63) throw std::invalid_argument("the stream does not hold key-switching keys"); // one digit per data prime: at most 64 limbs
             std::vector<uint64_t> host;
             for (size_t j = 0; j < digits; j++) {
                 const wire::CtFields f = wire::get_fields(stream);
@@ -849,8 +881,8 @@ public:
                 if (f.terms || f.seed || f.size != 2 || f.limbs != digits + 1 || words != 2 * f.limbs * f.n || (n && (f.n != n || f.limbs != limbs)))
                     throw std::invalid_argument("the stream does not hold key-switching keys");
                 n = f.n; limbs = f.limbs;
-                host.resize(digits * words);
-                wire::get_words(stream, host.data() + j * words, words);
+                const std::vector<uint64_t> digit = wire::get_vector(stream, words); // (grows with the stream, not with the header)
+                host.insert(host.end(), digit.begin(), digit.end());
             }
             auto a = std::make_shared<DeviceArray>(host.size());
             check(troyhip_copy_h2d(a->get(), host.data(), host.size() * 8, nullptr));
@@ -991,13 +1023,23 @@ private:
 class Encryptor { // src/encryptor_cuda.cuh:20-300, CPU sampling + upload
 public:
     // every encryption draws a fresh 128-bit seed for its samples from the operating system (src/randomgen.cpp:23,72)
-    Encryptor(const SEALContext &c, const PublicKey &pk) : c_(c), pk_(pk) {}
-    Encryptor(const SEALContext &c, const SecretKey &sk) : c_(c), sk_(sk) {}
-    Encryptor(const SEALContext &c, const PublicKey &pk, const SecretKey &sk) : c_(c), pk_(pk), sk_(sk) {}
+    // keys of another context (a loaded key can have any shape) are refused here, as the reference's Encryptor does (src/encryptor.cpp:31-46,
+    // "public_key / secret_key is not valid for encryption parameters"): the host encryption reads 2 K N / K N words of them
+    Encryptor(const SEALContext &c, const PublicKey &pk) : c_(c), pk_(valid(c, pk)) {}
+    Encryptor(const SEALContext &c, const SecretKey &sk) : c_(c), sk_(valid(c, sk)) {}
+    Encryptor(const SEALContext &c, const PublicKey &pk, const SecretKey &sk) : c_(c), pk_(valid(c, pk)), sk_(valid(c, sk)) {}
     // deterministic stream (seed, call counter) for tests ONLY
-    Encryptor(const SEALContext &c, const PublicKey &pk, uint64_t seed_lo, uint64_t seed_hi = 0) : c_(c), pk_(pk), seeded_(true), lo_(seed_lo), hi_(seed_hi) {}
-    void setPublicKey(const PublicKey &pk) { pk_ = pk; }
-    void setSecretKey(const SecretKey &sk) { sk_ = sk; }
+    Encryptor(const SEALContext &c, const PublicKey &pk, uint64_t seed_lo, uint64_t seed_hi = 0) : c_(c), pk_(valid(c, pk)), seeded_(true), lo_(seed_lo), hi_(seed_hi) {}
+    void setPublicKey(const PublicKey &pk) { pk_ = valid(c_, pk); }
+    void setSecretKey(const SecretKey &sk) { sk_ = valid(c_, sk); }
+    static const PublicKey &valid(const SEALContext &c, const PublicKey &pk) {
+        if (pk.parms_id != c.keyParmsID() || pk.data.size() != 2 * c.keyLimbs() * c.polyModulusDegree()) throw std::invalid_argument("public_key is not valid for encryption parameters");
+        return pk;
+    }
+    static const SecretKey &valid(const SEALContext &c, const SecretKey &sk) {
+        if (sk.parms_id != c.keyParmsID() || sk.data.size() != c.keyLimbs() * c.polyModulusDegree()) throw std::invalid_argument("secret_key is not valid for encryption parameters");
+        return sk;
+    }
     // The CPU reference refuses without a public key (src/encryptor.cpp:157-160); EncryptorCuda has no such check and its own caller
     // test/evaluator_cuda.cu:2566-2569 (BFVKeySwitching) encrypts through an Encryptor that was given ONLY a secret key -- meaning "a
     // ciphertext under that key".  An encryptor that holds just a secret key therefore encrypts symmetrically; one that holds neither throws.
@@ -1014,7 +1056,7 @@ public:
     // The ciphertext carries the seed its c1 was expanded from (dst.seed() != 0: src/utils/rlwe_cuda.cu:292-303), so save() writes half of it.
     void encryptSymmetric(const Plaintext &plain, Ciphertext &dst) const {
         if (sk_.data.empty()) throw std::logic_error("secret key is not set"); // src/encryptor.cpp:164-167
-        const uint64_t a_seed = fresh_a_seed();
+        const uint64_t a_seed = fresh_a_seed(counter_ + 1); // run() below consumes call number counter_ + 1: the seed belongs to THAT call
         run([a_seed](const troyhip_context *c, uint64_t lo, uint64_t hi, const uint64_t *key, const uint64_t *pl, uint64_t count, int limbs, uint64_t *out) {
             return troyhip_host_encrypt_symmetric_seeded(c, lo, hi, a_seed, key, pl, count, limbs, out);
         }, sk_.data, plain, dst);
@@ -1035,9 +1077,10 @@ public:
         zero(sk_.data, 1, parms_id, dst);
     }
     // a public 64-bit seed for c1, never zero (zero means "not seeded" on the wire): from the deterministic stream of a seeded encryptor, else fresh
-    uint64_t fresh_a_seed() const {
+    // `call` = the value of the call counter the calling encryption consumes (each call its own: two encryptions never share c1)
+    uint64_t fresh_a_seed(uint64_t call) const {
         uint64_t a = 0;
-        if (seeded_) a = (lo_ ^ 0x9E3779B97F4A7C15ull) + 0xD1B54A32D192ED03ull * (counter_ + 1);
+        if (seeded_) a = (lo_ ^ 0x9E3779B97F4A7C15ull) + 0xD1B54A32D192ED03ull * call;
         else check(troyhip_random_bytes(&a, sizeof(a)));
         return a ? a : 1;
     }
@@ -1052,7 +1095,7 @@ private:
         std::vector<uint64_t> h((size_t)2 * id.limbs * N);
         uint64_t s[2] = {lo_ + (++counter_), hi_};
         if (!seeded_) check(troyhip_random_bytes(s, sizeof(s)));
-        const uint64_t a_seed = symmetric ? fresh_a_seed() : 0;
+        const uint64_t a_seed = symmetric ? fresh_a_seed(counter_) : 0;
         if (symmetric) check(troyhip_host_encrypt_symmetric_seeded(c_.handle(), s[0], s[1], a_seed, key.data(), nullptr, 0, id.limbs, h.data()));
         else check(troyhip_host_encrypt_zero(c_.handle(), s[0], s[1], key.data(), 0, id.limbs, h.data()));
         dst.fromHost(h, N, (size_t)id.limbs, 2, ckks, 1.0, 1);
@@ -1082,7 +1125,7 @@ private:
 
 class Decryptor { // src/decryptor_cuda.cuh:13-60: the secret key is uploaded once, decryption runs on the device
 public:
-    Decryptor(const SEALContext &c, const SecretKey &sk) : c_(c), sk_(sk.data.size()) {
+    Decryptor(const SEALContext &c, const SecretKey &sk) : c_(c), sk_(Encryptor::valid(c, sk).data.size()) { // src/decryptor.cpp:46-55: a key of another context is refused
         check(troyhip_copy_h2d(sk_.get(), sk.data.data(), sk.data.size() * 8, nullptr));
     }
     void decrypt(const Ciphertext &ct, Plaintext &dst) const {
@@ -1400,6 +1443,8 @@ class Evaluator { // src/evaluator_cuda.cuh:13-361 -- every method const, non-co
 public:
     explicit Evaluator(const SEALContext &c) : c_(c) {}
     const SEALContext &context() const { return c_; }
+    // a key-switching key as the kernels take it, refused unless it belongs to this evaluator's context (KSwitchKeys::device)
+    const uint64_t *key_of(const KSwitchKeys &k, size_t index) const { return k.device(index, c_.keyParmsID(), c_.keyLimbs(), c_.polyModulusDegree()); }
     Evaluator(const Evaluator &) = delete;
     Evaluator &operator=(const Evaluator &) = delete;
 
@@ -1434,7 +1479,7 @@ public:
         std::vector<const uint64_t *> keys(need ? need : 1, nullptr);
         for (size_t i = 0; i < need; i++) {
             if (!k.hasKey(i + 2)) throw std::invalid_argument("not enough relinearization keys");
-            keys[i] = k.device(RelinKeys::getIndex(i + 2));
+            keys[i] = key_of(k, RelinKeys::getIndex(i + 2));
         }
         check(troyhip_relinearize_keys(h(), a.raw(), keys.data(), (int)need, 1, nullptr));
     }
@@ -1442,7 +1487,7 @@ public:
     void relinearize(const Ciphertext &a, const RelinKeys &k, Ciphertext &d) const {
         if (a.size() != 3 || &d == &a) { d = a; relinearizeInplace(d, k); return; }
         if (!k.hasKey(2)) throw std::invalid_argument("not enough relinearization keys");
-        const uint64_t *key = k.device(RelinKeys::getIndex(2));
+        const uint64_t *key = key_of(k, RelinKeys::getIndex(2));
         Ciphertext out;
         out.resize(a.polyModulusDegree(), a.coeffModulusSize(), 2);
         check(troyhip_relinearize_to(h(), a.raw(), out.raw(), &key, 1, 1, nullptr));
@@ -1452,7 +1497,7 @@ public:
     // applyKeySwitchingInplace (evaluator_cuda.cu:1365-1378), negacyclicShiftInplace (:2342-2351)
     void applyKeySwitchingInplace(Ciphertext &a, const KSwitchKeys &k) const {
         if (k.all().size() != 1) throw std::invalid_argument("kswitch_keys.data().size() != 1");
-        check(troyhip_apply_key_switching(h(), a.raw(), k.all().begin()->second->get(), 1, nullptr));
+        check(troyhip_apply_key_switching(h(), a.raw(), key_of(k, k.all().begin()->first), 1, nullptr));
     }
     void applyKeySwitching(const Ciphertext &a, const KSwitchKeys &k, Ciphertext &d) const { d = a; applyKeySwitchingInplace(d, k); } // src/evaluator_cuda.cuh:104-110
     void negacyclicShiftInplace(Ciphertext &a, size_t shift) const { check(troyhip_negacyclic_shift(h(), a.raw(), shift, 1, nullptr)); }
@@ -1514,7 +1559,7 @@ public:
     void rescaleTo(const Ciphertext &a, const ParmsID &parms_id, Ciphertext &d) const { d = a; rescaleToInplace(d, parms_id); } // :193-198
     void applyGaloisInplace(Ciphertext &a, uint32_t galois_elt, const GaloisKeys &gk) const {
         if (!gk.hasKey(galois_elt)) throw std::invalid_argument("Galois key not present");
-        check(troyhip_apply_galois(h(), a.raw(), galois_elt, gk.device(GaloisKeys::getIndex(galois_elt)), 1, nullptr));
+        check(troyhip_apply_galois(h(), a.raw(), galois_elt, key_of(gk, GaloisKeys::getIndex(galois_elt)), 1, nullptr));
     }
     void rotateRowsInplace(Ciphertext &a, int steps, const GaloisKeys &gk) const { need(SchemeType::ckks, false); rotate(a, steps, 0, gk); }
     void rotateColumnsInplace(Ciphertext &a, const GaloisKeys &gk) const { need(SchemeType::ckks, false); rotate(a, 0, 1, gk); }
@@ -1641,7 +1686,7 @@ public:
     void relinearizeInplaceBatch(std::vector<Ciphertext> &items, const RelinKeys &k) const { relinearizeInplaceBatch(Ciphertext::pointers(items), k); }
     void applyKeySwitchingInplaceBatch(const std::vector<Ciphertext *> &items, const KSwitchKeys &k) const {
         if (k.all().size() != 1) throw std::invalid_argument("kswitch_keys.data().size() != 1");
-        const uint64_t *key = k.all().begin()->second->get();
+        const uint64_t *key = key_of(k, k.all().begin()->first);
         inplaceBatch(items, [&](troyhip_ct *v, size_t count, const Ciphertext &) { check(troyhip_apply_key_switching(h(), v, key, count, nullptr)); });
     }
     std::vector<Ciphertext> modSwitchToNextBatch(const std::vector<const Ciphertext *> &a) const { return nextBatch(a, troyhip_mod_switch_to_next); }
@@ -1654,7 +1699,7 @@ public:
     void rescaleToNextInplaceBatch(std::vector<Ciphertext> &items) const { rescaleToNextInplaceBatch(Ciphertext::pointers(items)); }
     void applyGaloisInplaceBatch(const std::vector<Ciphertext *> &items, uint32_t galois_elt, const GaloisKeys &gk) const {
         if (!gk.hasKey(galois_elt)) throw std::invalid_argument("Galois key not present");
-        const uint64_t *key = gk.device(GaloisKeys::getIndex(galois_elt));
+        const uint64_t *key = key_of(gk, GaloisKeys::getIndex(galois_elt));
         inplaceBatch(items, [&](troyhip_ct *v, size_t count, const Ciphertext &) { check(troyhip_apply_galois(h(), v, galois_elt, key, count, nullptr)); });
     }
     void applyGaloisInplaceBatch(std::vector<Ciphertext> &items, uint32_t galois_elt, const GaloisKeys &gk) const { applyGaloisInplaceBatch(Ciphertext::pointers(items), galois_elt, gk); }
@@ -1882,7 +1927,7 @@ private:
         std::vector<const uint64_t *> keys(need ? need : 1, nullptr);
         for (size_t i = 0; i < need; i++) {
             if (!k.hasKey(i + 2)) throw std::invalid_argument("not enough relinearization keys");
-            keys[i] = k.device(RelinKeys::getIndex(i + 2));
+            keys[i] = key_of(k, RelinKeys::getIndex(i + 2));
         }
         return keys;
     }
@@ -1954,7 +1999,7 @@ inline Header get_header(std::istream &s, const SEALContext &c) {
     Header h;
     h.ntt = get<bool>(s); h.size = get<size_t>(s); h.n = get<size_t>(s); h.limbs = get<size_t>(s);
     h.scale = get<double>(s); h.cf = get<uint64_t>(s); h.seed = get<uint64_t>(s); h.terms = get<bool>(s);
-    if (h.n != c.polyModulusDegree() || h.limbs < 1 || h.limbs > c.keyLimbs() || h.size < 1) throw std::invalid_argument("encrypted is not valid for encryption parameters");
+    if (h.n != c.polyModulusDegree() || h.limbs < 1 || h.limbs > c.keyLimbs() || h.size < 1 || h.size > max_ct_size) throw std::invalid_argument("encrypted is not valid for encryption parameters");
     check(troyhip_context_parms_id(c.handle(), (int)h.limbs, mine));
     if (!std::equal(id, id + 4, mine)) throw std::invalid_argument("encrypted is not valid for encryption parameters");
     return h;
@@ -1977,8 +2022,7 @@ inline void Ciphertext::load(std::istream &stream, const SEALContext &context) {
     if (h.seed && h.size > 2) throw std::invalid_argument("Seed exists but size is not 2.");
     const size_t words = wire::get<size_t>(stream), poly = h.limbs * h.n;
     if (words != (h.seed ? poly : h.size * poly)) throw std::invalid_argument("encrypted is not valid for encryption parameters");
-    std::vector<uint64_t> host(h.seed ? 2 * poly : words);
-    wire::get_words(stream, host.data(), words);
+    std::vector<uint64_t> host = wire::get_vector(stream, words, h.seed ? poly : 0);
     if (h.seed) check(troyhip_host_expand_seed(context.handle(), h.seed, (int)h.limbs, host.data() + poly));
     fromHost(host, h.n, h.limbs, h.seed ? 2 : h.size, h.ntt, h.scale, h.cf);
     bind(context);
@@ -2033,9 +2077,7 @@ inline void Ciphertext::load(std::istream &stream) { // src/ciphertext_cuda.cu:6
     if (f.terms) throw std::invalid_argument("Trying to load a termed ciphertext, but indices is not specified");
     const size_t words = wire::get<size_t>(stream);
     if (words != size * limbs * n) throw std::invalid_argument("encrypted is not valid for encryption parameters");
-    std::vector<uint64_t> host(words);
-    stream.read(reinterpret_cast<char *>(host.data()), (std::streamsize)(words * 8));
-    if (!stream) throw std::invalid_argument("stream ended inside a ciphertext");
+    const std::vector<uint64_t> host = wire::get_vector(stream, words);
     fromHost(host, n, limbs, size, ntt, scale, cf);
 }
 inline void Ciphertext::saveTerms(std::ostream &stream, const Evaluator &evaluator, const std::vector<size_t> &termIds) const { saveTerms(stream, evaluator.context(), evaluator, termIds); }

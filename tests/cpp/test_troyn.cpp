@@ -255,6 +255,95 @@ static void scenario(SchemeType scheme, size_t n, std::vector<int> bits, int tbi
     EXPECT(threw, "level mismatch -> invalid_argument");
 }
 
+// Advisor findings of round 5: (1) on a seeded Encryptor two consecutive symmetric encryptions must never share c1 (the public polynomial a): with
+// one a under one key, c0 - c0' = delta m + e - e' gives the plaintext away; (2) keys of another context (a loaded key can have any shape) are
+// refused where they are used, with the reference's messages, instead of being read past their end
+static void key_hygiene() {
+    auto make = [](std::vector<int> bits) {
+        EncryptionParameters p(SchemeType::bfv);
+        p.setPolyModulusDegree(4096);
+        p.setCoeffModulus(CoeffModulus::Create(4096, bits));
+        p.setPlainModulus(PlainModulus::Batching(4096, 20));
+        return p;
+    };
+    SEALContext small(make({36, 36, 37}), true, SecurityLevel::none), big(make({36, 36, 37, 38}), true, SecurityLevel::none);
+    KeyGenerator kg_small(small, 5, 6), kg_big(big, 7, 8);
+    // (1) the seeds of consecutive symmetric encryptions, in every order of the two entry points
+    Encryptor enc(big, kg_big.createPublicKey(), 11, 12);
+    enc.setSecretKey(kg_big.secretKey());
+    const Plaintext m(sparse_poly(4096, 1 << 19, 3, 9));
+    std::vector<Ciphertext> cts;
+    cts.push_back(enc.encryptZeroSymmetric());
+    cts.push_back(enc.encryptSymmetric(m));
+    cts.push_back(enc.encryptSymmetric(m));
+    cts.push_back(enc.encryptZeroSymmetric());
+    cts.push_back(enc.encryptZeroSymmetric());
+    cts.push_back(enc.encryptSymmetric(m));
+    bool distinct = true;
+    for (size_t i = 0; i < cts.size(); i++)
+        for (size_t j = i + 1; j < cts.size(); j++) {
+            const std::vector<uint64_t> a = cts[i].toHost(), b = cts[j].toHost();
+            const size_t poly = a.size() / 2;
+            if (cts[i].seed() == 0 || cts[i].seed() == cts[j].seed() || std::equal(a.begin() + poly, a.end(), b.begin() + poly)) distinct = false;
+        }
+    EXPECT(distinct, "consecutive seeded symmetric encryptions never share seed() or c1");
+    Decryptor dec(big, kg_big.secretKey());
+    Plaintext out;
+    dec.decrypt(cts[1], out);
+    EXPECT(out == m, "seeded symmetric encryption still decrypts");
+    // (2) keys saved under the 3-prime context, loaded, and offered to the 4-prime context
+    auto refused = [](auto &&f, const char *needle) {
+        try { f(); } catch (const std::invalid_argument &e) { return std::string(e.what()).find(needle) != std::string::npos; }
+        return false;
+    };
+    std::stringstream ps, ss, rs, gs;
+    kg_small.createPublicKey().save(ps);
+    kg_small.secretKey().save(ss);
+    kg_small.createRelinKeys().save(rs);
+    GaloisKeys gsmall;
+    kg_small.createGaloisKeys(std::vector<int>{1}, gsmall);
+    gsmall.save(gs);
+    PublicKey pk2; pk2.load(ps);
+    SecretKey sk2; sk2.load(ss);
+    RelinKeys rk2; rk2.load(rs);
+    GaloisKeys gk2; gk2.load(gs);
+    EXPECT(refused([&] { Encryptor e(big, pk2); }, "public_key is not valid"), "Encryptor refuses a public key of another context");
+    EXPECT(refused([&] { Encryptor e(big, sk2); }, "secret_key is not valid"), "Encryptor refuses a secret key of another context");
+    EXPECT(refused([&] { Encryptor e(big, kg_big.createPublicKey()); e.setPublicKey(pk2); }, "public_key is not valid"), "setPublicKey refuses it too");
+    EXPECT(refused([&] { Encryptor e(big, kg_big.createPublicKey()); e.setSecretKey(sk2); }, "secret_key is not valid"), "setSecretKey refuses it too");
+    EXPECT(refused([&] { Decryptor d(big, sk2); }, "secret_key is not valid"), "Decryptor refuses a secret key of another context");
+    Evaluator ev(big);
+    Encryptor pub(big, kg_big.createPublicKey(), 21, 22);
+    Ciphertext x = pub.encrypt(m), y;
+    ev.multiply(x, x, y);
+    EXPECT(refused([&] { Ciphertext z = y; ev.relinearizeInplace(z, rk2); }, "kswitch_keys is not valid"), "relinearize refuses keys of another context");
+    EXPECT(refused([&] { Ciphertext z; ev.relinearize(y, rk2, z); }, "kswitch_keys is not valid"), "relinearize (destination form) refuses them");
+    uint32_t e1 = 0;
+    check(troyhip_galois_elt_from_step(big.handle(), 1, &e1));
+    EXPECT(refused([&] { Ciphertext z = x; ev.applyGaloisInplace(z, e1, gk2); }, "kswitch_keys is not valid"), "applyGalois refuses keys of another context");
+    EXPECT(refused([&] { Ciphertext z = x; ev.applyKeySwitchingInplace(z, rk2); }, "kswitch_keys is not valid"), "applyKeySwitching refuses keys of another context");
+    // the same keys under their own context still work after the round trip
+    Evaluator evs(small);
+    Encryptor es(small, pk2, 31, 32);
+    Decryptor ds(small, sk2);
+    Ciphertext xs = es.encrypt(m), ys;
+    evs.multiply(xs, xs, ys);
+    evs.relinearizeInplace(ys, rk2);
+    ds.decrypt(ys, out);
+    EXPECT(out == Plaintext(negacyclic_mul(sparse_poly(4096, 1 << 19, 3, 9), sparse_poly(4096, 1 << 19, 3, 9), small.parms().plainModulus().value())),
+           "loaded keys work under their own context");
+    // (3) a forged header must not drive an allocation: 70 bytes that announce a maximal ciphertext
+    std::stringstream forged;
+    wire::CtFields f{{1, 2, 3, 4}, false, 16, size_t(1) << 17, 64, 1.0, 1, 0, false};
+    wire::put_fields(forged, f);
+    wire::put<size_t>(forged, f.size * f.n * f.limbs);
+    EXPECT(refused([&] { Ciphertext c; c.load(forged); }, "stream ended"), "a header without its payload is refused before any large allocation");
+    std::stringstream oversized;
+    f.size = 17;
+    wire::put_fields(oversized, f);
+    EXPECT(refused([&] { Ciphertext c; c.load(oversized); }, "does not hold a ciphertext"), "more polynomials than the library handles are refused");
+}
+
 int main() {
     bool threw = false;
     try {
@@ -268,6 +357,7 @@ int main() {
     KernelProvider::initialize();
     scenario(SchemeType::bfv, 4096, {40, 40, 40}, 20);   // BASELINE config A shape
     scenario(SchemeType::bgv, 8192, {50, 40, 40, 50}, 20);
+    key_hygiene();
     std::printf(failures ? "FAILED %d\n" : "ALL OK\n", failures);
     return failures ? 1 : 0;
 }

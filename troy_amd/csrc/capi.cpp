@@ -286,13 +286,17 @@ int troyhip_pool_release(void) { return guard([&] { HIP_CHECK(hipDeviceSynchroni
 // events until a stream is registered).  One compare per call; a stream that was unregistered is announced again when it comes back.
 static inline hipStream_t on(void *stream) {
     if (stream) {
-        static thread_local void *last = nullptr;
+        // the streams this thread has announced in the current epoch: four entries, so that a caller alternating between a few streams (two lanes,
+        // a copy stream) takes neither the pool's mutex nor its linear search per call
+        static thread_local void *seen[4] = {nullptr, nullptr, nullptr, nullptr};
+        static thread_local unsigned next = 0;
         static thread_local uint64_t last_epoch = ~0ull;
         const uint64_t epoch = g_stream_epoch.load(std::memory_order_acquire);
-        if (stream != last || epoch != last_epoch) {
+        if (epoch != last_epoch) { seen[0] = seen[1] = seen[2] = seen[3] = nullptr; last_epoch = epoch; }
+        if (stream != seen[0] && stream != seen[1] && stream != seen[2] && stream != seen[3]) {
             DevicePool::instance().add_stream((hipStream_t)stream);
-            last = stream;
-            last_epoch = epoch;
+            seen[next] = stream;
+            next = (next + 1) & 3u;
         }
     }
     return (hipStream_t)stream;
