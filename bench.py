@@ -25,6 +25,7 @@ import ctypes as C
 import json
 import os
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -446,23 +447,25 @@ def ntt_roofline(ta, capi, lib, w, reps):
     return roof
 
 
-TRAFFIC_FILE = "r05_traffic_%s.json"  # one file per workload (tools/measure_traffic.sh <workload>)
+TRAFFIC_FILES = ("r06_traffic_%s.json", "r05_traffic_%s.json")  # one file per workload (tools/measure_traffic.sh <workload>); the newest whose build id matches
 
 
 def load_traffic(workload):
     """PMC HBM bytes per kernel (tools/measure_traffic.sh), valid only for the build they were measured on: the file carries the
     library's build id (troyhip_build_id: hash of the sources) and is ignored -- `traffic: null` -- when the loaded library differs"""
     try:
-        t = json.load(open(os.path.join(ROOT, "profiles", TRAFFIC_FILE % workload)))
-    except Exception:
-        return None
-    try:
         from troy_amd import capi
-        if t.get("build_id") != capi.build_id():
-            return None
+        build = capi.build_id()
     except Exception:
         return None
-    return t
+    for name in TRAFFIC_FILES:
+        try:
+            t = json.load(open(os.path.join(ROOT, "profiles", name % workload)))
+        except Exception:
+            continue
+        if t.get("build_id") == build:
+            return t
+    return None
 
 
 def ktime_report(capi, lib):
@@ -479,7 +482,7 @@ def ktime_report(capi, lib):
 
 def per_kernel(ta, capi, lib, w):
     """every kernel of ONE step of one lane, by the library's per-launch HIP events; algorithmic bytes (compulsory reads + writes
-    of the stage) where the table below knows the kernel; HBM traffic from profiles/r05_traffic_<workload>.json (rocprofv3 PMC, tools/measure_traffic.sh)"""
+    of the stage) where the table below knows the kernel; HBM traffic from profiles/r06_traffic_<workload>.json (rocprofv3 PMC, tools/measure_traffic.sh)"""
     w.sync_all()
     capi.check(lib, lib.troyhip_ktime_enable(1))
     w.profile_step()
@@ -834,13 +837,6 @@ def main():
     lib = capi.load()
     ta.KernelProvider.initialize(device)
     place = bind_to_device_numa(capi, lib, device)  # one process per GPU: the rank's host threads run on the GPU's NUMA node
-    placements = [place]
-    if use_dist:
-        try:
-            placements = [None] * world
-            _dist().all_gather_object(placements, place)
-        except Exception as e:  # informational: never let the placement report take the run down
-            placements = [place, {"note": "all_gather_object failed: " + str(e)[:80]}]
     wl = WORKLOADS[args.workload]
     if args.steps is None:
         args.steps = wl.get("steps", 100)
@@ -861,12 +857,22 @@ def main():
     for _ in range(args.warmup):
         w.step()
     barrier()
+    smi = SmiSampler(place.get("pci"))
+    smi.start()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         w.step()
     w.sync_all()
     dt = max(time.perf_counter() - t0, 1e-9)
+    place.update(smi.stop())  # sclk_mhz / power_w averaged over exactly the timed region (rank_devices[])
     barrier()
+    placements = [place]
+    if use_dist:  # after the timed region: every rank's device, NUMA binding, clock and power
+        try:
+            placements = [None] * world
+            _dist().all_gather_object(placements, place)
+        except Exception as e:  # informational: never let the placement report take the run down
+            placements = [place, {"note": "all_gather_object failed: " + str(e)[:80]}]
     own_dt = dt
     units = w.units_per_step * args.steps
     if use_dist:
@@ -901,6 +907,38 @@ def main():
             in_step = in_step_roofline(roofline["per_kernel"])
             if in_step:
                 roofline["in_step"] = in_step
+                # The ONE fraction a reader sees is that of the kernels the timed step runs (round-5 verdict): time-weighted over the step's transform kernels,
+                # algorithmic bytes / HIP-event time of each launch.  The standalone forward / inverse pair (whose forward half never runs in the step) keeps its
+                # numbers under roofline.standalone.
+                keep = ("kernel", "kernel_note", "achieved", "frac", "traffic", "traffic_ratio", "traffic_source", "algorithmic_bytes_per_launch", "launch_us",
+                        "limb_transforms_per_launch", "launch_batch", "launch_batch_cap", "launch_reps", "launch_kernels", "launch_kernels_note")
+                roofline["standalone"] = {k: roofline.pop(k) for k in keep if k in roofline}
+                ntt = [k for k in roofline["per_kernel"] if k["name"].startswith(("ntt1", "ntt2")) and k.get("algorithmic_bytes")]
+                tr = [k.get("traffic") for k in ntt]
+                roofline.update(
+                    kernel="the transform kernels of the timed step, time-weighted (%d kernels, %.0f %% of the step; dominant: %s at %.3f)"
+                           % (len(ntt), 100 * in_step["transform_share_of_step"], in_step["kernel"], in_step["frac"]),
+                    achieved=round(in_step["weighted_frac"] * HBM_PEAK_GBPS, 1), frac=in_step["weighted_frac"],
+                    traffic=int(sum(tr)) if tr and all(t is not None for t in tr) else None,
+                    algorithmic_bytes_per_launch=int(sum(k["algorithmic_bytes"] for k in ntt)), launch_us=round(sum(k["us"] for k in ntt), 1),
+                    launch_note="one lane's step (%d units) under per-launch HIP events on the launch stream: sum over the transform kernels" % w.profile_units)
+            # the metric's second half, "achieved HBM GB/s vs peak", for the OPERATION: HBM bytes of one whole step (PMC counters of this build,
+            # tools/measure_traffic.sh; the compulsory bytes beside them) over the step time of the timed region
+            pk = roofline["per_kernel"]
+            if args.steps and pk:
+                scale = w.units_per_step / float(w.profile_units)
+                algo_step = sum(k.get("algorithmic_bytes", 0) for k in pk) * scale
+                pmc = [k.get("traffic") for k in pk if k.get("algorithmic_bytes")]
+                step_s = dt / args.steps
+                st = {"algorithmic_bytes_per_step": int(algo_step), "algorithmic_GBps": round(algo_step / step_s / 1e9, 1),
+                      "bytes_per_step": None, "achieved_GBps": None, "frac": None, "peak": HBM_PEAK_GBPS, "units_per_step": w.units_per_step}
+                if pmc and all(t is not None for t in pmc):
+                    b = sum(pmc) * scale
+                    st.update(bytes_per_step=int(b), achieved_GBps=round(b / step_s / 1e9, 1), frac=round(b / step_s / 1e9 / HBM_PEAK_GBPS, 4),
+                              bytes_per_unit=int(b / w.units_per_step), source=(load_traffic(w.name) or {}).get("source"))
+                else:
+                    st["note"] = "no PMC traffic file for this build (profiles/%s): achieved_GBps needs tools/measure_traffic.sh on the same build" % (TRAFFIC_FILES[0] % w.name)
+                roofline["step"] = st
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -1148,6 +1186,61 @@ def bind_to_device_numa(capi, lib, device):
     except Exception as e:  # noqa: BLE001 -- informational only
         info["note"] = str(e)[:80]
     return info
+
+
+class SmiSampler:
+    """Clock and power of the rank's GPU over the timed region, from a side thread that only READS the amdgpu sysfs files of the device's PCI
+    function (hwmon freq1_input = shader clock in Hz, power1_average / power1_input in microwatts; pp_dpm_sclk as the fallback) -- no GPU call,
+    no child process, nothing that could perturb the step (a file read every 20 ms on a host thread).  Best effort: a box without the files
+    reports `{"note": ...}` instead of numbers."""
+
+    def __init__(self, pci, period_s=0.02):
+        import glob
+        self.period, self.sclk, self.power, self.note = period_s, [], [], None
+        self._stop = threading.Event()
+        self._thread = None
+        base = f"/sys/bus/pci/devices/{pci}" if pci else None
+        hw = sorted(glob.glob(base + "/hwmon/hwmon*")) if base else []
+        self.f_sclk = next((h + "/freq1_input" for h in hw if os.path.exists(h + "/freq1_input")), None)
+        self.f_power = next((h + "/" + n for h in hw for n in ("power1_average", "power1_input") if os.path.exists(h + "/" + n)), None)
+        self.f_dpm = base + "/pp_dpm_sclk" if base and os.path.exists(base + "/pp_dpm_sclk") else None
+        if not (self.f_sclk or self.f_dpm or self.f_power):
+            self.note = "no amdgpu hwmon / pp_dpm_sclk files under " + str(base)
+
+    def _read_once(self):
+        try:
+            if self.f_sclk:
+                self.sclk.append(int(open(self.f_sclk).read().strip()) / 1e6)
+            elif self.f_dpm:
+                for ln in open(self.f_dpm).read().splitlines():
+                    if ln.rstrip().endswith("*"):
+                        self.sclk.append(float(ln.split(":")[1].strip().lower().replace("mhz", "").replace("*", "").strip()))
+            if self.f_power:
+                self.power.append(int(open(self.f_power).read().strip()) / 1e6)
+        except (OSError, ValueError, IndexError):
+            pass
+
+    def _run(self):
+        while not self._stop.wait(self.period):
+            self._read_once()
+
+    def start(self):
+        if self.note is None:
+            self._thread = threading.Thread(target=self._run, daemon=True)
+            self._thread.start()
+
+    def stop(self):
+        self._stop.set()
+        if self._thread is not None:
+            self._thread.join(timeout=1.0)
+        out = {"samples": max(len(self.sclk), len(self.power)), "period_ms": round(self.period * 1e3, 1), "source": "amdgpu sysfs (hwmon freq1_input / power1_average), read-only side thread over the timed region"}
+        if self.sclk:
+            out.update(sclk_mhz=round(sum(self.sclk) / len(self.sclk), 1), sclk_mhz_min=round(min(self.sclk), 1), sclk_mhz_max=round(max(self.sclk), 1))
+        if self.power:
+            out.update(power_w=round(sum(self.power) / len(self.power), 1), power_w_max=round(max(self.power), 1))
+        if self.note:
+            out["note"] = self.note
+        return out
 
 
 def physical_cores():

@@ -54,6 +54,19 @@ typedef struct {
 /* ---- KernelProvider (src/kernelprovider.cuh:24-85) ---- */
 int troyhip_initialize(int device);                 /* KernelProvider::initialize (cudaSetDevice(0) there) */
 int troyhip_is_initialized(void);
+/* More than one GPU in one process (no reference counterpart: KernelProvider::initialize is cudaSetDevice(0), src/kernelprovider.cuh:29-33).  HIP's current
+ * device is PER HOST THREAD.  A context belongs to the device that was current on the thread that created it; every entry point that takes a context first
+ * makes that device the calling thread's current one and leaves it so (tables, scratch, launches, the caching pool and its streams all follow the current
+ * device).  So: troyhip_initialize once; troyhip_set_device(d) + troyhip_context_create for each device; then either a host thread per device or one thread
+ * walking over the contexts.  troyhip_malloc allocates on the calling thread's current device; troyhip_free returns a block to the device it came from.
+ * A stream (troyhip_stream_create) belongs to the device that was current when it was made and must be used with contexts of that device.
+ * troyhip_copy_peer moves bytes between two devices (hipMemcpyPeerAsync over xGMI; same device: an ordinary device copy) on `stream`, a stream of the
+ * calling thread's current device. */
+int troyhip_device_count(int *count);
+int troyhip_set_device(int device);
+int troyhip_get_device(int *device);
+int troyhip_context_device(const troyhip_context *ctx, int *device);  /* -1 for a host-only context */
+int troyhip_copy_peer(void *dst, int dst_device, const void *src, int src_device, size_t bytes, void *stream);
 const char *troyhip_last_error(void);
 const char *troyhip_build_info(void);               /* "gfx950" for the product build */
 int troyhip_malloc(void **out, size_t bytes);       /* KernelProvider::malloc */

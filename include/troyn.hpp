@@ -46,9 +46,44 @@ inline void check(int rc) { // status -> the reference's exception classes
 enum class SchemeType : uint8_t { none = 0, bfv = 1, ckks = 2, bgv = 3 }; // src/encryptionparams.h
 enum class SecurityLevel : int { none = 0, tc128 = 128, tc192 = 192, tc256 = 256 };
 
-class KernelProvider { // src/kernelprovider.cuh:24-33
+class KernelProvider { // src/kernelprovider.cuh:24-85
 public:
     static void initialize(int device = 0) { check(troyhip_initialize(device)); }
+    static void checkInitialized() { if (!troyhip_is_initialized()) throw std::invalid_argument("KernelProvider not initialized."); } // :24-27
+    // the reference's public statics (:35-85): lengths in ELEMENTS of T; zero lengths are no-ops (malloc returns nullptr).  malloc / free go through the
+    // library's caching pool (the reference's cudaMalloc / cudaFree synchronise the device, a pooled pair does not); the copies are synchronous like
+    // cudaMemcpy, on the calling thread's current device.
+    template <typename T> static T *malloc(size_t length) {
+        checkInitialized();
+        if (length == 0) return nullptr;
+        void *p = nullptr;
+        check(troyhip_malloc(&p, length * sizeof(T)));
+        return static_cast<T *>(p);
+    }
+    template <typename T> static void free(T *pointer) { checkInitialized(); if (pointer) { troyhip_stream_synchronize(nullptr); troyhip_free((void *)pointer); } }
+    template <typename T> static void copy(T *deviceDestPtr, const T *hostFromPtr, size_t length) {
+        checkInitialized();
+        if (length) check(troyhip_copy_h2d(deviceDestPtr, hostFromPtr, length * sizeof(T), nullptr));
+    }
+    template <typename T> static void copyOnDevice(T *deviceDestPtr, const T *deviceFromPtr, size_t length) {
+        checkInitialized();
+        if (!length) return;
+        check(troyhip_copy_d2d(deviceDestPtr, deviceFromPtr, length * sizeof(T), nullptr));
+        check(troyhip_stream_synchronize(nullptr));
+    }
+    template <typename T> static void retrieve(T *hostDestPtr, const T *deviceFromPtr, size_t length) {
+        checkInitialized();
+        if (length) check(troyhip_copy_d2h(hostDestPtr, deviceFromPtr, length * sizeof(T), nullptr));
+    }
+    template <typename T> static void memsetZero(T *devicePtr, size_t length) {
+        if (!length) return;
+        check(troyhip_memset_zero(devicePtr, length * sizeof(T), nullptr));
+        check(troyhip_stream_synchronize(nullptr));
+    }
+    // more than one GPU in one process (no reference counterpart: the reference is cudaSetDevice(0)): HIP's current device is per host thread
+    static int deviceCount() { int n = 0; check(troyhip_device_count(&n)); return n; }
+    static void setDevice(int device) { check(troyhip_set_device(device)); }
+    static int currentDevice() { int d = 0; check(troyhip_get_device(&d)); return d; }
 };
 
 class Modulus { // src/modulus.h:16-24 (value only; Barrett constants live inside the library)
@@ -218,6 +253,7 @@ public:
         ids_ = ids;
     }
     troyhip_context *handle() const { return ctx_.get(); }
+    int device() const { int d = 0; check(troyhip_context_device(ctx_.get(), &d)); return d; } // the HIP device this context lives on (the creating thread's current one)
     const EncryptionParameters &parms() const { return parms_; }
     const ParmsID &keyParmsID() const { return (*ids_)[(size_t)info_.key_limbs]; }
     const ParmsID &firstParmsID() const { return (*ids_)[(size_t)info_.first_limbs]; }
@@ -835,6 +871,18 @@ public:
     }
     const std::map<size_t, std::shared_ptr<DeviceArray>> &all() const { return keys_; }
     void clear() { keys_.clear(); } // src/kswitchkeys_cuda.cuh
+    // the same keys on another device (keys are replicated over the GPUs of a batch shard: BASELINE north_star).  Called with `to_device` current.
+    template <class K> static K replicate(const K &k, int from_device, int to_device) {
+        K out;
+        out.describe(k.parms_id_, k.n_, k.limbs_);
+        for (const auto &kv : k.keys_) {
+            auto a = std::make_shared<DeviceArray>(kv.second->size());
+            check(troyhip_copy_peer(a->get(), to_device, kv.second->get(), from_device, kv.second->size() * 8, nullptr));
+            out.keys_[kv.first] = a;
+        }
+        check(troyhip_stream_synchronize(nullptr));
+        return out;
+    }
     // the key level and shape (stamped by KeyGenerator, read back by load): one key is [K - 1][2][K][N]
     void describe(const ParmsID &key_parms_id, size_t poly_modulus_degree, size_t key_limbs) { parms_id_ = key_parms_id; n_ = poly_modulus_degree; limbs_ = key_limbs; }
     const ParmsID &parmsID() const noexcept { return parms_id_; }

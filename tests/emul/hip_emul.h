@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <mutex>
 #include <ucontext.h>
 #include <vector>
 
@@ -119,7 +120,9 @@ inline void run_block(int nthreads) {
         if (!progressed) { fprintf(stderr, "hip_emul: deadlock (divergent barrier)\n"); abort(); }
     }
 }
+inline std::mutex &launch_mutex() { static std::mutex m; return m; }
 inline void launch(dim3 grid, dim3 block, const std::function<void()> &body) {
+    std::lock_guard<std::mutex> one_at_a_time(launch_mutex()); // the emulator has ONE set of fibers and static "LDS": host threads take turns, a launch runs to completion
     State &s = S();
     s.gridDim = grid;
     s.blockDim = block;
@@ -189,9 +192,14 @@ template <class T> inline T atomicAdd(T *p, T v) { T o = *p; *p += v; return o; 
 // ---- host runtime API subset ----
 inline const char *hipGetErrorString(hipError_t) { return "emulated"; }
 inline hipError_t hipGetLastError() { return hipSuccess; }
-inline hipError_t hipSetDevice(int) { return hipSuccess; }
-inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
-inline hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
+// virtual devices (HIP_EMUL_DEVICES, default 1): the current device is per host thread, as in HIP; all of them share the host's memory, so what
+// the multi-device code paths of the library do with device ids (per-device pools, context binding, peer copies) runs for real
+inline int hip_emul_device_count() { static const int n = [] { const char *e = getenv("HIP_EMUL_DEVICES"); const int v = e ? atoi(e) : 1; return v < 1 ? 1 : v > 16 ? 16 : v; }(); return n; }
+inline int &hip_emul_current_device() { static thread_local int d = 0; return d; }
+inline hipError_t hipSetDevice(int d) { if (d < 0 || d >= hip_emul_device_count()) return hipErrorInvalidValue; hip_emul_current_device() = d; return hipSuccess; }
+inline hipError_t hipGetDeviceCount(int *n) { *n = hip_emul_device_count(); return hipSuccess; }
+inline hipError_t hipGetDevice(int *d) { *d = hip_emul_current_device(); return hipSuccess; }
+inline hipError_t hipMemcpyPeerAsync(void *d, int, const void *s, int, size_t n, hipStream_t) { memmove(d, s, n); return hipSuccess; }
 enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount = 1 };
 inline hipError_t hipDeviceGetAttribute(int *v, hipDeviceAttribute_t, int) { *v = 4; return hipSuccess; } // a small "chip": the launch planner sees several rounds
 inline hipError_t hipMalloc(void **p, size_t n) { *p = aligned_alloc(256, (n + 255) / 256 * 256); return *p ? hipSuccess : hipErrorInvalidValue; }

@@ -102,6 +102,43 @@ def test_bench_troyn_on_gpu(tmp_path):
     assert r.returncode == 0 and "ALL OK" in r.stdout and '"verified": false' not in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
 
 
+DEVICES = os.path.join(ROOT, "tests", "cpp", "test_troyn_devices.cpp")  # include/troyn_devices.hpp: a batch sharded over several contexts / devices / host threads
+
+
+def _build_threads(out, libdir, libfile, src):
+    cmd = ["g++", "-std=c++17", "-O2", "-Wall", "-Werror", "-pthread", "-I" + os.path.join(ROOT, "include"), src, "-o", out,
+           os.path.join(libdir, libfile), "-Wl,-rpath," + libdir, "-Wl,-rpath-link,/opt/rocm/lib"]
+    subprocess.run(cmd, check=True, capture_output=True, text=True)
+
+
+def test_troyn_devices_on_emulator(tmp_path):
+    """KernelProvider's statics, DeviceGroup / shardBatch: three members on three VIRTUAL devices of the emulator build (per-device pools, contexts bound to
+    their device, peer copies, a host thread per member) and three members sharing device 0 -- both equal the single-context batch limb for limb"""
+    subprocess.check_call(["make", "-s", "-j8", "-C", os.path.join(ROOT, "troy_amd", "csrc"), "emul"])
+    exe = str(tmp_path / "test_troyn_devices_emul")
+    _build_threads(exe, os.path.join(ROOT, "tests", "emul"), "libtroyhip_emul.so", DEVICES)
+    os.environ["HIP_EMUL_DEVICES"] = "3"
+    try:
+        _run(exe, "1024", "3", "1")
+    finally:
+        del os.environ["HIP_EMUL_DEVICES"]
+    _run(exe, "1024", "3", "0")
+    _run(exe, "1024", "1", "0")
+
+
+@pytest.mark.gpu
+def test_troyn_devices_on_gpu(tmp_path):
+    """the same on the device: four members (contexts, scratch arenas, host threads) sharing GPU 0; on a node with more GPUs also one member per GPU"""
+    exe = str(tmp_path / "test_troyn_devices")
+    _build_threads(exe, os.path.join(ROOT, "troy_amd"), "libtroyhip.so", DEVICES)
+    _run(exe, "8192", "4", "0")
+    _run(exe, "32768", "2", "0")
+    import torch
+    n = torch.cuda.device_count()
+    if n > 1:
+        _run(exe, "8192", str(min(n, 8)), "1")
+
+
 def test_fp64_arithmetic_and_bound_walk_on_cpu(tmp_path):
     """troy_amd/csrc/fpmod.h on the host: exact products within their stated magnitude, and a plain-loop model of the transforms under the masks of
     fp_plan / fp_plan_inv -- every intermediate value an exact integer below 2^53 and below the walk's bound, final residues equal to the integer

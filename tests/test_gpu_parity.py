@@ -640,7 +640,7 @@ def test_library_switches_agree_at_headline_size(env, gpu):
 
 @pytest.mark.skipif(not os.path.exists(PROBES_LIB), reason="tools/probe_libs/libtroyhip_probes.so: make -C troy_amd/csrc probes")
 @pytest.mark.parametrize("env", [{"TROYHIP_KS": "split"}, {"TROYHIP_TENSOR": "split"}, {"TROYHIP_BEHZ": "valu"}, {"TROYHIP_MODDOWN": "split"},
-                                 {"TROYHIP_AUX_BASE": "reference", "TROYHIP_BEHZ": "valu"}, {"TROYHIP_BFLY": "guarded"}])
+                                 {"TROYHIP_AUX_BASE": "reference", "TROYHIP_BEHZ": "valu"}, {"TROYHIP_BFLY": "guarded"}, {"TROYHIP_NTT2_MD_ORDER": "0"}])
 def test_probe_build_fallback_forms_agree(env, gpu):
     """The unfused kernels are the library's fallback for the shapes the fused ones do not take (N < 4096, N = 2^17, other ciphertext sizes, more
     than 15 limbs: all exercised by the golden scenarios).  The PROBE build (-DTROYHIP_PROBES) can force them at a fused shape: the unfused key-switch
@@ -654,7 +654,8 @@ def test_probe_build_fallback_forms_agree(env, gpu):
                                  {"TROYHIP_NTT": "single", "TROYHIP_CORR": "split"}, {"TROYHIP_NTT": "single", "TROYHIP_NTT1_XCD": "1"},
                                  {"TROYHIP_NTT": "single", "TROYHIP_NTT1_XCD": "1", "TROYHIP_NTT1_RPW": "1"}, {"TROYHIP_NTT": "single", "TROYHIP_NTT1_XCD": "0"},
                                  {"TROYHIP_NTT": "single", "TROYHIP_NTT1_XCD": "1", "TROYHIP_NTT1_XCD_GROUP": "3"}, {"TROYHIP_NTT2_WIDE": "1"},
-                                 {"TROYHIP_NTT2_WIDE": "1", "TROYHIP_NTT": "twopass"}, {"TROYHIP_NTT2_WIDE": "0"}])
+                                 {"TROYHIP_NTT2_WIDE": "1", "TROYHIP_NTT": "twopass"}, {"TROYHIP_NTT2_WIDE": "0"},
+                                 {"TROYHIP_NTT2_MD_ORDER": "0", "TROYHIP_NTT": "twopass"}])
 def test_probe_build_fallback_forms_agree_at_headline_size(env, gpu):
     """N = 2^15 on the probe build: guarded butterflies instead of the guard-free ones, the BFV mod-down in its own kernel instead of in the inverse
     transform's epilogue, the CKKS divide-and-round correction as element-wise kernels instead of inside the forward transform, the XCD-aware
@@ -663,6 +664,55 @@ def test_probe_build_fallback_forms_agree_at_headline_size(env, gpu):
     the wide form of the forward strided pass (ntt2.hip n2_wide: by default only launches that fill the chip twice over) forced on and off"""
     names = [n for n in HEADLINE_NAMES if n in cases.CONFIGS]
     assert names and _hashes_in_child(names, {**env, "TROYHIP_LIB": PROBES_LIB}) == [cases.mul_relin_hash(n) for n in names]
+
+
+def _full_batch_child(args, env, timeout=1500):
+    import json
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "full_batch.py")] + args, env={**os.environ, **env}, capture_output=True, text=True, timeout=timeout)
+    assert out.returncode == 0, out.stderr[-3000:]
+    return json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("[")][-1])
+
+
+FALLBACK_ENV = {"TROYHIP_LIB": PROBES_LIB, "TROYHIP_KS": "split", "TROYHIP_TENSOR": "split", "TROYHIP_MODDOWN": "split", "TROYHIP_NTT": "twopass",
+                "TROYHIP_NTT1_XCD": "0", "TROYHIP_NTT2_WIDE": "0", "TROYHIP_NTT2_MD_ORDER": "0"}
+
+
+@pytest.mark.skipif(not os.path.exists(PROBES_LIB), reason="tools/probe_libs/libtroyhip_probes.so: make -C troy_amd/csrc probes")
+def test_full_headline_batch_every_item(gpu):
+    """The FULL headline batch -- BFV N = 2^15, K = 15, two lanes of 128 ciphertext pairs on two HIP streams, multiply + relinearize, as bench.py runs it:
+    the wide strided pass, the XCD-aware and grouped workgroup orders of the single-pass kernels (n1_unit), the slot-fastest mod-down and the lane interleave
+    exist only at this size.  EVERY one of the 256 results is compared (a 128-bit digest per item) with the same pair computed by the PROBE build in a child
+    process under its fallback switches -- unfused key-switch inner product, unfused tensor, element-wise mod-down, two-pass transforms in flat workgroup
+    order, narrow strided pass -- eight pairs at a time on one stream; and 16 items spread evenly over both lanes (every XCD's eighth of the unit lists) are
+    compared limb for limb with the CPU oracle."""
+    import full_batch
+    from troy_amd import capi
+    b = full_batch.Batch()
+    wide0, n1 = capi.stat("ntt2_wide_launches"), capi.stat("ntt1_int_launches")
+    got = b.lanes(keep=True)
+    assert capi.stat("ntt2_wide_launches") > wide0 and capi.stat("ntt1_int_launches") > n1, "the full batch is expected to take the wide strided pass and the single-pass inverse"
+    assert len(got) == full_batch.TOTAL and len(set(got)) == full_batch.TOTAL, "256 distinct pairs give 256 distinct results"
+    picks = sorted({(i * (full_batch.TOTAL - 1)) // 15 for i in range(16)})
+    assert full_batch.oracle_items(b, picks) == [], "items differ from the oracle"
+    ref = _full_batch_child(["chunks", "8"], FALLBACK_ENV)
+    bad = [i for i in range(full_batch.TOTAL) if got[i] != ref[i]]
+    assert bad == [], f"items {bad[:16]} of the full batch differ from the fallback forms"
+
+
+@pytest.mark.skipif(not os.path.exists(PROBES_LIB), reason="tools/probe_libs/libtroyhip_probes.so: make -C troy_amd/csrc probes")
+def test_full_headline_batch_catches_a_perturbed_xcd_order(gpu):
+    """The check above must FAIL when the grouped XCD order is wrong: the probe build can perturb n1_unit (TROYHIP_NTT1_XCD_PERTURB: one interior chunk of the
+    second prime group is mapped onto its neighbour -- in range, so nothing faults, but its rows are never transformed).  Only a few interior items change (a
+    check of the first and last items of each lane stays green); the full comparison sees them."""
+    import full_batch
+    good = _full_batch_child(["chunks", "8"], FALLBACK_ENV)
+    bent = _full_batch_child(["lanes"], {"TROYHIP_LIB": PROBES_LIB, "TROYHIP_NTT1_XCD_PERTURB": "1"})
+    bad = [i for i in range(full_batch.TOTAL) if good[i] != bent[i]]
+    assert bad, "a perturbed workgroup order went unnoticed"
+    half = full_batch.TOTAL // 2
+    assert all(i % half not in (0, half - 1) for i in bad), bad  # interior items only: first and last of a lane are right
 
 
 def _run_bench(args, timeout=900):
@@ -693,6 +743,13 @@ def test_bench_accounts_for_every_kernel_at_small_batches(batch, gpu):
     line = _run_bench(["--steps", "1", "--warmup", "0", "--batch", str(batch), "--no-cpu-baseline", "--ntt-reps", "1"])
     assert line["verified"] is True and line["config"]["batch_per_gpu"] == batch
     assert all(k.get("frac") for k in line["roofline"]["per_kernel"]), [k["name"] for k in line["roofline"]["per_kernel"] if not k.get("frac")]
+    # round 6: the headline fraction is the in-step one (the standalone pair keeps its numbers beside it), the operation's own HBM rate and the
+    # device's clock / power over the timed region are on the line
+    roof = line["roofline"]
+    assert roof["frac"] == roof["in_step"]["weighted_frac"] and roof["standalone"]["frac"] > 0 and roof["standalone"]["limb_transforms_per_launch"] > 0
+    assert roof["step"]["algorithmic_bytes_per_step"] > 0 and roof["step"]["algorithmic_GBps"] > 0 and "achieved_GBps" in roof["step"]
+    dev = line["rank_devices"][0]
+    assert "samples" in dev and ("sclk_mhz" in dev or "note" in dev), dev
 
 
 @pytest.mark.gpu
@@ -898,6 +955,21 @@ def test_fp64_key_switch_instances_vs_oracle(N, bits, scheme, gpu):
     walk must place reductions), all-narrow sets -- and the path counter proves the FP64 kernels are what ran"""
     from troy_amd import capi
     cfg = dict(scheme=scheme, N=N, bits=bits, tbits=0 if scheme == cases.CKKS else 20)
+    before = capi.stat("ks_fp_launches")
+    got = cases.scenario(cases.GpuBackend(cfg, batch=2), cfg, light=True)
+    exp = cases.scenario(cases.oracle_backend(cfg), cfg, light=True)
+    assert not cases.compare(got, exp)
+    assert capi.stat("ks_fp_launches") > before, "the FP64 key-switch instances did not run"
+
+
+@pytest.mark.parametrize("N", [4096, 32768, 65536])
+@pytest.mark.parametrize("width", [34, 40, 41, 47, 48, 49, 50])
+def test_fp64_key_switch_prime_widths(N, width, gpu):
+    """the FP64 class of the fused key switch at every width it takes -- 34, 40, 41, 47, 48, 49 and 50-bit primes (the bound walk places its reductions
+    differently at each) -- at the narrowest (N = 2^16: 16 columns), the headline's (2^15) and a wide (2^12: 256 columns) strided tile, next to a 60-bit
+    prime whose rows take the integer kernels in the same key switch: relinearize, rotate and rescale against the oracle, limb for limb"""
+    from troy_amd import capi
+    cfg = dict(scheme=cases.CKKS, N=N, bits=[width, width, width, 60], tbits=0)
     before = capi.stat("ks_fp_launches")
     got = cases.scenario(cases.GpuBackend(cfg, batch=2), cfg, light=True)
     exp = cases.scenario(cases.oracle_backend(cfg), cfg, light=True)

@@ -51,7 +51,7 @@ class ContextInfo(C.Structure):
 
 # every symbol include/troyhip.h declares (tests/test_cabi.py checks the header against this list)
 SYMBOLS = [
-    "troyhip_initialize", "troyhip_is_initialized", "troyhip_last_error", "troyhip_build_info", "troyhip_malloc",
+    "troyhip_initialize", "troyhip_is_initialized", "troyhip_device_count", "troyhip_set_device", "troyhip_get_device", "troyhip_context_device", "troyhip_copy_peer", "troyhip_last_error", "troyhip_build_info", "troyhip_malloc",
     "troyhip_free", "troyhip_pool_release", "troyhip_copy_h2d", "troyhip_copy_d2h", "troyhip_copy_d2d", "troyhip_memset_zero",
     "troyhip_stream_synchronize", "troyhip_stream_create", "troyhip_stream_destroy", "troyhip_stream_register", "troyhip_stream_unregister", "troyhip_mem_info", "troyhip_device_pci_bus_id", "troyhip_timer_create", "troyhip_timer_destroy",
     "troyhip_timer_start", "troyhip_timer_stop", "troyhip_timer_elapsed_ms", "troyhip_coeff_modulus_create",

@@ -50,9 +50,18 @@ template <class F> int guard(F f, bool need_init = true) {
         return TROYHIP_RUNTIME_ERROR;
     }
 }
+// More than one GPU in one process (round 6): a context belongs to the device that was current when it was created, and every entry point that takes a
+// context makes that device the calling thread's current one before anything else runs (HIP's current device is per thread: pool, streams, launches and
+// device_cus() all follow it) -- so a host thread per device, or one thread walking over several contexts, both work; the thread is LEFT bound to it.
+inline void bind_device(int device) {
+    int cur = -1;
+    if (hipGetDevice(&cur) != hipSuccess) { (void)hipGetLastError(); cur = -1; }
+    if (cur != device) HIP_CHECK(hipSetDevice(device));
+}
 // a null context is an argument error like any other (every use below sits inside guard(): the caller gets INVALID_ARGUMENT, not a fault)
 template <class C> C *need(C *ctx) {
     if (!ctx) throw Error(ST_INVALID_ARGUMENT, "null context");
+    if (ctx->ctx.has_device && g_init.load()) bind_device(ctx->ctx.device);
     return ctx;
 }
 CtBatch view(const troyhip_ct *c) {
@@ -138,6 +147,11 @@ int troyhip_initialize(int device) {
     }, false);
 }
 int troyhip_is_initialized(void) { return g_init.load() ? 1 : 0; }
+int troyhip_device_count(int *count) {
+    return guard([&] { if (!count) throw Error(ST_INVALID_ARGUMENT, "null"); HIP_CHECK(hipGetDeviceCount(count)); }, false);
+}
+int troyhip_set_device(int device) { return guard([&] { HIP_CHECK(hipSetDevice(device)); }); }
+int troyhip_get_device(int *device) { return guard([&] { if (!device) throw Error(ST_INVALID_ARGUMENT, "null"); HIP_CHECK(hipGetDevice(device)); }); }
 const char *troyhip_last_error(void) { return g_err.c_str(); }
 const char *troyhip_build_info(void) {
 #ifdef TROYHIP_CPU_EMUL
@@ -275,11 +289,35 @@ struct DevicePool {
         }
         streams.erase(std::remove(streams.begin(), streams.end(), s), streams.end());
     }
-    static DevicePool &instance() { static DevicePool p; return p; }
+    // one pool per device: instance() is the calling thread's current device's; a block is returned to the pool it came from (owner_of)
+    static constexpr int kMaxDevices = 32;
+    static DevicePool &of(int device) { static DevicePool pools[kMaxDevices]; return pools[(unsigned)device % kMaxDevices]; }
+    static int current() { int d = 0; if (hipGetDevice(&d) != hipSuccess) { (void)hipGetLastError(); d = 0; } return d; }
+    static DevicePool &instance() { return of(current()); }
+    bool owns(void *p) { std::lock_guard<std::mutex> g(mu); return live.count(p) != 0; }
+    static int owner_of(void *p) { // the current device first (the usual case), then the others
+        const int cur = current();
+        if (of(cur).owns(p)) return cur;
+        for (int d = 0; d < kMaxDevices; d++) if (d != cur && of(d).owns(p)) return d;
+        return cur;
+    }
+};
+// troyhip_free from a thread that is bound to another device than the block's: events are recorded on the OWNER's streams, which needs the owner current
+struct DeviceScope {
+    int saved, target;
+    explicit DeviceScope(int device) : saved(DevicePool::current()), target(device) { if (saved != target) HIP_CHECK(hipSetDevice(target)); }
+    ~DeviceScope() { if (saved != target) (void)hipSetDevice(saved); }
 };
 } // namespace
 int troyhip_malloc(void **out, size_t bytes) { return guard([&] { if (!out) throw Error(ST_INVALID_ARGUMENT, "null"); *out = DevicePool::instance().get(bytes ? bytes : 8); }); }
-int troyhip_free(void *p) { return guard([&] { if (p) DevicePool::instance().put(p); }); }
+int troyhip_free(void *p) {
+    return guard([&] {
+        if (!p) return;
+        const int owner = DevicePool::owner_of(p);
+        DeviceScope scope(owner);
+        DevicePool::of(owner).put(p);
+    });
+}
 int troyhip_pool_release(void) { return guard([&] { HIP_CHECK(hipDeviceSynchronize()); DevicePool::instance().release(); }); }
 // A caller's stream the library was never told about (a hipStream_t made elsewhere, a torch / RCCL stream) is announced to the pool the first time an
 // entry point is handed it, so a block freed while that stream still reads it is not reused early (round-4 advisor: the pool records no free-point
@@ -306,6 +344,13 @@ int troyhip_copy_h2d(void *dst, const void *src, size_t bytes, void *stream) {
 }
 int troyhip_copy_d2h(void *dst, const void *src, size_t bytes, void *stream) {
     return guard([&] { HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream)); HIP_CHECK(hipStreamSynchronize((hipStream_t)stream)); });
+}
+int troyhip_copy_peer(void *dst, int dst_device, const void *src, int src_device, size_t bytes, void *stream) {
+    return guard([&] {
+        if (!bytes) return;
+        if (dst_device == src_device) { DeviceScope scope(src_device); HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, on(stream))); return; }
+        HIP_CHECK(hipMemcpyPeerAsync(dst, dst_device, src, src_device, bytes, (hipStream_t)stream));
+    });
 }
 int troyhip_copy_d2d(void *dst, const void *src, size_t bytes, void *stream) {
     return guard([&] { HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, on(stream))); });
@@ -418,7 +463,19 @@ int troyhip_context_create_host(int scheme, uint64_t N, const uint64_t *coeff_mo
         *out = new troyhip_context(scheme, N, std::vector<u64>(coeff_modulus, coeff_modulus + K), plain_modulus, false);
     }, false);
 }
-int troyhip_context_destroy(troyhip_context *ctx) { return guard([&] { delete ctx; }, false); }
+int troyhip_context_destroy(troyhip_context *ctx) {
+    return guard([&] {
+        if (!ctx) return;
+        if (ctx->ctx.has_device && g_init.load()) { DeviceScope scope(ctx->ctx.device); delete ctx; } // its tables and scratch go back to its own device's pool
+        else delete ctx;
+    }, false);
+}
+int troyhip_context_device(const troyhip_context *ctx, int *device) {
+    return guard([&] {
+        if (!ctx || !device) throw Error(ST_INVALID_ARGUMENT, "null");
+        *device = ctx->ctx.has_device ? ctx->ctx.device : -1;
+    }, false);
+}
 int troyhip_context_info(const troyhip_context *ctx, troyhip_context_info_t *out) {
     return guard([&] {
         if (!ctx || !out) throw Error(ST_INVALID_ARGUMENT, "null");

@@ -152,7 +152,10 @@ Context::Context(int scheme_, u64 N_, const std::vector<u64> &key_primes, u64 t_
         last_limbs = limbs;
     }
     if (!has_level(first_limbs)) throw Error(ST_INVALID_ARGUMENT, "encryption parameters are not valid");
-    if (has_device) upload_tables();
+    if (has_device) {
+        if (hipGetDevice(&device) != hipSuccess) { (void)hipGetLastError(); device = 0; }
+        upload_tables();
+    }
 }
 
 // Small launches take the merged forms (one launch over the q-base and the B_sk-base rows of a product, one first pass for a mod-down: evaluator.cpp).

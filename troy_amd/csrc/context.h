@@ -58,6 +58,7 @@ public:
     // with_device = false builds the host tables only (no HIP call): enough for hostcrypto (config A plumbing)
     Context(int scheme, u64 N, const std::vector<u64> &primes, u64 t, bool with_device = true);
     bool has_device = true;
+    int device = 0; // the HIP device the tables, the scratch arena and every launch of this context live on: the creating thread's current device
     ~Context();
     Context(const Context &) = delete;
     Context &operator=(const Context &) = delete;

@@ -23,6 +23,7 @@
 // transform needs no range guard at all in 15 stages (bound 1 + 15 * 3 = 46 p < 2^64), 16 VALU instructions per butterfly
 // instead of 20; other primes keep the guarded forms.
 #include "kernels.h"
+#include <atomic>
 #include "bfly.h"
 #include "fpmod.h"
 #include <cstdio>
@@ -48,6 +49,7 @@ struct Ntt1Args {
     unsigned nslots;      // a launch covers the prime slots slots[0 .. nslots) of the pattern (one launch per prime class)
     unsigned xcd_per;     // != 0: the grid is 8 * xcd_per workgroups and workgroup b takes unit (b % 8) * xcd_per + b / 8 of the slot-major list (n1_unit)
     unsigned xcd_group;   // > 1: that list is ordered (group of xcd_group primes, chunk, prime within the group)
+    unsigned xcd_perturb; // probe builds only (TROYHIP_NTT1_XCD_PERTURB): a deliberately WRONG grouped order, for the test that must notice it
     uint8_t slots[64];
     // forward only: divide-and-round correction (Ntt1Corr): rows are BUILT from cr_last on load and COMBINED with cr_in on store
     const u64 *cr_last, *cr_in;
@@ -148,6 +150,11 @@ __device__ __forceinline__ bool n1_unit(const Ntt1Args &a, unsigned &sidx, unsig
         const unsigned gsz = a.nslots - first < a.xcd_group ? a.nslots - first : a.xcd_group; // the last group may be short
         chunk = r / gsz;
         sidx = first + (r - chunk * gsz);
+#ifdef TROYHIP_PROBES
+        // tests/test_gpu_parity.py::test_full_headline_batch_catches_a_perturbed_xcd_order: one interior chunk of the second group is mapped onto its
+        // neighbour (in range: nothing faults; the chunk's rows are never transformed, its neighbour's are written twice with the same values)
+        if (a.xcd_perturb && g == 1 && a.chunks > 3 && chunk == a.chunks / 2 + 1) chunk -= 1;
+#endif
     }
     return true;
 }
@@ -1307,13 +1314,19 @@ template <int LOGN, bool MD> __global__ __launch_bounds__(64 << (LOGN - 10), 4) 
 
 // ---- host side ----
 
-unsigned device_cus() {
-    static const unsigned cus = [] {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-        return (unsigned)n;
-    }();
-    return cus;
+unsigned device_cus() { // of the calling thread's current device = the context's (every entry point binds it: capi.cpp need()); one query per device
+    static std::atomic<unsigned> cus[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
+    std::atomic<unsigned> &slot = cus[(unsigned)dev & 63u];
+    unsigned n = slot.load(std::memory_order_relaxed);
+    if (!n) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) { (void)hipGetLastError(); v = 256; }
+        n = (unsigned)v;
+        slot.store(n, std::memory_order_relaxed);
+    }
+    return n;
 }
 // TROYHIP_NTT = twopass | single forces one form (tests, A/B runs); by default the single-pass kernel takes the launches that give
 // every CU at least four rows.  Below that a whole-limb workgroup per CU is the wrong grain -- a lone row costs ~45 us however few rows
@@ -1422,6 +1435,8 @@ void launch_ntt1(u64 *data, const u64 *src, const PrimeDesc *primes, const LimbM
         const bool xcd = forced_xcd >= 0 ? forced_xcd != 0 : (N1_XCD && a.nslots > 1 && a.nslots * a.chunks >= 2 * cus);
         a.xcd_per = xcd ? (a.nslots * a.chunks + 7) / 8 : 0;
         a.xcd_group = forced_group > 0 ? (unsigned)forced_group : !(a.md_ct || a.cr_last) ? 1u : kind == 2 ? N1_XCD_GROUP_FP : N1_XCD_GROUP_INT;
+        static const bool perturb = probe_env("TROYHIP_NTT1_XCD_PERTURB") != nullptr;
+        a.xcd_perturb = perturb ? 1u : 0u;
         cls[ncls].a = a;
         cls[ncls].lean = kind != 0;
         cls[ncls++].fp = kind == 2;

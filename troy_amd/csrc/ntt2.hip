@@ -1250,6 +1250,13 @@ void launch_ntt2_slots(u64 *data, const u64 *src, u64 src_ostride, bool src_redu
             if (passes & 2) contig(std::integral_constant<int, 0>{}, second, true);
         } else {
             if (passes & 1) contig(std::integral_constant<int, 1>{}, first, false);
+            // Mod-down epilogue: the rows of DIFFERENT primes read one shared row per item (the special limb; BGV: its 16-byte shares).  Slot-major, the readers
+            // of a shared tile were a whole prime's workgroups apart and every one of them fetched it from HBM (traffic 1.51x the rows at N = 2^16).  Slot
+            // fastest, they are tiles_per_row workgroups apart -- a multiple of 8, so the hardware's round-robin deals them to the SAME XCD, back to back: one
+            // fetch into that L2 serves the class.  (The strided pass's twiddles are a handful of wave-uniform words per prime: nothing to lose in L2.)
+            // Same-box A/B at BGV N = 2^16 (profiles/r06_md_order_ab.txt): the FP64 mod-down 3545 -> 2449 us, the workload 4908 -> 5066 ops/s (+3.2 %).
+            static const int md_order = [] { const char *e = probe_env("TROYHIP_NTT2_MD_ORDER"); return e ? std::atoi(e) : 1; }();
+            if (md) second.slot_fastest = md_order;
             if (passes & 2) strided(std::integral_constant<int, 1>{}, second, false);
         }
     }
