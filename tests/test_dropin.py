@@ -77,6 +77,32 @@ def test_default_modulus_tables_match_reference():
         assert "{" + ", ".join(bits) + "}" in inc, (sec, bits)
 
 
+@needs_reference
+def test_reference_targets_build_with_cmake_against_the_package(tmp_path):
+    """what a maintainer of the reference does instead of this suite's stdin recipe: find_package(troyhip) (cmake/troyhipConfig.cmake: imported target
+    troyhip::troyhip = the library + include/) and the overlay project cmake/reference_overlay, which builds the reference's own test/ and test/app/ GPU
+    targets -- troytest (the three *_cuda.cu files), timetest, linear, linear_ckks -- unchanged, as LANGUAGE CXX, from a mirror of symlinks in the BUILD tree.
+    Here against the host emulator build of the library; the encryptor suite of the cmake-built troytest runs, the other binaries must link."""
+    import shutil
+    if not shutil.which("cmake"):
+        pytest.skip("cmake is not installed")
+    subprocess.check_call(["make", "-s", "-j8", "-C", os.path.join(ROOT, "troy_amd", "csrc"), "emul"])
+    build = str(tmp_path / "build")
+    gen = ["-G", "Ninja"] if shutil.which("ninja") else []
+    cfg = subprocess.run(["cmake", "-S", os.path.join(ROOT, "cmake", "reference_overlay"), "-B", build, *gen, "-Dtroyhip_DIR=" + os.path.join(ROOT, "cmake"),
+                          "-DTROY_REFERENCE_DIR=" + REF, "-DTROYHIP_LIBRARY=" + os.path.join(ROOT, "tests", "emul", "libtroyhip_emul.so"), "-DCMAKE_BUILD_TYPE=Release"],
+                         capture_output=True, text=True, timeout=600)
+    assert cfg.returncode == 0, cfg.stdout[-2000:] + cfg.stderr[-2000:]
+    bld = subprocess.run(["cmake", "--build", build, "-j8"], capture_output=True, text=True, timeout=1500)
+    assert bld.returncode == 0, bld.stdout[-3000:] + bld.stderr[-3000:]
+    for name in ("troytest", "timetest", "linear", "linear_ckks"):
+        assert os.access(os.path.join(build, name), os.X_OK), name
+    assert os.path.islink(os.path.join(build, "mirror", "test", "evaluator_cuda.cu"))  # the reference's file itself, not a copy
+    r = subprocess.run([os.path.join(build, "troytest"), "--gtest_filter=EncryptorCudaTest"], capture_output=True, text=True, timeout=900)
+    ran, failed = _summary(r.stdout)
+    assert (ran, failed, r.returncode) == (6, 0, 0), r.stdout[-3000:]
+
+
 def _gpu_binary(name):
     path = os.path.join(OUT, name + "_gpu")
     if not os.access(path, os.X_OK):

@@ -703,12 +703,13 @@ def test_full_headline_batch_every_item(gpu):
 
 @pytest.mark.skipif(not os.path.exists(PROBES_LIB), reason="tools/probe_libs/libtroyhip_probes.so: make -C troy_amd/csrc probes")
 def test_full_headline_batch_catches_a_perturbed_xcd_order(gpu):
-    """The check above must FAIL when the grouped XCD order is wrong: the probe build can perturb n1_unit (TROYHIP_NTT1_XCD_PERTURB: one interior chunk of the
-    second prime group is mapped onto its neighbour -- in range, so nothing faults, but its rows are never transformed).  Only a few interior items change (a
-    check of the first and last items of each lane stays green); the full comparison sees them."""
+    """The check above must FAIL when the XCD-aware workgroup order is wrong: the probe build can perturb n1_unit (TROYHIP_NTT1_XCD_PERTURB: one interior
+    chunk of the second prime -- of the second prime group in the grouped lists -- is mapped onto its neighbour: in range, so nothing faults, but its rows are
+    never transformed).  Only a few interior items change (a check of the first and last items of each lane stays green); the full comparison sees them.
+    (At two lanes of 128 the plain inverse after the tensor takes the XCD-aware list; TROYHIP_NTT1_XCD = 1 also gives it to the mod-down's grouped one.)"""
     import full_batch
     good = _full_batch_child(["chunks", "8"], FALLBACK_ENV)
-    bent = _full_batch_child(["lanes"], {"TROYHIP_LIB": PROBES_LIB, "TROYHIP_NTT1_XCD_PERTURB": "1"})
+    bent = _full_batch_child(["lanes"], {"TROYHIP_LIB": PROBES_LIB, "TROYHIP_NTT1_XCD_PERTURB": "1", "TROYHIP_NTT1_XCD": "1"})
     bad = [i for i in range(full_batch.TOTAL) if good[i] != bent[i]]
     assert bad, "a perturbed workgroup order went unnoticed"
     half = full_batch.TOTAL // 2

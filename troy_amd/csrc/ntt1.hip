@@ -145,6 +145,9 @@ __device__ __forceinline__ bool n1_unit(const Ntt1Args &a, unsigned &sidx, unsig
     if (!a.xcd_per || a.xcd_group <= 1) {
         sidx = q / a.chunks;
         chunk = q - sidx * a.chunks;
+#ifdef TROYHIP_PROBES
+        if (a.xcd_perturb && a.xcd_per && sidx == 1 && a.chunks > 3 && chunk == a.chunks / 2 + 1) chunk -= 1; // (see below; the XCD-aware flat list)
+#endif
     } else {
         const unsigned gs = a.xcd_group * a.chunks, g = q / gs, r = q - g * gs, first = g * a.xcd_group;
         const unsigned gsz = a.nslots - first < a.xcd_group ? a.nslots - first : a.xcd_group; // the last group may be short
