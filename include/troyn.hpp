@@ -1071,8 +1071,8 @@ private:
 class Encryptor { // src/encryptor_cuda.cuh:20-300, CPU sampling + upload
 public:
     // every encryption draws a fresh 128-bit seed for its samples from the operating system (src/randomgen.cpp:23,72)
-    // keys of another context (a loaded key can have any shape) are refused here, as the reference's Encryptor does (src/encryptor.cpp:31-46,
-    // "public_key / secret_key is not valid for encryption parameters"): the host encryption reads 2 K N / K N words of them
+    // keys of another context (a loaded key can have any shape) are refused here, as the reference's CPU classes refuse them (isValidFor: src/decryptor.cpp:62-65
+    // "secret key is not valid for encryption parameters", src/encryptor.h:92,107 setPublicKey / setSecretKey): the host encryption reads 2 K N / K N words of them
     Encryptor(const SEALContext &c, const PublicKey &pk) : c_(c), pk_(valid(c, pk)) {}
     Encryptor(const SEALContext &c, const SecretKey &sk) : c_(c), sk_(valid(c, sk)) {}
     Encryptor(const SEALContext &c, const PublicKey &pk, const SecretKey &sk) : c_(c), pk_(valid(c, pk)), sk_(valid(c, sk)) {}
@@ -1081,11 +1081,11 @@ public:
     void setPublicKey(const PublicKey &pk) { pk_ = valid(c_, pk); }
     void setSecretKey(const SecretKey &sk) { sk_ = valid(c_, sk); }
     static const PublicKey &valid(const SEALContext &c, const PublicKey &pk) {
-        if (pk.parms_id != c.keyParmsID() || pk.data.size() != 2 * c.keyLimbs() * c.polyModulusDegree()) throw std::invalid_argument("public_key is not valid for encryption parameters");
+        if (pk.parms_id != c.keyParmsID() || pk.data.size() != 2 * c.keyLimbs() * c.polyModulusDegree()) throw std::invalid_argument("public key is not valid for encryption parameters");
         return pk;
     }
     static const SecretKey &valid(const SEALContext &c, const SecretKey &sk) {
-        if (sk.parms_id != c.keyParmsID() || sk.data.size() != c.keyLimbs() * c.polyModulusDegree()) throw std::invalid_argument("secret_key is not valid for encryption parameters");
+        if (sk.parms_id != c.keyParmsID() || sk.data.size() != c.keyLimbs() * c.polyModulusDegree()) throw std::invalid_argument("secret key is not valid for encryption parameters");
         return sk;
     }
     // The CPU reference refuses without a public key (src/encryptor.cpp:157-160); EncryptorCuda has no such check and its own caller
@@ -1173,7 +1173,7 @@ private:
 
 class Decryptor { // src/decryptor_cuda.cuh:13-60: the secret key is uploaded once, decryption runs on the device
 public:
-    Decryptor(const SEALContext &c, const SecretKey &sk) : c_(c), sk_(Encryptor::valid(c, sk).data.size()) { // src/decryptor.cpp:46-55: a key of another context is refused
+    Decryptor(const SEALContext &c, const SecretKey &sk) : c_(c), sk_(Encryptor::valid(c, sk).data.size()) { // src/decryptor.cpp:62-65: a key of another context is refused
         check(troyhip_copy_h2d(sk_.get(), sk.data.data(), sk.data.size() * 8, nullptr));
     }
     void decrypt(const Ciphertext &ct, Plaintext &dst) const {

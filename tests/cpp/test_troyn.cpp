@@ -307,11 +307,11 @@ static void key_hygiene() {
     SecretKey sk2; sk2.load(ss);
     RelinKeys rk2; rk2.load(rs);
     GaloisKeys gk2; gk2.load(gs);
-    EXPECT(refused([&] { Encryptor e(big, pk2); }, "public_key is not valid"), "Encryptor refuses a public key of another context");
-    EXPECT(refused([&] { Encryptor e(big, sk2); }, "secret_key is not valid"), "Encryptor refuses a secret key of another context");
-    EXPECT(refused([&] { Encryptor e(big, kg_big.createPublicKey()); e.setPublicKey(pk2); }, "public_key is not valid"), "setPublicKey refuses it too");
-    EXPECT(refused([&] { Encryptor e(big, kg_big.createPublicKey()); e.setSecretKey(sk2); }, "secret_key is not valid"), "setSecretKey refuses it too");
-    EXPECT(refused([&] { Decryptor d(big, sk2); }, "secret_key is not valid"), "Decryptor refuses a secret key of another context");
+    EXPECT(refused([&] { Encryptor e(big, pk2); }, "public key is not valid"), "Encryptor refuses a public key of another context");
+    EXPECT(refused([&] { Encryptor e(big, sk2); }, "secret key is not valid"), "Encryptor refuses a secret key of another context");
+    EXPECT(refused([&] { Encryptor e(big, kg_big.createPublicKey()); e.setPublicKey(pk2); }, "public key is not valid"), "setPublicKey refuses it too");
+    EXPECT(refused([&] { Encryptor e(big, kg_big.createPublicKey()); e.setSecretKey(sk2); }, "secret key is not valid"), "setSecretKey refuses it too");
+    EXPECT(refused([&] { Decryptor d(big, sk2); }, "secret key is not valid"), "Decryptor refuses a secret key of another context");
     Evaluator ev(big);
     Encryptor pub(big, kg_big.createPublicKey(), 21, 22);
     Ciphertext x = pub.encrypt(m), y;

@@ -1,8 +1,9 @@
 #!/bin/bash
 # HBM traffic per kernel from PMC counters (MI355X_MICROARCH.md section HBM): FETCH_SIZE and WRITE_SIZE in SEPARATE passes (TCC slots), kernel-trace
 # only, over ONE step of a workload's bench command (per_kernel[].traffic) and over its roofline launches (roofline.traffic).
-# Writes gpurun_out/r06_traffic_<workload>.json, stamped with the library's build id; copy it to profiles/ to have bench.py use it.
+# Writes gpurun_out/${ROUND}_traffic_<workload>.json, stamped with the library's build id; copy it to profiles/ to have bench.py use it.
 # usage (on the GPU box): tools/measure_traffic.sh <workload> [batch]
+ROUND=${ROUND:-r06}
 WL=${1:-bfv_n32768_l14}
 B=${2:-0}
 R=$GRAFT_REPO_ROOT; [ -z "$R" ] && R=$PWD
@@ -13,9 +14,10 @@ for C in FETCH_SIZE WRITE_SIZE; do
   timeout 900 rocprofv3 --kernel-trace --pmc $C --output-format csv -d $R/gpurun_out/traffic_${WL}_rf_$C -o p -- python3 $R/bench.py --workload $WL --roofline-only --batch $B --ntt-reps 2 --no-cpu-baseline > $R/gpurun_out/traffic_${WL}_rf_$C.log 2>&1
 done
 cd $R
-WL=$WL python3 - <<'PY'
+WL=$WL ROUND=$ROUND python3 - <<'PY'
 import csv, json, collections, glob, re, os, sys
 WL = os.environ["WL"]
+ROUND = os.environ.get("ROUND", "r06")
 def load(tag):
     out = collections.defaultdict(lambda: collections.defaultdict(list))
     for C in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -37,7 +39,7 @@ op_line, rf_line = line_of("op"), line_of("rf")
 cfg = (op_line or rf_line or {}).get("config", {})
 res = {"method": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes (tools/measure_traffic.sh) over `bench.py --workload %s --streams 1 --steps 1`; "
                  "FETCH_SIZE doubled per /opt/skills/guides/MI355X_MICROARCH.md section HBM (gfx950 tallies 128-B requests as 64 B); counter unit KiB" % WL,
-       "source": "profiles/r06_traffic_%s.json (tools/measure_traffic.sh %s, this build)" % (WL, WL), "workload": WL, "N": cfg.get("N"), "batch": cfg.get("batch_per_gpu"),
+       "source": "profiles/%s_traffic_%s.json (tools/measure_traffic.sh %s, this build)" % (ROUND, WL, WL), "workload": WL, "N": cfg.get("N"), "batch": cfg.get("batch_per_gpu"),
        "per_kernel": {}, "hbm_bytes_per_limb_transform": {}}
 for name, v in load("op").items():
     if not v.get("FETCH_SIZE") or not v.get("WRITE_SIZE"): continue
@@ -64,7 +66,7 @@ res["algorithmic_bytes_per_limb_transform"] = 16 * (cfg.get("N") or 0)
 sys.path.insert(0, ".")
 from troy_amd import capi
 res["build_id"] = capi.build_id()  # bench.py ignores this file when the loaded library is another build
-json.dump(res, open(f"gpurun_out/r06_traffic_{WL}.json", "w"), indent=1)
+json.dump(res, open(f"gpurun_out/{ROUND}_traffic_{WL}.json", "w"), indent=1)
 for k, v in sorted(res["per_kernel"].items(), key=lambda kv: -kv[1]["hbm_bytes"])[:14]:
     print(f"{k[:64]:64s} calls={v['calls']:3d} fetch={v['fetch_bytes_corrected']/1e9:8.3f} GB write={v['write_bytes']/1e9:8.3f} GB")
 print(res["hbm_bytes_per_limb_transform"], "algorithmic", res["algorithmic_bytes_per_limb_transform"])

@@ -1435,7 +1435,11 @@ void launch_ntt1(u64 *data, const u64 *src, const PrimeDesc *primes, const LimbM
         a.rows_per_wg = plan(a.nslots);
         a.chunks = (a.m_total + a.rows_per_wg - 1) / a.rows_per_wg;
         // one prime, or a grid the chip holds at once: nothing to separate (probe builds: TROYHIP_NTT1_XCD = 1 always / 0 never, for the tests)
-        const bool xcd = forced_xcd >= 0 ? forced_xcd != 0 : (N1_XCD && a.nslots > 1 && a.nslots * a.chunks >= 2 * cus);
+        // The forms whose rows of different primes share a row (mod-down: the special limb; divide-and-round: the dropped limb) take the list -- grouped, below -- as
+        // soon as the launch is more than ONE round of workgroups: at the headline's two lanes of 128 the mod-down is 481 workgroups on 256 CUs, and flat order
+        // fetched the special limb once per prime (same-box A/B, profiles/r06_xcd_md_ab.txt: that kernel 867 -> 853 us, headline +0.4 %)
+        const bool shared_row = a.md_ct || a.cr_last;
+        const bool xcd = forced_xcd >= 0 ? forced_xcd != 0 : (N1_XCD && a.nslots > 1 && a.nslots * a.chunks >= (shared_row ? cus + 1 : 2 * cus));
         a.xcd_per = xcd ? (a.nslots * a.chunks + 7) / 8 : 0;
         a.xcd_group = forced_group > 0 ? (unsigned)forced_group : !(a.md_ct || a.cr_last) ? 1u : kind == 2 ? N1_XCD_GROUP_FP : N1_XCD_GROUP_INT;
         static const bool perturb = probe_env("TROYHIP_NTT1_XCD_PERTURB") != nullptr;
