@@ -1230,6 +1230,8 @@ class SmiSampler:
             self._thread.start()
 
     def stop(self):
+        if self.note is None and not self.sclk and not self.power:
+            self._read_once()  # a timed region shorter than one period still reports a reading (taken right after it: the clock is already on its way down)
         self._stop.set()
         if self._thread is not None:
             self._thread.join(timeout=1.0)
