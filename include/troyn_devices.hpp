@@ -70,7 +70,8 @@ public:
     const Evaluator &evaluator(size_t i) const { return *evaluators_.at(i); }
     std::vector<std::pair<size_t, size_t>> shards(size_t batch) const { return shardBatch(batch, size()); }
 
-    // the key-switching keys on every member's device (index 0 shares the original's storage when it already lies on that device)
+    // the key-switching keys on every member's device: one copy per member (a device-to-device copy where source and member share a device, a peer copy else);
+    // `keys_device`: where `keys` lie (default: the home device)
     template <class K> std::vector<K> replicate(const K &keys, int keys_device = -1) const {
         const int from = keys_device < 0 ? home() : keys_device;
         sync(from);

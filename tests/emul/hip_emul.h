@@ -199,6 +199,8 @@ inline int &hip_emul_current_device() { static thread_local int d = 0; return d;
 inline hipError_t hipSetDevice(int d) { if (d < 0 || d >= hip_emul_device_count()) return hipErrorInvalidValue; hip_emul_current_device() = d; return hipSuccess; }
 inline hipError_t hipGetDeviceCount(int *n) { *n = hip_emul_device_count(); return hipSuccess; }
 inline hipError_t hipGetDevice(int *d) { *d = hip_emul_current_device(); return hipSuccess; }
+inline hipError_t hipDeviceCanAccessPeer(int *can, int, int) { *can = 1; return hipSuccess; }
+inline hipError_t hipDeviceEnablePeerAccess(int, unsigned) { return hipSuccess; }
 inline hipError_t hipMemcpyPeerAsync(void *d, int, const void *s, int, size_t n, hipStream_t) { memmove(d, s, n); return hipSuccess; }
 enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount = 1 };
 inline hipError_t hipDeviceGetAttribute(int *v, hipDeviceAttribute_t, int) { *v = 4; return hipSuccess; } // a small "chip": the launch planner sees several rounds

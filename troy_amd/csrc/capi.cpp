@@ -345,10 +345,24 @@ int troyhip_copy_h2d(void *dst, const void *src, size_t bytes, void *stream) {
 int troyhip_copy_d2h(void *dst, const void *src, size_t bytes, void *stream) {
     return guard([&] { HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream)); HIP_CHECK(hipStreamSynchronize((hipStream_t)stream)); });
 }
+// direct access between two devices (xGMI), switched on the first time a pair is used: without it hipMemcpyPeerAsync still works, staged through host memory
+static void enable_peer_access(int device, int peer) {
+    static std::mutex mu;
+    static std::vector<std::pair<int, int>> done;
+    std::lock_guard<std::mutex> g(mu);
+    if (std::find(done.begin(), done.end(), std::make_pair(device, peer)) != done.end()) return;
+    done.emplace_back(device, peer);
+    int can = 0;
+    if (hipDeviceCanAccessPeer(&can, device, peer) != hipSuccess || !can) { (void)hipGetLastError(); return; }
+    DeviceScope scope(device);
+    if (hipDeviceEnablePeerAccess(peer, 0) != hipSuccess) (void)hipGetLastError(); // "already enabled" (another library did it) is fine
+}
 int troyhip_copy_peer(void *dst, int dst_device, const void *src, int src_device, size_t bytes, void *stream) {
     return guard([&] {
         if (!bytes) return;
         if (dst_device == src_device) { DeviceScope scope(src_device); HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, on(stream))); return; }
+        enable_peer_access(dst_device, src_device);
+        enable_peer_access(src_device, dst_device);
         HIP_CHECK(hipMemcpyPeerAsync(dst, dst_device, src, src_device, bytes, (hipStream_t)stream));
     });
 }
