@@ -1194,12 +1194,12 @@ class SmiSampler:
     no child process, nothing that could perturb the step (a file read every 20 ms on a host thread).  Best effort: a box without the files
     reports `{"note": ...}` instead of numbers."""
 
-    def __init__(self, pci, period_s=0.02):
+    def __init__(self, pci, period_s=0.02, sysfs="/sys/bus/pci/devices"):
         import glob
         self.period, self.sclk, self.power, self.note = period_s, [], [], None
         self._stop = threading.Event()
         self._thread = None
-        base = f"/sys/bus/pci/devices/{pci}" if pci else None
+        base = f"{sysfs}/{pci}" if pci else None
         hw = sorted(glob.glob(base + "/hwmon/hwmon*")) if base else []
         self.f_sclk = next((h + "/freq1_input" for h in hw if os.path.exists(h + "/freq1_input")), None)
         self.f_power = next((h + "/" + n for h in hw for n in ("power1_average", "power1_input") if os.path.exists(h + "/" + n)), None)
