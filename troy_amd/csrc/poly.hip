@@ -20,78 +20,88 @@ namespace troyhip {
 __device__ __forceinline__ const PrimeDesc &prime_of(const PrimeDesc *primes, const LimbMap &m, u64 row) {
     return primes[m.id[(row / m.inner) % m.period]];
 }
+// the same for a 32-bit row index that comes from the block id (workgroup-uniform: two short divisions per workgroup instead of two 64-bit ones per thread)
+__device__ __forceinline__ const PrimeDesc &prime_of_row(const PrimeDesc *primes, const LimbMap &m, u32 row) { return primes[m.id[(row / m.inner) % m.period]]; }
+// Row-structured element-wise kernels (round 6): grid x = pairs of coefficients of a row, y = rows (a stride loop beyond 65535 rows).  The flat forms derived the row
+// and its prime from 64-bit divisions per thread, about 200 instructions next to an addition or one product -- they were issue-bound streaming kernels.
+static dim3 row_grid(int logn, u64 rows) { return dim3((unsigned)ceil_div((u64(1) << logn) / 2 + ((u64(1) << logn) & 1), EW_THREADS), (unsigned)std::min<u64>(rows, 65535)); }
 
 // ---------------------------------------------------------------- element-wise
 // op: 0 add, 1 sub, 2 negate(a), 3 dyadic product a*b (Barrett-128)
-template <int OP> __global__ __launch_bounds__(EW_THREADS) void ew_kernel(const u64 *a, const u64 *b, u64 *out, const PrimeDesc *primes, LimbMap map, int logn, u64 total) {
-    u64 i = ((u64)blockIdx.x * EW_THREADS + threadIdx.x) * 2;
-    if (i >= total) return;
-    const PrimeDesc &pd = prime_of(primes, map, i >> logn);
-    const u64 p = pd.p;
-    ulonglong2 x = *reinterpret_cast<const ulonglong2 *>(a + i), y{0, 0}, r;
-    if (OP != 2) y = *reinterpret_cast<const ulonglong2 *>(b + i);
-    if (OP == 0) { r.x = addmod(x.x, y.x, p); r.y = addmod(x.y, y.y, p); }
-    else if (OP == 1) { r.x = submod(x.x, y.x, p); r.y = submod(x.y, y.y, p); }
-    else if (OP == 2) { r.x = negmod(x.x, p); r.y = negmod(x.y, p); }
-    else { const Mod m = mod_of(pd); r.x = mulmod(x.x, y.x, m); r.y = mulmod(x.y, y.y, m); }
-    *reinterpret_cast<ulonglong2 *>(out + i) = r;
+template <int OP> __global__ __launch_bounds__(EW_THREADS) void ew_kernel(const u64 *a, const u64 *b, u64 *out, const PrimeDesc *primes, LimbMap map, int logn, u32 rows) {
+    const u32 n = (blockIdx.x * EW_THREADS + threadIdx.x) * 2;
+    if (n >= (1u << logn)) return;
+    for (u32 row = blockIdx.y; row < rows; row += gridDim.y) {
+        const PrimeDesc &pd = prime_of_row(primes, map, row);
+        const u64 p = pd.p, i = ((u64)row << logn) + n;
+        ulonglong2 x = *reinterpret_cast<const ulonglong2 *>(a + i), y{0, 0}, r;
+        if (OP != 2) y = *reinterpret_cast<const ulonglong2 *>(b + i);
+        if (OP == 0) { r.x = addmod(x.x, y.x, p); r.y = addmod(x.y, y.y, p); }
+        else if (OP == 1) { r.x = submod(x.x, y.x, p); r.y = submod(x.y, y.y, p); }
+        else if (OP == 2) { r.x = negmod(x.x, p); r.y = negmod(x.y, p); }
+        else { const Mod m = mod_of(pd); r.x = mulmod(x.x, y.x, m); r.y = mulmod(x.y, y.y, m); }
+        *reinterpret_cast<ulonglong2 *>(out + i) = r;
+    }
 }
 void launch_ew(int op, const u64 *a, const u64 *b, u64 *out, const PrimeDesc *primes, const LimbMap &map, int logn, u64 rows, hipStream_t s) {
-    u64 total = rows << logn;
-    if (!total) return;
-    dim3 grid(ceil_div(total / 2 + (total & 1), EW_THREADS));
+    if (!rows) return;
+    if (logn < 1 || rows >> 32) throw Error(ST_LOGIC_ERROR, "element-wise: row shape");
+    const dim3 grid = row_grid(logn, rows);
     switch (op) {
-    case 0: TROY_LAUNCH(HIP_KERNEL_NAME(ew_kernel<0>), grid, dim3(EW_THREADS), 0, s, a, b, out, primes, map, logn, total); break;
-    case 1: TROY_LAUNCH(HIP_KERNEL_NAME(ew_kernel<1>), grid, dim3(EW_THREADS), 0, s, a, b, out, primes, map, logn, total); break;
-    case 2: TROY_LAUNCH(HIP_KERNEL_NAME(ew_kernel<2>), grid, dim3(EW_THREADS), 0, s, a, b, out, primes, map, logn, total); break;
-    default: TROY_LAUNCH(HIP_KERNEL_NAME(ew_kernel<3>), grid, dim3(EW_THREADS), 0, s, a, b, out, primes, map, logn, total); break;
+    case 0: TROY_LAUNCH(HIP_KERNEL_NAME(ew_kernel<0>), grid, dim3(EW_THREADS), 0, s, a, b, out, primes, map, logn, (u32)rows); break;
+    case 1: TROY_LAUNCH(HIP_KERNEL_NAME(ew_kernel<1>), grid, dim3(EW_THREADS), 0, s, a, b, out, primes, map, logn, (u32)rows); break;
+    case 2: TROY_LAUNCH(HIP_KERNEL_NAME(ew_kernel<2>), grid, dim3(EW_THREADS), 0, s, a, b, out, primes, map, logn, (u32)rows); break;
+    default: TROY_LAUNCH(HIP_KERNEL_NAME(ew_kernel<3>), grid, dim3(EW_THREADS), 0, s, a, b, out, primes, map, logn, (u32)rows); break;
     }
     launch_check("ew_kernel");
 }
 
 // x[row][n] *= scalar[row % limbs]  (scalars already reduced mod the limb's prime)
 struct ScalarArgs { u64 s[64]; };
-__global__ __launch_bounds__(EW_THREADS) void mul_scalar_kernel(u64 *x, const PrimeDesc *primes, LimbMap map, ScalarArgs sc, int logn, u64 total) {
-    u64 i = ((u64)blockIdx.x * EW_THREADS + threadIdx.x) * 2;
-    if (i >= total) return;
-    u64 row = i >> logn;
-    const PrimeDesc &pd = prime_of(primes, map, row);
-    const Mod m = mod_of(pd);
-    const u64 s = sc.s[(row / map.inner) % map.period];
-    ulonglong2 v = *reinterpret_cast<ulonglong2 *>(x + i);
-    v.x = mulmod(v.x, s, m);
-    v.y = mulmod(v.y, s, m);
-    *reinterpret_cast<ulonglong2 *>(x + i) = v;
+__global__ __launch_bounds__(EW_THREADS) void mul_scalar_kernel(u64 *x, const PrimeDesc *primes, LimbMap map, ScalarArgs sc, int logn, u32 rows) {
+    const u32 n = (blockIdx.x * EW_THREADS + threadIdx.x) * 2;
+    if (n >= (1u << logn)) return;
+    for (u32 row = blockIdx.y; row < rows; row += gridDim.y) {
+        const PrimeDesc &pd = prime_of_row(primes, map, row);
+        const Mod m = mod_of(pd);
+        const u64 s = sc.s[(row / map.inner) % map.period], i = ((u64)row << logn) + n;
+        ulonglong2 v = *reinterpret_cast<ulonglong2 *>(x + i);
+        v.x = mulmod(v.x, s, m);
+        v.y = mulmod(v.y, s, m);
+        *reinterpret_cast<ulonglong2 *>(x + i) = v;
+    }
 }
 void launch_mul_scalar(u64 *x, const PrimeDesc *primes, const LimbMap &map, const u64 *scalars, int logn, u64 rows, hipStream_t s) {
-    u64 total = rows << logn;
-    if (!total) return;
+    if (!rows) return;
+    if (logn < 1 || rows >> 32) throw Error(ST_LOGIC_ERROR, "element-wise: row shape");
     ScalarArgs sc;
     for (unsigned i = 0; i < 64; i++) sc.s[i] = i < map.period ? scalars[i] : 0;
-    TROY_LAUNCH(mul_scalar_kernel, dim3(ceil_div(total / 2 + (total & 1), EW_THREADS)), dim3(EW_THREADS), 0, s, x, primes, map, sc, logn, total);
+    TROY_LAUNCH(mul_scalar_kernel, row_grid(logn, rows), dim3(EW_THREADS), 0, s, x, primes, map, sc, logn, (u32)rows);
     launch_check("mul_scalar_kernel");
 }
 
 // ct (x) plaintext in NTT form: out[b][i][l][n] = a[b][i][l][n] * plain[(b)][l][n]   (multiplyPlainNtt)
-__global__ __launch_bounds__(EW_THREADS) void mul_plain_kernel(u64 *a, const u64 *plain, const PrimeDesc *primes, LimbMap map, int logn, u64 limbs, u64 total,
-                                                               u64 rows_per_item, u64 plain_bstride) {
-    u64 i = ((u64)blockIdx.x * EW_THREADS + threadIdx.x) * 2;
-    if (i >= total) return;
-    u64 row = i >> logn, l = row % limbs, n = i & ((u64(1) << logn) - 1);
-    const Mod m = mod_of(prime_of(primes, map, row));
-    const u64 *pl = rows_per_item ? plain + (row / rows_per_item) * plain_bstride : plain;
-    ulonglong2 v = *reinterpret_cast<ulonglong2 *>(a + i);
-    const ulonglong2 w = *reinterpret_cast<const ulonglong2 *>(pl + (l << logn) + n);
-    v.x = mulmod(v.x, w.x, m);
-    v.y = mulmod(v.y, w.y, m);
-    *reinterpret_cast<ulonglong2 *>(a + i) = v;
+__global__ __launch_bounds__(EW_THREADS) void mul_plain_kernel(u64 *a, const u64 *plain, const PrimeDesc *primes, LimbMap map, int logn, u32 limbs, u32 rows,
+                                                               u32 rows_per_item, u64 plain_bstride) {
+    const u32 n = (blockIdx.x * EW_THREADS + threadIdx.x) * 2;
+    if (n >= (1u << logn)) return;
+    for (u32 row = blockIdx.y; row < rows; row += gridDim.y) {
+        const u32 l = row % limbs;
+        const Mod m = mod_of(prime_of_row(primes, map, row));
+        const u64 *pl = rows_per_item ? plain + (u64)(row / rows_per_item) * plain_bstride : plain;
+        const u64 i = ((u64)row << logn) + n;
+        ulonglong2 v = *reinterpret_cast<ulonglong2 *>(a + i);
+        const ulonglong2 w = *reinterpret_cast<const ulonglong2 *>(pl + ((u64)l << logn) + n);
+        v.x = mulmod(v.x, w.x, m);
+        v.y = mulmod(v.y, w.y, m);
+        *reinterpret_cast<ulonglong2 *>(a + i) = v;
+    }
 }
 void launch_mul_plain(u64 *a, const u64 *plain, const PrimeDesc *primes, const LimbMap &map, int logn, u64 limbs, u64 rows, hipStream_t s, u64 rows_per_item,
                       u64 plain_bstride) {
-    u64 total = rows << logn;
-    if (!total) return;
-    TROY_LAUNCH(mul_plain_kernel, dim3(ceil_div(total / 2 + (total & 1), EW_THREADS)), dim3(EW_THREADS), 0, s, a, plain, primes, map, logn, limbs, total, rows_per_item,
-                plain_bstride);
+    if (!rows) return;
+    if (logn < 1 || rows >> 32 || rows_per_item >> 32) throw Error(ST_LOGIC_ERROR, "element-wise: row shape");
+    TROY_LAUNCH(mul_plain_kernel, row_grid(logn, rows), dim3(EW_THREADS), 0, s, a, plain, primes, map, logn, (u32)limbs, (u32)rows, (u32)rows_per_item, plain_bstride);
     launch_check("mul_plain_kernel");
 }
 
@@ -99,29 +109,54 @@ void launch_mul_plain(u64 *a, const u64 *plain, const PrimeDesc *primes, const L
 // addInplace a linear layer runs per output block (app/LinearHelperCKKS.cuh:227-248, 536-556) costs 2 count + (count - 1) kernels and moves
 // every partial product through HBM; here every operand is read once, the products accumulate in 128 bits (count * p^2 < 2^128) and
 // one Barrett step gives the same canonical residue (sums and products of residues are exact whatever the order of reductions).
-__global__ __launch_bounds__(EW_THREADS) void mul_plain_acc_kernel(MulPlainAccArgs x, u64 *out, u64 out_bstride, const PrimeDesc *primes, LimbMap map, int logn, u64 limbs,
-                                                                   u64 item_words, u64 total) {
-    const u64 i = ((u64)blockIdx.x * EW_THREADS + threadIdx.x) * 2; // two coefficients per thread, over batch * size * limbs * N
-    if (i >= total) return;
-    const u64 b = i / item_words, r = i - b * item_words, row = r >> logn, l = row % limbs, n = r & ((u64(1) << logn) - 1);
+// Grid (x: pairs of coefficients of a row, y: row = polynomial x limb, z: batch item): every index comes from the block id -- no 64-bit division per thread, the
+// prime and its Barrett constants are workgroup-uniform (scalar registers).  The flat form spent ~150 of its ~300 VALU instructions per thread on i / item_words
+// and row % limbs, which made a streaming kernel issue-bound (0.595 of the HBM peak at the 128 x 128 matmul; round 6).
+#ifndef MPA_PAIRS
+#define MPA_PAIRS 2 // pairs of coefficients per thread (the second pair half a row away: both sets of loads are in flight before the first product)
+#endif
+__global__ __launch_bounds__(EW_THREADS) void mul_plain_acc_kernel(MulPlainAccArgs x, u64 *out, u64 out_bstride, const PrimeDesc *primes, LimbMap map, int logn, u32 limbs, u32 batch) {
+    const u32 n = (blockIdx.x * EW_THREADS + threadIdx.x) * 2; // two coefficients per pair
+    const u32 N = 1u << logn, span = N / MPA_PAIRS < 2 ? 2 : N / MPA_PAIRS; // pair j of this thread: coefficients n + j span, n + j span + 1 (tiny rings: fewer pairs)
+    if (n >= span) return;
+    const u32 row = blockIdx.y, l = row % limbs;
+    const u64 r = ((u64)row << logn) + n;
     const Mod m = mod_of(prime_of(primes, map, l));
-    U128 s0{0, 0}, s1{0, 0};
-    for (int t = 0; t < x.count; t++) {
-        const ulonglong2 v = *reinterpret_cast<const ulonglong2 *>(x.ct[t] + b * x.ct_bstride[t] + r);
-        const ulonglong2 w = *reinterpret_cast<const ulonglong2 *>(x.plain[t] + (l << logn) + n);
-        mac128(s0, v.x, w.x);
-        mac128(s1, v.y, w.y);
+    for (u32 b = blockIdx.z; b < batch; b += gridDim.z) { // (batches beyond the grid's z extent: a stride loop)
+        U128 s[MPA_PAIRS][2];
+#pragma unroll
+        for (int j = 0; j < MPA_PAIRS; j++) s[j][0] = s[j][1] = U128{0, 0};
+        for (int t = 0; t < x.count; t++) {
+            ulonglong2 v[MPA_PAIRS], w[MPA_PAIRS];
+#pragma unroll
+            for (int j = 0; j < MPA_PAIRS; j++) {
+                if (j && n + j * span >= N) { v[j] = w[j] = ulonglong2{0, 0}; continue; }
+                v[j] = *reinterpret_cast<const ulonglong2 *>(x.ct[t] + (u64)b * x.ct_bstride[t] + r + j * span);
+                w[j] = *reinterpret_cast<const ulonglong2 *>(x.plain[t] + ((u64)l << logn) + n + j * span);
+            }
+#pragma unroll
+            for (int j = 0; j < MPA_PAIRS; j++) {
+                mac128(s[j][0], v[j].x, w[j].x);
+                mac128(s[j][1], v[j].y, w[j].y);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < MPA_PAIRS; j++) {
+            if (j && n + j * span >= N) continue;
+            ulonglong2 o;
+            o.x = barrett128(s[j][0].lo, s[j][0].hi, m);
+            o.y = barrett128(s[j][1].lo, s[j][1].hi, m);
+            *reinterpret_cast<ulonglong2 *>(out + (u64)b * out_bstride + r + j * span) = o;
+        }
     }
-    ulonglong2 o;
-    o.x = barrett128(s0.lo, s0.hi, m);
-    o.y = barrett128(s1.lo, s1.hi, m);
-    *reinterpret_cast<ulonglong2 *>(out + b * out_bstride + r) = o;
 }
 void launch_mul_plain_acc(const MulPlainAccArgs &x, u64 *out, u64 out_bstride, const PrimeDesc *primes, const LimbMap &map, int logn, u64 limbs, u64 size, u64 batch,
                           hipStream_t s) {
-    const u64 item_words = (size * limbs) << logn, total = batch * item_words;
-    if (!total) return;
-    TROY_LAUNCH(mul_plain_acc_kernel, dim3(ceil_div(total / 2, EW_THREADS)), dim3(EW_THREADS), 0, s, x, out, out_bstride, primes, map, logn, limbs, item_words, total);
+    if (!batch || !size || !limbs) return;
+    if (logn < 1) throw Error(ST_LOGIC_ERROR, "mul_plain_acc: two coefficients per access");
+    const u64 span = std::max<u64>((u64(1) << logn) / MPA_PAIRS, 2);
+    const unsigned gx = (unsigned)ceil_div(span / 2, EW_THREADS), gz = (unsigned)std::min<u64>(batch, 65535);
+    TROY_LAUNCH(mul_plain_acc_kernel, dim3(gx, (unsigned)(size * limbs), gz), dim3(EW_THREADS), 0, s, x, out, out_bstride, primes, map, logn, (u32)limbs, (u32)batch);
     launch_check("mul_plain_acc_kernel");
 }
 
@@ -217,31 +252,39 @@ void launch_plain_lift(const u64 *plain, u64 *lifted, const PlainArgs &a, hipStr
 // ---------------------------------------------------------------- ciphertext tensor (a-3 / A.7)
 // out[b][i][l][n] = sum_{j+k=i} a[b][j][l][n] * b[b][k][l][n] mod p_l.  Inputs may be lazy (< 4p).
 // One thread = one (b, l, n); all S1+S2 operands live in registers; 3..5 outputs.
+// Grid (x: pairs of coefficients of a row, y: limb, z: batch item): the indices come from the block id (the flat form's i / limbs and i % limbs were 64-bit
+// divisions per thread -- a third of the instructions of a kernel that is issue-bound, 0.94 of the VALU peak); the terms of one output accumulate in 128 bits
+// (at most three products of operands below 2^63) and are reduced ONCE: the same canonical residue as the reference's sum of reduced products.
 template <int S1, int S2> __global__ __launch_bounds__(EW_THREADS) void tensor_kernel(const u64 *a, const u64 *b, u64 *out, u64 a_bstride, u64 b_bstride,
-                                                                                       const PrimeDesc *primes, LimbMap map, int logn, u64 limbs, u64 total) {
-    u64 i = ((u64)blockIdx.x * EW_THREADS + threadIdx.x) * 2; // over batch * limbs * N, two coefficients (16 bytes) per thread
-    if (i >= total) return;
+                                                                                       const PrimeDesc *primes, LimbMap map, int logn, u32 limbs, u32 batch) {
+    static_assert(S1 <= 3 && S2 <= 3, "three lazy products fit 128 bits");
+    const u32 n = (blockIdx.x * EW_THREADS + threadIdx.x) * 2; // two coefficients (16 bytes) per thread
     const u64 N = u64(1) << logn;
-    u64 n = i & (N - 1), bl = i >> logn, l = bl % limbs, bb = bl / limbs;
+    if (n >= N) return;
+    const u32 l = blockIdx.y;
     const Mod m = mod_of(primes[map.id[l]]);
-    ulonglong2 x[S1], y[S2];
+    for (u32 bb = blockIdx.z; bb < batch; bb += gridDim.z) {
+        ulonglong2 x[S1], y[S2];
 #pragma unroll
-    for (int j = 0; j < S1; j++) x[j] = *reinterpret_cast<const ulonglong2 *>(a + bb * a_bstride + (j * limbs + l) * N + n);
+        for (int j = 0; j < S1; j++) x[j] = *reinterpret_cast<const ulonglong2 *>(a + (u64)bb * a_bstride + ((u64)j * limbs + l) * N + n);
 #pragma unroll
-    for (int k = 0; k < S2; k++) y[k] = *reinterpret_cast<const ulonglong2 *>(b + bb * b_bstride + (k * limbs + l) * N + n);
+        for (int k = 0; k < S2; k++) y[k] = *reinterpret_cast<const ulonglong2 *>(b + (u64)bb * b_bstride + ((u64)k * limbs + l) * N + n);
 #pragma unroll
-    for (int d = 0; d < S1 + S2 - 1; d++) {
-        ulonglong2 r{0, 0};
+        for (int d = 0; d < S1 + S2 - 1; d++) {
+            U128 s0{0, 0}, s1{0, 0};
 #pragma unroll
-        for (int j = 0; j < S1; j++) {
-            const int k = d - j;
-            if (k >= 0 && k < S2) {
-                // lazy operands (< 2^63 each) can make one product ~2^126: reduce each term
-                r.x = addmod(r.x, mulmod(x[j].x, y[k].x, m), m.p);
-                r.y = addmod(r.y, mulmod(x[j].y, y[k].y, m), m.p);
+            for (int j = 0; j < S1; j++) {
+                const int k = d - j;
+                if (k >= 0 && k < S2) {
+                    mac128(s0, x[j].x, y[k].x);
+                    mac128(s1, x[j].y, y[k].y);
+                }
             }
+            ulonglong2 r;
+            r.x = barrett128(s0.lo, s0.hi, m);
+            r.y = barrett128(s1.lo, s1.hi, m);
+            *reinterpret_cast<ulonglong2 *>(out + ((u64)bb * (S1 + S2 - 1) + d) * limbs * N + (u64)l * N + n) = r;
         }
-        *reinterpret_cast<ulonglong2 *>(out + (bb * (S1 + S2 - 1) + d) * limbs * N + l * N + n) = r;
     }
 }
 // any sizes (destination up to SEAL_CIPHERTEXT_SIZE_MAX = 16 polynomials, evaluator_cuda.cu:342-364 / :407-423): operands are re-read per
@@ -272,7 +315,8 @@ void launch_tensor(int s1, int s2, const u64 *a, const u64 *b, u64 *out, u64 a_b
     if (!total) return;
     if (logn < 1) throw Error(ST_LOGIC_ERROR, "tensor: N < 2");
     dim3 grid(ceil_div(total / 2, EW_THREADS)), blk(EW_THREADS);
-#define TENSOR_CASE(A, B) if (s1 == A && s2 == B) { TROY_LAUNCH(HIP_KERNEL_NAME(tensor_kernel<A, B>), grid, blk, 0, s, a, b, out, a_bstride, b_bstride, primes, map, logn, limbs, total); launch_check("tensor_kernel"); return; }
+    const dim3 grid3((unsigned)ceil_div((u64(1) << logn) / 2, EW_THREADS), (unsigned)limbs, (unsigned)std::min<u64>(batch, 65535));
+#define TENSOR_CASE(A, B) if (s1 == A && s2 == B) { TROY_LAUNCH(HIP_KERNEL_NAME(tensor_kernel<A, B>), grid3, blk, 0, s, a, b, out, a_bstride, b_bstride, primes, map, logn, (u32)limbs, (u32)batch); launch_check("tensor_kernel"); return; }
     TENSOR_CASE(2, 2) TENSOR_CASE(2, 3) TENSOR_CASE(3, 2) TENSOR_CASE(3, 3) TENSOR_CASE(1, 1) TENSOR_CASE(1, 2) TENSOR_CASE(2, 1) TENSOR_CASE(1, 3) TENSOR_CASE(3, 1)
 #undef TENSOR_CASE
     if (s1 < 1 || s2 < 1 || s1 + s2 - 1 > 16) throw Error(ST_INVALID_ARGUMENT, "invalid size");
@@ -287,6 +331,8 @@ void launch_tensor(int s1, int s2, const u64 *a, const u64 *b, u64 *out, u64 a_b
 // n0 < N and the negated input n0 - N otherwise (exactly one of j, j + N is n g mod 2N for an n below N, g being odd).  The scatter form wrote 64
 // different cache lines per wave-store (0.28-0.30 of the HBM roofline at N = 2^16); scattered READS of a row that fits L2 are served from there and the
 // stores are whole lines.  elt_inv = g^-1 mod 2N comes from the host.
+// (the grid-indexed form -- x: coefficient, y: limb, z: batch item, as galois_ntt_kernel below -- measured 2 % SLOWER here: the gather is bound by its scattered L2 reads,
+// not by the index arithmetic; profiles/r06_elementwise_ab.txt)
 __global__ __launch_bounds__(EW_THREADS) void galois_coeff_kernel(const u64 *in, u64 in_bstride, u64 *out, u64 out_bstride, const PrimeDesc *primes, LimbMap map, int logn,
                                                                   uint32_t elt_inv, u64 limbs, u64 total) {
     u64 i = (u64)blockIdx.x * EW_THREADS + threadIdx.x;
@@ -320,28 +366,29 @@ void launch_negacyclic_shift(const u64 *in, u64 in_bstride, u64 *out, u64 out_bs
                 limbs, total);
     launch_check("negacyclic_shift_kernel");
 }
-// NTT form: out[i] = in[bitrev(((g * bitrev(i + N, logN+1)) >> 1) mod N, logN)]   (galois.cpp:18-35)
-__global__ __launch_bounds__(EW_THREADS) void galois_ntt_kernel(const u64 *in, u64 in_bstride, u64 *out, u64 out_bstride, int logn, uint32_t elt, u64 limbs, u64 total) {
-    u64 i = (u64)blockIdx.x * EW_THREADS + threadIdx.x;
-    if (i >= total) return;
-    const u64 N = u64(1) << logn;
-    u64 row = i >> logn, n = i & (N - 1), b = row / limbs, l = row % limbs;
+// NTT form: out[i] = in[bitrev(((g * bitrev(i + N, logN+1)) >> 1) mod N, logN)]   (galois.cpp:18-35).  Grid x: coefficient, y: limb, z: batch item -- no 64-bit
+// division per thread (round 6: 957 -> 860 us in the CKKS chain)
+__global__ __launch_bounds__(EW_THREADS) void galois_ntt_kernel(const u64 *in, u64 in_bstride, u64 *out, u64 out_bstride, int logn, uint32_t elt, u32 batch) {
+    const u32 n = blockIdx.x * EW_THREADS + threadIdx.x;
+    const u32 N = 1u << logn;
+    if (n >= N) return;
+    const u32 l = blockIdx.y;
     uint32_t rev = __brev((uint32_t)(n + N)) >> (32 - (logn + 1));
     u64 raw = (((u64)elt * rev) >> 1) & (N - 1);
     uint32_t src = logn ? (__brev((uint32_t)raw) >> (32 - logn)) : 0;
-    out[b * out_bstride + (l << logn) + n] = in[b * in_bstride + (l << logn) + src];
+    for (u32 b = blockIdx.z; b < batch; b += gridDim.z) out[(u64)b * out_bstride + ((u64)l << logn) + n] = in[(u64)b * in_bstride + ((u64)l << logn) + src];
 }
 void launch_galois(bool ntt_form, const u64 *in, u64 in_bstride, u64 *out, u64 out_bstride, const PrimeDesc *primes, const LimbMap &map, int logn, uint32_t elt, u64 limbs,
                    u64 batch, hipStream_t s) {
     u64 total = (batch * limbs) << logn;
     if (!total) return;
-    dim3 grid(ceil_div(total, EW_THREADS)), blk(EW_THREADS);
-    if (ntt_form) TROY_LAUNCH(galois_ntt_kernel, grid, blk, 0, s, in, in_bstride, out, out_bstride, logn, elt, limbs, total);
+    const dim3 grid((unsigned)ceil_div(u64(1) << logn, EW_THREADS), (unsigned)limbs, (unsigned)std::min<u64>(batch, 65535)), blk(EW_THREADS);
+    if (ntt_form) TROY_LAUNCH(galois_ntt_kernel, grid, blk, 0, s, in, in_bstride, out, out_bstride, logn, elt, (u32)batch);
     else {
         uint32_t inv = 1; // g^-1 mod 2N by Newton steps (g odd): x <- x (2 - g x), five steps reach 32 bits
         for (int it = 0; it < 5; it++) inv *= 2u - elt * inv;
         inv &= (uint32_t)((2u << logn) - 1);
-        TROY_LAUNCH(galois_coeff_kernel, grid, blk, 0, s, in, in_bstride, out, out_bstride, primes, map, logn, inv, limbs, total);
+        TROY_LAUNCH(galois_coeff_kernel, dim3(ceil_div(total, EW_THREADS)), blk, 0, s, in, in_bstride, out, out_bstride, primes, map, logn, inv, limbs, total);
     }
     launch_check("galois_kernel");
 }
